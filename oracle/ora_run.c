@@ -1,0 +1,668 @@
+/* ora_run.c -- TEST INFRASTRUCTURE (see oracle.h).
+ * CPU restatement of the orcdchomp module's run lifecycle and obstacle-cost
+ * callbacks (src/orcdchomp_mod.cpp:850-1327, 1800-2852), with the build's own
+ * kinematic model standing in for OpenRAVE FK / CalculateJacobian (third party,
+ * absent: PARITY UNPINNED for FK and Jacobians, SURVEY 2 last table).
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+#include "oracle.h"
+
+/* ------------------------------------------------------------- robot FK */
+
+static void mat3_mul(const double * A, const double * B, double * C)
+{
+   int i, j, k;
+   for (i=0; i<3; i++) for (j=0; j<3; j++)
+   {
+      double s = 0.0;
+      for (k=0; k<3; k++) s += A[i*3+k] * B[k*3+j];
+      C[i*3+j] = s;
+   }
+}
+
+static void mat3_vec(const double * A, const double * v, double * out)
+{
+   int i;
+   for (i=0; i<3; i++) out[i] = A[i*3+0]*v[0] + A[i*3+1]*v[1] + A[i*3+2]*v[2];
+}
+
+/* Rodrigues rotation about a unit axis */
+static void axis_angle_R(const double * a, double q, double * R)
+{
+   double c = cos(q), s = sin(q), v = 1.0 - c;
+   R[0] = c + a[0]*a[0]*v;      R[1] = a[0]*a[1]*v - a[2]*s; R[2] = a[0]*a[2]*v + a[1]*s;
+   R[3] = a[1]*a[0]*v + a[2]*s; R[4] = c + a[1]*a[1]*v;      R[5] = a[1]*a[2]*v - a[0]*s;
+   R[6] = a[2]*a[0]*v - a[1]*s; R[7] = a[2]*a[1]*v + a[0]*s; R[8] = c + a[2]*a[2]*v;
+}
+
+void ora_robot_fk(const ora_robot * rob, const double base_pose[7], const double * dofvals,
+   double * R, double * t, double * axis_w, double * anchor_w)
+{
+   int li;
+   double Rb[3][3];
+   ora_kin_quat_to_R(base_pose+3, Rb);
+   for (li=0; li<rob->n_links; li++)
+   {
+      const double * pj = rob->pose_parent_joint + 7*li;
+      const double * Rp; const double * tp;
+      double Rfix[3][3], Rj[9], tj[3], Rm[9];
+      int type = rob->joint_type[li];
+      int dof = rob->dof_index[li];
+      double q = (dof >= 0 && type != 0) ? dofvals[dof] : 0.0;
+      if (rob->parent[li] < 0) { Rp = &Rb[0][0]; tp = base_pose; }
+      else { Rp = R + 9*rob->parent[li]; tp = t + 3*rob->parent[li]; }
+      /* joint frame in the world */
+      ora_kin_quat_to_R(pj+3, Rfix);
+      mat3_mul(Rp, &Rfix[0][0], Rj);
+      mat3_vec(Rp, pj, tj);
+      tj[0] += tp[0]; tj[1] += tp[1]; tj[2] += tp[2];
+      if (axis_w) mat3_vec(Rj, rob->axis + 3*li, axis_w + 3*li);
+      if (anchor_w) { anchor_w[3*li+0] = tj[0]; anchor_w[3*li+1] = tj[1]; anchor_w[3*li+2] = tj[2]; }
+      if (type == 1)
+      {
+         axis_angle_R(rob->axis + 3*li, q, Rm);
+         mat3_mul(Rj, Rm, R + 9*li);
+         t[3*li+0] = tj[0]; t[3*li+1] = tj[1]; t[3*li+2] = tj[2];
+      }
+      else
+      {
+         memcpy(R + 9*li, Rj, 9*sizeof(double));
+         if (type == 2)
+         {
+            double aw[3];
+            mat3_vec(Rj, rob->axis + 3*li, aw);
+            tj[0] += q*aw[0]; tj[1] += q*aw[1]; tj[2] += q*aw[2];
+         }
+         else if (axis_w) { axis_w[3*li+0] = 0.0; axis_w[3*li+1] = 0.0; axis_w[3*li+2] = 0.0; }
+         t[3*li+0] = tj[0]; t[3*li+1] = tj[1]; t[3*li+2] = tj[2];
+      }
+   }
+}
+
+int ora_robot_does_affect(const ora_robot * rob, int dof, int link)
+{
+   int li;
+   for (li=link; li>=0; li=rob->parent[li])
+      if (rob->joint_type[li] != 0 && rob->dof_index[li] == dof) return 1;
+   return 0;
+}
+
+/* ------------------------------------------------------------------ run */
+
+typedef struct run_sphere   /* src/orcdchomp_mod.cpp:857-864 */
+{
+   double radius;
+   int robot_linkindex;
+   double pos_wrt_link[3];
+   int xml_index;
+} run_sphere;
+
+struct ora_run              /* src/orcdchomp_mod.cpp:887-966 */
+{
+   double * traj;
+   int n_points;
+   const ora_robot * robot;
+   double base_pose[7];
+   double * dofvals;        /* all robot dofs; inactive ones stay at their create-time values */
+   int n_adof;
+   int floating_base;
+   int * adofindices;
+   double epsilon, epsilon_self, obs_factor, obs_factor_self;
+   run_sphere * spheres;    /* array, first n_spheres_active are active */
+   int n_spheres, n_spheres_active;
+   double * sphere_poss_inactive;
+   double * sphere_poss_all;
+   double * sphere_poss;
+   double * sphere_vels;
+   double * sphere_accs;
+   double * sphere_jacs;
+   double * J2;
+   int n_rsdfs;
+   ora_rsdf * rsdfs;
+   int use_hmc;
+   int hmc_resample_iter;
+   double hmc_resample_lambda;
+   ora_rng rng;
+   ora_chomp * c;
+   int iter;
+   /* FK scratch */
+   double * fkR, * fkt, * fkaxis, * fkanchor;
+};
+
+void ora_run_params_default(ora_run_params * p)   /* src/orcdchomp_mod.cpp:1824-1826,1838-1885 */
+{
+   p->n_points = 101;
+   p->floating_base = 0;
+   p->lambda = 10.0;
+   p->D = 1;
+   p->use_momentum = 0;
+   p->use_hmc = 0;
+   p->hmc_resample_lambda = 0.02;
+   p->seed = 0;
+   p->epsilon = 0.1;
+   p->epsilon_self = 0.04;
+   p->obs_factor = 200.0;
+   p->obs_factor_self = 10.0;
+}
+
+static double nrm2_3(const double * v) { return sqrt(v[0]*v[0] + v[1]*v[1] + v[2]*v[2]); }
+static double dot3(const double * a, const double * b) { return a[0]*b[0] + a[1]*b[1] + a[2]*b[2]; }
+
+/* src/orcdchomp_mod.cpp:968-1132 */
+static int sphere_cost_pre(void * vptr, ora_chomp * c, int m, double ** T_points)
+{
+   ora_run * r = (ora_run *) vptr;
+   const ora_robot * rob = r->robot;
+   int Sa = r->n_spheres_active, n = c->n;
+   int ti, sai, i, j, k;
+   (void) m; (void) T_points;
+
+   for (ti=0; ti<r->n_points; ti++)
+   {
+      const double * row = &r->traj[ti*n];
+      double pose[7];
+      double Jsp[6][7];
+      int ti_mov;
+      /* put the robot in the config (mod.cpp:991-1028) */
+      if (r->floating_base)
+      {
+         ora_spatial_pose_jac(row, Jsp);
+         for (i=0; i<7; i++) pose[i] = row[i];
+         for (j=0; j<r->n_adof; j++) r->dofvals[r->adofindices[j]] = row[7+j];
+      }
+      else
+      {
+         for (i=0; i<7; i++) pose[i] = r->base_pose[i];
+         for (j=0; j<r->n_adof; j++) r->dofvals[r->adofindices[j]] = row[j];
+      }
+      ora_robot_fk(rob, pose, r->dofvals, r->fkR, r->fkt, r->fkaxis, r->fkanchor);
+
+      ti_mov = ti - 1;                                   /* mod.cpp:1040-1043, no start_tsr */
+      for (sai=0; sai<Sa; sai++)
+      {
+         const run_sphere * s = &r->spheres[sai];
+         int li = s->robot_linkindex;
+         double v[3];
+         double * jac;
+         mat3_vec(r->fkR + 9*li, s->pos_wrt_link, v);
+         v[0] += r->fkt[3*li+0]; v[1] += r->fkt[3*li+1]; v[2] += r->fkt[3*li+2];
+         r->sphere_poss_all[ti*(Sa*3) + sai*3 + 0] = v[0];
+         r->sphere_poss_all[ti*(Sa*3) + sai*3 + 1] = v[1];
+         r->sphere_poss_all[ti*(Sa*3) + sai*3 + 2] = v[2];
+         if (ti_mov < 0 || c->m <= ti_mov) continue;
+         jac = r->sphere_jacs + ti_mov*Sa*3*n + sai*3*n;
+         memset(jac, 0, 3*n*sizeof(double));
+         /* linear Jacobian of the sphere centre wrt the active dofs:
+          * CalculateJacobian semantics */
+         for (j=0; j<r->n_adof; j++)
+         {
+            int dof = r->adofindices[j];
+            int col = (r->floating_base ? 7 : 0) + j;
+            int lk;
+            for (lk=li; lk>=0; lk=rob->parent[lk])
+            {
+               const double * a = r->fkaxis + 3*lk;
+               if (rob->joint_type[lk] == 0 || rob->dof_index[lk] != dof) continue;
+               if (rob->joint_type[lk] == 1)
+               {
+                  double d[3];
+                  d[0] = v[0] - r->fkanchor[3*lk+0];
+                  d[1] = v[1] - r->fkanchor[3*lk+1];
+                  d[2] = v[2] - r->fkanchor[3*lk+2];
+                  jac[0*n+col] += a[1]*d[2] - a[2]*d[1];
+                  jac[1*n+col] += a[2]*d[0] - a[0]*d[2];
+                  jac[2*n+col] += a[0]*d[1] - a[1]*d[0];
+               }
+               else
+               {
+                  jac[0*n+col] += a[0]; jac[1*n+col] += a[1]; jac[2*n+col] += a[2];
+               }
+            }
+         }
+         if (r->floating_base)
+         {
+            /* mod.cpp:1050-1080: left 3x7 block = Xm[3:6,:] * Jsp, then *= 0.01 */
+            double spose[7], Xm[6][6];
+            ora_kin_pose_identity(spose);
+            spose[0] = -v[0]; spose[1] = -v[1]; spose[2] = -v[2];
+            ora_spatial_xm_from_pose(Xm, spose);
+            for (i=0; i<3; i++) for (j=0; j<7; j++)
+            {
+               double sum = 0.0;
+               for (k=0; k<6; k++) sum += Xm[3+i][k] * Jsp[k][j];
+               jac[i*n+j] = sum;
+            }
+            for (i=0; i<3; i++) for (j=0; j<7; j++) jac[i*n+j] *= 0.01;
+         }
+      }
+   }
+
+   /* central-difference sphere velocities and accelerations (mod.cpp:1099-1127) */
+   {
+      int rows = r->n_points - 2, cols = Sa*3;
+      const double * P = r->sphere_poss_all;
+      for (i=0; i<rows; i++) for (j=0; j<cols; j++)
+      {
+         double vel = P[(i+2)*cols+j];
+         double acc = P[(i+1)*cols+j];
+         vel -= P[i*cols+j];
+         vel *= 1.0/(2.0*c->dt);
+         acc *= -2.0;
+         acc += P[i*cols+j];
+         acc += P[(i+2)*cols+j];
+         acc *= 1.0/(c->dt * c->dt);
+         r->sphere_vels[i*cols+j] = vel;
+         r->sphere_accs[i*cols+j] = acc;
+      }
+   }
+   return 0;
+}
+
+/* src/orcdchomp_mod.cpp:1134-1327 */
+static int sphere_cost(void * vptr, ora_chomp * c, int ti, double * c_point, double * c_vel, double * costp, double * c_grad)
+{
+   ora_run * r = (ora_run *) vptr;
+   int Sa = r->n_spheres_active, n = c->n;
+   int sai, sai2, i, j;
+   double cost = 0.0;
+   (void) c_point; (void) c_vel;
+
+   if (c_grad) memset(c_grad, 0, n*sizeof(double));
+
+   for (sai=0; sai<Sa; sai++)
+   {
+      const run_sphere * sact = &r->spheres[sai];
+      const double * x_vel = r->sphere_vels + ti*(Sa*3) + sai*3;
+      const double * pos = r->sphere_poss + ti*(Sa*3) + sai*3;
+      const double * jac = r->sphere_jacs + ti*Sa*3*n + sai*3*n;
+      double x_vel_norm = nrm2_3(x_vel);
+      double cost_sphere = 0.0;
+      double g_point[3], g_grad[3], x_grad[3], x_curv[3], dist, proj;
+      double best = HUGE_VAL;
+      int best_i = -1;
+
+      /* field with the smallest value (mod.cpp:1171-1188) */
+      for (i=0; i<r->n_rsdfs; i++)
+      {
+         ora_kin_pose_compos(r->rsdfs[i].pose_gsdf_world, pos, g_point);
+         if (ora_grid_double_interp(r->rsdfs[i].grid, g_point, &dist)) continue;
+         if (dist < best) { best = dist; best_i = i; }
+      }
+      if (best_i != -1)
+      {
+         ora_kin_pose_compos(r->rsdfs[best_i].pose_gsdf_world, pos, g_point);
+         ora_grid_double_interp(r->rsdfs[best_i].grid, g_point, &dist);
+         dist -= sact->radius;
+         if (dist < 0.0)
+            cost_sphere += x_vel_norm * r->obs_factor * (0.5 * r->epsilon - dist);
+         else if (dist < r->epsilon)
+            cost_sphere += x_vel_norm * r->obs_factor * (0.5/r->epsilon) * (dist - r->epsilon) * (dist - r->epsilon);
+
+         if (c_grad)
+         {
+            ora_grid_double_grad(r->rsdfs[best_i].grid, g_point, g_grad);
+            ora_kin_pose_compose_vec(r->rsdfs[best_i].pose_world_gsdf, g_grad, g_grad);
+            for (j=0; j<3; j++) x_grad[j] = g_grad[j];
+            if (dist < 0.0)
+               for (j=0; j<3; j++) x_grad[j] *= -1.0;
+            else if (dist < r->epsilon)
+               for (j=0; j<3; j++) x_grad[j] *= dist/r->epsilon - 1.0;
+            else
+               for (j=0; j<3; j++) x_grad[j] = 0.0;
+            for (j=0; j<3; j++) x_grad[j] *= x_vel_norm * r->obs_factor;
+            if (x_vel_norm > 0.000001)
+            {
+               proj = dot3(x_grad, x_vel) / (x_vel_norm * x_vel_norm);
+               for (j=0; j<3; j++) x_grad[j] += -proj * x_vel[j];
+            }
+            for (j=0; j<3; j++) x_curv[j] = r->sphere_accs[ti*(Sa*3) + sai*3 + j];
+            if (x_vel_norm > 0.000001)
+            {
+               proj = dot3(x_curv, x_vel) / (x_vel_norm * x_vel_norm);
+               for (j=0; j<3; j++) x_curv[j] += -proj * x_vel[j];
+            }
+            for (j=0; j<3; j++) x_curv[j] *= 1.0 / (x_vel_norm * x_vel_norm);
+            for (j=0; j<3; j++) x_grad[j] += -cost_sphere * x_curv[j];
+            /* dgemv(Trans, alpha=|v|): BLAS returns early for alpha==0, which is the
+             * only thing that keeps the NaN in x_grad out of c_grad */
+            if (x_vel_norm != 0.0)
+               for (j=0; j<n; j++)
+                  c_grad[j] += x_vel_norm * (jac[0*n+j]*x_grad[0] + jac[1*n+j]*x_grad[1] + jac[2*n+j]*x_grad[2]);
+         }
+      }
+
+      /* self collision against every other sphere (mod.cpp:1251-1317) */
+      for (sai2=0; sai2<r->n_spheres; sai2++)
+      {
+         const run_sphere * sact2 = &r->spheres[sai2];
+         double v_from_other[3];
+         if (sact->robot_linkindex == sact2->robot_linkindex) continue;
+         for (j=0; j<3; j++) v_from_other[j] = pos[j];
+         if (sai2 < Sa)
+            for (j=0; j<3; j++) v_from_other[j] -= r->sphere_poss[ti*(Sa*3) + sai2*3 + j];
+         else
+            for (j=0; j<3; j++) v_from_other[j] -= r->sphere_poss_inactive[(sai2-Sa)*3 + j];
+         dist = nrm2_3(v_from_other);
+         if (dist > sact->radius + sact2->radius + r->epsilon_self) continue;
+         if (c_grad)
+            for (j=0; j<3; j++) g_grad[j] = v_from_other[j] / dist;
+         dist -= sact->radius + sact2->radius;
+         if (costp)
+         {
+            if (dist < 0.0)
+               cost_sphere += x_vel_norm * r->obs_factor_self * (0.5 * r->epsilon_self - dist);
+            else
+               cost_sphere += x_vel_norm * r->obs_factor_self * (0.5/r->epsilon_self) * (dist - r->epsilon_self) * (dist - r->epsilon_self);
+         }
+         if (c_grad)
+         {
+            for (j=0; j<3; j++) x_grad[j] = g_grad[j];
+            if (dist < 0.0)
+               for (j=0; j<3; j++) x_grad[j] *= -1.0;
+            else if (dist < r->epsilon_self)
+               for (j=0; j<3; j++) x_grad[j] *= dist/r->epsilon_self - 1.0;
+            for (j=0; j<3; j++) x_grad[j] *= x_vel_norm * r->obs_factor_self;
+            if (x_vel_norm > 0.000001)
+            {
+               proj = dot3(x_grad, x_vel) / (x_vel_norm * x_vel_norm);
+               for (j=0; j<3; j++) x_grad[j] += -proj * x_vel[j];
+            }
+            memcpy(r->J2, jac, 3*n*sizeof(double));
+            if (sai2 < Sa)
+            {
+               const double * jac2 = r->sphere_jacs + ti*Sa*3*n + sai2*3*n;
+               for (j=0; j<3*n; j++) r->J2[j] -= jac2[j];
+            }
+            for (j=0; j<n; j++)
+               c_grad[j] += 1.0 * (r->J2[0*n+j]*x_grad[0] + r->J2[1*n+j]*x_grad[1] + r->J2[2*n+j]*x_grad[2]);
+         }
+      }
+      cost += cost_sphere;
+   }
+   if (costp) *costp = cost;
+   return 0;
+}
+
+static void run_free(ora_run * r)
+{
+   if (!r) return;
+   free(r->traj); free(r->dofvals); free(r->adofindices); free(r->spheres);
+   free(r->sphere_poss_inactive); free(r->sphere_poss_all); free(r->sphere_vels);
+   free(r->sphere_accs); free(r->sphere_jacs); free(r->J2); free(r->rsdfs);
+   free(r->fkR); free(r->fkt); free(r->fkaxis); free(r->fkanchor);
+   ora_chomp_free(r->c);
+   free(r);
+}
+
+/* src/orcdchomp_mod.cpp:1800-2688 */
+ora_run * ora_run_create(const ora_robot * rob, const double base_pose[7], const double * dofvals,
+   int n_adof, const int * adofindices, const double * adofgoal, const double * basegoal,
+   int n_sdfs, const ora_grid * const * grids, const double * poses_world_gsdf,
+   const ora_run_params * params, const char ** errmsg)
+{
+   static const char * dummy;
+   ora_run * r;
+   int n, m, i, j, si, n_act, n_inact;
+   int * is_active;
+   if (!errmsg) errmsg = &dummy;
+   *errmsg = 0;
+   /* validation (mod.cpp:2091-2097) */
+   if (!adofgoal) { *errmsg = "Did not pass either adofgoal or starttraj!"; return 0; }
+   if (params->floating_base && !basegoal) { *errmsg = "Passed floating_base with no basegoal!"; return 0; }
+   if (!params->floating_base && basegoal) { *errmsg = "Passed basegoal with no floating_base!"; return 0; }
+   if (!n_sdfs) { *errmsg = "No signed distance fields have yet been computed!"; return 0; }
+   if (params->lambda < 0.01) { *errmsg = "lambda must be >=0.01!"; return 0; }
+   if (params->n_points < 3) { *errmsg = "n_points must be >=3!"; return 0; }
+
+   r = (ora_run *) calloc(1, sizeof(ora_run));
+   r->robot = rob;
+   r->n_points = params->n_points;
+   r->floating_base = params->floating_base;
+   r->epsilon = params->epsilon;
+   r->epsilon_self = params->epsilon_self;
+   r->obs_factor = params->obs_factor;
+   r->obs_factor_self = params->obs_factor_self;
+   r->use_hmc = params->use_hmc;
+   r->hmc_resample_iter = 0;
+   r->hmc_resample_lambda = params->hmc_resample_lambda;
+   r->n_adof = n_adof;
+   memcpy(r->base_pose, base_pose, 7*sizeof(double));
+   r->dofvals = (double *) malloc((rob->n_dof ? rob->n_dof : 1) * sizeof(double));
+   memcpy(r->dofvals, dofvals, rob->n_dof * sizeof(double));
+   r->adofindices = (int *) malloc((n_adof ? n_adof : 1) * sizeof(int));
+   memcpy(r->adofindices, adofindices, n_adof * sizeof(int));
+   n = (r->floating_base ? 7 : 0) + n_adof;                       /* mod.cpp:2104-2105 */
+
+   /* spheres: active ones first, in XML order; inactive appended */
+   is_active = (int *) malloc((rob->n_spheres ? rob->n_spheres : 1) * sizeof(int));
+   n_act = 0;
+   for (si=0; si<rob->n_spheres; si++)
+   {
+      int act = r->floating_base ? 1 : 0;
+      for (j=0; j<n_adof && !act; j++)
+         if (ora_robot_does_affect(rob, adofindices[j], rob->sphere_link[si])) act = 1;
+      is_active[si] = act;
+      n_act += act;
+   }
+   n_inact = rob->n_spheres - n_act;
+   if (!n_act) { free(is_active); run_free(r); *errmsg = "robot active dofs must have at least one sphere!"; return 0; }
+   r->n_spheres = rob->n_spheres;
+   r->n_spheres_active = n_act;
+   r->spheres = (run_sphere *) calloc(rob->n_spheres, sizeof(run_sphere));
+   {
+      int ia = 0, ii = n_act;
+      /* the kdata list reverses XML order and the head insertion in create reverses it
+       * again for active spheres (XML order); inactive ones are head-inserted once more
+       * on an (uninitialised, treated as NULL) list, i.e. reversed kdata order = XML order */
+      for (si=0; si<rob->n_spheres; si++)
+      {
+         run_sphere * s = is_active[si] ? &r->spheres[ia++] : &r->spheres[ii++];
+         s->radius = rob->sphere_radius[si];
+         s->robot_linkindex = rob->sphere_link[si];
+         memcpy(s->pos_wrt_link, rob->sphere_pos + 3*si, 3*sizeof(double));
+         s->xml_index = si;
+      }
+   }
+   free(is_active);
+
+   ora_rng_set(&r->rng, params->seed);                            /* mod.cpp:2303-2304 */
+
+   m = r->n_points - 2;                                           /* mod.cpp:2315 */
+   r->J2 = (double *) malloc(3*n*sizeof(double));
+   r->sphere_poss_all = (double *) calloc((size_t) r->n_points * n_act * 3, sizeof(double));
+   r->sphere_poss = r->sphere_poss_all + n_act*3;                 /* mod.cpp:2323 */
+   r->sphere_vels = (double *) calloc((size_t) m * n_act * 3, sizeof(double));
+   r->sphere_accs = (double *) calloc((size_t) m * n_act * 3, sizeof(double));
+   r->sphere_jacs = (double *) calloc((size_t) m * n_act * 3 * n, sizeof(double));
+   r->fkR = (double *) malloc(rob->n_links * 9 * sizeof(double));
+   r->fkt = (double *) malloc(rob->n_links * 3 * sizeof(double));
+   r->fkaxis = (double *) malloc(rob->n_links * 3 * sizeof(double));
+   r->fkanchor = (double *) malloc(rob->n_links * 3 * sizeof(double));
+
+   /* world positions of the inactive spheres, once (mod.cpp:2332-2345) */
+   r->sphere_poss_inactive = (double *) calloc((size_t)(n_inact ? n_inact : 1) * 3, sizeof(double));
+   ora_robot_fk(rob, base_pose, dofvals, r->fkR, r->fkt, r->fkaxis, r->fkanchor);
+   for (si=0; si<n_inact; si++)
+   {
+      const run_sphere * s = &r->spheres[n_act + si];
+      double v[3];
+      mat3_vec(r->fkR + 9*s->robot_linkindex, s->pos_wrt_link, v);
+      for (j=0; j<3; j++) r->sphere_poss_inactive[si*3+j] = v[j] + r->fkt[3*s->robot_linkindex+j];
+   }
+
+   /* rooted sdfs (mod.cpp:2348-2369); the caller passes pose_world_gsdf already composed */
+   r->n_rsdfs = n_sdfs;
+   r->rsdfs = (ora_rsdf *) calloc(n_sdfs, sizeof(ora_rsdf));
+   for (i=0; i<n_sdfs; i++)
+   {
+      r->rsdfs[i].grid = grids[i];
+      memcpy(r->rsdfs[i].pose_world_gsdf, poses_world_gsdf + 7*i, 7*sizeof(double));
+      ora_kin_pose_invert(r->rsdfs[i].pose_world_gsdf, r->rsdfs[i].pose_gsdf_world);
+   }
+
+   /* straight-line trajectory (mod.cpp:2417-2464) */
+   r->traj = (double *) calloc((size_t) r->n_points * n, sizeof(double));
+   if (r->floating_base)
+   {
+      for (j=0; j<7; j++) r->traj[j] = base_pose[j];
+      for (j=0; j<n_adof; j++) r->traj[7+j] = dofvals[adofindices[j]];
+      for (j=0; j<7; j++) r->traj[(r->n_points-1)*n+j] = basegoal[j];
+      for (j=0; j<n_adof; j++) r->traj[(r->n_points-1)*n+7+j] = adofgoal[j];
+   }
+   else
+   {
+      for (j=0; j<n_adof; j++) r->traj[j] = dofvals[adofindices[j]];
+      for (j=0; j<n_adof; j++) r->traj[(r->n_points-1)*n+j] = adofgoal[j];
+   }
+   /* note the in-place form: row 0 is rewritten first (to itself), the last row last */
+   for (i=0; i<r->n_points; i++)
+      for (j=0; j<n; j++)
+         r->traj[i*n+j] = r->traj[j] + (r->traj[(r->n_points-1)*n+j]-r->traj[j]) * i/(r->n_points-1);
+   if (r->floating_base)
+      for (i=0; i<r->n_points; i++)
+         ora_kin_pose_normalize(&r->traj[i*n]);
+
+   /* the optimizer (mod.cpp:2521, 2567-2663) */
+   if (ora_chomp_create(&r->c, m, n, params->D, &r->traj[1*n], n)) { run_free(r); *errmsg = "error creating chomp instance!"; return 0; }
+   r->c->dt = 1.0/((r->n_points)-1);
+   r->c->inits[0] = &r->traj[0*n];
+   r->c->finals[0] = &r->traj[((r->n_points)-1)*n];
+   r->c->cptr = r;
+   r->c->cost_pre = sphere_cost_pre;
+   r->c->cost = sphere_cost;
+   r->c->lambda = params->lambda;
+   if (params->use_momentum) r->c->use_momentum = 1;
+   if (r->floating_base)
+   {
+      for (j=0; j<7; j++) { r->c->jlimit_lower[j] = -HUGE_VAL; r->c->jlimit_upper[j] = HUGE_VAL; }
+      for (j=0; j<n_adof; j++)
+      {
+         r->c->jlimit_lower[7+j] = rob->limit_lower[adofindices[j]];
+         r->c->jlimit_upper[7+j] = rob->limit_upper[adofindices[j]];
+      }
+   }
+   else for (j=0; j<n_adof; j++)
+   {
+      r->c->jlimit_lower[j] = rob->limit_lower[adofindices[j]];
+      r->c->jlimit_upper[j] = rob->limit_upper[adofindices[j]];
+   }
+   if (ora_chomp_init(r->c)) { run_free(r); *errmsg = "Error initializing chomp instance."; return 0; }
+   return r;
+}
+
+/* src/orcdchomp_mod.cpp:2690-2852 */
+static int run_iterate(ora_run * r, int n_iter, double * costs_out, double * trace, const double * noise, int n_noise)
+{
+   ora_chomp * c = r->c;
+   double cost_total = 0.0, cost_obs = 0.0, cost_smooth = 0.0;
+   int i, j, used_noise = 0;
+   for (r->iter=0; r->iter<n_iter; r->iter++)
+   {
+      int ret;
+      if (r->use_hmc && r->iter == r->hmc_resample_iter)           /* mod.cpp:2755-2768 */
+      {
+         double hmc_alpha = 100.0 * exp(0.02 * r->iter);
+         if (noise)
+         {
+            if (used_noise < n_noise)
+               memcpy(c->AG, noise + (size_t) used_noise * c->m * c->n, (size_t) c->m * c->n * sizeof(double));
+            /* keep the rng stream aligned as if the gaussians had been drawn */
+            for (i=0; i<c->m*c->n; i++) (void) ora_ran_gaussian(&r->rng, 1.0/sqrt(hmc_alpha));
+            used_noise++;
+         }
+         else
+            for (i=0; i<c->m; i++)
+               for (j=0; j<c->n; j++)
+                  c->AG[i*c->n+j] = ora_ran_gaussian(&r->rng, 1.0/sqrt(hmc_alpha));
+         c->leapfrog_first = 1;
+         r->hmc_resample_iter += 1 + (int) (- log(ora_rng_uniform(&r->rng)) / r->hmc_resample_lambda);
+      }
+      ret = ora_chomp_iterate(c, 1, &cost_total, &cost_obs, &cost_smooth);
+      if (trace) { trace[3*r->iter+0] = cost_total; trace[3*r->iter+1] = cost_obs; trace[3*r->iter+2] = cost_smooth; }
+      if (ret == -1) return -1;                                     /* mod.cpp:2799-2803 */
+      if (r->floating_base)                                         /* mod.cpp:2806-2808 */
+         for (i=0; i<r->n_points; i++)
+            ora_kin_pose_normalize(&r->traj[i*c->n]);
+   }
+   ora_chomp_iterate(c, 0, &cost_total, &cost_obs, &cost_smooth);  /* mod.cpp:2830 */
+   if (costs_out) { costs_out[0] = cost_total; costs_out[1] = cost_obs; costs_out[2] = cost_smooth; }
+   return 0;
+}
+
+int ora_run_iterate(ora_run * r, int n_iter, double * costs_out, double * trace)
+{
+   return run_iterate(r, n_iter, costs_out, trace, 0, 0);
+}
+
+int ora_run_iterate_noise(ora_run * r, int n_iter, double * costs_out, double * trace, const double * noise, int n_noise)
+{
+   return run_iterate(r, n_iter, costs_out, trace, noise, n_noise);
+}
+
+void ora_run_destroy(ora_run * r) { run_free(r); }
+int ora_run_n(const ora_run * r) { return r->c->n; }
+int ora_run_m(const ora_run * r) { return r->c->m; }
+int ora_run_n_points(const ora_run * r) { return r->n_points; }
+int ora_run_n_spheres_active(const ora_run * r) { return r->n_spheres_active; }
+int ora_run_n_spheres(const ora_run * r) { return r->n_spheres; }
+double * ora_run_traj(ora_run * r) { return r->traj; }
+ora_chomp * ora_run_chomp(ora_run * r) { return r->c; }
+int ora_run_hmc_resample_iter(const ora_run * r) { return r->hmc_resample_iter; }
+
+void ora_run_sphere_order(const ora_run * r, int * idx)
+{
+   int i;
+   for (i=0; i<r->n_spheres; i++) idx[i] = r->spheres[i].xml_index;
+}
+
+int ora_run_eval_obstacle(ora_run * r, double * G, double * costs, double * sphere_poss_all)
+{
+   ora_chomp * c = r->c;
+   int i;
+   sphere_cost_pre(r, c, c->m, c->T_points);
+   for (i=0; i<c->m; i++)
+      sphere_cost(r, c, i, c->T_points[i], 0, costs ? &costs[i] : 0, G ? &G[i*c->n] : 0);
+   if (sphere_poss_all)
+      memcpy(sphere_poss_all, r->sphere_poss_all, (size_t) r->n_points * r->n_spheres_active * 3 * sizeof(double));
+   return 0;
+}
+
+int ora_batch_run(const ora_robot * rob, const double base_pose[7], const double * dofvals,
+   int n_adof, const int * adofindices, int n_runs, const double * adofgoals, const double * basegoals,
+   int n_sdfs, const ora_grid * const * grids, const double * poses_world_gsdf,
+   const ora_run_params * params, const unsigned int * seeds, int n_iter,
+   double * traj_out, double * costs_out, int * status_out, int max_threads)
+{
+   int threads = 1, k;
+   int n = (params->floating_base ? 7 : 0) + n_adof;
+#ifdef _OPENMP
+   threads = omp_get_max_threads();
+   if (max_threads > 0 && max_threads < threads) threads = max_threads;
+#pragma omp parallel for schedule(dynamic) num_threads(threads)
+#else
+   (void) max_threads;
+#endif
+   for (k=0; k<n_runs; k++)
+   {
+      ora_run_params p = *params;
+      const char * err = 0;
+      ora_run * r;
+      double costs[3] = {0.0, 0.0, 0.0};
+      int st;
+      if (seeds) p.seed = seeds[k];
+      r = ora_run_create(rob, base_pose, dofvals, n_adof, adofindices, adofgoals + (size_t) k*n_adof,
+         basegoals ? basegoals + (size_t) k*7 : 0, n_sdfs, grids, poses_world_gsdf, &p, &err);
+      if (!r) { if (status_out) status_out[k] = -2; continue; }
+      st = ora_run_iterate(r, n_iter, costs, 0);
+      if (traj_out) memcpy(traj_out + (size_t) k * p.n_points * n, r->traj, (size_t) p.n_points * n * sizeof(double));
+      if (costs_out) memcpy(costs_out + 3*(size_t) k, costs, 3*sizeof(double));
+      if (status_out) status_out[k] = st;
+      ora_run_destroy(r);
+   }
+   return threads;
+}
