@@ -1,0 +1,157 @@
+/* orcdchomp_amd.h -- C ABI of the MI355X-native CHOMP hot path.
+ *
+ * Drop-in boundary for the path  computedistancefield -> create -> iterate ->
+ * gettraj -> destroy  of the orcdchomp OpenRAVE module (personalrobotics/or_cdchomp).
+ * Plain C: pointers and sizes only, no C++/torch types.  Every entry point names
+ * the reference interface it replaces (paths relative to /root/reference).
+ *
+ * Conventions
+ *   - all functions return 0 on success, non-zero on error; the message of the
+ *     last error of a module is available through orc_last_error() and uses the
+ *     reference's own exception strings.
+ *   - pose = 7 doubles [x y z qx qy qz qw]           (src/libcd/kin.c:42-52)
+ *   - grids are C ordered [x][y][z] doubles            (src/libcd/grid.c:31-32)
+ *   - trajectories are run-major: traj[run][waypoint][dof]
+ *   - handles returned as text by create are opaque strings, as in the reference
+ *     ("%p" there, an integer id here; src/orcdchomp_mod.cpp:2670-2674).
+ */
+#ifndef ORCDCHOMP_AMD_H
+#define ORCDCHOMP_AMD_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_module orc_module;
+
+/* ---- module lifetime ---------------------------------------------------------
+ * replaces the plugin entry points CreateInterfaceValidated / DestroyPlugin
+ * (src/orcdchomp.cpp:50-74) and the mod constructor/destructor
+ * (src/orcdchomp_mod.h:45-75).  device = HIP device ordinal (one process per GPU). */
+orc_module * orc_module_new(int device);
+void orc_module_free(orc_module * mod);
+const char * orc_last_error(const orc_module * mod);
+/* HIP stream all kernels and copies of this module are issued on (a hipStream_t,
+ * e.g. torch.cuda.current_stream().cuda_stream); NULL = the default stream. */
+int orc_set_stream(orc_module * mod, void * hip_stream);
+
+/* ---- SendCommand -------------------------------------------------------------
+ * replaces ModuleBase::SendCommand -> orcwrap_call (src/orcwrap.cpp:37-69) ->
+ * mod::computedistancefield / addfield_fromobsarray / removefield / create /
+ * iterate / gettraj / destroy (src/orcdchomp_mod.h:58-66).  Same command names,
+ * same argv grammar (shell-style quoting, src/libcd/util_shparse.c), same textual
+ * returns.  out receives the reply (NUL terminated, truncated to out_cap).
+ * Batch extensions (additive): createbatch, iteratebatch, gettrajbatch. */
+int orc_send_command(orc_module * mod, const char * cmd, char * out, size_t out_cap);
+/* size in bytes (without NUL) of the full reply of the last successful command */
+size_t orc_last_reply_size(const orc_module * mod);
+/* copy of the full reply of the last successful command (for replies larger than out_cap) */
+int orc_last_reply(const orc_module * mod, char * out, size_t out_cap);
+
+/* ---- environment stand-ins ---------------------------------------------------
+ * The reference reads robots and bodies from the OpenRAVE environment
+ * (e->GetRobot / e->GetKinBody, src/orcdchomp_mod.cpp:1894,336).  OpenRAVE is
+ * third party; these calls hand the same information over explicitly. */
+
+/* kinematic tree, links in topological order (parent index < own index):
+ *   link frame = parent link frame o pose_parent_joint o motion(axis, q[dof])
+ * joint_type 0 fixed, 1 revolute, 2 prismatic.  Spheres in <orcdchomp><spheres>
+ * XML order (src/orcdchomp_kdata.cpp:79-94, struct sphere src/orcdchomp_kdata.h:33-39). */
+typedef struct orc_robot_desc
+{
+   int n_links;
+   const int * parent;               /* [n_links], -1 for the root */
+   const double * pose_parent_joint; /* [n_links][7] */
+   const int * joint_type;           /* [n_links] */
+   const double * axis;              /* [n_links][3] unit, in the joint frame */
+   const int * dof_index;            /* [n_links] robot dof, -1 for fixed */
+   int n_dof;
+   const double * limit_lower;       /* [n_dof]  (GetDOFLimits, mod.cpp:2639) */
+   const double * limit_upper;       /* [n_dof] */
+   int n_spheres;
+   const int * sphere_link;          /* [n_spheres] link index */
+   const double * sphere_pos;        /* [n_spheres][3] in the link frame */
+   const double * sphere_radius;     /* [n_spheres] */
+} orc_robot_desc;
+
+int orc_env_add_robot(orc_module * mod, const char * name, const orc_robot_desc * desc);
+int orc_robot_set_transform(orc_module * mod, const char * name, const double pose[7]);      /* robot->SetTransform */
+int orc_robot_set_dof_values(orc_module * mod, const char * name, const double * values, int n); /* SetDOFValues */
+int orc_robot_set_active_dofs(orc_module * mod, const char * name, const int * indices, int n); /* SetActiveDOFs */
+
+/* a kinbody made of oriented boxes (InitFromBoxes-style); box_poses [n_boxes][7]
+ * in the kinbody frame, half_extents [n_boxes][3] */
+int orc_env_add_kinbody_boxes(orc_module * mod, const char * name, int n_boxes,
+   const double * box_poses, const double * half_extents);
+int orc_kinbody_set_transform(orc_module * mod, const char * name, const double pose[7]);
+int orc_kinbody_enable(orc_module * mod, const char * name, int enabled);
+
+/* ---- SDF access --------------------------------------------------------------
+ * the module's field list (struct sdf, src/orcdchomp_mod.cpp:148-153) */
+int orc_scene_add_sdf(orc_module * mod, const char * kinbody, const int sizes[3], const double lengths[3],
+   const double pose_kinbody_gsdf[7], const double * sdf_data);
+/* copy out a computed field: sizes[3], lengths[3], pose[7] (grid wrt kinbody), data (may be NULL to query sizes) */
+int orc_scene_get_sdf(orc_module * mod, const char * kinbody, int sizes[3], double lengths[3], double pose[7],
+   double * data, size_t data_cap);
+
+/* ---- kernel-level batch API --------------------------------------------------
+ * what the command layer calls; one batch = n_runs independent CHOMP runs that
+ * share robot, fields and parameters (struct run, src/orcdchomp_mod.cpp:887-966;
+ * cd_chomp, src/libcd/chomp.h:38-101).  A single `create` is a batch of 1. */
+typedef struct orc_batch_params
+{
+   int n_points;               /* default 101        (mod.cpp:1840) */
+   int floating_base;          /*                    (mod.cpp:1843,1928) */
+   double lambda;              /* default 10         (mod.cpp:1824) */
+   int derivative;             /* D, default 1       (mod.cpp:1826) */
+   int use_momentum;           /*                    (mod.cpp:1825) */
+   int use_hmc;                /*                    (mod.cpp:1873) */
+   double hmc_resample_lambda; /* default 0.02       (mod.cpp:1875) */
+   double epsilon;             /* default 0.1        (mod.cpp:1845) */
+   double epsilon_self;        /* default 0.04       (mod.cpp:1846) */
+   double obs_factor;          /* default 200        (mod.cpp:1847) */
+   double obs_factor_self;     /* default 10         (mod.cpp:1848) */
+   int precision;              /* 64 (default) or 32: arithmetic type of the device path */
+} orc_batch_params;
+void orc_batch_params_default(orc_batch_params * p);
+
+/* replaces mod::create (src/orcdchomp_mod.cpp:1800-2688) for n_runs runs at once.
+ * starts: [n_runs][n_adof] or NULL (= the robot's current active dof values, as the
+ * reference does); goals: [n_runs][n_adof]; basegoals: [n_runs][7] or NULL;
+ * seeds: [n_runs] or NULL (0).  *batch_id receives the handle. */
+int orc_batch_create(orc_module * mod, const char * robot, const orc_batch_params * params, int n_runs,
+   const double * starts, const double * goals, const double * basegoals, const unsigned int * seeds,
+   int * batch_id);
+/* replaces mod::iterate (src/orcdchomp_mod.cpp:2690-2852): n_iter iterations of
+ * cd_chomp_iterate (src/libcd/chomp.c:430-683) for every run, then the final
+ * cost evaluation.  costs_out [n_runs][3] = total, obs, smooth (may be NULL);
+ * status_out [n_runs]: 0 ok, -1 "Resulting trajectory is outside of joint limits!". */
+int orc_batch_iterate(orc_module * mod, int batch_id, int n_iter, double * costs_out, int * status_out);
+/* asynchronous form for measurement: enqueue only, results stay on the device */
+int orc_batch_iterate_async(orc_module * mod, int batch_id, int n_iter);
+int orc_batch_sync(orc_module * mod, int batch_id, double * costs_out, int * status_out);
+/* per-iteration cost trace of the last iterate call: [n_runs][n_iter][3] */
+int orc_batch_get_trace(orc_module * mod, int batch_id, double * trace_out, size_t cap_doubles);
+/* momentum noise for HMC resampling supplied by the caller instead of the module's
+ * own mt19937 stream: noise [n_runs][n_blocks][m][n] (used in resample order) */
+int orc_batch_set_noise(orc_module * mod, int batch_id, const double * noise, int n_blocks);
+/* replaces the waypoint export of mod::gettraj (src/orcdchomp_mod.cpp:2897-2903):
+ * traj_out [n_runs][n_points][n] */
+int orc_batch_gettraj(orc_module * mod, int batch_id, double * traj_out, size_t cap_doubles);
+/* optimizer state read-back for tests: which = "G", "AG", "T" ([n_runs][m][n]) */
+int orc_batch_get_state(orc_module * mod, int batch_id, const char * which, double * out, size_t cap_doubles);
+int orc_batch_dims(orc_module * mod, int batch_id, int * n_runs, int * n_points, int * n);
+/* replaces mod::destroy (src/orcdchomp_mod.cpp:3013-3066) */
+int orc_batch_destroy(orc_module * mod, int batch_id);
+
+/* ---- measurement -------------------------------------------------------------
+ * average device time (ms) of the iterate kernel launches since the last reset,
+ * measured with HIP events on the module's stream; count of launches */
+int orc_kernel_time(orc_module * mod, double * total_ms, int * launches, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,88 @@
+"""ctypes binding of include/orcdchomp_amd.h (liborcdchomp_amd.so, built in-tree).
+
+The library is the product: there is no Python or CPU fallback.  Importing this
+module only loads the shared object; a GPU is needed as soon as a Module is made.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liborcdchomp_amd.so")
+
+c_double_p = C.POINTER(C.c_double)
+c_int_p = C.POINTER(C.c_int)
+c_uint_p = C.POINTER(C.c_uint)
+
+
+class RobotDesc(C.Structure):
+    _fields_ = [("n_links", C.c_int), ("parent", c_int_p), ("pose_parent_joint", c_double_p),
+                ("joint_type", c_int_p), ("axis", c_double_p), ("dof_index", c_int_p),
+                ("n_dof", C.c_int), ("limit_lower", c_double_p), ("limit_upper", c_double_p),
+                ("n_spheres", C.c_int), ("sphere_link", c_int_p), ("sphere_pos", c_double_p),
+                ("sphere_radius", c_double_p)]
+
+
+class BatchParams(C.Structure):
+    _fields_ = [("n_points", C.c_int), ("floating_base", C.c_int), ("lambda_", C.c_double),
+                ("derivative", C.c_int), ("use_momentum", C.c_int), ("use_hmc", C.c_int),
+                ("hmc_resample_lambda", C.c_double), ("epsilon", C.c_double),
+                ("epsilon_self", C.c_double), ("obs_factor", C.c_double),
+                ("obs_factor_self", C.c_double), ("precision", C.c_int)]
+
+
+# every symbol include/orcdchomp_amd.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("orc_module_new", C.c_void_p, [C.c_int]),
+    ("orc_module_free", None, [C.c_void_p]),
+    ("orc_last_error", C.c_char_p, [C.c_void_p]),
+    ("orc_set_stream", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("orc_send_command", C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t]),
+    ("orc_last_reply_size", C.c_size_t, [C.c_void_p]),
+    ("orc_last_reply", C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
+    ("orc_env_add_robot", C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(RobotDesc)]),
+    ("orc_robot_set_transform", C.c_int, [C.c_void_p, C.c_char_p, c_double_p]),
+    ("orc_robot_set_dof_values", C.c_int, [C.c_void_p, C.c_char_p, c_double_p, C.c_int]),
+    ("orc_robot_set_active_dofs", C.c_int, [C.c_void_p, C.c_char_p, c_int_p, C.c_int]),
+    ("orc_env_add_kinbody_boxes", C.c_int, [C.c_void_p, C.c_char_p, C.c_int, c_double_p, c_double_p]),
+    ("orc_kinbody_set_transform", C.c_int, [C.c_void_p, C.c_char_p, c_double_p]),
+    ("orc_kinbody_enable", C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    ("orc_scene_add_sdf", C.c_int, [C.c_void_p, C.c_char_p, c_int_p, c_double_p, c_double_p, c_double_p]),
+    ("orc_scene_get_sdf", C.c_int, [C.c_void_p, C.c_char_p, c_int_p, c_double_p, c_double_p, c_double_p, C.c_size_t]),
+    ("orc_batch_params_default", None, [C.POINTER(BatchParams)]),
+    ("orc_batch_create", C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(BatchParams), C.c_int, c_double_p,
+                                   c_double_p, c_double_p, c_uint_p, c_int_p]),
+    ("orc_batch_iterate", C.c_int, [C.c_void_p, C.c_int, C.c_int, c_double_p, c_int_p]),
+    ("orc_batch_iterate_async", C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    ("orc_batch_sync", C.c_int, [C.c_void_p, C.c_int, c_double_p, c_int_p]),
+    ("orc_batch_get_trace", C.c_int, [C.c_void_p, C.c_int, c_double_p, C.c_size_t]),
+    ("orc_batch_set_noise", C.c_int, [C.c_void_p, C.c_int, c_double_p, C.c_int]),
+    ("orc_batch_gettraj", C.c_int, [C.c_void_p, C.c_int, c_double_p, C.c_size_t]),
+    ("orc_batch_get_state", C.c_int, [C.c_void_p, C.c_int, C.c_char_p, c_double_p, C.c_size_t]),
+    ("orc_batch_dims", C.c_int, [C.c_void_p, C.c_int, c_int_p, c_int_p, c_int_p]),
+    ("orc_batch_destroy", C.c_int, [C.c_void_p, C.c_int]),
+    ("orc_kernel_time", C.c_int, [C.c_void_p, c_double_p, c_int_p, C.c_int]),
+]
+
+_LIB = None
+
+
+def build():
+    """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "csrc")])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "liborcdchomp_amd.so is missing: run __graft_entry__.build() "
+                "(or `make -C or_cdchomp_amd/csrc`); there is no fallback path")
+        L = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB

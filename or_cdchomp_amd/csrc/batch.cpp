@@ -1,0 +1,583 @@
+// batch.cpp -- a batch of independent CHOMP runs on one GPU.
+// Host side of struct run / cd_chomp (src/orcdchomp_mod.cpp:887-966, 2104-2674;
+// src/libcd/chomp.h:38-101): builds the device model, keeps the per-run state in
+// HBM (run-major), plans the hmc resamples, launches the fused kernel.
+#include "module.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <stdexcept>
+
+// launch wrappers implemented in chomp_kernel.hip
+size_t orc_chomp_lds_bytes(int n_points, int n, int Sa, int nj, int tile_m, size_t real_size);
+hipError_t orc_launch_iterate_f64(const DevBatch<double> & b, size_t lds, hipStream_t stream);
+hipError_t orc_launch_iterate_f32(const DevBatch<float> & b, size_t lds, hipStream_t stream);
+hipError_t orc_launch_seed_f64(double * traj, const double * starts, const double * goals,
+   int n_runs, int n_points, int n, int floating, hipStream_t stream);
+hipError_t orc_launch_seed_f32(float * traj, const double * starts, const double * goals,
+   int n_runs, int n_points, int n, int floating, hipStream_t stream);
+
+namespace orc {
+
+namespace {
+
+template <typename T>
+T * dev_alloc(size_t count)
+{
+   T * p = nullptr;
+   hip_check(hipMalloc((void **) &p, (count ? count : 1) * sizeof(T)), "hipMalloc");
+   return p;
+}
+
+template <typename real>
+real * upload(const std::vector<double> & v, hipStream_t s)
+{
+   std::vector<real> tmp(v.begin(), v.end());
+   real * d = dev_alloc<real>(tmp.size());
+   hip_check(hipMemcpyAsync(d, tmp.data(), tmp.size() * sizeof(real), hipMemcpyHostToDevice, s), "upload");
+   hip_check(hipStreamSynchronize(s), "upload sync");
+   return d;
+}
+
+void dev_free(void * p) { if (p) hipFree(p); }
+
+hipError_t launch_typed(const DevBatch<double> & b, size_t lds, hipStream_t s) { return orc_launch_iterate_f64(b, lds, s); }
+hipError_t launch_typed(const DevBatch<float> & b, size_t lds, hipStream_t s) { return orc_launch_iterate_f32(b, lds, s); }
+
+} // namespace
+
+Batch::Batch(Module * mod, const Robot & robot, const BatchParams & p, int nruns,
+   const double * starts, const double * goals, const double * basegoals, const unsigned int * seeds)
+   : n_runs(nruns), params(p), mod_(mod)
+{
+   if (p.precision != 64 && p.precision != 32) throw std::runtime_error("precision must be 32 or 64!");
+   const int n_adof = (int) robot.active_dofs.size();
+   n_points = p.n_points;
+   m = n_points - 2;                                              // mod.cpp:2315
+   n = (p.floating_base ? 7 : 0) + n_adof;                        // mod.cpp:2104-2105
+   robot_name = robot.name;
+   adofindices = robot.active_dofs;
+   if (n > ORC_MAX_JOINTS + 7) throw std::runtime_error("too many optimizer dofs for this build!");
+   if (m < 1) throw std::runtime_error("n_points must be >=3!");
+
+   // joint limits (mod.cpp:2639-2660)
+   jl_lo_.assign(n, -HUGE_VAL); jl_hi_.assign(n, HUGE_VAL);
+   for (int j=0; j<n_adof; j++)
+   {
+      jl_lo_[(p.floating_base ? 7 : 0) + j] = robot.limit_lower[robot.active_dofs[j]];
+      jl_hi_[(p.floating_base ? 7 : 0) + j] = robot.limit_upper[robot.active_dofs[j]];
+   }
+
+   build_metric(m, p.derivative, 1.0/(n_points-1), metric_);       // dt: mod.cpp:2567
+
+   if (p.precision == 64) build_device<double>(robot); else build_device<float>(robot);
+
+   // endpoints of every run, then the straight-line seed on the device (mod.cpp:2417-2464)
+   std::vector<double> s((size_t) n_runs * n), g((size_t) n_runs * n);
+   for (int k=0; k<n_runs; k++)
+   {
+      double * sk = &s[(size_t) k*n]; double * gk = &g[(size_t) k*n];
+      int c0 = 0;
+      if (p.floating_base)
+      {
+         for (int j=0; j<7; j++) { sk[j] = robot.transform.v[j]; gk[j] = basegoals[(size_t) k*7+j]; }
+         c0 = 7;
+      }
+      for (int j=0; j<n_adof; j++)
+      {
+         sk[c0+j] = starts ? starts[(size_t) k*n_adof+j] : robot.dof_values[robot.active_dofs[j]];
+         gk[c0+j] = goals[(size_t) k*n_adof+j];
+      }
+   }
+   hipStream_t st = mod_->stream;
+   double * d_s = dev_alloc<double>(s.size());
+   double * d_g = dev_alloc<double>(g.size());
+   hip_check(hipMemcpyAsync(d_s, s.data(), s.size()*sizeof(double), hipMemcpyHostToDevice, st), "starts");
+   hip_check(hipMemcpyAsync(d_g, g.data(), g.size()*sizeof(double), hipMemcpyHostToDevice, st), "goals");
+   const size_t tcount = (size_t) n_runs * n_points * n, mcount = (size_t) n_runs * m * n;
+   if (p.precision == 64)
+   {
+      d_traj_ = dev_alloc<double>(tcount); d_AG_ = dev_alloc<double>(mcount); d_G_ = dev_alloc<double>(mcount);
+      hip_check(hipMemsetAsync(d_AG_, 0, mcount*sizeof(double), st), "memset");       // zero momentum, chomp.c:114-115
+      hip_check(hipMemsetAsync(d_G_, 0, mcount*sizeof(double), st), "memset");
+      hip_check(orc_launch_seed_f64((double *) d_traj_, d_s, d_g, n_runs, n_points, n, p.floating_base, st), "seed");
+   }
+   else
+   {
+      d_traj_ = dev_alloc<float>(tcount); d_AG_ = dev_alloc<float>(mcount); d_G_ = dev_alloc<float>(mcount);
+      hip_check(hipMemsetAsync(d_AG_, 0, mcount*sizeof(float), st), "memset");
+      hip_check(hipMemsetAsync(d_G_, 0, mcount*sizeof(float), st), "memset");
+      hip_check(orc_launch_seed_f32((float *) d_traj_, d_s, d_g, n_runs, n_points, n, p.floating_base, st), "seed");
+   }
+   d_costs_ = dev_alloc<double>((size_t) n_runs * 3);
+   d_status_ = dev_alloc<int>(n_runs);
+   d_leap_ = dev_alloc<int>(n_runs);
+   hip_check(hipMemsetAsync(d_costs_, 0, (size_t) n_runs*3*sizeof(double), st), "memset");
+   hip_check(hipMemsetAsync(d_status_, 0, n_runs*sizeof(int), st), "memset");
+   {
+      std::vector<int> ones(n_runs, 1);                              // leapfrog_first = 1, chomp.c:80
+      hip_check(hipMemcpyAsync(d_leap_, ones.data(), n_runs*sizeof(int), hipMemcpyHostToDevice, st), "leap");
+      hip_check(hipStreamSynchronize(st), "sync");
+   }
+   hipFree(d_s); hipFree(d_g);
+
+   // hmc state (mod.cpp:2303-2304, 2634-2635)
+   rng_.resize(p.use_hmc ? n_runs : 0);
+   for (int k=0; k<(int) rng_.size(); k++) rng_[k].set(seeds ? seeds[k] : 0);
+   hmc_resample_iter_.assign(n_runs, 0);
+}
+
+Batch::~Batch()
+{
+   hipStreamSynchronize(mod_->stream);
+   dev_free(d_model_); dev_free(d_sdfs_); dev_free(d_traj_); dev_free(d_AG_); dev_free(d_G_);
+   dev_free(d_costs_); dev_free(d_trace_); dev_free(d_status_); dev_free(d_leap_);
+   dev_free(d_Aband_); dev_free(d_beta_s_); dev_free(d_beta_g_); dev_free(d_pcr_); dev_free(d_Ainv_);
+   dev_free(d_jl_lo_); dev_free(d_jl_hi_); dev_free(d_hmc_iters_); dev_free(d_noise_);
+}
+
+// Fold the robot into the device model: only optimized joints remain, every other
+// joint is frozen at its current value inside the fixed transforms; active spheres are
+// sorted by the joint they ride on (SURVEY 8a T2 for the active/inactive split).
+template <typename real>
+void Batch::build_device(const Robot & robot)
+{
+   const int n_adof = (int) robot.active_dofs.size();
+   const int col0 = params.floating_base ? 7 : 0;
+   std::vector<Xform> frames;
+   robot.fk(robot.transform, robot.dof_values, frames);
+
+   // optimized joints = links whose joint moves with an active dof
+   std::vector<int> jlink;                 // link of optimized joint k
+   std::vector<int> jcol;
+   std::vector<int> link2joint(robot.n_links, -1);
+   for (int li=0; li<robot.n_links; li++)
+   {
+      if (robot.joint_type[li] == 0) continue;
+      for (int j=0; j<n_adof; j++)
+         if (robot.active_dofs[j] == robot.dof_index[li])
+         {
+            for (int lk : jlink)
+               if (robot.dof_index[lk] == robot.dof_index[li])
+                  throw std::runtime_error("two joints share one active dof (mimic joints are not supported)!");
+            link2joint[li] = (int) jlink.size();
+            jlink.push_back(li); jcol.push_back(col0 + j);
+         }
+   }
+   const int nj = (int) jlink.size();
+   if (nj > ORC_MAX_JOINTS) throw std::runtime_error("too many active joints for this build!");
+   // nearest optimized-joint ancestor-or-self of a link (-1: rigid with the base)
+   auto attach_of = [&](int link) -> int {
+      for (int li=link; li>=0; li=robot.parent[li]) if (link2joint[li] >= 0) return link2joint[li];
+      return -1;
+   };
+   std::vector<int> jparent(nj);
+   for (int k=0; k<nj; k++)
+   {
+      const int pl = robot.parent[jlink[k]];
+      jparent[k] = (pl >= 0) ? attach_of(pl) : -1;
+   }
+   // depth-first order over the joint tree with save/restore slots for branch points
+   std::vector<std::vector<int>> children(nj);
+   std::vector<int> roots;
+   for (int k=0; k<nj; k++) { if (jparent[k] < 0) roots.push_back(k); else children[jparent[k]].push_back(k); }
+   std::vector<int> order, load_slot(nj, -1), save_slot(nj, -1);
+   int open_slots = 0;
+   std::function<void(int)> visit = [&](int k)
+   {
+      order.push_back(k);
+      if (children[k].size() > 1)
+      {
+         if (open_slots >= ORC_MAX_SAVE) throw std::runtime_error("kinematic tree branches too deeply for this build!");
+         save_slot[k] = open_slots++;
+      }
+      for (size_t c=0; c<children[k].size(); c++)
+      {
+         load_slot[children[k][c]] = (c == 0) ? -1 : save_slot[k];
+         visit(children[k][c]);
+      }
+      if (children[k].size() > 1) open_slots--;
+   };
+   for (int rk : roots) { load_slot[rk] = -2; visit(rk); }
+   std::vector<int> pos_in_order(nj);
+   for (int k=0; k<nj; k++) pos_in_order[order[k]] = k;
+
+   // frozen local transforms of the current configuration.  Everything that is folded
+   // into the device model is a product of link-local transforms, so no frame is ever
+   // inverted (the base rotation need not be orthonormal, e.g. the demo's 0.70711 pose)
+   auto local_premotion = [&](int li) -> Xform { return xform_from_pose(robot.pose_parent_joint[li]); };
+   auto local_moved = [&](int li) -> Xform {
+      Xform x = xform_from_pose(robot.pose_parent_joint[li]);
+      if (robot.joint_type[li] == 1)
+      {
+         Xform rot; rot.R = axis_angle(&robot.axis[3*li], robot.dof_values[robot.dof_index[li]]);
+         rot.t[0] = rot.t[1] = rot.t[2] = 0.0;
+         x = xform_mul(x, rot);
+      }
+      else if (robot.joint_type[li] == 2)
+      {
+         double aw[3];
+         mat3_vec(x.R, &robot.axis[3*li], aw);
+         for (int q=0; q<3; q++) x.t[q] += robot.dof_values[robot.dof_index[li]] * aw[q];
+      }
+      return x;
+   };
+   const Xform xbase = xform_from_pose(robot.transform);
+   // joint frame of link li (before its own motion) relative to the moved frame of link
+   // `from_link` (-1: the base frame); every joint in between is frozen
+   auto fixed_between = [&](int from_link, int li) -> Xform {
+      Xform x = local_premotion(li);
+      for (int cur=robot.parent[li]; cur!=from_link && cur>=0; cur=robot.parent[cur])
+         x = xform_mul(local_moved(cur), x);
+      return x;
+   };
+   // a point of link `li` expressed in the moved frame of link `from_link` (-1: base)
+   auto point_in = [&](int from_link, int li, const double * pin, double * pout) {
+      double pt[3] = { pin[0], pin[1], pin[2] };
+      for (int cur=li; cur!=from_link && cur>=0; cur=robot.parent[cur])
+      {
+         const Xform x = local_moved(cur);
+         double r[3];
+         mat3_vec(x.R, pt, r);
+         for (int q=0; q<3; q++) pt[q] = r[q] + x.t[q];
+      }
+      pout[0] = pt[0]; pout[1] = pt[1]; pout[2] = pt[2];
+   };
+
+   std::vector<DevModel<real>> hm(1);
+   DevModel<real> & M = hm[0];
+   std::memset(&M, 0, sizeof(M));
+   M.nj = nj; M.n = n; M.floating = params.floating_base;
+   for (int k=0; k<9; k++) M.base_R[k] = (real) xbase.R.m[k];
+   for (int k=0; k<3; k++) M.base_t[k] = (real) xbase.t[k];
+
+   // spheres: active first (device order = by joint in DFS order), then inactive
+   struct SphRef { int xml; int attach_pos; };    // attach_pos: -1 base, else position in DFS order
+   std::vector<SphRef> act, inact;
+   for (int si=0; si<(int) robot.spheres.size(); si++)
+   {
+      bool active = params.floating_base != 0;
+      for (int j=0; j<n_adof && !active; j++)
+         if (robot.does_affect(robot.active_dofs[j], robot.spheres[si].link)) active = true;
+      const int at = attach_of(robot.spheres[si].link);
+      SphRef s; s.xml = si; s.attach_pos = (at < 0) ? -1 : pos_in_order[at];
+      (active ? act : inact).push_back(s);
+   }
+   if (act.empty()) throw std::runtime_error("robot active dofs must have at least one sphere!");
+   std::stable_sort(act.begin(), act.end(), [](const SphRef & a, const SphRef & b) { return a.attach_pos < b.attach_pos; });
+   const int Sa = (int) act.size(), S = Sa + (int) inact.size();
+   if (S > ORC_MAX_SPHERES) throw std::runtime_error("too many spheres for this build!");
+   M.Sa = Sa; M.S = S;
+   int GS = 1; while (GS < Sa) GS <<= 1;
+   M.GS = GS;
+   device_sphere_order.clear();
+   M.base_sph_begin = 0; M.base_sph_end = 0;
+   for (int k=0; k<nj; k++)
+   {
+      const int jk = order[k];
+      DevJoint<real> & J = M.joints[k];
+      const int li = jlink[jk];
+      // from-frame: the moved frame of the parent optimized joint's link (or the base)
+      const Xform fix = fixed_between((jparent[jk] < 0) ? -1 : jlink[jparent[jk]], li);
+      bool ident = true;
+      for (int q=0; q<9; q++)
+      {
+         J.Rfix[q] = (real) fix.R.m[q];
+         if (fix.R.m[q] != ((q % 4 == 0) ? 1.0 : 0.0)) ident = false;
+      }
+      for (int q=0; q<3; q++) { J.tfix[q] = (real) fix.t[q]; J.axis[q] = (real) robot.axis[3*li+q]; }
+      J.rfix_identity = ident ? 1 : 0;
+      J.type = robot.joint_type[li];
+      J.col = jcol[jk];
+      J.load_slot = load_slot[jk];
+      J.save_slot = save_slot[jk];
+      J.sph_begin = 0; J.sph_end = 0;
+   }
+   for (int s=0; s<Sa; s++)
+   {
+      const Robot::Sphere & sp = robot.spheres[act[s].xml];
+      const int ap = act[s].attach_pos;
+      // position in the attach frame (frozen intermediate joints folded in)
+      double pl[3];
+      point_in((ap < 0) ? -1 : jlink[order[ap]], sp.link, sp.pos, pl);
+      for (int q=0; q<3; q++) M.sph_pos[s][q] = (real) pl[q];
+      M.sph_radius[s] = (real) sp.radius;
+      M.sph_link[s] = sp.link;
+      unsigned long long aff = 0ull;
+      if (ap >= 0) for (int jk=order[ap]; jk>=0; jk=jparent[jk]) aff |= (1ull << pos_in_order[jk]);
+      M.sph_affects[s] = aff;
+      if (ap < 0) { if (M.base_sph_end == 0) M.base_sph_begin = s; M.base_sph_end = s+1; }
+      else
+      {
+         DevJoint<real> & J = M.joints[ap];
+         if (J.sph_end == 0 && J.sph_begin == 0) J.sph_begin = s;
+         J.sph_end = s+1;
+      }
+      device_sphere_order.push_back(act[s].xml);
+   }
+   for (int s=0; s<(int) inact.size(); s++)
+   {
+      const Robot::Sphere & sp = robot.spheres[inact[s].xml];
+      const Xform & lf = frames[sp.link];
+      double pw[3];
+      mat3_vec(lf.R, sp.pos, pw);                                    // mod.cpp:2332-2345
+      for (int q=0; q<3; q++) M.sph_inactive_pos[s][q] = (real)(pw[q] + lf.t[q]);
+      M.sph_radius[Sa+s] = (real) sp.radius;
+      M.sph_link[Sa+s] = sp.link;
+      device_sphere_order.push_back(inact[s].xml);
+   }
+   nj_ = nj; Sa_ = Sa;
+
+   hipStream_t st = mod_->stream;
+   DevModel<real> * dm = dev_alloc<DevModel<real>>(1);
+   hip_check(hipMemcpyAsync(dm, &M, sizeof(M), hipMemcpyHostToDevice, st), "model");
+   hip_check(hipStreamSynchronize(st), "model sync");
+   d_model_ = dm;
+
+   // rooted fields (mod.cpp:2348-2369)
+   n_sdfs_ = (int) mod_->sdfs.size();
+   if (n_sdfs_ > ORC_MAX_SDFS) throw std::runtime_error("too many signed distance fields for this build!");
+   std::vector<DevSdf<real>> hs(n_sdfs_);
+   for (int i=0; i<n_sdfs_; i++)
+   {
+      Sdf & s = *mod_->sdfs[i];
+      const size_t nc = s.grid.ncells();
+      if (sizeof(real) == 8)
+      {
+         if (!s.d_data64)
+         {
+            s.d_data64 = dev_alloc<double>(nc);
+            hip_check(hipMemcpy(s.d_data64, s.grid.data.data(), nc*sizeof(double), hipMemcpyHostToDevice), "sdf upload");
+         }
+         hs[i].data = (const real *) s.d_data64;
+      }
+      else
+      {
+         if (!s.d_data32)
+         {
+            std::vector<float> tmp(s.grid.data.begin(), s.grid.data.end());
+            s.d_data32 = dev_alloc<float>(nc);
+            hip_check(hipMemcpy(s.d_data32, tmp.data(), nc*sizeof(float), hipMemcpyHostToDevice), "sdf upload");
+         }
+         hs[i].data = (const real *) s.d_data32;
+      }
+      const Pose pose_world_gsdf = pose_compose(mod_->body_transform(s.kinbody_name), s.pose);
+      const Pose pose_gsdf_world = pose_invert(pose_world_gsdf);
+      const Mat3 Rgw = pose_rotation_expanded(pose_gsdf_world);
+      const Mat3 Rwg = pose_rotation_expanded(pose_world_gsdf);
+      for (int q=0; q<9; q++) { hs[i].Rgw[q] = (real) Rgw.m[q]; hs[i].Rwg[q] = (real) Rwg.m[q]; }
+      for (int q=0; q<3; q++)
+      {
+         hs[i].tgw[q] = (real) pose_gsdf_world.v[q];
+         hs[i].size[q] = s.grid.sizes[q];
+         hs[i].length[q] = (real) s.grid.lengths[q];
+      }
+      hs[i].pad = 0;
+   }
+   DevSdf<real> * ds = dev_alloc<DevSdf<real>>(n_sdfs_);
+   hip_check(hipMemcpy(ds, hs.data(), hs.size()*sizeof(DevSdf<real>), hipMemcpyHostToDevice), "sdfs");
+   d_sdfs_ = ds;
+
+   // metric tables
+   d_Aband_ = upload<real>(metric_.Aband, st);
+   d_beta_s_ = upload<real>(metric_.beta_s, st);
+   d_beta_g_ = upload<real>(metric_.beta_g, st);
+   if (!metric_.pcr.empty()) d_pcr_ = upload<real>(metric_.pcr, st);
+   if (!metric_.Ainv.empty()) d_Ainv_ = upload<real>(metric_.Ainv, st);
+   d_jl_lo_ = upload<real>(jl_lo_, st);
+   d_jl_hi_ = upload<real>(jl_hi_, st);
+
+   // waypoints per tile: the largest tile that keeps two workgroups per CU,
+   // else the largest that fits one
+   const size_t budgets[2] = { 80*1024 - 512, 160*1024 - 1024 };
+   const int cands[7] = { m, 126, 94, 62, 30, 14, 6 };
+   tile_m_ = 0;
+   for (int bi=0; bi<2 && !tile_m_; bi++)
+      for (int ci=0; ci<7 && !tile_m_; ci++)
+      {
+         const int t = cands[ci];
+         if (t > m || t > ORC_BLOCK - 2 || t < 1) continue;
+         const size_t need = orc_chomp_lds_bytes(n_points, n, Sa, nj, t, sizeof(real));
+         if (need <= budgets[bi]) { tile_m_ = t; lds_bytes_ = need; }
+      }
+   if (!tile_m_)
+   {
+      tile_m_ = 1;
+      lds_bytes_ = orc_chomp_lds_bytes(n_points, n, Sa, nj, 1, sizeof(real));
+      if (lds_bytes_ > budgets[1]) throw std::runtime_error("run does not fit the LDS of one CU!");
+   }
+}
+
+// which iterations of this call resample the momentum, and with what noise
+// (src/orcdchomp_mod.cpp:2755-2768; r->iter restarts at 0 on every call, 2752)
+void Batch::plan_hmc(int n_iter)
+{
+   const size_t mn = (size_t) m * n;
+   std::vector<std::vector<int>> iters(n_runs);
+   std::vector<std::vector<double>> noise(n_runs);
+   int maxr = 0;
+   for (int k=0; k<n_runs; k++)
+   {
+      int used_ext = 0;
+      for (int it=0; it<n_iter; it++)
+      {
+         if (it != hmc_resample_iter_[k]) continue;
+         const double alpha = 100.0 * std::exp(0.02 * it);
+         const double sigma = 1.0 / std::sqrt(alpha);
+         const size_t off = noise[k].size();
+         noise[k].resize(off + mn);
+         for (size_t e=0; e<mn; e++) noise[k][off+e] = rng_[k].gaussian(sigma);
+         if (ext_noise_blocks_ > 0 && used_ext < ext_noise_blocks_)
+            std::memcpy(&noise[k][off], &ext_noise_[((size_t) k * ext_noise_blocks_ + used_ext) * mn], mn*sizeof(double));
+         used_ext++;
+         iters[k].push_back(it);
+         hmc_resample_iter_[k] += 1 + (int)(-std::log(rng_[k].uniform()) / params.hmc_resample_lambda);
+      }
+      maxr = std::max(maxr, (int) iters[k].size());
+   }
+   max_resamples_ = maxr;
+   if (maxr == 0) return;
+   std::vector<int> flat((size_t) n_runs * maxr, -1);
+   for (int k=0; k<n_runs; k++) for (size_t r=0; r<iters[k].size(); r++) flat[(size_t) k*maxr + r] = iters[k][r];
+   if (flat.size() > hmc_cap_iters_)
+   {
+      dev_free(d_hmc_iters_); d_hmc_iters_ = dev_alloc<int>(flat.size()); hmc_cap_iters_ = flat.size();
+   }
+   hip_check(hipMemcpyAsync(d_hmc_iters_, flat.data(), flat.size()*sizeof(int), hipMemcpyHostToDevice, mod_->stream), "hmc iters");
+   const size_t ncount = (size_t) n_runs * maxr * mn;
+   const size_t rsize = (params.precision == 64) ? 8 : 4;
+   if (ncount * rsize > noise_cap_)
+   {
+      dev_free(d_noise_); hip_check(hipMalloc(&d_noise_, ncount * rsize), "noise"); noise_cap_ = ncount * rsize;
+   }
+   if (params.precision == 64)
+   {
+      std::vector<double> buf(ncount, 0.0);
+      for (int k=0; k<n_runs; k++) std::copy(noise[k].begin(), noise[k].end(), buf.begin() + (size_t) k*maxr*mn);
+      hip_check(hipMemcpyAsync(d_noise_, buf.data(), ncount*8, hipMemcpyHostToDevice, mod_->stream), "noise");
+      hip_check(hipStreamSynchronize(mod_->stream), "noise sync");
+   }
+   else
+   {
+      std::vector<float> buf(ncount, 0.f);
+      for (int k=0; k<n_runs; k++)
+         for (size_t e=0; e<noise[k].size(); e++) buf[(size_t) k*maxr*mn + e] = (float) noise[k][e];
+      hip_check(hipMemcpyAsync(d_noise_, buf.data(), ncount*4, hipMemcpyHostToDevice, mod_->stream), "noise");
+      hip_check(hipStreamSynchronize(mod_->stream), "noise sync");
+   }
+}
+
+template <typename real>
+void Batch::launch(int n_iter)
+{
+   DevBatch<real> b;
+   std::memset(&b, 0, sizeof(b));
+   b.model = (const DevModel<real> *) d_model_;
+   b.sdfs = (const DevSdf<real> *) d_sdfs_;
+   b.n_sdfs = n_sdfs_;
+   b.n_runs = n_runs; b.n_points = n_points; b.m = m; b.n = n;
+   b.tile_m = tile_m_;
+   b.traj = (real *) d_traj_; b.AG = (real *) d_AG_; b.Gdbg = (real *) d_G_;
+   b.costs = d_costs_; b.trace = d_trace_; b.status = d_status_; b.leapfrog_first = d_leap_;
+   const double dt = 1.0/(n_points-1);
+   b.dt = (real) dt;
+   b.inv_2dt = (real)(1.0/(2.0*dt));
+   b.inv_dt2 = (real)(1.0/(dt*dt));
+   b.lambda = (real) params.lambda;
+   b.inv_m = (real)(1.0/m);
+   b.epsilon = (real) params.epsilon; b.epsilon_self = (real) params.epsilon_self;
+   b.obs_factor = (real) params.obs_factor; b.obs_factor_self = (real) params.obs_factor_self;
+   b.use_momentum = params.use_momentum; b.use_hmc = params.use_hmc && max_resamples_ > 0; b.D = params.derivative;
+   b.Aband = (const real *) d_Aband_; b.beta_s = (const real *) d_beta_s_; b.beta_g = (const real *) d_beta_g_;
+   b.kss = metric_.kss; b.ksg = metric_.ksg; b.kgg = metric_.kgg;
+   b.solve_mode = (params.derivative == 1) ? 0 : 1;
+   b.pcr_levels = metric_.pcr_levels;
+   b.pcr = (const real *) d_pcr_; b.Ainv = (const real *) d_Ainv_;
+   b.jl_lo = (const real *) d_jl_lo_; b.jl_hi = (const real *) d_jl_hi_;
+   b.hmc_iters = d_hmc_iters_; b.noise = (const real *) d_noise_; b.max_resamples = max_resamples_;
+   b.n_iter = n_iter; b.final_eval = 1;
+   mod_->time_begin();
+   hipError_t e = launch_typed(b, lds_bytes_, mod_->stream);
+   hip_check(e, "chomp_iterate_kernel launch");
+   mod_->time_end();
+}
+
+void Batch::iterate_async(int n_iter)
+{
+   if (n_iter < 0) throw std::runtime_error("n_iter must be >=0!");
+   last_n_iter = n_iter;
+   const size_t tneed = (size_t) n_runs * (n_iter ? n_iter : 1) * 3;
+   if (tneed > trace_cap_)
+   {
+      hip_check(hipStreamSynchronize(mod_->stream), "sync");
+      dev_free(d_trace_); d_trace_ = dev_alloc<double>(tneed); trace_cap_ = tneed;
+   }
+   max_resamples_ = 0;
+   if (params.use_hmc) plan_hmc(n_iter);
+   if (params.precision == 64) launch<double>(n_iter); else launch<float>(n_iter);
+}
+
+void Batch::sync(double * costs_out, int * status_out)
+{
+   hipStream_t st = mod_->stream;
+   if (costs_out) hip_check(hipMemcpyAsync(costs_out, d_costs_, (size_t) n_runs*3*sizeof(double), hipMemcpyDeviceToHost, st), "costs");
+   if (status_out) hip_check(hipMemcpyAsync(status_out, d_status_, n_runs*sizeof(int), hipMemcpyDeviceToHost, st), "status");
+   hip_check(hipStreamSynchronize(st), "hipStreamSynchronize");
+   mod_->time_collect();
+}
+
+namespace {
+void download(void * d, size_t count, int precision, double * out, hipStream_t st)
+{
+   if (precision == 64)
+   {
+      hip_check(hipMemcpyAsync(out, d, count*sizeof(double), hipMemcpyDeviceToHost, st), "download");
+      hip_check(hipStreamSynchronize(st), "sync");
+   }
+   else
+   {
+      std::vector<float> tmp(count);
+      hip_check(hipMemcpyAsync(tmp.data(), d, count*sizeof(float), hipMemcpyDeviceToHost, st), "download");
+      hip_check(hipStreamSynchronize(st), "sync");
+      for (size_t i=0; i<count; i++) out[i] = tmp[i];
+   }
+}
+}
+
+void Batch::gettraj(double * out)
+{
+   download(d_traj_, (size_t) n_runs * n_points * n, params.precision, out, mod_->stream);
+}
+
+void Batch::get_state(const std::string & which, double * out)
+{
+   const size_t mcount = (size_t) n_runs * m * n;
+   if (which == "G") download(d_G_, mcount, params.precision, out, mod_->stream);
+   else if (which == "AG") download(d_AG_, mcount, params.precision, out, mod_->stream);
+   else if (which == "T")
+   {
+      std::vector<double> full((size_t) n_runs * n_points * n);
+      gettraj(full.data());
+      for (int k=0; k<n_runs; k++)
+         std::memcpy(out + (size_t) k*m*n, &full[((size_t) k*n_points + 1)*n], (size_t) m*n*sizeof(double));
+   }
+   else throw std::runtime_error("unknown state name");
+}
+
+void Batch::get_trace(double * out)
+{
+   hip_check(hipMemcpyAsync(out, d_trace_, (size_t) n_runs * last_n_iter * 3 * sizeof(double), hipMemcpyDeviceToHost, mod_->stream), "trace");
+   hip_check(hipStreamSynchronize(mod_->stream), "sync");
+}
+
+void Batch::set_noise(const double * noise, int n_blocks)
+{
+   ext_noise_blocks_ = n_blocks;
+   ext_noise_.assign(noise, noise + (size_t) n_runs * n_blocks * m * n);
+}
+
+template void Batch::build_device<double>(const Robot &);
+template void Batch::build_device<float>(const Robot &);
+
+} // namespace orc

@@ -1,0 +1,298 @@
+// capi.cpp -- the extern "C" boundary declared in include/orcdchomp_amd.h.
+#include "../../include/orcdchomp_amd.h"
+#include "module.h"
+#include <cstring>
+#include <new>
+#include <stdexcept>
+
+struct orc_module
+{
+   orc::Module * impl;
+   std::string last_error;
+};
+
+namespace {
+std::string g_new_error;
+
+template <typename F>
+int guarded(orc_module * mod, F f)
+{
+   if (!mod) return 2;
+   try { f(); mod->last_error.clear(); return 0; }
+   catch (const std::exception & e) { mod->last_error = e.what(); return 1; }
+   catch (...) { mod->last_error = "unknown error"; return 1; }
+}
+}
+
+extern "C" {
+
+orc_module * orc_module_new(int device)
+{
+   try
+   {
+      orc_module * m = new orc_module;
+      m->impl = new orc::Module(device);
+      return m;
+   }
+   catch (const std::exception & e) { g_new_error = e.what(); return nullptr; }
+}
+
+void orc_module_free(orc_module * mod)
+{
+   if (!mod) return;
+   delete mod->impl;
+   delete mod;
+}
+
+const char * orc_last_error(const orc_module * mod)
+{
+   if (!mod) return g_new_error.c_str();
+   return mod->last_error.c_str();
+}
+
+int orc_set_stream(orc_module * mod, void * hip_stream)
+{
+   return guarded(mod, [&] { mod->impl->stream = (hipStream_t) hip_stream; });
+}
+
+int orc_send_command(orc_module * mod, const char * cmd, char * out, size_t out_cap)
+{
+   return guarded(mod, [&] {
+      mod->impl->last_reply = mod->impl->send_command(cmd ? cmd : "");
+      if (out && out_cap)
+      {
+         const size_t k = std::min(out_cap - 1, mod->impl->last_reply.size());
+         std::memcpy(out, mod->impl->last_reply.data(), k);
+         out[k] = 0;
+      }
+   });
+}
+
+size_t orc_last_reply_size(const orc_module * mod) { return mod ? mod->impl->last_reply.size() : 0; }
+
+int orc_last_reply(const orc_module * mod, char * out, size_t out_cap)
+{
+   if (!mod || !out || !out_cap) return 2;
+   const size_t k = std::min(out_cap - 1, mod->impl->last_reply.size());
+   std::memcpy(out, mod->impl->last_reply.data(), k);
+   out[k] = 0;
+   return 0;
+}
+
+int orc_env_add_robot(orc_module * mod, const char * name, const orc_robot_desc * d)
+{
+   return guarded(mod, [&] {
+      orc::Robot r;
+      r.name = name;
+      r.n_links = d->n_links;
+      r.parent.assign(d->parent, d->parent + d->n_links);
+      for (int i=0; i<d->n_links; i++)
+      {
+         if (r.parent[i] >= i) throw std::runtime_error("links must be in topological order!");
+         r.pose_parent_joint.push_back(orc::Pose(d->pose_parent_joint + 7*i));
+      }
+      r.joint_type.assign(d->joint_type, d->joint_type + d->n_links);
+      r.axis.assign(d->axis, d->axis + 3*d->n_links);
+      r.dof_index.assign(d->dof_index, d->dof_index + d->n_links);
+      r.n_dof = d->n_dof;
+      r.limit_lower.assign(d->limit_lower, d->limit_lower + d->n_dof);
+      r.limit_upper.assign(d->limit_upper, d->limit_upper + d->n_dof);
+      for (int s=0; s<d->n_spheres; s++)
+      {
+         orc::Robot::Sphere sp;
+         sp.link = d->sphere_link[s];
+         if (sp.link < 0 || sp.link >= d->n_links) throw std::runtime_error("link in <orcdchomp> does not exist.");
+         for (int k=0; k<3; k++) sp.pos[k] = d->sphere_pos[3*s+k];
+         sp.radius = d->sphere_radius[s];
+         r.spheres.push_back(sp);
+      }
+      r.dof_values.assign(d->n_dof, 0.0);
+      for (int i=0; i<d->n_dof; i++) r.active_dofs.push_back(i);
+      mod->impl->add_robot(r);
+   });
+}
+
+int orc_robot_set_transform(orc_module * mod, const char * name, const double pose[7])
+{
+   return guarded(mod, [&] { mod->impl->robot(name).transform = orc::Pose(pose); });
+}
+
+int orc_robot_set_dof_values(orc_module * mod, const char * name, const double * values, int n)
+{
+   return guarded(mod, [&] {
+      orc::Robot & r = mod->impl->robot(name);
+      if (n != r.n_dof) throw std::runtime_error("wrong number of dof values!");
+      r.dof_values.assign(values, values + n);
+   });
+}
+
+int orc_robot_set_active_dofs(orc_module * mod, const char * name, const int * indices, int n)
+{
+   return guarded(mod, [&] {
+      orc::Robot & r = mod->impl->robot(name);
+      for (int i=0; i<n; i++) if (indices[i] < 0 || indices[i] >= r.n_dof) throw std::runtime_error("bad dof index!");
+      r.active_dofs.assign(indices, indices + n);
+   });
+}
+
+int orc_env_add_kinbody_boxes(orc_module * mod, const char * name, int n_boxes, const double * box_poses, const double * half_extents)
+{
+   return guarded(mod, [&] {
+      orc::KinBody k;
+      k.name = name;
+      for (int i=0; i<n_boxes; i++)
+      {
+         orc::KinBody::B b;
+         b.pose = orc::Pose(box_poses + 7*i);
+         for (int q=0; q<3; q++) b.half[q] = half_extents[3*i+q];
+         k.boxes.push_back(b);
+      }
+      mod->impl->add_kinbody(k);
+   });
+}
+
+int orc_kinbody_set_transform(orc_module * mod, const char * name, const double pose[7])
+{
+   return guarded(mod, [&] { mod->impl->kinbody(name).transform = orc::Pose(pose); });
+}
+
+int orc_kinbody_enable(orc_module * mod, const char * name, int enabled)
+{
+   return guarded(mod, [&] { mod->impl->kinbody(name).enabled = enabled != 0; });
+}
+
+int orc_scene_add_sdf(orc_module * mod, const char * kinbody, const int sizes[3], const double lengths[3],
+   const double pose[7], const double * data)
+{
+   return guarded(mod, [&] {
+      if (!mod->impl->has_body(kinbody)) throw std::runtime_error("Could not find kinbody with that name!");
+      orc::Grid g;
+      for (int i=0; i<3; i++) { g.sizes[i] = sizes[i]; g.lengths[i] = lengths[i]; }
+      g.data.assign(data, data + g.ncells());
+      mod->impl->add_sdf(kinbody, g, orc::Pose(pose));
+   });
+}
+
+int orc_scene_get_sdf(orc_module * mod, const char * kinbody, int sizes[3], double lengths[3], double pose[7],
+   double * data, size_t data_cap)
+{
+   return guarded(mod, [&] {
+      orc::Sdf * s = mod->impl->find_sdf(kinbody);
+      if (!s) throw std::runtime_error("No sdf for that kinbody!");
+      for (int i=0; i<3; i++) { sizes[i] = s->grid.sizes[i]; lengths[i] = s->grid.lengths[i]; }
+      for (int i=0; i<7; i++) pose[i] = s->pose.v[i];
+      if (data)
+      {
+         if (data_cap < s->grid.ncells()) throw std::runtime_error("buffer too small!");
+         std::memcpy(data, s->grid.data.data(), s->grid.ncells() * sizeof(double));
+      }
+   });
+}
+
+void orc_batch_params_default(orc_batch_params * p)
+{
+   orc::BatchParams d;
+   p->n_points = d.n_points; p->floating_base = d.floating_base; p->lambda = d.lambda;
+   p->derivative = d.derivative; p->use_momentum = d.use_momentum; p->use_hmc = d.use_hmc;
+   p->hmc_resample_lambda = d.hmc_resample_lambda; p->epsilon = d.epsilon; p->epsilon_self = d.epsilon_self;
+   p->obs_factor = d.obs_factor; p->obs_factor_self = d.obs_factor_self; p->precision = d.precision;
+}
+
+int orc_batch_create(orc_module * mod, const char * robot, const orc_batch_params * p, int n_runs,
+   const double * starts, const double * goals, const double * basegoals, const unsigned int * seeds, int * batch_id)
+{
+   return guarded(mod, [&] {
+      orc::BatchParams q;
+      q.n_points = p->n_points; q.floating_base = p->floating_base; q.lambda = p->lambda;
+      q.derivative = p->derivative; q.use_momentum = p->use_momentum; q.use_hmc = p->use_hmc;
+      q.hmc_resample_lambda = p->hmc_resample_lambda; q.epsilon = p->epsilon; q.epsilon_self = p->epsilon_self;
+      q.obs_factor = p->obs_factor; q.obs_factor_self = p->obs_factor_self; q.precision = p->precision;
+      // the same validation the create command performs (mod.cpp:2091-2097)
+      if (!goals) throw std::runtime_error("Did not pass either adofgoal or starttraj!");
+      if (q.floating_base && !basegoals) throw std::runtime_error("Passed floating_base with no basegoal!");
+      if (!q.floating_base && basegoals) throw std::runtime_error("Passed basegoal with no floating_base!");
+      if (mod->impl->sdfs.empty()) throw std::runtime_error("No signed distance fields have yet been computed!");
+      if (q.lambda < 0.01) throw std::runtime_error("lambda must be >=0.01!");
+      if (q.n_points < 3) throw std::runtime_error("n_points must be >=3!");
+      if (n_runs < 1) throw std::runtime_error("n_runs must be >=1!");
+      *batch_id = mod->impl->create_batch(robot, q, n_runs, starts, goals, basegoals, seeds);
+   });
+}
+
+int orc_batch_iterate(orc_module * mod, int id, int n_iter, double * costs_out, int * status_out)
+{
+   return guarded(mod, [&] {
+      orc::Batch & b = mod->impl->batch(id);
+      b.iterate_async(n_iter);
+      b.sync(costs_out, status_out);
+   });
+}
+
+int orc_batch_iterate_async(orc_module * mod, int id, int n_iter)
+{
+   return guarded(mod, [&] { mod->impl->batch(id).iterate_async(n_iter); });
+}
+
+int orc_batch_sync(orc_module * mod, int id, double * costs_out, int * status_out)
+{
+   return guarded(mod, [&] { mod->impl->batch(id).sync(costs_out, status_out); });
+}
+
+int orc_batch_get_trace(orc_module * mod, int id, double * out, size_t cap)
+{
+   return guarded(mod, [&] {
+      orc::Batch & b = mod->impl->batch(id);
+      if (cap < (size_t) b.n_runs * b.last_n_iter * 3) throw std::runtime_error("buffer too small!");
+      b.get_trace(out);
+   });
+}
+
+int orc_batch_set_noise(orc_module * mod, int id, const double * noise, int n_blocks)
+{
+   return guarded(mod, [&] { mod->impl->batch(id).set_noise(noise, n_blocks); });
+}
+
+int orc_batch_gettraj(orc_module * mod, int id, double * out, size_t cap)
+{
+   return guarded(mod, [&] {
+      orc::Batch & b = mod->impl->batch(id);
+      if (cap < (size_t) b.n_runs * b.n_points * b.n) throw std::runtime_error("buffer too small!");
+      b.gettraj(out);
+   });
+}
+
+int orc_batch_get_state(orc_module * mod, int id, const char * which, double * out, size_t cap)
+{
+   return guarded(mod, [&] {
+      orc::Batch & b = mod->impl->batch(id);
+      if (cap < (size_t) b.n_runs * b.m * b.n) throw std::runtime_error("buffer too small!");
+      b.get_state(which, out);
+   });
+}
+
+int orc_batch_dims(orc_module * mod, int id, int * n_runs, int * n_points, int * n)
+{
+   return guarded(mod, [&] {
+      orc::Batch & b = mod->impl->batch(id);
+      if (n_runs) *n_runs = b.n_runs;
+      if (n_points) *n_points = b.n_points;
+      if (n) *n = b.n;
+   });
+}
+
+int orc_batch_destroy(orc_module * mod, int id)
+{
+   return guarded(mod, [&] { mod->impl->destroy_batch(id); });
+}
+
+int orc_kernel_time(orc_module * mod, double * total_ms, int * launches, int reset)
+{
+   return guarded(mod, [&] {
+      mod->impl->time_collect();
+      if (total_ms) *total_ms = mod->impl->kernel_ms_total;
+      if (launches) *launches = mod->impl->kernel_launches;
+      if (reset) { mod->impl->kernel_ms_total = 0.0; mod->impl->kernel_launches = 0; }
+   });
+}
+
+} // extern "C"

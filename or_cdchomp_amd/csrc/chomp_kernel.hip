@@ -1,0 +1,808 @@
+// chomp_kernel.hip -- the CHOMP iteration as one fused gfx950 kernel.
+//
+// One workgroup (256 threads = 4 wavefronts) owns one run for all n_iter
+// iterations of a launch.  The trajectory, gradient and momentum of the run stay
+// in LDS for the whole launch; HBM is touched for the trajectory/momentum at
+// launch start and end, for the SDF gathers, and for three cost doubles.
+//
+// Per iteration (reference call stack: SURVEY.md 3.3):
+//   tiles of waypoints {
+//     FK phase    lane = waypoint        sphere_cost_pre   src/orcdchomp_mod.cpp:988-1093
+//     cost phase  lane = (waypoint,sphere) sphere_cost     src/orcdchomp_mod.cpp:1134-1327
+//                 J^T contraction + reduce over the spheres of a waypoint -> G row
+//   }
+//   update phase  lane = (waypoint,dof)  cd_chomp_iterate  src/libcd/chomp.c:490-677
+//                 G/m + A T + B, A^-1 G by parallel cyclic reduction, T -= AG/lambda,
+//                 joint-limit projection loop, smoothness cost
+//
+// Differences from the reference that are deliberate (all inside the stated
+// tolerance): the dense m x m products are replaced by the band
+// of A and a cyclic-reduction solve; the per-sphere 3 x n Jacobians are never
+// formed (J^T x is evaluated as axis . ((p - anchor) x force)); the reaction of
+// a self-collision pair on the other sphere is evaluated in that sphere's lane.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "dev_types.h"
+
+namespace {
+
+template <typename real> struct M;
+template <> struct M<double>
+{
+   static __device__ __forceinline__ double sqrt_(double x) { return ::sqrt(x); }
+   static __device__ __forceinline__ double floor_(double x) { return ::floor(x); }
+   static __device__ __forceinline__ double fabs_(double x) { return ::fabs(x); }
+   static __device__ __forceinline__ void sincos_(double x, double * s, double * c) { ::sincos(x, s, c); }
+   static __device__ __forceinline__ double inf() { return __longlong_as_double(0x7ff0000000000000LL); }
+};
+template <> struct M<float>
+{
+   static __device__ __forceinline__ float sqrt_(float x) { return ::sqrtf(x); }
+   static __device__ __forceinline__ float floor_(float x) { return ::floorf(x); }
+   static __device__ __forceinline__ float fabs_(float x) { return ::fabsf(x); }
+   static __device__ __forceinline__ void sincos_(float x, float * s, float * c) { ::sincosf(x, s, c); }
+   static __device__ __forceinline__ float inf() { return __int_as_float(0x7f800000); }
+};
+
+template <typename real>
+struct Frame { real R[9]; real t[3]; };
+
+// out = A * B (3x3 row major)
+template <typename real>
+__device__ __forceinline__ void mat3_mul(const real * A, const real * B, real * C)
+{
+#pragma unroll
+   for (int i=0; i<3; i++)
+#pragma unroll
+      for (int j=0; j<3; j++)
+         C[i*3+j] = A[i*3+0]*B[0*3+j] + A[i*3+1]*B[1*3+j] + A[i*3+2]*B[2*3+j];
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+   for (int o=32; o>0; o>>=1) v += __shfl_xor(v, o, 64);
+   return v;
+}
+
+// sum over the whole workgroup; every thread receives the result.
+__device__ __forceinline__ double block_sum(double v, double * red)
+{
+   v = wave_sum(v);
+   __syncthreads();
+   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+   __syncthreads();
+   return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// ---------------------------------------------------------------------------
+// SDF lookup: cd_grid_lookup_index + cd_grid_double_interp + cd_grid_double_grad
+// fused (they read the same four cells).  src/libcd/grid.c:191-209, 331-454.
+// returns 0 and value/grad, or 1 when p is outside the field.
+template <typename real>
+__device__ __forceinline__ int sdf_lookup(const DevSdf<real> & f, const real p[3], real & value, real grad[3])
+{
+   int sub[3];
+#pragma unroll
+   for (int d=0; d<3; d++)
+   {
+      real x = p[d] / f.length[d];
+      if (x < (real)0) return 1;
+      if (x > (real)1) return 1;
+      int s = (int) M<real>::floor_(x * (real) f.size[d]);
+      if (s == f.size[d]) s--;
+      sub[d] = s;
+   }
+   const long stride[3] = { (long) f.size[1] * f.size[2], (long) f.size[2], 1 };
+   const long index = sub[0]*stride[0] + sub[1]*stride[1] + sub[2];
+   const real v0 = f.data[index];
+   real va[3], vb[3], center[3];
+#pragma unroll
+   for (int d=0; d<3; d++)
+   {
+      center[d] = ((real)0.5 + (real) sub[d]) / (real) f.size[d] * f.length[d];
+      bool prev;
+      if (sub[d] == 0) prev = false;
+      else if (sub[d] == f.size[d]-1) prev = true;
+      else prev = (p[d] < center[d]);
+      const real vn = f.data[prev ? index - stride[d] : index + stride[d]];
+      va[d] = prev ? v0 : vn;      // "after"
+      vb[d] = prev ? vn : v0;      // "before"
+   }
+   const real inf = M<real>::inf();
+   real v = v0;
+   bool poisoned = (v0 == inf);
+   // the reference walks the axes last to first (z, y, x)
+#pragma unroll
+   for (int d=2; d>=0; d--)
+   {
+      if (va[d] == inf || vb[d] == inf) poisoned = true;
+      real diff = va[d];
+      diff -= vb[d];
+      const real slope = diff * (real) f.size[d] / f.length[d];
+      grad[d] = slope;
+      v += slope * (p[d] - center[d]);
+   }
+   value = poisoned ? inf : v;
+   return 0;
+}
+
+// ---------------------------------------------------------------------------
+// parallel cyclic reduction with precomputed multipliers: x = A^-1 d for all n
+// columns at once.  src holds d [m][n]; the result ends up in the returned
+// buffer (src or tmp).  Coefficients: pcr[l][0][i] (towards i-s), pcr[l][1][i]
+// (towards i+s), then the inverse of the reduced diagonal.
+template <typename real>
+__device__ __forceinline__ real * pcr_solve(const DevBatch<real> & b, real * src, real * tmp)
+{
+   const int m = b.m, n = b.n, mn = m*n;
+   real * cur = src;
+   real * nxt = tmp;
+   int stride = 1;
+   for (int l=0; l<b.pcr_levels; l++)
+   {
+      const real * ka = b.pcr + (size_t)(2*l) * m;
+      const real * kc = ka + m;
+      for (int e=threadIdx.x; e<mn; e+=ORC_BLOCK)
+      {
+         const int i = e / n;
+         real d = cur[e];
+         if (i - stride >= 0) d += ka[i] * cur[e - stride*n];
+         if (i + stride < m)  d += kc[i] * cur[e + stride*n];
+         nxt[e] = d;
+      }
+      __syncthreads();
+      real * t = cur; cur = nxt; nxt = t;
+      stride <<= 1;
+   }
+   const real * invb = b.pcr + (size_t)(2*b.pcr_levels) * m;
+   for (int e=threadIdx.x; e<mn; e+=ORC_BLOCK)
+      cur[e] *= invb[e / n];
+   __syncthreads();
+   return cur;
+}
+
+// dense fallback (derivative D >= 2): x = Ainv d
+template <typename real>
+__device__ __forceinline__ real * dense_solve(const DevBatch<real> & b, real * src, real * tmp)
+{
+   const int m = b.m, n = b.n, mn = m*n;
+   for (int e=threadIdx.x; e<mn; e+=ORC_BLOCK)
+   {
+      const int i = e / n, c = e - i*n;
+      real s = (real)0;
+      for (int k=0; k<m; k++) s += b.Ainv[(size_t) i*m + k] * src[k*n + c];
+      tmp[e] = s;
+   }
+   __syncthreads();
+   return tmp;
+}
+
+template <typename real>
+__device__ __forceinline__ real * metric_solve(const DevBatch<real> & b, real * src, real * tmp)
+{
+   return b.solve_mode == 0 ? pcr_solve(b, src, tmp) : dense_solve(b, src, tmp);
+}
+
+// (A T + B)[i][c] from the band of A and the endpoint couplings of B.
+// T_s holds all n_points rows (row 0 = start, row n_points-1 = goal).
+template <typename real>
+__device__ __forceinline__ real smooth_grad(const DevBatch<real> & b, const real * T_s, int i, int c)
+{
+   const int m = b.m, n = b.n, D = b.D;
+   real s = b.beta_s[i] * T_s[c] + b.beta_g[i] * T_s[(b.n_points-1)*n + c];
+   for (int k=-D; k<=D; k++)
+   {
+      const int r = i + k;
+      if (r < 0 || r >= m) continue;
+      s += b.Aband[(size_t)(k+D) * m + i] * T_s[(r+1)*n + c];
+   }
+   return s;
+}
+
+// ---------------------------------------------------------------------------
+template <typename real>
+__global__ __launch_bounds__(ORC_BLOCK, 2)
+void chomp_iterate_kernel(const DevBatch<real> b)
+{
+   extern __shared__ __align__(16) unsigned char smem_raw[];
+   const DevModel<real> & mod = *b.model;
+   const int run = blockIdx.x;
+   const int tid = threadIdx.x;
+   const int n = b.n, m = b.m, np = b.n_points, mn = m*n;
+   const int nj = mod.nj, Sa = mod.Sa, S = mod.S, GS = mod.GS;
+   const int tile_m = b.tile_m;
+   const real inf = M<real>::inf();
+
+   // ---- LDS carve-up ------------------------------------------------------
+   double * red = (double *) smem_raw;                  // [8] reduction scratch
+   int * redi = (int *)(red + 8);                       // [8]
+   real * T_s  = (real *)(smem_raw + 128);              // [np][n]
+   real * G_s  = T_s + ((np*n + 3) & ~3);               // [m][n]
+   real * W_s  = G_s + ((mn + 3) & ~3);                 // [m][n] work
+   real * AG_s = W_s + ((mn + 3) & ~3);                 // [m][n]
+   real * pos_s = AG_s + ((mn + 3) & ~3);               // [tile_m+2][Sa][3]
+   real * ax_s = pos_s + (((tile_m+2)*Sa*3 + 3) & ~3);  // [tile_m+2][nj][6]
+
+   real * traj_g = b.traj + (size_t) run * np * n;
+   real * AG_g = b.AG + (size_t) run * mn;
+
+   for (int e=tid; e<np*n; e+=ORC_BLOCK) T_s[e] = traj_g[e];
+   for (int e=tid; e<mn; e+=ORC_BLOCK) AG_s[e] = AG_g[e];
+   int leapfrog_first = b.leapfrog_first[run];
+   int status = b.status[run];
+   int next_resample = 0;      // index into this call's resample list
+   __syncthreads();
+
+   double cost_obs = 0.0, cost_smooth = 0.0;
+   const int total_passes = b.n_iter + (b.final_eval ? 1 : 0);
+
+   for (int it=0; it<total_passes; it++)
+   {
+      const bool do_iteration = (it < b.n_iter);
+      if (status != 0) break;
+
+      // ---- hmc momentum resample (src/orcdchomp_mod.cpp:2755-2768) ----------
+      if (do_iteration && b.use_hmc && next_resample < b.max_resamples
+          && b.hmc_iters[(size_t) run * b.max_resamples + next_resample] == it)
+      {
+         const real * nz = b.noise + ((size_t) run * b.max_resamples + next_resample) * mn;
+         for (int e=tid; e<mn; e+=ORC_BLOCK) AG_s[e] = nz[e];
+         leapfrog_first = 1;
+         next_resample++;
+         __syncthreads();
+      }
+
+      double cost_lane = 0.0;
+
+      for (int ts=0; ts<m; ts+=tile_m)
+      {
+         const int te = (ts + tile_m < m) ? ts + tile_m : m;
+         const int nfk = te - ts + 2;          // waypoints ts .. te+1 (global index)
+
+         // ================= FK phase: lane = waypoint =========================
+         if (tid < nfk)
+         {
+            const int w = ts + tid;
+            const real * row = T_s + w*n;
+            Frame<real> base, cur, sv0, sv1, sv2, sv3;
+            if (mod.floating)
+            {
+               // base pose from the trajectory row (src/orcdchomp_mod.cpp:1008-1016)
+               const real qx = row[3], qy = row[4], qz = row[5], qw = row[6];
+               const real xx = qx*qx, xy = qx*qy, xz = qx*qz, xw = qx*qw;
+               const real yy = qy*qy, yz = qy*qz, yw = qy*qw, zz = qz*qz, zw = qz*qw;
+               base.R[0] = 1 - 2*(yy+zz); base.R[1] = 2*(xy-zw);     base.R[2] = 2*(xz+yw);
+               base.R[3] = 2*(xy+zw);     base.R[4] = 1 - 2*(xx+zz); base.R[5] = 2*(yz-xw);
+               base.R[6] = 2*(xz-yw);     base.R[7] = 2*(yz+xw);     base.R[8] = 1 - 2*(xx+yy);
+               base.t[0] = row[0]; base.t[1] = row[1]; base.t[2] = row[2];
+               for (int s=mod.base_sph_begin; s<mod.base_sph_end; s++)
+               {
+                  const real * lp = mod.sph_pos[s];
+                  real * o = pos_s + (tid*Sa + s)*3;
+#pragma unroll
+                  for (int k=0; k<3; k++)
+                     o[k] = base.R[k*3+0]*lp[0] + base.R[k*3+1]*lp[1] + base.R[k*3+2]*lp[2] + base.t[k];
+               }
+            }
+            else
+            {
+#pragma unroll
+               for (int k=0; k<9; k++) base.R[k] = mod.base_R[k];
+#pragma unroll
+               for (int k=0; k<3; k++) base.t[k] = mod.base_t[k];
+            }
+            cur = base; sv0 = base; sv1 = base; sv2 = base; sv3 = base;
+            for (int j=0; j<nj; j++)
+            {
+               const DevJoint<real> & J = mod.joints[j];
+               Frame<real> from;
+               if (J.load_slot == -1) from = cur;
+               else if (J.load_slot == -2) from = base;
+               else if (J.load_slot == 0) from = sv0;
+               else if (J.load_slot == 1) from = sv1;
+               else if (J.load_slot == 2) from = sv2;
+               else from = sv3;
+               // joint frame in the world
+               real Rj[9], tj[3];
+               if (J.rfix_identity)
+               {
+#pragma unroll
+                  for (int k=0; k<9; k++) Rj[k] = from.R[k];
+               }
+               else mat3_mul(from.R, J.Rfix, Rj);
+#pragma unroll
+               for (int k=0; k<3; k++)
+                  tj[k] = from.R[k*3+0]*J.tfix[0] + from.R[k*3+1]*J.tfix[1] + from.R[k*3+2]*J.tfix[2] + from.t[k];
+               real aw[3];
+#pragma unroll
+               for (int k=0; k<3; k++)
+                  aw[k] = Rj[k*3+0]*J.axis[0] + Rj[k*3+1]*J.axis[1] + Rj[k*3+2]*J.axis[2];
+               real * axo = ax_s + (tid*nj + j)*6;
+               axo[0] = aw[0]; axo[1] = aw[1]; axo[2] = aw[2];
+               axo[3] = tj[0]; axo[4] = tj[1]; axo[5] = tj[2];
+               const real q = row[J.col];
+               if (J.type == 1)
+               {
+                  real sn, cs;
+                  M<real>::sincos_(q, &sn, &cs);
+                  const real v = (real)1 - cs;
+                  const real a0 = J.axis[0], a1 = J.axis[1], a2 = J.axis[2];
+                  real Rm[9];
+                  Rm[0] = cs + a0*a0*v;    Rm[1] = a0*a1*v - a2*sn; Rm[2] = a0*a2*v + a1*sn;
+                  Rm[3] = a1*a0*v + a2*sn; Rm[4] = cs + a1*a1*v;    Rm[5] = a1*a2*v - a0*sn;
+                  Rm[6] = a2*a0*v - a1*sn; Rm[7] = a2*a1*v + a0*sn; Rm[8] = cs + a2*a2*v;
+                  mat3_mul(Rj, Rm, cur.R);
+#pragma unroll
+                  for (int k=0; k<3; k++) cur.t[k] = tj[k];
+               }
+               else
+               {
+#pragma unroll
+                  for (int k=0; k<9; k++) cur.R[k] = Rj[k];
+#pragma unroll
+                  for (int k=0; k<3; k++) cur.t[k] = tj[k] + q*aw[k];
+               }
+               if (J.save_slot == 0) sv0 = cur;
+               else if (J.save_slot == 1) sv1 = cur;
+               else if (J.save_slot == 2) sv2 = cur;
+               else if (J.save_slot == 3) sv3 = cur;
+               for (int s=J.sph_begin; s<J.sph_end; s++)
+               {
+                  const real * lp = mod.sph_pos[s];
+                  real * o = pos_s + (tid*Sa + s)*3;
+#pragma unroll
+                  for (int k=0; k<3; k++)
+                     o[k] = cur.R[k*3+0]*lp[0] + cur.R[k*3+1]*lp[1] + cur.R[k*3+2]*lp[2] + cur.t[k];
+               }
+            }
+         }
+         __syncthreads();
+
+         // ================= cost phase: lane = (waypoint, sphere) =============
+         const int items = (te - ts) * GS;
+         for (int base_item=0; base_item<items; base_item+=ORC_BLOCK)
+         {
+            const int item = base_item + tid;
+            const int wl = item / GS;               // waypoint within the tile
+            const int s = item - wl*GS;             // sphere slot
+            const bool live = (item < items) && (s < Sa);
+            const int l = wl + 1;                   // row of pos_s / ax_s
+            real p[3] = {0,0,0}, vel[3] = {0,0,0}, acc[3] = {0,0,0};
+            real f[3] = {0,0,0};                    // total workspace force on this sphere
+            real vnorm = 0;
+            double cost_sphere = 0.0;
+            if (live)
+            {
+               const real * pc = pos_s + (l*Sa + s)*3;
+               const real * pp = pos_s + ((l-1)*Sa + s)*3;
+               const real * pn = pos_s + ((l+1)*Sa + s)*3;
+               const real radius = mod.sph_radius[s];
+               const int mylink = mod.sph_link[s];
+#pragma unroll
+               for (int k=0; k<3; k++)
+               {
+                  p[k] = pc[k];
+                  // src/orcdchomp_mod.cpp:1104-1106, 1120-1124
+                  real v = pn[k]; v -= pp[k]; v *= b.inv_2dt; vel[k] = v;
+                  real a = pc[k]; a *= (real)(-2); a += pp[k]; a += pn[k]; a *= b.inv_dt2; acc[k] = a;
+               }
+               vnorm = M<real>::sqrt_(vel[0]*vel[0] + vel[1]*vel[1] + vel[2]*vel[2]);
+               const real vn2 = vnorm * vnorm;
+
+               // ---- obstacle term (src/orcdchomp_mod.cpp:1171-1246) ----
+               real best = inf; int best_i = -1; real bgrad[3] = {0,0,0};
+               for (int i=0; i<b.n_sdfs; i++)
+               {
+                  const DevSdf<real> & F = b.sdfs[i];
+                  real g[3], gg[3], val;
+#pragma unroll
+                  for (int k=0; k<3; k++)
+                     g[k] = F.Rgw[k*3+0]*p[0] + F.Rgw[k*3+1]*p[1] + F.Rgw[k*3+2]*p[2] + F.tgw[k];
+                  if (sdf_lookup(F, g, val, gg)) continue;
+                  if (val < best) { best = val; best_i = i; bgrad[0] = gg[0]; bgrad[1] = gg[1]; bgrad[2] = gg[2]; }
+               }
+               if (best_i != -1)
+               {
+                  const DevSdf<real> & F = b.sdfs[best_i];
+                  const real dist = best - radius;
+                  real cs = 0;
+                  if (dist < (real)0)
+                     cs = vnorm * b.obs_factor * ((real)0.5 * b.epsilon - dist);
+                  else if (dist < b.epsilon)
+                     cs = vnorm * b.obs_factor * ((real)0.5/b.epsilon) * (dist - b.epsilon) * (dist - b.epsilon);
+                  cost_sphere += (double) cs;
+                  if (do_iteration && vnorm != (real)0)
+                  {
+                     real xg[3], xc[3];
+                     real scale;
+                     if (dist < (real)0) scale = (real)(-1);
+                     else if (dist < b.epsilon) scale = dist/b.epsilon - (real)1;
+                     else scale = (real)0;
+#pragma unroll
+                     for (int k=0; k<3; k++)
+                     {
+                        const real gw = F.Rwg[k*3+0]*bgrad[0] + F.Rwg[k*3+1]*bgrad[1] + F.Rwg[k*3+2]*bgrad[2];
+                        xg[k] = (scale == (real)0) ? (real)0 : gw * scale;
+                        xg[k] *= vnorm * b.obs_factor;
+                        xc[k] = acc[k];
+                     }
+                     if (vnorm > (real)0.000001)
+                     {
+                        real proj = (xg[0]*vel[0] + xg[1]*vel[1] + xg[2]*vel[2]) / vn2;
+#pragma unroll
+                        for (int k=0; k<3; k++) xg[k] -= proj * vel[k];
+                        proj = (xc[0]*vel[0] + xc[1]*vel[1] + xc[2]*vel[2]) / vn2;
+#pragma unroll
+                        for (int k=0; k<3; k++) xc[k] -= proj * vel[k];
+                     }
+                     const real ivn2 = (real)1 / vn2;
+#pragma unroll
+                     for (int k=0; k<3; k++)
+                     {
+                        xc[k] *= ivn2;
+                        xg[k] -= cs * xc[k];
+                        f[k] += vnorm * xg[k];        // c_grad += |v| J^T x_grad
+                     }
+                  }
+               }
+
+               // ---- self collision (src/orcdchomp_mod.cpp:1251-1317) ----
+               // pass 1: which spheres are within range (uniform loop)
+               unsigned long long near = 0ull;
+               for (int o=0; o<S; o++)
+               {
+                  const real * po = (o < Sa) ? pos_s + (l*Sa + o)*3 : mod.sph_inactive_pos[o - Sa];
+                  const real dx = p[0]-po[0], dy = p[1]-po[1], dz = p[2]-po[2];
+                  const real dist = M<real>::sqrt_(dx*dx + dy*dy + dz*dz);
+                  const bool skip = (mod.sph_link[o] == mylink) || (dist > radius + mod.sph_radius[o] + b.epsilon_self);
+                  if (!skip) near |= (1ull << o);
+               }
+               // pass 2: only the pairs in range
+               while (near)
+               {
+                  const int o = __builtin_ctzll(near);
+                  near &= near - 1;
+                  const real * po = (o < Sa) ? pos_s + (l*Sa + o)*3 : mod.sph_inactive_pos[o - Sa];
+                  const real ro = mod.sph_radius[o];
+                  real d[3] = { p[0]-po[0], p[1]-po[1], p[2]-po[2] };
+                  real dist = M<real>::sqrt_(d[0]*d[0] + d[1]*d[1] + d[2]*d[2]);
+                  real gh[3] = { d[0]/dist, d[1]/dist, d[2]/dist };
+                  dist -= radius + ro;
+                  real cself;
+                  if (dist < (real)0)
+                     cself = b.obs_factor_self * ((real)0.5 * b.epsilon_self - dist);
+                  else
+                     cself = b.obs_factor_self * ((real)0.5/b.epsilon_self) * (dist - b.epsilon_self) * (dist - b.epsilon_self);
+                  cost_sphere += (double)(vnorm * cself);
+                  if (do_iteration)
+                  {
+                     real scale = (real)1;
+                     if (dist < (real)0) scale = (real)(-1);
+                     else if (dist < b.epsilon_self) scale = dist/b.epsilon_self - (real)1;
+                     // my side of the pair: + J_me^T x
+                     real x[3];
+#pragma unroll
+                     for (int k=0; k<3; k++) { x[k] = gh[k] * scale; x[k] *= vnorm * b.obs_factor_self; }
+                     if (vnorm > (real)0.000001)
+                     {
+                        const real proj = (x[0]*vel[0] + x[1]*vel[1] + x[2]*vel[2]) / vn2;
+#pragma unroll
+                        for (int k=0; k<3; k++) x[k] -= proj * vel[k];
+                     }
+#pragma unroll
+                     for (int k=0; k<3; k++) f[k] += x[k];
+                     // the other sphere's side (it is active and visits this pair too):
+                     // its term (J_o - J_me)^T x_o puts -x_o on this sphere
+                     if (o < Sa)
+                     {
+                        const real * opp = pos_s + ((l-1)*Sa + o)*3;
+                        const real * opn = pos_s + ((l+1)*Sa + o)*3;
+                        real vo[3];
+#pragma unroll
+                        for (int k=0; k<3; k++) { real v = opn[k]; v -= opp[k]; v *= b.inv_2dt; vo[k] = v; }
+                        const real von = M<real>::sqrt_(vo[0]*vo[0] + vo[1]*vo[1] + vo[2]*vo[2]);
+                        real xo[3];
+#pragma unroll
+                        for (int k=0; k<3; k++) { xo[k] = (-gh[k]) * scale; xo[k] *= von * b.obs_factor_self; }
+                        if (von > (real)0.000001)
+                        {
+                           const real proj = (xo[0]*vo[0] + xo[1]*vo[1] + xo[2]*vo[2]) / (von*von);
+#pragma unroll
+                           for (int k=0; k<3; k++) xo[k] -= proj * vo[k];
+                        }
+#pragma unroll
+                        for (int k=0; k<3; k++) f[k] -= xo[k];
+                     }
+                  }
+               }
+               cost_lane += cost_sphere;
+            }
+
+            // ---- J^T contraction and reduction over the spheres of a waypoint ----
+            if (do_iteration)
+            {
+               const unsigned long long aff = live ? mod.sph_affects[s] : 0ull;
+               const bool row_ok = (item < items);
+               const int gi = ts + wl;               // moving waypoint index
+               for (int j=0; j<nj; j++)
+               {
+                  real cg = 0;
+                  if ((aff >> j) & 1ull)
+                  {
+                     const real * ax = ax_s + (l*nj + j)*6;
+                     if (mod.joints[j].type == 1)
+                     {
+                        const real r0 = p[0]-ax[3], r1 = p[1]-ax[4], r2 = p[2]-ax[5];
+                        const real c0 = r1*f[2] - r2*f[1];
+                        const real c1 = r2*f[0] - r0*f[2];
+                        const real c2 = r0*f[1] - r1*f[0];
+                        cg = ax[0]*c0 + ax[1]*c1 + ax[2]*c2;
+                     }
+                     else cg = ax[0]*f[0] + ax[1]*f[1] + ax[2]*f[2];
+                  }
+                  for (int o=GS>>1; o>0; o>>=1) cg += __shfl_xor(cg, o, 64);
+                  if (row_ok && s == 0) G_s[gi*n + mod.joints[j].col] = cg;
+               }
+               if (mod.floating)
+               {
+                  // base block: 0.01 * Jsp^T [p x f ; f] summed over all spheres
+                  // (src/orcdchomp_mod.cpp:1050-1080, src/libcd/spatial.c:295-337)
+                  real w6[6];
+                  w6[0] = p[1]*f[2] - p[2]*f[1];
+                  w6[1] = p[2]*f[0] - p[0]*f[2];
+                  w6[2] = p[0]*f[1] - p[1]*f[0];
+                  w6[3] = f[0]; w6[4] = f[1]; w6[5] = f[2];
+#pragma unroll
+                  for (int k=0; k<6; k++)
+                     for (int o=GS>>1; o>0; o>>=1) w6[k] += __shfl_xor(w6[k], o, 64);
+                  if (row_ok && s == 0)
+                  {
+                     const real * row = T_s + (gi+1)*n;
+                     const real x = row[0], y = row[1], z = row[2];
+                     const real qx = 2*row[3], qy = 2*row[4], qz = 2*row[5], qw = 2*row[6];
+                     real Jsp[6][7];
+#pragma unroll
+                     for (int a=0; a<6; a++)
+#pragma unroll
+                        for (int c=0; c<7; c++) Jsp[a][c] = 0;
+                     Jsp[3][0] = 1; Jsp[4][1] = 1; Jsp[5][2] = 1;
+                     Jsp[0][3] =  qw; Jsp[0][4] = -qz; Jsp[0][5] =  qy; Jsp[0][6] = -qx;
+                     Jsp[1][3] =  qz; Jsp[1][4] =  qw; Jsp[1][5] = -qx; Jsp[1][6] = -qy;
+                     Jsp[2][3] = -qy; Jsp[2][4] =  qx; Jsp[2][5] =  qw; Jsp[2][6] = -qz;
+                     Jsp[3][3] = -z*qz - y*qy; Jsp[3][4] = -z*qw + y*qx; Jsp[3][5] =  z*qx + y*qw; Jsp[3][6] =  z*qy - y*qz;
+                     Jsp[4][3] =  z*qw + x*qy; Jsp[4][4] = -z*qz - x*qx; Jsp[4][5] =  z*qy - x*qw; Jsp[4][6] = -z*qx + x*qz;
+                     Jsp[5][3] = -y*qw + x*qz; Jsp[5][4] =  y*qz + x*qw; Jsp[5][5] = -y*qy - x*qx; Jsp[5][6] =  y*qx - x*qy;
+#pragma unroll
+                     for (int c=0; c<7; c++)
+                     {
+                        real sum = 0;
+#pragma unroll
+                        for (int a=0; a<6; a++) sum += Jsp[a][c] * w6[a];
+                        G_s[gi*n + c] = (real)0.01 * sum;
+                     }
+                  }
+               }
+            }
+         }
+         __syncthreads();
+      } // tiles
+
+      // obstacle cost of the trajectory the gradient was taken at (chomp.c:484-491)
+      cost_obs = block_sum(cost_lane, red) / (double) m;
+
+      if (do_iteration)
+      {
+         // ================= update phase ======================================
+         // G = G/m + A T + B   (chomp.c:492, 515-522)
+         for (int e=tid; e<mn; e+=ORC_BLOCK)
+         {
+            const int i = e / n, c = e - i*n;
+            real g = G_s[e];
+            g *= b.inv_m;
+            g += smooth_grad(b, T_s, i, c);
+            G_s[e] = g;
+         }
+         __syncthreads();
+         if (b.Gdbg)
+            for (int e=tid; e<mn; e+=ORC_BLOCK) b.Gdbg[(size_t) run*mn + e] = G_s[e];
+         // X = A^-1 G   (chomp.c:525-548)
+         real * X = metric_solve(b, G_s, W_s);
+         if (!b.use_momentum)
+            for (int e=tid; e<mn; e+=ORC_BLOCK) AG_s[e] = X[e];
+         else
+         {
+            const real sc = (leapfrog_first ? (real)0.5 : (real)1) / b.lambda;
+            for (int e=tid; e<mn; e+=ORC_BLOCK) AG_s[e] += sc * X[e];
+            leapfrog_first = 0;
+         }
+         __syncthreads();
+         // T -= AG/lambda   (chomp.c:604-605)
+         {
+            const real sc = (real)(-1) / b.lambda;
+            for (int e=tid; e<mn; e+=ORC_BLOCK) T_s[n + e] += sc * AG_s[e];
+         }
+         __syncthreads();
+
+         // joint-limit projection (chomp.c:608-655)
+         int num_limadjs;
+         for (num_limadjs=0; num_limadjs<1000; num_limadjs++)
+         {
+            real best = 0; int best_e = 0x7fffffff;
+            for (int e=tid; e<mn; e+=ORC_BLOCK)
+            {
+               const int i = e / n, c = e - i*n;
+               const real t = T_s[n + e];
+               real gj = 0;
+               if (t < b.jl_lo[c]) gj = b.jl_lo[c] - t;
+               if (t > b.jl_hi[c]) gj = b.jl_hi[c] - t;
+               G_s[e] = gj;
+               const real a = M<real>::fabs_(gj);
+               if (a > best) { best = a; best_e = e; }
+            }
+            // workgroup arg-max, ties to the smallest index (first in row-major scan)
+#pragma unroll
+            for (int o=32; o>0; o>>=1)
+            {
+               const real ob = __shfl_xor(best, o, 64);
+               const int oe = __shfl_xor(best_e, o, 64);
+               if (ob > best || (ob == best && oe < best_e)) { best = ob; best_e = oe; }
+            }
+            __syncthreads();
+            if ((tid & 63) == 0) { red[tid >> 6] = (double) best; redi[tid >> 6] = best_e; }
+            __syncthreads();
+            double gb = red[0]; int ge = redi[0];
+#pragma unroll
+            for (int w=1; w<4; w++)
+               if (red[w] > gb || (red[w] == gb && redi[w] < ge)) { gb = red[w]; ge = redi[w]; }
+            if (gb == 0.0) break;
+            real * GA = metric_solve(b, G_s, W_s);
+            // PCR may return either buffer; Gjlimit[largest] is recomputed from T
+            const int gi = ge / n, gc = ge - gi*n;
+            const real tl = T_s[n + ge];
+            real gl = 0;
+            if (tl < b.jl_lo[gc]) gl = b.jl_lo[gc] - tl;
+            if (tl > b.jl_hi[gc]) gl = b.jl_hi[gc] - tl;
+            const real sc = (real)1.01 * gl / GA[ge];
+            __syncthreads();
+            for (int e=tid; e<mn; e+=ORC_BLOCK) T_s[n + e] += sc * GA[e];
+            __syncthreads();
+         }
+         if (!(num_limadjs < 1000)) status = -1;
+
+      }
+
+      // smoothness cost of the (updated) trajectory (chomp.c:660-677):
+      // 0.5 tr(T^T A T) + tr(B^T T) + trC
+      // evaluated before the quaternion renormalisation of the same iteration, as in
+      // the reference (cd_chomp_iterate returns before mod.cpp:2806-2808 runs)
+      {
+         double acc = 0.0;
+         for (int e=tid; e<mn; e+=ORC_BLOCK)
+         {
+            const int i = e / n, c = e - i*n;
+            const real sg = smooth_grad(b, T_s, i, c);           // (A T + B)
+            const real bt = b.beta_s[i] * T_s[c] + b.beta_g[i] * T_s[(np-1)*n + c];
+            acc += (double) T_s[n + e] * (0.5 * ((double) sg + (double) bt));
+         }
+         double ss = 0.0, sg2 = 0.0, gg = 0.0;
+         if (tid < n)
+         {
+            const double s0 = (double) T_s[tid], g0 = (double) T_s[(np-1)*n + tid];
+            ss = s0*s0; sg2 = s0*g0; gg = g0*g0;
+         }
+         acc += 0.5 * (b.kss*ss + 2.0*b.ksg*sg2 + b.kgg*gg);
+         cost_smooth = block_sum(acc, red);
+      }
+
+      // floating base: renormalise the quaternion of every row (mod.cpp:2806-2808)
+      if (do_iteration && mod.floating && status == 0)
+      {
+         for (int w=tid; w<np; w+=ORC_BLOCK)
+         {
+            real * row = T_s + w*n;
+            const real len = M<real>::sqrt_(row[3]*row[3] + row[4]*row[4] + row[5]*row[5] + row[6]*row[6]);
+            const real inv = (real)1 / len;
+            row[3] *= inv; row[4] *= inv; row[5] *= inv; row[6] *= inv;
+         }
+         __syncthreads();
+      }
+
+      if (tid == 0 && b.trace && do_iteration)
+      {
+         double * tr = b.trace + ((size_t) run * b.n_iter + it) * 3;
+         tr[0] = cost_obs + cost_smooth; tr[1] = cost_obs; tr[2] = cost_smooth;
+      }
+   }
+
+   // ---- write back ---------------------------------------------------------
+   __syncthreads();
+   for (int e=tid; e<np*n; e+=ORC_BLOCK) traj_g[e] = T_s[e];
+   for (int e=tid; e<mn; e+=ORC_BLOCK) AG_g[e] = AG_s[e];
+   if (tid == 0)
+   {
+      b.costs[(size_t) run*3 + 0] = cost_obs + cost_smooth;
+      b.costs[(size_t) run*3 + 1] = cost_obs;
+      b.costs[(size_t) run*3 + 2] = cost_smooth;
+      b.status[run] = status;
+      b.leapfrog_first[run] = leapfrog_first;
+   }
+}
+
+// straight-line seeding of every run (src/orcdchomp_mod.cpp:2417-2464):
+// traj[i][j] = s_j + (g_j - s_j) * i / (n_points-1), rows 0 and n_points-1 included,
+// then quaternion normalisation per row when floating.
+template <typename real>
+__global__ void seed_traj_kernel(real * traj, const double * starts, const double * goals,
+   int n_runs, int n_points, int n, int floating)
+{
+   const long total = (long) n_runs * n_points;
+   for (long idx = blockIdx.x * (long) blockDim.x + threadIdx.x; idx < total; idx += (long) gridDim.x * blockDim.x)
+   {
+      const int run = (int)(idx / n_points);
+      const int i = (int)(idx - (long) run * n_points);
+      double row[ORC_MAX_JOINTS + 7];
+      for (int j=0; j<n; j++)
+      {
+         const double s = starts[(size_t) run*n + j];
+         const double g = goals[(size_t) run*n + j];
+         row[j] = s + (g - s) * i / (n_points - 1);
+      }
+      if (floating)
+      {
+         const double len = ::sqrt(row[3]*row[3] + row[4]*row[4] + row[5]*row[5] + row[6]*row[6]);
+         const double inv = 1.0 / len;
+         row[3] *= inv; row[4] *= inv; row[5] *= inv; row[6] *= inv;
+      }
+      for (int j=0; j<n; j++) traj[((size_t) run * n_points + i) * n + j] = (real) row[j];
+   }
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------
+// host-side launch wrappers (called from module.cpp)
+size_t orc_chomp_lds_bytes(int n_points, int n, int Sa, int nj, int tile_m, size_t real_size)
+{
+   const int m = n_points - 2, mn = m*n;
+   size_t reals = ((size_t)(n_points*n + 3) & ~(size_t)3) + 3*(((size_t) mn + 3) & ~(size_t)3)
+                + (((size_t)(tile_m+2)*Sa*3 + 3) & ~(size_t)3) + (size_t)(tile_m+2)*nj*6;
+   return 128 + reals * real_size;
+}
+
+template <typename real>
+static hipError_t launch_iterate_t(const DevBatch<real> & b, size_t lds, hipStream_t stream)
+{
+   static bool attr_set = false;
+   if (!attr_set)
+   {
+      hipError_t e = hipFuncSetAttribute((const void *) chomp_iterate_kernel<real>,
+         hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256);
+      if (e != hipSuccess) return e;
+      attr_set = true;
+   }
+   hipLaunchKernelGGL(chomp_iterate_kernel<real>, dim3(b.n_runs), dim3(ORC_BLOCK), lds, stream, b);
+   return hipGetLastError();
+}
+
+hipError_t orc_launch_iterate_f64(const DevBatch<double> & b, size_t lds, hipStream_t stream)
+{ return launch_iterate_t<double>(b, lds, stream); }
+hipError_t orc_launch_iterate_f32(const DevBatch<float> & b, size_t lds, hipStream_t stream)
+{ return launch_iterate_t<float>(b, lds, stream); }
+
+hipError_t orc_launch_seed_f64(double * traj, const double * starts, const double * goals,
+   int n_runs, int n_points, int n, int floating, hipStream_t stream)
+{
+   const long total = (long) n_runs * n_points;
+   int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+   hipLaunchKernelGGL(seed_traj_kernel<double>, dim3(blocks), dim3(256), 0, stream, traj, starts, goals, n_runs, n_points, n, floating);
+   return hipGetLastError();
+}
+hipError_t orc_launch_seed_f32(float * traj, const double * starts, const double * goals,
+   int n_runs, int n_points, int n, int floating, hipStream_t stream)
+{
+   const long total = (long) n_runs * n_points;
+   int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+   hipLaunchKernelGGL(seed_traj_kernel<float>, dim3(blocks), dim3(256), 0, stream, traj, starts, goals, n_runs, n_points, n, floating);
+   return hipGetLastError();
+}

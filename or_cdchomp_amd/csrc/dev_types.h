@@ -1,0 +1,105 @@
+// dev_types.h -- plain-old-data handed from the host layer to the HIP kernels.
+//
+// Naming follows the reference's domain (runs, waypoints, spheres, rooted sdfs):
+//   struct run        /root/reference src/orcdchomp_mod.cpp:887-966
+//   struct run_rsdf   src/orcdchomp_mod.cpp:850-855
+//   struct cd_chomp   src/libcd/chomp.h:38-101
+#pragma once
+
+#define ORC_MAX_JOINTS   32      // active (optimized) joints of one robot
+#define ORC_MAX_SPHERES  64      // spheres of one robot (active + inactive)
+#define ORC_MAX_SAVE     4       // saved frames while walking a kinematic tree
+#define ORC_MAX_SDFS     8
+#define ORC_BLOCK        256     // threads per workgroup: one workgroup per run
+
+// one optimized joint, in topological order.  Non-optimized joints are folded
+// into the fixed transforms on the host when the batch is created.
+template <typename real>
+struct DevJoint
+{
+   real Rfix[9];      // rotation   from-frame -> joint frame (row major)
+   real tfix[3];      // translation from-frame -> joint frame
+   real axis[3];      // unit axis in the joint frame
+   int type;          // 1 revolute, 2 prismatic
+   int col;           // column of the trajectory / gradient this joint owns
+   int load_slot;     // -2 base frame, -1 previous joint's moved frame, k>=0 saved slot k
+   int save_slot;     // -1 none, k>=0: keep the moved frame in slot k
+   int sph_begin;     // active spheres [sph_begin, sph_end) ride on this joint's moved frame
+   int sph_end;
+   int rfix_identity; // Rfix == I (skips a 3x3 product)
+   int pad;
+};
+
+template <typename real>
+struct DevModel
+{
+   int nj;                 // optimized joints
+   int n;                  // optimizer dofs = 7*floating + n_adof
+   int floating;           // floating base: columns 0..6 are the base pose
+   int Sa;                 // active spheres (device order: sorted by joint)
+   int S;                  // all spheres
+   int GS;                 // lanes per waypoint in the cost phase (power of two >= Sa)
+   int base_sph_begin;     // active spheres fixed to the base frame (floating base only)
+   int base_sph_end;
+   real base_R[9];         // base frame when not floating
+   real base_t[3];
+   DevJoint<real> joints[ORC_MAX_JOINTS];
+   real sph_pos[ORC_MAX_SPHERES][3];     // active: in the attach frame; unused for inactive
+   real sph_radius[ORC_MAX_SPHERES];
+   int sph_link[ORC_MAX_SPHERES];        // robot link index (same-link test)
+   unsigned long long sph_affects[ORC_MAX_SPHERES]; // bit j: joint j moves the sphere
+   real sph_inactive_pos[ORC_MAX_SPHERES][3];       // world positions of inactive spheres [S-Sa]
+};
+
+// a rooted signed distance field (struct run_rsdf + struct cd_grid)
+template <typename real>
+struct DevSdf
+{
+   const real * data;      // C order [x][y][z]
+   int size[3];
+   int pad;
+   real length[3];
+   real Rgw[9];            // world -> grid: p_g = Rgw p + tgw   (pose_gsdf_world)
+   real tgw[3];
+   real Rwg[9];            // grid -> world rotation (pose_world_gsdf), for the gradient
+};
+
+template <typename real>
+struct DevBatch
+{
+   const DevModel<real> * model;
+   const DevSdf<real> * sdfs;
+   int n_sdfs;
+   int n_runs, n_points, m, n;
+   int tile_m;             // moving waypoints per tile
+   // per-run state in HBM, run-major
+   real * traj;            // [n_runs][n_points][n]
+   real * AG;              // [n_runs][m][n]   (A^-1 G, doubles as momentum)
+   real * Gdbg;            // [n_runs][m][n] or null: last gradient, for tests
+   double * costs;         // [n_runs][3] total, obs, smooth
+   double * trace;         // [n_runs][n_iter][3] or null
+   int * status;           // [n_runs]
+   int * leapfrog_first;   // [n_runs]
+   // run parameters
+   real dt, inv_2dt, inv_dt2, lambda, inv_m;
+   real epsilon, epsilon_self, obs_factor, obs_factor_self;
+   int use_momentum, use_hmc, D;
+   // metric: band of A, endpoint couplings of B and trC
+   const real * Aband;     // [2D+1][m]
+   const real * beta_s;    // [m]  B[i] = beta_s[i]*q_start + beta_g[i]*q_goal
+   const real * beta_g;    // [m]
+   double kss, ksg, kgg;   // trC = 0.5*(kss|s|^2 + 2 ksg s.g + kgg|g|^2)
+   // A^-1 application
+   int solve_mode;         // 0 cyclic reduction (tridiagonal), 1 dense A^-1
+   int pcr_levels;
+   const real * pcr;       // [levels][2][m] multipliers, then [m] inverse diagonal
+   const real * Ainv;      // dense [m][m] when solve_mode == 1
+   const real * jl_lo;     // [n]
+   const real * jl_hi;     // [n]
+   // hmc momentum resampling of this call
+   const int * hmc_iters;  // [n_runs][max_resamples], -1 padded
+   const real * noise;     // [n_runs][max_resamples][m][n]
+   int max_resamples;
+   int n_iter;
+   int final_eval;
+};

@@ -1,0 +1,106 @@
+// host_math.h -- host-side numerics of the product path: poses, grids, the
+// signed-distance-field build, the smoothness metric tables, GSL's noise stream.
+// (The oracle under oracle/ is test infrastructure and is never linked here.)
+#pragma once
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace orc {
+
+// ---------------------------------------------------------------- poses ---
+// pose = [x y z qx qy qz qw]  (reference: src/libcd/kin.c:42-52)
+struct Pose
+{
+   double v[7];
+   Pose() { for (int i=0; i<6; i++) v[i] = 0.0; v[6] = 1.0; }
+   explicit Pose(const double * p) { for (int i=0; i<7; i++) v[i] = p[i]; }
+};
+
+struct Mat3 { double m[9]; };
+struct Xform { Mat3 R; double t[3]; };   // rotation matrix + translation
+
+// rotation part of a pose as the reference's pose_compos evaluates it
+// (expanded quaternion products, not pre-normalised; src/libcd/kin.c:194-206)
+Mat3 pose_rotation_expanded(const Pose & p);
+// unit-quaternion to rotation matrix (src/libcd/kin.c:348-370)
+Mat3 quat_to_R(const double q[4]);
+Pose pose_compose(const Pose & ab, const Pose & bc);      // src/libcd/kin.c:136-178
+Pose pose_invert(const Pose & in);                        // src/libcd/kin.c:288-326
+void pose_normalize(Pose & p);                            // src/libcd/kin.c:64-70
+void pose_apply(const Pose & ab, const double in[3], double out[3]); // kin.c:180-212
+Xform xform_from_pose(const Pose & p);                    // via quat_to_R
+Xform xform_mul(const Xform & a, const Xform & b);
+Mat3 mat3_mul(const Mat3 & a, const Mat3 & b);
+void mat3_vec(const Mat3 & a, const double v[3], double out[3]);
+Mat3 axis_angle(const double axis[3], double q);
+
+// ----------------------------------------------------------------- grid ---
+// 3-d double grid, C order [x][y][z]   (struct cd_grid, src/libcd/grid.h:29-41)
+struct Grid
+{
+   int sizes[3];
+   double lengths[3];
+   std::vector<double> data;
+   size_t ncells() const { return (size_t) sizes[0] * sizes[1] * sizes[2]; }
+   size_t index(int x, int y, int z) const { return ((size_t) x * sizes[1] + y) * sizes[2] + z; }
+   void center(size_t idx, double c[3]) const;            // src/libcd/grid.c:172-189
+};
+
+// occupancy (0.0 free / HUGE_VAL obstacle) -> signed distance field, positive
+// outside (cd_grid_double_bin_sdf, src/libcd/grid.c:637-687)
+void grid_bin_sdf(const Grid & occ, Grid & sdf);
+// flood fill from a cell, turning reachable 1.0 into 0.0, 6-connected
+// (cd_grid_flood_fill + replace_1_to_0; src/libcd/grid_flood.c:30-111)
+void grid_flood_1_to_0(Grid & g, size_t start);
+
+// oriented box for the primitive voxelizer
+struct Box { Xform world; double half[3]; };
+// true when two oriented boxes overlap by more than `tol` (separating axis test)
+bool obb_overlap(const Xform & a, const double ha[3], const Xform & b, const double hb[3], double tol);
+
+// --------------------------------------------------------------- metric ---
+// Band form of the smoothness metric of cd_chomp_add_KEs / cd_chomp_init
+// (src/libcd/chomp.c:239-340, 393-403) for inits[0]=start, finals[0]=goal and
+// zero higher-order boundary derivatives (chomp.c:131-141).
+struct Metric
+{
+   int m, D;
+   std::vector<double> Aband;   // [2D+1][m]:  Aband[k+D][i] = A[i][i+k]
+   std::vector<double> beta_s;  // [m]  B[i][:] = beta_s[i]*start + beta_g[i]*goal
+   std::vector<double> beta_g;
+   double kss, ksg, kgg;        // trC = 0.5*(kss|s|^2 + 2ksg s.g + kgg|g|^2)
+   int pcr_levels;              // tridiagonal only
+   std::vector<double> pcr;     // [levels][2][m] + [m]
+   std::vector<double> Ainv;    // dense [m][m], only when D >= 2
+   std::vector<double> Adense;  // dense A (kept for tests / dense fallback)
+};
+void build_metric(int m, int D, double dt, Metric & out);
+
+// ------------------------------------------------------------------ rng ---
+// GSL's default generator and gaussian, restated from the published algorithm
+// (mt19937 with the 2002 seeding, seed 0 -> 4357; polar Box-Muller).  The
+// reference calls gsl_rng_alloc(gsl_rng_default)/gsl_rng_set/gsl_ran_gaussian/
+// gsl_rng_uniform at src/orcdchomp_mod.cpp:2303-2304,2763,2767.
+class GslRng
+{
+public:
+   explicit GslRng(unsigned long seed = 0) { set(seed); }
+   void set(unsigned long seed);
+   unsigned long get();
+   double uniform() { return get() / 4294967296.0; }
+   double uniform_pos() { double x; do { x = uniform(); } while (x == 0); return x; }
+   double gaussian(double sigma);
+private:
+   uint32_t mt_[624];
+   int mti_;
+};
+
+// --------------------------------------------------------------- shparse ---
+// POSIX-shell-like tokenizer with the reference's exact rules
+// (src/libcd/util_shparse.c:37-128)
+std::vector<std::string> shparse(const std::string & in);
+
+} // namespace orc

@@ -1,0 +1,695 @@
+// module.cpp -- environment stand-ins, SDF commands, command grammar.
+// Reference: src/orcdchomp_mod.cpp (commands), src/orcwrap.cpp (argv adaptor).
+#include "module.h"
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iomanip>
+#include <limits>
+#include <sstream>
+#include <stdexcept>
+
+namespace orc {
+
+void hip_check(hipError_t e, const char * what)
+{
+   if (e != hipSuccess)
+      throw std::runtime_error(std::string("HIP error in ") + what + ": " + hipGetErrorString(e));
+}
+
+// ================================================================ Robot ===
+bool Robot::does_affect(int dof, int link) const
+{
+   for (int li=link; li>=0; li=parent[li])
+      if (joint_type[li] != 0 && dof_index[li] == dof) return true;
+   return false;
+}
+
+void Robot::fk(const Pose & base, const std::vector<double> & q, std::vector<Xform> & frames) const
+{
+   frames.resize(n_links);
+   const Xform xb = xform_from_pose(base);
+   for (int li=0; li<n_links; li++)
+   {
+      const Xform & from = (parent[li] < 0) ? xb : frames[parent[li]];
+      Xform xj = xform_mul(from, xform_from_pose(pose_parent_joint[li]));
+      if (joint_type[li] == 1)
+      {
+         Xform rot; rot.R = axis_angle(&axis[3*li], q[dof_index[li]]); rot.t[0] = rot.t[1] = rot.t[2] = 0.0;
+         xj = xform_mul(xj, rot);
+      }
+      else if (joint_type[li] == 2)
+      {
+         double aw[3];
+         mat3_vec(xj.R, &axis[3*li], aw);
+         for (int k=0; k<3; k++) xj.t[k] += q[dof_index[li]] * aw[k];
+      }
+      frames[li] = xj;
+   }
+}
+
+// =============================================================== Module ===
+Module::Module(int dev) : device(dev)
+{
+   int count = 0;
+   hipError_t e = hipGetDeviceCount(&count);
+   if (e != hipSuccess || count <= 0)
+      throw std::runtime_error("orcdchomp_amd: no HIP device available (the MI355X path has no CPU fallback)");
+   if (dev < 0 || dev >= count) throw std::runtime_error("orcdchomp_amd: bad device ordinal");
+   hip_check(hipSetDevice(dev), "hipSetDevice");
+}
+
+Module::~Module()
+{
+   batches_.clear();
+   for (auto & s : sdfs) { if (s->d_data64) hipFree(s->d_data64); if (s->d_data32) hipFree(s->d_data32); }
+   for (auto & p : pending_events_) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+   for (auto & e : event_pool_) hipEventDestroy(e);
+}
+
+void Module::time_begin()
+{
+   hipEvent_t a;
+   if (!event_pool_.empty()) { a = event_pool_.back(); event_pool_.pop_back(); }
+   else hip_check(hipEventCreate(&a), "hipEventCreate");
+   hip_check(hipEventRecord(a, stream), "hipEventRecord");
+   ev_begin_ = a;
+}
+
+void Module::time_end()
+{
+   hipEvent_t b;
+   if (!event_pool_.empty()) { b = event_pool_.back(); event_pool_.pop_back(); }
+   else hip_check(hipEventCreate(&b), "hipEventCreate");
+   hip_check(hipEventRecord(b, stream), "hipEventRecord");
+   pending_events_.push_back(std::make_pair(ev_begin_, b));
+   ev_begin_ = nullptr;
+}
+
+void Module::time_collect()
+{
+   for (auto & p : pending_events_)
+   {
+      hip_check(hipEventSynchronize(p.second), "hipEventSynchronize");
+      float ms = 0.f;
+      hip_check(hipEventElapsedTime(&ms, p.first, p.second), "hipEventElapsedTime");
+      kernel_ms_total += ms;
+      kernel_launches++;
+      event_pool_.push_back(p.first);
+      event_pool_.push_back(p.second);
+   }
+   pending_events_.clear();
+}
+
+void Module::add_robot(const Robot & r)
+{
+   if (has_body(r.name)) throw std::runtime_error("a body with that name already exists!");
+   robots_[r.name] = r;
+}
+
+Robot & Module::robot(const std::string & name)
+{
+   auto it = robots_.find(name);
+   if (it == robots_.end()) throw std::runtime_error("Could not find robot with that name!");
+   return it->second;
+}
+
+void Module::add_kinbody(const KinBody & k)
+{
+   if (has_body(k.name)) throw std::runtime_error("a body with that name already exists!");
+   kinbodies_[k.name] = k;
+}
+
+KinBody & Module::kinbody(const std::string & name)
+{
+   auto it = kinbodies_.find(name);
+   if (it == kinbodies_.end()) throw std::runtime_error("Could not find kinbody with that name!");
+   return it->second;
+}
+
+bool Module::has_body(const std::string & name) const
+{
+   return robots_.count(name) || kinbodies_.count(name);
+}
+
+Pose Module::body_transform(const std::string & name) const
+{
+   auto r = robots_.find(name);
+   if (r != robots_.end()) return r->second.transform;
+   auto k = kinbodies_.find(name);
+   if (k != kinbodies_.end()) return k->second.transform;
+   throw std::runtime_error("KinBody " + name + " referenced by active signed distance field does not exist!\n");
+}
+
+Sdf * Module::find_sdf(const std::string & kinbody)
+{
+   for (auto & s : sdfs) if (s->kinbody_name == kinbody) return s.get();
+   return nullptr;
+}
+
+void Module::add_sdf(const std::string & kb, const Grid & g, const Pose & pose)
+{
+   if (find_sdf(kb)) throw std::runtime_error("We already have an sdf for this kinbody!");
+   for (int d=0; d<3; d++)
+      if (g.sizes[d] < 2) throw std::runtime_error("sdf grids need at least 2 cells per dimension!");
+   std::unique_ptr<Sdf> s(new Sdf);
+   s->kinbody_name = kb;
+   s->pose = pose;
+   s->grid = g;
+   sdfs.push_back(std::move(s));
+}
+
+int Module::create_batch(const std::string & rname, const BatchParams & p, int n_runs,
+   const double * starts, const double * goals, const double * basegoals, const unsigned int * seeds)
+{
+   Robot & r = robot(rname);
+   std::unique_ptr<Batch> b(new Batch(this, r, p, n_runs, starts, goals, basegoals, seeds));
+   const int id = next_batch_id_++;
+   batches_[id] = std::move(b);
+   return id;
+}
+
+Batch & Module::batch(int id)
+{
+   auto it = batches_.find(id);
+   if (it == batches_.end()) throw std::runtime_error("you must pass a created run!");
+   return *it->second;
+}
+
+void Module::destroy_batch(int id)
+{
+   auto it = batches_.find(id);
+   if (it == batches_.end()) throw std::runtime_error("you must pass a created run!");
+   batches_.erase(it);
+}
+
+// ------------------------------------------------------------ commands ---
+namespace {
+
+std::vector<double> parse_vector(const std::string & s)
+{
+   std::vector<double> out;
+   for (const std::string & tok : shparse(s)) out.push_back(std::atof(tok.c_str()));
+   return out;
+}
+
+void bad_arguments() { throw std::runtime_error("Bad arguments!"); }
+
+void * parse_pointer(const std::string & s)
+{
+   void * p = nullptr;
+   if (std::sscanf(s.c_str(), "%p", &p) != 1) return nullptr;
+   return p;
+}
+
+// an OpenRAVE-style trajectory document holding the waypoints of one run
+// (stands in for t->serialize(sout), src/orcdchomp_mod.cpp:3008)
+std::string serialize_traj(const std::string & robot, const std::vector<int> & adofs,
+   const double * traj, int n_points, int n, int col0)
+{
+   std::ostringstream o;
+   const int nd = n - col0;
+   o << std::setprecision(std::numeric_limits<double>::digits10 + 1);
+   o << "<trajectory>\n<configuration>\n<group name=\"joint_values " << robot;
+   for (int a : adofs) o << " " << a;
+   o << "\" offset=\"0\" dof=\"" << nd << "\" interpolation=\"linear\"/>\n";
+   o << "<group name=\"deltatime\" offset=\"" << nd << "\" dof=\"1\" interpolation=\"\"/>\n";
+   o << "</configuration>\n<data count=\"" << n_points << "\">\n";
+   for (int i=0; i<n_points; i++)
+   {
+      double dtm = 0.0;
+      for (int j=col0; j<n; j++)
+      {
+         o << traj[(size_t) i*n+j] << " ";
+         if (i > 0) dtm = std::max(dtm, std::fabs(traj[(size_t) i*n+j] - traj[(size_t)(i-1)*n+j]));
+      }
+      o << dtm << (i+1 < n_points ? " " : "");
+   }
+   o << "\n</data>\n</trajectory>\n";
+   return o.str();
+}
+
+} // namespace
+
+std::string Module::send_command(const std::string & cmd)
+{
+   // orcwrap_call (src/orcwrap.cpp:37-69): tokenise; argv[0] is the command name
+   std::vector<std::string> argv = shparse(cmd);
+   if (argv.empty()) throw std::runtime_error("empty command!");
+   const std::string name = argv[0];
+   if (name == "computedistancefield") return cmd_computedistancefield(argv);
+   if (name == "addfield_fromobsarray") return cmd_addfield_fromobsarray(argv);
+   if (name == "removefield") return cmd_removefield(argv);
+   if (name == "create") return cmd_create(argv, false);
+   if (name == "createbatch") return cmd_create(argv, true);
+   if (name == "iterate") return cmd_iterate(argv, false);
+   if (name == "iteratebatch") return cmd_iterate(argv, true);
+   if (name == "gettraj") return cmd_gettraj(argv, false);
+   if (name == "gettrajbatch") return cmd_gettraj(argv, true);
+   if (name == "destroy") return cmd_destroy(argv);
+   if (name == "viewspheres" || name == "viewfields")
+      throw std::runtime_error("command " + name + " needs an OpenRAVE viewer and is not part of this build");
+   throw std::runtime_error("unknown command " + name);
+}
+
+// src/orcdchomp_mod.cpp:297-589
+std::string Module::cmd_computedistancefield(const std::vector<std::string> & argv)
+{
+   std::string kb;
+   double cube_extent = 0.02, aabb_padding = 0.2;
+   std::string cache_filename;
+   bool have_cache = false, require_cache = false;
+   const int argc = (int) argv.size();
+   int i;
+   for (i=1; i<argc; i++)
+   {
+      if (argv[i] == "kinbody" && i+1 < argc)
+      {
+         if (!kb.empty()) throw std::runtime_error("Only one kinbody can be passed!");
+         kb = argv[++i];
+         if (!has_body(kb)) throw std::runtime_error("Could not find kinbody with that name!");
+      }
+      else if (argv[i] == "aabb_padding" && i+1 < argc) aabb_padding = std::atof(argv[++i].c_str());
+      else if (argv[i] == "cube_extent" && i+1 < argc) cube_extent = std::atof(argv[++i].c_str());
+      else if (argv[i] == "cache_filename" && i+1 < argc) { cache_filename = argv[++i]; have_cache = true; }
+      else if (argv[i] == "require_cache") require_cache = true;
+      else break;
+   }
+   if (i < argc) bad_arguments();
+   if (kb.empty()) throw std::runtime_error("Did not pass all required args!");
+   if (find_sdf(kb)) throw std::runtime_error("We already have an sdf for this kinbody!");
+
+   // AABB of the enabled geometry with the body at the world origin (mod.cpp:377-381, 88-140)
+   double amin[3] = {0,0,0}, amax[3] = {0,0,0};
+   bool init = false;
+   if (kinbodies_.count(kb))
+   {
+      const KinBody & k = kinbodies_[kb];
+      if (k.enabled) for (const KinBody::B & bx : k.boxes)
+      {
+         const Xform x = xform_from_pose(bx.pose);
+         double ext[3];
+         for (int r=0; r<3; r++)
+            ext[r] = std::fabs(x.R.m[r*3+0])*bx.half[0] + std::fabs(x.R.m[r*3+1])*bx.half[1] + std::fabs(x.R.m[r*3+2])*bx.half[2];
+         if (ext[0] == 0 && ext[1] == 0 && ext[2] == 0) continue;
+         for (int r=0; r<3; r++)
+         {
+            const double lo = x.t[r] - ext[r], hi = x.t[r] + ext[r];
+            if (!init) { amin[r] = lo; amax[r] = hi; }
+            else { if (amin[r] > lo) amin[r] = lo; if (amax[r] < hi) amax[r] = hi; }
+         }
+         init = true;
+      }
+   }
+   double apos[3], aext[3];
+   for (int r=0; r<3; r++)
+   {
+      if (init) { apos[r] = 0.5 * (amin[r] + amax[r]); aext[r] = amax[r] - apos[r]; }
+      else { apos[r] = 0.0; aext[r] = 0.0; }      // identity transform translation (mod.cpp:131-134)
+   }
+
+   Grid g;
+   for (int r=0; r<3; r++)
+   {
+      g.sizes[r] = (int) std::ceil((aext[r] + aabb_padding) / cube_extent);      // mod.cpp:391
+      g.lengths[r] = g.sizes[r] * 2.0 * cube_extent;                              // mod.cpp:403
+   }
+   for (int r=0; r<3; r++)
+      if (g.sizes[r] < 2) throw std::runtime_error("Not enough memory for distance field!");
+   Pose pose_gsdf;
+   for (int r=0; r<3; r++) pose_gsdf.v[r] = apos[r] - 0.5 * g.lengths[r];         // mod.cpp:407-409
+   g.data.assign(g.ncells(), 1.0);
+
+   bool loaded = false;
+   if (have_cache)
+   {
+      // raw doubles, C order, no header; validated by size only (mod.cpp:416-444)
+      std::ifstream fp(cache_filename.c_str(), std::ios::binary | std::ios::ate);
+      if (fp)
+      {
+         const std::streamoff sz = fp.tellg();
+         if ((size_t) sz == g.ncells() * sizeof(double))
+         {
+            fp.seekg(0);
+            fp.read((char *) g.data.data(), sz);
+            loaded = (bool) fp;
+         }
+      }
+   }
+   if (!loaded)
+   {
+      if (require_cache) throw std::runtime_error("Field not found from cache, but require_cache flag set!");
+      // occupancy by sweeping a cube of half-extent cube_extent over the cell centres
+      // (mod.cpp:462-531; OpenRAVE's CheckCollision replaced by a box-box test)
+      const Pose pose_world_gsdf = pose_compose(body_transform(kb), pose_gsdf);
+      std::vector<Box> obstacles;
+      for (auto & kv : kinbodies_)
+      {
+         const KinBody & k = kv.second;
+         if (!k.enabled) continue;
+         const Xform xk = xform_from_pose(k.transform);
+         for (const KinBody::B & bx : k.boxes)
+         {
+            Box b;
+            b.world = xform_mul(xk, xform_from_pose(bx.pose));
+            for (int r=0; r<3; r++) b.half[r] = bx.half[r];
+            obstacles.push_back(b);
+         }
+      }
+      const double hc[3] = { cube_extent, cube_extent, cube_extent };
+      const size_t nc = g.ncells();
+      for (size_t idx=0; idx<nc; idx++)
+      {
+         Pose pc;
+         g.center(idx, pc.v);
+         const Pose pw = pose_compose(pose_world_gsdf, pc);
+         const Xform xc = xform_from_pose(pw);
+         for (const Box & b : obstacles)
+            if (obb_overlap(xc, hc, b.world, b.half, 1e-9)) { g.data[idx] = HUGE_VAL; break; }
+      }
+      grid_flood_1_to_0(g, 0);                                                   // mod.cpp:540-548
+      for (size_t idx=0; idx<nc; idx++) if (g.data[idx] == 1.0) g.data[idx] = HUGE_VAL;
+      Grid sdf;
+      grid_bin_sdf(g, sdf);                                                      // mod.cpp:560
+      g = sdf;
+      if (have_cache)
+      {
+         std::ofstream fp(cache_filename.c_str(), std::ios::binary);
+         fp.write((const char *) g.data.data(), g.ncells() * sizeof(double));
+      }
+   }
+   add_sdf(kb, g, pose_gsdf);
+   return "";
+}
+
+// src/orcdchomp_mod.cpp:592-722
+std::string Module::cmd_addfield_fromobsarray(const std::vector<std::string> & argv)
+{
+   std::string kb;
+   double * obsarray = nullptr;
+   int sizes[3] = {0,0,0};
+   double lengths[3] = {0,0,0};
+   Pose pose;
+   const int argc = (int) argv.size();
+   int i;
+   for (i=1; i<argc; i++)
+   {
+      if (argv[i] == "kinbody" && i+1 < argc)
+      {
+         if (!kb.empty()) throw std::runtime_error("Only one kinbody can be passed!");
+         kb = argv[++i];
+         if (!has_body(kb)) throw std::runtime_error("Could not find kinbody with that name!");
+      }
+      else if (argv[i] == "obsarray" && i+1 < argc) obsarray = (double *) parse_pointer(argv[++i]);
+      else if (argv[i] == "sizes" && i+1 < argc)
+      {
+         std::vector<std::string> t = shparse(argv[++i]);
+         if (t.size() != 3) throw std::runtime_error("sizes must be length 3!");
+         for (int j=0; j<3; j++) sizes[j] = std::atoi(t[j].c_str());
+      }
+      else if (argv[i] == "lengths" && i+1 < argc)
+      {
+         std::vector<double> t = parse_vector(argv[++i]);
+         if (t.size() != 3) throw std::runtime_error("lengths must be length 3!");
+         for (int j=0; j<3; j++) lengths[j] = t[j];
+      }
+      else if (argv[i] == "pose" && i+1 < argc)
+      {
+         std::vector<double> t = parse_vector(argv[++i]);
+         if (t.size() != 7) throw std::runtime_error("pose must be length 7!");
+         for (int j=0; j<7; j++) pose.v[j] = t[j];
+      }
+      else break;
+   }
+   if (i < argc) bad_arguments();
+   if (kb.empty()) throw std::runtime_error("Did not pass a kinbody!");
+   if (!obsarray) throw std::runtime_error("Did not pass an obsarray!");
+   for (int j=0; j<3; j++) if (sizes[j] <= 0) throw std::runtime_error("Didn't pass non-zero sizes!");
+   for (int j=0; j<3; j++) if (lengths[j] <= 0.0) throw std::runtime_error("Didn't pass non-zero lengths!");
+   pose_normalize(pose);
+   if (find_sdf(kb)) throw std::runtime_error("We already have an sdf for this kinbody!");
+   Grid occ;
+   for (int j=0; j<3; j++) { occ.sizes[j] = sizes[j]; occ.lengths[j] = lengths[j]; }
+   // the reference takes ownership of the malloc'd array (mod.cpp:702-704); this build
+   // copies it and leaves ownership with the caller (no cross-allocator free)
+   occ.data.assign(obsarray, obsarray + occ.ncells());
+   Grid sdf;
+   grid_bin_sdf(occ, sdf);
+   add_sdf(kb, sdf, pose);
+   return "";
+}
+
+// src/orcdchomp_mod.cpp:799-847
+std::string Module::cmd_removefield(const std::vector<std::string> & argv)
+{
+   std::string kb;
+   const int argc = (int) argv.size();
+   int i;
+   for (i=1; i<argc; i++)
+   {
+      if (argv[i] == "kinbody" && i+1 < argc)
+      {
+         if (!kb.empty()) throw std::runtime_error("Only one kinbody can be passed!");
+         kb = argv[++i];
+      }
+      else break;
+   }
+   if (i < argc) bad_arguments();
+   if (kb.empty()) throw std::runtime_error("Did not pass a kinbody!");
+   for (size_t k=0; k<sdfs.size(); k++)
+      if (sdfs[k]->kinbody_name == kb)
+      {
+         if (sdfs[k]->d_data64) hipFree(sdfs[k]->d_data64);
+         if (sdfs[k]->d_data32) hipFree(sdfs[k]->d_data32);
+         sdfs.erase(sdfs.begin() + k);
+         return "";
+      }
+   throw std::runtime_error("No sdf for that kinbody!");
+}
+
+// src/orcdchomp_mod.cpp:1800-2688 (argument grammar 1888-2085)
+std::string Module::cmd_create(const std::vector<std::string> & argv, bool batchmode)
+{
+   std::string rname;
+   std::vector<double> adofgoal, basegoal;
+   bool have_adofgoal = false, have_basegoal = false;
+   BatchParams p;
+   unsigned int seed = 0;
+   int n_runs = 1;
+   const double * goals_ptr = nullptr, * starts_ptr = nullptr, * basegoals_ptr = nullptr;
+   const unsigned int * seeds_ptr = nullptr;
+   const int argc = (int) argv.size();
+   int i;
+   for (i=1; i<argc; i++)
+   {
+      const std::string & a = argv[i];
+      if (a == "robot" && i+1 < argc)
+      {
+         if (!rname.empty()) throw std::runtime_error("Only one robot can be passed!");
+         rname = argv[++i];
+         robot(rname);
+      }
+      else if (a == "adofgoal" && i+1 < argc)
+      {
+         if (have_adofgoal) throw std::runtime_error("Only one adofgoal can be passed!");
+         adofgoal = parse_vector(argv[++i]); have_adofgoal = true;
+      }
+      else if (a == "basegoal" && i+1 < argc)
+      {
+         if (have_basegoal) throw std::runtime_error("Only one basegoal can be passed!");
+         basegoal = parse_vector(argv[++i]);
+         if (basegoal.size() != 7) throw std::runtime_error("basegoal argument must be length 7!");
+         have_basegoal = true;
+      }
+      else if (a == "floating_base") p.floating_base = 1;
+      else if (a == "lambda" && i+1 < argc) p.lambda = std::atof(argv[++i].c_str());
+      else if (a == "n_points" && i+1 < argc) p.n_points = std::atoi(argv[++i].c_str());
+      else if (a == "derivative" && i+1 < argc) p.derivative = std::atoi(argv[++i].c_str());
+      else if (a == "use_momentum") p.use_momentum = 1;
+      else if (a == "use_hmc") p.use_hmc = 1;
+      else if (a == "hmc_resample_lambda" && i+1 < argc) p.hmc_resample_lambda = std::atof(argv[++i].c_str());
+      else if (a == "seed" && i+1 < argc) std::sscanf(argv[++i].c_str(), "%u", &seed);
+      else if (a == "epsilon" && i+1 < argc) p.epsilon = std::atof(argv[++i].c_str());
+      else if (a == "epsilon_self" && i+1 < argc) p.epsilon_self = std::atof(argv[++i].c_str());
+      else if (a == "obs_factor" && i+1 < argc) p.obs_factor = std::atof(argv[++i].c_str());
+      else if (a == "obs_factor_self" && i+1 < argc) p.obs_factor_self = std::atof(argv[++i].c_str());
+      else if (a == "no_report_cost") { /* emitted by the python layer, ignored */ }
+      else if (a == "dat_filename" && i+1 < argc)
+         throw std::runtime_error("dat_filename is not supported by this build (per-iteration costs: iteratebatch trace)");
+      else if ((a == "starttraj" || a == "start_tsr" || a == "everyn_tsr" || a == "start_cost"
+                || a == "ee_force" || a == "ee_force_at" || a == "ee_torque_weights") && i+1 < argc)
+         throw std::runtime_error("argument " + a + " is outside the scope of this build (SURVEY.md section 2)");
+      else if (a == "con_tsr" && i+2 < argc)
+         throw std::runtime_error("argument con_tsr is outside the scope of this build (SURVEY.md section 2)");
+      else if (batchmode && a == "n_runs" && i+1 < argc) n_runs = std::atoi(argv[++i].c_str());
+      else if (batchmode && a == "adofgoals" && i+1 < argc) goals_ptr = (const double *) parse_pointer(argv[++i]);
+      else if (batchmode && a == "adofstarts" && i+1 < argc) starts_ptr = (const double *) parse_pointer(argv[++i]);
+      else if (batchmode && a == "basegoals" && i+1 < argc) basegoals_ptr = (const double *) parse_pointer(argv[++i]);
+      else if (batchmode && a == "seeds" && i+1 < argc) seeds_ptr = (const unsigned int *) parse_pointer(argv[++i]);
+      else if (batchmode && a == "precision" && i+1 < argc) p.precision = std::atoi(argv[++i].c_str());
+      else break;
+   }
+   if (i < argc) bad_arguments();
+   if (rname.empty()) throw std::runtime_error("Did not pass a robot!");
+   if (!batchmode)
+   {
+      if (!have_adofgoal) throw std::runtime_error("Did not pass either adofgoal or starttraj!");
+      if (p.floating_base && !have_basegoal) throw std::runtime_error("Passed floating_base with no basegoal!");
+      if (!p.floating_base && have_basegoal) throw std::runtime_error("Passed basegoal with no floating_base!");
+   }
+   else
+   {
+      if (!goals_ptr) throw std::runtime_error("Did not pass either adofgoal or starttraj!");
+      if (p.floating_base && !basegoals_ptr) throw std::runtime_error("Passed floating_base with no basegoal!");
+      if (!p.floating_base && basegoals_ptr) throw std::runtime_error("Passed basegoal with no floating_base!");
+      if (n_runs < 1) throw std::runtime_error("n_runs must be >=1!");
+   }
+   if (sdfs.empty()) throw std::runtime_error("No signed distance fields have yet been computed!");
+   if (p.lambda < 0.01) throw std::runtime_error("lambda must be >=0.01!");
+   if (p.n_points < 3) throw std::runtime_error("n_points must be >=3!");
+   Robot & r = robot(rname);
+   if (!batchmode && adofgoal.size() != r.active_dofs.size())
+      throw std::runtime_error("size of adofgoal does not match active dofs!");
+   int id;
+   if (!batchmode)
+      id = create_batch(rname, p, 1, nullptr, adofgoal.data(), have_basegoal ? basegoal.data() : nullptr, &seed);
+   else
+      id = create_batch(rname, p, n_runs, starts_ptr, goals_ptr, basegoals_ptr, seeds_ptr);
+   std::ostringstream o;
+   o << id;
+   return o.str();
+}
+
+namespace {
+int parse_run(const std::vector<std::string> & argv, int & i, int & run, const char * dup_msg)
+{
+   if (run != 0) throw std::runtime_error(dup_msg);
+   int v = 0;
+   if (std::sscanf(argv[++i].c_str(), "%d", &v) != 1 || v <= 0) throw std::runtime_error("Could not parse r!");
+   run = v;
+   return v;
+}
+}
+
+// src/orcdchomp_mod.cpp:2690-2852
+std::string Module::cmd_iterate(const std::vector<std::string> & argv, bool batchmode)
+{
+   int run = 0, n_iter = 1;
+   double max_time = HUGE_VAL;
+   std::string fileform;
+   bool have_fileform = false;
+   double * costs_ptr = nullptr; int * status_ptr = nullptr;
+   const int argc = (int) argv.size();
+   int i;
+   for (i=1; i<argc; i++)
+   {
+      if (argv[i] == "run" && i+1 < argc) parse_run(argv, i, run, "Only one r can be passed!");
+      else if (argv[i] == "n_iter" && i+1 < argc) n_iter = std::atoi(argv[++i].c_str());
+      else if (argv[i] == "max_time" && i+1 < argc) max_time = std::atof(argv[++i].c_str());
+      else if (argv[i] == "trajs_fileformstr" && i+1 < argc) { fileform = argv[++i]; have_fileform = true; }
+      else if (batchmode && argv[i] == "costs" && i+1 < argc) costs_ptr = (double *) parse_pointer(argv[++i]);
+      else if (batchmode && argv[i] == "status" && i+1 < argc) status_ptr = (int *) parse_pointer(argv[++i]);
+      else break;
+   }
+   if (i < argc) bad_arguments();
+   if (!run) throw std::runtime_error("you must pass a created run!");
+   if (n_iter < 0) throw std::runtime_error("n_iter must be >=0!");
+   Batch & b = batch(run);
+   std::vector<double> costs((size_t) b.n_runs * 3, 0.0);
+   std::vector<int> status(b.n_runs, 0);
+   if (have_fileform && b.params.floating_base)
+      throw std::runtime_error("Error: trajs_fileformstr and floating_base combined is not yet implemented!");
+   if (!have_fileform && max_time == HUGE_VAL)
+   {
+      b.iterate_async(n_iter);
+      b.sync(costs.data(), status.data());
+   }
+   else
+   {
+      // the trajectory dump before each iteration and the time limit need the host
+      // between iterations: one iteration per launch.  Note r->iter restarts at 0 for
+      // every iterate call in the reference (mod.cpp:2752); hmc schedules are planned
+      // per call, so chunking is only offered without use_hmc.
+      if (b.params.use_hmc) throw std::runtime_error("max_time/trajs_fileformstr with use_hmc is not supported by this build");
+      const auto t0 = std::chrono::steady_clock::now();
+      std::vector<double> traj((size_t) b.n_runs * b.n_points * b.n);
+      for (int it=0; it<n_iter; it++)
+      {
+         if (have_fileform)
+         {
+            b.gettraj(traj.data());
+            char fname[1024];
+            std::snprintf(fname, sizeof(fname), fileform.c_str(), it);
+            std::ofstream f(fname);
+            f << serialize_traj(b.robot_name, b.adofindices, traj.data(), b.n_points, b.n, 0);
+         }
+         b.iterate_async(1);
+         b.sync(costs.data(), status.data());
+         if (status[0] != 0) break;
+         const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+         if (el > max_time) break;
+      }
+      if (n_iter == 0) { b.iterate_async(0); b.sync(costs.data(), status.data()); }
+   }
+   if (costs_ptr) std::memcpy(costs_ptr, costs.data(), costs.size() * sizeof(double));
+   if (status_ptr) std::memcpy(status_ptr, status.data(), status.size() * sizeof(int));
+   if (!batchmode)
+      for (int k=0; k<b.n_runs; k++)
+         if (status[k] == -1) throw std::runtime_error("Resulting trajectory is outside of joint limits!");
+   std::ostringstream o;
+   o << costs[0];                                                   // sout << cost_total (mod.cpp:2849)
+   return o.str();
+}
+
+// src/orcdchomp_mod.cpp:2854-3011
+std::string Module::cmd_gettraj(const std::vector<std::string> & argv, bool batchmode)
+{
+   int run = 0;
+   double * out_ptr = nullptr;
+   const int argc = (int) argv.size();
+   int i;
+   for (i=1; i<argc; i++)
+   {
+      if (argv[i] == "run" && i+1 < argc) parse_run(argv, i, run, "Only one r can be passed!");
+      else if (argv[i] == "no_collision_check") { }
+      else if (argv[i] == "no_collision_exception") { }
+      else if (argv[i] == "no_collision_details") { }
+      else if (batchmode && argv[i] == "out" && i+1 < argc) out_ptr = (double *) parse_pointer(argv[++i]);
+      else break;
+   }
+   if (i < argc) bad_arguments();
+   if (!run) throw std::runtime_error("you must pass a created run!");
+   Batch & b = batch(run);
+   std::vector<double> traj((size_t) b.n_runs * b.n_points * b.n);
+   b.gettraj(traj.data());
+   if (batchmode)
+   {
+      if (!out_ptr) throw std::runtime_error("gettrajbatch needs out %p!");
+      std::memcpy(out_ptr, traj.data(), traj.size() * sizeof(double));
+      return "";
+   }
+   // active dof columns only (mod.cpp:2899-2903)
+   return serialize_traj(b.robot_name, b.adofindices, traj.data(), b.n_points, b.n, b.params.floating_base ? 7 : 0);
+}
+
+// src/orcdchomp_mod.cpp:3013-3037
+std::string Module::cmd_destroy(const std::vector<std::string> & argv)
+{
+   int run = 0;
+   const int argc = (int) argv.size();
+   int i;
+   for (i=1; i<argc; i++)
+   {
+      if (argv[i] == "run" && i+1 < argc) parse_run(argv, i, run, "Only one run can be passed!");
+      else break;
+   }
+   if (i < argc) bad_arguments();
+   if (!run) throw std::runtime_error("you must pass a created run!");
+   destroy_batch(run);
+   return "";
+}
+
+} // namespace orc

@@ -1,0 +1,179 @@
+// module.h -- host side of the MI355X-native orcdchomp module.
+//
+// Mirrors class mod of the reference (src/orcdchomp_mod.h:38-90): the module owns
+// the list of signed distance fields and the runs, and exposes the same commands
+// through SendCommand.  OpenRAVE's environment (robots, kinbodies, transforms) is
+// third party; the pieces of it the hot path reads are held here explicitly.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+#include "dev_types.h"
+#include "host_math.h"
+
+namespace orc {
+
+struct Robot                      // what the path reads from an OpenRAVE::RobotBase
+{
+   std::string name;
+   int n_links = 0;
+   std::vector<int> parent;
+   std::vector<Pose> pose_parent_joint;
+   std::vector<int> joint_type;
+   std::vector<double> axis;      // [n_links][3]
+   std::vector<int> dof_index;
+   int n_dof = 0;
+   std::vector<double> limit_lower, limit_upper;
+   struct Sphere { int link; double pos[3]; double radius; };   // struct sphere, src/orcdchomp_kdata.h:33-39
+   std::vector<Sphere> spheres;   // XML order
+   // state
+   Pose transform;
+   std::vector<double> dof_values;
+   std::vector<int> active_dofs;
+   bool does_affect(int dof, int link) const;
+   // world frames of all links for the given state
+   void fk(const Pose & base, const std::vector<double> & q, std::vector<Xform> & frames) const;
+};
+
+struct KinBody                    // box-only kinbody (InitFromBoxes style)
+{
+   std::string name;
+   Pose transform;
+   bool enabled = true;
+   struct B { Pose pose; double half[3]; };
+   std::vector<B> boxes;
+};
+
+struct Sdf                        // struct sdf, src/orcdchomp_mod.cpp:148-153
+{
+   std::string kinbody_name;
+   Pose pose;                     // grid wrt kinbody frame
+   Grid grid;
+   // device copies, created on demand
+   double * d_data64 = nullptr;
+   float * d_data32 = nullptr;
+};
+
+struct BatchParams
+{
+   int n_points = 101;
+   int floating_base = 0;
+   double lambda = 10.0;
+   int derivative = 1;
+   int use_momentum = 0;
+   int use_hmc = 0;
+   double hmc_resample_lambda = 0.02;
+   double epsilon = 0.1, epsilon_self = 0.04, obs_factor = 200.0, obs_factor_self = 10.0;
+   int precision = 64;
+};
+
+class Module;
+
+// n_runs independent runs sharing robot, fields and parameters
+// (struct run, src/orcdchomp_mod.cpp:887-966, once per run in the reference)
+class Batch
+{
+public:
+   Batch(Module * mod, const Robot & robot, const BatchParams & p, int n_runs,
+      const double * starts, const double * goals, const double * basegoals, const unsigned int * seeds);
+   ~Batch();
+   void iterate_async(int n_iter);
+   void sync(double * costs_out, int * status_out);
+   void gettraj(double * out);
+   void get_state(const std::string & which, double * out);
+   void get_trace(double * out);
+   void set_noise(const double * noise, int n_blocks);
+
+   int n_runs, n_points, n, m;
+   BatchParams params;
+   int last_n_iter = 0;
+   std::string robot_name;
+   std::vector<int> adofindices;
+   std::vector<int> device_sphere_order;    // XML index of device sphere k
+private:
+   template <typename real> void build_device(const Robot & robot);
+   template <typename real> void launch(int n_iter);
+   void plan_hmc(int n_iter);
+   Module * mod_;
+   Metric metric_;
+   // device buffers (typed by params.precision)
+   void * d_model_ = nullptr; void * d_sdfs_ = nullptr;
+   void * d_traj_ = nullptr; void * d_AG_ = nullptr; void * d_G_ = nullptr;
+   double * d_costs_ = nullptr; double * d_trace_ = nullptr; size_t trace_cap_ = 0;
+   int * d_status_ = nullptr; int * d_leap_ = nullptr;
+   void * d_Aband_ = nullptr; void * d_beta_s_ = nullptr; void * d_beta_g_ = nullptr;
+   void * d_pcr_ = nullptr; void * d_Ainv_ = nullptr; void * d_jl_lo_ = nullptr; void * d_jl_hi_ = nullptr;
+   int * d_hmc_iters_ = nullptr; void * d_noise_ = nullptr; size_t hmc_cap_iters_ = 0, noise_cap_ = 0;
+   int max_resamples_ = 0;
+   int n_sdfs_ = 0;
+   int nj_ = 0, Sa_ = 0;
+   int tile_m_ = 0;
+   size_t lds_bytes_ = 0;
+   std::vector<double> jl_lo_, jl_hi_;
+   // hmc host state per run (src/orcdchomp_mod.cpp:948-952)
+   std::vector<GslRng> rng_;
+   std::vector<int> hmc_resample_iter_;
+   std::vector<double> ext_noise_; int ext_noise_blocks_ = 0;
+};
+
+class Module
+{
+public:
+   explicit Module(int device);
+   ~Module();
+   // the SendCommand surface (src/orcdchomp_mod.h:58-66); throws std::runtime_error
+   // with the reference's message strings
+   std::string send_command(const std::string & cmd);
+
+   // environment stand-ins
+   void add_robot(const Robot & r);
+   Robot & robot(const std::string & name);
+   void add_kinbody(const KinBody & k);
+   KinBody & kinbody(const std::string & name);
+   bool has_body(const std::string & name) const;
+   Pose body_transform(const std::string & name) const;   // robot or kinbody
+
+   // fields
+   void add_sdf(const std::string & kinbody, const Grid & sdf, const Pose & pose_kinbody_gsdf);
+   Sdf * find_sdf(const std::string & kinbody);
+   std::vector<std::unique_ptr<Sdf>> sdfs;
+
+   // batches
+   int create_batch(const std::string & robot, const BatchParams & p, int n_runs,
+      const double * starts, const double * goals, const double * basegoals, const unsigned int * seeds);
+   Batch & batch(int id);
+   void destroy_batch(int id);
+
+   hipStream_t stream = nullptr;
+   int device;
+   // kernel timing (HIP events on `stream`)
+   void time_begin();
+   void time_end();
+   void time_collect();
+   double kernel_ms_total = 0.0;
+   int kernel_launches = 0;
+   std::string last_error;
+   std::string last_reply;
+
+private:
+   std::string cmd_computedistancefield(const std::vector<std::string> & argv);
+   std::string cmd_addfield_fromobsarray(const std::vector<std::string> & argv);
+   std::string cmd_removefield(const std::vector<std::string> & argv);
+   std::string cmd_create(const std::vector<std::string> & argv, bool batch);
+   std::string cmd_iterate(const std::vector<std::string> & argv, bool batch);
+   std::string cmd_gettraj(const std::vector<std::string> & argv, bool batch);
+   std::string cmd_destroy(const std::vector<std::string> & argv);
+   std::map<std::string, Robot> robots_;
+   std::map<std::string, KinBody> kinbodies_;
+   std::map<int, std::unique_ptr<Batch>> batches_;
+   int next_batch_id_ = 1;
+   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events_;
+   std::vector<hipEvent_t> event_pool_;
+   hipEvent_t ev_begin_ = nullptr;
+};
+
+void hip_check(hipError_t e, const char * what);
+
+} // namespace orc

@@ -1,0 +1,206 @@
+"""Host-side Python mirror of the orcdchomp module object.
+
+``Module.SendCommand`` takes the same command strings as the reference's OpenRAVE
+module (/root/reference src/orcdchomp_mod.h:58-66) and returns the same text;
+errors surface as ``RuntimeError`` carrying the reference's exception message
+(openravepy turns openrave_exception into a Python exception the same way).
+Everything is executed by liborcdchomp_amd.so through its C ABI.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+
+
+def _dp(a):
+    return a.ctypes.data_as(_capi.c_double_p)
+
+
+def _ip(a):
+    return a.ctypes.data_as(_capi.c_int_p)
+
+
+def _f64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+class Module:
+    def __init__(self, device=0):
+        self._lib = _capi.lib()
+        self._h = self._lib.orc_module_new(int(device))
+        if not self._h:
+            raise RuntimeError(self._lib.orc_last_error(None).decode())
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.orc_module_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError(self._lib.orc_last_error(self._h).decode())
+
+    # ---- the reference's surface ------------------------------------------------
+    def SendCommand(self, cmd, releasegil=False):
+        buf = C.create_string_buffer(4096)
+        self._check(self._lib.orc_send_command(self._h, cmd.encode(), buf, len(buf)))
+        size = self._lib.orc_last_reply_size(self._h)
+        if size >= len(buf):
+            big = C.create_string_buffer(size + 1)
+            self._lib.orc_last_reply(self._h, big, len(big))
+            return big.value.decode()
+        return buf.value.decode()
+
+    def set_stream(self, hip_stream):
+        self._check(self._lib.orc_set_stream(self._h, C.c_void_p(hip_stream)))
+
+    # ---- environment stand-ins -----------------------------------------------------
+    def add_robot(self, model, transform=None, dof_values=None, active_dofs=None):
+        a = model.arrays()
+        d = _capi.RobotDesc()
+        d.n_links = a["n_links"]
+        d.parent = _ip(a["parent"]); d.pose_parent_joint = _dp(a["pose_parent_joint"])
+        d.joint_type = _ip(a["joint_type"]); d.axis = _dp(a["axis"]); d.dof_index = _ip(a["dof_index"])
+        d.n_dof = a["n_dof"]
+        d.limit_lower = _dp(a["limit_lower"]); d.limit_upper = _dp(a["limit_upper"])
+        d.n_spheres = a["n_spheres"]
+        d.sphere_link = _ip(a["sphere_link"]); d.sphere_pos = _dp(a["sphere_pos"])
+        d.sphere_radius = _dp(a["sphere_radius"])
+        self._check(self._lib.orc_env_add_robot(self._h, model.name.encode(), C.byref(d)))
+        if transform is not None:
+            self.set_robot_transform(model.name, transform)
+        if dof_values is not None:
+            self.set_dof_values(model.name, dof_values)
+        if active_dofs is not None:
+            self.set_active_dofs(model.name, active_dofs)
+
+    def set_robot_transform(self, name, pose):
+        self._check(self._lib.orc_robot_set_transform(self._h, name.encode(), _dp(_f64(pose))))
+
+    def set_dof_values(self, name, values):
+        v = _f64(values)
+        self._check(self._lib.orc_robot_set_dof_values(self._h, name.encode(), _dp(v), len(v)))
+
+    def set_active_dofs(self, name, indices):
+        idx = np.ascontiguousarray(indices, dtype=np.int32)
+        self._check(self._lib.orc_robot_set_active_dofs(self._h, name.encode(), _ip(idx), len(idx)))
+
+    def add_kinbody_boxes(self, name, boxes, transform=None):
+        """boxes: list of (pose7, half_extents3) in the kinbody frame."""
+        poses = _f64([b[0] for b in boxes]).reshape(-1, 7)
+        halfs = _f64([b[1] for b in boxes]).reshape(-1, 3)
+        self._check(self._lib.orc_env_add_kinbody_boxes(self._h, name.encode(), len(boxes), _dp(poses), _dp(halfs)))
+        if transform is not None:
+            self.set_kinbody_transform(name, transform)
+
+    def set_kinbody_transform(self, name, pose):
+        self._check(self._lib.orc_kinbody_set_transform(self._h, name.encode(), _dp(_f64(pose))))
+
+    def enable_kinbody(self, name, enabled=True):
+        self._check(self._lib.orc_kinbody_enable(self._h, name.encode(), 1 if enabled else 0))
+
+    # ---- fields ---------------------------------------------------------------------
+    def add_sdf(self, kinbody, data, lengths, pose_kinbody_gsdf):
+        data = _f64(data)
+        sizes = np.asarray(data.shape, dtype=np.int32)
+        self._check(self._lib.orc_scene_add_sdf(self._h, kinbody.encode(), _ip(sizes), _dp(_f64(lengths)),
+                                                _dp(_f64(pose_kinbody_gsdf)), _dp(data)))
+
+    def get_sdf(self, kinbody):
+        sizes = np.zeros(3, dtype=np.int32); lengths = np.zeros(3); pose = np.zeros(7)
+        self._check(self._lib.orc_scene_get_sdf(self._h, kinbody.encode(), _ip(sizes), _dp(lengths), _dp(pose), None, 0))
+        data = np.zeros(tuple(int(s) for s in sizes))
+        self._check(self._lib.orc_scene_get_sdf(self._h, kinbody.encode(), _ip(sizes), _dp(lengths), _dp(pose),
+                                                _dp(data), data.size))
+        return data, lengths, pose
+
+    # ---- kernel-level batch API -------------------------------------------------------
+    def batch_params(self, **kw):
+        p = _capi.BatchParams()
+        self._lib.orc_batch_params_default(C.byref(p))
+        for k, v in kw.items():
+            if k in ("lambda", "lambda_"):
+                p.lambda_ = v
+            elif k == "D":
+                p.derivative = v
+            else:
+                if not hasattr(p, k):
+                    raise TypeError("unknown batch parameter %s" % k)
+                setattr(p, k, v)
+        return p
+
+    def batch_create(self, robot, goals, starts=None, basegoals=None, seeds=None, **params):
+        p = self.batch_params(**params)
+        goals = _f64(goals)
+        goals = goals.reshape(1, -1) if goals.ndim == 1 else goals
+        n_runs = goals.shape[0]
+        st = None if starts is None else _f64(starts)
+        bg = None if basegoals is None else _f64(basegoals)
+        sd = None if seeds is None else np.ascontiguousarray(seeds, dtype=np.uint32)
+        bid = C.c_int(0)
+        self._check(self._lib.orc_batch_create(
+            self._h, robot.encode(), C.byref(p), n_runs,
+            None if st is None else _dp(st), _dp(goals), None if bg is None else _dp(bg),
+            None if sd is None else sd.ctypes.data_as(_capi.c_uint_p), C.byref(bid)))
+        return bid.value
+
+    def batch_dims(self, bid):
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        self._check(self._lib.orc_batch_dims(self._h, bid, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def batch_iterate(self, bid, n_iter):
+        n_runs = self.batch_dims(bid)[0]
+        costs = np.zeros((n_runs, 3)); status = np.zeros(n_runs, dtype=np.int32)
+        self._check(self._lib.orc_batch_iterate(self._h, bid, n_iter, _dp(costs), _ip(status)))
+        return costs, status
+
+    def batch_iterate_async(self, bid, n_iter):
+        self._check(self._lib.orc_batch_iterate_async(self._h, bid, n_iter))
+
+    def batch_sync(self, bid, fetch=True):
+        if not fetch:
+            self._check(self._lib.orc_batch_sync(self._h, bid, None, None))
+            return None
+        n_runs = self.batch_dims(bid)[0]
+        costs = np.zeros((n_runs, 3)); status = np.zeros(n_runs, dtype=np.int32)
+        self._check(self._lib.orc_batch_sync(self._h, bid, _dp(costs), _ip(status)))
+        return costs, status
+
+    def batch_trace(self, bid, n_iter):
+        n_runs = self.batch_dims(bid)[0]
+        tr = np.zeros((n_runs, n_iter, 3))
+        self._check(self._lib.orc_batch_get_trace(self._h, bid, _dp(tr), tr.size))
+        return tr
+
+    def batch_set_noise(self, bid, noise):
+        noise = _f64(noise)
+        self._check(self._lib.orc_batch_set_noise(self._h, bid, _dp(noise), noise.shape[1]))
+
+    def batch_gettraj(self, bid):
+        n_runs, n_points, n = self.batch_dims(bid)
+        out = np.zeros((n_runs, n_points, n))
+        self._check(self._lib.orc_batch_gettraj(self._h, bid, _dp(out), out.size))
+        return out
+
+    def batch_state(self, bid, which):
+        n_runs, n_points, n = self.batch_dims(bid)
+        out = np.zeros((n_runs, n_points - 2, n))
+        self._check(self._lib.orc_batch_get_state(self._h, bid, which.encode(), _dp(out), out.size))
+        return out
+
+    def batch_destroy(self, bid):
+        self._check(self._lib.orc_batch_destroy(self._h, bid))
+
+    def kernel_time(self, reset=False):
+        ms = C.c_double(); n = C.c_int()
+        self._check(self._lib.orc_kernel_time(self._h, C.byref(ms), C.byref(n), 1 if reset else 0))
+        return ms.value, n.value
