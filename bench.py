@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py -- CHOMP iterations/sec on MI355X for the BASELINE.json workload.
+
+  python bench.py --gpus N --steps K --warmup W
+
+A *step* is one `iterate` of the hot path over one batch: n_iter=100 CHOMP
+iterations (costs every iteration, final cost pass included) of `--batch` WAM-7
+runs with 100 waypoints each (BASELINE.json configs[1]: WAM 7-DOF, n_points=100,
+batch=1024 random adofgoal, fp64).  Every step works on its own freshly seeded
+batch (created before the timed region), so all steps do identical work; the
+trajectories are resident in HBM when the timed region starts.  For N > 1 every
+rank owns `--batch` runs with its own goals (weak scaling, no data-path
+collective: the runs are independent).
+
+Rank 0 prints ONE JSON line; see the task contract for the fields.  `roofline`
+prices the fused iterate kernel against HBM with the ALGORITHMIC bytes of
+SURVEY.md 8(d) (58 040 B per iteration per run for this workload); the kernel
+duration is measured live with HIP events on the stream the kernel is launched
+on.  `cpu_baseline` times the oracle (oracle/, a CPU restatement of the reference)
+on the host cores over a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+N_POINTS = 100
+N_ITER = 100
+LAMBDA = 100.0
+OBS_FACTOR = 500.0
+HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def algorithmic_bytes_per_iter(m, n, Sa, n_sdf, w, momentum):
+    """2 m n w (T) [+ 2 m n w momentum] + m Sa Nsdf 4 w (SDF gathers) + 3 w (costs)."""
+    return 2 * m * n * w + (2 * m * n * w if momentum else 0) + m * Sa * n_sdf * 4 * w + 3 * w
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=1024, help="runs per GPU (configs[1]: 1024)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-runs", type=int, default=0, help="override the cpu baseline sample size")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import or_cdchomp_amd
+    import common
+
+    mod = or_cdchomp_amd.Module(local_rank)
+    model = common.setup_product_wam(mod)
+    n_runs = args.batch
+    kw = dict(n_points=N_POINTS, lambda_=LAMBDA, obs_factor=OBS_FACTOR)
+
+    def make_batches(count, seed0):
+        ids = []
+        for k in range(count):
+            goals = common.wam_goals(n_runs, seed=seed0 + 1000 * rank + k)
+            ids.append(mod.batch_create(model.name, goals, **kw))
+        return ids
+
+    warm = make_batches(args.warmup, 30250101)
+    timed = make_batches(args.steps, 20250101)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for bid in warm:
+        mod.batch_iterate_async(bid, N_ITER)
+    for bid in warm:
+        mod.batch_sync(bid)
+    mod.kernel_time(reset=True)
+
+    barrier()
+    t0 = time.perf_counter()
+    for bid in timed:
+        mod.batch_iterate_async(bid, N_ITER)
+    results = [mod.batch_sync(bid) for bid in timed]      # costs + status come back with iterate
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kernel_ms, launches = mod.kernel_time()
+    status_bad = int(sum(int((st != 0).sum()) for _, st in results))
+
+    # ---- parity spot check against the oracle on the first timed batch (untimed) ----
+    parity = None
+    cpu = None
+    if rank == 0:
+        from oracle import oracle_py as O
+        O.build(ref=False)
+        prob = common.tabletop_problem(O)
+        rob = O.OraRobot(model)
+        _, base, dofvals, adofs = common.wam_state()
+        p = O.default_params(**kw)
+        goals0 = common.wam_goals(n_runs, seed=20250101)
+        traj0 = mod.batch_gettraj(timed[0])
+        k_check = min(4, n_runs)
+        otraj, ocosts, ost, _ = O.batch_run(rob, base, dofvals, adofs, goals0[:k_check], [prob["sdf"]],
+                                            [prob["pose"]], p, N_ITER, max_threads=k_check)
+        parity = max(common.rel_l2(traj0[k], otraj[k]) for k in range(k_check))
+
+        if not args.no_cpu_baseline:
+            cores = os.cpu_count() or 1
+            # ~0.1 s per run (100 iterations) on one core; aim for 10-20 s of wall time
+            sample = args.cpu_runs or int(min(n_runs, max(8, 128 * cores // 1)))
+            sample = min(sample, n_runs)
+            c0 = time.perf_counter()
+            _, _, _, threads = O.batch_run(rob, base, dofvals, adofs, goals0[:sample], [prob["sdf"]],
+                                           [prob["pose"]], p, N_ITER, max_threads=0)
+            c1 = time.perf_counter()
+            cpu = {"value": sample * N_ITER / (c1 - c0), "unit": "CHOMP iterations/s", "cores": int(threads),
+                   "kind": "port",
+                   "sample": "%d of the %d runs of step 0 x %d iterations, oracle (C restatement of libcd + "
+                             "sphere cost, dense A^-1 as the reference), OpenMP over runs, %.1f s wall"
+                             % (sample, n_runs, N_ITER, c1 - c0)}
+
+    if rank == 0:
+        total_iters = float(world) * n_runs * N_ITER * args.steps
+        value = total_iters / elapsed
+        m, n, Sa = N_POINTS - 2, 7, 15
+        bytes_iter = algorithmic_bytes_per_iter(m, n, Sa, 1, 8, False)
+        avg_ms = kernel_ms / max(launches, 1)
+        bytes_launch = bytes_iter * n_runs * N_ITER
+        achieved = bytes_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("batch") == n_runs and tj.get("n_iter") == N_ITER:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "CHOMP iters/sec, 7-DOF x 100-waypoint",
+            "value": value,
+            "unit": "CHOMP iterations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "WAM 7-DOF, n_points=100, batch=%d random adofgoal per GPU, n_iter=%d per step, "
+                                   "lambda=100 obs_factor=500, tabletop SDF 40x31x12 (BASELINE configs[1])"
+                                   % (n_runs, N_ITER),
+                       "runs_per_gpu": n_runs, "n_iter": N_ITER, "n_points": N_POINTS, "dof": 7,
+                       "parallelism": "runs sharded over %d GPU(s), no collective" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "kernel": "chomp_iterate_kernel<double>", "avg_kernel_ms": avg_ms, "launches": launches,
+                         "algorithmic_bytes_per_launch": bytes_launch,
+                         "algorithmic_bytes_per_iteration_per_run": bytes_iter},
+            "cpu_baseline": cpu,
+            "parity_rel_l2_max_vs_oracle": parity,
+            "runs_outside_joint_limits": status_bad,
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
