@@ -105,14 +105,14 @@ def main():
     results = [mod.batch_sync(bid) for bid in timed]      # costs + status come back with iterate
     barrier()
     t1 = time.perf_counter()
-    elapsed = t1 - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    from or_cdchomp_amd import sharding
+    elapsed = sharding.max_over_ranks(t1 - t0, dist)
 
     kernel_ms, launches = mod.kernel_time()
-    status_bad = int(sum(int((st != 0).sum()) for _, st in results))
+    # host-side gather of the per-run verdicts of all ranks (untimed; gloo, no RCCL data path)
+    local = {"status": np.concatenate([st for _, st in results]), "costs": np.concatenate([c for c, _ in results])}
+    whole = sharding.gather_host(local, dist, sharding.host_group(dist))
+    status_bad = int((whole["status"] != 0).sum()) if whole is not None else 0
 
     # ---- parity spot check against the oracle on the first timed batch (untimed) ----
     parity = None

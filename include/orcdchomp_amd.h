@@ -151,6 +151,27 @@ int orc_batch_destroy(orc_module * mod, int batch_id);
  * measured with HIP events on the module's stream; count of launches */
 int orc_kernel_time(orc_module * mod, double * total_ms, int * launches, int reset);
 
+/* ---- host utilities (no GPU needed) -------------------------------------------
+ * the host-side numerics of the path, callable on their own */
+/* occupancy (0.0 free, HUGE_VAL obstacle) -> signed distance field, positive outside:
+ * replaces cd_grid_double_bin_sdf (src/libcd/grid.c:637-687) */
+int orc_host_bin_sdf(const int sizes[3], const double lengths[3], const double * occupancy, double * sdf_out);
+/* flood fill from cell `start`, 1.0 -> 0.0, axis neighbours: replaces cd_grid_flood_fill with
+ * replace_1_to_0 (src/libcd/grid_flood.c:30-111, src/orcdchomp_mod.cpp:160-168); in place */
+int orc_host_flood_fill(const int sizes[3], double * cells, size_t start);
+/* tokenizer of the command grammar: replaces cd_util_shparse (src/libcd/util_shparse.c:37-128).
+ * tokens are written NUL-separated into out; returns the token count or -1 if out is too small */
+int orc_host_shparse(const char * in, char * out, size_t out_cap);
+/* smoothness metric of cd_chomp_init (src/libcd/chomp.c:239-340, 393-403) in the form the
+ * kernels use: dense A [m][m], endpoint couplings beta_s/beta_g [m], kappa[3] = kss ksg kgg
+ * (trC), and A^-1 applied to rhs [m][ncols] by the same cyclic-reduction tables (D=1) or dense
+ * inverse (D>=2) the device uses; any output may be NULL */
+int orc_host_metric(int m, int derivative, double dt, double * A_out, double * beta_s_out, double * beta_g_out,
+   double kappa_out[3], const double * rhs, int ncols, double * solve_out);
+/* GSL's default generator restated (src/orcdchomp_mod.cpp:2303-2304,2763,2767): n gaussians with
+ * the given sigma from seed, then one uniform; out_gauss[n], out_uniform[1] */
+int orc_host_gsl_stream(unsigned long seed, double sigma, int n, double * out_gauss, double * out_uniform);
+
 #ifdef __cplusplus
 }
 #endif

@@ -62,6 +62,12 @@ SYMBOLS = [
     ("orc_batch_dims", C.c_int, [C.c_void_p, C.c_int, c_int_p, c_int_p, c_int_p]),
     ("orc_batch_destroy", C.c_int, [C.c_void_p, C.c_int]),
     ("orc_kernel_time", C.c_int, [C.c_void_p, c_double_p, c_int_p, C.c_int]),
+    ("orc_host_bin_sdf", C.c_int, [c_int_p, c_double_p, c_double_p, c_double_p]),
+    ("orc_host_flood_fill", C.c_int, [c_int_p, c_double_p, C.c_size_t]),
+    ("orc_host_shparse", C.c_int, [C.c_char_p, C.c_char_p, C.c_size_t]),
+    ("orc_host_metric", C.c_int, [C.c_int, C.c_int, C.c_double, c_double_p, c_double_p, c_double_p, c_double_p,
+                                  c_double_p, C.c_int, c_double_p]),
+    ("orc_host_gsl_stream", C.c_int, [C.c_ulong, C.c_double, C.c_int, c_double_p, c_double_p]),
 ]
 
 _LIB = None

@@ -295,4 +295,99 @@ int orc_kernel_time(orc_module * mod, double * total_ms, int * launches, int res
    });
 }
 
+int orc_host_bin_sdf(const int sizes[3], const double lengths[3], const double * occupancy, double * sdf_out)
+{
+   try
+   {
+      orc::Grid occ, sdf;
+      for (int i=0; i<3; i++) { occ.sizes[i] = sizes[i]; occ.lengths[i] = lengths[i]; }
+      occ.data.assign(occupancy, occupancy + occ.ncells());
+      orc::grid_bin_sdf(occ, sdf);
+      std::memcpy(sdf_out, sdf.data.data(), sdf.ncells() * sizeof(double));
+      return 0;
+   }
+   catch (...) { return 1; }
+}
+
+int orc_host_flood_fill(const int sizes[3], double * cells, size_t start)
+{
+   try
+   {
+      orc::Grid g;
+      for (int i=0; i<3; i++) { g.sizes[i] = sizes[i]; g.lengths[i] = 1.0; }
+      g.data.assign(cells, cells + g.ncells());
+      orc::grid_flood_1_to_0(g, start);
+      std::memcpy(cells, g.data.data(), g.ncells() * sizeof(double));
+      return 0;
+   }
+   catch (...) { return 1; }
+}
+
+int orc_host_shparse(const char * in, char * out, size_t out_cap)
+{
+   const std::vector<std::string> toks = orc::shparse(in ? in : "");
+   size_t need = 0;
+   for (const std::string & t : toks) need += t.size() + 1;
+   if (need > out_cap) return -1;
+   size_t off = 0;
+   for (const std::string & t : toks) { std::memcpy(out + off, t.c_str(), t.size() + 1); off += t.size() + 1; }
+   return (int) toks.size();
+}
+
+int orc_host_metric(int m, int derivative, double dt, double * A_out, double * beta_s_out, double * beta_g_out,
+   double kappa_out[3], const double * rhs, int ncols, double * solve_out)
+{
+   try
+   {
+      orc::Metric M;
+      orc::build_metric(m, derivative, dt, M);
+      if (A_out) std::memcpy(A_out, M.Adense.data(), (size_t) m*m*sizeof(double));
+      if (beta_s_out) std::memcpy(beta_s_out, M.beta_s.data(), m*sizeof(double));
+      if (beta_g_out) std::memcpy(beta_g_out, M.beta_g.data(), m*sizeof(double));
+      if (kappa_out) { kappa_out[0] = M.kss; kappa_out[1] = M.ksg; kappa_out[2] = M.kgg; }
+      if (rhs && solve_out)
+      {
+         const int n = ncols;
+         if (derivative == 1)
+         {
+            // the device's cyclic reduction, executed serially with the same tables
+            std::vector<double> cur(rhs, rhs + (size_t) m*n), nxt((size_t) m*n);
+            int stride = 1;
+            for (int l=0; l<M.pcr_levels; l++)
+            {
+               const double * ka = &M.pcr[(size_t)(2*l)*m]; const double * kc = ka + m;
+               for (int i=0; i<m; i++) for (int c=0; c<n; c++)
+               {
+                  double d = cur[(size_t) i*n+c];
+                  if (i-stride >= 0) d += ka[i] * cur[(size_t)(i-stride)*n+c];
+                  if (i+stride < m)  d += kc[i] * cur[(size_t)(i+stride)*n+c];
+                  nxt[(size_t) i*n+c] = d;
+               }
+               cur.swap(nxt);
+               stride <<= 1;
+            }
+            const double * invb = &M.pcr[(size_t)(2*M.pcr_levels)*m];
+            for (int i=0; i<m; i++) for (int c=0; c<n; c++) solve_out[(size_t) i*n+c] = cur[(size_t) i*n+c] * invb[i];
+         }
+         else
+            for (int i=0; i<m; i++) for (int c=0; c<n; c++)
+            {
+               double s = 0.0;
+               for (int k=0; k<m; k++) s += M.Ainv[(size_t) i*m+k] * rhs[(size_t) k*n+c];
+               solve_out[(size_t) i*n+c] = s;
+            }
+      }
+      return 0;
+   }
+   catch (...) { return 1; }
+}
+
+int orc_host_gsl_stream(unsigned long seed, double sigma, int n, double * out_gauss, double * out_uniform)
+{
+   orc::GslRng r(seed);
+   for (int i=0; i<n; i++) out_gauss[i] = r.gaussian(sigma);
+   if (out_uniform) out_uniform[0] = r.uniform();
+   return 0;
+}
+
 } // extern "C"

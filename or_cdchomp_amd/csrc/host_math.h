@@ -1,6 +1,6 @@
 // host_math.h -- host-side numerics of the product path: poses, grids, the
 // signed-distance-field build, the smoothness metric tables, GSL's noise stream.
-// (The oracle under oracle/ is test infrastructure and is never linked here.)
+// (The test-only CPU restatement of the reference is never linked into this library.)
 #pragma once
 #include <cmath>
 #include <cstddef>
