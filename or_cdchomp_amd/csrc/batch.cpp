@@ -372,6 +372,9 @@ void Batch::build_device(const Robot & robot)
          hs[i].tgw[q] = (real) pose_gsdf_world.v[q];
          hs[i].size[q] = s.grid.sizes[q];
          hs[i].length[q] = (real) s.grid.lengths[q];
+         hs[i].inv_length[q] = (real)(1.0 / s.grid.lengths[q]);
+         hs[i].cell[q] = (real)(s.grid.lengths[q] / s.grid.sizes[q]);
+         hs[i].size_over_len[q] = (real)(s.grid.sizes[q] / s.grid.lengths[q]);
       }
       hs[i].pad = 0;
    }

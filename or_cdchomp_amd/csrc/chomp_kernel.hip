@@ -44,6 +44,68 @@ template <> struct M<float>
    static __device__ __forceinline__ float inf() { return __int_as_float(0x7f800000); }
 };
 
+// 1/x and (sqrt(x), 1/sqrt(x)) from the hardware seeds plus Newton/Goldschmidt steps:
+// ~1 ulp, a third of the instructions of the IEEE division / sqrt expansions.
+__device__ __forceinline__ double rcp_fast(double x)
+{
+   double r = __builtin_amdgcn_rcp(x);
+   r = fma(fma(-x, r, 1.0), r, r);
+   r = fma(fma(-x, r, 1.0), r, r);
+   return r;
+}
+__device__ __forceinline__ float rcp_fast(float x) { return 1.0f / x; }
+// returns sqrt(x); *inv = 1/sqrt(x).  x == 0 gives 0 and inf.
+__device__ __forceinline__ double sqrt_rsq(double x, double * inv)
+{
+   double r = __builtin_amdgcn_rsq(x);
+   double g = x * r, h = 0.5 * r;
+#pragma unroll
+   for (int k=0; k<2; k++)
+   {
+      const double e = fma(-h, g, 0.5);
+      g = fma(g, e, g);
+      h = fma(h, e, h);
+   }
+   const double d = fma(-g, g, x);
+   g = fma(d, h, g);
+   const bool zero = !(x > 0.0);
+   *inv = zero ? M<double>::inf() : 2.0 * h;
+   return zero ? 0.0 : g;
+}
+__device__ __forceinline__ float sqrt_rsq(float x, float * inv)
+{
+   const float g = ::sqrtf(x);
+   *inv = 1.0f / g;
+   return g;
+}
+
+// sum over aligned groups of GS lanes (GS a power of two <= 64); every lane of the group
+// receives the total.  Up to 16 lanes stay inside a DPP row (no LDS pipe).
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v)
+{
+   int lo = __double2loint(v), hi = __double2hiint(v);
+   lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+   hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+   return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v)
+{
+   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <typename real>
+__device__ __forceinline__ real group_sum(real v, int GS)
+{
+   if (GS >= 2)  v += dpp_move<0xB1>(v);      // quad_perm [1,0,3,2]
+   if (GS >= 4)  v += dpp_move<0x4E>(v);      // quad_perm [2,3,0,1]
+   if (GS >= 8)  v += dpp_move<0x141>(v);     // row_half_mirror
+   if (GS >= 16) v += dpp_move<0x140>(v);     // row_mirror
+   if (GS >= 32) v += __shfl_xor(v, 16, 64);
+   if (GS >= 64) v += __shfl_xor(v, 32, 64);
+   return v;
+}
+
 template <typename real>
 struct Frame { real R[9]; real t[3]; };
 
@@ -82,25 +144,27 @@ __device__ __forceinline__ double block_sum(double v, double * red)
 template <typename real>
 __device__ __forceinline__ int sdf_lookup(const DevSdf<real> & f, const real p[3], real & value, real grad[3])
 {
+   // the reference divides (x = p/len, centre = (0.5+sub)/size*len, slope = diff*size/len);
+   // here the three quotients per axis are host-precomputed reciprocals (<= 1 ulp apart)
    int sub[3];
 #pragma unroll
    for (int d=0; d<3; d++)
    {
-      real x = p[d] / f.length[d];
+      const real x = p[d] * f.inv_length[d];
       if (x < (real)0) return 1;
       if (x > (real)1) return 1;
-      int s = (int) M<real>::floor_(x * (real) f.size[d]);
-      if (s == f.size[d]) s--;
-      sub[d] = s;
+      int sb = (int) M<real>::floor_(x * (real) f.size[d]);
+      if (sb == f.size[d]) sb--;
+      sub[d] = sb;
    }
-   const long stride[3] = { (long) f.size[1] * f.size[2], (long) f.size[2], 1 };
-   const long index = sub[0]*stride[0] + sub[1]*stride[1] + sub[2];
+   const int stride[3] = { f.size[1] * f.size[2], f.size[2], 1 };
+   const int index = sub[0]*stride[0] + sub[1]*stride[1] + sub[2];
    const real v0 = f.data[index];
    real va[3], vb[3], center[3];
 #pragma unroll
    for (int d=0; d<3; d++)
    {
-      center[d] = ((real)0.5 + (real) sub[d]) / (real) f.size[d] * f.length[d];
+      center[d] = ((real)0.5 + (real) sub[d]) * f.cell[d];
       bool prev;
       if (sub[d] == 0) prev = false;
       else if (sub[d] == f.size[d]-1) prev = true;
@@ -119,7 +183,7 @@ __device__ __forceinline__ int sdf_lookup(const DevSdf<real> & f, const real p[3
       if (va[d] == inf || vb[d] == inf) poisoned = true;
       real diff = va[d];
       diff -= vb[d];
-      const real slope = diff * (real) f.size[d] / f.length[d];
+      const real slope = diff * f.size_over_len[d];
       grad[d] = slope;
       v += slope * (p[d] - center[d]);
    }
@@ -223,11 +287,20 @@ void chomp_iterate_kernel(const DevBatch<real> b)
    real * AG_s = W_s + ((mn + 3) & ~3);                 // [m][n]
    real * pos_s = AG_s + ((mn + 3) & ~3);               // [tile_m+2][Sa][3]
    real * ax_s = pos_s + (((tile_m+2)*Sa*3 + 3) & ~3);  // [tile_m+2][nj][6]
+   real * srad_s = ax_s + (((tile_m+2)*nj*6 + 3) & ~3); // [S] sphere radii
+   real * sinact_s = srad_s + ORC_MAX_SPHERES;          // [S-Sa][3] inactive sphere centres
+   int * slink_s = (int *)(sinact_s + 3*ORC_MAX_SPHERES); // [S] link of each sphere
+   int * jtype_s = slink_s + ORC_MAX_SPHERES;           // [nj]
+   int * jcol_s = jtype_s + ORC_MAX_JOINTS;             // [nj]
 
    real * traj_g = b.traj + (size_t) run * np * n;
    real * AG_g = b.AG + (size_t) run * mn;
 
    for (int e=tid; e<np*n; e+=ORC_BLOCK) T_s[e] = traj_g[e];
+   for (int e=tid; e<S; e+=ORC_BLOCK) { srad_s[e] = mod.sph_radius[e]; slink_s[e] = mod.sph_link[e]; }
+   for (int e=tid; e<(S-Sa)*3; e+=ORC_BLOCK) sinact_s[e] = mod.sph_inactive_pos[e/3][e%3];
+   for (int e=tid; e<nj; e+=ORC_BLOCK) { jtype_s[e] = mod.joints[e].type; jcol_s[e] = mod.joints[e].col; }
+   const real inv_eps = (real)1 / b.epsilon, inv_eps_self = (real)1 / b.epsilon_self;
    for (int e=tid; e<mn; e+=ORC_BLOCK) AG_s[e] = AG_g[e];
    int leapfrog_first = b.leapfrog_first[run];
    int status = b.status[run];
@@ -296,13 +369,13 @@ void chomp_iterate_kernel(const DevBatch<real> b)
             for (int j=0; j<nj; j++)
             {
                const DevJoint<real> & J = mod.joints[j];
-               Frame<real> from;
-               if (J.load_slot == -1) from = cur;
-               else if (J.load_slot == -2) from = base;
-               else if (J.load_slot == 0) from = sv0;
-               else if (J.load_slot == 1) from = sv1;
-               else if (J.load_slot == 2) from = sv2;
-               else from = sv3;
+               // continue from the previous joint's frame unless the tree branches here
+               if (J.load_slot == -2) cur = base;
+               else if (J.load_slot == 0) cur = sv0;
+               else if (J.load_slot == 1) cur = sv1;
+               else if (J.load_slot == 2) cur = sv2;
+               else if (J.load_slot == 3) cur = sv3;
+               const Frame<real> & from = cur;
                // joint frame in the world
                real Rj[9], tj[3];
                if (J.rfix_identity)
@@ -377,8 +450,8 @@ void chomp_iterate_kernel(const DevBatch<real> b)
                const real * pc = pos_s + (l*Sa + s)*3;
                const real * pp = pos_s + ((l-1)*Sa + s)*3;
                const real * pn = pos_s + ((l+1)*Sa + s)*3;
-               const real radius = mod.sph_radius[s];
-               const int mylink = mod.sph_link[s];
+               const real radius = srad_s[s];
+               const int mylink = slink_s[s];
 #pragma unroll
                for (int k=0; k<3; k++)
                {
@@ -387,8 +460,11 @@ void chomp_iterate_kernel(const DevBatch<real> b)
                   real v = pn[k]; v -= pp[k]; v *= b.inv_2dt; vel[k] = v;
                   real a = pc[k]; a *= (real)(-2); a += pp[k]; a += pn[k]; a *= b.inv_dt2; acc[k] = a;
                }
-               vnorm = M<real>::sqrt_(vel[0]*vel[0] + vel[1]*vel[1] + vel[2]*vel[2]);
-               const real vn2 = vnorm * vnorm;
+               const real vn2 = vel[0]*vel[0] + vel[1]*vel[1] + vel[2]*vel[2];
+               real inv_vn;
+               vnorm = sqrt_rsq(vn2, &inv_vn);
+               const real inv_vn2 = inv_vn * inv_vn;          // only used when vnorm > 1e-6
+               const bool moving = vnorm > (real)0.000001;
 
                // ---- obstacle term (src/orcdchomp_mod.cpp:1171-1246) ----
                real best = inf; int best_i = -1; real bgrad[3] = {0,0,0};
@@ -410,83 +486,81 @@ void chomp_iterate_kernel(const DevBatch<real> b)
                   if (dist < (real)0)
                      cs = vnorm * b.obs_factor * ((real)0.5 * b.epsilon - dist);
                   else if (dist < b.epsilon)
-                     cs = vnorm * b.obs_factor * ((real)0.5/b.epsilon) * (dist - b.epsilon) * (dist - b.epsilon);
+                     cs = vnorm * b.obs_factor * ((real)0.5 * inv_eps) * (dist - b.epsilon) * (dist - b.epsilon);
                   cost_sphere += (double) cs;
                   if (do_iteration && vnorm != (real)0)
                   {
                      real xg[3], xc[3];
                      real scale;
                      if (dist < (real)0) scale = (real)(-1);
-                     else if (dist < b.epsilon) scale = dist/b.epsilon - (real)1;
+                     else if (dist < b.epsilon) scale = dist * inv_eps - (real)1;
                      else scale = (real)0;
+                     const real sc2 = scale * (vnorm * b.obs_factor);
 #pragma unroll
                      for (int k=0; k<3; k++)
                      {
                         const real gw = F.Rwg[k*3+0]*bgrad[0] + F.Rwg[k*3+1]*bgrad[1] + F.Rwg[k*3+2]*bgrad[2];
-                        xg[k] = (scale == (real)0) ? (real)0 : gw * scale;
-                        xg[k] *= vnorm * b.obs_factor;
+                        xg[k] = (scale == (real)0) ? (real)0 : gw * sc2;
                         xc[k] = acc[k];
                      }
-                     if (vnorm > (real)0.000001)
+                     if (moving)
                      {
-                        real proj = (xg[0]*vel[0] + xg[1]*vel[1] + xg[2]*vel[2]) / vn2;
+                        real proj = (xg[0]*vel[0] + xg[1]*vel[1] + xg[2]*vel[2]) * inv_vn2;
 #pragma unroll
                         for (int k=0; k<3; k++) xg[k] -= proj * vel[k];
-                        proj = (xc[0]*vel[0] + xc[1]*vel[1] + xc[2]*vel[2]) / vn2;
+                        proj = (xc[0]*vel[0] + xc[1]*vel[1] + xc[2]*vel[2]) * inv_vn2;
 #pragma unroll
                         for (int k=0; k<3; k++) xc[k] -= proj * vel[k];
                      }
-                     const real ivn2 = (real)1 / vn2;
+                     // x_grad -= cost * curvature, curvature = xc / |v|^2; then c_grad += |v| J^T x_grad
+                     const real cw = cs * inv_vn2;
 #pragma unroll
-                     for (int k=0; k<3; k++)
-                     {
-                        xc[k] *= ivn2;
-                        xg[k] -= cs * xc[k];
-                        f[k] += vnorm * xg[k];        // c_grad += |v| J^T x_grad
-                     }
+                     for (int k=0; k<3; k++) f[k] += vnorm * (xg[k] - cw * xc[k]);
                   }
                }
 
                // ---- self collision (src/orcdchomp_mod.cpp:1251-1317) ----
-               // pass 1: which spheres are within range (uniform loop)
+               // pass 1: which spheres are within range (uniform loop, squared distances)
                unsigned long long near = 0ull;
+#pragma unroll 4
                for (int o=0; o<S; o++)
                {
-                  const real * po = (o < Sa) ? pos_s + (l*Sa + o)*3 : mod.sph_inactive_pos[o - Sa];
+                  const real * po = (o < Sa) ? pos_s + (l*Sa + o)*3 : sinact_s + (o - Sa)*3;
                   const real dx = p[0]-po[0], dy = p[1]-po[1], dz = p[2]-po[2];
-                  const real dist = M<real>::sqrt_(dx*dx + dy*dy + dz*dz);
-                  const bool skip = (mod.sph_link[o] == mylink) || (dist > radius + mod.sph_radius[o] + b.epsilon_self);
+                  const real d2 = dx*dx + dy*dy + dz*dz;
+                  const real R = radius + srad_s[o] + b.epsilon_self;
+                  const bool skip = (slink_s[o] == mylink) || (d2 > R*R);
                   if (!skip) near |= (1ull << o);
                }
                // pass 2: only the pairs in range
+               const real wself = vnorm * b.obs_factor_self;
                while (near)
                {
                   const int o = __builtin_ctzll(near);
                   near &= near - 1;
-                  const real * po = (o < Sa) ? pos_s + (l*Sa + o)*3 : mod.sph_inactive_pos[o - Sa];
-                  const real ro = mod.sph_radius[o];
-                  real d[3] = { p[0]-po[0], p[1]-po[1], p[2]-po[2] };
-                  real dist = M<real>::sqrt_(d[0]*d[0] + d[1]*d[1] + d[2]*d[2]);
-                  real gh[3] = { d[0]/dist, d[1]/dist, d[2]/dist };
+                  const real * po = (o < Sa) ? pos_s + (l*Sa + o)*3 : sinact_s + (o - Sa)*3;
+                  const real ro = srad_s[o];
+                  const real d[3] = { p[0]-po[0], p[1]-po[1], p[2]-po[2] };
+                  real inv_d;
+                  real dist = sqrt_rsq(d[0]*d[0] + d[1]*d[1] + d[2]*d[2], &inv_d);
                   dist -= radius + ro;
-                  real cself;
-                  if (dist < (real)0)
-                     cself = b.obs_factor_self * ((real)0.5 * b.epsilon_self - dist);
-                  else
-                     cself = b.obs_factor_self * ((real)0.5/b.epsilon_self) * (dist - b.epsilon_self) * (dist - b.epsilon_self);
-                  cost_sphere += (double)(vnorm * cself);
+                  const real de = dist - b.epsilon_self;
+                  const real cself = (dist < (real)0) ? ((real)0.5 * b.epsilon_self - dist)
+                                                      : ((real)0.5 * inv_eps_self) * de * de;
+                  cost_sphere += (double)(wself * cself);
                   if (do_iteration)
                   {
                      real scale = (real)1;
                      if (dist < (real)0) scale = (real)(-1);
-                     else if (dist < b.epsilon_self) scale = dist/b.epsilon_self - (real)1;
+                     else if (dist < b.epsilon_self) scale = dist * inv_eps_self - (real)1;
+                     const real sd = scale * inv_d;              // x = (d/|d|) * scale * weight
                      // my side of the pair: + J_me^T x
                      real x[3];
 #pragma unroll
-                     for (int k=0; k<3; k++) { x[k] = gh[k] * scale; x[k] *= vnorm * b.obs_factor_self; }
-                     if (vnorm > (real)0.000001)
+                     for (int k=0; k<3; k++) x[k] = d[k] * (sd * wself);
+                     if (moving)
                      {
-                        const real proj = (x[0]*vel[0] + x[1]*vel[1] + x[2]*vel[2]) / vn2;
+                        const real proj = (x[0]*vel[0] + x[1]*vel[1] + x[2]*vel[2]) * inv_vn2;
 #pragma unroll
                         for (int k=0; k<3; k++) x[k] -= proj * vel[k];
                      }
@@ -501,13 +575,15 @@ void chomp_iterate_kernel(const DevBatch<real> b)
                         real vo[3];
 #pragma unroll
                         for (int k=0; k<3; k++) { real v = opn[k]; v -= opp[k]; v *= b.inv_2dt; vo[k] = v; }
-                        const real von = M<real>::sqrt_(vo[0]*vo[0] + vo[1]*vo[1] + vo[2]*vo[2]);
+                        real inv_von;
+                        const real von = sqrt_rsq(vo[0]*vo[0] + vo[1]*vo[1] + vo[2]*vo[2], &inv_von);
                         real xo[3];
+                        const real so = -sd * (von * b.obs_factor_self);
 #pragma unroll
-                        for (int k=0; k<3; k++) { xo[k] = (-gh[k]) * scale; xo[k] *= von * b.obs_factor_self; }
+                        for (int k=0; k<3; k++) xo[k] = d[k] * so;
                         if (von > (real)0.000001)
                         {
-                           const real proj = (xo[0]*vo[0] + xo[1]*vo[1] + xo[2]*vo[2]) / (von*von);
+                           const real proj = (xo[0]*vo[0] + xo[1]*vo[1] + xo[2]*vo[2]) * (inv_von * inv_von);
 #pragma unroll
                            for (int k=0; k<3; k++) xo[k] -= proj * vo[k];
                         }
@@ -531,7 +607,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
                   if ((aff >> j) & 1ull)
                   {
                      const real * ax = ax_s + (l*nj + j)*6;
-                     if (mod.joints[j].type == 1)
+                     if (jtype_s[j] == 1)
                      {
                         const real r0 = p[0]-ax[3], r1 = p[1]-ax[4], r2 = p[2]-ax[5];
                         const real c0 = r1*f[2] - r2*f[1];
@@ -541,8 +617,8 @@ void chomp_iterate_kernel(const DevBatch<real> b)
                      }
                      else cg = ax[0]*f[0] + ax[1]*f[1] + ax[2]*f[2];
                   }
-                  for (int o=GS>>1; o>0; o>>=1) cg += __shfl_xor(cg, o, 64);
-                  if (row_ok && s == 0) G_s[gi*n + mod.joints[j].col] = cg;
+                  cg = group_sum(cg, GS);
+                  if (row_ok && s == 0) G_s[gi*n + jcol_s[j]] = cg;
                }
                if (mod.floating)
                {
@@ -554,8 +630,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
                   w6[2] = p[0]*f[1] - p[1]*f[0];
                   w6[3] = f[0]; w6[4] = f[1]; w6[5] = f[2];
 #pragma unroll
-                  for (int k=0; k<6; k++)
-                     for (int o=GS>>1; o>0; o>>=1) w6[k] += __shfl_xor(w6[k], o, 64);
+                  for (int k=0; k<6; k++) w6[k] = group_sum(w6[k], GS);
                   if (row_ok && s == 0)
                   {
                      const real * row = T_s + (gi+1)*n;
@@ -766,8 +841,9 @@ size_t orc_chomp_lds_bytes(int n_points, int n, int Sa, int nj, int tile_m, size
 {
    const int m = n_points - 2, mn = m*n;
    size_t reals = ((size_t)(n_points*n + 3) & ~(size_t)3) + 3*(((size_t) mn + 3) & ~(size_t)3)
-                + (((size_t)(tile_m+2)*Sa*3 + 3) & ~(size_t)3) + (size_t)(tile_m+2)*nj*6;
-   return 128 + reals * real_size;
+                + (((size_t)(tile_m+2)*Sa*3 + 3) & ~(size_t)3) + (((size_t)(tile_m+2)*nj*6 + 3) & ~(size_t)3)
+                + (size_t) 4 * ORC_MAX_SPHERES;
+   return 128 + reals * real_size + (ORC_MAX_SPHERES + 2*ORC_MAX_JOINTS) * sizeof(int);
 }
 
 template <typename real>

@@ -59,6 +59,9 @@ struct DevSdf
    int size[3];
    int pad;
    real length[3];
+   real inv_length[3];     // 1/length
+   real cell[3];           // length/size
+   real size_over_len[3];  // size/length
    real Rgw[9];            // world -> grid: p_g = Rgw p + tgw   (pose_gsdf_world)
    real tgw[3];
    real Rwg[9];            // grid -> world rotation (pose_world_gsdf), for the gradient
