@@ -8,7 +8,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liborcdchomp_amd.so")
+LIB_PATH = os.environ.get("ORC_LIB") or os.path.join(_HERE, "liborcdchomp_amd.so")   # ORC_LIB: diagnostic builds
 
 c_double_p = C.POINTER(C.c_double)
 c_int_p = C.POINTER(C.c_int)

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <functional>
 #include <stdexcept>
+#include <cstdlib>
 
 // launch wrappers implemented in chomp_kernel.hip
 size_t orc_chomp_lds_bytes(int n_points, int n, int Sa, int nj, int tile_m, size_t real_size);
@@ -122,6 +123,8 @@ Batch::Batch(Module * mod, const Robot & robot, const BatchParams & p, int nruns
    }
    hipFree(d_s); hipFree(d_g);
 
+   if (getenv("ORC_PHASE_TIMERS")) d_phase_ = dev_alloc<long long>((size_t) n_runs * 8);
+   debug_state_ = getenv("ORC_DEBUG_STATE") != nullptr;
    // hmc state (mod.cpp:2303-2304, 2634-2635)
    rng_.resize(p.use_hmc ? n_runs : 0);
    for (int k=0; k<(int) rng_.size(); k++) rng_[k].set(seeds ? seeds[k] : 0);
@@ -134,7 +137,7 @@ Batch::~Batch()
    dev_free(d_model_); dev_free(d_sdfs_); dev_free(d_traj_); dev_free(d_AG_); dev_free(d_G_);
    dev_free(d_costs_); dev_free(d_trace_); dev_free(d_status_); dev_free(d_leap_);
    dev_free(d_Aband_); dev_free(d_beta_s_); dev_free(d_beta_g_); dev_free(d_pcr_); dev_free(d_Ainv_);
-   dev_free(d_jl_lo_); dev_free(d_jl_hi_); dev_free(d_hmc_iters_); dev_free(d_noise_);
+   dev_free(d_jl_lo_); dev_free(d_jl_hi_); dev_free(d_hmc_iters_); dev_free(d_noise_); dev_free(d_phase_);
 }
 
 // Fold the robot into the device model: only optimized joints remain, every other
@@ -500,6 +503,8 @@ void Batch::launch(int n_iter)
    b.jl_lo = (const real *) d_jl_lo_; b.jl_hi = (const real *) d_jl_hi_;
    b.hmc_iters = d_hmc_iters_; b.noise = (const real *) d_noise_; b.max_resamples = max_resamples_;
    b.n_iter = n_iter; b.final_eval = 1;
+   b.phase_cycles = d_phase_;
+   b.Gdbg = debug_state_ ? (real *) d_G_ : nullptr;
    mod_->time_begin();
    hipError_t e = launch_typed(b, lds_bytes_, mod_->stream);
    hip_check(e, "chomp_iterate_kernel launch");
@@ -572,6 +577,12 @@ void Batch::get_trace(double * out)
 {
    hip_check(hipMemcpyAsync(out, d_trace_, (size_t) n_runs * last_n_iter * 3 * sizeof(double), hipMemcpyDeviceToHost, mod_->stream), "trace");
    hip_check(hipStreamSynchronize(mod_->stream), "sync");
+}
+
+void Batch::get_phase_cycles(long long * out)
+{
+   if (!d_phase_) throw std::runtime_error("phase timers are off (set ORC_PHASE_TIMERS=1 before create)");
+   hip_check(hipMemcpy(out, d_phase_, (size_t) n_runs*8*sizeof(long long), hipMemcpyDeviceToHost), "phase");
 }
 
 void Batch::set_noise(const double * noise, int n_blocks)

@@ -265,6 +265,14 @@ int orc_batch_get_state(orc_module * mod, int id, const char * which, double * o
 {
    return guarded(mod, [&] {
       orc::Batch & b = mod->impl->batch(id);
+      if (std::string(which) == "phase")
+      {
+         if (cap < (size_t) b.n_runs * 8) throw std::runtime_error("buffer too small!");
+         std::vector<long long> tmp((size_t) b.n_runs * 8);
+         b.get_phase_cycles(tmp.data());
+         for (size_t i=0; i<tmp.size(); i++) out[i] = (double) tmp[i];
+         return;
+      }
       if (cap < (size_t) b.n_runs * b.m * b.n) throw std::runtime_error("buffer too small!");
       b.get_state(which, out);
    });

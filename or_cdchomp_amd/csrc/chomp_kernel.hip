@@ -24,6 +24,10 @@
 #include <math.h>
 #include "dev_types.h"
 
+// the device arithmetic may fuse a*b+c (the host files are built with -ffp-contract=off so that
+// the SDF build stays bit-identical to the reference; the kernels are held to a tolerance)
+#pragma clang fp contract(fast)
+
 namespace {
 
 template <typename real> struct M;
@@ -104,6 +108,63 @@ __device__ __forceinline__ real group_sum(real v, int GS)
    if (GS >= 32) v += __shfl_xor(v, 16, 64);
    if (GS >= 64) v += __shfl_xor(v, 32, 64);
    return v;
+}
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_move(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+
+// One rotation step of the self-collision term for 16 lanes per waypoint (src/orcdchomp_mod.cpp:
+// 1251-1317).  Every lane looks at the sphere K lanes away in its row (row_ror:K); all partner
+// attributes travel through the same DPP rotation, so the code does not depend on its direction.
+// The lane evaluates only ITS side of the pair (force x on its own sphere, its own velocity);
+// the reaction -x of the pair seen from the partner's side is fetched with the inverse rotation.
+// Must be executed by all lanes of the wave (DPP sources must be live lanes).
+template <typename real, int K>
+__device__ __forceinline__ void self_pair_step16(unsigned kmask, bool live, const real p[3], real radius, int mylink,
+   const real vel[3], bool moving, real inv_vn2, real wself, real eps_self, real inv_eps_self, bool do_iteration,
+   real f[3], double & cost_sphere)
+{
+   if (!(kmask & (1u << K))) return;                       // wave-uniform
+   constexpr int FWD = 0x120 + K, BWD = 0x120 + (16 - K);  // row_ror:K and its inverse
+   real d[3];
+#pragma unroll
+   for (int k=0; k<3; k++) d[k] = p[k] - dpp_move<FWD>(p[k]);
+   const real ro = dpp_move<FWD>(radius);
+   const int lo = dpp_move<FWD>(mylink);
+   const int ao = dpp_move<FWD>(live ? 1 : 0);
+   const real d2 = d[0]*d[0] + d[1]*d[1] + d[2]*d[2];
+   const real R = radius + ro + eps_self;
+   const bool near = live && ao && (lo != mylink) && !(d2 > R*R);
+   real x[3] = {0, 0, 0};
+   if (near)
+   {
+      real inv_d;
+      real dist = sqrt_rsq(d2, &inv_d);
+      dist -= radius + ro;
+      const real de = dist - eps_self;
+      const real cself = (dist < (real)0) ? ((real)0.5 * eps_self - dist) : ((real)0.5 * inv_eps_self) * de * de;
+      cost_sphere += (double)(wself * cself);
+      if (do_iteration)
+      {
+         real scale = (real)1;
+         if (dist < (real)0) scale = (real)(-1);
+         else if (dist < eps_self) scale = dist * inv_eps_self - (real)1;
+         const real sd = scale * inv_d * wself;
+#pragma unroll
+         for (int k=0; k<3; k++) x[k] = d[k] * sd;
+         if (moving)
+         {
+            const real proj = (x[0]*vel[0] + x[1]*vel[1] + x[2]*vel[2]) * inv_vn2;
+#pragma unroll
+            for (int k=0; k<3; k++) x[k] -= proj * vel[k];
+         }
+      }
+   }
+   if (do_iteration)
+   {
+#pragma unroll
+      for (int k=0; k<3; k++) f[k] += x[k] - dpp_move<BWD>(x[k]);
+   }
 }
 
 template <typename real>
@@ -307,6 +368,12 @@ void chomp_iterate_kernel(const DevBatch<real> b)
    int next_resample = 0;      // index into this call's resample list
    __syncthreads();
 
+   // optional per-phase cycle counters (diagnostics: b.phase_cycles == null in production)
+   long long ph[8] = {0,0,0,0,0,0,0,0};
+   long long tmark = 0;
+#define ORC_MARK(slot) do { if (b.phase_cycles && tid == 0) { const long long now_ = clock64(); ph[slot] += now_ - tmark; tmark = now_; } } while (0)
+   if (b.phase_cycles && tid == 0) tmark = clock64();
+
    double cost_obs = 0.0, cost_smooth = 0.0;
    const int total_passes = b.n_iter + (b.final_eval ? 1 : 0);
 
@@ -431,6 +498,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
             }
          }
          __syncthreads();
+         ORC_MARK(0);
 
          // ================= cost phase: lane = (waypoint, sphere) =============
          const int items = (te - ts) * GS;
@@ -445,13 +513,16 @@ void chomp_iterate_kernel(const DevBatch<real> b)
             real f[3] = {0,0,0};                    // total workspace force on this sphere
             real vnorm = 0;
             double cost_sphere = 0.0;
+            real radius = 0, inv_vn2 = 0;
+            int mylink = -1;
+            bool moving = false;
             if (live)
             {
                const real * pc = pos_s + (l*Sa + s)*3;
                const real * pp = pos_s + ((l-1)*Sa + s)*3;
                const real * pn = pos_s + ((l+1)*Sa + s)*3;
-               const real radius = srad_s[s];
-               const int mylink = slink_s[s];
+               radius = srad_s[s];
+               mylink = slink_s[s];
 #pragma unroll
                for (int k=0; k<3; k++)
                {
@@ -463,11 +534,12 @@ void chomp_iterate_kernel(const DevBatch<real> b)
                const real vn2 = vel[0]*vel[0] + vel[1]*vel[1] + vel[2]*vel[2];
                real inv_vn;
                vnorm = sqrt_rsq(vn2, &inv_vn);
-               const real inv_vn2 = inv_vn * inv_vn;          // only used when vnorm > 1e-6
-               const bool moving = vnorm > (real)0.000001;
+               inv_vn2 = inv_vn * inv_vn;                     // only used when vnorm > 1e-6
+               moving = vnorm > (real)0.000001;
 
                // ---- obstacle term (src/orcdchomp_mod.cpp:1171-1246) ----
                real best = inf; int best_i = -1; real bgrad[3] = {0,0,0};
+#ifndef ORC_ABLATE_SDF
                for (int i=0; i<b.n_sdfs; i++)
                {
                   const DevSdf<real> & F = b.sdfs[i];
@@ -478,6 +550,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
                   if (sdf_lookup(F, g, val, gg)) continue;
                   if (val < best) { best = val; best_i = i; bgrad[0] = gg[0]; bgrad[1] = gg[1]; bgrad[2] = gg[2]; }
                }
+#endif
                if (best_i != -1)
                {
                   const DevSdf<real> & F = b.sdfs[best_i];
@@ -518,10 +591,78 @@ void chomp_iterate_kernel(const DevBatch<real> b)
                      for (int k=0; k<3; k++) f[k] += vnorm * (xg[k] - cw * xc[k]);
                   }
                }
+            }
 
-               // ---- self collision (src/orcdchomp_mod.cpp:1251-1317) ----
+            // ---- self collision (src/orcdchomp_mod.cpp:1251-1317) ----
+            if (GS == 16)
+            {
+               // 16 lanes per waypoint: pairs are formed by rotating the row (registers only)
+               const real wself = vnorm * b.obs_factor_self;
+               unsigned kl = 0u;
+               if (live)
+               {
+                  // which rotations does this waypoint need?  (uniform loop, squared distances)
+#pragma unroll 4
+                  for (int o=0; o<Sa; o++)
+                  {
+                     const real * po = pos_s + (l*Sa + o)*3;
+                     const real dx = p[0]-po[0], dy = p[1]-po[1], dz = p[2]-po[2];
+                     const real d2 = dx*dx + dy*dy + dz*dz;
+                     const real R = radius + srad_s[o] + b.epsilon_self;
+                     const bool skip = (slink_s[o] == mylink) || (d2 > R*R);
+                     if (!skip) kl |= (1u << ((o - s) & 15)) | (1u << ((s - o) & 15));
+                  }
+                  // inactive spheres have no lane: only this lane's side exists
+                  for (int o=Sa; o<S; o++)
+                  {
+                     const real * po = sinact_s + (o - Sa)*3;
+                     const real ro = srad_s[o];
+                     const real d[3] = { p[0]-po[0], p[1]-po[1], p[2]-po[2] };
+                     const real d2 = d[0]*d[0] + d[1]*d[1] + d[2]*d[2];
+                     const real R = radius + ro + b.epsilon_self;
+                     if ((slink_s[o] == mylink) || (d2 > R*R)) continue;
+                     real inv_d;
+                     real dist = sqrt_rsq(d2, &inv_d);
+                     dist -= radius + ro;
+                     const real de = dist - b.epsilon_self;
+                     const real cself = (dist < (real)0) ? ((real)0.5 * b.epsilon_self - dist)
+                                                         : ((real)0.5 * inv_eps_self) * de * de;
+                     cost_sphere += (double)(wself * cself);
+                     if (do_iteration)
+                     {
+                        real scale = (real)1;
+                        if (dist < (real)0) scale = (real)(-1);
+                        else if (dist < b.epsilon_self) scale = dist * inv_eps_self - (real)1;
+                        const real sd = scale * inv_d * wself;
+                        real x[3] = { d[0]*sd, d[1]*sd, d[2]*sd };
+                        if (moving)
+                        {
+                           const real proj = (x[0]*vel[0] + x[1]*vel[1] + x[2]*vel[2]) * inv_vn2;
+#pragma unroll
+                           for (int k=0; k<3; k++) x[k] -= proj * vel[k];
+                        }
+#pragma unroll
+                        for (int k=0; k<3; k++) f[k] += x[k];
+                     }
+                  }
+               }
+               // union over the wave (the rotation steps are wave-uniform branches)
+               unsigned km = kl;
+#pragma unroll
+               for (int o=32; o>0; o>>=1) km |= (unsigned) __shfl_xor((int) km, o, 64);
+               km = (unsigned) __builtin_amdgcn_readfirstlane((int) km);
+#define ORC_STEP(K) self_pair_step16<real, K>(km, live, p, radius, mylink, vel, moving, inv_vn2, wself, \
+                      b.epsilon_self, inv_eps_self, do_iteration, f, cost_sphere)
+               ORC_STEP(1); ORC_STEP(2); ORC_STEP(3); ORC_STEP(4); ORC_STEP(5);
+               ORC_STEP(6); ORC_STEP(7); ORC_STEP(8); ORC_STEP(9); ORC_STEP(10);
+               ORC_STEP(11); ORC_STEP(12); ORC_STEP(13); ORC_STEP(14); ORC_STEP(15);
+#undef ORC_STEP
+            }
+            else if (live)
+            {
                // pass 1: which spheres are within range (uniform loop, squared distances)
                unsigned long long near = 0ull;
+#ifndef ORC_ABLATE_PASS1
 #pragma unroll 4
                for (int o=0; o<S; o++)
                {
@@ -532,6 +673,10 @@ void chomp_iterate_kernel(const DevBatch<real> b)
                   const bool skip = (slink_s[o] == mylink) || (d2 > R*R);
                   if (!skip) near |= (1ull << o);
                }
+#endif
+#ifdef ORC_ABLATE_PASS2
+               near = 0ull;
+#endif
                // pass 2: only the pairs in range
                const real wself = vnorm * b.obs_factor_self;
                while (near)
@@ -592,8 +737,8 @@ void chomp_iterate_kernel(const DevBatch<real> b)
                      }
                   }
                }
-               cost_lane += cost_sphere;
             }
+            if (live) cost_lane += cost_sphere;
 
             // ---- J^T contraction and reduction over the spheres of a waypoint ----
             if (do_iteration)
@@ -601,6 +746,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
                const unsigned long long aff = live ? mod.sph_affects[s] : 0ull;
                const bool row_ok = (item < items);
                const int gi = ts + wl;               // moving waypoint index
+#ifndef ORC_ABLATE_JT
                for (int j=0; j<nj; j++)
                {
                   real cg = 0;
@@ -620,6 +766,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
                   cg = group_sum(cg, GS);
                   if (row_ok && s == 0) G_s[gi*n + jcol_s[j]] = cg;
                }
+#endif
                if (mod.floating)
                {
                   // base block: 0.01 * Jsp^T [p x f ; f] summed over all spheres
@@ -661,10 +808,12 @@ void chomp_iterate_kernel(const DevBatch<real> b)
             }
          }
          __syncthreads();
+         ORC_MARK(1);
       } // tiles
 
       // obstacle cost of the trajectory the gradient was taken at (chomp.c:484-491)
       cost_obs = block_sum(cost_lane, red) / (double) m;
+      ORC_MARK(2);
 
       if (do_iteration)
       {
@@ -699,6 +848,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
          }
          __syncthreads();
 
+         ORC_MARK(3);
          // joint-limit projection (chomp.c:608-655)
          int num_limadjs;
          for (num_limadjs=0; num_limadjs<1000; num_limadjs++)
@@ -744,6 +894,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
             __syncthreads();
          }
          if (!(num_limadjs < 1000)) status = -1;
+         ORC_MARK(4);
 
       }
 
@@ -769,6 +920,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
          acc += 0.5 * (b.kss*ss + 2.0*b.ksg*sg2 + b.kgg*gg);
          cost_smooth = block_sum(acc, red);
       }
+      ORC_MARK(5);
 
       // floating base: renormalise the quaternion of every row (mod.cpp:2806-2808)
       if (do_iteration && mod.floating && status == 0)
@@ -796,6 +948,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
    for (int e=tid; e<mn; e+=ORC_BLOCK) AG_g[e] = AG_s[e];
    if (tid == 0)
    {
+      if (b.phase_cycles) for (int k=0; k<8; k++) b.phase_cycles[(size_t) run*8 + k] = ph[k];
       b.costs[(size_t) run*3 + 0] = cost_obs + cost_smooth;
       b.costs[(size_t) run*3 + 1] = cost_obs;
       b.costs[(size_t) run*3 + 2] = cost_smooth;

@@ -105,4 +105,5 @@ struct DevBatch
    int max_resamples;
    int n_iter;
    int final_eval;
+   long long * phase_cycles; // [n_runs][8] or null: diagnostics (cycles per phase, wave 0)
 };

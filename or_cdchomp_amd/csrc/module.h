@@ -85,6 +85,7 @@ public:
    void get_state(const std::string & which, double * out);
    void get_trace(double * out);
    void set_noise(const double * noise, int n_blocks);
+   void get_phase_cycles(long long * out);   // [n_runs][8], diagnostics (ORC_PHASE_TIMERS=1)
 
    int n_runs, n_points, n, m;
    BatchParams params;
@@ -102,11 +103,12 @@ private:
    void * d_model_ = nullptr; void * d_sdfs_ = nullptr;
    void * d_traj_ = nullptr; void * d_AG_ = nullptr; void * d_G_ = nullptr;
    double * d_costs_ = nullptr; double * d_trace_ = nullptr; size_t trace_cap_ = 0;
-   int * d_status_ = nullptr; int * d_leap_ = nullptr;
+   int * d_status_ = nullptr; int * d_leap_ = nullptr; long long * d_phase_ = nullptr;
    void * d_Aband_ = nullptr; void * d_beta_s_ = nullptr; void * d_beta_g_ = nullptr;
    void * d_pcr_ = nullptr; void * d_Ainv_ = nullptr; void * d_jl_lo_ = nullptr; void * d_jl_hi_ = nullptr;
    int * d_hmc_iters_ = nullptr; void * d_noise_ = nullptr; size_t hmc_cap_iters_ = 0, noise_cap_ = 0;
    int max_resamples_ = 0;
+   bool debug_state_ = false;   // ORC_DEBUG_STATE=1: keep the last gradient readable (get_state "G")
    int n_sdfs_ = 0;
    int nj_ = 0, Sa_ = 0;
    int tile_m_ = 0;

@@ -46,6 +46,7 @@ def _oracle_runs(oracle, wam, goals, n_iter, **params):
 
 def test_seed_and_first_gradient(wam, oracle):
     """straight-line seed bit-exact; first obstacle+smoothness gradient and A^-1 G vs the oracle"""
+    import os; os.environ["ORC_DEBUG_STATE"] = "1"      # keep the gradient of the last iteration readable
     mod = wam["mod"]
     goals = common.wam_goals(3, seed=7)
     model, base, dofvals, adofs = common.wam_state()
@@ -70,6 +71,7 @@ def test_seed_and_first_gradient(wam, oracle):
         assert np.allclose(trd[k, 0], tr[0], rtol=1e-9, atol=0), (trd[k, 0], tr[0])
         run.destroy()
     mod.batch_destroy(bid)
+    os.environ.pop("ORC_DEBUG_STATE", None)
 
 
 @pytest.mark.parametrize("n_points,momentum", [(100, False), (101, False), (100, True)])
