@@ -325,6 +325,12 @@ __device__ __forceinline__ real smooth_grad(const DevBatch<real> & b, const real
    return s;
 }
 
+#include "cost_gs16.h"
+
+#ifndef ORC_U
+#define ORC_U 2          // waypoints per lane in the 16-sphere cost phase (independent streams)
+#endif
+
 // ---------------------------------------------------------------------------
 template <typename real>
 __global__ __launch_bounds__(ORC_BLOCK, 2)
@@ -501,6 +507,11 @@ void chomp_iterate_kernel(const DevBatch<real> b)
          ORC_MARK(0);
 
          // ================= cost phase: lane = (waypoint, sphere) =============
+         if (GS == 16)
+            cost_tile_gs16<real, ORC_U>(b, mod, ts, te, do_iteration, T_s, G_s, pos_s, ax_s, srad_s, sinact_s,
+                                        slink_s, jtype_s, jcol_s, inv_eps, inv_eps_self, cost_lane);
+         else
+         {
          const int items = (te - ts) * GS;
          for (int base_item=0; base_item<items; base_item+=ORC_BLOCK)
          {
@@ -594,71 +605,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
             }
 
             // ---- self collision (src/orcdchomp_mod.cpp:1251-1317) ----
-            if (GS == 16)
-            {
-               // 16 lanes per waypoint: pairs are formed by rotating the row (registers only)
-               const real wself = vnorm * b.obs_factor_self;
-               unsigned kl = 0u;
-               if (live)
-               {
-                  // which rotations does this waypoint need?  (uniform loop, squared distances)
-#pragma unroll 4
-                  for (int o=0; o<Sa; o++)
-                  {
-                     const real * po = pos_s + (l*Sa + o)*3;
-                     const real dx = p[0]-po[0], dy = p[1]-po[1], dz = p[2]-po[2];
-                     const real d2 = dx*dx + dy*dy + dz*dz;
-                     const real R = radius + srad_s[o] + b.epsilon_self;
-                     const bool skip = (slink_s[o] == mylink) || (d2 > R*R);
-                     if (!skip) kl |= (1u << ((o - s) & 15)) | (1u << ((s - o) & 15));
-                  }
-                  // inactive spheres have no lane: only this lane's side exists
-                  for (int o=Sa; o<S; o++)
-                  {
-                     const real * po = sinact_s + (o - Sa)*3;
-                     const real ro = srad_s[o];
-                     const real d[3] = { p[0]-po[0], p[1]-po[1], p[2]-po[2] };
-                     const real d2 = d[0]*d[0] + d[1]*d[1] + d[2]*d[2];
-                     const real R = radius + ro + b.epsilon_self;
-                     if ((slink_s[o] == mylink) || (d2 > R*R)) continue;
-                     real inv_d;
-                     real dist = sqrt_rsq(d2, &inv_d);
-                     dist -= radius + ro;
-                     const real de = dist - b.epsilon_self;
-                     const real cself = (dist < (real)0) ? ((real)0.5 * b.epsilon_self - dist)
-                                                         : ((real)0.5 * inv_eps_self) * de * de;
-                     cost_sphere += (double)(wself * cself);
-                     if (do_iteration)
-                     {
-                        real scale = (real)1;
-                        if (dist < (real)0) scale = (real)(-1);
-                        else if (dist < b.epsilon_self) scale = dist * inv_eps_self - (real)1;
-                        const real sd = scale * inv_d * wself;
-                        real x[3] = { d[0]*sd, d[1]*sd, d[2]*sd };
-                        if (moving)
-                        {
-                           const real proj = (x[0]*vel[0] + x[1]*vel[1] + x[2]*vel[2]) * inv_vn2;
-#pragma unroll
-                           for (int k=0; k<3; k++) x[k] -= proj * vel[k];
-                        }
-#pragma unroll
-                        for (int k=0; k<3; k++) f[k] += x[k];
-                     }
-                  }
-               }
-               // union over the wave (the rotation steps are wave-uniform branches)
-               unsigned km = kl;
-#pragma unroll
-               for (int o=32; o>0; o>>=1) km |= (unsigned) __shfl_xor((int) km, o, 64);
-               km = (unsigned) __builtin_amdgcn_readfirstlane((int) km);
-#define ORC_STEP(K) self_pair_step16<real, K>(km, live, p, radius, mylink, vel, moving, inv_vn2, wself, \
-                      b.epsilon_self, inv_eps_self, do_iteration, f, cost_sphere)
-               ORC_STEP(1); ORC_STEP(2); ORC_STEP(3); ORC_STEP(4); ORC_STEP(5);
-               ORC_STEP(6); ORC_STEP(7); ORC_STEP(8); ORC_STEP(9); ORC_STEP(10);
-               ORC_STEP(11); ORC_STEP(12); ORC_STEP(13); ORC_STEP(14); ORC_STEP(15);
-#undef ORC_STEP
-            }
-            else if (live)
+            if (live)
             {
                // pass 1: which spheres are within range (uniform loop, squared distances)
                unsigned long long near = 0ull;
@@ -806,6 +753,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
                   }
                }
             }
+         }
          }
          __syncthreads();
          ORC_MARK(1);

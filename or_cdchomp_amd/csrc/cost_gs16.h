@@ -1,0 +1,371 @@
+// cost_gs16.h -- cost phase of the CHOMP iteration for robots with <= 16 active spheres.
+//
+// Included by chomp_kernel.hip.  Lane = (waypoint group, sphere): 16 lanes form one DPP row and
+// own one sphere each; every lane works on U waypoints at once (group g owns waypoints
+// g, g+ngroups, ...).  The U instruction streams are independent, which is what hides the
+// 32-cycle dependent latency of the fp64 pipe (measured, scripts/ubench/lat.hip): the code is
+// written branch-free per stream (selects) so that the scheduler can interleave them.
+//
+// Reference: sphere_cost, src/orcdchomp_mod.cpp:1134-1327 (per-sphere obstacle term 1171-1246,
+// self collision 1251-1317); velocities/accelerations src/orcdchomp_mod.cpp:1099-1127;
+// SDF lookup src/libcd/grid.c:191-209, 331-454.
+#pragma once
+
+// SDF lookup without early exits: returns whether p is inside the field; value/grad are only
+// meaningful then (indices are clamped so that the loads stay inside the grid either way).
+template <typename real>
+__device__ __forceinline__ bool sdf_lookup_pred(const DevSdf<real> & f, const real p[3], real & value, real grad[3])
+{
+   int sub[3];
+   bool inb = true;
+#pragma unroll
+   for (int d=0; d<3; d++)
+   {
+      const real x = p[d] * f.inv_length[d];
+      inb = inb && !(x < (real)0) && !(x > (real)1);
+      int sb = (int) M<real>::floor_(x * (real) f.size[d]);
+      sb = sb < 0 ? 0 : sb;
+      sb = sb > f.size[d]-1 ? f.size[d]-1 : sb;           // also the reference's sub==size -> size-1
+      sub[d] = inb ? sb : 0;
+   }
+   const int stride[3] = { f.size[1] * f.size[2], f.size[2], 1 };
+   const int index = sub[0]*stride[0] + sub[1]*stride[1] + sub[2];
+   real center[3]; bool prev[3]; int nidx[3];
+#pragma unroll
+   for (int d=0; d<3; d++)
+   {
+      center[d] = ((real)0.5 + (real) sub[d]) * f.cell[d];
+      prev[d] = (sub[d] == 0) ? false : ((sub[d] == f.size[d]-1) ? true : (p[d] < center[d]));
+      nidx[d] = prev[d] ? index - stride[d] : index + stride[d];
+   }
+   const real v0 = f.data[index];
+   const real vn0 = f.data[nidx[0]], vn1 = f.data[nidx[1]], vn2 = f.data[nidx[2]];
+   const real vn[3] = { vn0, vn1, vn2 };
+   const real inf = M<real>::inf();
+   real v = v0;
+   bool poisoned = (v0 == inf);
+#pragma unroll
+   for (int d=2; d>=0; d--)                     // the reference walks the axes z, y, x
+   {
+      poisoned = poisoned || (vn[d] == inf);
+      const real diff = prev[d] ? (v0 - vn[d]) : (vn[d] - v0);      // after - before
+      const real slope = diff * f.size_over_len[d];
+      grad[d] = slope;
+      v += slope * (p[d] - center[d]);
+   }
+   value = poisoned ? inf : v;
+   return inb;
+}
+
+// one rotation step of the self-collision term for U waypoints per lane (see self_pair_step16)
+template <typename real, int U, int K>
+__device__ __forceinline__ void self_pair_step16u(unsigned kmask, const bool live[U], const real p[U][3],
+   real radius, int mylink, const real vel[U][3], const bool moving[U], const real inv_vn2[U], const real wself[U],
+   real eps_self, real inv_eps_self, bool do_iteration, real f[U][3], double cost_sphere[U])
+{
+   if (!(kmask & (1u << K))) return;                       // wave-uniform
+   constexpr int FWD = 0x120 + K, BWD = 0x120 + (16 - K);  // row_ror:K and its inverse
+   const real ro = dpp_move<FWD>(radius);
+   const int lo = dpp_move<FWD>(mylink);
+   const real R = radius + ro + eps_self;
+   const real R2 = R * R;
+   const bool other_link = (lo != mylink);
+   real d[U][3], d2[U]; bool near[U]; bool any = false;
+#pragma unroll
+   for (int u=0; u<U; u++)
+   {
+#pragma unroll
+      for (int k=0; k<3; k++) d[u][k] = p[u][k] - dpp_move<FWD>(p[u][k]);
+      const int ao = dpp_move<FWD>(live[u] ? 1 : 0);
+      d2[u] = d[u][0]*d[u][0] + d[u][1]*d[u][1] + d[u][2]*d[u][2];
+      near[u] = live[u] && ao && other_link && !(d2[u] > R2);
+      any = any || near[u];
+   }
+   real x[U][3];
+#pragma unroll
+   for (int u=0; u<U; u++) { x[u][0] = 0; x[u][1] = 0; x[u][2] = 0; }
+   if (any)
+   {
+#pragma unroll
+      for (int u=0; u<U; u++)
+      {
+         real inv_d;
+         real dist = sqrt_rsq(near[u] ? d2[u] : (real)1, &inv_d);
+         dist -= radius + ro;
+         const real de = dist - eps_self;
+         const real cself = (dist < (real)0) ? ((real)0.5 * eps_self - dist) : ((real)0.5 * inv_eps_self) * de * de;
+         cost_sphere[u] += near[u] ? (double)(wself[u] * cself) : 0.0;
+         const real scale = (dist < (real)0) ? (real)(-1) : ((dist < eps_self) ? dist * inv_eps_self - (real)1 : (real)1);
+         const real sd = scale * inv_d * wself[u];
+         real xx[3];
+#pragma unroll
+         for (int k=0; k<3; k++) xx[k] = d[u][k] * sd;
+         const real proj = moving[u] ? (xx[0]*vel[u][0] + xx[1]*vel[u][1] + xx[2]*vel[u][2]) * inv_vn2[u] : (real)0;
+#pragma unroll
+         for (int k=0; k<3; k++) x[u][k] = (near[u] && do_iteration) ? (xx[k] - proj * vel[u][k]) : (real)0;
+      }
+   }
+   if (do_iteration)
+   {
+#pragma unroll
+      for (int u=0; u<U; u++)
+#pragma unroll
+         for (int k=0; k<3; k++) f[u][k] += x[u][k] - dpp_move<BWD>(x[u][k]);
+   }
+}
+
+template <typename real, int U>
+__device__ __forceinline__ void cost_tile_gs16(const DevBatch<real> & b, const DevModel<real> & mod,
+   int ts, int te, bool do_iteration, const real * T_s, real * G_s, const real * pos_s, const real * ax_s,
+   const real * srad_s, const real * sinact_s, const int * slink_s, const int * jtype_s, const int * jcol_s,
+   real inv_eps, real inv_eps_self, double & cost_lane)
+{
+   const int tid = threadIdx.x;
+   const int Sa = mod.Sa, S = mod.S, nj = mod.nj, n = b.n;
+   const int nw = te - ts;                      // moving waypoints of this tile
+   const int ngroups = (nw + U - 1) / U;        // group g owns waypoints g + u*ngroups
+   const int items = ngroups * 16;
+   const real inf = M<real>::inf();
+
+   for (int base_item=0; base_item<items; base_item+=ORC_BLOCK)
+   {
+      const int item = base_item + tid;
+      const int g = item >> 4, s = item & 15;
+      const bool lane_ok = (item < items) && (s < Sa);
+      const int ss = lane_ok ? s : 0;           // dead lanes read sphere 0 (valid memory), results masked
+      const real radius = srad_s[ss];
+      const int mylink = lane_ok ? slink_s[ss] : -1 - s;
+      bool live[U]; int wl[U], l[U];
+      real p[U][3], vel[U][3], acc[U][3], f[U][3];
+      real vnorm[U], inv_vn2[U], wself[U];
+      bool moving[U];
+      double cost_sphere[U];
+#pragma unroll
+      for (int u=0; u<U; u++)
+      {
+         wl[u] = g + u*ngroups;
+         live[u] = lane_ok && (wl[u] < nw);
+         l[u] = (wl[u] < nw && item < items ? wl[u] : 0) + 1;
+         const real * pc = pos_s + (l[u]*Sa + ss)*3;
+         const real * pp = pc - Sa*3;
+         const real * pn = pc + Sa*3;
+#pragma unroll
+         for (int k=0; k<3; k++)
+         {
+            p[u][k] = pc[k];
+            // src/orcdchomp_mod.cpp:1104-1106, 1120-1124
+            real v = pn[k]; v -= pp[k]; v *= b.inv_2dt; vel[u][k] = v;
+            real a = pc[k]; a *= (real)(-2); a += pp[k]; a += pn[k]; a *= b.inv_dt2; acc[u][k] = a;
+            f[u][k] = 0;
+         }
+         const real vn2 = vel[u][0]*vel[u][0] + vel[u][1]*vel[u][1] + vel[u][2]*vel[u][2];
+         real inv_vn;
+         vnorm[u] = sqrt_rsq(vn2, &inv_vn);
+         inv_vn2[u] = inv_vn * inv_vn;           // only used when vnorm > 1e-6
+         moving[u] = vnorm[u] > (real)0.000001;
+         wself[u] = vnorm[u] * b.obs_factor_self;
+         cost_sphere[u] = 0.0;
+      }
+
+      // ---- obstacle term (src/orcdchomp_mod.cpp:1171-1246) ----
+      real best[U], bgrad[U][3]; bool has[U];
+#pragma unroll
+      for (int u=0; u<U; u++) { best[u] = inf; has[u] = false; bgrad[u][0] = 0; bgrad[u][1] = 0; bgrad[u][2] = 0; }
+      for (int i=0; i<b.n_sdfs; i++)
+      {
+         const DevSdf<real> & F = b.sdfs[i];
+#pragma unroll
+         for (int u=0; u<U; u++)
+         {
+            real gp[3], gg[3], val;
+#pragma unroll
+            for (int k=0; k<3; k++)
+               gp[k] = F.Rgw[k*3+0]*p[u][0] + F.Rgw[k*3+1]*p[u][1] + F.Rgw[k*3+2]*p[u][2] + F.tgw[k];
+            const bool inb = sdf_lookup_pred(F, gp, val, gg);
+            const bool better = inb && (val < best[u]);           // strict <: HUGE_VAL never wins
+            best[u] = better ? val : best[u];
+            has[u] = has[u] || better;
+#pragma unroll
+            for (int k=0; k<3; k++)
+            {
+               const real gw = F.Rwg[k*3+0]*gg[0] + F.Rwg[k*3+1]*gg[1] + F.Rwg[k*3+2]*gg[2];   // grid -> world
+               bgrad[u][k] = better ? gw : bgrad[u][k];
+            }
+         }
+      }
+#pragma unroll
+      for (int u=0; u<U; u++)
+      {
+         const bool on = live[u] && has[u];
+         const real dist = best[u] - radius;
+         const real de = dist - b.epsilon;
+         real cs = (dist < (real)0) ? ((real)0.5 * b.epsilon - dist)
+                 : ((dist < b.epsilon) ? ((real)0.5 * inv_eps) * de * de : (real)0);
+         cs *= vnorm[u] * b.obs_factor;
+         cs = on ? cs : (real)0;
+         cost_sphere[u] += (double) cs;
+         const real scale = (dist < (real)0) ? (real)(-1) : ((dist < b.epsilon) ? dist * inv_eps - (real)1 : (real)0);
+         const real sc2 = scale * (vnorm[u] * b.obs_factor);
+         real xg[3], xc[3];
+#pragma unroll
+         for (int k=0; k<3; k++) { xg[k] = (scale == (real)0) ? (real)0 : bgrad[u][k] * sc2; xc[k] = acc[u][k]; }
+         const real pg = moving[u] ? (xg[0]*vel[u][0] + xg[1]*vel[u][1] + xg[2]*vel[u][2]) * inv_vn2[u] : (real)0;
+         const real pc2 = moving[u] ? (xc[0]*vel[u][0] + xc[1]*vel[u][1] + xc[2]*vel[u][2]) * inv_vn2[u] : (real)0;
+         // x_grad -= cost * curvature, curvature = xc/|v|^2; then c_grad += |v| J^T x_grad.  |v| == 0:
+         // the reference's dgemv(alpha=0) leaves c_grad untouched, so the sphere is skipped
+         const real cw = cs * inv_vn2[u];
+         const bool push = on && do_iteration && (vnorm[u] != (real)0);
+#pragma unroll
+         for (int k=0; k<3; k++)
+         {
+            const real val = vnorm[u] * ((xg[k] - pg * vel[u][k]) - cw * (xc[k] - pc2 * vel[u][k]));
+            f[u][k] = push ? val : (real)0;
+         }
+      }
+
+      // ---- self collision (src/orcdchomp_mod.cpp:1251-1317) ----
+      // which row rotations are needed (squared distances), and the inactive spheres
+      unsigned kl = 0u;
+      for (int o=0; o<Sa; o++)
+      {
+         const real R = radius + srad_s[o] + b.epsilon_self;
+         const real R2 = R * R;
+         const bool other_link = (slink_s[o] != mylink);
+         const unsigned bits = (1u << ((o - s) & 15)) | (1u << ((s - o) & 15));
+#pragma unroll
+         for (int u=0; u<U; u++)
+         {
+            const real * po = pos_s + (l[u]*Sa + o)*3;
+            const real dx = p[u][0]-po[0], dy = p[u][1]-po[1], dz = p[u][2]-po[2];
+            const real d2 = dx*dx + dy*dy + dz*dz;
+            kl |= (live[u] && other_link && !(d2 > R2)) ? bits : 0u;
+         }
+      }
+      for (int o=Sa; o<S; o++)                 // inactive spheres have no lane: only this lane's side
+      {
+         const real * po = sinact_s + (o - Sa)*3;
+         const real ro = srad_s[o];
+         const real R = radius + ro + b.epsilon_self;
+         const real R2 = R * R;
+         const bool other_link = (slink_s[o] != mylink);
+         real d[U][3], d2[U]; bool near[U]; bool any = false;
+#pragma unroll
+         for (int u=0; u<U; u++)
+         {
+#pragma unroll
+            for (int k=0; k<3; k++) d[u][k] = p[u][k] - po[k];
+            d2[u] = d[u][0]*d[u][0] + d[u][1]*d[u][1] + d[u][2]*d[u][2];
+            near[u] = live[u] && other_link && !(d2[u] > R2);
+            any = any || near[u];
+         }
+         if (!any) continue;
+#pragma unroll
+         for (int u=0; u<U; u++)
+         {
+            real inv_d;
+            real dist = sqrt_rsq(near[u] ? d2[u] : (real)1, &inv_d);
+            dist -= radius + ro;
+            const real de = dist - b.epsilon_self;
+            const real cself = (dist < (real)0) ? ((real)0.5 * b.epsilon_self - dist) : ((real)0.5 * inv_eps_self) * de * de;
+            cost_sphere[u] += near[u] ? (double)(wself[u] * cself) : 0.0;
+            const real scale = (dist < (real)0) ? (real)(-1) : ((dist < b.epsilon_self) ? dist * inv_eps_self - (real)1 : (real)1);
+            const real sd = scale * inv_d * wself[u];
+            real xx[3];
+#pragma unroll
+            for (int k=0; k<3; k++) xx[k] = d[u][k] * sd;
+            const real proj = moving[u] ? (xx[0]*vel[u][0] + xx[1]*vel[u][1] + xx[2]*vel[u][2]) * inv_vn2[u] : (real)0;
+#pragma unroll
+            for (int k=0; k<3; k++) f[u][k] += (near[u] && do_iteration) ? (xx[k] - proj * vel[u][k]) : (real)0;
+         }
+      }
+      // union over the wave (the rotation steps are wave-uniform branches)
+      unsigned km = kl;
+#pragma unroll
+      for (int o=32; o>0; o>>=1) km |= (unsigned) __shfl_xor((int) km, o, 64);
+      km = (unsigned) __builtin_amdgcn_readfirstlane((int) km);
+#define ORC_STEP(K) self_pair_step16u<real, U, K>(km, live, p, radius, mylink, vel, moving, inv_vn2, wself, \
+                       b.epsilon_self, inv_eps_self, do_iteration, f, cost_sphere)
+      ORC_STEP(1); ORC_STEP(2); ORC_STEP(3); ORC_STEP(4); ORC_STEP(5);
+      ORC_STEP(6); ORC_STEP(7); ORC_STEP(8); ORC_STEP(9); ORC_STEP(10);
+      ORC_STEP(11); ORC_STEP(12); ORC_STEP(13); ORC_STEP(14); ORC_STEP(15);
+#undef ORC_STEP
+
+#pragma unroll
+      for (int u=0; u<U; u++) cost_lane += live[u] ? cost_sphere[u] : 0.0;
+
+      // ---- J^T contraction and reduction over the 16 spheres of a waypoint ----
+      if (do_iteration)
+      {
+         const unsigned long long aff = lane_ok ? mod.sph_affects[ss] : 0ull;
+         bool row_ok[U];
+#pragma unroll
+         for (int u=0; u<U; u++) row_ok[u] = (item < items) && (wl[u] < nw) && (s == 0);
+         for (int j=0; j<nj; j++)
+         {
+            const bool hit = (aff >> j) & 1ull;
+            const bool rev = (jtype_s[j] == 1);
+            const int col = jcol_s[j];
+            real cg[U];
+#pragma unroll
+            for (int u=0; u<U; u++)
+            {
+               const real * ax = ax_s + (l[u]*nj + j)*6;
+               const real r0 = p[u][0]-ax[3], r1 = p[u][1]-ax[4], r2 = p[u][2]-ax[5];
+               const real c0 = r1*f[u][2] - r2*f[u][1];
+               const real c1 = r2*f[u][0] - r0*f[u][2];
+               const real c2 = r0*f[u][1] - r1*f[u][0];
+               const real crev = ax[0]*c0 + ax[1]*c1 + ax[2]*c2;
+               const real cpri = ax[0]*f[u][0] + ax[1]*f[u][1] + ax[2]*f[u][2];
+               cg[u] = (hit && live[u]) ? (rev ? crev : cpri) : (real)0;
+            }
+#pragma unroll
+            for (int u=0; u<U; u++) cg[u] = group_sum(cg[u], 16);
+#pragma unroll
+            for (int u=0; u<U; u++) if (row_ok[u]) G_s[(ts + wl[u])*n + col] = cg[u];
+         }
+         if (mod.floating)
+         {
+            // base block: 0.01 * Jsp^T [p x f ; f] summed over all spheres
+            // (src/orcdchomp_mod.cpp:1050-1080, src/libcd/spatial.c:295-337)
+#pragma unroll
+            for (int u=0; u<U; u++)
+            {
+               real w6[6];
+               w6[0] = p[u][1]*f[u][2] - p[u][2]*f[u][1];
+               w6[1] = p[u][2]*f[u][0] - p[u][0]*f[u][2];
+               w6[2] = p[u][0]*f[u][1] - p[u][1]*f[u][0];
+               w6[3] = f[u][0]; w6[4] = f[u][1]; w6[5] = f[u][2];
+#pragma unroll
+               for (int k=0; k<6; k++) w6[k] = group_sum(live[u] ? w6[k] : (real)0, 16);
+               if (row_ok[u])
+               {
+                  const int gi = ts + wl[u];
+                  const real * row = T_s + (gi+1)*n;
+                  const real x = row[0], y = row[1], z = row[2];
+                  const real qx = 2*row[3], qy = 2*row[4], qz = 2*row[5], qw = 2*row[6];
+                  real Jsp[6][7];
+#pragma unroll
+                  for (int a=0; a<6; a++)
+#pragma unroll
+                     for (int c=0; c<7; c++) Jsp[a][c] = 0;
+                  Jsp[3][0] = 1; Jsp[4][1] = 1; Jsp[5][2] = 1;
+                  Jsp[0][3] =  qw; Jsp[0][4] = -qz; Jsp[0][5] =  qy; Jsp[0][6] = -qx;
+                  Jsp[1][3] =  qz; Jsp[1][4] =  qw; Jsp[1][5] = -qx; Jsp[1][6] = -qy;
+                  Jsp[2][3] = -qy; Jsp[2][4] =  qx; Jsp[2][5] =  qw; Jsp[2][6] = -qz;
+                  Jsp[3][3] = -z*qz - y*qy; Jsp[3][4] = -z*qw + y*qx; Jsp[3][5] =  z*qx + y*qw; Jsp[3][6] =  z*qy - y*qz;
+                  Jsp[4][3] =  z*qw + x*qy; Jsp[4][4] = -z*qz - x*qx; Jsp[4][5] =  z*qy - x*qw; Jsp[4][6] = -z*qx + x*qz;
+                  Jsp[5][3] = -y*qw + x*qz; Jsp[5][4] =  y*qz + x*qw; Jsp[5][5] = -y*qy - x*qx; Jsp[5][6] =  y*qx - x*qy;
+#pragma unroll
+                  for (int c=0; c<7; c++)
+                  {
+                     real sum = 0;
+#pragma unroll
+                     for (int a=0; a<6; a++) sum += Jsp[a][c] * w6[a];
+                     G_s[gi*n + c] = (real)0.01 * sum;
+                  }
+               }
+            }
+         }
+      }
+   }
+}
