@@ -11,7 +11,7 @@
 #include <cstdlib>
 
 // launch wrappers implemented in chomp_kernel.hip
-size_t orc_chomp_lds_bytes(int n_points, int n, int Sa, int nj, int tile_m, size_t real_size);
+size_t orc_chomp_lds_bytes(int n_points, int n, int Sa, int S, int nj, int tile_m, int pcr_rows, size_t real_size);
 hipError_t orc_launch_iterate_f64(const DevBatch<double> & b, size_t lds, hipStream_t stream);
 hipError_t orc_launch_iterate_f32(const DevBatch<float> & b, size_t lds, hipStream_t stream);
 hipError_t orc_launch_seed_f64(double * traj, const double * starts, const double * goals,
@@ -399,18 +399,22 @@ void Batch::build_device(const Robot & robot)
    const size_t budgets[2] = { 80*1024 - 512, 160*1024 - 1024 };
    const int cands[7] = { m, 126, 94, 62, 30, 14, 6 };
    tile_m_ = 0;
-   for (int bi=0; bi<2 && !tile_m_; bi++)
-      for (int ci=0; ci<7 && !tile_m_; ci++)
-      {
-         const int t = cands[ci];
-         if (t > m || t > ORC_BLOCK - 2 || t < 1) continue;
-         const size_t need = orc_chomp_lds_bytes(n_points, n, Sa, nj, t, sizeof(real));
-         if (need <= budgets[bi]) { tile_m_ = t; lds_bytes_ = need; }
-      }
+   const int pcr_rows = metric_.pcr.empty() ? 0 : 2*metric_.pcr_levels + 1;
+   // the cyclic-reduction tables are staged in LDS when that does not cost a workgroup per CU
+   for (int with_pcr=1; with_pcr>=0 && !tile_m_; with_pcr--)
+      for (int bi=0; bi<2 && !tile_m_; bi++)
+         for (int ci=0; ci<7 && !tile_m_; ci++)
+         {
+            const int t = cands[ci];
+            if (t > m || t > ORC_BLOCK - 2 || t < 1) continue;
+            if (with_pcr && (!pcr_rows || bi > 0 || ci > 3)) continue;
+            const size_t need = orc_chomp_lds_bytes(n_points, n, Sa, S, nj, t, with_pcr ? pcr_rows : 0, sizeof(real));
+            if (need <= budgets[bi]) { tile_m_ = t; lds_bytes_ = need; pcr_in_lds_ = with_pcr; }
+         }
    if (!tile_m_)
    {
-      tile_m_ = 1;
-      lds_bytes_ = orc_chomp_lds_bytes(n_points, n, Sa, nj, 1, sizeof(real));
+      tile_m_ = 1; pcr_in_lds_ = 0;
+      lds_bytes_ = orc_chomp_lds_bytes(n_points, n, Sa, S, nj, 1, 0, sizeof(real));
       if (lds_bytes_ > budgets[1]) throw std::runtime_error("run does not fit the LDS of one CU!");
    }
 }
@@ -504,6 +508,17 @@ void Batch::launch(int n_iter)
    b.hmc_iters = d_hmc_iters_; b.noise = (const real *) d_noise_; b.max_resamples = max_resamples_;
    b.n_iter = n_iter; b.final_eval = 1;
    b.phase_cycles = d_phase_;
+   b.pcr_in_lds = pcr_in_lds_;
+   if (params.derivative == 1 && m >= 2)
+   {
+      b.a_diag = (real) metric_.Adense[(size_t) 1*m + 1];
+      b.a_off = (real) metric_.Adense[(size_t) 1*m + 0];
+   }
+   else if (params.derivative == 1)
+   {
+      b.a_diag = (real) metric_.Adense[0];
+      b.a_off = (real) metric_.beta_s[0];
+   }
    b.Gdbg = debug_state_ ? (real *) d_G_ : nullptr;
    mod_->time_begin();
    hipError_t e = launch_typed(b, lds_bytes_, mod_->stream);

@@ -258,7 +258,7 @@ __device__ __forceinline__ int sdf_lookup(const DevSdf<real> & f, const real p[3
 // buffer (src or tmp).  Coefficients: pcr[l][0][i] (towards i-s), pcr[l][1][i]
 // (towards i+s), then the inverse of the reduced diagonal.
 template <typename real>
-__device__ __forceinline__ real * pcr_solve(const DevBatch<real> & b, real * src, real * tmp)
+__device__ __forceinline__ real * pcr_solve(const DevBatch<real> & b, const real * tab, real * src, real * tmp)
 {
    const int m = b.m, n = b.n, mn = m*n;
    real * cur = src;
@@ -266,7 +266,7 @@ __device__ __forceinline__ real * pcr_solve(const DevBatch<real> & b, real * src
    int stride = 1;
    for (int l=0; l<b.pcr_levels; l++)
    {
-      const real * ka = b.pcr + (size_t)(2*l) * m;
+      const real * ka = tab + (size_t)(2*l) * m;
       const real * kc = ka + m;
       for (int e=threadIdx.x; e<mn; e+=ORC_BLOCK)
       {
@@ -280,7 +280,7 @@ __device__ __forceinline__ real * pcr_solve(const DevBatch<real> & b, real * src
       real * t = cur; cur = nxt; nxt = t;
       stride <<= 1;
    }
-   const real * invb = b.pcr + (size_t)(2*b.pcr_levels) * m;
+   const real * invb = tab + (size_t)(2*b.pcr_levels) * m;
    for (int e=threadIdx.x; e<mn; e+=ORC_BLOCK)
       cur[e] *= invb[e / n];
    __syncthreads();
@@ -304,9 +304,9 @@ __device__ __forceinline__ real * dense_solve(const DevBatch<real> & b, real * s
 }
 
 template <typename real>
-__device__ __forceinline__ real * metric_solve(const DevBatch<real> & b, real * src, real * tmp)
+__device__ __forceinline__ real * metric_solve(const DevBatch<real> & b, const real * tab, real * src, real * tmp)
 {
-   return b.solve_mode == 0 ? pcr_solve(b, src, tmp) : dense_solve(b, src, tmp);
+   return b.solve_mode == 0 ? pcr_solve(b, tab, src, tmp) : dense_solve(b, src, tmp);
 }
 
 // (A T + B)[i][c] from the band of A and the endpoint couplings of B.
@@ -315,6 +315,8 @@ template <typename real>
 __device__ __forceinline__ real smooth_grad(const DevBatch<real> & b, const real * T_s, int i, int c)
 {
    const int m = b.m, n = b.n, D = b.D;
+   if (D == 1)       // tridiagonal Toeplitz: the end rows couple to the fixed endpoints with a_off
+      return b.a_diag * T_s[(i+1)*n + c] + b.a_off * (T_s[i*n + c] + T_s[(i+2)*n + c]);
    real s = b.beta_s[i] * T_s[c] + b.beta_g[i] * T_s[(b.n_points-1)*n + c];
    for (int k=-D; k<=D; k++)
    {
@@ -346,19 +348,23 @@ void chomp_iterate_kernel(const DevBatch<real> b)
    const real inf = M<real>::inf();
 
    // ---- LDS carve-up ------------------------------------------------------
+   const LdsLayout L = lds_layout(np, n, Sa, S, nj, tile_m, b.pcr_in_lds ? 2*b.pcr_levels+1 : 0, (int) sizeof(real));
    double * red = (double *) smem_raw;                  // [8] reduction scratch
    int * redi = (int *)(red + 8);                       // [8]
-   real * T_s  = (real *)(smem_raw + 128);              // [np][n]
-   real * G_s  = T_s + ((np*n + 3) & ~3);               // [m][n]
-   real * W_s  = G_s + ((mn + 3) & ~3);                 // [m][n] work
-   real * AG_s = W_s + ((mn + 3) & ~3);                 // [m][n]
-   real * pos_s = AG_s + ((mn + 3) & ~3);               // [tile_m+2][Sa][3]
-   real * ax_s = pos_s + (((tile_m+2)*Sa*3 + 3) & ~3);  // [tile_m+2][nj][6]
-   real * srad_s = ax_s + (((tile_m+2)*nj*6 + 3) & ~3); // [S] sphere radii
-   real * sinact_s = srad_s + ORC_MAX_SPHERES;          // [S-Sa][3] inactive sphere centres
-   int * slink_s = (int *)(sinact_s + 3*ORC_MAX_SPHERES); // [S] link of each sphere
-   int * jtype_s = slink_s + ORC_MAX_SPHERES;           // [nj]
-   int * jcol_s = jtype_s + ORC_MAX_JOINTS;             // [nj]
+   real * lds = (real *)(smem_raw + 128);
+   real * T_s  = lds + L.T;                             // [np][n]
+   real * G_s  = lds + L.G;                             // [m][n]
+   real * W_s  = lds + L.W;                             // [m][n] work
+   real * AG_s = lds + L.AG;                            // [m][n]
+   real * pos_s = lds + L.pos;                          // [tile_m+2][Sa][3]
+   real * ax_s = lds + L.ax;                            // [tile_m+2][nj][6]
+   real * srad_s = lds + L.srad;                        // [S] sphere radii
+   real * sinact_s = lds + L.sinact;                    // [S-Sa][3] inactive sphere centres
+   real * jl_s = lds + L.jl;                            // [2][n] joint limits
+   real * pcr_s = lds + L.pcr;                          // cyclic-reduction tables (when staged)
+   int * slink_s = (int *)(smem_raw + L.ints_bytes);    // [S] link of each sphere
+   int * jtype_s = slink_s + S;                         // [nj]
+   int * jcol_s = jtype_s + nj;                         // [nj]
 
    real * traj_g = b.traj + (size_t) run * np * n;
    real * AG_g = b.AG + (size_t) run * mn;
@@ -367,6 +373,10 @@ void chomp_iterate_kernel(const DevBatch<real> b)
    for (int e=tid; e<S; e+=ORC_BLOCK) { srad_s[e] = mod.sph_radius[e]; slink_s[e] = mod.sph_link[e]; }
    for (int e=tid; e<(S-Sa)*3; e+=ORC_BLOCK) sinact_s[e] = mod.sph_inactive_pos[e/3][e%3];
    for (int e=tid; e<nj; e+=ORC_BLOCK) { jtype_s[e] = mod.joints[e].type; jcol_s[e] = mod.joints[e].col; }
+   for (int e=tid; e<n; e+=ORC_BLOCK) { jl_s[e] = b.jl_lo[e]; jl_s[n+e] = b.jl_hi[e]; }
+   if (b.pcr_in_lds)
+      for (int e=tid; e<(2*b.pcr_levels+1)*m; e+=ORC_BLOCK) pcr_s[e] = b.pcr[e];
+   const real * pcr_tab = b.pcr_in_lds ? pcr_s : b.pcr;
    const real inv_eps = (real)1 / b.epsilon, inv_eps_self = (real)1 / b.epsilon_self;
    for (int e=tid; e<mn; e+=ORC_BLOCK) AG_s[e] = AG_g[e];
    int leapfrog_first = b.leapfrog_first[run];
@@ -779,7 +789,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
          if (b.Gdbg)
             for (int e=tid; e<mn; e+=ORC_BLOCK) b.Gdbg[(size_t) run*mn + e] = G_s[e];
          // X = A^-1 G   (chomp.c:525-548)
-         real * X = metric_solve(b, G_s, W_s);
+         real * X = metric_solve(b, pcr_tab, G_s, W_s);
          if (!b.use_momentum)
             for (int e=tid; e<mn; e+=ORC_BLOCK) AG_s[e] = X[e];
          else
@@ -807,11 +817,19 @@ void chomp_iterate_kernel(const DevBatch<real> b)
                const int i = e / n, c = e - i*n;
                const real t = T_s[n + e];
                real gj = 0;
-               if (t < b.jl_lo[c]) gj = b.jl_lo[c] - t;
-               if (t > b.jl_hi[c]) gj = b.jl_hi[c] - t;
+               if (t < jl_s[c]) gj = jl_s[c] - t;
+               if (t > jl_s[n+c]) gj = jl_s[n+c] - t;
                G_s[e] = gj;
                const real a = M<real>::fabs_(gj);
                if (a > best) { best = a; best_e = e; }
+            }
+            // common case: nothing violated anywhere in the workgroup
+            {
+               const bool mine = __ballot(best > (real)0) != 0ull;
+               __syncthreads();
+               if ((tid & 63) == 0) redi[tid >> 6] = mine ? 1 : 0;
+               __syncthreads();
+               if (!(redi[0] | redi[1] | redi[2] | redi[3])) break;
             }
             // workgroup arg-max, ties to the smallest index (first in row-major scan)
 #pragma unroll
@@ -829,13 +847,13 @@ void chomp_iterate_kernel(const DevBatch<real> b)
             for (int w=1; w<4; w++)
                if (red[w] > gb || (red[w] == gb && redi[w] < ge)) { gb = red[w]; ge = redi[w]; }
             if (gb == 0.0) break;
-            real * GA = metric_solve(b, G_s, W_s);
+            real * GA = metric_solve(b, pcr_tab, G_s, W_s);
             // PCR may return either buffer; Gjlimit[largest] is recomputed from T
             const int gi = ge / n, gc = ge - gi*n;
             const real tl = T_s[n + ge];
             real gl = 0;
-            if (tl < b.jl_lo[gc]) gl = b.jl_lo[gc] - tl;
-            if (tl > b.jl_hi[gc]) gl = b.jl_hi[gc] - tl;
+            if (tl < jl_s[gc]) gl = jl_s[gc] - tl;
+            if (tl > jl_s[n+gc]) gl = jl_s[n+gc] - tl;
             const real sc = (real)1.01 * gl / GA[ge];
             __syncthreads();
             for (int e=tid; e<mn; e+=ORC_BLOCK) T_s[n + e] += sc * GA[e];
@@ -856,7 +874,8 @@ void chomp_iterate_kernel(const DevBatch<real> b)
          {
             const int i = e / n, c = e - i*n;
             const real sg = smooth_grad(b, T_s, i, c);           // (A T + B)
-            const real bt = b.beta_s[i] * T_s[c] + b.beta_g[i] * T_s[(np-1)*n + c];
+            const real bt = (b.D == 1) ? b.a_off * ((i == 0 ? T_s[c] : (real)0) + (i == m-1 ? T_s[(np-1)*n + c] : (real)0))
+                                       : b.beta_s[i] * T_s[c] + b.beta_g[i] * T_s[(np-1)*n + c];
             acc += (double) T_s[n + e] * (0.5 * ((double) sg + (double) bt));
          }
          double ss = 0.0, sg2 = 0.0, gg = 0.0;
@@ -938,13 +957,9 @@ __global__ void seed_traj_kernel(real * traj, const double * starts, const doubl
 
 // ---------------------------------------------------------------------------
 // host-side launch wrappers (called from module.cpp)
-size_t orc_chomp_lds_bytes(int n_points, int n, int Sa, int nj, int tile_m, size_t real_size)
+size_t orc_chomp_lds_bytes(int n_points, int n, int Sa, int S, int nj, int tile_m, int pcr_rows, size_t real_size)
 {
-   const int m = n_points - 2, mn = m*n;
-   size_t reals = ((size_t)(n_points*n + 3) & ~(size_t)3) + 3*(((size_t) mn + 3) & ~(size_t)3)
-                + (((size_t)(tile_m+2)*Sa*3 + 3) & ~(size_t)3) + (((size_t)(tile_m+2)*nj*6 + 3) & ~(size_t)3)
-                + (size_t) 4 * ORC_MAX_SPHERES;
-   return 128 + reals * real_size + (ORC_MAX_SPHERES + 2*ORC_MAX_JOINTS) * sizeof(int);
+   return (size_t) lds_layout(n_points, n, Sa, S, nj, tile_m, pcr_rows, (int) real_size).total_bytes;
 }
 
 template <typename real>

@@ -106,4 +106,39 @@ struct DevBatch
    int n_iter;
    int final_eval;
    long long * phase_cycles; // [n_runs][8] or null: diagnostics (cycles per phase, wave 0)
+   real a_diag, a_off;     // D == 1: A = tridiag(a_off, a_diag, a_off), B couples the end rows with a_off
+   int pcr_in_lds;         // the cyclic-reduction tables are staged in LDS
 };
+
+// LDS carve-up of one workgroup, shared by the kernel and the host-side size computation.
+// Offsets are in units of `real` after a 128-byte header (reduction scratch).
+struct LdsLayout
+{
+   int T, G, W, AG, pos, ax, srad, sinact, jl, pcr, end_reals;
+   int ints_bytes;         // byte offset of the int tables (slink, jtype, jcol)
+   int total_bytes;
+};
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline LdsLayout lds_layout(int np, int n, int Sa, int S, int nj, int tile_m, int pcr_rows, int real_size)
+{
+   const int m = np - 2, mn = m*n;
+   LdsLayout L;
+   int o = 0;
+   auto take = [&o](int count) { const int at = o; o += (count + 3) & ~3; return at; };
+   L.T = take(np*n);
+   L.G = take(mn);
+   L.W = take(mn);
+   L.AG = take(mn);
+   L.pos = take((tile_m+2)*Sa*3);
+   L.ax = take((tile_m+2)*nj*6);
+   L.srad = take(S);
+   L.sinact = take((S-Sa)*3 + 1);
+   L.jl = take(2*n);
+   L.pcr = take(pcr_rows*m);
+   L.end_reals = o;
+   L.ints_bytes = 128 + o*real_size;
+   L.total_bytes = L.ints_bytes + (S + 2*nj + 4) * (int) sizeof(int);
+   return L;
+}
