@@ -12,8 +12,8 @@
 
 // launch wrappers implemented in chomp_kernel.hip
 size_t orc_chomp_lds_bytes(int n_points, int n, int Sa, int S, int nj, int tile_m, int pcr_rows, size_t real_size);
-hipError_t orc_launch_iterate_f64(const DevBatch<double> & b, size_t lds, hipStream_t stream);
-hipError_t orc_launch_iterate_f32(const DevBatch<float> & b, size_t lds, hipStream_t stream);
+hipError_t orc_launch_iterate_f64(const DevBatch<double> & b, size_t lds, hipStream_t stream, int tree);
+hipError_t orc_launch_iterate_f32(const DevBatch<float> & b, size_t lds, hipStream_t stream, int tree);
 hipError_t orc_launch_seed_f64(double * traj, const double * starts, const double * goals,
    int n_runs, int n_points, int n, int floating, hipStream_t stream);
 hipError_t orc_launch_seed_f32(float * traj, const double * starts, const double * goals,
@@ -43,8 +43,8 @@ real * upload(const std::vector<double> & v, hipStream_t s)
 
 void dev_free(void * p) { if (p) hipFree(p); }
 
-hipError_t launch_typed(const DevBatch<double> & b, size_t lds, hipStream_t s) { return orc_launch_iterate_f64(b, lds, s); }
-hipError_t launch_typed(const DevBatch<float> & b, size_t lds, hipStream_t s) { return orc_launch_iterate_f32(b, lds, s); }
+hipError_t launch_typed(const DevBatch<double> & b, size_t lds, hipStream_t s, int tree) { return orc_launch_iterate_f64(b, lds, s, tree); }
+hipError_t launch_typed(const DevBatch<float> & b, size_t lds, hipStream_t s, int tree) { return orc_launch_iterate_f32(b, lds, s, tree); }
 
 } // namespace
 
@@ -291,10 +291,15 @@ void Batch::build_device(const Robot & robot)
       }
       for (int q=0; q<3; q++) { J.tfix[q] = (real) fix.t[q]; J.axis[q] = (real) robot.axis[3*li+q]; }
       J.rfix_identity = ident ? 1 : 0;
+      J.axis_kind = 0; J.axis_sign = (real) 1;
+      for (int q=0; q<3; q++)
+         if (std::fabs(robot.axis[3*li+q]) == 1.0 && robot.axis[3*li+(q+1)%3] == 0.0 && robot.axis[3*li+(q+2)%3] == 0.0)
+         { J.axis_kind = q + 1; J.axis_sign = (real) robot.axis[3*li+q]; }
       J.type = robot.joint_type[li];
       J.col = jcol[jk];
       J.load_slot = load_slot[jk];
       J.save_slot = save_slot[jk];
+      if (save_slot[jk] >= 0 || load_slot[jk] >= 0 || (load_slot[jk] == -2 && k > 0)) M.tree = 1;
       J.sph_begin = 0; J.sph_end = 0;
    }
    for (int s=0; s<Sa; s++)
@@ -330,7 +335,7 @@ void Batch::build_device(const Robot & robot)
       M.sph_link[Sa+s] = sp.link;
       device_sphere_order.push_back(inact[s].xml);
    }
-   nj_ = nj; Sa_ = Sa;
+   nj_ = nj; Sa_ = Sa; tree_ = M.tree;
 
    hipStream_t st = mod_->stream;
    DevModel<real> * dm = dev_alloc<DevModel<real>>(1);
@@ -521,7 +526,7 @@ void Batch::launch(int n_iter)
    }
    b.Gdbg = debug_state_ ? (real *) d_G_ : nullptr;
    mod_->time_begin();
-   hipError_t e = launch_typed(b, lds_bytes_, mod_->stream);
+   hipError_t e = launch_typed(b, lds_bytes_, mod_->stream, tree_);
    hip_check(e, "chomp_iterate_kernel launch");
    mod_->time_end();
 }

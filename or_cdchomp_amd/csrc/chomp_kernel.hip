@@ -328,13 +328,14 @@ __device__ __forceinline__ real smooth_grad(const DevBatch<real> & b, const real
 }
 
 #include "cost_gs16.h"
+#include "fk.h"
 
 #ifndef ORC_U
 #define ORC_U 2          // waypoints per lane in the 16-sphere cost phase (independent streams)
 #endif
 
 // ---------------------------------------------------------------------------
-template <typename real>
+template <typename real, bool TREE>
 __global__ __launch_bounds__(ORC_BLOCK, 2)
 void chomp_iterate_kernel(const DevBatch<real> b)
 {
@@ -418,101 +419,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
 
          // ================= FK phase: lane = waypoint =========================
          if (tid < nfk)
-         {
-            const int w = ts + tid;
-            const real * row = T_s + w*n;
-            Frame<real> base, cur, sv0, sv1, sv2, sv3;
-            if (mod.floating)
-            {
-               // base pose from the trajectory row (src/orcdchomp_mod.cpp:1008-1016)
-               const real qx = row[3], qy = row[4], qz = row[5], qw = row[6];
-               const real xx = qx*qx, xy = qx*qy, xz = qx*qz, xw = qx*qw;
-               const real yy = qy*qy, yz = qy*qz, yw = qy*qw, zz = qz*qz, zw = qz*qw;
-               base.R[0] = 1 - 2*(yy+zz); base.R[1] = 2*(xy-zw);     base.R[2] = 2*(xz+yw);
-               base.R[3] = 2*(xy+zw);     base.R[4] = 1 - 2*(xx+zz); base.R[5] = 2*(yz-xw);
-               base.R[6] = 2*(xz-yw);     base.R[7] = 2*(yz+xw);     base.R[8] = 1 - 2*(xx+yy);
-               base.t[0] = row[0]; base.t[1] = row[1]; base.t[2] = row[2];
-               for (int s=mod.base_sph_begin; s<mod.base_sph_end; s++)
-               {
-                  const real * lp = mod.sph_pos[s];
-                  real * o = pos_s + (tid*Sa + s)*3;
-#pragma unroll
-                  for (int k=0; k<3; k++)
-                     o[k] = base.R[k*3+0]*lp[0] + base.R[k*3+1]*lp[1] + base.R[k*3+2]*lp[2] + base.t[k];
-               }
-            }
-            else
-            {
-#pragma unroll
-               for (int k=0; k<9; k++) base.R[k] = mod.base_R[k];
-#pragma unroll
-               for (int k=0; k<3; k++) base.t[k] = mod.base_t[k];
-            }
-            cur = base; sv0 = base; sv1 = base; sv2 = base; sv3 = base;
-            for (int j=0; j<nj; j++)
-            {
-               const DevJoint<real> & J = mod.joints[j];
-               // continue from the previous joint's frame unless the tree branches here
-               if (J.load_slot == -2) cur = base;
-               else if (J.load_slot == 0) cur = sv0;
-               else if (J.load_slot == 1) cur = sv1;
-               else if (J.load_slot == 2) cur = sv2;
-               else if (J.load_slot == 3) cur = sv3;
-               const Frame<real> & from = cur;
-               // joint frame in the world
-               real Rj[9], tj[3];
-               if (J.rfix_identity)
-               {
-#pragma unroll
-                  for (int k=0; k<9; k++) Rj[k] = from.R[k];
-               }
-               else mat3_mul(from.R, J.Rfix, Rj);
-#pragma unroll
-               for (int k=0; k<3; k++)
-                  tj[k] = from.R[k*3+0]*J.tfix[0] + from.R[k*3+1]*J.tfix[1] + from.R[k*3+2]*J.tfix[2] + from.t[k];
-               real aw[3];
-#pragma unroll
-               for (int k=0; k<3; k++)
-                  aw[k] = Rj[k*3+0]*J.axis[0] + Rj[k*3+1]*J.axis[1] + Rj[k*3+2]*J.axis[2];
-               real * axo = ax_s + (tid*nj + j)*6;
-               axo[0] = aw[0]; axo[1] = aw[1]; axo[2] = aw[2];
-               axo[3] = tj[0]; axo[4] = tj[1]; axo[5] = tj[2];
-               const real q = row[J.col];
-               if (J.type == 1)
-               {
-                  real sn, cs;
-                  M<real>::sincos_(q, &sn, &cs);
-                  const real v = (real)1 - cs;
-                  const real a0 = J.axis[0], a1 = J.axis[1], a2 = J.axis[2];
-                  real Rm[9];
-                  Rm[0] = cs + a0*a0*v;    Rm[1] = a0*a1*v - a2*sn; Rm[2] = a0*a2*v + a1*sn;
-                  Rm[3] = a1*a0*v + a2*sn; Rm[4] = cs + a1*a1*v;    Rm[5] = a1*a2*v - a0*sn;
-                  Rm[6] = a2*a0*v - a1*sn; Rm[7] = a2*a1*v + a0*sn; Rm[8] = cs + a2*a2*v;
-                  mat3_mul(Rj, Rm, cur.R);
-#pragma unroll
-                  for (int k=0; k<3; k++) cur.t[k] = tj[k];
-               }
-               else
-               {
-#pragma unroll
-                  for (int k=0; k<9; k++) cur.R[k] = Rj[k];
-#pragma unroll
-                  for (int k=0; k<3; k++) cur.t[k] = tj[k] + q*aw[k];
-               }
-               if (J.save_slot == 0) sv0 = cur;
-               else if (J.save_slot == 1) sv1 = cur;
-               else if (J.save_slot == 2) sv2 = cur;
-               else if (J.save_slot == 3) sv3 = cur;
-               for (int s=J.sph_begin; s<J.sph_end; s++)
-               {
-                  const real * lp = mod.sph_pos[s];
-                  real * o = pos_s + (tid*Sa + s)*3;
-#pragma unroll
-                  for (int k=0; k<3; k++)
-                     o[k] = cur.R[k*3+0]*lp[0] + cur.R[k*3+1]*lp[1] + cur.R[k*3+2]*lp[2] + cur.t[k];
-               }
-            }
-         }
+            fk_waypoint<real, TREE>(mod, T_s + (ts + tid)*n, nj, Sa, pos_s + tid*Sa*3, ax_s + tid*nj*6);
          __syncthreads();
          ORC_MARK(0);
 
@@ -962,25 +869,31 @@ size_t orc_chomp_lds_bytes(int n_points, int n, int Sa, int S, int nj, int tile_
    return (size_t) lds_layout(n_points, n, Sa, S, nj, tile_m, pcr_rows, (int) real_size).total_bytes;
 }
 
-template <typename real>
-static hipError_t launch_iterate_t(const DevBatch<real> & b, size_t lds, hipStream_t stream)
+template <typename real, bool TREE>
+static hipError_t launch_iterate_tt(const DevBatch<real> & b, size_t lds, hipStream_t stream)
 {
    static bool attr_set = false;
    if (!attr_set)
    {
-      hipError_t e = hipFuncSetAttribute((const void *) chomp_iterate_kernel<real>,
+      hipError_t e = hipFuncSetAttribute((const void *) chomp_iterate_kernel<real, TREE>,
          hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256);
       if (e != hipSuccess) return e;
       attr_set = true;
    }
-   hipLaunchKernelGGL(chomp_iterate_kernel<real>, dim3(b.n_runs), dim3(ORC_BLOCK), lds, stream, b);
+   hipLaunchKernelGGL((chomp_iterate_kernel<real, TREE>), dim3(b.n_runs), dim3(ORC_BLOCK), lds, stream, b);
    return hipGetLastError();
 }
 
-hipError_t orc_launch_iterate_f64(const DevBatch<double> & b, size_t lds, hipStream_t stream)
-{ return launch_iterate_t<double>(b, lds, stream); }
-hipError_t orc_launch_iterate_f32(const DevBatch<float> & b, size_t lds, hipStream_t stream)
-{ return launch_iterate_t<float>(b, lds, stream); }
+template <typename real>
+static hipError_t launch_iterate_t(const DevBatch<real> & b, size_t lds, hipStream_t stream, int tree)
+{
+   return tree ? launch_iterate_tt<real, true>(b, lds, stream) : launch_iterate_tt<real, false>(b, lds, stream);
+}
+
+hipError_t orc_launch_iterate_f64(const DevBatch<double> & b, size_t lds, hipStream_t stream, int tree)
+{ return launch_iterate_t<double>(b, lds, stream, tree); }
+hipError_t orc_launch_iterate_f32(const DevBatch<float> & b, size_t lds, hipStream_t stream, int tree)
+{ return launch_iterate_t<float>(b, lds, stream, tree); }
 
 hipError_t orc_launch_seed_f64(double * traj, const double * starts, const double * goals,
    int n_runs, int n_points, int n, int floating, hipStream_t stream)

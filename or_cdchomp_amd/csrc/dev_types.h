@@ -27,7 +27,8 @@ struct DevJoint
    int sph_begin;     // active spheres [sph_begin, sph_end) ride on this joint's moved frame
    int sph_end;
    int rfix_identity; // Rfix == I (skips a 3x3 product)
-   int pad;
+   int axis_kind;     // 1/2/3: the axis is +-x/+-y/+-z of the joint frame (cheap column rotation), 0 general
+   real axis_sign;    // +-1 for axis_kind != 0
 };
 
 template <typename real>
@@ -36,6 +37,7 @@ struct DevModel
    int nj;                 // optimized joints
    int n;                  // optimizer dofs = 7*floating + n_adof
    int floating;           // floating base: columns 0..6 are the base pose
+   int tree;               // the joint tree branches (frames are saved/restored while walking it)
    int Sa;                 // active spheres (device order: sorted by joint)
    int S;                  // all spheres
    int GS;                 // lanes per waypoint in the cost phase (power of two >= Sa)

@@ -113,6 +113,7 @@ private:
    int nj_ = 0, Sa_ = 0;
    int tile_m_ = 0;
    int pcr_in_lds_ = 0;
+   int tree_ = 0;
    size_t lds_bytes_ = 0;
    std::vector<double> jl_lo_, jl_hi_;
    // hmc host state per run (src/orcdchomp_mod.cpp:948-952)
