@@ -11,7 +11,8 @@
 #include <cstdlib>
 
 // launch wrappers implemented in chomp_kernel.hip
-size_t orc_chomp_lds_bytes(int n_points, int n, int Sa, int S, int nj, int tile_m, int pcr_rows, size_t real_size);
+size_t orc_chomp_lds_bytes(int n_points, int n, int Sa, int S, int nj, int tile_m, int pcr_rows, size_t real_size,
+   int use_momentum, int n_sdfs);
 hipError_t orc_launch_iterate_f64(const DevBatch<double> & b, size_t lds, hipStream_t stream, int tree);
 hipError_t orc_launch_iterate_f32(const DevBatch<float> & b, size_t lds, hipStream_t stream, int tree);
 hipError_t orc_launch_seed_f64(double * traj, const double * starts, const double * goals,
@@ -413,13 +414,13 @@ void Batch::build_device(const Robot & robot)
             const int t = cands[ci];
             if (t > m || t > ORC_BLOCK - 2 || t < 1) continue;
             if (with_pcr && (!pcr_rows || bi > 0 || ci > 3)) continue;
-            const size_t need = orc_chomp_lds_bytes(n_points, n, Sa, S, nj, t, with_pcr ? pcr_rows : 0, sizeof(real));
+            const size_t need = orc_chomp_lds_bytes(n_points, n, Sa, S, nj, t, with_pcr ? pcr_rows : 0, sizeof(real), params.use_momentum, n_sdfs_);
             if (need <= budgets[bi]) { tile_m_ = t; lds_bytes_ = need; pcr_in_lds_ = with_pcr; }
          }
    if (!tile_m_)
    {
       tile_m_ = 1; pcr_in_lds_ = 0;
-      lds_bytes_ = orc_chomp_lds_bytes(n_points, n, Sa, S, nj, 1, 0, sizeof(real));
+      lds_bytes_ = orc_chomp_lds_bytes(n_points, n, Sa, S, nj, 1, 0, sizeof(real), params.use_momentum, n_sdfs_);
       if (lds_bytes_ > budgets[1]) throw std::runtime_error("run does not fit the LDS of one CU!");
    }
 }

@@ -340,16 +340,17 @@ __global__ __launch_bounds__(ORC_BLOCK, 2)
 void chomp_iterate_kernel(const DevBatch<real> b)
 {
    extern __shared__ __align__(16) unsigned char smem_raw[];
-   const DevModel<real> & mod = *b.model;
+   const DevModel<real> & gmod = *b.model;      // global copy: read once, staged into LDS below
    const int run = blockIdx.x;
    const int tid = threadIdx.x;
    const int n = b.n, m = b.m, np = b.n_points, mn = m*n;
-   const int nj = mod.nj, Sa = mod.Sa, S = mod.S, GS = mod.GS;
+   const int nj = gmod.nj, Sa = gmod.Sa, S = gmod.S, GS = gmod.GS;
    const int tile_m = b.tile_m;
    const real inf = M<real>::inf();
 
    // ---- LDS carve-up ------------------------------------------------------
-   const LdsLayout L = lds_layout(np, n, Sa, S, nj, tile_m, b.pcr_in_lds ? 2*b.pcr_levels+1 : 0, (int) sizeof(real));
+   const LdsLayout L = lds_layout(np, n, Sa, S, nj, tile_m, b.pcr_in_lds ? 2*b.pcr_levels+1 : 0, (int) sizeof(real),
+                                  b.use_momentum, b.n_sdfs, (int) sizeof(DevJoint<real>), (int) sizeof(DevSdf<real>));
    double * red = (double *) smem_raw;                  // [8] reduction scratch
    int * redi = (int *)(red + 8);                       // [8]
    real * lds = (real *)(smem_raw + 128);
@@ -366,20 +367,41 @@ void chomp_iterate_kernel(const DevBatch<real> b)
    int * slink_s = (int *)(smem_raw + L.ints_bytes);    // [S] link of each sphere
    int * jtype_s = slink_s + S;                         // [nj]
    int * jcol_s = jtype_s + nj;                         // [nj]
+   real * sphpos_s = pcr_s + (((b.pcr_in_lds ? 2*b.pcr_levels+1 : 0)*m + 3) & ~3);   // [Sa][3] + base frame [12]
+   real * base_s = sphpos_s + Sa*3;
+   DevJoint<real> * joints_s = (DevJoint<real> *)(smem_raw + L.joints_bytes);
+   DevSdf<real> * sdfs_s = (DevSdf<real> *)(smem_raw + L.sdfs_bytes);
+   unsigned long long * saff_s = (unsigned long long *)(smem_raw + L.saff_bytes);
+   ModelView<real> mod;
+   mod.nj = nj; mod.n = n; mod.floating = gmod.floating; mod.tree = gmod.tree; mod.Sa = Sa; mod.S = S; mod.GS = GS;
+   mod.base_sph_begin = gmod.base_sph_begin; mod.base_sph_end = gmod.base_sph_end;
+   mod.base_R = base_s; mod.base_t = base_s + 9;
+   mod.joints = joints_s; mod.sph_pos = (const real (*)[3]) sphpos_s; mod.sph_affects = saff_s;
+   const DevSdf<real> * sdfs = sdfs_s;
 
    real * traj_g = b.traj + (size_t) run * np * n;
    real * AG_g = b.AG + (size_t) run * mn;
 
    for (int e=tid; e<np*n; e+=ORC_BLOCK) T_s[e] = traj_g[e];
-   for (int e=tid; e<S; e+=ORC_BLOCK) { srad_s[e] = mod.sph_radius[e]; slink_s[e] = mod.sph_link[e]; }
-   for (int e=tid; e<(S-Sa)*3; e+=ORC_BLOCK) sinact_s[e] = mod.sph_inactive_pos[e/3][e%3];
-   for (int e=tid; e<nj; e+=ORC_BLOCK) { jtype_s[e] = mod.joints[e].type; jcol_s[e] = mod.joints[e].col; }
+   for (int e=tid; e<S; e+=ORC_BLOCK) { srad_s[e] = gmod.sph_radius[e]; slink_s[e] = gmod.sph_link[e]; }
+   for (int e=tid; e<(S-Sa)*3; e+=ORC_BLOCK) sinact_s[e] = gmod.sph_inactive_pos[e/3][e%3];
+   for (int e=tid; e<nj; e+=ORC_BLOCK) { jtype_s[e] = gmod.joints[e].type; jcol_s[e] = gmod.joints[e].col; }
+   for (int e=tid; e<Sa*3; e+=ORC_BLOCK) sphpos_s[e] = gmod.sph_pos[e/3][e%3];
+   for (int e=tid; e<Sa; e+=ORC_BLOCK) saff_s[e] = gmod.sph_affects[e];
+   for (int e=tid; e<12; e+=ORC_BLOCK) base_s[e] = (e < 9) ? gmod.base_R[e] : gmod.base_t[e-9];
+   {
+      // word-wise copies of the joint and field descriptors
+      const int * src = (const int *) gmod.joints; int * dst = (int *) joints_s;
+      for (int e=tid; e<nj*(int)(sizeof(DevJoint<real>)/4); e+=ORC_BLOCK) dst[e] = src[e];
+      const int * src2 = (const int *) b.sdfs; int * dst2 = (int *) sdfs_s;
+      for (int e=tid; e<b.n_sdfs*(int)(sizeof(DevSdf<real>)/4); e+=ORC_BLOCK) dst2[e] = src2[e];
+   }
    for (int e=tid; e<n; e+=ORC_BLOCK) { jl_s[e] = b.jl_lo[e]; jl_s[n+e] = b.jl_hi[e]; }
    if (b.pcr_in_lds)
       for (int e=tid; e<(2*b.pcr_levels+1)*m; e+=ORC_BLOCK) pcr_s[e] = b.pcr[e];
    const real * pcr_tab = b.pcr_in_lds ? pcr_s : b.pcr;
    const real inv_eps = (real)1 / b.epsilon, inv_eps_self = (real)1 / b.epsilon_self;
-   for (int e=tid; e<mn; e+=ORC_BLOCK) AG_s[e] = AG_g[e];
+   if (b.use_momentum) for (int e=tid; e<mn; e+=ORC_BLOCK) AG_s[e] = AG_g[e];
    int leapfrog_first = b.leapfrog_first[run];
    int status = b.status[run];
    int next_resample = 0;      // index into this call's resample list
@@ -400,7 +422,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
       if (status != 0) break;
 
       // ---- hmc momentum resample (src/orcdchomp_mod.cpp:2755-2768) ----------
-      if (do_iteration && b.use_hmc && next_resample < b.max_resamples
+      if (do_iteration && b.use_hmc && b.use_momentum && next_resample < b.max_resamples
           && b.hmc_iters[(size_t) run * b.max_resamples + next_resample] == it)
       {
          const real * nz = b.noise + ((size_t) run * b.max_resamples + next_resample) * mn;
@@ -425,7 +447,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
 
          // ================= cost phase: lane = (waypoint, sphere) =============
          if (GS == 16)
-            cost_tile_gs16<real, ORC_U>(b, mod, ts, te, do_iteration, T_s, G_s, pos_s, ax_s, srad_s, sinact_s,
+            cost_tile_gs16<real, ORC_U>(b, mod, sdfs, ts, te, do_iteration, T_s, G_s, pos_s, ax_s, srad_s, sinact_s,
                                         slink_s, jtype_s, jcol_s, inv_eps, inv_eps_self, cost_lane);
          else
          {
@@ -470,7 +492,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
 #ifndef ORC_ABLATE_SDF
                for (int i=0; i<b.n_sdfs; i++)
                {
-                  const DevSdf<real> & F = b.sdfs[i];
+                  const DevSdf<real> & F = sdfs[i];
                   real g[3], gg[3], val;
 #pragma unroll
                   for (int k=0; k<3; k++)
@@ -481,7 +503,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
 #endif
                if (best_i != -1)
                {
-                  const DevSdf<real> & F = b.sdfs[best_i];
+                  const DevSdf<real> & F = sdfs[best_i];
                   const real dist = best - radius;
                   real cs = 0;
                   if (dist < (real)0)
@@ -697,19 +719,29 @@ void chomp_iterate_kernel(const DevBatch<real> b)
             for (int e=tid; e<mn; e+=ORC_BLOCK) b.Gdbg[(size_t) run*mn + e] = G_s[e];
          // X = A^-1 G   (chomp.c:525-548)
          real * X = metric_solve(b, pcr_tab, G_s, W_s);
+         // T -= AG/lambda   (chomp.c:604-605)
+         const real step = (real)(-1) / b.lambda;
          if (!b.use_momentum)
-            for (int e=tid; e<mn; e+=ORC_BLOCK) AG_s[e] = X[e];
+         {
+            // AG = X is not carried between iterations: keep only the last one (read-back state)
+            const bool keep = (it == b.n_iter - 1) || (b.Gdbg != nullptr);
+            for (int e=tid; e<mn; e+=ORC_BLOCK)
+            {
+               const real x = X[e];
+               if (keep) AG_g[e] = x;
+               T_s[n + e] += step * x;
+            }
+         }
          else
          {
             const real sc = (leapfrog_first ? (real)0.5 : (real)1) / b.lambda;
-            for (int e=tid; e<mn; e+=ORC_BLOCK) AG_s[e] += sc * X[e];
+            for (int e=tid; e<mn; e+=ORC_BLOCK)
+            {
+               const real ag = AG_s[e] + sc * X[e];
+               AG_s[e] = ag;
+               T_s[n + e] += step * ag;
+            }
             leapfrog_first = 0;
-         }
-         __syncthreads();
-         // T -= AG/lambda   (chomp.c:604-605)
-         {
-            const real sc = (real)(-1) / b.lambda;
-            for (int e=tid; e<mn; e+=ORC_BLOCK) T_s[n + e] += sc * AG_s[e];
          }
          __syncthreads();
 
@@ -819,7 +851,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
    // ---- write back ---------------------------------------------------------
    __syncthreads();
    for (int e=tid; e<np*n; e+=ORC_BLOCK) traj_g[e] = T_s[e];
-   for (int e=tid; e<mn; e+=ORC_BLOCK) AG_g[e] = AG_s[e];
+   if (b.use_momentum) for (int e=tid; e<mn; e+=ORC_BLOCK) AG_g[e] = AG_s[e];
    if (tid == 0)
    {
       if (b.phase_cycles) for (int k=0; k<8; k++) b.phase_cycles[(size_t) run*8 + k] = ph[k];
@@ -864,9 +896,12 @@ __global__ void seed_traj_kernel(real * traj, const double * starts, const doubl
 
 // ---------------------------------------------------------------------------
 // host-side launch wrappers (called from module.cpp)
-size_t orc_chomp_lds_bytes(int n_points, int n, int Sa, int S, int nj, int tile_m, int pcr_rows, size_t real_size)
+size_t orc_chomp_lds_bytes(int n_points, int n, int Sa, int S, int nj, int tile_m, int pcr_rows, size_t real_size,
+   int use_momentum, int n_sdfs)
 {
-   return (size_t) lds_layout(n_points, n, Sa, S, nj, tile_m, pcr_rows, (int) real_size).total_bytes;
+   const int js = real_size == 8 ? (int) sizeof(DevJoint<double>) : (int) sizeof(DevJoint<float>);
+   const int ss = real_size == 8 ? (int) sizeof(DevSdf<double>) : (int) sizeof(DevSdf<float>);
+   return (size_t) lds_layout(n_points, n, Sa, S, nj, tile_m, pcr_rows, (int) real_size, use_momentum, n_sdfs, js, ss).total_bytes;
 }
 
 template <typename real, bool TREE>

@@ -114,9 +114,152 @@ __device__ __forceinline__ void self_pair_step16u(unsigned kmask, const bool liv
    }
 }
 
+
+// NC independent evaluations of (sqrt(x), 1/sqrt(x)) written in lockstep, so that consecutive
+// instructions belong to different dependency chains (see sqrt_rsq for the scheme)
+template <int NC>
+__device__ __forceinline__ void sqrt_rsq_lockstep(const double x[NC], double g[NC], double inv[NC])
+{
+   double r[NC], h[NC], e[NC];
+#pragma unroll
+   for (int c=0; c<NC; c++) r[c] = __builtin_amdgcn_rsq(x[c]);
+#pragma unroll
+   for (int c=0; c<NC; c++) g[c] = x[c] * r[c];
+#pragma unroll
+   for (int c=0; c<NC; c++) h[c] = 0.5 * r[c];
+#pragma unroll
+   for (int k=0; k<2; k++)
+   {
+#pragma unroll
+      for (int c=0; c<NC; c++) e[c] = fma(-h[c], g[c], 0.5);
+#pragma unroll
+      for (int c=0; c<NC; c++) g[c] = fma(g[c], e[c], g[c]);
+#pragma unroll
+      for (int c=0; c<NC; c++) h[c] = fma(h[c], e[c], h[c]);
+   }
+#pragma unroll
+   for (int c=0; c<NC; c++) e[c] = fma(-g[c], g[c], x[c]);
+#pragma unroll
+   for (int c=0; c<NC; c++) g[c] = fma(e[c], h[c], g[c]);
+#pragma unroll
+   for (int c=0; c<NC; c++) inv[c] = 2.0 * h[c];
+}
+template <int NC>
+__device__ __forceinline__ void sqrt_rsq_lockstep(const float x[NC], float g[NC], float inv[NC])
+{
+#pragma unroll
+   for (int c=0; c<NC; c++) { g[c] = ::sqrtf(x[c]); inv[c] = 1.0f / g[c]; }
+}
+
+// the arithmetic of NC pair evaluations (chains) in lockstep: from the separation vectors d to
+// the forces x on this lane's spheres.  near[c] masks chains that are out of range.
+template <typename real, int NC>
+__device__ __forceinline__ void pair_forces_lockstep(const real d[NC][3], const real d2[NC], const bool near[NC],
+   const real rsum[NC], const real * const vel[NC], const bool moving[NC], const real inv_vn2[NC], const real wself[NC],
+   real eps_self, real inv_eps_self, bool do_iteration, real x[NC][3], double cadd[NC])
+{
+   real xs[NC], dist[NC], inv_d[NC];
+#pragma unroll
+   for (int c=0; c<NC; c++) xs[c] = near[c] ? d2[c] : (real)1;
+   sqrt_rsq_lockstep<NC>(xs, dist, inv_d);
+#pragma unroll
+   for (int c=0; c<NC; c++) dist[c] -= rsum[c];
+   real de[NC], cself[NC], scale[NC], sd[NC], proj[NC];
+#pragma unroll
+   for (int c=0; c<NC; c++) de[c] = dist[c] - eps_self;
+#pragma unroll
+   for (int c=0; c<NC; c++)
+      cself[c] = (dist[c] < (real)0) ? ((real)0.5 * eps_self - dist[c]) : ((real)0.5 * inv_eps_self) * de[c] * de[c];
+#pragma unroll
+   for (int c=0; c<NC; c++) cadd[c] = near[c] ? (double)(wself[c] * cself[c]) : 0.0;
+#pragma unroll
+   for (int c=0; c<NC; c++)
+      scale[c] = (dist[c] < (real)0) ? (real)(-1) : ((dist[c] < eps_self) ? dist[c] * inv_eps_self - (real)1 : (real)1);
+#pragma unroll
+   for (int c=0; c<NC; c++) sd[c] = scale[c] * inv_d[c] * wself[c];
+   real xx[NC][3];
+#pragma unroll
+   for (int k=0; k<3; k++)
+#pragma unroll
+      for (int c=0; c<NC; c++) xx[c][k] = d[c][k] * sd[c];
+#pragma unroll
+   for (int c=0; c<NC; c++) proj[c] = xx[c][0]*vel[c][0];
+#pragma unroll
+   for (int c=0; c<NC; c++) proj[c] = fma(xx[c][1], vel[c][1], proj[c]);
+#pragma unroll
+   for (int c=0; c<NC; c++) proj[c] = fma(xx[c][2], vel[c][2], proj[c]);
+#pragma unroll
+   for (int c=0; c<NC; c++) proj[c] = moving[c] ? proj[c] * inv_vn2[c] : (real)0;
+#pragma unroll
+   for (int k=0; k<3; k++)
+#pragma unroll
+      for (int c=0; c<NC; c++) x[c][k] = (near[c] && do_iteration) ? (xx[c][k] - proj[c] * vel[c][k]) : (real)0;
+}
+
+// two rotation steps (K1, K2) of the self-collision term for U waypoints per lane: 2U chains
+// evaluated in lockstep.  See self_pair_step16 for the pairing scheme.
+template <typename real, int U, int K1, int K2>
+__device__ __forceinline__ void self_pair_steps16(const bool live[U], const real p[U][3],
+   real radius, int mylink, const real vel[U][3], const bool moving[U], const real inv_vn2[U], const real wself[U],
+   real eps_self, real inv_eps_self, bool do_iteration, real f[U][3], double cost_sphere[U])
+{
+   constexpr int NC = 2*U;
+   constexpr int F1 = 0x120 + K1, B1 = 0x120 + (16 - K1);
+   constexpr int F2 = 0x120 + K2, B2 = 0x120 + (16 - K2);
+   real d[NC][3], d2[NC], rsum[NC], R2[2], iv2[NC], ws[NC];
+   const real * vp[NC];
+   bool near[NC], mv[NC], other[2];
+   {
+      const real ro1 = dpp_move<F1>(radius), ro2 = dpp_move<F2>(radius);
+      const int lo1 = dpp_move<F1>(mylink), lo2 = dpp_move<F2>(mylink);
+      other[0] = (lo1 != mylink); other[1] = (lo2 != mylink);
+      const real s1 = radius + ro1, s2 = radius + ro2;
+      const real Ra = s1 + eps_self, Rb = s2 + eps_self;
+      R2[0] = Ra * Ra; R2[1] = Rb * Rb;
+#pragma unroll
+      for (int u=0; u<U; u++) { rsum[u] = s1; rsum[U+u] = s2; }
+   }
+   bool any = false;
+#pragma unroll
+   for (int u=0; u<U; u++)
+   {
+#pragma unroll
+      for (int k=0; k<3; k++)
+      {
+         d[u][k] = p[u][k] - dpp_move<F1>(p[u][k]);
+         d[U+u][k] = p[u][k] - dpp_move<F2>(p[u][k]);
+      }
+      const int a1 = dpp_move<F1>(live[u] ? 1 : 0), a2 = dpp_move<F2>(live[u] ? 1 : 0);
+      d2[u] = d[u][0]*d[u][0] + d[u][1]*d[u][1] + d[u][2]*d[u][2];
+      d2[U+u] = d[U+u][0]*d[U+u][0] + d[U+u][1]*d[U+u][1] + d[U+u][2]*d[U+u][2];
+      near[u] = live[u] && a1 && other[0] && !(d2[u] > R2[0]);
+      near[U+u] = live[u] && a2 && other[1] && !(d2[U+u] > R2[1]);
+      any = any || near[u] || near[U+u];
+      vp[u] = vel[u]; vp[U+u] = vel[u];
+      mv[u] = moving[u]; mv[U+u] = moving[u];
+      iv2[u] = inv_vn2[u]; iv2[U+u] = inv_vn2[u];
+      ws[u] = wself[u]; ws[U+u] = wself[u];
+   }
+   real x[NC][3]; double cadd[NC];
+#pragma unroll
+   for (int c=0; c<NC; c++) { x[c][0] = 0; x[c][1] = 0; x[c][2] = 0; cadd[c] = 0.0; }
+   if (any)
+      pair_forces_lockstep<real, NC>(d, d2, near, rsum, vp, mv, iv2, ws, eps_self, inv_eps_self, do_iteration, x, cadd);
+#pragma unroll
+   for (int u=0; u<U; u++) cost_sphere[u] += cadd[u] + cadd[U+u];
+   if (do_iteration)
+   {
+#pragma unroll
+      for (int u=0; u<U; u++)
+#pragma unroll
+         for (int k=0; k<3; k++)
+            f[u][k] += (x[u][k] - dpp_move<B1>(x[u][k])) + (x[U+u][k] - dpp_move<B2>(x[U+u][k]));
+   }
+}
+
 template <typename real, int U>
-__device__ __forceinline__ void cost_tile_gs16(const DevBatch<real> & b, const DevModel<real> & mod,
-   int ts, int te, bool do_iteration, const real * T_s, real * G_s, const real * pos_s, const real * ax_s,
+__device__ __forceinline__ void cost_tile_gs16(const DevBatch<real> & b, const ModelView<real> & mod,
+   const DevSdf<real> * sdfs, int ts, int te, bool do_iteration, const real * T_s, real * G_s, const real * pos_s, const real * ax_s,
    const real * srad_s, const real * sinact_s, const int * slink_s, const int * jtype_s, const int * jcol_s,
    real inv_eps, real inv_eps_self, double & cost_lane)
 {
@@ -171,9 +314,10 @@ __device__ __forceinline__ void cost_tile_gs16(const DevBatch<real> & b, const D
       real best[U], bgrad[U][3]; bool has[U];
 #pragma unroll
       for (int u=0; u<U; u++) { best[u] = inf; has[u] = false; bgrad[u][0] = 0; bgrad[u][1] = 0; bgrad[u][2] = 0; }
+#ifndef ORC_ABLATE_SDF
       for (int i=0; i<b.n_sdfs; i++)
       {
-         const DevSdf<real> & F = b.sdfs[i];
+         const DevSdf<real> & F = sdfs[i];
 #pragma unroll
          for (int u=0; u<U; u++)
          {
@@ -193,6 +337,7 @@ __device__ __forceinline__ void cost_tile_gs16(const DevBatch<real> & b, const D
             }
          }
       }
+#endif
 #pragma unroll
       for (int u=0; u<U; u++)
       {
@@ -224,23 +369,6 @@ __device__ __forceinline__ void cost_tile_gs16(const DevBatch<real> & b, const D
       }
 
       // ---- self collision (src/orcdchomp_mod.cpp:1251-1317) ----
-      // which row rotations are needed (squared distances), and the inactive spheres
-      unsigned kl = 0u;
-      for (int o=0; o<Sa; o++)
-      {
-         const real R = radius + srad_s[o] + b.epsilon_self;
-         const real R2 = R * R;
-         const bool other_link = (slink_s[o] != mylink);
-         const unsigned bits = (1u << ((o - s) & 15)) | (1u << ((s - o) & 15));
-#pragma unroll
-         for (int u=0; u<U; u++)
-         {
-            const real * po = pos_s + (l[u]*Sa + o)*3;
-            const real dx = p[u][0]-po[0], dy = p[u][1]-po[1], dz = p[u][2]-po[2];
-            const real d2 = dx*dx + dy*dy + dz*dz;
-            kl |= (live[u] && other_link && !(d2 > R2)) ? bits : 0u;
-         }
-      }
       for (int o=Sa; o<S; o++)                 // inactive spheres have no lane: only this lane's side
       {
          const real * po = sinact_s + (o - Sa)*3;
@@ -278,17 +406,16 @@ __device__ __forceinline__ void cost_tile_gs16(const DevBatch<real> & b, const D
             for (int k=0; k<3; k++) f[u][k] += (near[u] && do_iteration) ? (xx[k] - proj * vel[u][k]) : (real)0;
          }
       }
-      // union over the wave (the rotation steps are wave-uniform branches)
-      unsigned km = kl;
-#pragma unroll
-      for (int o=32; o>0; o>>=1) km |= (unsigned) __shfl_xor((int) km, o, 64);
-      km = (unsigned) __builtin_amdgcn_readfirstlane((int) km);
-#define ORC_STEP(K) self_pair_step16u<real, U, K>(km, live, p, radius, mylink, vel, moving, inv_vn2, wself, \
-                       b.epsilon_self, inv_eps_self, do_iteration, f, cost_sphere)
-      ORC_STEP(1); ORC_STEP(2); ORC_STEP(3); ORC_STEP(4); ORC_STEP(5);
-      ORC_STEP(6); ORC_STEP(7); ORC_STEP(8); ORC_STEP(9); ORC_STEP(10);
-      ORC_STEP(11); ORC_STEP(12); ORC_STEP(13); ORC_STEP(14); ORC_STEP(15);
-#undef ORC_STEP
+      // all 15 row rotations, two at a time (every rotation tests its own pairs for range)
+#ifndef ORC_ABLATE_ROT
+#define ORC_STEPS(K1, K2) self_pair_steps16<real, U, K1, K2>(live, p, radius, mylink, vel, moving, inv_vn2, wself, \
+                             b.epsilon_self, inv_eps_self, do_iteration, f, cost_sphere)
+      ORC_STEPS(1, 2); ORC_STEPS(3, 4); ORC_STEPS(5, 6); ORC_STEPS(7, 8); ORC_STEPS(9, 10);
+      ORC_STEPS(11, 12); ORC_STEPS(13, 14);
+#undef ORC_STEPS
+      self_pair_step16u<real, U, 15>(0xffffu, live, p, radius, mylink, vel, moving, inv_vn2, wself,
+                                     b.epsilon_self, inv_eps_self, do_iteration, f, cost_sphere);
+#endif
 
 #pragma unroll
       for (int u=0; u<U; u++) cost_lane += live[u] ? cost_sphere[u] : 0.0;
@@ -300,6 +427,7 @@ __device__ __forceinline__ void cost_tile_gs16(const DevBatch<real> & b, const D
          bool row_ok[U];
 #pragma unroll
          for (int u=0; u<U; u++) row_ok[u] = (item < items) && (wl[u] < nw) && (s == 0);
+#ifndef ORC_ABLATE_JT
          for (int j=0; j<nj; j++)
          {
             const bool hit = (aff >> j) & 1ull;
@@ -323,6 +451,7 @@ __device__ __forceinline__ void cost_tile_gs16(const DevBatch<real> & b, const D
 #pragma unroll
             for (int u=0; u<U; u++) if (row_ok[u]) G_s[(ts + wl[u])*n + col] = cg[u];
          }
+#endif
          if (mod.floating)
          {
             // base block: 0.01 * Jsp^T [p x f ; f] summed over all spheres

@@ -118,12 +118,29 @@ struct LdsLayout
 {
    int T, G, W, AG, pos, ax, srad, sinact, jl, pcr, end_reals;
    int ints_bytes;         // byte offset of the int tables (slink, jtype, jcol)
+   int joints_bytes;       // byte offset of the staged DevJoint[nj]
+   int sdfs_bytes;         // byte offset of the staged DevSdf[n_sdfs]
+   int saff_bytes;         // byte offset of the staged affects masks [Sa]
    int total_bytes;
+};
+
+// what the kernels read of the robot, staged in LDS at kernel start (global reads of the
+// model inside the iteration loop cost a full memory round trip each)
+template <typename real>
+struct ModelView
+{
+   int nj, n, floating, tree, Sa, S, GS, base_sph_begin, base_sph_end;
+   const real * base_R;                    // [9]
+   const real * base_t;                    // [3]
+   const DevJoint<real> * joints;          // [nj]
+   const real (* sph_pos)[3];              // [Sa][3]
+   const unsigned long long * sph_affects; // [Sa]
 };
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
-inline LdsLayout lds_layout(int np, int n, int Sa, int S, int nj, int tile_m, int pcr_rows, int real_size)
+inline LdsLayout lds_layout(int np, int n, int Sa, int S, int nj, int tile_m, int pcr_rows, int real_size,
+   int use_ag, int n_sdfs, int joint_size, int sdf_size)
 {
    const int m = np - 2, mn = m*n;
    LdsLayout L;
@@ -132,15 +149,21 @@ inline LdsLayout lds_layout(int np, int n, int Sa, int S, int nj, int tile_m, in
    L.T = take(np*n);
    L.G = take(mn);
    L.W = take(mn);
-   L.AG = take(mn);
+   L.AG = take(use_ag ? mn : 0);
    L.pos = take((tile_m+2)*Sa*3);
    L.ax = take((tile_m+2)*nj*6);
    L.srad = take(S);
    L.sinact = take((S-Sa)*3 + 1);
    L.jl = take(2*n);
    L.pcr = take(pcr_rows*m);
+   (void) take(Sa*3 + 12);                 // staged sphere local positions + base frame (after pcr)
    L.end_reals = o;
    L.ints_bytes = 128 + o*real_size;
-   L.total_bytes = L.ints_bytes + (S + 2*nj + 4) * (int) sizeof(int);
+   int bytes = L.ints_bytes + (S + 2*nj + 4) * (int) sizeof(int);
+   bytes = (bytes + 15) & ~15;
+   L.joints_bytes = bytes; bytes += nj * joint_size; bytes = (bytes + 15) & ~15;
+   L.sdfs_bytes = bytes;   bytes += n_sdfs * sdf_size; bytes = (bytes + 15) & ~15;
+   L.saff_bytes = bytes;   bytes += Sa * 8;
+   L.total_bytes = bytes;
    return L;
 }

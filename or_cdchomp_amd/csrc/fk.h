@@ -55,7 +55,7 @@ __device__ __forceinline__ void rot_cols(real * R, real c, real s)
 
 // apply joint j to the frame `cur` (in place), emit axis/anchor and the spheres riding on it
 template <typename real>
-__device__ __forceinline__ void fk_joint(const DevModel<real> & mod, const DevJoint<real> & J, Frame<real> & cur,
+__device__ __forceinline__ void fk_joint(const ModelView<real> & mod, const DevJoint<real> & J, Frame<real> & cur,
    real q, real sn, real cs, real * axo, real * pos_lane)
 {
    // joint frame in the world: cur o (Rfix, tfix)
@@ -125,7 +125,7 @@ __device__ __forceinline__ void fk_joint(const DevModel<real> & mod, const DevJo
 
 // FK of one waypoint (row = its trajectory row).  TREE = the joint tree branches (saved frames).
 template <typename real, bool TREE>
-__device__ __forceinline__ void fk_waypoint(const DevModel<real> & mod, const real * row, int nj, int Sa,
+__device__ __forceinline__ void fk_waypoint(const ModelView<real> & mod, const real * row, int nj, int Sa,
    real * pos_lane, real * ax_lane)
 {
    Frame<real> base, cur, sv0, sv1, sv2, sv3;
