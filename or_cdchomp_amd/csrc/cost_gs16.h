@@ -257,6 +257,134 @@ __device__ __forceinline__ void self_pair_steps16(const bool live[U], const real
    }
 }
 
+// Two SYMMETRIC rotation steps (K1, K2 in 1..8) for U waypoints per lane.  A pair of spheres
+// {a, b} is visited twice by the reference (once from each side, src/orcdchomp_mod.cpp:1251-1317).
+// Here the lane of a fetches everything it needs about b through the row rotation (centre,
+// radius, link, velocity), evaluates the shared part once (distance, piecewise factor) and both
+// sides' forces: the net force on a is x_ab - x_ba, and b receives the opposite through the
+// inverse rotation.  Rotations 1..7 therefore cover every pair exactly once; rotation 8 pairs each
+// lane with the lane that pairs with it, so both compute the pair and nothing is exchanged.
+// flags: bit 0 live, bit 1 moving.  The obstacle cost of both sides is summed where it is
+// computed (the per-run cost is a sum over all lanes anyway).
+template <typename real, int U, int K1, int K2>
+__device__ __forceinline__ void self_sym_steps16(const int flags[U], const real p[U][3],
+   real radius, int mylink, const real vel[U][3], const real inv_vn2[U], const real wself[U],
+   real eps_self, real inv_eps_self, bool do_iteration, real f[U][3], double cost_sphere[U])
+{
+   constexpr int NC = 2*U;
+   constexpr int F1 = 0x120 + K1, B1 = 0x120 + (16 - K1);
+   constexpr int F2 = 0x120 + K2, B2 = 0x120 + (16 - K2);
+   real d[NC][3], vo[NC][3], d2[NC], rsum[NC], wo[NC], ivo[NC], R2[2];
+   bool near[NC], mo[NC], other[2];
+   {
+      const real ro1 = dpp_move<F1>(radius), ro2 = dpp_move<F2>(radius);
+      const int lo1 = dpp_move<F1>(mylink), lo2 = dpp_move<F2>(mylink);
+      other[0] = (lo1 != mylink); other[1] = (lo2 != mylink);
+      const real s1 = radius + ro1, s2 = radius + ro2;
+      const real Ra = s1 + eps_self, Rb = s2 + eps_self;
+      R2[0] = Ra * Ra; R2[1] = Rb * Rb;
+#pragma unroll
+      for (int u=0; u<U; u++) { rsum[u] = s1; rsum[U+u] = s2; }
+   }
+   bool any = false;
+#pragma unroll
+   for (int u=0; u<U; u++)
+   {
+#pragma unroll
+      for (int k=0; k<3; k++)
+      {
+         d[u][k] = p[u][k] - dpp_move<F1>(p[u][k]);
+         d[U+u][k] = p[u][k] - dpp_move<F2>(p[u][k]);
+         vo[u][k] = dpp_move<F1>(vel[u][k]);
+         vo[U+u][k] = dpp_move<F2>(vel[u][k]);
+      }
+      wo[u] = dpp_move<F1>(wself[u]);    wo[U+u] = dpp_move<F2>(wself[u]);
+      ivo[u] = dpp_move<F1>(inv_vn2[u]); ivo[U+u] = dpp_move<F2>(inv_vn2[u]);
+      const int a1 = dpp_move<F1>(flags[u]), a2 = dpp_move<F2>(flags[u]);
+      mo[u] = (a1 & 2) != 0; mo[U+u] = (a2 & 2) != 0;
+      d2[u] = d[u][0]*d[u][0] + d[u][1]*d[u][1] + d[u][2]*d[u][2];
+      d2[U+u] = d[U+u][0]*d[U+u][0] + d[U+u][1]*d[U+u][1] + d[U+u][2]*d[U+u][2];
+      near[u] = (flags[u] & 1) && (a1 & 1) && other[0] && !(d2[u] > R2[0]);
+      near[U+u] = (flags[u] & 1) && (a2 & 1) && other[1] && !(d2[U+u] > R2[1]);
+      any = any || near[u] || near[U+u];
+   }
+   real inc[NC][3]; double cadd[NC];
+#pragma unroll
+   for (int c=0; c<NC; c++) { inc[c][0] = 0; inc[c][1] = 0; inc[c][2] = 0; cadd[c] = 0.0; }
+   if (any)
+   {
+      // shared part of the NC pairs, in lockstep
+      real xs[NC], dist[NC], inv_d[NC], de[NC], cself[NC], scale[NC], sdi[NC];
+#pragma unroll
+      for (int c=0; c<NC; c++) xs[c] = near[c] ? d2[c] : (real)1;
+      sqrt_rsq_lockstep<NC>(xs, dist, inv_d);
+#pragma unroll
+      for (int c=0; c<NC; c++) dist[c] -= rsum[c];
+#pragma unroll
+      for (int c=0; c<NC; c++) de[c] = dist[c] - eps_self;
+#pragma unroll
+      for (int c=0; c<NC; c++)
+         cself[c] = (dist[c] < (real)0) ? ((real)0.5 * eps_self - dist[c]) : ((real)0.5 * inv_eps_self) * de[c] * de[c];
+#pragma unroll
+      for (int c=0; c<NC; c++)
+         scale[c] = (dist[c] < (real)0) ? (real)(-1) : ((dist[c] < eps_self) ? dist[c] * inv_eps_self - (real)1 : (real)1);
+#pragma unroll
+      for (int c=0; c<NC; c++) sdi[c] = scale[c] * inv_d[c];
+      // both sides: side 0 = this lane's sphere (own velocity), side 1 = the partner's
+      real sa[NC], sb[NC], pa[NC], pb[NC];
+#pragma unroll
+      for (int c=0; c<NC; c++) { sa[c] = sdi[c] * wself[c % U]; sb[c] = -sdi[c] * wo[c]; }
+#pragma unroll
+      for (int c=0; c<NC; c++)
+      {
+         const bool second_is_8 = (K2 == 8) && (c >= U);     // rotation 8: the partner computes its own side
+         const real wsum = second_is_8 ? wself[c % U] : wself[c % U] + wo[c];
+         cadd[c] = near[c] ? (double)(wsum * cself[c]) : 0.0;
+      }
+#pragma unroll
+      for (int c=0; c<NC; c++) pa[c] = d[c][0]*vel[c % U][0];
+#pragma unroll
+      for (int c=0; c<NC; c++) pb[c] = d[c][0]*vo[c][0];
+#pragma unroll
+      for (int c=0; c<NC; c++) pa[c] = fma(d[c][1], vel[c % U][1], pa[c]);
+#pragma unroll
+      for (int c=0; c<NC; c++) pb[c] = fma(d[c][1], vo[c][1], pb[c]);
+#pragma unroll
+      for (int c=0; c<NC; c++) pa[c] = fma(d[c][2], vel[c % U][2], pa[c]);
+#pragma unroll
+      for (int c=0; c<NC; c++) pb[c] = fma(d[c][2], vo[c][2], pb[c]);
+      // projections (d . v) * s / |v|^2, zero when that sphere is (nearly) at rest
+#pragma unroll
+      for (int c=0; c<NC; c++) pa[c] = (flags[c % U] & 2) ? pa[c] * sa[c] * inv_vn2[c % U] : (real)0;
+#pragma unroll
+      for (int c=0; c<NC; c++) pb[c] = mo[c] ? pb[c] * sb[c] * ivo[c] : (real)0;
+      // net force on this lane's sphere: x_ab - x_ba
+#pragma unroll
+      for (int k=0; k<3; k++)
+#pragma unroll
+         for (int c=0; c<NC; c++)
+         {
+            const real xab = d[c][k] * sa[c] - pa[c] * vel[c % U][k];
+            const real xba = d[c][k] * sb[c] - pb[c] * vo[c][k];
+            inc[c][k] = (near[c] && do_iteration) ? (xab - xba) : (real)0;
+         }
+   }
+#pragma unroll
+   for (int u=0; u<U; u++) cost_sphere[u] += cadd[u] + cadd[U+u];
+   if (do_iteration)
+   {
+#pragma unroll
+      for (int u=0; u<U; u++)
+#pragma unroll
+         for (int k=0; k<3; k++)
+         {
+            real v = inc[u][k] - dpp_move<B1>(inc[u][k]);
+            v += (K2 == 8) ? inc[U+u][k] : (inc[U+u][k] - dpp_move<B2>(inc[U+u][k]));
+            f[u][k] += v;
+         }
+   }
+}
+
 template <typename real, int U>
 __device__ __forceinline__ void cost_tile_gs16(const DevBatch<real> & b, const ModelView<real> & mod,
    const DevSdf<real> * sdfs, int ts, int te, bool do_iteration, const real * T_s, real * G_s, const real * pos_s, const real * ax_s,
@@ -406,15 +534,17 @@ __device__ __forceinline__ void cost_tile_gs16(const DevBatch<real> & b, const M
             for (int k=0; k<3; k++) f[u][k] += (near[u] && do_iteration) ? (xx[k] - proj * vel[u][k]) : (real)0;
          }
       }
-      // all 15 row rotations, two at a time (every rotation tests its own pairs for range)
+      // row rotations 1..8, two at a time; each visits its pairs once for both sides
 #ifndef ORC_ABLATE_ROT
-#define ORC_STEPS(K1, K2) self_pair_steps16<real, U, K1, K2>(live, p, radius, mylink, vel, moving, inv_vn2, wself, \
+      {
+         int flags[U];
+#pragma unroll
+         for (int u=0; u<U; u++) flags[u] = (live[u] ? 1 : 0) | (moving[u] ? 2 : 0);
+#define ORC_STEPS(K1, K2) self_sym_steps16<real, U, K1, K2>(flags, p, radius, mylink, vel, inv_vn2, wself, \
                              b.epsilon_self, inv_eps_self, do_iteration, f, cost_sphere)
-      ORC_STEPS(1, 2); ORC_STEPS(3, 4); ORC_STEPS(5, 6); ORC_STEPS(7, 8); ORC_STEPS(9, 10);
-      ORC_STEPS(11, 12); ORC_STEPS(13, 14);
+         ORC_STEPS(1, 2); ORC_STEPS(3, 4); ORC_STEPS(5, 6); ORC_STEPS(7, 8);
 #undef ORC_STEPS
-      self_pair_step16u<real, U, 15>(0xffffu, live, p, radius, mylink, vel, moving, inv_vn2, wself,
-                                     b.epsilon_self, inv_eps_self, do_iteration, f, cost_sphere);
+      }
 #endif
 
 #pragma unroll
