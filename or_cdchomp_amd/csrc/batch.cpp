@@ -403,7 +403,8 @@ void Batch::build_device(const Robot & robot)
    // waypoints per tile: the largest tile that keeps two workgroups per CU,
    // else the largest that fits one
    const size_t budgets[2] = { 80*1024 - 512, 160*1024 - 1024 };
-   const int cands[7] = { m, 126, 94, 62, 30, 14, 6 };
+   int cands[7] = { m, 126, 94, 62, 30, 14, 6 };
+   if (const char * e = getenv("ORC_TILE_M")) { const int t = atoi(e); if (t > 0) for (int k=0; k<7; k++) cands[k] = t; }   // experiments
    tile_m_ = 0;
    const int pcr_rows = metric_.pcr.empty() ? 0 : 2*metric_.pcr_levels + 1;
    // the cyclic-reduction tables are staged in LDS when that does not cost a workgroup per CU
@@ -413,7 +414,7 @@ void Batch::build_device(const Robot & robot)
          {
             const int t = cands[ci];
             if (t > m || t > ORC_BLOCK - 2 || t < 1) continue;
-            if (with_pcr && (!pcr_rows || bi > 0 || ci > 3)) continue;
+            if (with_pcr && (!pcr_rows || bi > 0 || (ci > 3 && !getenv("ORC_TILE_M")))) continue;
             const size_t need = orc_chomp_lds_bytes(n_points, n, Sa, S, nj, t, with_pcr ? pcr_rows : 0, sizeof(real), params.use_momentum, n_sdfs_);
             if (need <= budgets[bi]) { tile_m_ = t; lds_bytes_ = need; pcr_in_lds_ = with_pcr; }
          }

@@ -331,7 +331,7 @@ __device__ __forceinline__ real smooth_grad(const DevBatch<real> & b, const real
 #include "fk.h"
 
 #ifndef ORC_U
-#define ORC_U 2          // waypoints per lane in the 16-sphere cost phase (independent streams)
+#define ORC_U 1          // waypoints per lane in the 16-sphere cost phase (2 measured no faster: the rotation steps already run 2 chains in lockstep)
 #endif
 
 // ---------------------------------------------------------------------------
@@ -449,6 +449,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
          if (GS == 16)
             cost_tile_gs16<real, ORC_U>(b, mod, sdfs, ts, te, do_iteration, T_s, G_s, pos_s, ax_s, srad_s, sinact_s,
                                         slink_s, jtype_s, jcol_s, inv_eps, inv_eps_self, cost_lane);
+#ifndef ORC_NO_GENERIC
          else
          {
          const int items = (te - ts) * GS;
@@ -694,6 +695,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
             }
          }
          }
+#endif
          __syncthreads();
          ORC_MARK(1);
       } // tiles

@@ -113,6 +113,7 @@ __device__ __forceinline__ void fk_joint(const ModelView<real> & mod, const DevJ
 #pragma unroll
       for (int k=0; k<3; k++) cur.t[k] = tj[k] + q*aw[k];
    }
+#ifndef ORC_ABLATE_FKSPH
    for (int s=J.sph_begin; s<J.sph_end; s++)
    {
       const real * lp = mod.sph_pos[s];
@@ -121,6 +122,7 @@ __device__ __forceinline__ void fk_joint(const ModelView<real> & mod, const DevJ
       for (int k=0; k<3; k++)
          o[k] = cur.R[k*3+0]*lp[0] + cur.R[k*3+1]*lp[1] + cur.R[k*3+2]*lp[2] + cur.t[k];
    }
+#endif
 }
 
 // FK of one waypoint (row = its trajectory row).  TREE = the joint tree branches (saved frames).
@@ -167,8 +169,13 @@ __device__ __forceinline__ void fk_waypoint(const ModelView<real> & mod, const r
          const int j = (j0 + jj < nj) ? j0 + jj : nj - 1;
          qv[jj] = row[mod.joints[j].col];
       }
+#ifdef ORC_ABLATE_FKSIN
+#pragma unroll
+      for (int jj=0; jj<4; jj++) { sn[jj] = qv[jj]; cs[jj] = (real)1 - qv[jj]; }
+#else
 #pragma unroll
       for (int jj=0; jj<4; jj++) sincos_joint(qv[jj], &sn[jj], &cs[jj]);
+#endif
 #pragma unroll
       for (int jj=0; jj<4; jj++)
       {
