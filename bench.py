@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="runs per GPU (configs[1]: 1024)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-runs", type=int, default=0, help="override the cpu baseline sample size")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for a "
+                                                      "single-GPU rehearsal of the multi-rank path)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -62,17 +64,21 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    device = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend=args.backend)
 
     import or_cdchomp_amd
     import common
 
-    mod = or_cdchomp_amd.Module(local_rank)
+    mod = or_cdchomp_amd.Module(device)
     model = common.setup_product_wam(mod)
     n_runs = args.batch
     kw = dict(n_points=N_POINTS, lambda_=LAMBDA, obs_factor=OBS_FACTOR)

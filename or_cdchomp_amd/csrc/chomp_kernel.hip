@@ -168,6 +168,36 @@ __device__ __forceinline__ void self_pair_step16(unsigned kmask, bool live, cons
 }
 
 template <typename real>
+__device__ __forceinline__ real dpp_row_max(real v)
+{
+   real o;
+   o = dpp_move<0xB1>(v);  v = o > v ? o : v;
+   o = dpp_move<0x4E>(v);  v = o > v ? o : v;
+   o = dpp_move<0x141>(v); v = o > v ? o : v;
+   o = dpp_move<0x140>(v); v = o > v ? o : v;
+   return v;
+}
+template <typename real>
+__device__ __forceinline__ void wave_argmax(real & best, int & best_e)
+{
+   real m = dpp_row_max(best);
+   // the four row maxima (lanes 0, 16, 32, 48 hold them after the row reduction)
+   real m1 = __shfl(m, 16, 64), m2 = __shfl(m, 32, 64), m3 = __shfl(m, 48, 64), m0 = __shfl(m, 0, 64);
+   real mm = m0 > m1 ? m0 : m1; mm = m2 > mm ? m2 : mm; mm = m3 > mm ? m3 : mm;
+   if (!(mm > (real)0)) { best = 0; best_e = 0x7fffffff; return; }      // nothing to find (wave-uniform)
+   unsigned long long cand = __ballot(best == mm);
+   int win = 0x7fffffff;
+   while (cand)                       // one iteration unless two lanes tie exactly
+   {
+      const int ln = __builtin_ctzll(cand);
+      cand &= cand - 1;
+      const int e = __shfl(best_e, ln, 64);
+      win = e < win ? e : win;
+   }
+   best = mm; best_e = win;
+}
+
+template <typename real>
 struct Frame { real R[9]; real t[3]; };
 
 // out = A * B (3x3 row major)
@@ -187,6 +217,13 @@ __device__ __forceinline__ double wave_sum(double v)
    for (int o=32; o>0; o>>=1) v += __shfl_xor(v, o, 64);
    return v;
 }
+
+// wavefront arg-max of (value >= 0, index), ties to the smallest index; every lane gets the result.
+// Row maxima by DPP, rows combined through readlane; the owner is found with a ballot.
+template <typename real>
+__device__ __forceinline__ real dpp_row_max(real v);   // defined after dpp_move
+template <typename real>
+__device__ __forceinline__ void wave_argmax(real & best, int & best_e);
 
 // sum over the whole workgroup; every thread receives the result.
 __device__ __forceinline__ double block_sum(double v, double * red)
@@ -764,22 +801,8 @@ void chomp_iterate_kernel(const DevBatch<real> b)
                const real a = M<real>::fabs_(gj);
                if (a > best) { best = a; best_e = e; }
             }
-            // common case: nothing violated anywhere in the workgroup
-            {
-               const bool mine = __ballot(best > (real)0) != 0ull;
-               __syncthreads();
-               if ((tid & 63) == 0) redi[tid >> 6] = mine ? 1 : 0;
-               __syncthreads();
-               if (!(redi[0] | redi[1] | redi[2] | redi[3])) break;
-            }
             // workgroup arg-max, ties to the smallest index (first in row-major scan)
-#pragma unroll
-            for (int o=32; o>0; o>>=1)
-            {
-               const real ob = __shfl_xor(best, o, 64);
-               const int oe = __shfl_xor(best_e, o, 64);
-               if (ob > best || (ob == best && oe < best_e)) { best = ob; best_e = oe; }
-            }
+            wave_argmax(best, best_e);
             __syncthreads();
             if ((tid & 63) == 0) { red[tid >> 6] = (double) best; redi[tid >> 6] = best_e; }
             __syncthreads();
@@ -787,18 +810,94 @@ void chomp_iterate_kernel(const DevBatch<real> b)
 #pragma unroll
             for (int w=1; w<4; w++)
                if (red[w] > gb || (red[w] == gb && redi[w] < ge)) { gb = red[w]; ge = redi[w]; }
-            if (gb == 0.0) break;
-            real * GA = metric_solve(b, pcr_tab, G_s, W_s);
-            // PCR may return either buffer; Gjlimit[largest] is recomputed from T
+            if (gb == 0.0) break;                  // nothing violated anywhere in the workgroup
             const int gi = ge / n, gc = ge - gi*n;
-            const real tl = T_s[n + ge];
-            real gl = 0;
-            if (tl < jl_s[gc]) gl = jl_s[gc] - tl;
-            if (tl > jl_s[n+gc]) gl = jl_s[n+gc] - tl;
-            const real sc = (real)1.01 * gl / GA[ge];
-            __syncthreads();
-            for (int e=tid; e<mn; e+=ORC_BLOCK) T_s[n + e] += sc * GA[e];
-            __syncthreads();
+            const real gl = G_s[ge];               // Gjlimit[largest]
+
+            // GA = A^-1 Gjlimit.  Gjlimit is sparse (a few violated entries): for the tridiagonal
+            // Toeplitz metric (D == 1) the columns of A^-1 are known in closed form,
+            //    Ainv[i][k] = (min(i,k)+1) (m - max(i,k)) / ((m+1) ca),   A = ca tridiag(-1,2,-1),
+            // so GA is a short sum per element instead of a full solve.
+            bool sparse_done = false;
+            if (b.D == 1 && b.solve_mode == 0)
+            {
+               const int K = (mn + ORC_BLOCK - 1) / ORC_BLOCK;       // elements per thread
+               int * cnt = (int *) W_s;                               // [K][4] counts per (slice, wave)
+               int * lst = cnt + 64;                                  // [64][2]  (row, column) of a violated entry
+               real * lval = (real *)(lst + 128);                     // [64] its Gjlimit value
+               const int lane = tid & 63, wave = tid >> 6;
+               if (K <= 16)
+               {
+                  for (int k=0; k<K; k++)
+                  {
+                     const int e = tid + k*ORC_BLOCK;
+                     const bool v = (e < mn) && (G_s[e] != (real)0);
+                     const unsigned long long mask = __ballot(v);
+                     if (lane == 0) cnt[k*4 + wave] = __popcll(mask);
+                  }
+                  __syncthreads();
+                  int total = 0;
+                  for (int q=0; q<K*4; q++) total += cnt[q];
+                  if (total <= 64)
+                  {
+                     for (int k=0; k<K; k++)
+                     {
+                        const int e = tid + k*ORC_BLOCK;
+                        const bool v = (e < mn) && (G_s[e] != (real)0);
+                        const unsigned long long mask = __ballot(v);
+                        if (v)
+                        {
+                           int off = 0;
+                           for (int q=0; q<k*4 + wave; q++) off += cnt[q];
+                           off += __popcll(mask & ((1ull << lane) - 1ull));
+                           const int i = e / n;
+                           lst[2*off] = i; lst[2*off+1] = e - i*n;
+                           lval[off] = G_s[e];
+                        }
+                     }
+                     __syncthreads();
+                     const real kinv = (real)(-1) / ((real)(m + 1) * b.a_off);     // 1/((m+1) ca), ca = -a_off
+                     // the entry the scale is taken from
+                     real ga_l = 0;
+                     for (int v=0; v<total; v++)
+                     {
+                        const int iv = lst[2*v], cv = lst[2*v+1];
+                        if (cv == gc)
+                        {
+                           const int lo = iv < gi ? iv : gi, hi = iv < gi ? gi : iv;
+                           ga_l += lval[v] * (real)((lo + 1) * (m - hi));
+                        }
+                     }
+                     const real sc = (real)1.01 * gl / (ga_l * kinv);
+                     for (int e=tid; e<mn; e+=ORC_BLOCK)
+                     {
+                        const int i = e / n, c = e - i*n;
+                        real ga = 0;
+                        for (int v=0; v<total; v++)
+                        {
+                           const int iv = lst[2*v], cv = lst[2*v+1];
+                           if (cv == c)
+                           {
+                              const int lo = iv < i ? iv : i, hi = iv < i ? i : iv;
+                              ga += lval[v] * (real)((lo + 1) * (m - hi));
+                           }
+                        }
+                        T_s[n + e] += sc * (ga * kinv);
+                     }
+                     __syncthreads();
+                     sparse_done = true;
+                  }
+               }
+            }
+            if (!sparse_done)
+            {
+               __syncthreads();
+               real * GA = metric_solve(b, pcr_tab, G_s, W_s);
+               const real sc = (real)1.01 * gl / GA[ge];
+               __syncthreads();
+               for (int e=tid; e<mn; e+=ORC_BLOCK) T_s[n + e] += sc * GA[e];
+               __syncthreads();
+            }
          }
          if (!(num_limadjs < 1000)) status = -1;
          ORC_MARK(4);

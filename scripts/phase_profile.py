@@ -23,3 +23,9 @@ tot = out[:, :6].sum(1)
 print("runs %d  kernel %.2f ms  -> %.3g it/s ; mean cycles/iteration per WG %.0f" % (n_runs, ms, n_runs*100/(ms*1e-3), tot.mean()/101))
 for k in range(6):
     print("  %-18s %8.0f cycles/iter  %5.1f %%" % (names[k], out[:, k].mean()/101, 100*out[:, k].sum()/tot.sum()))
+tot_all = out[:, :6].sum(1)
+q = np.percentile(tot_all, [0, 10, 50, 90, 99, 100]) / 1e6
+print("per-WG total Mcycles: min %.1f p10 %.1f median %.1f p90 %.1f p99 %.1f max %.1f" % tuple(q))
+jl = out[:, 4]
+print("joint-limit Mcycles: median %.2f p90 %.2f p99 %.2f max %.2f ; share of runs with >20%% of time there: %.1f %%" % (
+    np.median(jl)/1e6, np.percentile(jl, 90)/1e6, np.percentile(jl, 99)/1e6, jl.max()/1e6, 100*np.mean(jl > 0.2*tot_all)))
