@@ -80,6 +80,8 @@ int orc_env_add_robot(orc_module * mod, const char * name, const orc_robot_desc 
 int orc_robot_set_transform(orc_module * mod, const char * name, const double pose[7]);      /* robot->SetTransform */
 int orc_robot_set_dof_values(orc_module * mod, const char * name, const double * values, int n); /* SetDOFValues */
 int orc_robot_set_active_dofs(orc_module * mod, const char * name, const int * indices, int n); /* SetActiveDOFs */
+/* GetDOFVelocityLimits: used by the linear retimer of gettraj (default 1 for every dof) */
+int orc_robot_set_velocity_limits(orc_module * mod, const char * name, const double * limits, int n);
 
 /* a kinbody made of oriented boxes (InitFromBoxes-style); box_poses [n_boxes][7]
  * in the kinbody frame, half_extents [n_boxes][3] */
@@ -143,6 +145,11 @@ int orc_batch_gettraj(orc_module * mod, int batch_id, double * traj_out, size_t 
 /* optimizer state read-back for tests: which = "G", "AG", "T" ([n_runs][m][n]) */
 int orc_batch_get_state(orc_module * mod, int batch_id, const char * which, double * out, size_t cap_doubles);
 int orc_batch_dims(orc_module * mod, int batch_id, int * n_runs, int * n_points, int * n);
+/* overwrite the trajectories of a batch (warm start; what `create starttraj` does for one run,
+ * src/orcdchomp_mod.cpp:2375-2416): traj [n_runs][n_points][n] */
+int orc_batch_set_traj(orc_module * mod, int batch_id, const double * traj, size_t count_doubles);
+/* the collision report the last gettraj produced (the reference logs it, mod.cpp:3000) */
+const char * orc_last_collision_details(const orc_module * mod);
 /* replaces mod::destroy (src/orcdchomp_mod.cpp:3013-3066) */
 int orc_batch_destroy(orc_module * mod, int batch_id);
 

@@ -44,6 +44,7 @@ SYMBOLS = [
     ("orc_robot_set_transform", C.c_int, [C.c_void_p, C.c_char_p, c_double_p]),
     ("orc_robot_set_dof_values", C.c_int, [C.c_void_p, C.c_char_p, c_double_p, C.c_int]),
     ("orc_robot_set_active_dofs", C.c_int, [C.c_void_p, C.c_char_p, c_int_p, C.c_int]),
+    ("orc_robot_set_velocity_limits", C.c_int, [C.c_void_p, C.c_char_p, c_double_p, C.c_int]),
     ("orc_env_add_kinbody_boxes", C.c_int, [C.c_void_p, C.c_char_p, C.c_int, c_double_p, c_double_p]),
     ("orc_kinbody_set_transform", C.c_int, [C.c_void_p, C.c_char_p, c_double_p]),
     ("orc_kinbody_enable", C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
@@ -60,6 +61,8 @@ SYMBOLS = [
     ("orc_batch_gettraj", C.c_int, [C.c_void_p, C.c_int, c_double_p, C.c_size_t]),
     ("orc_batch_get_state", C.c_int, [C.c_void_p, C.c_int, C.c_char_p, c_double_p, C.c_size_t]),
     ("orc_batch_dims", C.c_int, [C.c_void_p, C.c_int, c_int_p, c_int_p, c_int_p]),
+    ("orc_batch_set_traj", C.c_int, [C.c_void_p, C.c_int, c_double_p, C.c_size_t]),
+    ("orc_last_collision_details", C.c_char_p, [C.c_void_p]),
     ("orc_batch_destroy", C.c_int, [C.c_void_p, C.c_int]),
     ("orc_kernel_time", C.c_int, [C.c_void_p, c_double_p, c_int_p, C.c_int]),
     ("orc_host_bin_sdf", C.c_int, [c_int_p, c_double_p, c_double_p, c_double_p]),

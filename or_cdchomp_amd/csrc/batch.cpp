@@ -607,6 +607,19 @@ void Batch::get_phase_cycles(long long * out)
    hip_check(hipMemcpy(out, d_phase_, (size_t) n_runs*8*sizeof(long long), hipMemcpyDeviceToHost), "phase");
 }
 
+void Batch::set_traj(const double * traj)
+{
+   const size_t count = (size_t) n_runs * n_points * n;
+   if (params.precision == 64)
+      hip_check(hipMemcpyAsync(d_traj_, traj, count*sizeof(double), hipMemcpyHostToDevice, mod_->stream), "set_traj");
+   else
+   {
+      std::vector<float> tmp(traj, traj + count);
+      hip_check(hipMemcpyAsync(d_traj_, tmp.data(), count*sizeof(float), hipMemcpyHostToDevice, mod_->stream), "set_traj");
+   }
+   hip_check(hipStreamSynchronize(mod_->stream), "set_traj sync");
+}
+
 void Batch::set_noise(const double * noise, int n_blocks)
 {
    ext_noise_blocks_ = n_blocks;

@@ -135,6 +135,15 @@ int orc_robot_set_active_dofs(orc_module * mod, const char * name, const int * i
    });
 }
 
+int orc_robot_set_velocity_limits(orc_module * mod, const char * name, const double * limits, int n)
+{
+   return guarded(mod, [&] {
+      orc::Robot & r = mod->impl->robot(name);
+      if (n != r.n_dof) throw std::runtime_error("wrong number of velocity limits!");
+      r.limit_vel.assign(limits, limits + n);
+   });
+}
+
 int orc_env_add_kinbody_boxes(orc_module * mod, const char * name, int n_boxes, const double * box_poses, const double * half_extents)
 {
    return guarded(mod, [&] {
@@ -286,6 +295,20 @@ int orc_batch_dims(orc_module * mod, int id, int * n_runs, int * n_points, int *
       if (n_points) *n_points = b.n_points;
       if (n) *n = b.n;
    });
+}
+
+int orc_batch_set_traj(orc_module * mod, int id, const double * traj, size_t count)
+{
+   return guarded(mod, [&] {
+      orc::Batch & b = mod->impl->batch(id);
+      if (count != (size_t) b.n_runs * b.n_points * b.n) throw std::runtime_error("wrong trajectory size!");
+      b.set_traj(traj);
+   });
+}
+
+const char * orc_last_collision_details(const orc_module * mod)
+{
+   return mod ? mod->impl->last_collision_details.c_str() : "";
 }
 
 int orc_batch_destroy(orc_module * mod, int id)

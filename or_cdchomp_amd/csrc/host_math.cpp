@@ -226,6 +226,39 @@ void grid_flood_1_to_0(Grid & g, size_t start)
    }
 }
 
+int grid_interp(const Grid & g, const double p[3], double * value)
+{
+   int sub[3];
+   for (int d=0; d<3; d++)
+   {
+      const double x = p[d] / g.lengths[d];
+      if (x < 0.0 || x > 1.0) return 1;
+      int s = (int) std::floor(x * g.sizes[d]);
+      if (s == g.sizes[d]) s--;
+      sub[d] = s;
+   }
+   const size_t stride[3] = { (size_t) g.sizes[1] * g.sizes[2], (size_t) g.sizes[2], 1 };
+   const size_t index = sub[0]*stride[0] + sub[1]*stride[1] + sub[2];
+   double v = g.data[index];
+   if (v == HUGE_VAL) { *value = HUGE_VAL; return 0; }
+   for (int d=2; d>=0; d--)
+   {
+      const double center = (0.5 + sub[d]) / g.sizes[d] * g.lengths[d];
+      bool prev;
+      if (sub[d] == 0) prev = false;
+      else if (sub[d] == g.sizes[d]-1) prev = true;
+      else prev = p[d] < center;
+      const double after = prev ? g.data[index] : g.data[index + stride[d]];
+      const double before = prev ? g.data[index - stride[d]] : g.data[index];
+      if (after == HUGE_VAL || before == HUGE_VAL) { *value = HUGE_VAL; return 0; }
+      double diff = after;
+      diff -= before;
+      v += diff * g.sizes[d] / g.lengths[d] * (p[d] - center);
+   }
+   *value = v;
+   return 0;
+}
+
 bool obb_overlap(const Xform & a, const double ha[3], const Xform & b, const double hb[3], double tol)
 {
    // separating axis theorem for two oriented boxes (15 axes); R = A^T B

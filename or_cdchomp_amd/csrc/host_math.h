@@ -56,6 +56,9 @@ void grid_bin_sdf(const Grid & occ, Grid & sdf);
 // (cd_grid_flood_fill + replace_1_to_0; src/libcd/grid_flood.c:30-111)
 void grid_flood_1_to_0(Grid & g, size_t start);
 
+// cd_grid_double_interp on the host (src/libcd/grid.c:386-454): returns 1 when p is outside
+int grid_interp(const Grid & g, const double p[3], double * value);
+
 // oriented box for the primitive voxelizer
 struct Box { Xform world; double half[3]; };
 // true when two oriented boxes overlap by more than `tol` (separating axis test)

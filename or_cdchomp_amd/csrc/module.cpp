@@ -12,7 +12,21 @@
 #include <sstream>
 #include <stdexcept>
 
+hipError_t orc_sdf_from_occupancy_device(const double * occ, double * sdf_out, const int sizes[3], const double lengths[3],
+   hipStream_t st);
+
 namespace orc {
+
+// occupancy -> signed distance field: on the GPU for large grids (or ORC_SDF_DEVICE=1), on the host
+// otherwise (ORC_SDF_DEVICE=0 forces the host); both are bit-identical
+static void bin_sdf_any(const Grid & occ, Grid & sdf, hipStream_t st)
+{
+   const char * env = getenv("ORC_SDF_DEVICE");
+   const bool on_device = env ? (atoi(env) != 0) : (occ.ncells() >= (size_t) 1 << 18);
+   if (!on_device) { grid_bin_sdf(occ, sdf); return; }
+   sdf = occ;
+   hip_check(orc_sdf_from_occupancy_device(occ.data.data(), sdf.data.data(), occ.sizes, occ.lengths, st), "sdf build");
+}
 
 void hip_check(hipError_t e, const char * what)
 {
@@ -206,9 +220,10 @@ void * parse_pointer(const std::string & s)
 }
 
 // an OpenRAVE-style trajectory document holding the waypoints of one run
-// (stands in for t->serialize(sout), src/orcdchomp_mod.cpp:3008)
+// (stands in for t->serialize(sout), src/orcdchomp_mod.cpp:3008).  One row per waypoint:
+// the joint values followed by the deltatime to reach it from the previous waypoint.
 std::string serialize_traj(const std::string & robot, const std::vector<int> & adofs,
-   const double * traj, int n_points, int n, int col0)
+   const double * traj, int n_points, int n, int col0, const std::vector<double> & deltatime)
 {
    std::ostringstream o;
    const int nd = n - col0;
@@ -220,16 +235,51 @@ std::string serialize_traj(const std::string & robot, const std::vector<int> & a
    o << "</configuration>\n<data count=\"" << n_points << "\">\n";
    for (int i=0; i<n_points; i++)
    {
-      double dtm = 0.0;
-      for (int j=col0; j<n; j++)
-      {
-         o << traj[(size_t) i*n+j] << " ";
-         if (i > 0) dtm = std::max(dtm, std::fabs(traj[(size_t) i*n+j] - traj[(size_t)(i-1)*n+j]));
-      }
-      o << dtm << (i+1 < n_points ? " " : "");
+      for (int j=col0; j<n; j++) o << traj[(size_t) i*n+j] << " ";
+      o << deltatime[i] << (i+1 < n_points ? " " : "");
    }
    o << "\n</data>\n</trajectory>\n";
    return o.str();
+}
+
+// LinearTrajectoryRetimer stand-in (reference: RetimeActiveDOFTrajectory(..., "LinearTrajectoryRetimer"),
+// src/orcdchomp_mod.cpp:2905-2911): each segment is traversed at the largest constant velocity
+// the dof velocity limits allow.
+std::vector<double> retime_linear(const double * traj, int n_points, int n, int col0, const std::vector<double> & vmax)
+{
+   std::vector<double> dtm(n_points, 0.0);
+   for (int i=1; i<n_points; i++)
+      for (int j=col0; j<n; j++)
+      {
+         const double v = vmax[j-col0] > 0.0 ? vmax[j-col0] : 1.0;
+         dtm[i] = std::max(dtm[i], std::fabs(traj[(size_t) i*n+j] - traj[(size_t)(i-1)*n+j]) / v);
+      }
+   return dtm;
+}
+
+// reads a document written by serialize_traj: waypoints [count][dof] and their deltatimes
+bool parse_traj(const std::string & text, std::vector<double> & wp, std::vector<double> & dtm, int & count, int & dof)
+{
+   const size_t c0 = text.find("<data count=\"");
+   if (c0 == std::string::npos) return false;
+   count = std::atoi(text.c_str() + c0 + 13);
+   const size_t d0 = text.find('>', c0), d1 = text.find("</data>", c0);
+   if (d0 == std::string::npos || d1 == std::string::npos || count < 1) return false;
+   std::vector<double> vals;
+   std::istringstream is(text.substr(d0+1, d1-d0-1));
+   double v;
+   while (is >> v) vals.push_back(v);
+   if (vals.empty() || vals.size() % (size_t) count) return false;
+   const int width = (int)(vals.size() / count);
+   dof = width - 1;
+   if (dof < 1) return false;
+   wp.resize((size_t) count * dof); dtm.resize(count);
+   for (int i=0; i<count; i++)
+   {
+      for (int j=0; j<dof; j++) wp[(size_t) i*dof+j] = vals[(size_t) i*width+j];
+      dtm[i] = vals[(size_t) i*width+dof];
+   }
+   return true;
 }
 
 } // namespace
@@ -373,7 +423,7 @@ std::string Module::cmd_computedistancefield(const std::vector<std::string> & ar
       grid_flood_1_to_0(g, 0);                                                   // mod.cpp:540-548
       for (size_t idx=0; idx<nc; idx++) if (g.data[idx] == 1.0) g.data[idx] = HUGE_VAL;
       Grid sdf;
-      grid_bin_sdf(g, sdf);                                                      // mod.cpp:560
+      bin_sdf_any(g, sdf, stream);                                               // mod.cpp:560
       g = sdf;
       if (have_cache)
       {
@@ -437,7 +487,7 @@ std::string Module::cmd_addfield_fromobsarray(const std::vector<std::string> & a
    // copies it and leaves ownership with the caller (no cross-allocator free)
    occ.data.assign(obsarray, obsarray + occ.ncells());
    Grid sdf;
-   grid_bin_sdf(occ, sdf);
+   bin_sdf_any(occ, sdf, stream);
    add_sdf(kb, sdf, pose);
    return "";
 }
@@ -475,7 +525,8 @@ std::string Module::cmd_create(const std::vector<std::string> & argv, bool batch
 {
    std::string rname;
    std::vector<double> adofgoal, basegoal;
-   bool have_adofgoal = false, have_basegoal = false;
+   bool have_adofgoal = false, have_basegoal = false, have_starttraj = false;
+   std::string starttraj;
    BatchParams p;
    unsigned int seed = 0;
    int n_runs = 1;
@@ -495,6 +546,7 @@ std::string Module::cmd_create(const std::vector<std::string> & argv, bool batch
       else if (a == "adofgoal" && i+1 < argc)
       {
          if (have_adofgoal) throw std::runtime_error("Only one adofgoal can be passed!");
+         if (have_starttraj) throw std::runtime_error("Cannot pass both adofgoal and starttraj!");
          adofgoal = parse_vector(argv[++i]); have_adofgoal = true;
       }
       else if (a == "basegoal" && i+1 < argc)
@@ -519,7 +571,13 @@ std::string Module::cmd_create(const std::vector<std::string> & argv, bool batch
       else if (a == "no_report_cost") { /* emitted by the python layer, ignored */ }
       else if (a == "dat_filename" && i+1 < argc)
          throw std::runtime_error("dat_filename is not supported by this build (per-iteration costs: iteratebatch trace)");
-      else if ((a == "starttraj" || a == "start_tsr" || a == "everyn_tsr" || a == "start_cost"
+      else if (a == "starttraj" && i+1 < argc)
+      {
+         if (have_starttraj) throw std::runtime_error("Only one starttraj can be passed!");
+         if (have_adofgoal) throw std::runtime_error("Cannot pass both adofgoal and starttraj!");
+         starttraj = argv[++i]; have_starttraj = true;
+      }
+      else if ((a == "start_tsr" || a == "everyn_tsr" || a == "start_cost"
                 || a == "ee_force" || a == "ee_force_at" || a == "ee_torque_weights") && i+1 < argc)
          throw std::runtime_error("argument " + a + " is outside the scope of this build (SURVEY.md section 2)");
       else if (a == "con_tsr" && i+2 < argc)
@@ -536,8 +594,8 @@ std::string Module::cmd_create(const std::vector<std::string> & argv, bool batch
    if (rname.empty()) throw std::runtime_error("Did not pass a robot!");
    if (!batchmode)
    {
-      if (!have_adofgoal) throw std::runtime_error("Did not pass either adofgoal or starttraj!");
-      if (p.floating_base && !have_basegoal) throw std::runtime_error("Passed floating_base with no basegoal!");
+      if (!have_adofgoal && !have_starttraj) throw std::runtime_error("Did not pass either adofgoal or starttraj!");
+      if (p.floating_base && !have_basegoal && !have_starttraj) throw std::runtime_error("Passed floating_base with no basegoal!");
       if (!p.floating_base && have_basegoal) throw std::runtime_error("Passed basegoal with no floating_base!");
    }
    else
@@ -551,11 +609,48 @@ std::string Module::cmd_create(const std::vector<std::string> & argv, bool batch
    if (p.lambda < 0.01) throw std::runtime_error("lambda must be >=0.01!");
    if (p.n_points < 3) throw std::runtime_error("n_points must be >=3!");
    Robot & r = robot(rname);
+   // initialisation from a passed trajectory (src/orcdchomp_mod.cpp:2375-2416): sampled at
+   // i * duration / (n_points-1), linear interpolation between its waypoints
+   std::vector<double> sampled;
+   if (!batchmode && have_starttraj)
+   {
+      if (p.floating_base) throw std::runtime_error("starttraj with floating_base is not supported by this build");
+      std::vector<double> wp, dtm; int count = 0, dof = 0;
+      if (!parse_traj(starttraj, wp, dtm, count, dof)) throw std::runtime_error("Cannot parse starttraj!");
+      if (dof != (int) r.active_dofs.size()) throw std::runtime_error("size of adofgoal does not match active dofs!");
+      std::vector<double> tcum(count, 0.0);
+      for (int k=1; k<count; k++) tcum[k] = tcum[k-1] + dtm[k];
+      const double duration = tcum[count-1];
+      sampled.resize((size_t) p.n_points * dof);
+      for (int k=0; k<p.n_points; k++)
+      {
+         // untimed documents (all deltatimes zero) are sampled uniformly over the waypoint index
+         const double t = duration > 0.0 ? k * duration / (p.n_points - 1) : (double) k * (count - 1) / (p.n_points - 1);
+         int seg = 0; double u = 0.0;
+         if (duration > 0.0)
+         {
+            while (seg < count-2 && tcum[seg+1] < t) seg++;
+            const double dt = tcum[seg+1] - tcum[seg];
+            u = dt > 0.0 ? (t - tcum[seg]) / dt : 0.0;
+         }
+         else { seg = std::min((int) t, count-2); if (seg < 0) seg = 0; u = t - seg; }
+         if (count == 1) { seg = 0; u = 0.0; }
+         for (int j=0; j<dof; j++)
+         {
+            const double a0 = wp[(size_t) seg*dof+j], a1 = wp[(size_t) std::min(seg+1, count-1)*dof+j];
+            sampled[(size_t) k*dof+j] = a0 + (a1 - a0) * u;
+         }
+      }
+      adofgoal.assign(sampled.end() - dof, sampled.end());
+   }
    if (!batchmode && adofgoal.size() != r.active_dofs.size())
       throw std::runtime_error("size of adofgoal does not match active dofs!");
    int id;
    if (!batchmode)
+   {
       id = create_batch(rname, p, 1, nullptr, adofgoal.data(), have_basegoal ? basegoal.data() : nullptr, &seed);
+      if (have_starttraj) batch(id).set_traj(sampled.data());
+   }
    else
       id = create_batch(rname, p, n_runs, starts_ptr, goals_ptr, basegoals_ptr, seeds_ptr);
    std::ostringstream o;
@@ -624,7 +719,8 @@ std::string Module::cmd_iterate(const std::vector<std::string> & argv, bool batc
             char fname[1024];
             std::snprintf(fname, sizeof(fname), fileform.c_str(), it);
             std::ofstream f(fname);
-            f << serialize_traj(b.robot_name, b.adofindices, traj.data(), b.n_points, b.n, 0);
+            f << serialize_traj(b.robot_name, b.adofindices, traj.data(), b.n_points, b.n, 0,
+                                std::vector<double>(b.n_points, 0.0));
          }
          b.iterate_async(1);
          b.sync(costs.data(), status.data());
@@ -648,15 +744,16 @@ std::string Module::cmd_iterate(const std::vector<std::string> & argv, bool batc
 std::string Module::cmd_gettraj(const std::vector<std::string> & argv, bool batchmode)
 {
    int run = 0;
+   bool no_collision_check = false, no_collision_exception = false, no_collision_details = false;
    double * out_ptr = nullptr;
    const int argc = (int) argv.size();
    int i;
    for (i=1; i<argc; i++)
    {
       if (argv[i] == "run" && i+1 < argc) parse_run(argv, i, run, "Only one r can be passed!");
-      else if (argv[i] == "no_collision_check") { }
-      else if (argv[i] == "no_collision_exception") { }
-      else if (argv[i] == "no_collision_details") { }
+      else if (argv[i] == "no_collision_check") no_collision_check = true;
+      else if (argv[i] == "no_collision_exception") no_collision_exception = true;
+      else if (argv[i] == "no_collision_details") no_collision_details = true;
       else if (batchmode && argv[i] == "out" && i+1 < argc) out_ptr = (double *) parse_pointer(argv[++i]);
       else break;
    }
@@ -671,8 +768,78 @@ std::string Module::cmd_gettraj(const std::vector<std::string> & argv, bool batc
       std::memcpy(out_ptr, traj.data(), traj.size() * sizeof(double));
       return "";
    }
+   const int col0 = b.params.floating_base ? 7 : 0;
+   Robot & rob = robot(b.robot_name);
+   std::vector<double> vmax;
+   for (int a : b.adofindices) vmax.push_back(a < (int) rob.limit_vel.size() ? rob.limit_vel[a] : 1.0);
+   // timing (mod.cpp:2905-2911)
+   const std::vector<double> dtm = retime_linear(traj.data(), b.n_points, b.n, col0, vmax);
+   if (!no_collision_check)
+   {
+      // The reference samples the timed trajectory every 0.04 rad of C-space distance and asks
+      // OpenRAVE for environment/self collisions (mod.cpp:2958-3006).  Here the verdict comes from
+      // the model the optimizer itself uses: a configuration collides when an active sphere
+      // penetrates a signed distance field (interpolated field value below the sphere radius).
+      double total_dist = 0.0, duration = 0.0;
+      for (int i=0; i+1<b.n_points; i++)
+      {
+         double d2 = 0.0;
+         for (int j=col0; j<b.n; j++) { const double d = traj[(size_t) i*b.n+j] - traj[(size_t)(i+1)*b.n+j]; d2 += d*d; }
+         total_dist += std::sqrt(d2);
+         duration += dtm[i+1];
+      }
+      const double step_time = total_dist > 0.0 ? duration * 0.04 / total_dist : duration + 1.0;
+      std::vector<Xform> frames;
+      std::vector<double> q = rob.dof_values;
+      bool collides = false;
+      std::ostringstream details;
+      int seg = 0; double tseg0 = 0.0;
+      for (double time=0.0; time<duration && !(collides && !no_collision_exception); time+=step_time)
+      {
+         while (seg < b.n_points-2 && tseg0 + dtm[seg+1] < time) { tseg0 += dtm[seg+1]; seg++; }
+         const double u = dtm[seg+1] > 0.0 ? (time - tseg0) / dtm[seg+1] : 0.0;
+         Pose base = rob.transform;
+         if (col0)
+         {
+            for (int j=0; j<7; j++) base.v[j] = traj[(size_t) seg*b.n+j] + (traj[(size_t)(seg+1)*b.n+j] - traj[(size_t) seg*b.n+j]) * u;
+            pose_normalize(base);
+         }
+         for (size_t a=0; a<b.adofindices.size(); a++)
+         {
+            const double a0 = traj[(size_t) seg*b.n+col0+a], a1 = traj[(size_t)(seg+1)*b.n+col0+a];
+            q[b.adofindices[a]] = a0 + (a1 - a0) * u;
+         }
+         rob.fk(base, q, frames);
+         for (size_t si=0; si<rob.spheres.size() && !collides; si++)
+         {
+            const Robot::Sphere & sp = rob.spheres[si];
+            bool active = col0 != 0;
+            for (size_t a=0; a<b.adofindices.size() && !active; a++) active = rob.does_affect(b.adofindices[a], sp.link);
+            if (!active) continue;
+            double pw[3];
+            mat3_vec(frames[sp.link].R, sp.pos, pw);
+            for (int k=0; k<3; k++) pw[k] += frames[sp.link].t[k];
+            for (auto & f : sdfs)
+            {
+               const Pose pose_world_gsdf = pose_compose(body_transform(f->kinbody_name), f->pose);
+               double pg[3], val;
+               pose_apply(pose_invert(pose_world_gsdf), pw, pg);
+               if (grid_interp(f->grid, pg, &val)) continue;
+               if (val - sp.radius < 0.0)
+               {
+                  collides = true;
+                  details << "Collision at t=" << time << ": sphere " << si << " of " << b.robot_name
+                          << " is " << (sp.radius - val) << " m inside the field of " << f->kinbody_name << "\n";
+                  break;
+               }
+            }
+         }
+      }
+      last_collision_details = no_collision_details ? std::string() : details.str();
+      if (collides && !no_collision_exception) throw std::runtime_error("Resulting trajectory is in collision!");
+   }
    // active dof columns only (mod.cpp:2899-2903)
-   return serialize_traj(b.robot_name, b.adofindices, traj.data(), b.n_points, b.n, b.params.floating_base ? 7 : 0);
+   return serialize_traj(b.robot_name, b.adofindices, traj.data(), b.n_points, b.n, col0, dtm);
 }
 
 // src/orcdchomp_mod.cpp:3013-3037

@@ -26,6 +26,7 @@ struct Robot                      // what the path reads from an OpenRAVE::Robot
    std::vector<int> dof_index;
    int n_dof = 0;
    std::vector<double> limit_lower, limit_upper;
+   std::vector<double> limit_vel;   // GetDOFVelocityLimits, used by the retimer of gettraj (default 1)
    struct Sphere { int link; double pos[3]; double radius; };   // struct sphere, src/orcdchomp_kdata.h:33-39
    std::vector<Sphere> spheres;   // XML order
    // state
@@ -85,6 +86,7 @@ public:
    void get_state(const std::string & which, double * out);
    void get_trace(double * out);
    void set_noise(const double * noise, int n_blocks);
+   void set_traj(const double * traj);          // [n_runs][n_points][n] host -> device (warm start)
    void get_phase_cycles(long long * out);   // [n_runs][8], diagnostics (ORC_PHASE_TIMERS=1)
 
    int n_runs, n_points, n, m;
@@ -160,6 +162,7 @@ public:
    int kernel_launches = 0;
    std::string last_error;
    std::string last_reply;
+   std::string last_collision_details;   // what the reference logs with RAVELOG_ERROR in gettraj
 
 private:
    std::string cmd_computedistancefield(const std::vector<std::string> & argv);

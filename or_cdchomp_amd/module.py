@@ -93,6 +93,17 @@ class Module:
         idx = np.ascontiguousarray(indices, dtype=np.int32)
         self._check(self._lib.orc_robot_set_active_dofs(self._h, name.encode(), _ip(idx), len(idx)))
 
+    def set_velocity_limits(self, name, limits):
+        v = _f64(limits)
+        self._check(self._lib.orc_robot_set_velocity_limits(self._h, name.encode(), _dp(v), len(v)))
+
+    def last_collision_details(self):
+        return self._lib.orc_last_collision_details(self._h).decode()
+
+    def batch_set_traj(self, bid, traj):
+        t = _f64(traj)
+        self._check(self._lib.orc_batch_set_traj(self._h, bid, _dp(t), t.size))
+
     def add_kinbody_boxes(self, name, boxes, transform=None):
         """boxes: list of (pose7, half_extents3) in the kinbody frame."""
         poses = _f64([b[0] for b in boxes]).reshape(-1, 7)

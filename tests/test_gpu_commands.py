@@ -123,3 +123,103 @@ def test_robot_outside_every_field(oracle):
     assert np.array_equal(status, ostatus)
     assert max(common.rel_l2(traj[k], otraj[k]) for k in range(2)) <= 1e-6
     assert np.allclose(costs, ocosts, rtol=1e-6, atol=0)
+
+
+def test_device_sdf_build_bit_exact(oracle, monkeypatch):
+    """the GPU distance-transform path produces the same bits as the host path and
+    as the oracle's bin_sdf; also timed against the host on a 1-cm-cell sized grid"""
+    import time
+    from or_cdchomp_amd import scenes
+    monkeypatch.setenv("ORC_SDF_DEVICE", "1")
+    mod = bindings.bind(_mk())
+    scenes.add_tabletop(mod)
+    mod.computedistancefield(kinbody="table")
+    data, _, _ = mod.get_sdf("table")
+    assert np.array_equal(data, common.tabletop_problem(oracle)["sdf"].data)
+    # a larger random occupancy through addfield_fromobsarray, device vs host vs oracle
+    rng = np.random.default_rng(42)
+    shape = (96, 80, 72)
+    occ = np.ascontiguousarray(np.where(rng.uniform(size=shape) < 0.002, np.inf, 0.0))
+    occ[10:30, 20:40, 5:25] = np.inf
+    lengths = [0.96, 0.8, 0.72]
+    mod.add_kinbody_boxes("big", [(scenes.IDENT, [0.1, 0.1, 0.1])], transform=scenes.IDENT)
+    t0 = time.perf_counter()
+    mod.addfield_fromobsarray(kinbody="big", obsarray="%#x" % occ.ctypes.data, sizes=shape, lengths=lengths)
+    t_dev = time.perf_counter() - t0
+    dev, _, _ = mod.get_sdf("big")
+    monkeypatch.setenv("ORC_SDF_DEVICE", "0")
+    mod.add_kinbody_boxes("big2", [(scenes.IDENT, [0.1, 0.1, 0.1])], transform=scenes.IDENT)
+    t0 = time.perf_counter()
+    mod.addfield_fromobsarray(kinbody="big2", obsarray="%#x" % occ.ctypes.data, sizes=shape, lengths=lengths)
+    t_host = time.perf_counter() - t0
+    host, _, _ = mod.get_sdf("big2")
+    assert np.array_equal(dev, host)
+    assert np.array_equal(dev, oracle.OraGrid(occ, lengths).bin_sdf().data)
+    print("sdf build %s: device %.1f ms, host %.1f ms" % (shape, 1e3 * t_dev, 1e3 * t_host))
+
+
+def _doc(waypoints, deltatimes):
+    rows = " ".join(" ".join(repr(float(v)) for v in wp) + " " + repr(float(dt)) for wp, dt in zip(waypoints, deltatimes))
+    return '<trajectory>\n<data count="%d">\n%s\n</data>\n</trajectory>\n' % (len(waypoints), rows)
+
+
+def test_gettraj_retime_and_collision_verdict(oracle):
+    """gettraj: linear retiming at the dof velocity limits and the sphere-vs-field verdict
+    (reference src/orcdchomp_mod.cpp:2905-3006)"""
+    import re
+    mod = bindings.bind(_mk())
+    model = common.setup_product_wam(mod)
+    vmax = np.ones(model.n_dof); vmax[:7] = [0.5, 1.0, 2.0, 1.0, 4.0, 1.0, 0.25]
+    mod.set_velocity_limits(model.name, vmax)
+    goal = [0.6, -1.2, 0.3, 1.6, -0.4, 0.5, 0.2]
+    run = mod.create(robot=model.name, adofgoal=goal, n_points=30, lambda_=100.0, obs_factor=500.0)
+    mod.iterate(run=run, n_iter=10)
+    text = mod.gettraj(run=run, no_collision_check=True)
+    vals = np.array(re.search(r'<data count="30">\s*(.*?)\s*</data>', text, re.S).group(1).split(), dtype=float).reshape(30, 8)
+    wp, dt = vals[:, :7], vals[:, 7]
+    want = np.r_[0.0, (np.abs(np.diff(wp, axis=0)) / vmax[:7]).max(axis=1)]
+    assert np.allclose(dt, want, rtol=1e-12, atol=0)
+    mod.destroy(run=run)
+    # a goal that drives the forearm through the table top: the verdict must be "in collision"
+    model_, base, dofvals, adofs = common.wam_state()
+    deep = [1.2, -0.2, 0.0, 0.3, 0.0, 0.0, 0.0]
+    run = mod.create(robot=model.name, adofgoal=deep, n_points=30, lambda_=100.0, obs_factor=0.0, obs_factor_self=0.0)
+    with pytest.raises(RuntimeError, match="Resulting trajectory is in collision!"):
+        mod.gettraj(run=run)
+    text = mod.gettraj(run=run, no_collision_exception=True)
+    assert "Collision at t=" in mod.last_collision_details() and "table" in mod.last_collision_details()
+    mod.gettraj(run=run, no_collision_exception=True, no_collision_details=True)
+    assert mod.last_collision_details() == ""
+    mod.destroy(run=run)
+
+
+def test_starttraj_seeding(oracle):
+    """create starttraj: the run starts from the passed trajectory sampled at i*duration/(n_points-1)
+    (reference src/orcdchomp_mod.cpp:2375-2416)"""
+    mod = bindings.bind(_mk())
+    model = common.setup_product_wam(mod)
+    goal = common.wam_goals(1, seed=21)[0]
+    kw = dict(n_points=40, lambda_=100.0, obs_factor=500.0)
+    a = mod.batch_create(model.name, goal, **kw)
+    mod.batch_iterate(a, 15)
+    ta = mod.batch_gettraj(a)[0]
+    # untimed document (deltatimes 0): sampled uniformly over the waypoint index -> identical waypoints
+    run = mod.create(robot=model.name, starttraj=_doc(ta, np.zeros(40)), **kw)
+    tb = mod.batch_gettraj(int(run))[0]
+    assert np.array_equal(tb, ta)
+    ca, _ = mod.batch_iterate(a, 5)
+    cb, _ = mod.batch_iterate(int(run), 5)
+    assert np.array_equal(mod.batch_gettraj(a)[0], mod.batch_gettraj(int(run))[0]) and np.array_equal(ca, cb)
+    # timed document with non-uniform deltatimes, resampled to a different n_points
+    wp = np.array([[0.0] * 7, [1.0] * 7, [3.0] * 7])
+    run2 = mod.create(robot=model.name, starttraj=_doc(wp, [0.0, 1.0, 1.0]), n_points=5)
+    t2 = mod.batch_gettraj(int(run2))[0]
+    assert np.allclose(t2[:, 0], [0.0, 0.5, 1.0, 2.0, 3.0])
+    with pytest.raises(RuntimeError, match="Cannot pass both adofgoal and starttraj!"):
+        mod.SendCommand("create robot %s adofgoal '0 0 0 0 0 0 0' starttraj 'x'" % model.name)
+    # orc_batch_set_traj: warm start of a whole batch
+    goals = common.wam_goals(3, seed=22)
+    b1 = mod.batch_create(model.name, goals, **kw); mod.batch_iterate(b1, 8)
+    b2 = mod.batch_create(model.name, goals, **kw); mod.batch_set_traj(b2, mod.batch_gettraj(b1))
+    c1, _ = mod.batch_iterate(b1, 4); c2, _ = mod.batch_iterate(b2, 4)
+    assert np.array_equal(c1, c2)
