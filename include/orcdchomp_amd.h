@@ -36,6 +36,9 @@ const char * orc_last_error(const orc_module * mod);
 /* HIP stream all kernels and copies of this module are issued on (a hipStream_t,
  * e.g. torch.cuda.current_stream().cuda_stream); NULL = the default stream. */
 int orc_set_stream(orc_module * mod, void * hip_stream);
+/* give the module a pool of n internal streams: batches created afterwards are bound to them
+ * round-robin, so launches of independent batches overlap on the GPU (0 = back to one stream) */
+int orc_set_num_streams(orc_module * mod, int n);
 
 /* ---- SendCommand -------------------------------------------------------------
  * replaces ModuleBase::SendCommand -> orcwrap_call (src/orcwrap.cpp:37-69) ->

@@ -37,6 +37,7 @@ SYMBOLS = [
     ("orc_module_free", None, [C.c_void_p]),
     ("orc_last_error", C.c_char_p, [C.c_void_p]),
     ("orc_set_stream", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("orc_set_num_streams", C.c_int, [C.c_void_p, C.c_int]),
     ("orc_send_command", C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t]),
     ("orc_last_reply_size", C.c_size_t, [C.c_void_p]),
     ("orc_last_reply", C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),

@@ -53,6 +53,7 @@ Batch::Batch(Module * mod, const Robot & robot, const BatchParams & p, int nruns
    const double * starts, const double * goals, const double * basegoals, const unsigned int * seeds)
    : n_runs(nruns), params(p), mod_(mod)
 {
+   stream_ = mod_->pick_stream();
    if (p.precision != 64 && p.precision != 32) throw std::runtime_error("precision must be 32 or 64!");
    const int n_adof = (int) robot.active_dofs.size();
    n_points = p.n_points;
@@ -92,7 +93,7 @@ Batch::Batch(Module * mod, const Robot & robot, const BatchParams & p, int nruns
          gk[c0+j] = goals[(size_t) k*n_adof+j];
       }
    }
-   hipStream_t st = mod_->stream;
+   hipStream_t st = stream_;
    double * d_s = dev_alloc<double>(s.size());
    double * d_g = dev_alloc<double>(g.size());
    hip_check(hipMemcpyAsync(d_s, s.data(), s.size()*sizeof(double), hipMemcpyHostToDevice, st), "starts");
@@ -134,7 +135,7 @@ Batch::Batch(Module * mod, const Robot & robot, const BatchParams & p, int nruns
 
 Batch::~Batch()
 {
-   hipStreamSynchronize(mod_->stream);
+   hipStreamSynchronize(stream_);
    dev_free(d_model_); dev_free(d_sdfs_); dev_free(d_traj_); dev_free(d_AG_); dev_free(d_G_);
    dev_free(d_costs_); dev_free(d_trace_); dev_free(d_status_); dev_free(d_leap_);
    dev_free(d_Aband_); dev_free(d_beta_s_); dev_free(d_beta_g_); dev_free(d_pcr_); dev_free(d_Ainv_);
@@ -338,7 +339,7 @@ void Batch::build_device(const Robot & robot)
    }
    nj_ = nj; Sa_ = Sa; tree_ = M.tree;
 
-   hipStream_t st = mod_->stream;
+   hipStream_t st = stream_;
    DevModel<real> * dm = dev_alloc<DevModel<real>>(1);
    hip_check(hipMemcpyAsync(dm, &M, sizeof(M), hipMemcpyHostToDevice, st), "model");
    hip_check(hipStreamSynchronize(st), "model sync");
@@ -461,7 +462,7 @@ void Batch::plan_hmc(int n_iter)
    {
       dev_free(d_hmc_iters_); d_hmc_iters_ = dev_alloc<int>(flat.size()); hmc_cap_iters_ = flat.size();
    }
-   hip_check(hipMemcpyAsync(d_hmc_iters_, flat.data(), flat.size()*sizeof(int), hipMemcpyHostToDevice, mod_->stream), "hmc iters");
+   hip_check(hipMemcpyAsync(d_hmc_iters_, flat.data(), flat.size()*sizeof(int), hipMemcpyHostToDevice, stream_), "hmc iters");
    const size_t ncount = (size_t) n_runs * maxr * mn;
    const size_t rsize = (params.precision == 64) ? 8 : 4;
    if (ncount * rsize > noise_cap_)
@@ -472,16 +473,16 @@ void Batch::plan_hmc(int n_iter)
    {
       std::vector<double> buf(ncount, 0.0);
       for (int k=0; k<n_runs; k++) std::copy(noise[k].begin(), noise[k].end(), buf.begin() + (size_t) k*maxr*mn);
-      hip_check(hipMemcpyAsync(d_noise_, buf.data(), ncount*8, hipMemcpyHostToDevice, mod_->stream), "noise");
-      hip_check(hipStreamSynchronize(mod_->stream), "noise sync");
+      hip_check(hipMemcpyAsync(d_noise_, buf.data(), ncount*8, hipMemcpyHostToDevice, stream_), "noise");
+      hip_check(hipStreamSynchronize(stream_), "noise sync");
    }
    else
    {
       std::vector<float> buf(ncount, 0.f);
       for (int k=0; k<n_runs; k++)
          for (size_t e=0; e<noise[k].size(); e++) buf[(size_t) k*maxr*mn + e] = (float) noise[k][e];
-      hip_check(hipMemcpyAsync(d_noise_, buf.data(), ncount*4, hipMemcpyHostToDevice, mod_->stream), "noise");
-      hip_check(hipStreamSynchronize(mod_->stream), "noise sync");
+      hip_check(hipMemcpyAsync(d_noise_, buf.data(), ncount*4, hipMemcpyHostToDevice, stream_), "noise");
+      hip_check(hipStreamSynchronize(stream_), "noise sync");
    }
 }
 
@@ -516,6 +517,8 @@ void Batch::launch(int n_iter)
    b.n_iter = n_iter; b.final_eval = 1;
    b.phase_cycles = d_phase_;
    b.pcr_in_lds = pcr_in_lds_;
+   b.stagger_mode = getenv("ORC_STAGGER_MODE") ? atoi(getenv("ORC_STAGGER_MODE")) : 0;
+   b.stagger_sleeps = getenv("ORC_STAGGER_SLEEPS") ? atoi(getenv("ORC_STAGGER_SLEEPS")) : 10;
    if (params.derivative == 1 && m >= 2)
    {
       b.a_diag = (real) metric_.Adense[(size_t) 1*m + 1];
@@ -527,10 +530,10 @@ void Batch::launch(int n_iter)
       b.a_off = (real) metric_.beta_s[0];
    }
    b.Gdbg = debug_state_ ? (real *) d_G_ : nullptr;
-   mod_->time_begin();
-   hipError_t e = launch_typed(b, lds_bytes_, mod_->stream, tree_);
+   mod_->time_begin(stream_);
+   hipError_t e = launch_typed(b, lds_bytes_, stream_, tree_);
    hip_check(e, "chomp_iterate_kernel launch");
-   mod_->time_end();
+   mod_->time_end(stream_);
 }
 
 void Batch::iterate_async(int n_iter)
@@ -540,7 +543,7 @@ void Batch::iterate_async(int n_iter)
    const size_t tneed = (size_t) n_runs * (n_iter ? n_iter : 1) * 3;
    if (tneed > trace_cap_)
    {
-      hip_check(hipStreamSynchronize(mod_->stream), "sync");
+      hip_check(hipStreamSynchronize(stream_), "sync");
       dev_free(d_trace_); d_trace_ = dev_alloc<double>(tneed); trace_cap_ = tneed;
    }
    max_resamples_ = 0;
@@ -550,7 +553,7 @@ void Batch::iterate_async(int n_iter)
 
 void Batch::sync(double * costs_out, int * status_out)
 {
-   hipStream_t st = mod_->stream;
+   hipStream_t st = stream_;
    if (costs_out) hip_check(hipMemcpyAsync(costs_out, d_costs_, (size_t) n_runs*3*sizeof(double), hipMemcpyDeviceToHost, st), "costs");
    if (status_out) hip_check(hipMemcpyAsync(status_out, d_status_, n_runs*sizeof(int), hipMemcpyDeviceToHost, st), "status");
    hip_check(hipStreamSynchronize(st), "hipStreamSynchronize");
@@ -577,14 +580,14 @@ void download(void * d, size_t count, int precision, double * out, hipStream_t s
 
 void Batch::gettraj(double * out)
 {
-   download(d_traj_, (size_t) n_runs * n_points * n, params.precision, out, mod_->stream);
+   download(d_traj_, (size_t) n_runs * n_points * n, params.precision, out, stream_);
 }
 
 void Batch::get_state(const std::string & which, double * out)
 {
    const size_t mcount = (size_t) n_runs * m * n;
-   if (which == "G") download(d_G_, mcount, params.precision, out, mod_->stream);
-   else if (which == "AG") download(d_AG_, mcount, params.precision, out, mod_->stream);
+   if (which == "G") download(d_G_, mcount, params.precision, out, stream_);
+   else if (which == "AG") download(d_AG_, mcount, params.precision, out, stream_);
    else if (which == "T")
    {
       std::vector<double> full((size_t) n_runs * n_points * n);
@@ -597,8 +600,8 @@ void Batch::get_state(const std::string & which, double * out)
 
 void Batch::get_trace(double * out)
 {
-   hip_check(hipMemcpyAsync(out, d_trace_, (size_t) n_runs * last_n_iter * 3 * sizeof(double), hipMemcpyDeviceToHost, mod_->stream), "trace");
-   hip_check(hipStreamSynchronize(mod_->stream), "sync");
+   hip_check(hipMemcpyAsync(out, d_trace_, (size_t) n_runs * last_n_iter * 3 * sizeof(double), hipMemcpyDeviceToHost, stream_), "trace");
+   hip_check(hipStreamSynchronize(stream_), "sync");
 }
 
 void Batch::get_phase_cycles(long long * out)
@@ -611,13 +614,13 @@ void Batch::set_traj(const double * traj)
 {
    const size_t count = (size_t) n_runs * n_points * n;
    if (params.precision == 64)
-      hip_check(hipMemcpyAsync(d_traj_, traj, count*sizeof(double), hipMemcpyHostToDevice, mod_->stream), "set_traj");
+      hip_check(hipMemcpyAsync(d_traj_, traj, count*sizeof(double), hipMemcpyHostToDevice, stream_), "set_traj");
    else
    {
       std::vector<float> tmp(traj, traj + count);
-      hip_check(hipMemcpyAsync(d_traj_, tmp.data(), count*sizeof(float), hipMemcpyHostToDevice, mod_->stream), "set_traj");
+      hip_check(hipMemcpyAsync(d_traj_, tmp.data(), count*sizeof(float), hipMemcpyHostToDevice, stream_), "set_traj");
    }
-   hip_check(hipStreamSynchronize(mod_->stream), "set_traj sync");
+   hip_check(hipStreamSynchronize(stream_), "set_traj sync");
 }
 
 void Batch::set_noise(const double * noise, int n_blocks)

@@ -55,6 +55,11 @@ int orc_set_stream(orc_module * mod, void * hip_stream)
    return guarded(mod, [&] { mod->impl->stream = (hipStream_t) hip_stream; });
 }
 
+int orc_set_num_streams(orc_module * mod, int n)
+{
+   return guarded(mod, [&] { mod->impl->set_num_streams(n < 0 ? 0 : n); });
+}
+
 int orc_send_command(orc_module * mod, const char * cmd, char * out, size_t out_cap)
 {
    return guarded(mod, [&] {

@@ -450,6 +450,14 @@ void chomp_iterate_kernel(const DevBatch<real> b)
 #define ORC_MARK(slot) do { if (b.phase_cycles && tid == 0) { const long long now_ = clock64(); ph[slot] += now_ - tmark; tmark = now_; } } while (0)
    if (b.phase_cycles && tid == 0) tmark = clock64();
 
+   // co-resident workgroups that start in lockstep stay in lockstep (all in the one-wave FK phase
+   // together, then all in the cost phase): delaying every other one interleaves their phases
+   if (b.stagger_mode)
+   {
+      const bool late = (b.stagger_mode == 1) ? (blockIdx.x & 1) : ((blockIdx.x >> 8) & 1);
+      if (late) for (int k=0; k<b.stagger_sleeps; k++) __builtin_amdgcn_s_sleep(127);
+   }
+
    double cost_obs = 0.0, cost_smooth = 0.0;
    const int total_passes = b.n_iter + (b.final_eval ? 1 : 0);
 

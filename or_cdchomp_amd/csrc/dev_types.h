@@ -110,6 +110,8 @@ struct DevBatch
    long long * phase_cycles; // [n_runs][8] or null: diagnostics (cycles per phase, wave 0)
    real a_diag, a_off;     // D == 1: A = tridiag(a_off, a_diag, a_off), B couples the end rows with a_off
    int pcr_in_lds;         // the cyclic-reduction tables are staged in LDS
+   int stagger_mode;       // 0 none; 1 odd workgroups, 2 every other group of 256: start half an iteration late
+   int stagger_sleeps;     // length of that delay in s_sleep(127) units (~8k cycles each)
 };
 
 // LDS carve-up of one workgroup, shared by the kernel and the host-side size computation.

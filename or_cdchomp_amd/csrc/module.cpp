@@ -82,23 +82,43 @@ Module::~Module()
    for (auto & s : sdfs) { if (s->d_data64) hipFree(s->d_data64); if (s->d_data32) hipFree(s->d_data32); }
    for (auto & p : pending_events_) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
    for (auto & e : event_pool_) hipEventDestroy(e);
+   for (hipStream_t st : stream_pool) hipStreamDestroy(st);
 }
 
-void Module::time_begin()
+void Module::set_num_streams(int n)
+{
+   for (hipStream_t st : stream_pool) hipStreamDestroy(st);
+   stream_pool.clear();
+   for (int k=0; k<n; k++)
+   {
+      hipStream_t st;
+      hip_check(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate");
+      stream_pool.push_back(st);
+   }
+   next_pool_stream = 0;
+}
+
+hipStream_t Module::pick_stream()
+{
+   if (stream_pool.empty()) return stream;
+   return stream_pool[next_pool_stream++ % stream_pool.size()];
+}
+
+void Module::time_begin(hipStream_t st)
 {
    hipEvent_t a;
    if (!event_pool_.empty()) { a = event_pool_.back(); event_pool_.pop_back(); }
    else hip_check(hipEventCreate(&a), "hipEventCreate");
-   hip_check(hipEventRecord(a, stream), "hipEventRecord");
+   hip_check(hipEventRecord(a, st), "hipEventRecord");
    ev_begin_ = a;
 }
 
-void Module::time_end()
+void Module::time_end(hipStream_t st)
 {
    hipEvent_t b;
    if (!event_pool_.empty()) { b = event_pool_.back(); event_pool_.pop_back(); }
    else hip_check(hipEventCreate(&b), "hipEventCreate");
-   hip_check(hipEventRecord(b, stream), "hipEventRecord");
+   hip_check(hipEventRecord(b, st), "hipEventRecord");
    pending_events_.push_back(std::make_pair(ev_begin_, b));
    ev_begin_ = nullptr;
 }

@@ -100,6 +100,7 @@ private:
    template <typename real> void launch(int n_iter);
    void plan_hmc(int n_iter);
    Module * mod_;
+   hipStream_t stream_ = nullptr;   // the stream all work of this batch is issued on
    Metric metric_;
    // device buffers (typed by params.precision)
    void * d_model_ = nullptr; void * d_sdfs_ = nullptr;
@@ -154,9 +155,15 @@ public:
 
    hipStream_t stream = nullptr;
    int device;
+   // optional pool of streams: batches are bound round-robin to one of them at creation so that
+   // independent batches overlap on the GPU (the tail of one launch fills with the next)
+   std::vector<hipStream_t> stream_pool;
+   size_t next_pool_stream = 0;
+   void set_num_streams(int n);
+   hipStream_t pick_stream();
    // kernel timing (HIP events on `stream`)
-   void time_begin();
-   void time_end();
+   void time_begin(hipStream_t st);
+   void time_end(hipStream_t st);
    void time_collect();
    double kernel_ms_total = 0.0;
    int kernel_launches = 0;

@@ -62,6 +62,9 @@ class Module:
     def set_stream(self, hip_stream):
         self._check(self._lib.orc_set_stream(self._h, C.c_void_p(hip_stream)))
 
+    def set_num_streams(self, n):
+        self._check(self._lib.orc_set_num_streams(self._h, int(n)))
+
     # ---- environment stand-ins -----------------------------------------------------
     def add_robot(self, model, transform=None, dof_values=None, active_dofs=None):
         a = model.arrays()
