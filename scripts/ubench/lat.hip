@@ -50,6 +50,25 @@ __global__ void dpp_chain(double * out, long long * cyc, int n)
    long long t1 = clock64();
    out[threadIdx.x] = x; if (threadIdx.x == 0) cyc[0] = t1 - t0;
 }
+template <int ILP>
+__global__ void fma_lanes(double * out, long long * cyc, double a, double b, int n, int active)
+{
+   double x[ILP];
+   for (int k=0; k<ILP; k++) x[k] = threadIdx.x * 1e-3 + k;
+   long long t0 = clock64();
+   if ((int)(threadIdx.x & 63) < active)
+   {
+      for (int i=0; i<n; i++)
+      {
+#pragma unroll
+         for (int k=0; k<ILP; k++) x[k] = fma(x[k], a, b);
+      }
+   }
+   long long t1 = clock64();
+   double s = 0; for (int k=0; k<ILP; k++) s += x[k];
+   out[blockIdx.x*blockDim.x+threadIdx.x] = s;
+   if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
 int main()
 {
    double * out; long long * cyc; hipMalloc(&out, 1<<20); hipMalloc(&cyc, 4096);
@@ -66,5 +85,7 @@ int main()
    RUN(rsq_chain, 1, 64, out, cyc, n); printf("rsq f64 + add dependent        : %.1f cyc/iter\n", (double) h[0]/n);
    RUN(lds_chain, 1, 64, out, cyc, n); printf("lds read dependent (+cvt)      : %.1f cyc/iter\n", (double) h[0]/n);
    RUN(dpp_chain, 1, 64, out, cyc, n); printf("2 dpp mov + add f64 dependent  : %.1f cyc/iter\n", (double) h[0]/n);
+   for (int act : {64, 48, 32, 16, 8})
+   { RUN(fma_lanes<8>, 1, 64, out, cyc, 1.0000001, 1e-9, n, act); printf("fma f64 ILP8, %2d active lanes    : %.1f cyc/instr\n", act, (double) h[0]/n/8); }
    return 0;
 }
