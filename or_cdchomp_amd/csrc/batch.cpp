@@ -326,6 +326,20 @@ void Batch::build_device(const Robot & robot)
       }
       device_sphere_order.push_back(act[s].xml);
    }
+   // which spheres a joint moves, as a range of the device order (J^T through wrench suffix sums)
+   M.jt_scan = 1;
+   for (int k=0; k<nj; k++)
+   {
+      DevJoint<real> & J = M.joints[k];
+      int first = -1, last = -1, count = 0;
+      for (int s=0; s<Sa; s++)
+         if ((M.sph_affects[s] >> k) & 1ull) { if (first < 0) first = s; last = s; count++; }
+      J.aff_begin = (count > 0) ? first : Sa;
+      J.aff_end = (count > 0) ? last + 1 : Sa;
+      if (count > 0 && last - first + 1 != count) { M.jt_scan = 0; break; }
+      if (count > 0 && J.aff_end != Sa) M.jt_scan = 2;
+   }
+   if (getenv("ORC_NO_JT_SCAN")) M.jt_scan = 0;      // experiments: per-joint reductions
    for (int s=0; s<(int) inact.size(); s++)
    {
       const Robot::Sphere & sp = robot.spheres[inact[s].xml];

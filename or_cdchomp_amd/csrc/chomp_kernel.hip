@@ -397,6 +397,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
    real * AG_s = lds + L.AG;                            // [m][n]
    real * pos_s = lds + L.pos;                          // [tile_m+2][Sa][3]
    real * ax_s = lds + L.ax;                            // [tile_m+2][nj][6]
+   const int pstr = L.pstr, astr = L.astr;              // padded waypoint strides of pos_s / ax_s
    real * srad_s = lds + L.srad;                        // [S] sphere radii
    real * sinact_s = lds + L.sinact;                    // [S-Sa][3] inactive sphere centres
    real * jl_s = lds + L.jl;                            // [2][n] joint limits
@@ -410,7 +411,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
    DevSdf<real> * sdfs_s = (DevSdf<real> *)(smem_raw + L.sdfs_bytes);
    unsigned long long * saff_s = (unsigned long long *)(smem_raw + L.saff_bytes);
    ModelView<real> mod;
-   mod.nj = nj; mod.n = n; mod.floating = gmod.floating; mod.tree = gmod.tree; mod.Sa = Sa; mod.S = S; mod.GS = GS;
+   mod.nj = nj; mod.n = n; mod.floating = gmod.floating; mod.tree = gmod.tree; mod.Sa = Sa; mod.S = S; mod.GS = GS; mod.jt_scan = gmod.jt_scan;
    mod.base_sph_begin = gmod.base_sph_begin; mod.base_sph_end = gmod.base_sph_end;
    mod.base_R = base_s; mod.base_t = base_s + 9;
    mod.joints = joints_s; mod.sph_pos = (const real (*)[3]) sphpos_s; mod.sph_affects = saff_s;
@@ -484,9 +485,14 @@ void chomp_iterate_kernel(const DevBatch<real> b)
          const int te = (ts + tile_m < m) ? ts + tile_m : m;
          const int nfk = te - ts + 2;          // waypoints ts .. te+1 (global index)
 
-         // ================= FK phase: lane = waypoint =========================
-         if (tid < nfk)
-            fk_waypoint<real, TREE>(mod, T_s + (ts + tid)*n, nj, Sa, pos_s + tid*Sa*3, ax_s + tid*nj*6);
+         // ================= FK phase: lane = (waypoint, world axis) ===========
+         for (int w0=0; w0<nfk; w0+=ORC_BLOCK/4)
+         {
+            const int w = w0 + (tid >> 2);
+            const bool valid = (w < nfk);
+            const int wr = valid ? w : 0;
+            fk_waypoint_quad<real, TREE>(mod, T_s + (ts + wr)*n, nj, tid & 3, valid, pos_s + wr*pstr, ax_s + wr*astr);
+         }
          __syncthreads();
          ORC_MARK(0);
 
@@ -514,9 +520,9 @@ void chomp_iterate_kernel(const DevBatch<real> b)
             bool moving = false;
             if (live)
             {
-               const real * pc = pos_s + (l*Sa + s)*3;
-               const real * pp = pos_s + ((l-1)*Sa + s)*3;
-               const real * pn = pos_s + ((l+1)*Sa + s)*3;
+               const real * pc = pos_s + l*pstr + s*3;
+               const real * pp = pos_s + (l-1)*pstr + s*3;
+               const real * pn = pos_s + (l+1)*pstr + s*3;
                radius = srad_s[s];
                mylink = slink_s[s];
 #pragma unroll
@@ -598,7 +604,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
 #pragma unroll 4
                for (int o=0; o<S; o++)
                {
-                  const real * po = (o < Sa) ? pos_s + (l*Sa + o)*3 : sinact_s + (o - Sa)*3;
+                  const real * po = (o < Sa) ? pos_s + l*pstr + o*3 : sinact_s + (o - Sa)*3;
                   const real dx = p[0]-po[0], dy = p[1]-po[1], dz = p[2]-po[2];
                   const real d2 = dx*dx + dy*dy + dz*dz;
                   const real R = radius + srad_s[o] + b.epsilon_self;
@@ -615,7 +621,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
                {
                   const int o = __builtin_ctzll(near);
                   near &= near - 1;
-                  const real * po = (o < Sa) ? pos_s + (l*Sa + o)*3 : sinact_s + (o - Sa)*3;
+                  const real * po = (o < Sa) ? pos_s + l*pstr + o*3 : sinact_s + (o - Sa)*3;
                   const real ro = srad_s[o];
                   const real d[3] = { p[0]-po[0], p[1]-po[1], p[2]-po[2] };
                   real inv_d;
@@ -647,8 +653,8 @@ void chomp_iterate_kernel(const DevBatch<real> b)
                      // its term (J_o - J_me)^T x_o puts -x_o on this sphere
                      if (o < Sa)
                      {
-                        const real * opp = pos_s + ((l-1)*Sa + o)*3;
-                        const real * opn = pos_s + ((l+1)*Sa + o)*3;
+                        const real * opp = pos_s + (l-1)*pstr + o*3;
+                        const real * opn = pos_s + (l+1)*pstr + o*3;
                         real vo[3];
 #pragma unroll
                         for (int k=0; k<3; k++) { real v = opn[k]; v -= opp[k]; v *= b.inv_2dt; vo[k] = v; }
@@ -684,7 +690,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
                   real cg = 0;
                   if ((aff >> j) & 1ull)
                   {
-                     const real * ax = ax_s + (l*nj + j)*6;
+                     const real * ax = ax_s + l*astr + j*6;
                      if (jtype_s[j] == 1)
                      {
                         const real r0 = p[0]-ax[3], r1 = p[1]-ax[4], r2 = p[2]-ax[5];

@@ -393,6 +393,7 @@ __device__ __forceinline__ void cost_tile_gs16(const DevBatch<real> & b, const M
 {
    const int tid = threadIdx.x;
    const int Sa = mod.Sa, S = mod.S, nj = mod.nj, n = b.n;
+   const int pstr = (Sa*3) | 1, astr = (nj*6) | 1;   // padded waypoint strides (LdsLayout::pstr/astr)
    const int nw = te - ts;                      // moving waypoints of this tile
    const int ngroups = (nw + U - 1) / U;        // group g owns waypoints g + u*ngroups
    const int items = ngroups * 16;
@@ -417,9 +418,9 @@ __device__ __forceinline__ void cost_tile_gs16(const DevBatch<real> & b, const M
          wl[u] = g + u*ngroups;
          live[u] = lane_ok && (wl[u] < nw);
          l[u] = (wl[u] < nw && item < items ? wl[u] : 0) + 1;
-         const real * pc = pos_s + (l[u]*Sa + ss)*3;
-         const real * pp = pc - Sa*3;
-         const real * pn = pc + Sa*3;
+         const real * pc = pos_s + l[u]*pstr + ss*3;
+         const real * pp = pc - pstr;
+         const real * pn = pc + pstr;
 #pragma unroll
          for (int k=0; k<3; k++)
          {
@@ -558,6 +559,78 @@ __device__ __forceinline__ void cost_tile_gs16(const DevBatch<real> & b, const M
 #pragma unroll
          for (int u=0; u<U; u++) row_ok[u] = (item < items) && (wl[u] < nw) && (s == 0);
 #ifndef ORC_ABLATE_JT
+         // Wrench of the lane's force about the world origin [p x f ; f].  When the spheres a joint
+         // moves are a contiguous range of the row (chains: a suffix), the sums over those spheres
+         // come from ONE suffix scan of the wrench over the row, and lane r of the row finishes
+         // joint r on its own:  G_j = axis_j . (sum tau - anchor_j x sum f)   (revolute)
+         //                      G_j = axis_j . sum f                          (prismatic)
+         // which is sum_s axis_j . ((p_s - anchor_j) x f_s) of src/orcdchomp_mod.cpp:1040-1048,1323.
+         real w6[U][6];
+         if (mod.jt_scan || mod.floating)
+         {
+#pragma unroll
+            for (int u=0; u<U; u++)
+            {
+               w6[u][0] = p[u][1]*f[u][2] - p[u][2]*f[u][1];
+               w6[u][1] = p[u][2]*f[u][0] - p[u][0]*f[u][2];
+               w6[u][2] = p[u][0]*f[u][1] - p[u][1]*f[u][0];
+               w6[u][3] = f[u][0]; w6[u][4] = f[u][1]; w6[u][5] = f[u][2];
+#pragma unroll
+               for (int k=0; k<6; k++) w6[u][k] = live[u] ? w6[u][k] : (real)0;
+            }
+         }
+         if (mod.jt_scan)
+         {
+#pragma unroll
+            for (int u=0; u<U; u++)
+#pragma unroll
+               for (int k=0; k<6; k++)
+               {
+                  real v = w6[u][k];
+                  v += dpp_move<0x101>(v);       // row_shl:1  (lane i takes lane i+1, 0 past the row)
+                  v += dpp_move<0x102>(v);       // row_shl:2
+                  v += dpp_move<0x104>(v);       // row_shl:4
+                  v += dpp_move<0x108>(v);       // row_shl:8
+                  w6[u][k] = v;                  // sum over the spheres s .. 15 of this waypoint
+               }
+            for (int j0=0; j0<nj; j0+=16)
+            {
+               const int j = j0 + s;
+               const bool jok = (j < nj);
+               const DevJoint<real> & J = mod.joints[jok ? j : 0];
+               const int ab = J.aff_begin, ae = J.aff_end;
+               const bool rev = (J.type == 1);
+               const int col = J.col;
+#pragma unroll
+               for (int u=0; u<U; u++)
+               {
+                  real W[6];
+#pragma unroll
+                  for (int k=0; k<6; k++)
+                  {
+                     const real hi = __shfl(w6[u][k], ab & 15, 16);
+                     W[k] = (ab < 16) ? hi : (real)0;
+                  }
+                  if (mod.jt_scan == 2)
+                  {
+#pragma unroll
+                     for (int k=0; k<6; k++)
+                     {
+                        const real lo = __shfl(w6[u][k], ae & 15, 16);
+                        W[k] -= (ae < 16) ? lo : (real)0;
+                     }
+                  }
+                  const real * ax = ax_s + l[u]*astr + (jok ? j : 0)*6;
+                  const real c0 = W[0] - (ax[4]*W[5] - ax[5]*W[4]);
+                  const real c1 = W[1] - (ax[5]*W[3] - ax[3]*W[5]);
+                  const real c2 = W[2] - (ax[3]*W[4] - ax[4]*W[3]);
+                  const real crev = ax[0]*c0 + ax[1]*c1 + ax[2]*c2;
+                  const real cpri = ax[0]*W[3] + ax[1]*W[4] + ax[2]*W[5];
+                  if (jok && (item < items) && (wl[u] < nw)) G_s[(ts + wl[u])*n + col] = rev ? crev : cpri;
+               }
+            }
+         }
+         else
          for (int j=0; j<nj; j++)
          {
             const bool hit = (aff >> j) & 1ull;
@@ -567,7 +640,7 @@ __device__ __forceinline__ void cost_tile_gs16(const DevBatch<real> & b, const M
 #pragma unroll
             for (int u=0; u<U; u++)
             {
-               const real * ax = ax_s + (l[u]*nj + j)*6;
+               const real * ax = ax_s + l[u]*astr + j*6;
                const real r0 = p[u][0]-ax[3], r1 = p[u][1]-ax[4], r2 = p[u][2]-ax[5];
                const real c0 = r1*f[u][2] - r2*f[u][1];
                const real c1 = r2*f[u][0] - r0*f[u][2];
@@ -589,13 +662,9 @@ __device__ __forceinline__ void cost_tile_gs16(const DevBatch<real> & b, const M
 #pragma unroll
             for (int u=0; u<U; u++)
             {
-               real w6[6];
-               w6[0] = p[u][1]*f[u][2] - p[u][2]*f[u][1];
-               w6[1] = p[u][2]*f[u][0] - p[u][0]*f[u][2];
-               w6[2] = p[u][0]*f[u][1] - p[u][1]*f[u][0];
-               w6[3] = f[u][0]; w6[4] = f[u][1]; w6[5] = f[u][2];
+               real wt[6];       // total wrench of the waypoint (lane 0 of the row holds it after the scan)
 #pragma unroll
-               for (int k=0; k<6; k++) w6[k] = group_sum(live[u] ? w6[k] : (real)0, 16);
+               for (int k=0; k<6; k++) wt[k] = mod.jt_scan ? w6[u][k] : group_sum(w6[u][k], 16);
                if (row_ok[u])
                {
                   const int gi = ts + wl[u];
@@ -619,7 +688,7 @@ __device__ __forceinline__ void cost_tile_gs16(const DevBatch<real> & b, const M
                   {
                      real sum = 0;
 #pragma unroll
-                     for (int a=0; a<6; a++) sum += Jsp[a][c] * w6[a];
+                     for (int a=0; a<6; a++) sum += Jsp[a][c] * wt[a];
                      G_s[gi*n + c] = (real)0.01 * sum;
                   }
                }

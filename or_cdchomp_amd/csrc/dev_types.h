@@ -29,6 +29,8 @@ struct DevJoint
    int rfix_identity; // Rfix == I (skips a 3x3 product)
    int axis_kind;     // 1/2/3: the axis is +-x/+-y/+-z of the joint frame (cheap column rotation), 0 general
    real axis_sign;    // +-1 for axis_kind != 0
+   int aff_begin;     // the active spheres this joint moves are [aff_begin, aff_end) when DevModel::jt_scan != 0
+   int aff_end;
 };
 
 template <typename real>
@@ -43,6 +45,7 @@ struct DevModel
    int GS;                 // lanes per waypoint in the cost phase (power of two >= Sa)
    int base_sph_begin;     // active spheres fixed to the base frame (floating base only)
    int base_sph_end;
+   int jt_scan;            // spheres moved by a joint are contiguous: 1 every set ends at Sa (chain), 2 general ranges, 0 not contiguous
    real base_R[9];         // base frame when not floating
    real base_t[3];
    DevJoint<real> joints[ORC_MAX_JOINTS];
@@ -119,6 +122,7 @@ struct DevBatch
 struct LdsLayout
 {
    int T, G, W, AG, pos, ax, srad, sinact, jl, pcr, end_reals;
+   int pstr, astr;         // waypoint strides of pos / ax: odd, so that lane = waypoint accesses (FK) hit distinct LDS banks
    int ints_bytes;         // byte offset of the int tables (slink, jtype, jcol)
    int joints_bytes;       // byte offset of the staged DevJoint[nj]
    int sdfs_bytes;         // byte offset of the staged DevSdf[n_sdfs]
@@ -131,7 +135,7 @@ struct LdsLayout
 template <typename real>
 struct ModelView
 {
-   int nj, n, floating, tree, Sa, S, GS, base_sph_begin, base_sph_end;
+   int nj, n, floating, tree, Sa, S, GS, base_sph_begin, base_sph_end, jt_scan;
    const real * base_R;                    // [9]
    const real * base_t;                    // [3]
    const DevJoint<real> * joints;          // [nj]
@@ -152,8 +156,10 @@ inline LdsLayout lds_layout(int np, int n, int Sa, int S, int nj, int tile_m, in
    L.G = take(mn);
    L.W = take(mn);
    L.AG = take(use_ag ? mn : 0);
-   L.pos = take((tile_m+2)*Sa*3);
-   L.ax = take((tile_m+2)*nj*6);
+   L.pstr = (Sa*3) | 1;
+   L.astr = (nj*6) | 1;
+   L.pos = take((tile_m+2)*L.pstr);
+   L.ax = take((tile_m+2)*L.astr);
    L.srad = take(S);
    L.sinact = take((S-Sa)*3 + 1);
    L.jl = take(2*n);

@@ -1,13 +1,19 @@
-// fk.h -- forward kinematics of one waypoint per lane (FK phase of the CHOMP iteration).
+// fk.h -- forward kinematics, FK phase of the CHOMP iteration: lane = (waypoint, world axis).
 //
 // Included by chomp_kernel.hip.  Restates the FK half of sphere_cost_pre
 // (/root/reference src/orcdchomp_mod.cpp:988-1038) on the build's own kinematic model: walks
 // the folded joint tree with the current frame in registers and writes, per waypoint,
 //   pos_s[lane][sphere][3]   sphere centres in the world
 //   ax_s [lane][joint][6]    world joint axis and anchor (what J^T needs instead of 3 x n Jacobians)
-// The phase is issue-bound on a single wavefront (64 waypoints), so the work is kept small:
-// joints whose axis is a coordinate axis of their frame rotate two columns in place, and
-// sin/cos come from a short Cody-Waite + minimax kernel (the angles are joint values).
+// Row k of a frame (R[k][0..2], t[k]) evolves independently of the other two rows under every
+// operation of the walk (R <- R*Rfix, R <- R*Rot(axis,q), t <- R*tfix + t, p = R*lp + t), so four
+// lanes share a waypoint: lanes 0..2 carry the x, y, z rows, lane 3 idles but evaluates its share
+// of the sin/cos (lane k of the quad evaluates joints k, k+4, ...; the values travel by quad
+// broadcast).  64 waypoints fill all four wavefronts with a third of the arithmetic each, where
+// one lane per waypoint left three wavefronts waiting (an fp64 instruction costs the same issue
+// time for 16 live lanes as for 64: scripts/ubench/lat.hip).  Joints whose axis is a coordinate
+// axis of their frame rotate two columns in place; sin/cos come from a short Cody-Waite + minimax
+// kernel (the angles are joint values).
 #pragma once
 
 // sin and cos of a joint angle.  3-part Cody-Waite reduction by pi/2 and the fdlibm minimax
@@ -40,142 +46,133 @@ __device__ __forceinline__ void sincos_joint(double x, double * sn, double * cs)
 }
 __device__ __forceinline__ void sincos_joint(float x, float * sn, float * cs) { ::sincosf(x, sn, cs); }
 
-// columns A and B of R rotate into each other: A' = c A + s B, B' = c B - s A
+// one row of a frame: R[k][0..2] and t[k]
+template <typename real>
+struct FrameRow { real r[3]; real t; };
+
+// columns A and B of the row rotate into each other: a' = c a + s b, b' = c b - s a
 template <typename real, int A, int B>
-__device__ __forceinline__ void rot_cols(real * R, real c, real s)
+__device__ __forceinline__ void rot_cols(real * r, real c, real s)
 {
-#pragma unroll
-   for (int r=0; r<3; r++)
-   {
-      const real ua = R[r*3+A], ub = R[r*3+B];
-      R[r*3+A] = c*ua + s*ub;
-      R[r*3+B] = c*ub - s*ua;
-   }
+   const real ua = r[A], ub = r[B];
+   r[A] = c*ua + s*ub;
+   r[B] = c*ub - s*ua;
 }
 
-// apply joint j to the frame `cur` (in place), emit axis/anchor and the spheres riding on it
+// apply joint J to row `cur` (in place); emit component k of the world axis / anchor and of the
+// centres of the spheres riding on the joint's link.  `store` is false on the idle lane.
 template <typename real>
-__device__ __forceinline__ void fk_joint(const ModelView<real> & mod, const DevJoint<real> & J, Frame<real> & cur,
-   real q, real sn, real cs, real * axo, real * pos_lane)
+__device__ __forceinline__ void fk_joint_row(const ModelView<real> & mod, const DevJoint<real> & J, FrameRow<real> & cur,
+   real q, real sn, real cs, bool store, real * axo_k, real * pos_k)
 {
    // joint frame in the world: cur o (Rfix, tfix)
-   real tj[3];
-#pragma unroll
-   for (int k=0; k<3; k++)
-      tj[k] = cur.R[k*3+0]*J.tfix[0] + cur.R[k*3+1]*J.tfix[1] + cur.R[k*3+2]*J.tfix[2] + cur.t[k];
+   const real tj = cur.r[0]*J.tfix[0] + cur.r[1]*J.tfix[1] + cur.r[2]*J.tfix[2] + cur.t;
    if (!J.rfix_identity)
    {
-      real Rj[9];
-      mat3_mul(cur.R, J.Rfix, Rj);
+      real rn[3];
 #pragma unroll
-      for (int k=0; k<9; k++) cur.R[k] = Rj[k];
+      for (int c=0; c<3; c++)
+         rn[c] = cur.r[0]*J.Rfix[0*3+c] + cur.r[1]*J.Rfix[1*3+c] + cur.r[2]*J.Rfix[2*3+c];
+#pragma unroll
+      for (int c=0; c<3; c++) cur.r[c] = rn[c];
    }
-#pragma unroll
-   for (int k=0; k<3; k++) cur.t[k] = tj[k];
-   real aw[3];
+   cur.t = tj;
    const int kind = J.axis_kind;          // 0 general, 1/2/3: +-x, +-y, +-z of the joint frame
-   if (kind == 3) { aw[0] = J.axis_sign*cur.R[2]; aw[1] = J.axis_sign*cur.R[5]; aw[2] = J.axis_sign*cur.R[8]; }
-   else if (kind == 2) { aw[0] = J.axis_sign*cur.R[1]; aw[1] = J.axis_sign*cur.R[4]; aw[2] = J.axis_sign*cur.R[7]; }
-   else if (kind == 1) { aw[0] = J.axis_sign*cur.R[0]; aw[1] = J.axis_sign*cur.R[3]; aw[2] = J.axis_sign*cur.R[6]; }
-   else
-   {
-#pragma unroll
-      for (int k=0; k<3; k++)
-         aw[k] = cur.R[k*3+0]*J.axis[0] + cur.R[k*3+1]*J.axis[1] + cur.R[k*3+2]*J.axis[2];
-   }
-   axo[0] = aw[0]; axo[1] = aw[1]; axo[2] = aw[2];
-   axo[3] = tj[0]; axo[4] = tj[1]; axo[5] = tj[2];
+   real aw;
+   if (kind == 3) aw = J.axis_sign*cur.r[2];
+   else if (kind == 2) aw = J.axis_sign*cur.r[1];
+   else if (kind == 1) aw = J.axis_sign*cur.r[0];
+   else aw = cur.r[0]*J.axis[0] + cur.r[1]*J.axis[1] + cur.r[2]*J.axis[2];
+   if (store) { axo_k[0] = aw; axo_k[3] = tj; }
    if (J.type == 1)
    {
       if (kind != 0)
       {
          // R <- R * Rot(axis_kind, q): two columns mix, the third is the axis itself
          const real s = J.axis_sign * sn;
-         if (kind == 3) rot_cols<real, 0, 1>(cur.R, cs, s);
-         else if (kind == 2) rot_cols<real, 2, 0>(cur.R, cs, s);
-         else rot_cols<real, 1, 2>(cur.R, cs, s);
+         if (kind == 3) rot_cols<real, 0, 1>(cur.r, cs, s);
+         else if (kind == 2) rot_cols<real, 2, 0>(cur.r, cs, s);
+         else rot_cols<real, 1, 2>(cur.r, cs, s);
       }
       else
       {
          const real v = (real)1 - cs;
          const real a0 = J.axis[0], a1 = J.axis[1], a2 = J.axis[2];
-         real Rm[9], Rn[9];
+         real Rm[9], rn[3];
          Rm[0] = cs + a0*a0*v;    Rm[1] = a0*a1*v - a2*sn; Rm[2] = a0*a2*v + a1*sn;
          Rm[3] = a1*a0*v + a2*sn; Rm[4] = cs + a1*a1*v;    Rm[5] = a1*a2*v - a0*sn;
          Rm[6] = a2*a0*v - a1*sn; Rm[7] = a2*a1*v + a0*sn; Rm[8] = cs + a2*a2*v;
-         mat3_mul(cur.R, Rm, Rn);
 #pragma unroll
-         for (int k=0; k<9; k++) cur.R[k] = Rn[k];
+         for (int c=0; c<3; c++) rn[c] = cur.r[0]*Rm[0*3+c] + cur.r[1]*Rm[1*3+c] + cur.r[2]*Rm[2*3+c];
+#pragma unroll
+         for (int c=0; c<3; c++) cur.r[c] = rn[c];
       }
    }
    else
-   {
-#pragma unroll
-      for (int k=0; k<3; k++) cur.t[k] = tj[k] + q*aw[k];
-   }
+      cur.t = tj + q*aw;
 #ifndef ORC_ABLATE_FKSPH
    for (int s=J.sph_begin; s<J.sph_end; s++)
    {
       const real * lp = mod.sph_pos[s];
-      real * o = pos_lane + s*3;
-#pragma unroll
-      for (int k=0; k<3; k++)
-         o[k] = cur.R[k*3+0]*lp[0] + cur.R[k*3+1]*lp[1] + cur.R[k*3+2]*lp[2] + cur.t[k];
+      const real o = cur.r[0]*lp[0] + cur.r[1]*lp[1] + cur.r[2]*lp[2] + cur.t;
+      if (store) pos_k[s*3] = o;
    }
 #endif
 }
 
-// FK of one waypoint (row = its trajectory row).  TREE = the joint tree branches (saved frames).
+// FK of one waypoint by the four lanes of a quad (k = lane & 3; row = its trajectory row).  Must be
+// executed by whole wavefronts (quad broadcasts); `valid` is false for lanes past the last
+// waypoint, which compute on a clamped row and store nothing.
+// TREE = the joint tree branches (saved frames).
 template <typename real, bool TREE>
-__device__ __forceinline__ void fk_waypoint(const ModelView<real> & mod, const real * row, int nj, int Sa,
-   real * pos_lane, real * ax_lane)
+__device__ __forceinline__ void fk_waypoint_quad(const ModelView<real> & mod, const real * row, int nj, int k, bool valid,
+   real * pos_wp, real * ax_wp)
 {
-   Frame<real> base, cur, sv0, sv1, sv2, sv3;
+   const bool store = valid && (k < 3);
+   const int kk = (k < 3) ? k : 0;
+   real * pos_k = pos_wp + kk;
+   FrameRow<real> base, cur, sv0, sv1, sv2, sv3;
    if (mod.floating)
    {
       // base pose from the trajectory row (src/orcdchomp_mod.cpp:1008-1016)
       const real qx = row[3], qy = row[4], qz = row[5], qw = row[6];
       const real xx = qx*qx, xy = qx*qy, xz = qx*qz, xw = qx*qw;
       const real yy = qy*qy, yz = qy*qz, yw = qy*qw, zz = qz*qz, zw = qz*qw;
-      base.R[0] = 1 - 2*(yy+zz); base.R[1] = 2*(xy-zw);     base.R[2] = 2*(xz+yw);
-      base.R[3] = 2*(xy+zw);     base.R[4] = 1 - 2*(xx+zz); base.R[5] = 2*(yz-xw);
-      base.R[6] = 2*(xz-yw);     base.R[7] = 2*(yz+xw);     base.R[8] = 1 - 2*(xx+yy);
-      base.t[0] = row[0]; base.t[1] = row[1]; base.t[2] = row[2];
+      if (kk == 0)      { base.r[0] = 1 - 2*(yy+zz); base.r[1] = 2*(xy-zw);     base.r[2] = 2*(xz+yw); }
+      else if (kk == 1) { base.r[0] = 2*(xy+zw);     base.r[1] = 1 - 2*(xx+zz); base.r[2] = 2*(yz-xw); }
+      else              { base.r[0] = 2*(xz-yw);     base.r[1] = 2*(yz+xw);     base.r[2] = 1 - 2*(xx+yy); }
+      base.t = row[kk];
       for (int s=mod.base_sph_begin; s<mod.base_sph_end; s++)
       {
          const real * lp = mod.sph_pos[s];
-         real * o = pos_lane + s*3;
-#pragma unroll
-         for (int k=0; k<3; k++)
-            o[k] = base.R[k*3+0]*lp[0] + base.R[k*3+1]*lp[1] + base.R[k*3+2]*lp[2] + base.t[k];
+         const real o = base.r[0]*lp[0] + base.r[1]*lp[1] + base.r[2]*lp[2] + base.t;
+         if (store) pos_k[s*3] = o;
       }
    }
    else
    {
 #pragma unroll
-      for (int k=0; k<9; k++) base.R[k] = mod.base_R[k];
-#pragma unroll
-      for (int k=0; k<3; k++) base.t[k] = mod.base_t[k];
+      for (int c=0; c<3; c++) base.r[c] = mod.base_R[kk*3+c];
+      base.t = mod.base_t[kk];
    }
    cur = base;
    if (TREE) { sv0 = base; sv1 = base; sv2 = base; sv3 = base; }
-   // joints in chunks of four: the four sin/cos evaluations are independent chains
+   // joints in chunks of four: lane k of the quad evaluates sin/cos of joint j0+k
    for (int j0=0; j0<nj; j0+=4)
    {
-      real qv[4], sn[4], cs[4];
-#pragma unroll
-      for (int jj=0; jj<4; jj++)
-      {
-         const int j = (j0 + jj < nj) ? j0 + jj : nj - 1;
-         qv[jj] = row[mod.joints[j].col];
-      }
+      const int jm = (j0 + k < nj) ? j0 + k : nj - 1;
+      const real qm = row[mod.joints[jm].col];
+      real snm, csm;
 #ifdef ORC_ABLATE_FKSIN
-#pragma unroll
-      for (int jj=0; jj<4; jj++) { sn[jj] = qv[jj]; cs[jj] = (real)1 - qv[jj]; }
+      snm = qm; csm = (real)1 - qm;
 #else
-#pragma unroll
-      for (int jj=0; jj<4; jj++) sincos_joint(qv[jj], &sn[jj], &cs[jj]);
+      sincos_joint(qm, &snm, &csm);
 #endif
+      real qv[4], sn[4], cs[4];
+      qv[0] = dpp_move<0x00>(qm); sn[0] = dpp_move<0x00>(snm); cs[0] = dpp_move<0x00>(csm);   // quad_perm [0,0,0,0]
+      qv[1] = dpp_move<0x55>(qm); sn[1] = dpp_move<0x55>(snm); cs[1] = dpp_move<0x55>(csm);   // quad_perm [1,1,1,1]
+      qv[2] = dpp_move<0xAA>(qm); sn[2] = dpp_move<0xAA>(snm); cs[2] = dpp_move<0xAA>(csm);   // quad_perm [2,2,2,2]
+      qv[3] = dpp_move<0xFF>(qm); sn[3] = dpp_move<0xFF>(snm); cs[3] = dpp_move<0xFF>(csm);   // quad_perm [3,3,3,3]
 #pragma unroll
       for (int jj=0; jj<4; jj++)
       {
@@ -192,7 +189,7 @@ __device__ __forceinline__ void fk_waypoint(const ModelView<real> & mod, const r
                else if (J.load_slot == 2) cur = sv2;
                else if (J.load_slot == 3) cur = sv3;
             }
-            fk_joint(mod, J, cur, qv[jj], sn[jj], cs[jj], ax_lane + j*6, pos_lane);
+            fk_joint_row(mod, J, cur, qv[jj], sn[jj], cs[jj], store, ax_wp + j*6 + kk, pos_k);
             if (TREE)
             {
                if (J.save_slot == 0) sv0 = cur;
