@@ -351,7 +351,7 @@ void Batch::build_device(const Robot & robot)
       M.sph_link[Sa+s] = sp.link;
       device_sphere_order.push_back(inact[s].xml);
    }
-   nj_ = nj; Sa_ = Sa; tree_ = M.tree;
+   nj_ = nj; Sa_ = Sa; tree_ = M.tree | ((M.GS == 16) ? 2 : 0);     // kernel variant bits
 
    hipStream_t st = stream_;
    DevModel<real> * dm = dev_alloc<DevModel<real>>(1);
@@ -410,35 +410,66 @@ void Batch::build_device(const Robot & robot)
    d_Aband_ = upload<real>(metric_.Aband, st);
    d_beta_s_ = upload<real>(metric_.beta_s, st);
    d_beta_g_ = upload<real>(metric_.beta_g, st);
-   if (!metric_.pcr.empty()) d_pcr_ = upload<real>(metric_.pcr, st);
+   pcr_rows_ = 0;
+   if (!metric_.pcr.empty())
+   {
+      if (metric_.pcr_sym && !getenv("ORC_PCR_FULL"))
+      {
+         // compact table: the rows towards i-s of every level, then the inverse diagonal
+         std::vector<double> compact;
+         for (int l=0; l<metric_.pcr_levels; l++)
+            compact.insert(compact.end(), metric_.pcr.begin() + (size_t)(2*l)*m, metric_.pcr.begin() + (size_t)(2*l+1)*m);
+         compact.insert(compact.end(), metric_.pcr.begin() + (size_t)(2*metric_.pcr_levels)*m, metric_.pcr.end());
+         d_pcr_ = upload<real>(compact, st);
+         pcr_rows_ = metric_.pcr_levels + 1; pcr_sym_ = 1;
+      }
+      else
+      {
+         d_pcr_ = upload<real>(metric_.pcr, st);
+         pcr_rows_ = 2*metric_.pcr_levels + 1; pcr_sym_ = 0;
+      }
+   }
    if (!metric_.Ainv.empty()) d_Ainv_ = upload<real>(metric_.Ainv, st);
    d_jl_lo_ = upload<real>(jl_lo_, st);
    d_jl_hi_ = upload<real>(jl_hi_, st);
 
-   // waypoints per tile: the largest tile that keeps two workgroups per CU,
-   // else the largest that fits one
-   const size_t budgets[2] = { 80*1024 - 512, 160*1024 - 1024 };
-   int cands[7] = { m, 126, 94, 62, 30, 14, 6 };
-   if (const char * e = getenv("ORC_TILE_M")) { const int t = atoi(e); if (t > 0) for (int k=0; k<7; k++) cands[k] = t; }   // experiments
+   // Tile size and LDS plan.  The kernel is latency bound, so resident workgroups per CU come first
+   // (as many as the kernel's register budget allows, ORC_WGS_PER_CU), then the fewest tiles per
+   // iteration (every tile costs one FK pass), then the cyclic-reduction tables in LDS.
+   const int pcr_rows = pcr_rows_;
+   const size_t lds_cu = 160*1024;
+   int force_t = 0, force_pcr = -1, max_wgs = ORC_WGS_PER_CU;
+   if (const char * e = getenv("ORC_TILE_M")) force_t = atoi(e);          // experiments
+   if (const char * e = getenv("ORC_PCR_LDS")) force_pcr = atoi(e);
+   if (const char * e = getenv("ORC_WGS")) max_wgs = atoi(e);
    tile_m_ = 0;
-   const int pcr_rows = metric_.pcr.empty() ? 0 : 2*metric_.pcr_levels + 1;
-   // the cyclic-reduction tables are staged in LDS when that does not cost a workgroup per CU
-   for (int with_pcr=1; with_pcr>=0 && !tile_m_; with_pcr--)
-      for (int bi=0; bi<2 && !tile_m_; bi++)
-         for (int ci=0; ci<7 && !tile_m_; ci++)
-         {
-            const int t = cands[ci];
-            if (t > m || t > ORC_BLOCK - 2 || t < 1) continue;
-            if (with_pcr && (!pcr_rows || bi > 0 || (ci > 3 && !getenv("ORC_TILE_M")))) continue;
-            const size_t need = orc_chomp_lds_bytes(n_points, n, Sa, S, nj, t, with_pcr ? pcr_rows : 0, sizeof(real), params.use_momentum, n_sdfs_);
-            if (need <= budgets[bi]) { tile_m_ = t; lds_bytes_ = need; pcr_in_lds_ = with_pcr; }
-         }
-   if (!tile_m_)
+   for (int wgs=max_wgs; wgs>=1 && !tile_m_; wgs--)
    {
-      tile_m_ = 1; pcr_in_lds_ = 0;
-      lds_bytes_ = orc_chomp_lds_bytes(n_points, n, Sa, S, nj, 1, 0, sizeof(real), params.use_momentum, n_sdfs_);
-      if (lds_bytes_ > budgets[1]) throw std::runtime_error("run does not fit the LDS of one CU!");
+      const size_t budget = ((lds_cu / wgs) & ~(size_t) 511) - (wgs == 1 ? 1024 : 0);
+      int best_t = 0, best_pcr = 0, best_tiles = 1 << 30;
+      for (int with_pcr=1; with_pcr>=0; with_pcr--)
+      {
+         if (with_pcr && !pcr_rows) continue;
+         if (force_pcr >= 0 && with_pcr != force_pcr && pcr_rows) continue;
+         for (int t=(m < ORC_BLOCK - 2 ? m : ORC_BLOCK - 2); t>=1; t--)
+         {
+            if (force_t > 0 && t != force_t) continue;
+            const size_t need = orc_chomp_lds_bytes(n_points, n, Sa, S, nj, t, with_pcr ? pcr_rows : 0, sizeof(real), params.use_momentum, n_sdfs_);
+            if (need > budget) continue;
+            const int tiles = (m + t - 1) / t;
+            if (tiles < best_tiles) { best_tiles = tiles; best_t = t; best_pcr = with_pcr; }
+            break;                                   // largest tile of this plan
+         }
+      }
+      if (best_t)
+      {
+         tile_m_ = best_t; pcr_in_lds_ = best_pcr;
+         lds_bytes_ = orc_chomp_lds_bytes(n_points, n, Sa, S, nj, best_t, best_pcr ? pcr_rows : 0, sizeof(real), params.use_momentum, n_sdfs_);
+      }
    }
+   if (!tile_m_) throw std::runtime_error("run does not fit the LDS of one CU!");
+   if (getenv("ORC_DEBUG_PLAN"))
+      fprintf(stderr, "orc plan: tile_m %d (%d tiles) lds %zu bytes pcr_in_lds %d pcr_sym %d\n", tile_m_, (m + tile_m_ - 1) / tile_m_, lds_bytes_, pcr_in_lds_, pcr_sym_);
 }
 
 // which iterations of this call resample the momentum, and with what noise
@@ -530,7 +561,7 @@ void Batch::launch(int n_iter)
    b.hmc_iters = d_hmc_iters_; b.noise = (const real *) d_noise_; b.max_resamples = max_resamples_;
    b.n_iter = n_iter; b.final_eval = 1;
    b.phase_cycles = d_phase_;
-   b.pcr_in_lds = pcr_in_lds_;
+   b.pcr_in_lds = pcr_in_lds_; b.pcr_sym = pcr_sym_; b.pcr_rows = pcr_rows_;
    b.stagger_mode = getenv("ORC_STAGGER_MODE") ? atoi(getenv("ORC_STAGGER_MODE")) : 0;
    b.stagger_sleeps = getenv("ORC_STAGGER_SLEEPS") ? atoi(getenv("ORC_STAGGER_SLEEPS")) : 10;
    if (params.derivative == 1 && m >= 2)

@@ -177,13 +177,20 @@ __device__ __forceinline__ real dpp_row_max(real v)
    o = dpp_move<0x140>(v); v = o > v ? o : v;
    return v;
 }
+__device__ __forceinline__ double read_lane(double v, int ln)
+{
+   const int lo = __builtin_amdgcn_readlane(__double2loint(v), ln), hi = __builtin_amdgcn_readlane(__double2hiint(v), ln);
+   return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float read_lane(float v, int ln) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), ln)); }
 template <typename real>
 __device__ __forceinline__ void wave_argmax(real & best, int & best_e)
 {
    real m = dpp_row_max(best);
    // the four row maxima (lanes 0, 16, 32, 48 hold them after the row reduction)
-   real m1 = __shfl(m, 16, 64), m2 = __shfl(m, 32, 64), m3 = __shfl(m, 48, 64), m0 = __shfl(m, 0, 64);
-   real mm = m0 > m1 ? m0 : m1; mm = m2 > mm ? m2 : mm; mm = m3 > mm ? m3 : mm;
+   const real m0 = read_lane(m, 0), m1 = read_lane(m, 16), m2 = read_lane(m, 32), m3 = read_lane(m, 48);
+   const real ma = m0 > m1 ? m0 : m1, mb = m2 > m3 ? m2 : m3;
+   const real mm = ma > mb ? ma : mb;
    if (!(mm > (real)0)) { best = 0; best_e = 0x7fffffff; return; }      // nothing to find (wave-uniform)
    unsigned long long cand = __ballot(best == mm);
    int win = 0x7fffffff;
@@ -191,7 +198,7 @@ __device__ __forceinline__ void wave_argmax(real & best, int & best_e)
    {
       const int ln = __builtin_ctzll(cand);
       cand &= cand - 1;
-      const int e = __shfl(best_e, ln, 64);
+      const int e = __builtin_amdgcn_readlane(best_e, ln);
       win = e < win ? e : win;
    }
    best = mm; best_e = win;
@@ -233,6 +240,172 @@ __device__ __forceinline__ double block_sum(double v, double * red)
    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
    __syncthreads();
    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// ---------------------------------------------------------------------------
+// Joint-limit projection rounds (src/libcd/chomp.c:608-655) for the tridiagonal Toeplitz metric
+// (D == 1).  Thread (r, c) = (tid / n, tid % n) owns rows r, r+R, r+2R, ... (R = ORC_BLOCK / n) of
+// column c and keeps them in registers for all rounds.  A round is: violations + wave arg-max +
+// per-wave counts -> one record per wave in LDS -> barrier -> global arg-max, offsets -> violated
+// entries compacted into a list (rows of a column in increasing order, the order the reference's
+// product A^-1 Gjlimit sums them in) -> barrier -> GA = A^-1 Gjlimit from the closed form
+//    Ainv[i][k] = (min(i,k)+1) (m - max(i,k)) / ((m+1) ca),   A = ca tridiag(-1,2,-1),
+// as a short sum over the list, T += 1.01 Gjlimit[l]/GA[l] * GA.
+// Returns true when the loop is finished (no violation left, or 1000 rounds: the caller sets the
+// status), false when a round has more than ORC_LIM_LIST violated entries (the caller continues
+// with the general path).  T_s is up to date and the workgroup is synchronised on return.
+// Requires m <= KMAX * (ORC_BLOCK / n).
+template <typename real, int KMAX>
+__device__ __forceinline__ bool limit_rounds_sparse(const DevBatch<real> & b, real * T_s, const real * jl_s, unsigned char * scratch,
+   int m, int n, int & num_limadjs, long long * dbg_total)
+{
+   struct WaveRec { double best; int best_e; unsigned cnt4; };      // 16 bytes; cnt4: one byte per slice k
+   struct Head { double gl; int gi, gc; };
+   WaveRec * rec = (WaveRec *) scratch;                      // [4]
+   Head * head = (Head *)(scratch + 128);
+   int2 * lst = (int2 *)(scratch + 256);                     // [ORC_LIM_LIST] (row, column)
+   real * lval = (real *)(scratch + 256 + ORC_LIM_LIST*8);   // [ORC_LIM_LIST] Gjlimit value
+   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+   const int R = ORC_BLOCK / n;
+   const int r = (int)(((float) tid + 0.5f) * (1.0f / (float) n));     // tid / n
+   const int c = tid - r*n;
+   const bool owner = (r < R);
+   const int K = (m + R - 1) / R;
+   const real inf = M<real>::inf();
+   const real lo = owner ? jl_s[c] : -inf, hi = owner ? jl_s[n+c] : inf;
+   real t[KMAX];
+#pragma unroll
+   for (int k=0; k<KMAX; k++)
+   {
+      const int i = r + k*R;
+      t[k] = (owner && i < m) ? T_s[n + i*n + c] : (real)0;      // inside the limits of every joint? no: masked below
+   }
+   const real kinv = (real)(-1) / ((real)(m + 1) * b.a_off);     // 1/((m+1) ca), ca = -a_off
+   bool finished = true;
+   for (; num_limadjs<1000; num_limadjs++)
+   {
+      real gj[KMAX]; unsigned long long vm[KMAX];
+      real best = 0; int best_e = 0x7fffffff;
+#pragma unroll
+      for (int k=0; k<KMAX; k++)
+      {
+         real g = 0;
+         const int i = r + k*R;
+         if (k < K)
+         {
+            if (t[k] < lo) g = lo - t[k];
+            if (t[k] > hi) g = hi - t[k];
+            if (!(owner && i < m)) g = 0;
+            const real a = M<real>::fabs_(g);
+            const int e = i*n + c;
+            // largest violation, ties to the smallest row-major index (the reference's scan order)
+            if (a > best || (a == best && a > (real)0 && e < best_e)) { best = a; best_e = e; }
+         }
+         gj[k] = g;
+         vm[k] = __ballot(g != (real)0);
+      }
+      wave_argmax(best, best_e);
+      if (lane == 0)
+      {
+         unsigned c4 = 0;
+#pragma unroll
+         for (int k=0; k<KMAX; k++) c4 |= ((unsigned) __popcll(vm[k])) << (8*k);      // counts <= 64
+         WaveRec w; w.best = (double) best; w.best_e = best_e; w.cnt4 = c4;
+         rec[wave] = w;
+      }
+      __syncthreads();
+      WaveRec rr[4];
+#pragma unroll
+      for (int w=0; w<4; w++) rr[w] = rec[w];
+      double gb = rr[0].best; int ge = rr[0].best_e;
+#pragma unroll
+      for (int w=1; w<4; w++)
+      {
+         const double rb = rr[w].best; const int re = rr[w].best_e;
+         if (rb > gb || (rb == gb && re < ge)) { gb = rb; ge = re; }
+      }
+      if (gb == 0.0) break;                  // nothing violated anywhere in the workgroup
+      // offsets of this wave's entries in the list: slices in order, waves in order
+      int total = 0, base[KMAX];
+#pragma unroll
+      for (int k=0; k<KMAX; k++)
+      {
+         base[k] = 0;
+#pragma unroll
+         for (int w=0; w<4; w++)
+         {
+            if (w == wave) base[k] = total;
+            total += (int)((rr[w].cnt4 >> (8*k)) & 0xffu);
+         }
+      }
+      if (total > ORC_LIM_LIST) { finished = false; break; }
+      if (dbg_total) *dbg_total += total;
+#pragma unroll
+      for (int k=0; k<KMAX; k++)
+      {
+         const int i = r + k*R;
+         if (gj[k] != (real)0)
+         {
+            const int off = base[k] + __popcll(vm[k] & ((1ull << lane) - 1ull));
+            lst[off] = make_int2(i, c);
+            lval[off] = gj[k];
+            if (i*n + c == ge) { Head h; h.gl = (double) gj[k]; h.gi = i; h.gc = c; *head = h; }
+         }
+      }
+      __syncthreads();
+      const Head hd = *head;
+      const real gl = (real) hd.gl;             // Gjlimit[largest]
+      const int gi = hd.gi, gc = hd.gc;
+      real ga[KMAX], ga_l = 0;
+#pragma unroll
+      for (int k=0; k<KMAX; k++) ga[k] = 0;
+      // one entry of the list: its term of GA at the arg-max entry and at this thread's rows
+#define ORC_LIM_TERM(IV, VAL) do { \
+         if ((IV).y == gc) \
+         { \
+            const int l0 = (IV).x < gi ? (IV).x : gi, h0 = (IV).x < gi ? gi : (IV).x; \
+            ga_l += (VAL) * (real)((l0 + 1) * (m - h0)); \
+         } \
+         const bool mine = ((IV).y == c); \
+         _Pragma("unroll") \
+         for (int k=0; k<KMAX; k++) \
+            if (k < K) \
+            { \
+               const int i = r + k*R; \
+               const int l0 = (IV).x < i ? (IV).x : i, h0 = (IV).x < i ? i : (IV).x; \
+               const real term = (VAL) * (real)((l0 + 1) * (m - h0)); \
+               ga[k] += mine ? term : (real)0; \
+            } \
+      } while (0)
+      // the first four entries are fetched together (one LDS round trip), the rest one by one
+      int2 pre_i[4]; real pre_v[4];
+#pragma unroll
+      for (int v=0; v<4; v++) { pre_i[v] = lst[v]; pre_v[v] = lval[v]; }
+#pragma unroll
+      for (int v=0; v<4; v++)
+      {
+         const int2 iv = make_int2(pre_i[v].x, (v < total) ? pre_i[v].y : -2);     // -2 matches no column
+         ORC_LIM_TERM(iv, pre_v[v]);
+      }
+      for (int v=4; v<total; v++)
+      {
+         const int2 iv = lst[v];
+         const real val = lval[v];
+         ORC_LIM_TERM(iv, val);
+      }
+#undef ORC_LIM_TERM
+      const real sc = ((real)1.01 * gl) * rcp_fast(ga_l * kinv);
+#pragma unroll
+      for (int k=0; k<KMAX; k++) t[k] += sc * (ga[k] * kinv);
+   }
+#pragma unroll
+   for (int k=0; k<KMAX; k++)
+   {
+      const int i = r + k*R;
+      if (owner && i < m) T_s[n + i*n + c] = t[k];
+   }
+   __syncthreads();
+   return finished;
 }
 
 // ---------------------------------------------------------------------------
@@ -289,6 +462,10 @@ __device__ __forceinline__ int sdf_lookup(const DevSdf<real> & f, const real p[3
    return 0;
 }
 
+// e / n for 0 <= e < 2^20 without the ~35-instruction integer division: (e + 0.5)/n is at least
+// 0.5/n away from an integer, far more than the rounding of the float product.  rn = 1.0f / n.
+__device__ __forceinline__ int div_n(int e, float rn) { return (int)(((float) e + 0.5f) * rn); }
+
 // ---------------------------------------------------------------------------
 // parallel cyclic reduction with precomputed multipliers: x = A^-1 d for all n
 // columns at once.  src holds d [m][n]; the result ends up in the returned
@@ -298,28 +475,29 @@ template <typename real>
 __device__ __forceinline__ real * pcr_solve(const DevBatch<real> & b, const real * tab, real * src, real * tmp)
 {
    const int m = b.m, n = b.n, mn = m*n;
+   const float rn = 1.0f / (float) n;
    real * cur = src;
    real * nxt = tmp;
    int stride = 1;
    for (int l=0; l<b.pcr_levels; l++)
    {
-      const real * ka = tab + (size_t)(2*l) * m;
+      const real * ka = tab + (size_t)(b.pcr_sym ? l : 2*l) * m;
       const real * kc = ka + m;
       for (int e=threadIdx.x; e<mn; e+=ORC_BLOCK)
       {
-         const int i = e / n;
+         const int i = div_n(e, rn);
          real d = cur[e];
          if (i - stride >= 0) d += ka[i] * cur[e - stride*n];
-         if (i + stride < m)  d += kc[i] * cur[e + stride*n];
+         if (i + stride < m)  d += (b.pcr_sym ? ka[m-1-i] : kc[i]) * cur[e + stride*n];
          nxt[e] = d;
       }
       __syncthreads();
       real * t = cur; cur = nxt; nxt = t;
       stride <<= 1;
    }
-   const real * invb = tab + (size_t)(2*b.pcr_levels) * m;
+   const real * invb = tab + (size_t)(b.pcr_rows - 1) * m;
    for (int e=threadIdx.x; e<mn; e+=ORC_BLOCK)
-      cur[e] *= invb[e / n];
+      cur[e] *= invb[div_n(e, rn)];
    __syncthreads();
    return cur;
 }
@@ -372,8 +550,8 @@ __device__ __forceinline__ real smooth_grad(const DevBatch<real> & b, const real
 #endif
 
 // ---------------------------------------------------------------------------
-template <typename real, bool TREE>
-__global__ __launch_bounds__(ORC_BLOCK, 2)
+template <typename real, bool TREE, bool GS16>
+__global__ __launch_bounds__(ORC_BLOCK, ORC_WGS_PER_CU)
 void chomp_iterate_kernel(const DevBatch<real> b)
 {
    extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -384,9 +562,10 @@ void chomp_iterate_kernel(const DevBatch<real> b)
    const int nj = gmod.nj, Sa = gmod.Sa, S = gmod.S, GS = gmod.GS;
    const int tile_m = b.tile_m;
    const real inf = M<real>::inf();
+   const float rn_f = 1.0f / (float) n;        // for div_n
 
    // ---- LDS carve-up ------------------------------------------------------
-   const LdsLayout L = lds_layout(np, n, Sa, S, nj, tile_m, b.pcr_in_lds ? 2*b.pcr_levels+1 : 0, (int) sizeof(real),
+   const LdsLayout L = lds_layout(np, n, Sa, S, nj, tile_m, b.pcr_in_lds ? b.pcr_rows : 0, (int) sizeof(real),
                                   b.use_momentum, b.n_sdfs, (int) sizeof(DevJoint<real>), (int) sizeof(DevSdf<real>));
    double * red = (double *) smem_raw;                  // [8] reduction scratch
    int * redi = (int *)(red + 8);                       // [8]
@@ -405,7 +584,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
    int * slink_s = (int *)(smem_raw + L.ints_bytes);    // [S] link of each sphere
    int * jtype_s = slink_s + S;                         // [nj]
    int * jcol_s = jtype_s + nj;                         // [nj]
-   real * sphpos_s = pcr_s + (((b.pcr_in_lds ? 2*b.pcr_levels+1 : 0)*m + 3) & ~3);   // [Sa][3] + base frame [12]
+   real * sphpos_s = pcr_s + (((b.pcr_in_lds ? b.pcr_rows : 0)*m + 3) & ~3);   // [Sa][3] + base frame [12]
    real * base_s = sphpos_s + Sa*3;
    DevJoint<real> * joints_s = (DevJoint<real> *)(smem_raw + L.joints_bytes);
    DevSdf<real> * sdfs_s = (DevSdf<real> *)(smem_raw + L.sdfs_bytes);
@@ -436,7 +615,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
    }
    for (int e=tid; e<n; e+=ORC_BLOCK) { jl_s[e] = b.jl_lo[e]; jl_s[n+e] = b.jl_hi[e]; }
    if (b.pcr_in_lds)
-      for (int e=tid; e<(2*b.pcr_levels+1)*m; e+=ORC_BLOCK) pcr_s[e] = b.pcr[e];
+      for (int e=tid; e<b.pcr_rows*m; e+=ORC_BLOCK) pcr_s[e] = b.pcr[e];
    const real * pcr_tab = b.pcr_in_lds ? pcr_s : b.pcr;
    const real inv_eps = (real)1 / b.epsilon, inv_eps_self = (real)1 / b.epsilon_self;
    if (b.use_momentum) for (int e=tid; e<mn; e+=ORC_BLOCK) AG_s[e] = AG_g[e];
@@ -497,10 +676,9 @@ void chomp_iterate_kernel(const DevBatch<real> b)
          ORC_MARK(0);
 
          // ================= cost phase: lane = (waypoint, sphere) =============
-         if (GS == 16)
+         if constexpr (GS16)
             cost_tile_gs16<real, ORC_U>(b, mod, sdfs, ts, te, do_iteration, T_s, G_s, pos_s, ax_s, srad_s, sinact_s,
                                         slink_s, jtype_s, jcol_s, inv_eps, inv_eps_self, cost_lane);
-#ifndef ORC_NO_GENERIC
          else
          {
          const int items = (te - ts) * GS;
@@ -746,7 +924,6 @@ void chomp_iterate_kernel(const DevBatch<real> b)
             }
          }
          }
-#endif
          __syncthreads();
          ORC_MARK(1);
       } // tiles
@@ -761,7 +938,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
          // G = G/m + A T + B   (chomp.c:492, 515-522)
          for (int e=tid; e<mn; e+=ORC_BLOCK)
          {
-            const int i = e / n, c = e - i*n;
+            const int i = div_n(e, rn_f), c = e - i*n;
             real g = G_s[e];
             g *= b.inv_m;
             g += smooth_grad(b, T_s, i, c);
@@ -800,13 +977,17 @@ void chomp_iterate_kernel(const DevBatch<real> b)
 
          ORC_MARK(3);
          // joint-limit projection (chomp.c:608-655)
-         int num_limadjs;
-         for (num_limadjs=0; num_limadjs<1000; num_limadjs++)
+         int num_limadjs = 0;
+         bool lim_done = false;
+         if (b.D == 1 && b.solve_mode == 0 && n <= 64 && m <= 4*(ORC_BLOCK / n))
+            lim_done = limit_rounds_sparse<real, 4>(b, T_s, jl_s, smem_raw + L.lim_bytes, m, n, num_limadjs, (b.phase_cycles && tid == 0) ? &ph[7] : nullptr);
+         if (!lim_done)
+         for (; num_limadjs<1000; num_limadjs++)
          {
             real best = 0; int best_e = 0x7fffffff;
             for (int e=tid; e<mn; e+=ORC_BLOCK)
             {
-               const int i = e / n, c = e - i*n;
+               const int i = div_n(e, rn_f), c = e - i*n;
                const real t = T_s[n + e];
                real gj = 0;
                if (t < jl_s[c]) gj = jl_s[c] - t;
@@ -825,7 +1006,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
             for (int w=1; w<4; w++)
                if (red[w] > gb || (red[w] == gb && redi[w] < ge)) { gb = red[w]; ge = redi[w]; }
             if (gb == 0.0) break;                  // nothing violated anywhere in the workgroup
-            const int gi = ge / n, gc = ge - gi*n;
+            const int gi = div_n(ge, rn_f), gc = ge - gi*n;
             const real gl = G_s[ge];               // Gjlimit[largest]
 
             // GA = A^-1 Gjlimit.  Gjlimit is sparse (a few violated entries): for the tridiagonal
@@ -864,7 +1045,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
                            int off = 0;
                            for (int q=0; q<k*4 + wave; q++) off += cnt[q];
                            off += __popcll(mask & ((1ull << lane) - 1ull));
-                           const int i = e / n;
+                           const int i = div_n(e, rn_f);
                            lst[2*off] = i; lst[2*off+1] = e - i*n;
                            lval[off] = G_s[e];
                         }
@@ -885,7 +1066,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
                      const real sc = (real)1.01 * gl / (ga_l * kinv);
                      for (int e=tid; e<mn; e+=ORC_BLOCK)
                      {
-                        const int i = e / n, c = e - i*n;
+                        const int i = div_n(e, rn_f), c = e - i*n;
                         real ga = 0;
                         for (int v=0; v<total; v++)
                         {
@@ -915,6 +1096,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
          }
          if (!(num_limadjs < 1000)) status = -1;
          ORC_MARK(4);
+         if (b.phase_cycles && tid == 0) { ph[6] += num_limadjs; }   // rounds (ph[7]: violated entries summed over the sparse rounds)
 
       }
 
@@ -926,7 +1108,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
          double acc = 0.0;
          for (int e=tid; e<mn; e+=ORC_BLOCK)
          {
-            const int i = e / n, c = e - i*n;
+            const int i = div_n(e, rn_f), c = e - i*n;
             const real sg = smooth_grad(b, T_s, i, c);           // (A T + B)
             const real bt = (b.D == 1) ? b.a_off * ((i == 0 ? T_s[c] : (real)0) + (i == m-1 ? T_s[(np-1)*n + c] : (real)0))
                                        : b.beta_s[i] * T_s[c] + b.beta_g[i] * T_s[(np-1)*n + c];
@@ -1019,31 +1201,38 @@ size_t orc_chomp_lds_bytes(int n_points, int n, int Sa, int S, int nj, int tile_
    return (size_t) lds_layout(n_points, n, Sa, S, nj, tile_m, pcr_rows, (int) real_size, use_momentum, n_sdfs, js, ss).total_bytes;
 }
 
-template <typename real, bool TREE>
+template <typename real, bool TREE, bool GS16>
 static hipError_t launch_iterate_tt(const DevBatch<real> & b, size_t lds, hipStream_t stream)
 {
    static bool attr_set = false;
    if (!attr_set)
    {
-      hipError_t e = hipFuncSetAttribute((const void *) chomp_iterate_kernel<real, TREE>,
+      hipError_t e = hipFuncSetAttribute((const void *) chomp_iterate_kernel<real, TREE, GS16>,
          hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256);
       if (e != hipSuccess) return e;
       attr_set = true;
    }
-   hipLaunchKernelGGL((chomp_iterate_kernel<real, TREE>), dim3(b.n_runs), dim3(ORC_BLOCK), lds, stream, b);
+   hipLaunchKernelGGL((chomp_iterate_kernel<real, TREE, GS16>), dim3(b.n_runs), dim3(ORC_BLOCK), lds, stream, b);
    return hipGetLastError();
 }
 
+// variant: bit 0 the joint tree branches, bit 1 the robot has <= 16 active spheres (DPP-row cost phase)
 template <typename real>
-static hipError_t launch_iterate_t(const DevBatch<real> & b, size_t lds, hipStream_t stream, int tree)
+static hipError_t launch_iterate_t(const DevBatch<real> & b, size_t lds, hipStream_t stream, int variant)
 {
-   return tree ? launch_iterate_tt<real, true>(b, lds, stream) : launch_iterate_tt<real, false>(b, lds, stream);
+   switch (variant & 3)
+   {
+   case 0: return launch_iterate_tt<real, false, false>(b, lds, stream);
+   case 1: return launch_iterate_tt<real, true, false>(b, lds, stream);
+   case 2: return launch_iterate_tt<real, false, true>(b, lds, stream);
+   default: return launch_iterate_tt<real, true, true>(b, lds, stream);
+   }
 }
 
-hipError_t orc_launch_iterate_f64(const DevBatch<double> & b, size_t lds, hipStream_t stream, int tree)
-{ return launch_iterate_t<double>(b, lds, stream, tree); }
-hipError_t orc_launch_iterate_f32(const DevBatch<float> & b, size_t lds, hipStream_t stream, int tree)
-{ return launch_iterate_t<float>(b, lds, stream, tree); }
+hipError_t orc_launch_iterate_f64(const DevBatch<double> & b, size_t lds, hipStream_t stream, int variant)
+{ return launch_iterate_t<double>(b, lds, stream, variant); }
+hipError_t orc_launch_iterate_f32(const DevBatch<float> & b, size_t lds, hipStream_t stream, int variant)
+{ return launch_iterate_t<float>(b, lds, stream, variant); }
 
 hipError_t orc_launch_seed_f64(double * traj, const double * starts, const double * goals,
    int n_runs, int n_points, int n, int floating, hipStream_t stream)

@@ -271,20 +271,34 @@ __device__ __forceinline__ void self_sym_steps16(const int flags[U], const real 
    real radius, int mylink, const real vel[U][3], const real inv_vn2[U], const real wself[U],
    real eps_self, real inv_eps_self, bool do_iteration, real f[U][3], double cost_sphere[U])
 {
-   constexpr int NC = 2*U;
+   // K2 == 0: a single rotation (fewer live registers; used when more wavefronts per SIMD hide the
+   // latency that the second lockstep chain hides otherwise)
+   constexpr int NR = (K2 == 0) ? 1 : 2;
+   constexpr int NC = NR*U;
    constexpr int F1 = 0x120 + K1, B1 = 0x120 + (16 - K1);
-   constexpr int F2 = 0x120 + K2, B2 = 0x120 + (16 - K2);
-   real d[NC][3], vo[NC][3], d2[NC], rsum[NC], wo[NC], ivo[NC], R2[2];
-   bool near[NC], mo[NC], other[2];
+   constexpr int F2 = 0x120 + (K2 == 0 ? 1 : K2), B2 = 0x120 + (16 - (K2 == 0 ? 1 : K2));
+   real d[NC][3], vo[NC][3], d2[NC], rsum[NC], wo[NC], ivo[NC], R2[NR];
+   bool near[NC], mo[NC], other[NR];
    {
-      const real ro1 = dpp_move<F1>(radius), ro2 = dpp_move<F2>(radius);
-      const int lo1 = dpp_move<F1>(mylink), lo2 = dpp_move<F2>(mylink);
-      other[0] = (lo1 != mylink); other[1] = (lo2 != mylink);
-      const real s1 = radius + ro1, s2 = radius + ro2;
-      const real Ra = s1 + eps_self, Rb = s2 + eps_self;
-      R2[0] = Ra * Ra; R2[1] = Rb * Rb;
+      const real ro1 = dpp_move<F1>(radius);
+      const int lo1 = dpp_move<F1>(mylink);
+      other[0] = (lo1 != mylink);
+      const real s1 = radius + ro1;
+      const real Ra = s1 + eps_self;
+      R2[0] = Ra * Ra;
 #pragma unroll
-      for (int u=0; u<U; u++) { rsum[u] = s1; rsum[U+u] = s2; }
+      for (int u=0; u<U; u++) rsum[u] = s1;
+      if constexpr (NR == 2)
+      {
+         const real ro2 = dpp_move<F2>(radius);
+         const int lo2 = dpp_move<F2>(mylink);
+         other[1] = (lo2 != mylink);
+         const real s2 = radius + ro2;
+         const real Rb = s2 + eps_self;
+         R2[1] = Rb * Rb;
+#pragma unroll
+         for (int u=0; u<U; u++) rsum[U+u] = s2;
+      }
    }
    bool any = false;
 #pragma unroll
@@ -294,19 +308,30 @@ __device__ __forceinline__ void self_sym_steps16(const int flags[U], const real 
       for (int k=0; k<3; k++)
       {
          d[u][k] = p[u][k] - dpp_move<F1>(p[u][k]);
-         d[U+u][k] = p[u][k] - dpp_move<F2>(p[u][k]);
          vo[u][k] = dpp_move<F1>(vel[u][k]);
-         vo[U+u][k] = dpp_move<F2>(vel[u][k]);
+         if constexpr (NR == 2)
+         {
+            d[U+u][k] = p[u][k] - dpp_move<F2>(p[u][k]);
+            vo[U+u][k] = dpp_move<F2>(vel[u][k]);
+         }
       }
-      wo[u] = dpp_move<F1>(wself[u]);    wo[U+u] = dpp_move<F2>(wself[u]);
-      ivo[u] = dpp_move<F1>(inv_vn2[u]); ivo[U+u] = dpp_move<F2>(inv_vn2[u]);
-      const int a1 = dpp_move<F1>(flags[u]), a2 = dpp_move<F2>(flags[u]);
-      mo[u] = (a1 & 2) != 0; mo[U+u] = (a2 & 2) != 0;
+      wo[u] = dpp_move<F1>(wself[u]);
+      ivo[u] = dpp_move<F1>(inv_vn2[u]);
+      const int a1 = dpp_move<F1>(flags[u]);
+      mo[u] = (a1 & 2) != 0;
       d2[u] = d[u][0]*d[u][0] + d[u][1]*d[u][1] + d[u][2]*d[u][2];
-      d2[U+u] = d[U+u][0]*d[U+u][0] + d[U+u][1]*d[U+u][1] + d[U+u][2]*d[U+u][2];
       near[u] = (flags[u] & 1) && (a1 & 1) && other[0] && !(d2[u] > R2[0]);
-      near[U+u] = (flags[u] & 1) && (a2 & 1) && other[1] && !(d2[U+u] > R2[1]);
-      any = any || near[u] || near[U+u];
+      any = any || near[u];
+      if constexpr (NR == 2)
+      {
+         wo[U+u] = dpp_move<F2>(wself[u]);
+         ivo[U+u] = dpp_move<F2>(inv_vn2[u]);
+         const int a2 = dpp_move<F2>(flags[u]);
+         mo[U+u] = (a2 & 2) != 0;
+         d2[U+u] = d[U+u][0]*d[U+u][0] + d[U+u][1]*d[U+u][1] + d[U+u][2]*d[U+u][2];
+         near[U+u] = (flags[u] & 1) && (a2 & 1) && other[1] && !(d2[U+u] > R2[1]);
+         any = any || near[U+u];
+      }
    }
    real inc[NC][3]; double cadd[NC];
 #pragma unroll
@@ -337,8 +362,9 @@ __device__ __forceinline__ void self_sym_steps16(const int flags[U], const real 
 #pragma unroll
       for (int c=0; c<NC; c++)
       {
-         const bool second_is_8 = (K2 == 8) && (c >= U);     // rotation 8: the partner computes its own side
-         const real wsum = second_is_8 ? wself[c % U] : wself[c % U] + wo[c];
+         // rotation 8: the partner computes its own side
+         const bool is_8 = (c < U) ? (K1 == 8) : (K2 == 8);
+         const real wsum = is_8 ? wself[c % U] : wself[c % U] + wo[c];
          cadd[c] = near[c] ? (double)(wsum * cself[c]) : 0.0;
       }
 #pragma unroll
@@ -370,7 +396,11 @@ __device__ __forceinline__ void self_sym_steps16(const int flags[U], const real 
          }
    }
 #pragma unroll
-   for (int u=0; u<U; u++) cost_sphere[u] += cadd[u] + cadd[U+u];
+   for (int u=0; u<U; u++)
+   {
+      cost_sphere[u] += cadd[u];
+      if constexpr (NR == 2) cost_sphere[u] += cadd[U+u];
+   }
    if (do_iteration)
    {
 #pragma unroll
@@ -378,8 +408,9 @@ __device__ __forceinline__ void self_sym_steps16(const int flags[U], const real 
 #pragma unroll
          for (int k=0; k<3; k++)
          {
-            real v = inc[u][k] - dpp_move<B1>(inc[u][k]);
-            v += (K2 == 8) ? inc[U+u][k] : (inc[U+u][k] - dpp_move<B2>(inc[U+u][k]));
+            real v = (K1 == 8) ? inc[u][k] : (inc[u][k] - dpp_move<B1>(inc[u][k]));
+            if constexpr (NR == 2)
+               v += (K2 == 8) ? inc[U+u][k] : (inc[U+u][k] - dpp_move<B2>(inc[U+u][k]));
             f[u][k] += v;
          }
    }
@@ -543,7 +574,12 @@ __device__ __forceinline__ void cost_tile_gs16(const DevBatch<real> & b, const M
          for (int u=0; u<U; u++) flags[u] = (live[u] ? 1 : 0) | (moving[u] ? 2 : 0);
 #define ORC_STEPS(K1, K2) self_sym_steps16<real, U, K1, K2>(flags, p, radius, mylink, vel, inv_vn2, wself, \
                              b.epsilon_self, inv_eps_self, do_iteration, f, cost_sphere)
+#if ORC_WGS_PER_CU >= 3
+         ORC_STEPS(1, 0); ORC_STEPS(2, 0); ORC_STEPS(3, 0); ORC_STEPS(4, 0);
+         ORC_STEPS(5, 0); ORC_STEPS(6, 0); ORC_STEPS(7, 0); ORC_STEPS(8, 0);
+#else
          ORC_STEPS(1, 2); ORC_STEPS(3, 4); ORC_STEPS(5, 6); ORC_STEPS(7, 8);
+#endif
 #undef ORC_STEPS
       }
 #endif

@@ -11,6 +11,11 @@
 #define ORC_MAX_SAVE     4       // saved frames while walking a kinematic tree
 #define ORC_MAX_SDFS     8
 #define ORC_BLOCK        256     // threads per workgroup: one workgroup per run
+#ifndef ORC_WGS_PER_CU
+#define ORC_WGS_PER_CU    3       // resident workgroups per CU the kernels' register budget is sized for (launch bounds)
+#endif
+#define ORC_LIM_LIST      64      // violated entries the sparse joint-limit rounds handle
+#define ORC_LIM_SCRATCH  (256 + ORC_LIM_LIST*16)   // bytes: 4 wave records + header, entry list
 
 // one optimized joint, in topological order.  Non-optimized joints are folded
 // into the fixed transforms on the host when the batch is created.
@@ -113,6 +118,8 @@ struct DevBatch
    long long * phase_cycles; // [n_runs][8] or null: diagnostics (cycles per phase, wave 0)
    real a_diag, a_off;     // D == 1: A = tridiag(a_off, a_diag, a_off), B couples the end rows with a_off
    int pcr_in_lds;         // the cyclic-reduction tables are staged in LDS
+   int pcr_sym;            // compact tables: pcr[l][m] (towards i-s; towards i+s is the mirrored entry), then [m] inverse diagonal
+   int pcr_rows;           // rows of m entries in the table
    int stagger_mode;       // 0 none; 1 odd workgroups, 2 every other group of 256: start half an iteration late
    int stagger_sleeps;     // length of that delay in s_sleep(127) units (~8k cycles each)
 };
@@ -122,6 +129,7 @@ struct DevBatch
 struct LdsLayout
 {
    int T, G, W, AG, pos, ax, srad, sinact, jl, pcr, end_reals;
+   int lim_bytes;          // byte offset of the joint-limit scratch (ORC_LIM_SCRATCH bytes)
    int pstr, astr;         // waypoint strides of pos / ax: odd, so that lane = waypoint accesses (FK) hit distinct LDS banks
    int ints_bytes;         // byte offset of the int tables (slink, jtype, jcol)
    int joints_bytes;       // byte offset of the staged DevJoint[nj]
@@ -152,14 +160,21 @@ inline LdsLayout lds_layout(int np, int n, int Sa, int S, int nj, int tile_m, in
    LdsLayout L;
    int o = 0;
    auto take = [&o](int count) { const int at = o; o += (count + 3) & ~3; return at; };
-   L.T = take(np*n);
-   L.G = take(mn);
-   L.W = take(mn);
-   L.AG = take(use_ag ? mn : 0);
    L.pstr = (Sa*3) | 1;
    L.astr = (nj*6) | 1;
+   // the work buffer of the update phase (solve ping-pong, joint-limit scratch) lives in the tile
+   // buffers pos/ax, which are dead by then, when they are large enough
+   const int lim_reals = (ORC_LIM_SCRATCH + real_size - 1) / real_size;
+   const int work_reals = ((mn > 1280/real_size ? mn : 1280/real_size) + 3) & ~3;
+   const int tile_reals = (((tile_m+2)*L.pstr + 3) & ~3) + (((tile_m+2)*L.astr + 3) & ~3);
+   const bool alias = tile_reals >= work_reals + lim_reals;
+   L.T = take(np*n);
+   L.G = take(mn);
+   L.W = alias ? 0 : take(work_reals);
+   L.AG = take(use_ag ? mn : 0);
    L.pos = take((tile_m+2)*L.pstr);
    L.ax = take((tile_m+2)*L.astr);
+   if (alias) L.W = L.pos;
    L.srad = take(S);
    L.sinact = take((S-Sa)*3 + 1);
    L.jl = take(2*n);
@@ -172,6 +187,8 @@ inline LdsLayout lds_layout(int np, int n, int Sa, int S, int nj, int tile_m, in
    L.joints_bytes = bytes; bytes += nj * joint_size; bytes = (bytes + 15) & ~15;
    L.sdfs_bytes = bytes;   bytes += n_sdfs * sdf_size; bytes = (bytes + 15) & ~15;
    L.saff_bytes = bytes;   bytes += Sa * 8;
+   if (alias) L.lim_bytes = 128 + (L.pos + work_reals) * real_size;
+   else { L.lim_bytes = bytes; bytes += ORC_LIM_SCRATCH; }
    L.total_bytes = bytes;
    return L;
 }

@@ -407,7 +407,7 @@ void build_metric(int m, int D, double dt, Metric & out)
    for (int i=0; i<m; i++) for (int k=-D; k<=D; k++)
       if (i+k >= 0 && i+k < m) out.Aband[(size_t)(k+D)*m + i] = A[(size_t) i*m + i+k];
 
-   out.pcr.clear(); out.Ainv.clear(); out.pcr_levels = 0;
+   out.pcr.clear(); out.Ainv.clear(); out.pcr_levels = 0; out.pcr_sym = 0;
    if (D == 1)
    {
       // parallel cyclic reduction, coefficient part: the multipliers only depend on A
@@ -432,7 +432,8 @@ void build_metric(int m, int D, double dt, Metric & out)
             const double ga = (i+stride < m)  ? -c[i] / bdiag[i+stride] : 0.0;
             out.pcr[(size_t)(2*l) * m + i] = al;
             out.pcr[(size_t)(2*l+1) * m + i] = ga;
-            b2[i] = bdiag[i] + ((i-stride >= 0) ? al * c[i-stride] : 0.0) + ((i+stride < m) ? ga * a[i+stride] : 0.0);
+            // (the two products are added to each other first: mirrored rows then round identically)
+            b2[i] = bdiag[i] + (((i-stride >= 0) ? al * c[i-stride] : 0.0) + ((i+stride < m) ? ga * a[i+stride] : 0.0));
             a2[i] = (i-stride >= 0) ? al * a[i-stride] : 0.0;
             c2[i] = (i+stride < m)  ? ga * c[i+stride] : 0.0;
          }
@@ -440,6 +441,14 @@ void build_metric(int m, int D, double dt, Metric & out)
          stride <<= 1;
       }
       for (int i=0; i<m; i++) out.pcr[(size_t)(2*levels) * m + i] = 1.0 / bdiag[i];
+      // persymmetric metric (Toeplitz): the multiplier towards i+s of row i is the multiplier towards
+      // i-s of the mirrored row, so the device needs half of the table
+      out.pcr_sym = 1;
+      for (int l=0; l<levels && out.pcr_sym; l++)
+         for (int i=0; i<m; i++)
+            if (out.pcr[(size_t)(2*l+1) * m + i] != out.pcr[(size_t)(2*l) * m + (m-1-i)]) { out.pcr_sym = 0; break; }
+      for (int i=0; i<m && out.pcr_sym; i++)
+         if (out.pcr[(size_t)(2*levels) * m + i] != out.pcr[(size_t)(2*levels) * m + (m-1-i)]) out.pcr_sym = 0;
    }
    else
    {

@@ -76,6 +76,7 @@ struct Metric
    std::vector<double> beta_g;
    double kss, ksg, kgg;        // trC = 0.5*(kss|s|^2 + 2ksg s.g + kgg|g|^2)
    int pcr_levels;              // tridiagonal only
+   int pcr_sym;                 // pcr[l][1][i] == pcr[l][0][m-1-i] (the device keeps only pcr[l][0])
    std::vector<double> pcr;     // [levels][2][m] + [m]
    std::vector<double> Ainv;    // dense [m][m], only when D >= 2
    std::vector<double> Adense;  // dense A (kept for tests / dense fallback)
