@@ -445,7 +445,8 @@ void Batch::build_device(const Robot & robot)
    tile_m_ = 0;
    for (int wgs=max_wgs; wgs>=1 && !tile_m_; wgs--)
    {
-      const size_t budget = ((lds_cu / wgs) & ~(size_t) 511) - (wgs == 1 ? 1024 : 0);
+      // LDS is handed out in 1280-byte granules (measured: three 53512-byte workgroups share a CU, three 54184-byte ones do not)
+      const size_t budget = (lds_cu / wgs / 1280) * 1280 - (wgs == 1 ? 1024 : 0);
       int best_t = 0, best_pcr = 0, best_tiles = 1 << 30;
       for (int with_pcr=1; with_pcr>=0; with_pcr--)
       {

@@ -580,6 +580,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
    real * srad_s = lds + L.srad;                        // [S] sphere radii
    real * sinact_s = lds + L.sinact;                    // [S-Sa][3] inactive sphere centres
    real * jl_s = lds + L.jl;                            // [2][n] joint limits
+   real * r2_s = lds + L.r2;                            // [8][16] squared ranges of the self-collision row rotations
    real * pcr_s = lds + L.pcr;                          // cyclic-reduction tables (when staged)
    int * slink_s = (int *)(smem_raw + L.ints_bytes);    // [S] link of each sphere
    int * jtype_s = slink_s + S;                         // [nj]
@@ -622,6 +623,27 @@ void chomp_iterate_kernel(const DevBatch<real> b)
    int leapfrog_first = b.leapfrog_first[run];
    int status = b.status[run];
    int next_resample = 0;      // index into this call's resample list
+   __syncthreads();
+
+   if (GS16 && tid < 64)
+   {
+      // squared range of the pair (lane, lane rotated by K) for the row rotations of the
+      // self-collision term; -1: the pair never counts (same link, or a lane without a sphere).
+      // The partner's identity comes through the same DPP rotation the cost phase uses.
+      const int srow = tid & 15;
+      const bool has = (srow < Sa);
+      const real rad = has ? srad_s[srow] : (real)0;
+      const int link = has ? slink_s[srow] : -1 - srow;
+#define ORC_R2(K) do { \
+         const int sp_ = dpp_move<0x120 + K>(srow); \
+         const real ro_ = dpp_move<0x120 + K>(rad); \
+         const int lo_ = dpp_move<0x120 + K>(link); \
+         const real R_ = rad + ro_ + b.epsilon_self; \
+         if (tid < 16) r2_s[(K-1)*16 + srow] = (has && sp_ < Sa && lo_ != link) ? R_ * R_ : (real)(-1); \
+      } while (0)
+      ORC_R2(1); ORC_R2(2); ORC_R2(3); ORC_R2(4); ORC_R2(5); ORC_R2(6); ORC_R2(7); ORC_R2(8);
+#undef ORC_R2
+   }
    __syncthreads();
 
    // optional per-phase cycle counters (diagnostics: b.phase_cycles == null in production)
@@ -677,7 +699,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
 
          // ================= cost phase: lane = (waypoint, sphere) =============
          if constexpr (GS16)
-            cost_tile_gs16<real, ORC_U>(b, mod, sdfs, ts, te, do_iteration, T_s, G_s, pos_s, ax_s, srad_s, sinact_s,
+            cost_tile_gs16<real, ORC_U>(b, mod, sdfs, ts, te, do_iteration, T_s, G_s, pos_s, ax_s, srad_s, sinact_s, r2_s,
                                         slink_s, jtype_s, jcol_s, inv_eps, inv_eps_self, cost_lane);
          else
          {

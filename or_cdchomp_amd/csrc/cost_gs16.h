@@ -57,369 +57,80 @@ __device__ __forceinline__ bool sdf_lookup_pred(const DevSdf<real> & f, const re
    return inb;
 }
 
-// one rotation step of the self-collision term for U waypoints per lane (see self_pair_step16)
-template <typename real, int U, int K>
-__device__ __forceinline__ void self_pair_step16u(unsigned kmask, const bool live[U], const real p[U][3],
-   real radius, int mylink, const real vel[U][3], const bool moving[U], const real inv_vn2[U], const real wself[U],
-   real eps_self, real inv_eps_self, bool do_iteration, real f[U][3], double cost_sphere[U])
-{
-   if (!(kmask & (1u << K))) return;                       // wave-uniform
-   constexpr int FWD = 0x120 + K, BWD = 0x120 + (16 - K);  // row_ror:K and its inverse
-   const real ro = dpp_move<FWD>(radius);
-   const int lo = dpp_move<FWD>(mylink);
-   const real R = radius + ro + eps_self;
-   const real R2 = R * R;
-   const bool other_link = (lo != mylink);
-   real d[U][3], d2[U]; bool near[U]; bool any = false;
-#pragma unroll
-   for (int u=0; u<U; u++)
-   {
-#pragma unroll
-      for (int k=0; k<3; k++) d[u][k] = p[u][k] - dpp_move<FWD>(p[u][k]);
-      const int ao = dpp_move<FWD>(live[u] ? 1 : 0);
-      d2[u] = d[u][0]*d[u][0] + d[u][1]*d[u][1] + d[u][2]*d[u][2];
-      near[u] = live[u] && ao && other_link && !(d2[u] > R2);
-      any = any || near[u];
-   }
-   real x[U][3];
-#pragma unroll
-   for (int u=0; u<U; u++) { x[u][0] = 0; x[u][1] = 0; x[u][2] = 0; }
-   if (any)
-   {
-#pragma unroll
-      for (int u=0; u<U; u++)
-      {
-         real inv_d;
-         real dist = sqrt_rsq(near[u] ? d2[u] : (real)1, &inv_d);
-         dist -= radius + ro;
-         const real de = dist - eps_self;
-         const real cself = (dist < (real)0) ? ((real)0.5 * eps_self - dist) : ((real)0.5 * inv_eps_self) * de * de;
-         cost_sphere[u] += near[u] ? (double)(wself[u] * cself) : 0.0;
-         const real scale = (dist < (real)0) ? (real)(-1) : ((dist < eps_self) ? dist * inv_eps_self - (real)1 : (real)1);
-         const real sd = scale * inv_d * wself[u];
-         real xx[3];
-#pragma unroll
-         for (int k=0; k<3; k++) xx[k] = d[u][k] * sd;
-         const real proj = moving[u] ? (xx[0]*vel[u][0] + xx[1]*vel[u][1] + xx[2]*vel[u][2]) * inv_vn2[u] : (real)0;
-#pragma unroll
-         for (int k=0; k<3; k++) x[u][k] = (near[u] && do_iteration) ? (xx[k] - proj * vel[u][k]) : (real)0;
-      }
-   }
-   if (do_iteration)
-   {
-#pragma unroll
-      for (int u=0; u<U; u++)
-#pragma unroll
-         for (int k=0; k<3; k++) f[u][k] += x[u][k] - dpp_move<BWD>(x[u][k]);
-   }
-}
-
-
-// NC independent evaluations of (sqrt(x), 1/sqrt(x)) written in lockstep, so that consecutive
-// instructions belong to different dependency chains (see sqrt_rsq for the scheme)
-template <int NC>
-__device__ __forceinline__ void sqrt_rsq_lockstep(const double x[NC], double g[NC], double inv[NC])
-{
-   double r[NC], h[NC], e[NC];
-#pragma unroll
-   for (int c=0; c<NC; c++) r[c] = __builtin_amdgcn_rsq(x[c]);
-#pragma unroll
-   for (int c=0; c<NC; c++) g[c] = x[c] * r[c];
-#pragma unroll
-   for (int c=0; c<NC; c++) h[c] = 0.5 * r[c];
-#pragma unroll
-   for (int k=0; k<2; k++)
-   {
-#pragma unroll
-      for (int c=0; c<NC; c++) e[c] = fma(-h[c], g[c], 0.5);
-#pragma unroll
-      for (int c=0; c<NC; c++) g[c] = fma(g[c], e[c], g[c]);
-#pragma unroll
-      for (int c=0; c<NC; c++) h[c] = fma(h[c], e[c], h[c]);
-   }
-#pragma unroll
-   for (int c=0; c<NC; c++) e[c] = fma(-g[c], g[c], x[c]);
-#pragma unroll
-   for (int c=0; c<NC; c++) g[c] = fma(e[c], h[c], g[c]);
-#pragma unroll
-   for (int c=0; c<NC; c++) inv[c] = 2.0 * h[c];
-}
-template <int NC>
-__device__ __forceinline__ void sqrt_rsq_lockstep(const float x[NC], float g[NC], float inv[NC])
-{
-#pragma unroll
-   for (int c=0; c<NC; c++) { g[c] = ::sqrtf(x[c]); inv[c] = 1.0f / g[c]; }
-}
-
-// the arithmetic of NC pair evaluations (chains) in lockstep: from the separation vectors d to
-// the forces x on this lane's spheres.  near[c] masks chains that are out of range.
-template <typename real, int NC>
-__device__ __forceinline__ void pair_forces_lockstep(const real d[NC][3], const real d2[NC], const bool near[NC],
-   const real rsum[NC], const real * const vel[NC], const bool moving[NC], const real inv_vn2[NC], const real wself[NC],
-   real eps_self, real inv_eps_self, bool do_iteration, real x[NC][3], double cadd[NC])
-{
-   real xs[NC], dist[NC], inv_d[NC];
-#pragma unroll
-   for (int c=0; c<NC; c++) xs[c] = near[c] ? d2[c] : (real)1;
-   sqrt_rsq_lockstep<NC>(xs, dist, inv_d);
-#pragma unroll
-   for (int c=0; c<NC; c++) dist[c] -= rsum[c];
-   real de[NC], cself[NC], scale[NC], sd[NC], proj[NC];
-#pragma unroll
-   for (int c=0; c<NC; c++) de[c] = dist[c] - eps_self;
-#pragma unroll
-   for (int c=0; c<NC; c++)
-      cself[c] = (dist[c] < (real)0) ? ((real)0.5 * eps_self - dist[c]) : ((real)0.5 * inv_eps_self) * de[c] * de[c];
-#pragma unroll
-   for (int c=0; c<NC; c++) cadd[c] = near[c] ? (double)(wself[c] * cself[c]) : 0.0;
-#pragma unroll
-   for (int c=0; c<NC; c++)
-      scale[c] = (dist[c] < (real)0) ? (real)(-1) : ((dist[c] < eps_self) ? dist[c] * inv_eps_self - (real)1 : (real)1);
-#pragma unroll
-   for (int c=0; c<NC; c++) sd[c] = scale[c] * inv_d[c] * wself[c];
-   real xx[NC][3];
-#pragma unroll
-   for (int k=0; k<3; k++)
-#pragma unroll
-      for (int c=0; c<NC; c++) xx[c][k] = d[c][k] * sd[c];
-#pragma unroll
-   for (int c=0; c<NC; c++) proj[c] = xx[c][0]*vel[c][0];
-#pragma unroll
-   for (int c=0; c<NC; c++) proj[c] = fma(xx[c][1], vel[c][1], proj[c]);
-#pragma unroll
-   for (int c=0; c<NC; c++) proj[c] = fma(xx[c][2], vel[c][2], proj[c]);
-#pragma unroll
-   for (int c=0; c<NC; c++) proj[c] = moving[c] ? proj[c] * inv_vn2[c] : (real)0;
-#pragma unroll
-   for (int k=0; k<3; k++)
-#pragma unroll
-      for (int c=0; c<NC; c++) x[c][k] = (near[c] && do_iteration) ? (xx[c][k] - proj[c] * vel[c][k]) : (real)0;
-}
-
-// two rotation steps (K1, K2) of the self-collision term for U waypoints per lane: 2U chains
-// evaluated in lockstep.  See self_pair_step16 for the pairing scheme.
-template <typename real, int U, int K1, int K2>
-__device__ __forceinline__ void self_pair_steps16(const bool live[U], const real p[U][3],
-   real radius, int mylink, const real vel[U][3], const bool moving[U], const real inv_vn2[U], const real wself[U],
-   real eps_self, real inv_eps_self, bool do_iteration, real f[U][3], double cost_sphere[U])
-{
-   constexpr int NC = 2*U;
-   constexpr int F1 = 0x120 + K1, B1 = 0x120 + (16 - K1);
-   constexpr int F2 = 0x120 + K2, B2 = 0x120 + (16 - K2);
-   real d[NC][3], d2[NC], rsum[NC], R2[2], iv2[NC], ws[NC];
-   const real * vp[NC];
-   bool near[NC], mv[NC], other[2];
-   {
-      const real ro1 = dpp_move<F1>(radius), ro2 = dpp_move<F2>(radius);
-      const int lo1 = dpp_move<F1>(mylink), lo2 = dpp_move<F2>(mylink);
-      other[0] = (lo1 != mylink); other[1] = (lo2 != mylink);
-      const real s1 = radius + ro1, s2 = radius + ro2;
-      const real Ra = s1 + eps_self, Rb = s2 + eps_self;
-      R2[0] = Ra * Ra; R2[1] = Rb * Rb;
-#pragma unroll
-      for (int u=0; u<U; u++) { rsum[u] = s1; rsum[U+u] = s2; }
-   }
-   bool any = false;
-#pragma unroll
-   for (int u=0; u<U; u++)
-   {
-#pragma unroll
-      for (int k=0; k<3; k++)
-      {
-         d[u][k] = p[u][k] - dpp_move<F1>(p[u][k]);
-         d[U+u][k] = p[u][k] - dpp_move<F2>(p[u][k]);
-      }
-      const int a1 = dpp_move<F1>(live[u] ? 1 : 0), a2 = dpp_move<F2>(live[u] ? 1 : 0);
-      d2[u] = d[u][0]*d[u][0] + d[u][1]*d[u][1] + d[u][2]*d[u][2];
-      d2[U+u] = d[U+u][0]*d[U+u][0] + d[U+u][1]*d[U+u][1] + d[U+u][2]*d[U+u][2];
-      near[u] = live[u] && a1 && other[0] && !(d2[u] > R2[0]);
-      near[U+u] = live[u] && a2 && other[1] && !(d2[U+u] > R2[1]);
-      any = any || near[u] || near[U+u];
-      vp[u] = vel[u]; vp[U+u] = vel[u];
-      mv[u] = moving[u]; mv[U+u] = moving[u];
-      iv2[u] = inv_vn2[u]; iv2[U+u] = inv_vn2[u];
-      ws[u] = wself[u]; ws[U+u] = wself[u];
-   }
-   real x[NC][3]; double cadd[NC];
-#pragma unroll
-   for (int c=0; c<NC; c++) { x[c][0] = 0; x[c][1] = 0; x[c][2] = 0; cadd[c] = 0.0; }
-   if (any)
-      pair_forces_lockstep<real, NC>(d, d2, near, rsum, vp, mv, iv2, ws, eps_self, inv_eps_self, do_iteration, x, cadd);
-#pragma unroll
-   for (int u=0; u<U; u++) cost_sphere[u] += cadd[u] + cadd[U+u];
-   if (do_iteration)
-   {
-#pragma unroll
-      for (int u=0; u<U; u++)
-#pragma unroll
-         for (int k=0; k<3; k++)
-            f[u][k] += (x[u][k] - dpp_move<B1>(x[u][k])) + (x[U+u][k] - dpp_move<B2>(x[U+u][k]));
-   }
-}
-
-// Two SYMMETRIC rotation steps (K1, K2 in 1..8) for U waypoints per lane.  A pair of spheres
-// {a, b} is visited twice by the reference (once from each side, src/orcdchomp_mod.cpp:1251-1317).
-// Here the lane of a fetches everything it needs about b through the row rotation (centre,
-// radius, link, velocity), evaluates the shared part once (distance, piecewise factor) and both
-// sides' forces: the net force on a is x_ab - x_ba, and b receives the opposite through the
-// inverse rotation.  Rotations 1..7 therefore cover every pair exactly once; rotation 8 pairs each
-// lane with the lane that pairs with it, so both compute the pair and nothing is exchanged.
+// One SYMMETRIC rotation step K (1..8) of the self-collision term (src/orcdchomp_mod.cpp:1251-1317).
+// A pair of spheres {a, b} is visited twice by the reference, once from each side.  Here lane a
+// looks at the sphere K lanes away in its 16-lane row, evaluates the shared part once (distance,
+// piecewise factor) and both sides' forces: the net force on a is x_ab - x_ba, and b receives the
+// opposite through the inverse rotation.  Rotations 1..7 cover every pair exactly once; rotation 8
+// pairs each lane with the lane that pairs with it, so both compute the pair and nothing is exchanged.
+//
+// The range test is the part every pair pays, so it is kept off the vector pipe as far as possible:
+// the partner's centre comes from the tile's position buffer in LDS (its index `sp` through the
+// same row rotation as everything else, so the code does not depend on the rotation's direction)
+// and the squared range from a table staged at kernel start (r2row[K-1][lane]: (r_a + r_b +
+// eps_self)^2, or -1 when the pair never counts: same link, or a lane without a sphere).  The rest
+// (velocities, weights, forces) runs only when some lane of the wavefront has a pair in range.
+// Must be executed by all lanes of the wave (DPP sources must be live lanes).
 // flags: bit 0 live, bit 1 moving.  The obstacle cost of both sides is summed where it is
 // computed (the per-run cost is a sum over all lanes anyway).
-template <typename real, int U, int K1, int K2>
-__device__ __forceinline__ void self_sym_steps16(const int flags[U], const real p[U][3],
-   real radius, int mylink, const real vel[U][3], const real inv_vn2[U], const real wself[U],
-   real eps_self, real inv_eps_self, bool do_iteration, real f[U][3], double cost_sphere[U])
+template <typename real, int K>
+__device__ __forceinline__ void self_sym_step16(const real * prow, const real * r2row, int srow, int flags, const real p[3],
+   real radius, const real vel[3], real inv_vn2, real wself, real eps_self, real inv_eps_self, bool do_iteration,
+   real f[3], double & cost_sphere)
 {
-   // K2 == 0: a single rotation (fewer live registers; used when more wavefronts per SIMD hide the
-   // latency that the second lockstep chain hides otherwise)
-   constexpr int NR = (K2 == 0) ? 1 : 2;
-   constexpr int NC = NR*U;
-   constexpr int F1 = 0x120 + K1, B1 = 0x120 + (16 - K1);
-   constexpr int F2 = 0x120 + (K2 == 0 ? 1 : K2), B2 = 0x120 + (16 - (K2 == 0 ? 1 : K2));
-   real d[NC][3], vo[NC][3], d2[NC], rsum[NC], wo[NC], ivo[NC], R2[NR];
-   bool near[NC], mo[NC], other[NR];
-   {
-      const real ro1 = dpp_move<F1>(radius);
-      const int lo1 = dpp_move<F1>(mylink);
-      other[0] = (lo1 != mylink);
-      const real s1 = radius + ro1;
-      const real Ra = s1 + eps_self;
-      R2[0] = Ra * Ra;
+   constexpr int F = 0x120 + K, B = 0x120 + (16 - K);     // row_ror:K and its inverse
+   const int sp = dpp_move<F>(srow);
+   const real * pp = prow + sp*3;
+   real d[3];
 #pragma unroll
-      for (int u=0; u<U; u++) rsum[u] = s1;
-      if constexpr (NR == 2)
-      {
-         const real ro2 = dpp_move<F2>(radius);
-         const int lo2 = dpp_move<F2>(mylink);
-         other[1] = (lo2 != mylink);
-         const real s2 = radius + ro2;
-         const real Rb = s2 + eps_self;
-         R2[1] = Rb * Rb;
+   for (int k=0; k<3; k++) d[k] = p[k] - pp[k];
+   const real d2 = d[0]*d[0] + d[1]*d[1] + d[2]*d[2];
+   const real R2 = r2row[(K-1)*16 + srow];
+   const bool near = (flags & 1) && (d2 <= R2);
+   if (__ballot(near) == 0ull) return;                     // wave-uniform
+   const real ro = dpp_move<F>(radius);
+   real vo[3];
 #pragma unroll
-         for (int u=0; u<U; u++) rsum[U+u] = s2;
-      }
-   }
-   bool any = false;
-#pragma unroll
-   for (int u=0; u<U; u++)
-   {
-#pragma unroll
-      for (int k=0; k<3; k++)
-      {
-         d[u][k] = p[u][k] - dpp_move<F1>(p[u][k]);
-         vo[u][k] = dpp_move<F1>(vel[u][k]);
-         if constexpr (NR == 2)
-         {
-            d[U+u][k] = p[u][k] - dpp_move<F2>(p[u][k]);
-            vo[U+u][k] = dpp_move<F2>(vel[u][k]);
-         }
-      }
-      wo[u] = dpp_move<F1>(wself[u]);
-      ivo[u] = dpp_move<F1>(inv_vn2[u]);
-      const int a1 = dpp_move<F1>(flags[u]);
-      mo[u] = (a1 & 2) != 0;
-      d2[u] = d[u][0]*d[u][0] + d[u][1]*d[u][1] + d[u][2]*d[u][2];
-      near[u] = (flags[u] & 1) && (a1 & 1) && other[0] && !(d2[u] > R2[0]);
-      any = any || near[u];
-      if constexpr (NR == 2)
-      {
-         wo[U+u] = dpp_move<F2>(wself[u]);
-         ivo[U+u] = dpp_move<F2>(inv_vn2[u]);
-         const int a2 = dpp_move<F2>(flags[u]);
-         mo[U+u] = (a2 & 2) != 0;
-         d2[U+u] = d[U+u][0]*d[U+u][0] + d[U+u][1]*d[U+u][1] + d[U+u][2]*d[U+u][2];
-         near[U+u] = (flags[u] & 1) && (a2 & 1) && other[1] && !(d2[U+u] > R2[1]);
-         any = any || near[U+u];
-      }
-   }
-   real inc[NC][3]; double cadd[NC];
-#pragma unroll
-   for (int c=0; c<NC; c++) { inc[c][0] = 0; inc[c][1] = 0; inc[c][2] = 0; cadd[c] = 0.0; }
-   if (any)
-   {
-      // shared part of the NC pairs, in lockstep
-      real xs[NC], dist[NC], inv_d[NC], de[NC], cself[NC], scale[NC], sdi[NC];
-#pragma unroll
-      for (int c=0; c<NC; c++) xs[c] = near[c] ? d2[c] : (real)1;
-      sqrt_rsq_lockstep<NC>(xs, dist, inv_d);
-#pragma unroll
-      for (int c=0; c<NC; c++) dist[c] -= rsum[c];
-#pragma unroll
-      for (int c=0; c<NC; c++) de[c] = dist[c] - eps_self;
-#pragma unroll
-      for (int c=0; c<NC; c++)
-         cself[c] = (dist[c] < (real)0) ? ((real)0.5 * eps_self - dist[c]) : ((real)0.5 * inv_eps_self) * de[c] * de[c];
-#pragma unroll
-      for (int c=0; c<NC; c++)
-         scale[c] = (dist[c] < (real)0) ? (real)(-1) : ((dist[c] < eps_self) ? dist[c] * inv_eps_self - (real)1 : (real)1);
-#pragma unroll
-      for (int c=0; c<NC; c++) sdi[c] = scale[c] * inv_d[c];
-      // both sides: side 0 = this lane's sphere (own velocity), side 1 = the partner's
-      real sa[NC], sb[NC], pa[NC], pb[NC];
-#pragma unroll
-      for (int c=0; c<NC; c++) { sa[c] = sdi[c] * wself[c % U]; sb[c] = -sdi[c] * wo[c]; }
-#pragma unroll
-      for (int c=0; c<NC; c++)
-      {
-         // rotation 8: the partner computes its own side
-         const bool is_8 = (c < U) ? (K1 == 8) : (K2 == 8);
-         const real wsum = is_8 ? wself[c % U] : wself[c % U] + wo[c];
-         cadd[c] = near[c] ? (double)(wsum * cself[c]) : 0.0;
-      }
-#pragma unroll
-      for (int c=0; c<NC; c++) pa[c] = d[c][0]*vel[c % U][0];
-#pragma unroll
-      for (int c=0; c<NC; c++) pb[c] = d[c][0]*vo[c][0];
-#pragma unroll
-      for (int c=0; c<NC; c++) pa[c] = fma(d[c][1], vel[c % U][1], pa[c]);
-#pragma unroll
-      for (int c=0; c<NC; c++) pb[c] = fma(d[c][1], vo[c][1], pb[c]);
-#pragma unroll
-      for (int c=0; c<NC; c++) pa[c] = fma(d[c][2], vel[c % U][2], pa[c]);
-#pragma unroll
-      for (int c=0; c<NC; c++) pb[c] = fma(d[c][2], vo[c][2], pb[c]);
-      // projections (d . v) * s / |v|^2, zero when that sphere is (nearly) at rest
-#pragma unroll
-      for (int c=0; c<NC; c++) pa[c] = (flags[c % U] & 2) ? pa[c] * sa[c] * inv_vn2[c % U] : (real)0;
-#pragma unroll
-      for (int c=0; c<NC; c++) pb[c] = mo[c] ? pb[c] * sb[c] * ivo[c] : (real)0;
-      // net force on this lane's sphere: x_ab - x_ba
-#pragma unroll
-      for (int k=0; k<3; k++)
-#pragma unroll
-         for (int c=0; c<NC; c++)
-         {
-            const real xab = d[c][k] * sa[c] - pa[c] * vel[c % U][k];
-            const real xba = d[c][k] * sb[c] - pb[c] * vo[c][k];
-            inc[c][k] = (near[c] && do_iteration) ? (xab - xba) : (real)0;
-         }
-   }
-#pragma unroll
-   for (int u=0; u<U; u++)
-   {
-      cost_sphere[u] += cadd[u];
-      if constexpr (NR == 2) cost_sphere[u] += cadd[U+u];
-   }
+   for (int k=0; k<3; k++) vo[k] = dpp_move<F>(vel[k]);
+   const real wo = dpp_move<F>(wself);
+   const real ivo = dpp_move<F>(inv_vn2);
+   const bool mo = (dpp_move<F>(flags) & 2) != 0;
+   // shared part of the pair
+   real inv_d;
+   real dist = sqrt_rsq(near ? d2 : (real)1, &inv_d);
+   dist -= radius + ro;
+   const real de = dist - eps_self;
+   const real cself = (dist < (real)0) ? ((real)0.5 * eps_self - dist) : ((real)0.5 * inv_eps_self) * de * de;
+   const real scale = (dist < (real)0) ? (real)(-1) : ((dist < eps_self) ? dist * inv_eps_self - (real)1 : (real)1);
+   const real sdi = scale * inv_d;
+   // both sides: a = this lane's sphere (own velocity), b = the partner's
+   const real sa = sdi * wself, sb = -sdi * wo;
+   const real wsum = (K == 8) ? wself : wself + wo;        // rotation 8: the partner computes its own side
+   cost_sphere += near ? (double)(wsum * cself) : 0.0;
+   real pa = d[0]*vel[0], pb = d[0]*vo[0];
+   pa = fma(d[1], vel[1], pa); pb = fma(d[1], vo[1], pb);
+   pa = fma(d[2], vel[2], pa); pb = fma(d[2], vo[2], pb);
+   // projections (d . v) * s / |v|^2, zero when that sphere is (nearly) at rest
+   pa = (flags & 2) ? pa * sa * inv_vn2 : (real)0;
+   pb = mo ? pb * sb * ivo : (real)0;
    if (do_iteration)
    {
 #pragma unroll
-      for (int u=0; u<U; u++)
-#pragma unroll
-         for (int k=0; k<3; k++)
-         {
-            real v = (K1 == 8) ? inc[u][k] : (inc[u][k] - dpp_move<B1>(inc[u][k]));
-            if constexpr (NR == 2)
-               v += (K2 == 8) ? inc[U+u][k] : (inc[U+u][k] - dpp_move<B2>(inc[U+u][k]));
-            f[u][k] += v;
-         }
+      for (int k=0; k<3; k++)
+      {
+         // net force on this lane's sphere: x_ab - x_ba
+         const real xab = d[k] * sa - pa * vel[k];
+         const real xba = d[k] * sb - pb * vo[k];
+         const real inc = near ? (xab - xba) : (real)0;
+         f[k] += (K == 8) ? inc : (inc - dpp_move<B>(inc));
+      }
    }
 }
 
 template <typename real, int U>
 __device__ __forceinline__ void cost_tile_gs16(const DevBatch<real> & b, const ModelView<real> & mod,
    const DevSdf<real> * sdfs, int ts, int te, bool do_iteration, const real * T_s, real * G_s, const real * pos_s, const real * ax_s,
-   const real * srad_s, const real * sinact_s, const int * slink_s, const int * jtype_s, const int * jcol_s,
+   const real * srad_s, const real * sinact_s, const real * r2_s, const int * slink_s, const int * jtype_s, const int * jcol_s,
    real inv_eps, real inv_eps_self, double & cost_lane)
 {
    const int tid = threadIdx.x;
@@ -566,21 +277,17 @@ __device__ __forceinline__ void cost_tile_gs16(const DevBatch<real> & b, const M
             for (int k=0; k<3; k++) f[u][k] += (near[u] && do_iteration) ? (xx[k] - proj * vel[u][k]) : (real)0;
          }
       }
-      // row rotations 1..8, two at a time; each visits its pairs once for both sides
+      // row rotations 1..8; each visits its pairs once for both sides
 #ifndef ORC_ABLATE_ROT
-      {
-         int flags[U];
 #pragma unroll
-         for (int u=0; u<U; u++) flags[u] = (live[u] ? 1 : 0) | (moving[u] ? 2 : 0);
-#define ORC_STEPS(K1, K2) self_sym_steps16<real, U, K1, K2>(flags, p, radius, mylink, vel, inv_vn2, wself, \
-                             b.epsilon_self, inv_eps_self, do_iteration, f, cost_sphere)
-#if ORC_WGS_PER_CU >= 3
-         ORC_STEPS(1, 0); ORC_STEPS(2, 0); ORC_STEPS(3, 0); ORC_STEPS(4, 0);
-         ORC_STEPS(5, 0); ORC_STEPS(6, 0); ORC_STEPS(7, 0); ORC_STEPS(8, 0);
-#else
-         ORC_STEPS(1, 2); ORC_STEPS(3, 4); ORC_STEPS(5, 6); ORC_STEPS(7, 8);
-#endif
-#undef ORC_STEPS
+      for (int u=0; u<U; u++)
+      {
+         const int flags = (live[u] ? 1 : 0) | (moving[u] ? 2 : 0);
+         const real * prow = pos_s + l[u]*pstr;
+#define ORC_STEP(K) self_sym_step16<real, K>(prow, r2_s, s, flags, p[u], radius, vel[u], inv_vn2[u], wself[u], \
+                       b.epsilon_self, inv_eps_self, do_iteration, f[u], cost_sphere[u])
+         ORC_STEP(1); ORC_STEP(2); ORC_STEP(3); ORC_STEP(4); ORC_STEP(5); ORC_STEP(6); ORC_STEP(7); ORC_STEP(8);
+#undef ORC_STEP
       }
 #endif
 

@@ -128,7 +128,7 @@ struct DevBatch
 // Offsets are in units of `real` after a 128-byte header (reduction scratch).
 struct LdsLayout
 {
-   int T, G, W, AG, pos, ax, srad, sinact, jl, pcr, end_reals;
+   int T, G, W, AG, pos, ax, srad, sinact, jl, pcr, r2, end_reals;
    int lim_bytes;          // byte offset of the joint-limit scratch (ORC_LIM_SCRATCH bytes)
    int pstr, astr;         // waypoint strides of pos / ax: odd, so that lane = waypoint accesses (FK) hit distinct LDS banks
    int ints_bytes;         // byte offset of the int tables (slink, jtype, jcol)
@@ -178,6 +178,7 @@ inline LdsLayout lds_layout(int np, int n, int Sa, int S, int nj, int tile_m, in
    L.srad = take(S);
    L.sinact = take((S-Sa)*3 + 1);
    L.jl = take(2*n);
+   L.r2 = take(8*16);                      // squared ranges of the self-collision row rotations [8][16]
    L.pcr = take(pcr_rows*m);
    (void) take(Sa*3 + 12);                 // staged sphere local positions + base frame (after pcr)
    L.end_reals = o;
