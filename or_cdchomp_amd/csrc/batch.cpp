@@ -391,6 +391,9 @@ void Batch::build_device(const Robot & robot)
       const Mat3 Rgw = pose_rotation_expanded(pose_gsdf_world);
       const Mat3 Rwg = pose_rotation_expanded(pose_world_gsdf);
       for (int q=0; q<9; q++) { hs[i].Rgw[q] = (real) Rgw.m[q]; hs[i].Rwg[q] = (real) Rwg.m[q]; }
+      hs[i].rot_identity = 1;
+      for (int q=0; q<9; q++)
+         if (Rgw.m[q] != ((q % 4 == 0) ? 1.0 : 0.0) || Rwg.m[q] != ((q % 4 == 0) ? 1.0 : 0.0)) hs[i].rot_identity = 0;
       for (int q=0; q<3; q++)
       {
          hs[i].tgw[q] = (real) pose_gsdf_world.v[q];
@@ -400,7 +403,6 @@ void Batch::build_device(const Robot & robot)
          hs[i].cell[q] = (real)(s.grid.lengths[q] / s.grid.sizes[q]);
          hs[i].size_over_len[q] = (real)(s.grid.sizes[q] / s.grid.lengths[q]);
       }
-      hs[i].pad = 0;
    }
    DevSdf<real> * ds = dev_alloc<DevSdf<real>>(n_sdfs_);
    hip_check(hipMemcpy(ds, hs.data(), hs.size()*sizeof(DevSdf<real>), hipMemcpyHostToDevice), "sdfs");

@@ -113,60 +113,6 @@ __device__ __forceinline__ real group_sum(real v, int GS)
 template <int CTRL>
 __device__ __forceinline__ int dpp_move(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
 
-// One rotation step of the self-collision term for 16 lanes per waypoint (src/orcdchomp_mod.cpp:
-// 1251-1317).  Every lane looks at the sphere K lanes away in its row (row_ror:K); all partner
-// attributes travel through the same DPP rotation, so the code does not depend on its direction.
-// The lane evaluates only ITS side of the pair (force x on its own sphere, its own velocity);
-// the reaction -x of the pair seen from the partner's side is fetched with the inverse rotation.
-// Must be executed by all lanes of the wave (DPP sources must be live lanes).
-template <typename real, int K>
-__device__ __forceinline__ void self_pair_step16(unsigned kmask, bool live, const real p[3], real radius, int mylink,
-   const real vel[3], bool moving, real inv_vn2, real wself, real eps_self, real inv_eps_self, bool do_iteration,
-   real f[3], double & cost_sphere)
-{
-   if (!(kmask & (1u << K))) return;                       // wave-uniform
-   constexpr int FWD = 0x120 + K, BWD = 0x120 + (16 - K);  // row_ror:K and its inverse
-   real d[3];
-#pragma unroll
-   for (int k=0; k<3; k++) d[k] = p[k] - dpp_move<FWD>(p[k]);
-   const real ro = dpp_move<FWD>(radius);
-   const int lo = dpp_move<FWD>(mylink);
-   const int ao = dpp_move<FWD>(live ? 1 : 0);
-   const real d2 = d[0]*d[0] + d[1]*d[1] + d[2]*d[2];
-   const real R = radius + ro + eps_self;
-   const bool near = live && ao && (lo != mylink) && !(d2 > R*R);
-   real x[3] = {0, 0, 0};
-   if (near)
-   {
-      real inv_d;
-      real dist = sqrt_rsq(d2, &inv_d);
-      dist -= radius + ro;
-      const real de = dist - eps_self;
-      const real cself = (dist < (real)0) ? ((real)0.5 * eps_self - dist) : ((real)0.5 * inv_eps_self) * de * de;
-      cost_sphere += (double)(wself * cself);
-      if (do_iteration)
-      {
-         real scale = (real)1;
-         if (dist < (real)0) scale = (real)(-1);
-         else if (dist < eps_self) scale = dist * inv_eps_self - (real)1;
-         const real sd = scale * inv_d * wself;
-#pragma unroll
-         for (int k=0; k<3; k++) x[k] = d[k] * sd;
-         if (moving)
-         {
-            const real proj = (x[0]*vel[0] + x[1]*vel[1] + x[2]*vel[2]) * inv_vn2;
-#pragma unroll
-            for (int k=0; k<3; k++) x[k] -= proj * vel[k];
-         }
-      }
-   }
-   if (do_iteration)
-   {
-#pragma unroll
-      for (int k=0; k<3; k++) f[k] += x[k] - dpp_move<BWD>(x[k]);
-   }
-}
-
 template <typename real>
 __device__ __forceinline__ real dpp_row_max(real v)
 {
@@ -202,20 +148,6 @@ __device__ __forceinline__ void wave_argmax(real & best, int & best_e)
       win = e < win ? e : win;
    }
    best = mm; best_e = win;
-}
-
-template <typename real>
-struct Frame { real R[9]; real t[3]; };
-
-// out = A * B (3x3 row major)
-template <typename real>
-__device__ __forceinline__ void mat3_mul(const real * A, const real * B, real * C)
-{
-#pragma unroll
-   for (int i=0; i<3; i++)
-#pragma unroll
-      for (int j=0; j<3; j++)
-         C[i*3+j] = A[i*3+0]*B[0*3+j] + A[i*3+1]*B[1*3+j] + A[i*3+2]*B[2*3+j];
 }
 
 __device__ __forceinline__ double wave_sum(double v)
@@ -546,7 +478,7 @@ __device__ __forceinline__ real smooth_grad(const DevBatch<real> & b, const real
 #include "fk.h"
 
 #ifndef ORC_U
-#define ORC_U 1          // waypoints per lane in the 16-sphere cost phase (2 measured no faster: the rotation steps already run 2 chains in lockstep)
+#define ORC_U 1          // waypoints per lane in the 16-sphere cost phase (1: registers go to a third workgroup per CU instead)
 #endif
 
 // ---------------------------------------------------------------------------

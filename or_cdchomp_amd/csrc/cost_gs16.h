@@ -1,10 +1,9 @@
 // cost_gs16.h -- cost phase of the CHOMP iteration for robots with <= 16 active spheres.
 //
-// Included by chomp_kernel.hip.  Lane = (waypoint group, sphere): 16 lanes form one DPP row and
-// own one sphere each; every lane works on U waypoints at once (group g owns waypoints
-// g, g+ngroups, ...).  The U instruction streams are independent, which is what hides the
-// 32-cycle dependent latency of the fp64 pipe (measured, scripts/ubench/lat.hip): the code is
-// written branch-free per stream (selects) so that the scheduler can interleave them.
+// Included by chomp_kernel.hip.  Lane = (waypoint, sphere): 16 lanes form one DPP row and own one
+// sphere each, four waypoints per wavefront.  The phase is written for few live registers (168
+// VGPRs = three workgroups per CU): the kernel is bound by dependent fp64 latency, which resident
+// wavefronts hide better than unrolled instruction streams do.
 //
 // Reference: sphere_cost, src/orcdchomp_mod.cpp:1134-1327 (per-sphere obstacle term 1171-1246,
 // self collision 1251-1317); velocities/accelerations src/orcdchomp_mod.cpp:1099-1127;
@@ -102,26 +101,26 @@ __device__ __forceinline__ void self_sym_step16(const real * prow, const real * 
    const real de = dist - eps_self;
    const real cself = (dist < (real)0) ? ((real)0.5 * eps_self - dist) : ((real)0.5 * inv_eps_self) * de * de;
    const real scale = (dist < (real)0) ? (real)(-1) : ((dist < eps_self) ? dist * inv_eps_self - (real)1 : (real)1);
-   const real sdi = scale * inv_d;
-   // both sides: a = this lane's sphere (own velocity), b = the partner's
-   const real sa = sdi * wself, sb = -sdi * wo;
-   const real wsum = (K == 8) ? wself : wself + wo;        // rotation 8: the partner computes its own side
+   const real sdi = near ? scale * inv_d : (real)0;        // out of range: every force term below vanishes
+   const real wboth = wself + wo;
+   const real wsum = (K == 8) ? wself : wboth;             // rotation 8: the partner adds its own side of the cost
    cost_sphere += near ? (double)(wsum * cself) : 0.0;
-   real pa = d[0]*vel[0], pb = d[0]*vo[0];
-   pa = fma(d[1], vel[1], pa); pb = fma(d[1], vo[1], pb);
-   pa = fma(d[2], vel[2], pa); pb = fma(d[2], vo[2], pb);
-   // projections (d . v) * s / |v|^2, zero when that sphere is (nearly) at rest
-   pa = (flags & 2) ? pa * sa * inv_vn2 : (real)0;
-   pb = mo ? pb * sb * ivo : (real)0;
    if (do_iteration)
    {
+      // forces of both sides, x_ab = s w_a (d - (d.v_a) v_a/|v_a|^2) on this sphere and
+      // x_ba = -s w_b (d - (d.v_b) v_b/|v_b|^2) on the partner; the net force on this lane's sphere is
+      // x_ab - x_ba = s (w_a + w_b) d - pa v_a - pb v_b, and the partner receives the opposite
+      real pa = d[0]*vel[0], pb = d[0]*vo[0];
+      pa = fma(d[1], vel[1], pa); pb = fma(d[1], vo[1], pb);
+      pa = fma(d[2], vel[2], pa); pb = fma(d[2], vo[2], pb);
+      // projections (d . v) s w / |v|^2, zero when that sphere is (nearly) at rest
+      pa = (flags & 2) ? pa * (sdi * wself) * inv_vn2 : (real)0;
+      pb = mo ? pb * (sdi * wo) * ivo : (real)0;
+      const real sboth = sdi * wboth;
 #pragma unroll
       for (int k=0; k<3; k++)
       {
-         // net force on this lane's sphere: x_ab - x_ba
-         const real xab = d[k] * sa - pa * vel[k];
-         const real xba = d[k] * sb - pb * vo[k];
-         const real inc = near ? (xab - xba) : (real)0;
+         const real inc = fma(d[k], sboth, -fma(pa, vel[k], pb * vo[k]));
          f[k] += (K == 8) ? inc : (inc - dpp_move<B>(inc));
       }
    }
@@ -143,6 +142,7 @@ __device__ __forceinline__ void cost_tile_gs16(const DevBatch<real> & b, const M
 
    for (int base_item=0; base_item<items; base_item+=ORC_BLOCK)
    {
+      if (base_item + (tid & ~63) >= items) continue;      // a wavefront without a waypoint in this round (wave-uniform)
       const int item = base_item + tid;
       const int g = item >> 4, s = item & 15;
       const bool lane_ok = (item < items) && (s < Sa);
@@ -192,20 +192,32 @@ __device__ __forceinline__ void cost_tile_gs16(const DevBatch<real> & b, const M
 #pragma unroll
          for (int u=0; u<U; u++)
          {
-            real gp[3], gg[3], val;
+            real gp[3], gg[3], gw[3], val;
+            // field axes = world axes (the field is only translated): the products with 0 and 1 are exact
+            const bool aligned = (__builtin_amdgcn_readfirstlane(F.rot_identity) != 0);
+            if (aligned)
+            {
 #pragma unroll
-            for (int k=0; k<3; k++)
-               gp[k] = F.Rgw[k*3+0]*p[u][0] + F.Rgw[k*3+1]*p[u][1] + F.Rgw[k*3+2]*p[u][2] + F.tgw[k];
+               for (int k=0; k<3; k++) gp[k] = p[u][k] + F.tgw[k];
+            }
+            else
+            {
+#pragma unroll
+               for (int k=0; k<3; k++)
+                  gp[k] = F.Rgw[k*3+0]*p[u][0] + F.Rgw[k*3+1]*p[u][1] + F.Rgw[k*3+2]*p[u][2] + F.tgw[k];
+            }
             const bool inb = sdf_lookup_pred(F, gp, val, gg);
             const bool better = inb && (val < best[u]);           // strict <: HUGE_VAL never wins
             best[u] = better ? val : best[u];
             has[u] = has[u] || better;
-#pragma unroll
-            for (int k=0; k<3; k++)
+            if (aligned) { gw[0] = gg[0]; gw[1] = gg[1]; gw[2] = gg[2]; }
+            else
             {
-               const real gw = F.Rwg[k*3+0]*gg[0] + F.Rwg[k*3+1]*gg[1] + F.Rwg[k*3+2]*gg[2];   // grid -> world
-               bgrad[u][k] = better ? gw : bgrad[u][k];
+#pragma unroll
+               for (int k=0; k<3; k++) gw[k] = F.Rwg[k*3+0]*gg[0] + F.Rwg[k*3+1]*gg[1] + F.Rwg[k*3+2]*gg[2];   // grid -> world
             }
+#pragma unroll
+            for (int k=0; k<3; k++) bgrad[u][k] = better ? gw[k] : bgrad[u][k];
          }
       }
 #endif

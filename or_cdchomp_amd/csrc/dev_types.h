@@ -67,7 +67,7 @@ struct DevSdf
 {
    const real * data;      // C order [x][y][z]
    int size[3];
-   int pad;
+   int rot_identity;       // Rgw == Rwg == I exactly (the field is only translated)
    real length[3];
    real inv_length[3];     // 1/length
    real cell[3];           // length/size
