@@ -39,6 +39,8 @@ N_ITER = 100
 LAMBDA = 100.0
 OBS_FACTOR = 500.0
 HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # half the FP32 vector rate of that guide (157.3 TF): a wave64 fp64 instruction holds a SIMD for 4 cycles
+FLOP_PER_ITERATION = 0.8e6      # SURVEY.md 8(d) "Algorithmic flops", config W
 
 
 def algorithmic_bytes_per_iter(m, n, Sa, n_sdf, w, momentum):
@@ -200,7 +202,13 @@ def main():
                          "kernel": "chomp_iterate_kernel<double>", "avg_kernel_ms": avg_ms, "launches": launches,
                          "concurrent_launches": max(1, args.streams),
                          "algorithmic_bytes_per_launch": bytes_launch,
-                         "algorithmic_bytes_per_iteration_per_run": bytes_iter},
+                         "algorithmic_bytes_per_iteration_per_run": bytes_iter,
+                         # the kernel is bound by the fp64 vector pipe, not by HBM:
+                         # SURVEY.md 8(d) asks for this figure beside the HBM one
+                         "fp64_vector": {"achieved": value * FLOP_PER_ITERATION / 1e12 / world,
+                                         "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                         "frac": value * FLOP_PER_ITERATION / 1e12 / world / FP64_VECTOR_PEAK_TFLOPS,
+                                         "algorithmic_flop_per_iteration_per_run": FLOP_PER_ITERATION}},
             "cpu_baseline": cpu,
             "parity_rel_l2_max_vs_oracle": parity,
             "runs_outside_joint_limits": status_bad,
