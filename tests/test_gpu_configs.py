@@ -160,3 +160,79 @@ def test_joint_limit_status(oracle):
     with pytest.raises(RuntimeError, match="Resulting trajectory is outside of joint limits!"):
         bindings.runchomp(mod, robot=model.name, n_iter=100, lambda_=100.0, obs_factor=500.0, n_points=100,
                           adofgoal=list(goals[k]))
+
+
+def test_wam_with_finger_dofs_tree_row_kernel(oracle):
+    """arm + the three finger joints optimized: a branching joint tree with <= 16 active spheres,
+    i.e. the DPP-row cost phase with saved FK frames, and J^T from wrench range sums (the spheres a
+    finger joint moves are a range of the row that does not end at the last sphere)"""
+    mod = _mk_module()
+    model = common.setup_product_wam(mod)
+    prob = common.tabletop_problem(oracle)
+    _, base, dofvals, _ = common.wam_state()
+    adofs = list(range(10))
+    mod.set_active_dofs(model.name, adofs)
+    n_runs, n_points, n_iter = 6, 70, 30
+    rng = np.random.default_rng(77)
+    lo = np.asarray(model.limit_lower[:10]) + 0.1
+    hi = np.asarray(model.limit_upper[:10]) - 0.1
+    goals = rng.uniform(lo, hi, size=(n_runs, 10))
+    kw = dict(n_points=n_points, lambda_=100.0, obs_factor=300.0)
+    bid = mod.batch_create(model.name, goals, **kw)
+    costs, status = mod.batch_iterate(bid, n_iter)
+    traj = mod.batch_gettraj(bid)
+    mod.batch_destroy(bid)
+    rob = oracle.OraRobot(model)
+    errs = []
+    for k in range(n_runs):
+        run = oracle.OraRun(rob, base, dofvals, adofs, goals[k], [prob["sdf"]], [prob["pose"]], oracle.default_params(**kw))
+        assert run.n == 10 and run.Sa == 15
+        st, ocosts = run.iterate(n_iter)
+        assert st == status[k]
+        if st == 0:
+            errs.append(common.rel_l2(traj[k], run.traj()))
+            assert np.allclose(costs[k], ocosts, rtol=1e-6, atol=0), (costs[k], ocosts)
+        run.destroy()
+    assert errs and max(errs) <= 1e-6, errs
+    print("wam + fingers (tree, 15 spheres) worst rel L2 %.3e" % max(errs))
+
+
+def test_two_link_arm_single_tile(oracle):
+    """a 2-dof arm with 3 spheres: the whole trajectory is one tile (FK in two passes of 64
+    waypoints), the sparse joint-limit rounds run with 128 rows per slice, most row lanes are empty"""
+    mod = _mk_module()
+    model = robots.RobotModel("twolink")
+    R = robots.JOINT_REVOLUTE
+    model.add_link("base")
+    model.add_link("upper", "base", (0, 0, 0.8), joint=R, axis=(0, 1, 0), limits=(-1.2, 1.2))
+    model.add_link("fore", "upper", (0.4, 0, 0), joint=R, axis=(0, 1, 0), limits=(-2.0, 0.3))
+    model.add_sphere("upper", (0.2, 0, 0), 0.07)
+    model.add_sphere("fore", (0.15, 0, 0), 0.06)
+    model.add_sphere("fore", (0.35, 0, 0), 0.05)
+    base = [-0.9, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0]
+    dofvals = np.array([-1.0, 0.2])
+    adofs = [0, 1]
+    mod.add_robot(model, transform=base, dof_values=dofvals, active_dofs=adofs)
+    scenes.add_tabletop(mod)
+    mod.SendCommand("computedistancefield kinbody table")
+    prob = common.tabletop_problem(oracle)
+    n_runs, n_points, n_iter = 5, 100, 60
+    goals = np.random.default_rng(9).uniform([0.2, -1.9], [1.1, 0.2], size=(n_runs, 2))
+    kw = dict(n_points=n_points, lambda_=20.0, obs_factor=200.0)
+    bid = mod.batch_create(model.name, goals, **kw)
+    costs, status = mod.batch_iterate(bid, n_iter)
+    traj = mod.batch_gettraj(bid)
+    mod.batch_destroy(bid)
+    rob = oracle.OraRobot(model)
+    errs = []
+    for k in range(n_runs):
+        run = oracle.OraRun(rob, base, dofvals, adofs, goals[k], [prob["sdf"]], [prob["pose"]], oracle.default_params(**kw))
+        assert run.n == 2 and run.Sa == 3
+        st, ocosts = run.iterate(n_iter)
+        assert st == status[k]
+        if st == 0:
+            errs.append(common.rel_l2(traj[k], run.traj()))
+            assert np.allclose(costs[k], ocosts, rtol=1e-6, atol=0), (costs[k], ocosts)
+        run.destroy()
+    assert errs and max(errs) <= 1e-6, errs
+    print("two-link arm worst rel L2 %.3e" % max(errs))
