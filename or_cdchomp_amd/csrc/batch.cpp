@@ -44,6 +44,112 @@ real * upload(const std::vector<double> & v, hipStream_t s)
 
 void dev_free(void * p) { if (p) hipFree(p); }
 
+// Placement of the active spheres (given by XML index, sorted by joint) on the 16 lanes of a DPP
+// row.  Rotation K of the self-collision term costs its force evaluation whenever some pair of
+// spheres K lanes apart is within range in any of the four waypoints of a wavefront; pairs are
+// within range mostly for structural reasons (neighbouring links, a hand's fingers), so their
+// frequencies are estimated from configurations on the batch's own seed lines (line_q: values of the
+// active dofs, topped up with random ones when the batch is small) and a seeded annealing run looks
+// for the placement with the fewest expected evaluations.  Returns slot[k] for the k-th
+// sphere; the identity when nothing better than the sorted order is found.  Purely a performance
+// choice: every pair is visited exactly once whatever the placement.
+std::vector<int> place_spheres_on_row(const Robot & robot, const std::vector<double> & line_q, double eps_self, const std::vector<int> & xml)
+{
+   const int Sa = (int) xml.size();
+   std::vector<int> ident(Sa);
+   for (int s=0; s<Sa; s++) ident[s] = s;
+   if (Sa > 16) return ident;
+   unsigned long long rng = 0x9E3779B97F4A7C15ull;
+   auto next = [&rng]() { rng = rng * 6364136223846793005ull + 1442695040888963407ull; return (double)(rng >> 11) * (1.0 / 9007199254740992.0); };
+   // frequencies of "within range" per pair
+   const int n_adof = (int) robot.active_dofs.size();
+   const int n_line = n_adof ? (int)(line_q.size() / n_adof) : 0;
+   const int n_samples = (n_line >= 32) ? n_line : n_line + 64;
+   std::vector<double> freq((size_t) Sa * Sa, 0.0);
+   std::vector<double> q = robot.dof_values;
+   std::vector<Xform> frames;
+   std::vector<double> pw((size_t) Sa * 3);
+   for (int it=0; it<n_samples; it++)
+   {
+      for (int j=0; j<n_adof; j++)
+      {
+         const int d = robot.active_dofs[j];
+         if (it < n_line) { q[d] = line_q[(size_t) it*n_adof + j]; continue; }
+         double lo = robot.limit_lower[d], hi = robot.limit_upper[d];
+         if (!(lo > -1e30)) lo = -3.14159265358979;
+         if (!(hi < 1e30)) hi = 3.14159265358979;
+         q[d] = lo + (hi - lo) * next();
+      }
+      robot.fk(robot.transform, q, frames);
+      for (int s=0; s<Sa; s++)
+      {
+         const Robot::Sphere & sp = robot.spheres[xml[s]];
+         double r[3];
+         mat3_vec(frames[sp.link].R, sp.pos, r);
+         for (int k=0; k<3; k++) pw[(size_t) s*3+k] = r[k] + frames[sp.link].t[k];
+      }
+      for (int a=0; a<Sa; a++) for (int b=a+1; b<Sa; b++)
+      {
+         const Robot::Sphere & sa = robot.spheres[xml[a]], & sb = robot.spheres[xml[b]];
+         if (sa.link == sb.link) continue;
+         double d2 = 0;
+         for (int k=0; k<3; k++) { const double d = pw[(size_t) a*3+k] - pw[(size_t) b*3+k]; d2 += d*d; }
+         const double R = sa.radius + sb.radius + eps_self;
+         if (d2 <= R*R) freq[(size_t) a*Sa+b] += 1.0 / n_samples;
+      }
+   }
+   struct Pair { int a, b; double keep; };      // keep = probability that none of 4 waypoints has the pair in range
+   std::vector<Pair> pairs;
+   for (int a=0; a<Sa; a++) for (int b=a+1; b<Sa; b++)
+      if (freq[(size_t) a*Sa+b] > 0.0)
+      {
+         const double f = freq[(size_t) a*Sa+b];
+         pairs.push_back({ a, b, (1-f)*(1-f)*(1-f)*(1-f) });
+      }
+   auto cost = [&](const std::vector<int> & slot) {
+      double none[9];
+      for (int K=0; K<9; K++) none[K] = 1.0;
+      for (const Pair & p : pairs)
+      {
+         int d = slot[p.a] - slot[p.b]; if (d < 0) d = -d; if (d > 8) d = 16 - d;
+         none[d] *= p.keep;
+      }
+      double c = 0;
+      for (int K=1; K<=8; K++) c += 1.0 - none[K];
+      return c;
+   };
+   const double c_ident = cost(ident);
+   std::vector<int> best = ident; double c_best = c_ident;
+   for (int restart=0; restart<16; restart++)
+   {
+      // random start: a shuffle of the 16 slots
+      int slots[16];
+      for (int k=0; k<16; k++) slots[k] = k;
+      for (int k=15; k>0; k--) { const int j = (int)(next() * (k+1)); std::swap(slots[k], slots[j]); }
+      std::vector<int> cur(slots, slots + Sa);
+      double c_cur = cost(cur), T = 0.5;
+      for (int it=0; it<8000; it++, T *= 0.9993)
+      {
+         std::vector<int> cand = cur;
+         const int i = (int)(next() * Sa);
+         const int target = (int)(next() * 16);                 // a slot: swap with its owner, or move there if free
+         int owner = -1;
+         for (int k=0; k<Sa; k++) if (cand[k] == target) owner = k;
+         if (owner >= 0) std::swap(cand[i], cand[owner]); else cand[i] = target;
+         const double c = cost(cand);
+         if (c < c_cur || next() < std::exp((c_cur - c) / T)) { cur.swap(cand); c_cur = c; }
+         if (c_cur < c_best) { c_best = c_cur; best = cur; }
+      }
+   }
+   if (getenv("ORC_DEBUG_PLAN"))
+   {
+      fprintf(stderr, "orc placement: expected force evaluations per wavefront pass %.2f sorted -> %.2f placed; slots", c_ident, c_best);
+      for (int s=0; s<Sa; s++) fprintf(stderr, " %d", best[s]);
+      fprintf(stderr, "\n");
+   }
+   return (c_best < c_ident - 0.25) ? best : ident;
+}
+
 hipError_t launch_typed(const DevBatch<double> & b, size_t lds, hipStream_t s, int tree) { return orc_launch_iterate_f64(b, lds, s, tree); }
 hipError_t launch_typed(const DevBatch<float> & b, size_t lds, hipStream_t s, int tree) { return orc_launch_iterate_f32(b, lds, s, tree); }
 
@@ -73,6 +179,19 @@ Batch::Batch(Module * mod, const Robot & robot, const BatchParams & p, int nruns
    }
 
    build_metric(m, p.derivative, 1.0/(n_points-1), metric_);       // dt: mod.cpp:2567
+
+   // configurations on the seed lines of (up to 48 of) the runs: what place_spheres_on_row samples
+   placement_q_.clear();
+   for (int i=0, cnt=(n_runs < 48 ? n_runs : 48); i<cnt; i++)
+   {
+      const size_t k = (size_t) i * n_runs / cnt;
+      for (int f=0; f<=5; f++)
+         for (int j=0; j<n_adof; j++)
+         {
+            const double a = starts ? starts[k*n_adof+j] : robot.dof_values[robot.active_dofs[j]];
+            placement_q_.push_back(a + (goals[k*n_adof+j] - a) * (f / 5.0));
+         }
+   }
 
    if (p.precision == 64) build_device<double>(robot); else build_device<float>(robot);
 
@@ -340,6 +459,42 @@ void Batch::build_device(const Robot & robot)
       if (count > 0 && J.aff_end != Sa) M.jt_scan = 2;
    }
    if (getenv("ORC_NO_JT_SCAN")) M.jt_scan = 0;      // experiments: per-joint reductions
+   // Lanes of the DPP row.  The self-collision term walks the row in rotations 1..8 and evaluates
+   // the forces of a rotation only when some pair at that lane distance is in range, so the spheres
+   // are placed on the 16 lanes such that the pairs that are usually in range share few distances
+   // (place_spheres_on_row).  Everything indexed by lane (pos, radius, link, affects) is in slot
+   // order; FK and the J^T ranges keep the order sorted by joint and go through slot_of.
+   std::vector<int> slot_of(Sa);
+   for (int s=0; s<Sa; s++) slot_of[s] = s;
+   int lanes = Sa;
+   bool is_placed = false;
+   if (M.GS == 16 && Sa >= 4 && !getenv("ORC_NO_PLACEMENT"))
+   {
+      std::vector<int> xml_of(Sa);
+      for (int s=0; s<Sa; s++) xml_of[s] = act[s].xml;
+      std::string key = robot.name + (params.floating_base ? "|f|" : "|a|") + std::to_string(params.epsilon_self);
+      for (int d : robot.active_dofs) key += "," + std::to_string(d);
+      auto hit = mod_->placement_cache.find(key);
+      if (hit == mod_->placement_cache.end() || (int) hit->second.size() != Sa)
+         hit = mod_->placement_cache.insert_or_assign(key, place_spheres_on_row(robot, placement_q_, params.epsilon_self, xml_of)).first;
+      const std::vector<int> & placed = hit->second;
+      bool ident = true;
+      for (int s=0; s<Sa; s++) if (placed[s] != s) ident = false;
+      if (!ident) { slot_of = placed; lanes = 16; is_placed = true; }
+   }
+   {
+      std::vector<real> rad(Sa); std::vector<int> link(Sa); std::vector<unsigned long long> aff(Sa);
+      for (int s=0; s<Sa; s++) { rad[s] = M.sph_radius[s]; link[s] = M.sph_link[s]; aff[s] = M.sph_affects[s]; }
+      for (int q=0; q<lanes; q++) { M.sph_radius[q] = (real) 0; M.sph_link[q] = -1000 - q; M.sph_affects[q] = 0ull; }
+      M.live_mask = 0ull; M.placed = is_placed ? 1 : 0;
+      for (int s=0; s<Sa; s++)
+      {
+         const int q = slot_of[s];
+         M.slot_of[s] = q; M.sph_radius[q] = rad[s]; M.sph_link[q] = link[s]; M.sph_affects[q] = aff[s];
+         M.live_mask |= (1ull << q);
+      }
+   }
+   M.Sa_real = Sa; M.Sa = lanes; M.S = lanes + (int) inact.size();
    for (int s=0; s<(int) inact.size(); s++)
    {
       const Robot::Sphere & sp = robot.spheres[inact[s].xml];
@@ -347,11 +502,11 @@ void Batch::build_device(const Robot & robot)
       double pw[3];
       mat3_vec(lf.R, sp.pos, pw);                                    // mod.cpp:2332-2345
       for (int q=0; q<3; q++) M.sph_inactive_pos[s][q] = (real)(pw[q] + lf.t[q]);
-      M.sph_radius[Sa+s] = (real) sp.radius;
-      M.sph_link[Sa+s] = sp.link;
+      M.sph_radius[lanes+s] = (real) sp.radius;
+      M.sph_link[lanes+s] = sp.link;
       device_sphere_order.push_back(inact[s].xml);
    }
-   nj_ = nj; Sa_ = Sa; tree_ = M.tree | ((M.GS == 16) ? 2 : 0);     // kernel variant bits
+   nj_ = nj; Sa_ = lanes; S_ = lanes + (int) inact.size(); tree_ = M.tree | ((M.GS == 16) ? 2 : 0);     // kernel variant bits
 
    hipStream_t st = stream_;
    DevModel<real> * dm = dev_alloc<DevModel<real>>(1);
@@ -457,7 +612,7 @@ void Batch::build_device(const Robot & robot)
          for (int t=(m < ORC_BLOCK - 2 ? m : ORC_BLOCK - 2); t>=1; t--)
          {
             if (force_t > 0 && t != force_t) continue;
-            const size_t need = orc_chomp_lds_bytes(n_points, n, Sa, S, nj, t, with_pcr ? pcr_rows : 0, sizeof(real), params.use_momentum, n_sdfs_);
+            const size_t need = orc_chomp_lds_bytes(n_points, n, Sa_, S_, nj, t, with_pcr ? pcr_rows : 0, sizeof(real), params.use_momentum, n_sdfs_);
             if (need > budget) continue;
             const int tiles = (m + t - 1) / t;
             if (tiles < best_tiles) { best_tiles = tiles; best_t = t; best_pcr = with_pcr; }
@@ -467,7 +622,7 @@ void Batch::build_device(const Robot & robot)
       if (best_t)
       {
          tile_m_ = best_t; pcr_in_lds_ = best_pcr;
-         lds_bytes_ = orc_chomp_lds_bytes(n_points, n, Sa, S, nj, best_t, best_pcr ? pcr_rows : 0, sizeof(real), params.use_momentum, n_sdfs_);
+         lds_bytes_ = orc_chomp_lds_bytes(n_points, n, Sa_, S_, nj, best_t, best_pcr ? pcr_rows : 0, sizeof(real), params.use_momentum, n_sdfs_);
       }
    }
    if (!tile_m_) throw std::runtime_error("run does not fit the LDS of one CU!");

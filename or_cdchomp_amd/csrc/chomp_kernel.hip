@@ -517,6 +517,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
    int * slink_s = (int *)(smem_raw + L.ints_bytes);    // [S] link of each sphere
    int * jtype_s = slink_s + S;                         // [nj]
    int * jcol_s = jtype_s + nj;                         // [nj]
+   int * slot_s = jcol_s + nj;                          // [Sa_real] slot of the k-th active sphere (sorted order)
    real * sphpos_s = pcr_s + (((b.pcr_in_lds ? b.pcr_rows : 0)*m + 3) & ~3);   // [Sa][3] + base frame [12]
    real * base_s = sphpos_s + Sa*3;
    DevJoint<real> * joints_s = (DevJoint<real> *)(smem_raw + L.joints_bytes);
@@ -524,6 +525,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
    unsigned long long * saff_s = (unsigned long long *)(smem_raw + L.saff_bytes);
    ModelView<real> mod;
    mod.nj = nj; mod.n = n; mod.floating = gmod.floating; mod.tree = gmod.tree; mod.Sa = Sa; mod.S = S; mod.GS = GS; mod.jt_scan = gmod.jt_scan;
+   mod.Sa_real = gmod.Sa_real; mod.placed = gmod.placed; mod.live_mask = gmod.live_mask; mod.slot_of = slot_s;
    mod.base_sph_begin = gmod.base_sph_begin; mod.base_sph_end = gmod.base_sph_end;
    mod.base_R = base_s; mod.base_t = base_s + 9;
    mod.joints = joints_s; mod.sph_pos = (const real (*)[3]) sphpos_s; mod.sph_affects = saff_s;
@@ -537,6 +539,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
    for (int e=tid; e<(S-Sa)*3; e+=ORC_BLOCK) sinact_s[e] = gmod.sph_inactive_pos[e/3][e%3];
    for (int e=tid; e<nj; e+=ORC_BLOCK) { jtype_s[e] = gmod.joints[e].type; jcol_s[e] = gmod.joints[e].col; }
    for (int e=tid; e<Sa*3; e+=ORC_BLOCK) sphpos_s[e] = gmod.sph_pos[e/3][e%3];
+   for (int e=tid; e<gmod.Sa_real; e+=ORC_BLOCK) slot_s[e] = gmod.slot_of[e];
    for (int e=tid; e<Sa; e+=ORC_BLOCK) saff_s[e] = gmod.sph_affects[e];
    for (int e=tid; e<12; e+=ORC_BLOCK) base_s[e] = (e < 9) ? gmod.base_R[e] : gmod.base_t[e-9];
    {
@@ -563,7 +566,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
       // self-collision term; -1: the pair never counts (same link, or a lane without a sphere).
       // The partner's identity comes through the same DPP rotation the cost phase uses.
       const int srow = tid & 15;
-      const bool has = (srow < Sa);
+      const bool has = ((gmod.live_mask >> srow) & 1ull) != 0;
       const real rad = has ? srad_s[srow] : (real)0;
       const int link = has ? slink_s[srow] : -1 - srow;
 #define ORC_R2(K) do { \
@@ -571,7 +574,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
          const real ro_ = dpp_move<0x120 + K>(rad); \
          const int lo_ = dpp_move<0x120 + K>(link); \
          const real R_ = rad + ro_ + b.epsilon_self; \
-         if (tid < 16) r2_s[(K-1)*16 + srow] = (has && sp_ < Sa && lo_ != link) ? R_ * R_ : (real)(-1); \
+         if (tid < 16) r2_s[(K-1)*16 + srow] = (has && ((gmod.live_mask >> sp_) & 1ull) && lo_ != link) ? R_ * R_ : (real)(-1); \
       } while (0)
       ORC_R2(1); ORC_R2(2); ORC_R2(3); ORC_R2(4); ORC_R2(5); ORC_R2(6); ORC_R2(7); ORC_R2(8);
 #undef ORC_R2

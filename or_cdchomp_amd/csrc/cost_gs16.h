@@ -101,7 +101,7 @@ __device__ __forceinline__ void self_sym_step16(const real * prow, const real * 
    const real de = dist - eps_self;
    const real cself = (dist < (real)0) ? ((real)0.5 * eps_self - dist) : ((real)0.5 * inv_eps_self) * de * de;
    const real scale = (dist < (real)0) ? (real)(-1) : ((dist < eps_self) ? dist * inv_eps_self - (real)1 : (real)1);
-   const real sdi = near ? scale * inv_d : (real)0;        // out of range: every force term below vanishes
+   const real sdi = scale * inv_d;
    const real wboth = wself + wo;
    const real wsum = (K == 8) ? wself : wboth;             // rotation 8: the partner adds its own side of the cost
    cost_sphere += near ? (double)(wsum * cself) : 0.0;
@@ -120,7 +120,8 @@ __device__ __forceinline__ void self_sym_step16(const real * prow, const real * 
 #pragma unroll
       for (int k=0; k<3; k++)
       {
-         const real inc = fma(d[k], sboth, -fma(pa, vel[k], pb * vo[k]));
+         // (selected, not multiplied by zero: lanes without a pair may hold anything, an empty slot's centre included)
+         const real inc = near ? fma(d[k], sboth, -fma(pa, vel[k], pb * vo[k])) : (real)0;
          f[k] += (K == 8) ? inc : (inc - dpp_move<B>(inc));
       }
    }
@@ -145,7 +146,7 @@ __device__ __forceinline__ void cost_tile_gs16(const DevBatch<real> & b, const M
       if (base_item + (tid & ~63) >= items) continue;      // a wavefront without a waypoint in this round (wave-uniform)
       const int item = base_item + tid;
       const int g = item >> 4, s = item & 15;
-      const bool lane_ok = (item < items) && (s < Sa);
+      const bool lane_ok = (item < items) && (((mod.live_mask >> s) & 1ull) != 0);
       const int ss = lane_ok ? s : 0;           // dead lanes read sphere 0 (valid memory), results masked
       const real radius = srad_s[ss];
       const int mylink = lane_ok ? slink_s[ss] : -1 - s;
@@ -336,6 +337,19 @@ __device__ __forceinline__ void cost_tile_gs16(const DevBatch<real> & b, const M
          }
          if (mod.jt_scan)
          {
+            if (mod.placed)
+            {
+               // the scan runs over the spheres sorted by joint: lane i takes the wrench of the i-th of them
+               const int src = (s < mod.Sa_real) ? mod.slot_of[s] : s;
+#pragma unroll
+               for (int u=0; u<U; u++)
+#pragma unroll
+                  for (int k=0; k<6; k++)
+                  {
+                     const real v = __shfl(w6[u][k], src, 16);
+                     w6[u][k] = (s < mod.Sa_real) ? v : (real)0;
+                  }
+            }
 #pragma unroll
             for (int u=0; u<U; u++)
 #pragma unroll

@@ -45,8 +45,12 @@ struct DevModel
    int n;                  // optimizer dofs = 7*floating + n_adof
    int floating;           // floating base: columns 0..6 are the base pose
    int tree;               // the joint tree branches (frames are saved/restored while walking it)
-   int Sa;                 // active spheres (device order: sorted by joint)
-   int S;                  // all spheres
+   int Sa;                 // lanes of the active block: active spheres, or 16 slots when the spheres are placed (see slot_of)
+   int S;                  // Sa + inactive spheres
+   int Sa_real;            // active spheres (sorted by the joint they ride on: the order of sph_pos, J^T ranges, slot_of)
+   int placed;             // slot_of is not the identity
+   unsigned long long live_mask;   // bit s: lane/slot s of the active block holds a sphere
+   int slot_of[ORC_MAX_SPHERES];   // sorted index -> slot (lane of the DPP row / index of pos, sph_radius, sph_link, sph_affects)
    int GS;                 // lanes per waypoint in the cost phase (power of two >= Sa)
    int base_sph_begin;     // active spheres fixed to the base frame (floating base only)
    int base_sph_end;
@@ -54,7 +58,7 @@ struct DevModel
    real base_R[9];         // base frame when not floating
    real base_t[3];
    DevJoint<real> joints[ORC_MAX_JOINTS];
-   real sph_pos[ORC_MAX_SPHERES][3];     // active: in the attach frame; unused for inactive
+   real sph_pos[ORC_MAX_SPHERES][3];     // active, SORTED order: in the attach frame
    real sph_radius[ORC_MAX_SPHERES];
    int sph_link[ORC_MAX_SPHERES];        // robot link index (same-link test)
    unsigned long long sph_affects[ORC_MAX_SPHERES]; // bit j: joint j moves the sphere
@@ -143,7 +147,9 @@ struct LdsLayout
 template <typename real>
 struct ModelView
 {
-   int nj, n, floating, tree, Sa, S, GS, base_sph_begin, base_sph_end, jt_scan;
+   int nj, n, floating, tree, Sa, S, GS, base_sph_begin, base_sph_end, jt_scan, Sa_real, placed;
+   unsigned long long live_mask;
+   const int * slot_of;                    // [Sa_real]
    const real * base_R;                    // [9]
    const real * base_t;                    // [3]
    const DevJoint<real> * joints;          // [nj]
@@ -183,7 +189,7 @@ inline LdsLayout lds_layout(int np, int n, int Sa, int S, int nj, int tile_m, in
    (void) take(Sa*3 + 12);                 // staged sphere local positions + base frame (after pcr)
    L.end_reals = o;
    L.ints_bytes = 128 + o*real_size;
-   int bytes = L.ints_bytes + (S + 2*nj + 4) * (int) sizeof(int);
+   int bytes = L.ints_bytes + (S + 2*nj + 4 + Sa) * (int) sizeof(int);     // slink, jtype, jcol, slot_of
    bytes = (bytes + 15) & ~15;
    L.joints_bytes = bytes; bytes += nj * joint_size; bytes = (bytes + 15) & ~15;
    L.sdfs_bytes = bytes;   bytes += n_sdfs * sdf_size; bytes = (bytes + 15) & ~15;

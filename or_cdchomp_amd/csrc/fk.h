@@ -115,7 +115,7 @@ __device__ __forceinline__ void fk_joint_row(const ModelView<real> & mod, const 
    {
       const real * lp = mod.sph_pos[s];
       const real o = cur.r[0]*lp[0] + cur.r[1]*lp[1] + cur.r[2]*lp[2] + cur.t;
-      if (store) pos_k[s*3] = o;
+      if (store) pos_k[mod.slot_of[s]*3] = o;
    }
 #endif
 }
@@ -146,7 +146,7 @@ __device__ __forceinline__ void fk_waypoint_quad(const ModelView<real> & mod, co
       {
          const real * lp = mod.sph_pos[s];
          const real o = base.r[0]*lp[0] + base.r[1]*lp[1] + base.r[2]*lp[2] + base.t;
-         if (store) pos_k[s*3] = o;
+         if (store) pos_k[mod.slot_of[s]*3] = o;
       }
    }
    else

@@ -113,11 +113,12 @@ private:
    int max_resamples_ = 0;
    bool debug_state_ = false;   // ORC_DEBUG_STATE=1: keep the last gradient readable (get_state "G")
    int n_sdfs_ = 0;
-   int nj_ = 0, Sa_ = 0;
+   int nj_ = 0, Sa_ = 0, S_ = 0;      // optimized joints; lanes of the active sphere block; lanes + inactive spheres
    int tile_m_ = 0;
    int pcr_in_lds_ = 0;
    int tree_ = 0;
    int pcr_rows_ = 0, pcr_sym_ = 0;
+   std::vector<double> placement_q_;   // [samples][n_adof] configurations on the seed lines (sphere placement)
    size_t lds_bytes_ = 0;
    std::vector<double> jl_lo_, jl_hi_;
    // hmc host state per run (src/orcdchomp_mod.cpp:948-952)
@@ -147,6 +148,10 @@ public:
    void add_sdf(const std::string & kinbody, const Grid & sdf, const Pose & pose_kinbody_gsdf);
    Sdf * find_sdf(const std::string & kinbody);
    std::vector<std::unique_ptr<Sdf>> sdfs;
+
+   // lane placement of a robot's active spheres (place_spheres_on_row), found once per
+   // (robot, active dofs, floating base, epsilon_self) from the first batch's seed lines
+   std::map<std::string, std::vector<int>> placement_cache;
 
    // batches
    int create_batch(const std::string & robot, const BatchParams & p, int n_runs,
