@@ -611,7 +611,7 @@ void Batch::build_device(const Robot & robot)
          if (force_pcr >= 0 && with_pcr != force_pcr && pcr_rows) continue;
          for (int t=(m < ORC_BLOCK - 2 ? m : ORC_BLOCK - 2); t>=1; t--)
          {
-            if (force_t > 0 && t != force_t) continue;
+            if (force_t > 0 && t != (force_t < m ? force_t : m)) continue;
             const size_t need = orc_chomp_lds_bytes(n_points, n, Sa_, S_, nj, t, with_pcr ? pcr_rows : 0, sizeof(real), params.use_momentum, n_sdfs_);
             if (need > budget) continue;
             const int tiles = (m + t - 1) / t;
