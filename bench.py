@@ -17,7 +17,7 @@ prices the fused iterate kernel against HBM with the ALGORITHMIC bytes of
 SURVEY.md 8(d) (58 040 B per iteration per run for this workload); the kernel
 duration is measured live with HIP events on the stream the kernel is launched
 on.  The steps are independent batches and are issued round-robin on `--streams`
-HIP streams (default 2) so that the tail of one launch overlaps the next; the
+HIP streams (default 3) so that the tail of one launch overlaps the next; the
 per-launch duration (and with it `roofline.achieved`) is that of a launch that
 shares the GPU with its neighbour.  `cpu_baseline` times the oracle (oracle/, a CPU restatement of the reference)
 on the host cores over a bounded sample of the same workload.
@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1024, help="runs per GPU (configs[1]: 1024)")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams the steps are issued on round-robin: consecutive steps are independent batches, "
                          "so the tail of one launch (a few slow runs) is filled by the next; 1 = strictly serial launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -201,6 +201,9 @@ def main():
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": "chomp_iterate_kernel<double>", "avg_kernel_ms": avg_ms, "launches": launches,
                          "concurrent_launches": max(1, args.streams),
+                         # all overlapping launches together: algorithmic bytes of the K steps / their wall time
+                         "aggregate_achieved": value / world * bytes_iter / 1e9,
+                         "aggregate_frac": value / world * bytes_iter / 1e9 / HBM_PEAK_GBPS,
                          "algorithmic_bytes_per_launch": bytes_launch,
                          "algorithmic_bytes_per_iteration_per_run": bytes_iter,
                          # the kernel is bound by the fp64 vector pipe, not by HBM:

@@ -567,8 +567,14 @@ void Batch::build_device(const Robot & robot)
    d_Aband_ = upload<real>(metric_.Aband, st);
    d_beta_s_ = upload<real>(metric_.beta_s, st);
    d_beta_g_ = upload<real>(metric_.beta_g, st);
+   // A^-1: closed-form Toeplitz inverse through two wave scans per column when the metric is
+   // ca tridiag(-1,2,-1) (derivative 1), else cyclic reduction (tridiagonal) or the dense inverse
+   solve_mode_ = (params.derivative == 1) ? 0 : 1;
+   if (params.derivative == 1 && m <= 64*ORC_SCAN_RPL && metric_.Aband.size() == (size_t) 3*m
+       && (m < 2 || metric_.Aband[(size_t) 1*m] == -2.0 * metric_.Aband[(size_t) 2*m]) && !getenv("ORC_NO_SCAN_SOLVE"))
+      solve_mode_ = 2;
    pcr_rows_ = 0;
-   if (!metric_.pcr.empty())
+   if (!metric_.pcr.empty() && solve_mode_ == 0)
    {
       if (metric_.pcr_sym && !getenv("ORC_PCR_FULL"))
       {
@@ -712,7 +718,7 @@ void Batch::launch(int n_iter)
    b.use_momentum = params.use_momentum; b.use_hmc = params.use_hmc && max_resamples_ > 0; b.D = params.derivative;
    b.Aband = (const real *) d_Aband_; b.beta_s = (const real *) d_beta_s_; b.beta_g = (const real *) d_beta_g_;
    b.kss = metric_.kss; b.ksg = metric_.ksg; b.kgg = metric_.kgg;
-   b.solve_mode = (params.derivative == 1) ? 0 : 1;
+   b.solve_mode = solve_mode_;
    b.pcr_levels = metric_.pcr_levels;
    b.pcr = (const real *) d_pcr_; b.Ainv = (const real *) d_Ainv_;
    b.jl_lo = (const real *) d_jl_lo_; b.jl_hi = (const real *) d_jl_hi_;

@@ -450,9 +450,90 @@ __device__ __forceinline__ real * dense_solve(const DevBatch<real> & b, real * s
    return tmp;
 }
 
+// inclusive prefix / suffix sums over the 64 lanes of a wavefront: Kogge-Stone inside the 16-lane
+// DPP rows, then the row totals through v_readlane (no LDS, no barrier)
+template <typename real>
+__device__ __forceinline__ real wave_prefix_incl(real v)
+{
+   v += dpp_move<0x111>(v);      // row_shr:1 (lane i takes lane i-1, 0 before the row)
+   v += dpp_move<0x112>(v);
+   v += dpp_move<0x114>(v);
+   v += dpp_move<0x118>(v);
+   const real t0 = read_lane(v, 15), t1 = read_lane(v, 31), t2 = read_lane(v, 47);
+   const int row = (threadIdx.x & 63) >> 4;
+   real add = (row >= 1) ? t0 : (real)0;
+   add += (row >= 2) ? t1 : (real)0;
+   add += (row >= 3) ? t2 : (real)0;
+   return v + add;
+}
+template <typename real>
+__device__ __forceinline__ real wave_suffix_incl(real v)
+{
+   v += dpp_move<0x101>(v);      // row_shl:1 (lane i takes lane i+1, 0 past the row)
+   v += dpp_move<0x102>(v);
+   v += dpp_move<0x104>(v);
+   v += dpp_move<0x108>(v);
+   const real t1 = read_lane(v, 16), t2 = read_lane(v, 32), t3 = read_lane(v, 48);
+   const int row = (threadIdx.x & 63) >> 4;
+   real add = (row <= 2) ? t3 : (real)0;
+   add += (row <= 1) ? t2 : (real)0;
+   add += (row <= 0) ? t1 : (real)0;
+   return v + add;
+}
+
+// x = A^-1 g in place for the tridiagonal Toeplitz metric A = ca tridiag(-1, 2, -1) (derivative 1),
+// all n columns of buf [m][n].  The inverse is known in closed form,
+//    Ainv[i][v] = (min(i,v)+1) (m - max(i,v)) / ((m+1) ca),
+// so x_i = kinv ( (m-i) sum_{v<=i} (v+1) g_v  +  (i+1) sum_{v>i} (m-v) g_v ): one prefix and one
+// suffix sum per column.  A wavefront owns a column at a time, a lane `rpl` consecutive rows
+// (m <= 64 ORC_SCAN_RPL); the sums across lanes are wave scans, so the whole solve costs one barrier
+// where cyclic reduction costs one per level.  (The reference multiplies by the dense inverse,
+// src/libcd/chomp.c:525-548: the same products, summed in another order.)
+template <typename real>
+__device__ __forceinline__ real * toeplitz_scan_solve(const DevBatch<real> & b, real * buf)
+{
+   const int m = b.m, n = b.n;
+   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+   const int rpl = (m + 63) >> 6;
+   const real kinv = (real)(-1) / ((real)(m + 1) * b.a_off);      // 1/((m+1) ca), ca = -a_off
+   for (int c=wave; c<n; c+=ORC_BLOCK/64)
+   {
+      real g[ORC_SCAN_RPL], wp[ORC_SCAN_RPL], wq[ORC_SCAN_RPL];
+      real sp = 0, sq = 0;
+#pragma unroll
+      for (int r=0; r<ORC_SCAN_RPL; r++)
+      {
+         const int row = lane*rpl + r;
+         const bool valid = (r < rpl) && (row < m);
+         g[r] = valid ? buf[row*n + c] : (real)0;
+         wp[r] = (real)(row + 1); wq[r] = (real)(m - row);
+         sp += g[r] * wp[r];
+         sq += g[r] * wq[r];
+      }
+      // sums over the lanes before / after this one
+      const real ip = wave_prefix_incl(sp), is = wave_suffix_incl(sq);
+      real run_p = __shfl_up(ip, 1, 64);   if (lane == 0) run_p = 0;
+      real run_q = __shfl_down(is, 1, 64); if (lane == 63) run_q = 0;
+      real q[ORC_SCAN_RPL];
+#pragma unroll
+      for (int r=ORC_SCAN_RPL-1; r>=0; r--) { q[r] = run_q; run_q += g[r] * wq[r]; }      // rows after row r
+#pragma unroll
+      for (int r=0; r<ORC_SCAN_RPL; r++)
+      {
+         const int row = lane*rpl + r;
+         run_p += g[r] * wp[r];                                                             // rows up to row r
+         const real x = kinv * (wq[r] * run_p + wp[r] * q[r]);
+         if ((r < rpl) && (row < m)) buf[row*n + c] = x;
+      }
+   }
+   __syncthreads();
+   return buf;
+}
+
 template <typename real>
 __device__ __forceinline__ real * metric_solve(const DevBatch<real> & b, const real * tab, real * src, real * tmp)
 {
+   if (b.solve_mode == 2) return toeplitz_scan_solve(b, src);
    return b.solve_mode == 0 ? pcr_solve(b, tab, src, tmp) : dense_solve(b, src, tmp);
 }
 
@@ -936,7 +1017,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
          // joint-limit projection (chomp.c:608-655)
          int num_limadjs = 0;
          bool lim_done = false;
-         if (b.D == 1 && b.solve_mode == 0 && n <= 64 && m <= 4*(ORC_BLOCK / n))
+         if (b.D == 1 && b.solve_mode != 1 && n <= 64 && m <= 4*(ORC_BLOCK / n))
             lim_done = limit_rounds_sparse<real, 4>(b, T_s, jl_s, smem_raw + L.lim_bytes, m, n, num_limadjs, (b.phase_cycles && tid == 0) ? &ph[7] : nullptr);
          if (!lim_done)
          for (; num_limadjs<1000; num_limadjs++)
@@ -971,7 +1052,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
             //    Ainv[i][k] = (min(i,k)+1) (m - max(i,k)) / ((m+1) ca),   A = ca tridiag(-1,2,-1),
             // so GA is a short sum per element instead of a full solve.
             bool sparse_done = false;
-            if (b.D == 1 && b.solve_mode == 0)
+            if (b.D == 1 && b.solve_mode != 1)
             {
                const int K = (mn + ORC_BLOCK - 1) / ORC_BLOCK;       // elements per thread
                int * cnt = (int *) W_s;                               // [K][4] counts per (slice, wave)

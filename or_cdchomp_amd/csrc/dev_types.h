@@ -14,6 +14,7 @@
 #ifndef ORC_WGS_PER_CU
 #define ORC_WGS_PER_CU    3       // resident workgroups per CU the kernels' register budget is sized for (launch bounds)
 #endif
+#define ORC_SCAN_RPL      4       // rows per lane of the scan solve: m <= 64*ORC_SCAN_RPL
 #define ORC_LIM_LIST      64      // violated entries the sparse joint-limit rounds handle
 #define ORC_LIM_SCRATCH  (256 + ORC_LIM_LIST*16)   // bytes: 4 wave records + header, entry list
 
@@ -107,7 +108,7 @@ struct DevBatch
    const real * beta_g;    // [m]
    double kss, ksg, kgg;   // trC = 0.5*(kss|s|^2 + 2 ksg s.g + kgg|g|^2)
    // A^-1 application
-   int solve_mode;         // 0 cyclic reduction (tridiagonal), 1 dense A^-1
+   int solve_mode;         // 0 cyclic reduction (tridiagonal), 1 dense A^-1, 2 closed-form Toeplitz inverse by wave scans
    int pcr_levels;
    const real * pcr;       // [levels][2][m] multipliers, then [m] inverse diagonal
    const real * Ainv;      // dense [m][m] when solve_mode == 1
