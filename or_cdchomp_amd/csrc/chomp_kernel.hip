@@ -175,172 +175,6 @@ __device__ __forceinline__ double block_sum(double v, double * red)
 }
 
 // ---------------------------------------------------------------------------
-// Joint-limit projection rounds (src/libcd/chomp.c:608-655) for the tridiagonal Toeplitz metric
-// (D == 1).  Thread (r, c) = (tid / n, tid % n) owns rows r, r+R, r+2R, ... (R = ORC_BLOCK / n) of
-// column c and keeps them in registers for all rounds.  A round is: violations + wave arg-max +
-// per-wave counts -> one record per wave in LDS -> barrier -> global arg-max, offsets -> violated
-// entries compacted into a list (rows of a column in increasing order, the order the reference's
-// product A^-1 Gjlimit sums them in) -> barrier -> GA = A^-1 Gjlimit from the closed form
-//    Ainv[i][k] = (min(i,k)+1) (m - max(i,k)) / ((m+1) ca),   A = ca tridiag(-1,2,-1),
-// as a short sum over the list, T += 1.01 Gjlimit[l]/GA[l] * GA.
-// Returns true when the loop is finished (no violation left, or 1000 rounds: the caller sets the
-// status), false when a round has more than ORC_LIM_LIST violated entries (the caller continues
-// with the general path).  T_s is up to date and the workgroup is synchronised on return.
-// Requires m <= KMAX * (ORC_BLOCK / n).
-template <typename real, int KMAX>
-__device__ __forceinline__ bool limit_rounds_sparse(const DevBatch<real> & b, real * T_s, const real * jl_s, unsigned char * scratch,
-   int m, int n, int & num_limadjs, long long * dbg_total)
-{
-   struct WaveRec { double best; int best_e; unsigned cnt4; };      // 16 bytes; cnt4: one byte per slice k
-   struct Head { double gl; int gi, gc; };
-   WaveRec * rec = (WaveRec *) scratch;                      // [4]
-   Head * head = (Head *)(scratch + 128);
-   int2 * lst = (int2 *)(scratch + 256);                     // [ORC_LIM_LIST] (row, column)
-   real * lval = (real *)(scratch + 256 + ORC_LIM_LIST*8);   // [ORC_LIM_LIST] Gjlimit value
-   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-   const int R = ORC_BLOCK / n;
-   const int r = (int)(((float) tid + 0.5f) * (1.0f / (float) n));     // tid / n
-   const int c = tid - r*n;
-   const bool owner = (r < R);
-   const int K = (m + R - 1) / R;
-   const real inf = M<real>::inf();
-   const real lo = owner ? jl_s[c] : -inf, hi = owner ? jl_s[n+c] : inf;
-   real t[KMAX];
-#pragma unroll
-   for (int k=0; k<KMAX; k++)
-   {
-      const int i = r + k*R;
-      t[k] = (owner && i < m) ? T_s[n + i*n + c] : (real)0;      // inside the limits of every joint? no: masked below
-   }
-   const real kinv = (real)(-1) / ((real)(m + 1) * b.a_off);     // 1/((m+1) ca), ca = -a_off
-   bool finished = true;
-   for (; num_limadjs<1000; num_limadjs++)
-   {
-      real gj[KMAX]; unsigned long long vm[KMAX];
-      real best = 0; int best_e = 0x7fffffff;
-#pragma unroll
-      for (int k=0; k<KMAX; k++)
-      {
-         real g = 0;
-         const int i = r + k*R;
-         if (k < K)
-         {
-            if (t[k] < lo) g = lo - t[k];
-            if (t[k] > hi) g = hi - t[k];
-            if (!(owner && i < m)) g = 0;
-            const real a = M<real>::fabs_(g);
-            const int e = i*n + c;
-            // largest violation, ties to the smallest row-major index (the reference's scan order)
-            if (a > best || (a == best && a > (real)0 && e < best_e)) { best = a; best_e = e; }
-         }
-         gj[k] = g;
-         vm[k] = __ballot(g != (real)0);
-      }
-      wave_argmax(best, best_e);
-      if (lane == 0)
-      {
-         unsigned c4 = 0;
-#pragma unroll
-         for (int k=0; k<KMAX; k++) c4 |= ((unsigned) __popcll(vm[k])) << (8*k);      // counts <= 64
-         WaveRec w; w.best = (double) best; w.best_e = best_e; w.cnt4 = c4;
-         rec[wave] = w;
-      }
-      __syncthreads();
-      WaveRec rr[4];
-#pragma unroll
-      for (int w=0; w<4; w++) rr[w] = rec[w];
-      double gb = rr[0].best; int ge = rr[0].best_e;
-#pragma unroll
-      for (int w=1; w<4; w++)
-      {
-         const double rb = rr[w].best; const int re = rr[w].best_e;
-         if (rb > gb || (rb == gb && re < ge)) { gb = rb; ge = re; }
-      }
-      if (gb == 0.0) break;                  // nothing violated anywhere in the workgroup
-      // offsets of this wave's entries in the list: slices in order, waves in order
-      int total = 0, base[KMAX];
-#pragma unroll
-      for (int k=0; k<KMAX; k++)
-      {
-         base[k] = 0;
-#pragma unroll
-         for (int w=0; w<4; w++)
-         {
-            if (w == wave) base[k] = total;
-            total += (int)((rr[w].cnt4 >> (8*k)) & 0xffu);
-         }
-      }
-      if (total > ORC_LIM_LIST) { finished = false; break; }
-      if (dbg_total) *dbg_total += total;
-#pragma unroll
-      for (int k=0; k<KMAX; k++)
-      {
-         const int i = r + k*R;
-         if (gj[k] != (real)0)
-         {
-            const int off = base[k] + __popcll(vm[k] & ((1ull << lane) - 1ull));
-            lst[off] = make_int2(i, c);
-            lval[off] = gj[k];
-            if (i*n + c == ge) { Head h; h.gl = (double) gj[k]; h.gi = i; h.gc = c; *head = h; }
-         }
-      }
-      __syncthreads();
-      const Head hd = *head;
-      const real gl = (real) hd.gl;             // Gjlimit[largest]
-      const int gi = hd.gi, gc = hd.gc;
-      real ga[KMAX], ga_l = 0;
-#pragma unroll
-      for (int k=0; k<KMAX; k++) ga[k] = 0;
-      // one entry of the list: its term of GA at the arg-max entry and at this thread's rows
-#define ORC_LIM_TERM(IV, VAL) do { \
-         if ((IV).y == gc) \
-         { \
-            const int l0 = (IV).x < gi ? (IV).x : gi, h0 = (IV).x < gi ? gi : (IV).x; \
-            ga_l += (VAL) * (real)((l0 + 1) * (m - h0)); \
-         } \
-         const bool mine = ((IV).y == c); \
-         _Pragma("unroll") \
-         for (int k=0; k<KMAX; k++) \
-            if (k < K) \
-            { \
-               const int i = r + k*R; \
-               const int l0 = (IV).x < i ? (IV).x : i, h0 = (IV).x < i ? i : (IV).x; \
-               const real term = (VAL) * (real)((l0 + 1) * (m - h0)); \
-               ga[k] += mine ? term : (real)0; \
-            } \
-      } while (0)
-      // the first four entries are fetched together (one LDS round trip), the rest one by one
-      int2 pre_i[4]; real pre_v[4];
-#pragma unroll
-      for (int v=0; v<4; v++) { pre_i[v] = lst[v]; pre_v[v] = lval[v]; }
-#pragma unroll
-      for (int v=0; v<4; v++)
-      {
-         const int2 iv = make_int2(pre_i[v].x, (v < total) ? pre_i[v].y : -2);     // -2 matches no column
-         ORC_LIM_TERM(iv, pre_v[v]);
-      }
-      for (int v=4; v<total; v++)
-      {
-         const int2 iv = lst[v];
-         const real val = lval[v];
-         ORC_LIM_TERM(iv, val);
-      }
-#undef ORC_LIM_TERM
-      const real sc = ((real)1.01 * gl) * rcp_fast(ga_l * kinv);
-#pragma unroll
-      for (int k=0; k<KMAX; k++) t[k] += sc * (ga[k] * kinv);
-   }
-#pragma unroll
-   for (int k=0; k<KMAX; k++)
-   {
-      const int i = r + k*R;
-      if (owner && i < m) T_s[n + i*n + c] = t[k];
-   }
-   __syncthreads();
-   return finished;
-}
-
-// ---------------------------------------------------------------------------
 // SDF lookup: cd_grid_lookup_index + cd_grid_double_interp + cd_grid_double_grad
 // fused (they read the same four cells).  src/libcd/grid.c:191-209, 331-454.
 // returns 0 and value/grad, or 1 when p is outside the field.
@@ -528,6 +362,102 @@ __device__ __forceinline__ real * toeplitz_scan_solve(const DevBatch<real> & b, 
    }
    __syncthreads();
    return buf;
+}
+
+// one column of toeplitz_scan_solve, by the calling wavefront: buf[:, c] <- A^-1 buf[:, c]
+template <typename real>
+__device__ __forceinline__ void toeplitz_scan_column(real * buf, int m, int n, int c, int rpl, real kinv)
+{
+   const int lane = threadIdx.x & 63;
+   real g[ORC_SCAN_RPL], wp[ORC_SCAN_RPL], wq[ORC_SCAN_RPL];
+   real sp = 0, sq = 0;
+#pragma unroll
+   for (int r=0; r<ORC_SCAN_RPL; r++)
+   {
+      const int row = lane*rpl + r;
+      const bool valid = (r < rpl) && (row < m);
+      g[r] = valid ? buf[row*n + c] : (real)0;
+      wp[r] = (real)(row + 1); wq[r] = (real)(m - row);
+      sp += g[r] * wp[r];
+      sq += g[r] * wq[r];
+   }
+   const real ip = wave_prefix_incl(sp), is = wave_suffix_incl(sq);
+   real run_p = __shfl_up(ip, 1, 64);   if (lane == 0) run_p = 0;
+   real run_q = __shfl_down(is, 1, 64); if (lane == 63) run_q = 0;
+   real q[ORC_SCAN_RPL];
+#pragma unroll
+   for (int r=ORC_SCAN_RPL-1; r>=0; r--) { q[r] = run_q; run_q += g[r] * wq[r]; }
+#pragma unroll
+   for (int r=0; r<ORC_SCAN_RPL; r++)
+   {
+      const int row = lane*rpl + r;
+      run_p += g[r] * wp[r];
+      const real x = kinv * (wq[r] * run_p + wp[r] * q[r]);
+      if ((r < rpl) && (row < m)) buf[row*n + c] = x;
+   }
+}
+
+// Joint-limit projection rounds (src/libcd/chomp.c:608-655) for the tridiagonal Toeplitz metric,
+// executed by ONE wavefront (the caller's; the others wait at the barrier that follows): a round has
+// no barrier in it.  Lane = `rpl` consecutive waypoints, loop over the columns.  A round is:
+// violations of every entry -> Gjlimit in G (dense) and the largest violation (wave arg-max, ties
+// to the first row-major index) -> GA = A^-1 Gjlimit by the scan solve, only for the columns that
+// have a violation -> T += 1.01 Gjlimit[l]/GA[l] * GA on those columns.
+// Returns the number of rounds made (1000: the caller sets the status).
+template <typename real>
+__device__ __forceinline__ int limit_rounds_wave(const DevBatch<real> & b, real * T_s, real * G_s, const real * jl_s, int m, int n,
+   long long * dbg_total)
+{
+   const int lane = threadIdx.x & 63;
+   const int rpl = (m + 63) >> 6;
+   const real kinv = (real)(-1) / ((real)(m + 1) * b.a_off);      // 1/((m+1) ca), ca = -a_off
+   const float rn = 1.0f / (float) n;
+   const int mn = m*n;
+   int rounds;
+   for (rounds=0; rounds<1000; rounds++)
+   {
+      // violations of all entries, in row-major order (lane + 64 k): Gjlimit, the largest one
+      // (first index on ties) and the set of columns that have one
+      real best = 0; int best_e = 0x7fffffff;
+      unsigned long long mycols = 0ull;
+#pragma unroll 4
+      for (int e=lane; e<mn; e+=64)
+      {
+         const int i = div_n(e, rn), c = e - i*n;
+         const real t = T_s[n + e], lo = jl_s[c], hi = jl_s[n+c];
+         real g = (t < lo) ? lo - t : (real)0;
+         g = (t > hi) ? hi - t : g;
+         G_s[e] = g;
+         const real a = M<real>::fabs_(g);
+         const bool better = (a > best);
+         best = better ? a : best;
+         best_e = better ? e : best_e;
+         mycols |= (g != (real)0) ? (1ull << c) : 0ull;
+      }
+      unsigned long long cols = 0ull;                 // wave-uniform
+      for (int c=0; c<n; c++)
+         if (__ballot(((mycols >> c) & 1ull) != 0ull) != 0ull) cols |= (1ull << c);
+      wave_argmax(best, best_e);
+      if (!(best > (real)0)) break;                   // nothing violated
+      const int ge = best_e;
+      const int gi = div_n(ge, rn), gc = ge - gi*n;
+      const real gl = G_s[ge];                        // Gjlimit[largest]
+      if (dbg_total) *dbg_total += __popcll(cols);
+      for (int c=0; c<n; c++)
+         if ((cols >> c) & 1ull) toeplitz_scan_column(G_s, m, n, c, rpl, kinv);
+      const real sc = ((real)1.01 * gl) * rcp_fast(G_s[gi*n + gc]);
+      for (int c=0; c<n; c++)
+         if ((cols >> c) & 1ull)
+         {
+#pragma unroll
+            for (int r=0; r<ORC_SCAN_RPL; r++)
+            {
+               const int row = lane*rpl + r;
+               if ((r < rpl) && (row < m)) T_s[n + row*n + c] += sc * G_s[row*n + c];
+            }
+         }
+   }
+   return rounds;
 }
 
 template <typename real>
@@ -1017,8 +947,19 @@ void chomp_iterate_kernel(const DevBatch<real> b)
          // joint-limit projection (chomp.c:608-655)
          int num_limadjs = 0;
          bool lim_done = false;
-         if (b.D == 1 && b.solve_mode != 1 && n <= 64 && m <= 4*(ORC_BLOCK / n))
-            lim_done = limit_rounds_sparse<real, 4>(b, T_s, jl_s, smem_raw + L.lim_bytes, m, n, num_limadjs, (b.phase_cycles && tid == 0) ? &ph[7] : nullptr);
+         if (b.solve_mode == 2 && n <= 64)
+         {
+            // one wavefront makes all rounds (no barrier inside them), the others wait here
+            if (tid < 64)
+            {
+               const int rounds = limit_rounds_wave<real>(b, T_s, G_s, jl_s, m, n, (b.phase_cycles && tid == 0) ? &ph[7] : nullptr);
+               if (tid == 0) redi[0] = rounds;
+            }
+            __syncthreads();
+            num_limadjs = redi[0];
+            lim_done = true;
+            __syncthreads();             // redi is reused by the reductions below
+         }
          if (!lim_done)
          for (; num_limadjs<1000; num_limadjs++)
          {
