@@ -445,6 +445,13 @@ void Batch::build_device(const Robot & robot)
       }
       device_sphere_order.push_back(act[s].xml);
    }
+   for (int k=0; k<nj; k++)
+   {
+      DevJoint<real> & J = M.joints[k];
+      J.packed = (J.type & 3) | ((J.axis_kind & 3) << 2) | ((J.rfix_identity & 1) << 4) | ((J.axis_sign < 0 ? 1 : 0) << 5)
+               | ((J.sph_begin & 255) << 8) | ((J.sph_end & 255) << 16) | ((J.col & 127) << 24);
+      J.pad_ = 0;
+   }
    // which spheres a joint moves, as a range of the device order (J^T through wrench suffix sums)
    M.jt_scan = 1;
    for (int k=0; k<nj; k++)

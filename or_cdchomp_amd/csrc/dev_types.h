@@ -37,6 +37,8 @@ struct DevJoint
    real axis_sign;    // +-1 for axis_kind != 0
    int aff_begin;     // the active spheres this joint moves are [aff_begin, aff_end) when DevModel::jt_scan != 0
    int aff_end;
+   int packed;        // the walk's control word in one LDS read: type | axis_kind<<2 | rfix_identity<<4 | (axis_sign<0)<<5 | sph_begin<<8 | sph_end<<16 | col<<24
+   int pad_;
 };
 
 template <typename real>

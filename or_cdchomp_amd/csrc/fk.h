@@ -61,35 +61,46 @@ __device__ __forceinline__ void rot_cols(real * r, real c, real s)
 
 // apply joint J to row `cur` (in place); emit component k of the world axis / anchor and of the
 // centres of the spheres riding on the joint's link.  `store` is false on the idle lane.
+// pk = J.packed as a scalar: every branch of the walk is a scalar branch on it, and the joint's
+// numbers are fetched in one batch, so a joint costs one LDS round trip (a flag per branch, read
+// where it is tested, cost one each: 1.7 k cycles per joint measured).
 template <typename real>
-__device__ __forceinline__ void fk_joint_row(const ModelView<real> & mod, const DevJoint<real> & J, FrameRow<real> & cur,
+__device__ __forceinline__ void fk_joint_row(const ModelView<real> & mod, const DevJoint<real> & J, int pk, FrameRow<real> & cur,
    real q, real sn, real cs, bool store, real * axo_k, real * pos_k)
 {
+   const int type = pk & 3, kind = (pk >> 2) & 3;          // kind 0 general, 1/2/3: +-x, +-y, +-z of the joint frame
+   const bool rfix_identity = (pk >> 4) & 1;
+   const real sign = ((pk >> 5) & 1) ? (real)(-1) : (real)1;
+   const int s_begin = (pk >> 8) & 255, s_end = (pk >> 16) & 255;
+   real Rf[9], tf[3], ax[3];
+#pragma unroll
+   for (int c=0; c<9; c++) Rf[c] = J.Rfix[c];
+#pragma unroll
+   for (int c=0; c<3; c++) { tf[c] = J.tfix[c]; ax[c] = J.axis[c]; }
    // joint frame in the world: cur o (Rfix, tfix)
-   const real tj = cur.r[0]*J.tfix[0] + cur.r[1]*J.tfix[1] + cur.r[2]*J.tfix[2] + cur.t;
-   if (!J.rfix_identity)
+   const real tj = cur.r[0]*tf[0] + cur.r[1]*tf[1] + cur.r[2]*tf[2] + cur.t;
+   if (!rfix_identity)
    {
       real rn[3];
 #pragma unroll
       for (int c=0; c<3; c++)
-         rn[c] = cur.r[0]*J.Rfix[0*3+c] + cur.r[1]*J.Rfix[1*3+c] + cur.r[2]*J.Rfix[2*3+c];
+         rn[c] = cur.r[0]*Rf[0*3+c] + cur.r[1]*Rf[1*3+c] + cur.r[2]*Rf[2*3+c];
 #pragma unroll
       for (int c=0; c<3; c++) cur.r[c] = rn[c];
    }
    cur.t = tj;
-   const int kind = J.axis_kind;          // 0 general, 1/2/3: +-x, +-y, +-z of the joint frame
    real aw;
-   if (kind == 3) aw = J.axis_sign*cur.r[2];
-   else if (kind == 2) aw = J.axis_sign*cur.r[1];
-   else if (kind == 1) aw = J.axis_sign*cur.r[0];
-   else aw = cur.r[0]*J.axis[0] + cur.r[1]*J.axis[1] + cur.r[2]*J.axis[2];
+   if (kind == 3) aw = sign*cur.r[2];
+   else if (kind == 2) aw = sign*cur.r[1];
+   else if (kind == 1) aw = sign*cur.r[0];
+   else aw = cur.r[0]*ax[0] + cur.r[1]*ax[1] + cur.r[2]*ax[2];
    if (store) { axo_k[0] = aw; axo_k[3] = tj; }
-   if (J.type == 1)
+   if (type == 1)
    {
       if (kind != 0)
       {
          // R <- R * Rot(axis_kind, q): two columns mix, the third is the axis itself
-         const real s = J.axis_sign * sn;
+         const real s = sign * sn;
          if (kind == 3) rot_cols<real, 0, 1>(cur.r, cs, s);
          else if (kind == 2) rot_cols<real, 2, 0>(cur.r, cs, s);
          else rot_cols<real, 1, 2>(cur.r, cs, s);
@@ -97,7 +108,7 @@ __device__ __forceinline__ void fk_joint_row(const ModelView<real> & mod, const 
       else
       {
          const real v = (real)1 - cs;
-         const real a0 = J.axis[0], a1 = J.axis[1], a2 = J.axis[2];
+         const real a0 = ax[0], a1 = ax[1], a2 = ax[2];
          real Rm[9], rn[3];
          Rm[0] = cs + a0*a0*v;    Rm[1] = a0*a1*v - a2*sn; Rm[2] = a0*a2*v + a1*sn;
          Rm[3] = a1*a0*v + a2*sn; Rm[4] = cs + a1*a1*v;    Rm[5] = a1*a2*v - a0*sn;
@@ -111,11 +122,24 @@ __device__ __forceinline__ void fk_joint_row(const ModelView<real> & mod, const 
    else
       cur.t = tj + q*aw;
 #ifndef ORC_ABLATE_FKSPH
-   for (int s=J.sph_begin; s<J.sph_end; s++)
+   // four spheres per step: their table reads are issued together (one LDS round trip per step
+   // where one sphere per step pays one each)
+   for (int s0=s_begin; s0<s_end; s0+=4)
    {
-      const real * lp = mod.sph_pos[s];
-      const real o = cur.r[0]*lp[0] + cur.r[1]*lp[1] + cur.r[2]*lp[2] + cur.t;
-      if (store) pos_k[mod.slot_of[s]*3] = o;
+      real lp[4][3]; int slot[4];
+#pragma unroll
+      for (int u=0; u<4; u++)
+      {
+         const int su = (s0 + u < s_end) ? s0 + u : s_end - 1;
+         lp[u][0] = mod.sph_pos[su][0]; lp[u][1] = mod.sph_pos[su][1]; lp[u][2] = mod.sph_pos[su][2];
+         slot[u] = mod.slot_of[su];
+      }
+#pragma unroll
+      for (int u=0; u<4; u++)
+      {
+         const real o = cur.r[0]*lp[u][0] + cur.r[1]*lp[u][1] + cur.r[2]*lp[u][2] + cur.t;
+         if (store && (s0 + u < s_end)) pos_k[slot[u]*3] = o;
+      }
    }
 #endif
 }
@@ -161,7 +185,7 @@ __device__ __forceinline__ void fk_waypoint_quad(const ModelView<real> & mod, co
    for (int j0=0; j0<nj; j0+=4)
    {
       const int jm = (j0 + k < nj) ? j0 + k : nj - 1;
-      const real qm = row[mod.joints[jm].col];
+      const real qm = row[(mod.joints[jm].packed >> 24) & 127];
       real snm, csm;
 #ifdef ORC_ABLATE_FKSIN
       snm = qm; csm = (real)1 - qm;
@@ -180,6 +204,7 @@ __device__ __forceinline__ void fk_waypoint_quad(const ModelView<real> & mod, co
          if (j < nj)
          {
             const DevJoint<real> & J = mod.joints[j];
+            const int pk = __builtin_amdgcn_readfirstlane(J.packed);
             if (TREE)
             {
                // continue from the previous joint's frame unless the tree branches here
@@ -189,7 +214,7 @@ __device__ __forceinline__ void fk_waypoint_quad(const ModelView<real> & mod, co
                else if (J.load_slot == 2) cur = sv2;
                else if (J.load_slot == 3) cur = sv3;
             }
-            fk_joint_row(mod, J, cur, qv[jj], sn[jj], cs[jj], store, ax_wp + j*6 + kk, pos_k);
+            fk_joint_row(mod, J, pk, cur, qv[jj], sn[jj], cs[jj], store, ax_wp + j*6 + kk, pos_k);
             if (TREE)
             {
                if (J.save_slot == 0) sv0 = cur;
