@@ -340,7 +340,9 @@ __device__ __forceinline__ void cost_tile_gs16(const DevBatch<real> & b, const M
             if (mod.placed)
             {
                // the scan runs over the spheres sorted by joint: lane i takes the wrench of the i-th of them
-               const int src = (s < mod.Sa_real) ? mod.slot_of[s] : s;
+               int sl = s;
+               __asm__ volatile("" : "+v"(sl));      // keeps the table read inside the pass (hoisted, it is spilled to scratch)
+               const int src = (sl < mod.Sa_real) ? mod.slot_of[sl] : sl;
 #pragma unroll
                for (int u=0; u<U; u++)
 #pragma unroll
