@@ -8,6 +8,7 @@
 #include <cstring>
 #include <functional>
 #include <stdexcept>
+#include <thread>
 #include <cstdlib>
 
 // launch wrappers implemented in chomp_kernel.hip
@@ -513,7 +514,7 @@ void Batch::build_device(const Robot & robot)
       M.sph_link[lanes+s] = sp.link;
       device_sphere_order.push_back(inact[s].xml);
    }
-   nj_ = nj; Sa_ = lanes; S_ = lanes + (int) inact.size(); tree_ = M.tree | ((M.GS == 16) ? 2 : 0);     // kernel variant bits
+   nj_ = nj; Sa_ = lanes; S_ = lanes + (int) inact.size(); GS_ = M.GS; tree_ = M.tree | ((M.GS == 16) ? 2 : 0);     // kernel variant bits
 
    hipStream_t st = stream_;
    DevModel<real> * dm = dev_alloc<DevModel<real>>(1);
@@ -603,55 +604,84 @@ void Batch::build_device(const Robot & robot)
    d_jl_lo_ = upload<real>(jl_lo_, st);
    d_jl_hi_ = upload<real>(jl_hi_, st);
 
-   // Tile size and LDS plan.  The kernel is latency bound, so resident workgroups per CU come first
-   // (as many as the kernel's register budget allows, ORC_WGS_PER_CU), then the fewest tiles per
-   // iteration (every tile costs one FK pass), then the cyclic-reduction tables in LDS.
+   // Tile size and LDS plan.  The kernel is latency bound: resident workgroups per CU (up to the
+   // register budget, ORC_WGS_PER_CU) multiply throughput almost linearly, every tile costs an FK pass
+   // per 64 waypoints and the cost phase rounds of four wavefronts.  Every plan (workgroups per CU,
+   // cyclic-reduction tables in LDS or read through L2, momentum AG in LDS or in global memory) gets
+   // its largest tile; the plan with the best estimated throughput wins (cycle figures measured on
+   // the WAM workload, scripts/phase_profile.py).
    const int pcr_rows = pcr_rows_;
    const size_t lds_cu = 160*1024;
-   int force_t = 0, force_pcr = -1, max_wgs = ORC_WGS_PER_CU;
+   int force_t = 0, force_pcr = -1, force_ag = -1, max_wgs = ORC_WGS_PER_CU;
    if (const char * e = getenv("ORC_TILE_M")) force_t = atoi(e);          // experiments
    if (const char * e = getenv("ORC_PCR_LDS")) force_pcr = atoi(e);
+   if (const char * e = getenv("ORC_AG_LDS")) force_ag = atoi(e);
    if (const char * e = getenv("ORC_WGS")) max_wgs = atoi(e);
+   const int lanes_per_wp = (GS_ == 16) ? 16 : GS_;
    tile_m_ = 0;
-   for (int wgs=max_wgs; wgs>=1 && !tile_m_; wgs--)
+   double best_score = -1.0;
+   for (int wgs=max_wgs; wgs>=1; wgs--)
    {
       // LDS is handed out in 1280-byte granules (measured: three 53512-byte workgroups share a CU, three 54184-byte ones do not)
       const size_t budget = (lds_cu / wgs / 1280) * 1280 - (wgs == 1 ? 1024 : 0);
-      int best_t = 0, best_pcr = 0, best_tiles = 1 << 30;
       for (int with_pcr=1; with_pcr>=0; with_pcr--)
-      {
-         if (with_pcr && !pcr_rows) continue;
-         if (force_pcr >= 0 && with_pcr != force_pcr && pcr_rows) continue;
-         for (int t=(m < ORC_BLOCK - 2 ? m : ORC_BLOCK - 2); t>=1; t--)
+         for (int ag_lds=1; ag_lds>=0; ag_lds--)
          {
-            if (force_t > 0 && t != (force_t < m ? force_t : m)) continue;
-            const size_t need = orc_chomp_lds_bytes(n_points, n, Sa_, S_, nj, t, with_pcr ? pcr_rows : 0, sizeof(real), params.use_momentum, n_sdfs_);
-            if (need > budget) continue;
-            const int tiles = (m + t - 1) / t;
-            if (tiles < best_tiles) { best_tiles = tiles; best_t = t; best_pcr = with_pcr; }
-            break;                                   // largest tile of this plan
+            if (with_pcr && !pcr_rows) continue;
+            if (force_pcr >= 0 && with_pcr != force_pcr && pcr_rows) continue;
+            if (!ag_lds && !params.use_momentum) continue;
+            if (force_ag >= 0 && ag_lds != force_ag && params.use_momentum) continue;
+            for (int t=(m < ORC_BLOCK - 2 ? m : ORC_BLOCK - 2); t>=1; t--)
+            {
+               if (force_t > 0 && t != (force_t < m ? force_t : m)) continue;
+               const size_t need = orc_chomp_lds_bytes(n_points, n, Sa_, S_, nj, t, with_pcr ? pcr_rows : 0, sizeof(real),
+                                                       params.use_momentum && ag_lds, n_sdfs_);
+               if (need > budget) continue;
+               const int tiles = (m + t - 1) / t;
+               const double fk_passes = tiles * std::ceil((t + 2) / 64.0);
+               const double rounds = tiles * std::ceil(t * (double) lanes_per_wp / ORC_BLOCK);
+               const double cycles = 12e3 * fk_passes + 11e3 * rounds + 30e3 + (with_pcr ? 0.0 : 1e3) + (ag_lds ? 0.0 : 2e3);
+               const double score = wgs * (1.0 - 0.05 * (wgs - 1)) / cycles;
+               if (score > best_score)
+               {
+                  best_score = score; tile_m_ = t; pcr_in_lds_ = with_pcr; ag_in_lds_ = ag_lds; lds_bytes_ = need;
+               }
+               break;                                   // largest tile of this plan
+            }
          }
-      }
-      if (best_t)
-      {
-         tile_m_ = best_t; pcr_in_lds_ = best_pcr;
-         lds_bytes_ = orc_chomp_lds_bytes(n_points, n, Sa_, S_, nj, best_t, best_pcr ? pcr_rows : 0, sizeof(real), params.use_momentum, n_sdfs_);
-      }
    }
    if (!tile_m_) throw std::runtime_error("run does not fit the LDS of one CU!");
    if (getenv("ORC_DEBUG_PLAN"))
-      fprintf(stderr, "orc plan: tile_m %d (%d tiles) lds %zu bytes pcr_in_lds %d pcr_sym %d\n", tile_m_, (m + tile_m_ - 1) / tile_m_, lds_bytes_, pcr_in_lds_, pcr_sym_);
+      fprintf(stderr, "orc plan: tile_m %d (%d tiles) lds %zu bytes (%d workgroups per CU) pcr_in_lds %d ag_in_lds %d solve_mode %d\n", tile_m_,
+              (m + tile_m_ - 1) / tile_m_, lds_bytes_, (int)(lds_cu / ((lds_bytes_ + 1279) / 1280 * 1280)), pcr_in_lds_, ag_in_lds_, solve_mode_);
 }
 
 // which iterations of this call resample the momentum, and with what noise
 // (src/orcdchomp_mod.cpp:2755-2768; r->iter restarts at 0 on every call, 2752)
+// runs [0, count) split over the host cores (the per-run noise streams are independent)
+static void parallel_for_runs(int count, const std::function<void(int, int)> & body)
+{
+   unsigned hw = std::thread::hardware_concurrency();
+   int nt = (int) std::min<unsigned>(hw ? hw : 1u, 64u);
+   if (count < 64 || nt < 2) { body(0, count); return; }
+   nt = std::min(nt, count / 16);
+   std::vector<std::thread> pool;
+   for (int t=0; t<nt; t++)
+   {
+      const int lo = (int)((long long) count * t / nt), hi = (int)((long long) count * (t+1) / nt);
+      pool.emplace_back([&body, lo, hi]() { body(lo, hi); });
+   }
+   for (std::thread & th : pool) th.join();
+}
+
 void Batch::plan_hmc(int n_iter)
 {
    const size_t mn = (size_t) m * n;
    std::vector<std::vector<int>> iters(n_runs);
    std::vector<std::vector<double>> noise(n_runs);
    int maxr = 0;
-   for (int k=0; k<n_runs; k++)
+   parallel_for_runs(n_runs, [&](int k_lo, int k_hi) {
+   for (int k=k_lo; k<k_hi; k++)
    {
       int used_ext = 0;
       for (int it=0; it<n_iter; it++)
@@ -668,8 +698,9 @@ void Batch::plan_hmc(int n_iter)
          iters[k].push_back(it);
          hmc_resample_iter_[k] += 1 + (int)(-std::log(rng_[k].uniform()) / params.hmc_resample_lambda);
       }
-      maxr = std::max(maxr, (int) iters[k].size());
    }
+   });
+   for (int k=0; k<n_runs; k++) maxr = std::max(maxr, (int) iters[k].size());
    max_resamples_ = maxr;
    if (maxr == 0) return;
    std::vector<int> flat((size_t) n_runs * maxr, -1);
@@ -688,7 +719,9 @@ void Batch::plan_hmc(int n_iter)
    if (params.precision == 64)
    {
       std::vector<double> buf(ncount, 0.0);
-      for (int k=0; k<n_runs; k++) std::copy(noise[k].begin(), noise[k].end(), buf.begin() + (size_t) k*maxr*mn);
+      parallel_for_runs(n_runs, [&](int k_lo, int k_hi) {
+         for (int k=k_lo; k<k_hi; k++) std::copy(noise[k].begin(), noise[k].end(), buf.begin() + (size_t) k*maxr*mn);
+      });
       hip_check(hipMemcpyAsync(d_noise_, buf.data(), ncount*8, hipMemcpyHostToDevice, stream_), "noise");
       hip_check(hipStreamSynchronize(stream_), "noise sync");
    }
@@ -732,7 +765,7 @@ void Batch::launch(int n_iter)
    b.hmc_iters = d_hmc_iters_; b.noise = (const real *) d_noise_; b.max_resamples = max_resamples_;
    b.n_iter = n_iter; b.final_eval = 1;
    b.phase_cycles = d_phase_;
-   b.pcr_in_lds = pcr_in_lds_; b.pcr_sym = pcr_sym_; b.pcr_rows = pcr_rows_;
+   b.pcr_in_lds = pcr_in_lds_; b.pcr_sym = pcr_sym_; b.pcr_rows = pcr_rows_; b.ag_in_lds = ag_in_lds_;
    b.stagger_mode = getenv("ORC_STAGGER_MODE") ? atoi(getenv("ORC_STAGGER_MODE")) : 0;
    b.stagger_sleeps = getenv("ORC_STAGGER_SLEEPS") ? atoi(getenv("ORC_STAGGER_SLEEPS")) : 10;
    if (params.derivative == 1 && m >= 2)

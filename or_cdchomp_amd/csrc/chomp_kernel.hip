@@ -509,14 +509,13 @@ void chomp_iterate_kernel(const DevBatch<real> b)
 
    // ---- LDS carve-up ------------------------------------------------------
    const LdsLayout L = lds_layout(np, n, Sa, S, nj, tile_m, b.pcr_in_lds ? b.pcr_rows : 0, (int) sizeof(real),
-                                  b.use_momentum, b.n_sdfs, (int) sizeof(DevJoint<real>), (int) sizeof(DevSdf<real>));
+                                  b.use_momentum && b.ag_in_lds, b.n_sdfs, (int) sizeof(DevJoint<real>), (int) sizeof(DevSdf<real>));
    double * red = (double *) smem_raw;                  // [8] reduction scratch
    int * redi = (int *)(red + 8);                       // [8]
    real * lds = (real *)(smem_raw + 128);
    real * T_s  = lds + L.T;                             // [np][n]
    real * G_s  = lds + L.G;                             // [m][n]
    real * W_s  = lds + L.W;                             // [m][n] work
-   real * AG_s = lds + L.AG;                            // [m][n]
    real * pos_s = lds + L.pos;                          // [tile_m+2][Sa][3]
    real * ax_s = lds + L.ax;                            // [tile_m+2][nj][6]
    const int pstr = L.pstr, astr = L.astr;              // padded waypoint strides of pos_s / ax_s
@@ -544,6 +543,9 @@ void chomp_iterate_kernel(const DevBatch<real> b)
 
    real * traj_g = b.traj + (size_t) run * np * n;
    real * AG_g = b.AG + (size_t) run * mn;
+   // momentum: in LDS for the launch, or in place in global memory (every entry is read and written
+   // by the same thread, e = tid + k ORC_BLOCK, in all loops that touch it)
+   real * AG_s = b.ag_in_lds ? lds + L.AG : AG_g;       // [m][n]
 
    for (int e=tid; e<np*n; e+=ORC_BLOCK) T_s[e] = traj_g[e];
    for (int e=tid; e<S; e+=ORC_BLOCK) { srad_s[e] = gmod.sph_radius[e]; slink_s[e] = gmod.sph_link[e]; }
@@ -565,7 +567,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
       for (int e=tid; e<b.pcr_rows*m; e+=ORC_BLOCK) pcr_s[e] = b.pcr[e];
    const real * pcr_tab = b.pcr_in_lds ? pcr_s : b.pcr;
    const real inv_eps = (real)1 / b.epsilon, inv_eps_self = (real)1 / b.epsilon_self;
-   if (b.use_momentum) for (int e=tid; e<mn; e+=ORC_BLOCK) AG_s[e] = AG_g[e];
+   if (b.use_momentum && b.ag_in_lds) for (int e=tid; e<mn; e+=ORC_BLOCK) AG_s[e] = AG_g[e];
    int leapfrog_first = b.leapfrog_first[run];
    int status = b.status[run];
    int next_resample = 0;      // index into this call's resample list
@@ -1127,7 +1129,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
    // ---- write back ---------------------------------------------------------
    __syncthreads();
    for (int e=tid; e<np*n; e+=ORC_BLOCK) traj_g[e] = T_s[e];
-   if (b.use_momentum) for (int e=tid; e<mn; e+=ORC_BLOCK) AG_g[e] = AG_s[e];
+   if (b.use_momentum && b.ag_in_lds) for (int e=tid; e<mn; e+=ORC_BLOCK) AG_g[e] = AG_s[e];
    if (tid == 0)
    {
       if (b.phase_cycles) for (int k=0; k<8; k++) b.phase_cycles[(size_t) run*8 + k] = ph[k];

@@ -125,6 +125,7 @@ struct DevBatch
    long long * phase_cycles; // [n_runs][8] or null: diagnostics (cycles per phase, wave 0)
    real a_diag, a_off;     // D == 1: A = tridiag(a_off, a_diag, a_off), B couples the end rows with a_off
    int pcr_in_lds;         // the cyclic-reduction tables are staged in LDS
+   int ag_in_lds;          // the momentum AG lives in LDS for the launch (else it is updated in place in global memory)
    int pcr_sym;            // compact tables: pcr[l][m] (towards i-s; towards i+s is the mirrored entry), then [m] inverse diagonal
    int pcr_rows;           // rows of m entries in the table
    int stagger_mode;       // 0 none; 1 odd workgroups, 2 every other group of 256: start half an iteration late

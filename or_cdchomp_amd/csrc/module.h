@@ -117,7 +117,7 @@ private:
    int tile_m_ = 0;
    int pcr_in_lds_ = 0;
    int tree_ = 0;
-   int pcr_rows_ = 0, pcr_sym_ = 0, solve_mode_ = 0;
+   int pcr_rows_ = 0, pcr_sym_ = 0, solve_mode_ = 0, ag_in_lds_ = 1, GS_ = 0;
    std::vector<double> placement_q_;   // [samples][n_adof] configurations on the seed lines (sphere placement)
    size_t lds_bytes_ = 0;
    std::vector<double> jl_lo_, jl_hi_;
