@@ -147,7 +147,7 @@ def main():
                                             [prob["pose"]], p, N_ITER, max_threads=k_check)
         parity = max(common.rel_l2(traj0[k], otraj[k]) for k in range(k_check))
 
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:         # the CPU baseline is reported at N=1 only
             cores = os.cpu_count() or 1
             # ~0.1 s per run (100 iterations) on one core; aim for 10-20 s of wall time
             sample = args.cpu_runs or int(min(n_runs, max(8, 128 * cores // 1)))
