@@ -51,8 +51,8 @@ def algorithmic_bytes_per_iter(m, n, Sa, n_sdf, w, momentum):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1024, help="runs per GPU (configs[1]: 1024)")
     ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams the steps are issued on round-robin: consecutive steps are independent batches, "
