@@ -36,6 +36,8 @@ template <> struct M<double>
    static __device__ __forceinline__ double sqrt_(double x) { return ::sqrt(x); }
    static __device__ __forceinline__ double floor_(double x) { return ::floor(x); }
    static __device__ __forceinline__ double fabs_(double x) { return ::fabs(x); }
+   static __device__ __forceinline__ double max_(double a, double b) { return ::fmax(a, b); }
+   static __device__ __forceinline__ double min_(double a, double b) { return ::fmin(a, b); }
    static __device__ __forceinline__ void sincos_(double x, double * s, double * c) { ::sincos(x, s, c); }
    static __device__ __forceinline__ double inf() { return __longlong_as_double(0x7ff0000000000000LL); }
 };
@@ -44,6 +46,8 @@ template <> struct M<float>
    static __device__ __forceinline__ float sqrt_(float x) { return ::sqrtf(x); }
    static __device__ __forceinline__ float floor_(float x) { return ::floorf(x); }
    static __device__ __forceinline__ float fabs_(float x) { return ::fabsf(x); }
+   static __device__ __forceinline__ float max_(float a, float b) { return ::fmaxf(a, b); }
+   static __device__ __forceinline__ float min_(float a, float b) { return ::fminf(a, b); }
    static __device__ __forceinline__ void sincos_(float x, float * s, float * c) { ::sincosf(x, s, c); }
    static __device__ __forceinline__ float inf() { return __int_as_float(0x7f800000); }
 };
@@ -420,25 +424,52 @@ __device__ __forceinline__ int limit_rounds_wave(const DevBatch<real> & b, real 
       // (first index on ties) and the set of columns that have one
       real best = 0; int best_e = 0x7fffffff;
       unsigned long long mycols = 0ull;
-#pragma unroll 4
-      for (int e=lane; e<mn; e+=64)
+      // four entries of the lane per trip: their reads and short dependent chains overlap (one entry
+      // per trip pays the full latency of each)
+#pragma unroll 1
+      for (int e0=lane; e0<mn; e0+=4*64)
       {
-         const int i = div_n(e, rn), c = e - i*n;
-         const real t = T_s[n + e], lo = jl_s[c], hi = jl_s[n+c];
-         real g = (t < lo) ? lo - t : (real)0;
-         g = (t > hi) ? hi - t : g;
-         G_s[e] = g;
-         const real a = M<real>::fabs_(g);
-         const bool better = (a > best);
-         best = better ? a : best;
-         best_e = better ? e : best_e;
-         mycols |= (g != (real)0) ? (1ull << c) : 0ull;
+         real gk[4]; int ck[4];
+#pragma unroll
+         for (int k=0; k<4; k++)
+         {
+            const int e = e0 + 64*k;
+            const bool ok = (e < mn);
+            const int i = div_n(ok ? e : 0, rn), c = (ok ? e : 0) - i*n;
+            const real t = ok ? T_s[n + e] : (real)0;
+            const real lo = jl_s[c], hi = jl_s[n+c];
+            // lo - t when below, hi - t when above, else 0 (at most one of the two terms is non-zero)
+            real g = M<real>::max_(lo - t, (real)0) + M<real>::min_(hi - t, (real)0);
+            g = ok ? g : (real)0;
+            if (ok) G_s[e] = g;
+            gk[k] = g; ck[k] = c;
+         }
+         // arg-max of the four, then against the running one: a later entry wins only when strictly larger
+         const real a0 = M<real>::fabs_(gk[0]), a1 = M<real>::fabs_(gk[1]), a2 = M<real>::fabs_(gk[2]), a3 = M<real>::fabs_(gk[3]);
+         const bool l01 = (a1 > a0), l23 = (a3 > a2);
+         const real a01 = l01 ? a1 : a0, a23 = l23 ? a3 : a2;
+         const int e01 = l01 ? e0 + 64 : e0, e23 = l23 ? e0 + 192 : e0 + 128;
+         const bool l2 = (a23 > a01);
+         const real a4 = l2 ? a23 : a01; const int e4 = l2 ? e23 : e01;
+         const bool better = (a4 > best);
+         best = better ? a4 : best;
+         best_e = better ? e4 : best_e;
+#pragma unroll
+         for (int k=0; k<4; k++) mycols |= (gk[k] != (real)0) ? (1ull << ck[k]) : 0ull;
       }
-      unsigned long long cols = 0ull;                 // wave-uniform
-      for (int c=0; c<n; c++)
-         if (__ballot(((mycols >> c) & 1ull) != 0ull) != 0ull) cols |= (1ull << c);
       wave_argmax(best, best_e);
       if (!(best > (real)0)) break;                   // nothing violated
+      // columns with a violated entry: OR of the lanes' masks (DPP inside the rows, then the four rows)
+      unsigned int clo = (unsigned int) mycols, chi = (unsigned int)(mycols >> 32);
+      clo |= (unsigned int) dpp_move<0xB1>((int) clo); chi |= (unsigned int) dpp_move<0xB1>((int) chi);     // quad_perm [1,0,3,2]
+      clo |= (unsigned int) dpp_move<0x4E>((int) clo); chi |= (unsigned int) dpp_move<0x4E>((int) chi);     // quad_perm [2,3,0,1]
+      clo |= (unsigned int) dpp_move<0x141>((int) clo); chi |= (unsigned int) dpp_move<0x141>((int) chi);   // row_half_mirror
+      clo |= (unsigned int) dpp_move<0x140>((int) clo); chi |= (unsigned int) dpp_move<0x140>((int) chi);   // row_mirror
+      const unsigned int lo32 = __builtin_amdgcn_readlane((int) clo, 0) | __builtin_amdgcn_readlane((int) clo, 16)
+                              | __builtin_amdgcn_readlane((int) clo, 32) | __builtin_amdgcn_readlane((int) clo, 48);
+      const unsigned int hi32 = __builtin_amdgcn_readlane((int) chi, 0) | __builtin_amdgcn_readlane((int) chi, 16)
+                              | __builtin_amdgcn_readlane((int) chi, 32) | __builtin_amdgcn_readlane((int) chi, 48);
+      const unsigned long long cols = ((unsigned long long) hi32 << 32) | lo32;      // wave-uniform
       const int ge = best_e;
       const int gi = div_n(ge, rn), gc = ge - gi*n;
       const real gl = G_s[ge];                        // Gjlimit[largest]
