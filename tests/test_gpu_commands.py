@@ -78,9 +78,11 @@ def test_addfield_fromobsarray_and_removefield(oracle):
         mod.destroy(run=run)
 
 
-@pytest.mark.parametrize("n_points", [3, 4, 7, 65, 130])
+@pytest.mark.parametrize("n_points", [3, 4, 7, 65, 130, 259, 300])
 def test_trajectory_lengths(oracle, n_points):
-    """m = 1 (a single moving waypoint) up to more waypoints than one tile holds"""
+    """m = 1 (a single moving waypoint) up to more waypoints than one tile holds, and past the 256
+    moving waypoints the scan solve and the one-wavefront limit rounds cover (cyclic reduction and the
+    general limit loop take over)"""
     mod = _mk()
     model = common.setup_product_wam(mod)
     prob = common.tabletop_problem(oracle)
