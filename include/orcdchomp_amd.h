@@ -145,6 +145,14 @@ int orc_batch_set_noise(orc_module * mod, int batch_id, const double * noise, in
 /* replaces the waypoint export of mod::gettraj (src/orcdchomp_mod.cpp:2897-2903):
  * traj_out [n_runs][n_points][n] */
 int orc_batch_gettraj(orc_module * mod, int batch_id, double * traj_out, size_t cap_doubles);
+/* replaces the collision re-check of mod::gettraj (src/orcdchomp_mod.cpp:2958-3006) for all runs of
+ * a batch at once, on the device: every run's trajectory is retimed at the dof velocity limits and
+ * sampled every 0.04 rad of C-space distance like the reference's loop; a sample collides when an
+ * active sphere penetrates a field (the optimizer's own model; OpenRAVE's mesh checker is third
+ * party).  Per run (any output may be NULL): collides 0/1, time of the first contact, XML index of
+ * the sphere, index of the field, penetration depth in metres. */
+int orc_batch_collision_verdict(orc_module * mod, int batch_id, int * collides_out, double * time_out,
+                                int * sphere_out, int * field_out, double * depth_out);
 /* optimizer state read-back for tests: which = "G", "AG", "T" ([n_runs][m][n]) */
 int orc_batch_get_state(orc_module * mod, int batch_id, const char * which, double * out, size_t cap_doubles);
 int orc_batch_dims(orc_module * mod, int batch_id, int * n_runs, int * n_points, int * n);

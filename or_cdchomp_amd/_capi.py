@@ -60,6 +60,7 @@ SYMBOLS = [
     ("orc_batch_get_trace", C.c_int, [C.c_void_p, C.c_int, c_double_p, C.c_size_t]),
     ("orc_batch_set_noise", C.c_int, [C.c_void_p, C.c_int, c_double_p, C.c_int]),
     ("orc_batch_gettraj", C.c_int, [C.c_void_p, C.c_int, c_double_p, C.c_size_t]),
+    ("orc_batch_collision_verdict", C.c_int, [C.c_void_p, C.c_int, c_int_p, c_double_p, c_int_p, c_int_p, c_double_p]),
     ("orc_batch_get_state", C.c_int, [C.c_void_p, C.c_int, C.c_char_p, c_double_p, C.c_size_t]),
     ("orc_batch_dims", C.c_int, [C.c_void_p, C.c_int, c_int_p, c_int_p, c_int_p]),
     ("orc_batch_set_traj", C.c_int, [C.c_void_p, C.c_int, c_double_p, C.c_size_t]),

@@ -16,6 +16,9 @@ size_t orc_chomp_lds_bytes(int n_points, int n, int Sa, int S, int nj, int tile_
    int use_momentum, int n_sdfs);
 hipError_t orc_launch_iterate_f64(const DevBatch<double> & b, size_t lds, hipStream_t stream, int tree);
 hipError_t orc_launch_iterate_f32(const DevBatch<float> & b, size_t lds, hipStream_t stream, int tree);
+hipError_t orc_launch_verdict_f64(const DevVerdict<double> & v, size_t lds, hipStream_t stream, int tree);
+hipError_t orc_launch_verdict_f32(const DevVerdict<float> & v, size_t lds, hipStream_t stream, int tree);
+size_t orc_verdict_lds_bytes(int n, int Sa, int Sa_real, int nj, size_t real_size);
 hipError_t orc_launch_seed_f64(double * traj, const double * starts, const double * goals,
    int n_runs, int n_points, int n, int floating, hipStream_t stream);
 hipError_t orc_launch_seed_f32(float * traj, const double * starts, const double * goals,
@@ -503,6 +506,9 @@ void Batch::build_device(const Robot & robot)
       }
    }
    M.Sa_real = Sa; M.Sa = lanes; M.S = lanes + (int) inact.size();
+   slot_xml.assign(lanes, -1);
+   for (int s=0; s<Sa; s++) slot_xml[slot_of[s]] = act[s].xml;
+   Sa_real_ = Sa;
    for (int s=0; s<(int) inact.size(); s++)
    {
       const Robot::Sphere & sp = robot.spheres[inact[s].xml];
@@ -654,6 +660,45 @@ void Batch::build_device(const Robot & robot)
    if (getenv("ORC_DEBUG_PLAN"))
       fprintf(stderr, "orc plan: tile_m %d (%d tiles) lds %zu bytes (%d workgroups per CU) pcr_in_lds %d ag_in_lds %d solve_mode %d\n", tile_m_,
               (m + tile_m_ - 1) / tile_m_, lds_bytes_, (int)(lds_cu / ((lds_bytes_ + 1279) / 1280 * 1280)), pcr_in_lds_, ag_in_lds_, solve_mode_);
+}
+
+void Batch::collision_verdict(const std::vector<int> & offs, const std::vector<int> & seg, const std::vector<double> & u,
+   int * key_out, double * depth_out)
+{
+   hipStream_t st = stream_;
+   hip_check(hipStreamSynchronize(st), "verdict: pending work");
+   const size_t ns = seg.size();
+   int * d_offs = dev_alloc<int>(offs.size()); int * d_seg = dev_alloc<int>(ns); int * d_xml = dev_alloc<int>(slot_xml.size());
+   int * d_key = dev_alloc<int>(n_runs); double * d_depth = dev_alloc<double>(n_runs);
+   hip_check(hipMemcpyAsync(d_offs, offs.data(), offs.size()*sizeof(int), hipMemcpyHostToDevice, st), "verdict offs");
+   hip_check(hipMemcpyAsync(d_seg, seg.data(), ns*sizeof(int), hipMemcpyHostToDevice, st), "verdict seg");
+   hip_check(hipMemcpyAsync(d_xml, slot_xml.data(), slot_xml.size()*sizeof(int), hipMemcpyHostToDevice, st), "verdict xml");
+   hip_check(hipMemsetAsync(d_depth, 0, n_runs*sizeof(double), st), "verdict depth");
+   void * d_u = nullptr;
+   hipError_t e;
+   if (params.precision == 64)
+   {
+      d_u = upload<double>(u, st);
+      DevVerdict<double> v;
+      v.model = (const DevModel<double> *) d_model_; v.sdfs = (const DevSdf<double> *) d_sdfs_; v.n_sdfs = n_sdfs_;
+      v.n_runs = n_runs; v.n_points = n_points; v.n = n; v.traj = (const double *) d_traj_;
+      v.offs = d_offs; v.seg = d_seg; v.u = (const double *) d_u; v.slot_xml = d_xml; v.key_out = d_key; v.depth_out = d_depth;
+      e = orc_launch_verdict_f64(v, orc_verdict_lds_bytes(n, Sa_, Sa_real_, nj_, 8), st, tree_ & 1);
+   }
+   else
+   {
+      d_u = upload<float>(u, st);
+      DevVerdict<float> v;
+      v.model = (const DevModel<float> *) d_model_; v.sdfs = (const DevSdf<float> *) d_sdfs_; v.n_sdfs = n_sdfs_;
+      v.n_runs = n_runs; v.n_points = n_points; v.n = n; v.traj = (const float *) d_traj_;
+      v.offs = d_offs; v.seg = d_seg; v.u = (const float *) d_u; v.slot_xml = d_xml; v.key_out = d_key; v.depth_out = d_depth;
+      e = orc_launch_verdict_f32(v, orc_verdict_lds_bytes(n, Sa_, Sa_real_, nj_, 4), st, tree_ & 1);
+   }
+   hip_check(e, "collision_verdict_kernel launch");
+   hip_check(hipMemcpyAsync(key_out, d_key, n_runs*sizeof(int), hipMemcpyDeviceToHost, st), "verdict keys");
+   hip_check(hipMemcpyAsync(depth_out, d_depth, n_runs*sizeof(double), hipMemcpyDeviceToHost, st), "verdict depth");
+   hip_check(hipStreamSynchronize(st), "verdict sync");
+   dev_free(d_offs); dev_free(d_seg); dev_free(d_xml); dev_free(d_key); dev_free(d_depth); dev_free(d_u);
 }
 
 // which iterations of this call resample the momentum, and with what noise

@@ -275,6 +275,12 @@ int orc_batch_gettraj(orc_module * mod, int id, double * out, size_t cap)
    });
 }
 
+int orc_batch_collision_verdict(orc_module * mod, int id, int * collides_out, double * time_out, int * sphere_out,
+   int * field_out, double * depth_out)
+{
+   return guarded(mod, [&] { mod->impl->batch_collision_verdict(id, collides_out, time_out, sphere_out, field_out, depth_out); });
+}
+
 int orc_batch_get_state(orc_module * mod, int id, const char * which, double * out, size_t cap)
 {
    return guarded(mod, [&] {

@@ -1201,6 +1201,113 @@ __global__ void seed_traj_kernel(real * traj, const double * starts, const doubl
    }
 }
 
+// ---------------------------------------------------------------------------
+// Collision verdict of every run's trajectory: one workgroup per run walks the run's samples (planned
+// on the host: every 0.04 rad of C-space distance along the retimed trajectory, as the reference's
+// re-check in gettraj, src/orcdchomp_mod.cpp:2958-3006) 64 at a time: rows interpolated on their
+// segments -> FK (fk.h, four lanes per sample) -> every active sphere against every field.  The
+// first contact in (sample, XML sphere, field) order is reported, which is where the reference's
+// loop stops.
+template <typename real, bool TREE>
+__global__ __launch_bounds__(ORC_BLOCK)
+void collision_verdict_kernel(DevVerdict<real> v)
+{
+   extern __shared__ __align__(16) unsigned char smem_raw[];
+   const DevModel<real> & gmod = *v.model;
+   const int run = blockIdx.x, tid = threadIdx.x;
+   const int n = v.n, np = v.n_points, nj = gmod.nj, Sa = gmod.Sa;
+   const int pstr = (Sa*3) | 1, astr = (nj*6) | 1;
+   int * key_s = (int *) smem_raw;                                   // [4]
+   real * lds = (real *)(smem_raw + 16);
+   real * rows_s = lds;                                              // [64][n]
+   real * pos_s = rows_s + ((64*n + 3) & ~3);                        // [64][pstr]
+   real * ax_s = pos_s + ((64*pstr + 3) & ~3);                       // [64][astr]
+   real * sphpos_s = ax_s + ((64*astr + 3) & ~3);                    // [Sa][3]
+   real * base_s = sphpos_s + ((Sa*3 + 3) & ~3);                     // [12]
+   real * srad_s = base_s + 12;                                      // [Sa]
+   int * slot_s = (int *)(srad_s + ((Sa + 3) & ~3));                 // [Sa_real]
+   int * xml_s = slot_s + ((gmod.Sa_real + 3) & ~3);                 // [Sa]
+   DevJoint<real> * joints_s = (DevJoint<real> *)(xml_s + ((Sa + 3) & ~3));
+   for (int e=tid; e<Sa*3; e+=ORC_BLOCK) sphpos_s[e] = gmod.sph_pos[e/3][e%3];
+   for (int e=tid; e<12; e+=ORC_BLOCK) base_s[e] = (e < 9) ? gmod.base_R[e] : gmod.base_t[e-9];
+   for (int e=tid; e<Sa; e+=ORC_BLOCK) { srad_s[e] = gmod.sph_radius[e]; xml_s[e] = v.slot_xml[e]; }
+   for (int e=tid; e<gmod.Sa_real; e+=ORC_BLOCK) slot_s[e] = gmod.slot_of[e];
+   {
+      const int * src = (const int *) gmod.joints; int * dst = (int *) joints_s;
+      for (int e=tid; e<nj*(int)(sizeof(DevJoint<real>)/4); e+=ORC_BLOCK) dst[e] = src[e];
+   }
+   if (tid == 0) key_s[0] = 0x7fffffff;
+   ModelView<real> mod;
+   mod.nj = nj; mod.n = n; mod.floating = gmod.floating; mod.tree = gmod.tree; mod.Sa = Sa; mod.S = gmod.S; mod.GS = gmod.GS;
+   mod.base_sph_begin = gmod.base_sph_begin; mod.base_sph_end = gmod.base_sph_end; mod.jt_scan = 0;
+   mod.Sa_real = gmod.Sa_real; mod.placed = gmod.placed; mod.live_mask = gmod.live_mask; mod.slot_of = slot_s;
+   mod.base_R = base_s; mod.base_t = base_s + 9;
+   mod.joints = joints_s; mod.sph_pos = (const real (*)[3]) sphpos_s; mod.sph_affects = nullptr;
+   __syncthreads();
+
+   const real * traj = v.traj + (size_t) run * np * n;
+   const int s0 = v.offs[run], s1 = v.offs[run+1];
+   double my_depth = 0.0; int my_key = 0x7fffffff;
+   for (int base=s0; base<s1; base+=64)
+   {
+      const int count = (s1 - base < 64) ? s1 - base : 64;
+      // rows of the samples: a0 + (a1 - a0) u on their segments
+      for (int e=tid; e<count*n; e+=ORC_BLOCK)
+      {
+         const int s = e / n, c = e - s*n;
+         const int sg = v.seg[base + s];
+         const real uu = v.u[base + s];
+         const real a0 = traj[sg*n + c], a1 = traj[(sg+1)*n + c];
+         rows_s[s*n + c] = a0 + (a1 - a0) * uu;
+      }
+      __syncthreads();
+      if (mod.floating && tid < count)
+      {
+         real * row = rows_s + tid*n;
+         const real len = M<real>::sqrt_(row[3]*row[3] + row[4]*row[4] + row[5]*row[5] + row[6]*row[6]);
+         const real inv = (real)1 / len;
+         row[3] *= inv; row[4] *= inv; row[5] *= inv; row[6] *= inv;
+      }
+      __syncthreads();
+      {
+         const int s = tid >> 2;
+         const bool valid = (s < count);
+         const int sr = valid ? s : 0;
+         fk_waypoint_quad<real, TREE>(mod, rows_s + sr*n, nj, tid & 3, valid, pos_s + sr*pstr, ax_s + sr*astr);
+      }
+      __syncthreads();
+      for (int item=tid; item<count*Sa; item+=ORC_BLOCK)
+      {
+         const int s = item / Sa, slot = item - s*Sa;
+         if (!((mod.live_mask >> slot) & 1ull)) continue;
+         const real * p = pos_s + s*pstr + slot*3;
+         const real radius = srad_s[slot];
+         for (int i=0; i<v.n_sdfs; i++)
+         {
+            const DevSdf<real> & F = v.sdfs[i];
+            real gp[3], gg[3], val;
+#pragma unroll
+            for (int k=0; k<3; k++)
+               gp[k] = F.Rgw[k*3+0]*p[0] + F.Rgw[k*3+1]*p[1] + F.Rgw[k*3+2]*p[2] + F.tgw[k];
+            if (sdf_lookup(F, gp, val, gg)) continue;                 // outside this field
+            if (val - radius < (real)0)
+            {
+               const int key = ((base - s0 + s) << 12) | (xml_s[slot] << 4) | i;
+               if (key < my_key) { my_key = key; my_depth = (double)(radius - val); }
+               atomicMin(&key_s[0], key);
+            }
+         }
+      }
+      __syncthreads();
+      if (key_s[0] != 0x7fffffff) break;          // a contact in this chunk: later samples cannot come first
+      __syncthreads();
+   }
+   __syncthreads();
+   const int first = key_s[0];
+   if (tid == 0) v.key_out[run] = first;
+   if (first != 0x7fffffff && my_key == first) v.depth_out[run] = my_depth;
+}
+
 } // namespace
 
 // ---------------------------------------------------------------------------
@@ -1261,4 +1368,34 @@ hipError_t orc_launch_seed_f32(float * traj, const double * starts, const double
    int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
    hipLaunchKernelGGL(seed_traj_kernel<float>, dim3(blocks), dim3(256), 0, stream, traj, starts, goals, n_runs, n_points, n, floating);
    return hipGetLastError();
+}
+
+template <typename real>
+static hipError_t launch_verdict_t(const DevVerdict<real> & v, size_t lds, hipStream_t stream, int tree)
+{
+   static bool attr_set = false;
+   if (!attr_set)
+   {
+      hipError_t e = hipFuncSetAttribute((const void *) collision_verdict_kernel<real, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256);
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void *) collision_verdict_kernel<real, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256);
+      if (e != hipSuccess) return e;
+      attr_set = true;
+   }
+   if (lds > 160*1024 - 256) return hipErrorInvalidValue;
+   if (tree) hipLaunchKernelGGL((collision_verdict_kernel<real, true>), dim3(v.n_runs), dim3(ORC_BLOCK), lds, stream, v);
+   else hipLaunchKernelGGL((collision_verdict_kernel<real, false>), dim3(v.n_runs), dim3(ORC_BLOCK), lds, stream, v);
+   return hipGetLastError();
+}
+hipError_t orc_launch_verdict_f64(const DevVerdict<double> & v, size_t lds, hipStream_t stream, int tree) { return launch_verdict_t<double>(v, lds, stream, tree); }
+hipError_t orc_launch_verdict_f32(const DevVerdict<float> & v, size_t lds, hipStream_t stream, int tree) { return launch_verdict_t<float>(v, lds, stream, tree); }
+
+// dynamic LDS of collision_verdict_kernel (the carve-up at its top)
+size_t orc_verdict_lds_bytes(int n, int Sa, int Sa_real, int nj, size_t real_size)
+{
+   const int pstr = (Sa*3) | 1, astr = (nj*6) | 1;
+   auto r4 = [](int x) { return (x + 3) & ~3; };
+   size_t reals = (size_t) r4(64*n) + r4(64*pstr) + r4(64*astr) + r4(Sa*3) + 12 + r4(Sa);
+   size_t ints = (size_t) r4(Sa_real) + r4(Sa);
+   const size_t js = real_size == 8 ? sizeof(DevJoint<double>) : sizeof(DevJoint<float>);
+   return 16 + reals * real_size + ints * 4 + (size_t) nj * js + 64;
 }

@@ -132,6 +132,24 @@ struct DevBatch
    int stagger_sleeps;     // length of that delay in s_sleep(127) units (~8k cycles each)
 };
 
+// Collision verdict of the trajectories of a batch (the step after the path: gettraj's re-check,
+// src/orcdchomp_mod.cpp:2958-3006, with the optimizer's own sphere / field model).
+template <typename real>
+struct DevVerdict
+{
+   const DevModel<real> * model;
+   const DevSdf<real> * sdfs;
+   int n_sdfs;
+   int n_runs, n_points, n;
+   const real * traj;          // [n_runs][n_points][n]
+   const int * offs;           // [n_runs+1] first sample of every run
+   const int * seg;            // [samples] segment of the trajectory the sample lies on
+   const real * u;             // [samples] position on the segment, 0..1
+   const int * slot_xml;       // [Sa lanes] XML index of the sphere in a slot, -1: empty
+   int * key_out;              // [n_runs] first contact: (sample << 12) | (XML sphere << 4) | field, or INT_MAX
+   double * depth_out;         // [n_runs] penetration depth of that contact
+};
+
 // LDS carve-up of one workgroup, shared by the kernel and the host-side size computation.
 // Offsets are in units of `real` after a 128-byte header (reduction scratch).
 struct LdsLayout

@@ -760,12 +760,69 @@ std::string Module::cmd_iterate(const std::vector<std::string> & argv, bool batc
    return o.str();
 }
 
+// Samples of a retimed trajectory every 0.04 rad of C-space distance, the grid of the reference's
+// re-check (src/orcdchomp_mod.cpp:2958-3006): for every sample the segment it lies on, the position
+// on the segment and its time.
+static void plan_collision_samples(const double * traj, int n_points, int n, int col0, const std::vector<double> & dtm,
+   std::vector<int> & seg_out, std::vector<double> & u_out, std::vector<double> & time_out)
+{
+   double total_dist = 0.0, duration = 0.0;
+   for (int i=0; i+1<n_points; i++)
+   {
+      double d2 = 0.0;
+      for (int j=col0; j<n; j++) { const double d = traj[(size_t) i*n+j] - traj[(size_t)(i+1)*n+j]; d2 += d*d; }
+      total_dist += std::sqrt(d2);
+      duration += dtm[i+1];
+   }
+   const double step_time = total_dist > 0.0 ? duration * 0.04 / total_dist : duration + 1.0;
+   int seg = 0; double tseg0 = 0.0;
+   for (double time=0.0; time<duration; time+=step_time)
+   {
+      while (seg < n_points-2 && tseg0 + dtm[seg+1] < time) { tseg0 += dtm[seg+1]; seg++; }
+      const double u = dtm[seg+1] > 0.0 ? (time - tseg0) / dtm[seg+1] : 0.0;
+      seg_out.push_back(seg); u_out.push_back(u); time_out.push_back(time);
+   }
+}
+
+void Module::batch_collision_verdict(int id, int * collides, double * time, int * sphere, int * field, double * depth)
+{
+   Batch & b = batch(id);
+   const int col0 = b.params.floating_base ? 7 : 0;
+   Robot & rob = robot(b.robot_name);
+   std::vector<double> vmax;
+   for (int a : b.adofindices) vmax.push_back(a < (int) rob.limit_vel.size() ? rob.limit_vel[a] : 1.0);
+   std::vector<double> traj((size_t) b.n_runs * b.n_points * b.n);
+   b.gettraj(traj.data());
+   std::vector<int> offs(b.n_runs + 1, 0), seg;
+   std::vector<double> u, times;
+   for (int k=0; k<b.n_runs; k++)
+   {
+      const double * tk = &traj[(size_t) k * b.n_points * b.n];
+      const std::vector<double> dtm = retime_linear(tk, b.n_points, b.n, col0, vmax);
+      plan_collision_samples(tk, b.n_points, b.n, col0, dtm, seg, u, times);
+      offs[k+1] = (int) seg.size();
+      if (offs[k+1] - offs[k] >= (1 << 19)) throw std::runtime_error("trajectory too long for the batched collision verdict!");
+   }
+   std::vector<int> key(b.n_runs); std::vector<double> dep(b.n_runs);
+   b.collision_verdict(offs, seg, u, key.data(), dep.data());
+   for (int k=0; k<b.n_runs; k++)
+   {
+      const bool hit = key[k] != 0x7fffffff;
+      if (collides) collides[k] = hit ? 1 : 0;
+      if (time) time[k] = hit ? times[(size_t) offs[k] + (key[k] >> 12)] : -1.0;
+      if (sphere) sphere[k] = hit ? ((key[k] >> 4) & 255) : -1;
+      if (field) field[k] = hit ? (key[k] & 15) : -1;
+      if (depth) depth[k] = hit ? dep[k] : 0.0;
+   }
+}
+
 // src/orcdchomp_mod.cpp:2854-3011
 std::string Module::cmd_gettraj(const std::vector<std::string> & argv, bool batchmode)
 {
    int run = 0;
    bool no_collision_check = false, no_collision_exception = false, no_collision_details = false;
    double * out_ptr = nullptr;
+   int * verdict_ptr = nullptr;
    const int argc = (int) argv.size();
    int i;
    for (i=1; i<argc; i++)
@@ -775,6 +832,7 @@ std::string Module::cmd_gettraj(const std::vector<std::string> & argv, bool batc
       else if (argv[i] == "no_collision_exception") no_collision_exception = true;
       else if (argv[i] == "no_collision_details") no_collision_details = true;
       else if (batchmode && argv[i] == "out" && i+1 < argc) out_ptr = (double *) parse_pointer(argv[++i]);
+      else if (batchmode && argv[i] == "verdict" && i+1 < argc) verdict_ptr = (int *) parse_pointer(argv[++i]);
       else break;
    }
    if (i < argc) bad_arguments();
@@ -786,6 +844,7 @@ std::string Module::cmd_gettraj(const std::vector<std::string> & argv, bool batc
    {
       if (!out_ptr) throw std::runtime_error("gettrajbatch needs out %p!");
       std::memcpy(out_ptr, traj.data(), traj.size() * sizeof(double));
+      if (verdict_ptr) batch_collision_verdict(run, verdict_ptr, nullptr, nullptr, nullptr, nullptr);
       return "";
    }
    const int col0 = b.params.floating_base ? 7 : 0;

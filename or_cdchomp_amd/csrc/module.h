@@ -87,6 +87,9 @@ public:
    void get_trace(double * out);
    void set_noise(const double * noise, int n_blocks);
    void set_traj(const double * traj);          // [n_runs][n_points][n] host -> device (warm start)
+   // first contact of every run's trajectory with a field, on the device (Module::batch_collision_verdict plans the samples)
+   void collision_verdict(const std::vector<int> & offs, const std::vector<int> & seg, const std::vector<double> & u,
+                          int * key_out, double * depth_out);
    void get_phase_cycles(long long * out);   // [n_runs][8], diagnostics (ORC_PHASE_TIMERS=1)
 
    int n_runs, n_points, n, m;
@@ -95,6 +98,7 @@ public:
    std::string robot_name;
    std::vector<int> adofindices;
    std::vector<int> device_sphere_order;    // XML index of device sphere k
+   std::vector<int> slot_xml;               // XML index of the sphere in lane/slot q of the active block, -1: empty
 private:
    template <typename real> void build_device(const Robot & robot);
    template <typename real> void launch(int n_iter);
@@ -113,6 +117,7 @@ private:
    int max_resamples_ = 0;
    bool debug_state_ = false;   // ORC_DEBUG_STATE=1: keep the last gradient readable (get_state "G")
    int n_sdfs_ = 0;
+   int Sa_real_ = 0;                  // active spheres
    int nj_ = 0, Sa_ = 0, S_ = 0;      // optimized joints; lanes of the active sphere block; lanes + inactive spheres
    int tile_m_ = 0;
    int pcr_in_lds_ = 0;
@@ -158,6 +163,9 @@ public:
       const double * starts, const double * goals, const double * basegoals, const unsigned int * seeds);
    Batch & batch(int id);
    void destroy_batch(int id);
+   // collision verdict of all runs of a batch (gettraj's re-check, batched on the device): per run
+   // collides (0/1), time of the first contact on the retimed trajectory, XML sphere, field, depth
+   void batch_collision_verdict(int id, int * collides, double * time, int * sphere, int * field, double * depth);
 
    hipStream_t stream = nullptr;
    int device;

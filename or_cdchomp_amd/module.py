@@ -205,6 +205,16 @@ class Module:
         self._check(self._lib.orc_batch_gettraj(self._h, bid, _dp(out), out.size))
         return out
 
+    def batch_collision_verdict(self, bid):
+        """gettraj's collision re-check for every run of the batch, on the device: returns a dict of
+        arrays per run: collides (0/1), time of the first contact on the retimed trajectory, XML index
+        of the sphere, index of the field, penetration depth [m]"""
+        n_runs = self.batch_dims(bid)[0]
+        col = np.zeros(n_runs, dtype=np.int32); sph = np.zeros(n_runs, dtype=np.int32); fld = np.zeros(n_runs, dtype=np.int32)
+        tim = np.zeros(n_runs); dep = np.zeros(n_runs)
+        self._check(self._lib.orc_batch_collision_verdict(self._h, bid, _ip(col), _dp(tim), _ip(sph), _ip(fld), _dp(dep)))
+        return dict(collides=col, time=tim, sphere=sph, field=fld, depth=dep)
+
     def batch_state(self, bid, which):
         n_runs, n_points, n = self.batch_dims(bid)
         out = np.zeros((n_runs, n_points - 2, n))

@@ -195,6 +195,45 @@ def test_gettraj_retime_and_collision_verdict(oracle):
     mod.destroy(run=run)
 
 
+def test_batched_collision_verdict_matches_gettraj(oracle):
+    """the device verdict of a whole batch (orc_batch_collision_verdict, `gettrajbatch ... verdict %p`)
+    against the host re-check of `gettraj`, run by run: same first contact (time, sphere, field, depth)"""
+    import re
+    mod = bindings.bind(_mk())
+    model = common.setup_product_wam(mod)
+    vmax = np.ones(model.n_dof); vmax[:7] = [0.5, 1.0, 2.0, 1.0, 4.0, 1.0, 0.25]
+    mod.set_velocity_limits(model.name, vmax)
+    n_runs = 48
+    goals = common.wam_goals(n_runs, seed=99)
+    goals[:8, 1] = np.linspace(-0.4, 0.6, 8)          # a few that sweep the forearm through the table
+    goals[:8, 0] = 1.2; goals[:8, 3] = 0.3
+    kw = dict(n_points=40, lambda_=100.0, obs_factor=20.0)
+    bid = mod.batch_create(model.name, goals, **kw)
+    mod.batch_iterate(bid, 3)
+    got = mod.batch_collision_verdict(bid)
+    # the command form: waypoints and verdicts in one call
+    out = np.zeros((n_runs, 40, 7)); ver = np.full(n_runs, -7, dtype=np.int32)
+    mod.SendCommand("gettrajbatch run %d out 0x%x verdict 0x%x" % (bid, out.ctypes.data, ver.ctypes.data))
+    assert np.array_equal(ver, got["collides"])
+    assert np.array_equal(out, mod.batch_gettraj(bid))
+    mod.batch_destroy(bid)
+    assert 0 < got["collides"].sum() < n_runs, got["collides"]
+    for k in range(n_runs):
+        run = mod.create(robot=model.name, adofgoal=list(goals[k]), **kw)
+        mod.iterate(run=run, n_iter=3)
+        mod.gettraj(run=run, no_collision_exception=True)
+        details = mod.last_collision_details()
+        mod.destroy(run=run)
+        if not got["collides"][k]:
+            assert details == "", (k, details)
+            continue
+        m = re.match(r"Collision at t=(\S+): sphere (\d+) of \S+ is (\S+) m inside the field of (\S+)", details)
+        assert m, (k, details)
+        assert int(m.group(2)) == got["sphere"][k] and m.group(4) == "table" and got["field"][k] == 0
+        assert np.isclose(float(m.group(1)), got["time"][k], rtol=1e-5, atol=1e-9), (k, details, got["time"][k])
+        assert np.isclose(float(m.group(3)), got["depth"][k], rtol=1e-4, atol=1e-9), (k, details, got["depth"][k])
+
+
 def test_starttraj_seeding(oracle):
     """create starttraj: the run starts from the passed trajectory sampled at i*duration/(n_points-1)
     (reference src/orcdchomp_mod.cpp:2375-2416)"""
