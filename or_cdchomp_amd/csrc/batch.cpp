@@ -19,6 +19,11 @@ hipError_t orc_launch_iterate_f32(const DevBatch<float> & b, size_t lds, hipStre
 hipError_t orc_launch_verdict_f64(const DevVerdict<double> & v, size_t lds, hipStream_t stream, int tree);
 hipError_t orc_launch_verdict_f32(const DevVerdict<float> & v, size_t lds, hipStream_t stream, int tree);
 size_t orc_verdict_lds_bytes(int n, int Sa, int Sa_real, int nj, size_t real_size);
+hipError_t orc_launch_hmc_seed(uint32_t * state, int * next, const unsigned int * seeds, int n_runs, hipStream_t stream);
+hipError_t orc_launch_hmc_plan_f64(uint32_t * state, int * next, int n_runs, int n_iter, int cap, size_t mn, double lambda,
+   double * noise, int * iters, int * overflow, hipStream_t stream);
+hipError_t orc_launch_hmc_plan_f32(uint32_t * state, int * next, int n_runs, int n_iter, int cap, size_t mn, double lambda,
+   float * noise, int * iters, int * overflow, hipStream_t stream);
 hipError_t orc_launch_seed_f64(double * traj, const double * starts, const double * goals,
    int n_runs, int n_points, int n, int floating, hipStream_t stream);
 hipError_t orc_launch_seed_f32(float * traj, const double * starts, const double * goals,
@@ -251,8 +256,28 @@ Batch::Batch(Module * mod, const Robot & robot, const BatchParams & p, int nruns
    if (getenv("ORC_PHASE_TIMERS")) d_phase_ = dev_alloc<long long>((size_t) n_runs * 8);
    debug_state_ = getenv("ORC_DEBUG_STATE") != nullptr;
    // hmc state (mod.cpp:2303-2304, 2634-2635)
-   rng_.resize(p.use_hmc ? n_runs : 0);
-   for (int k=0; k<(int) rng_.size(); k++) rng_[k].set(seeds ? seeds[k] : 0);
+   // the streams live on the device for large batches (one thread per run draws the plan of a call),
+   // in host GslRng objects otherwise (and whenever the caller supplies the noise: set_noise)
+   hmc_on_device_ = p.use_hmc && (n_runs >= 256 || getenv("ORC_HMC_DEVICE")) && !getenv("ORC_HMC_HOST");
+   if (hmc_on_device_)
+   {
+      d_mt_ = dev_alloc<uint32_t>((size_t) 625 * n_runs); d_mt_bak_ = dev_alloc<uint32_t>((size_t) 625 * n_runs);
+      d_hmc_next_ = dev_alloc<int>(n_runs); d_hmc_next_bak_ = dev_alloc<int>(n_runs); d_overflow_ = dev_alloc<int>(1);
+      unsigned int * d_seeds = nullptr;
+      if (seeds)
+      {
+         d_seeds = dev_alloc<unsigned int>(n_runs);
+         hip_check(hipMemcpyAsync(d_seeds, seeds, n_runs*sizeof(unsigned int), hipMemcpyHostToDevice, st), "seeds");
+      }
+      hip_check(orc_launch_hmc_seed(d_mt_, d_hmc_next_, d_seeds, n_runs, st), "hmc seed");
+      hip_check(hipStreamSynchronize(st), "hmc seed sync");
+      dev_free(d_seeds);
+   }
+   else
+   {
+      rng_.resize(p.use_hmc ? n_runs : 0);
+      for (int k=0; k<(int) rng_.size(); k++) rng_[k].set(seeds ? seeds[k] : 0);
+   }
    hmc_resample_iter_.assign(n_runs, 0);
 }
 
@@ -260,6 +285,7 @@ Batch::~Batch()
 {
    hipStreamSynchronize(stream_);
    dev_free(d_model_); dev_free(d_sdfs_); dev_free(d_traj_); dev_free(d_AG_); dev_free(d_G_);
+   dev_free(d_mt_); dev_free(d_mt_bak_); dev_free(d_hmc_next_); dev_free(d_hmc_next_bak_); dev_free(d_overflow_);
    dev_free(d_costs_); dev_free(d_trace_); dev_free(d_status_); dev_free(d_leap_);
    dev_free(d_Aband_); dev_free(d_beta_s_); dev_free(d_beta_g_); dev_free(d_pcr_); dev_free(d_Ainv_);
    dev_free(d_jl_lo_); dev_free(d_jl_hi_); dev_free(d_hmc_iters_); dev_free(d_noise_); dev_free(d_phase_);
@@ -722,6 +748,32 @@ static void parallel_for_runs(int count, const std::function<void(int, int)> & b
 void Batch::plan_hmc(int n_iter)
 {
    const size_t mn = (size_t) m * n;
+   if (hmc_on_device_)
+   {
+      const size_t rsize = (params.precision == 64) ? 8 : 4;
+      int cap = 6 + (int) std::ceil(n_iter * params.hmc_resample_lambda * 3.0);
+      for (;;)
+      {
+         const size_t icount = (size_t) n_runs * cap, ncount = icount * mn;
+         if (icount > hmc_cap_iters_) { dev_free(d_hmc_iters_); d_hmc_iters_ = dev_alloc<int>(icount); hmc_cap_iters_ = icount; }
+         if (ncount * rsize > noise_cap_) { dev_free(d_noise_); hip_check(hipMalloc(&d_noise_, ncount * rsize), "noise"); noise_cap_ = ncount * rsize; }
+         // a run with more resamples than `cap` makes the call start over with twice the room
+         hip_check(hipMemcpyAsync(d_mt_bak_, d_mt_, (size_t) 625 * n_runs * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream_), "hmc backup");
+         hip_check(hipMemcpyAsync(d_hmc_next_bak_, d_hmc_next_, n_runs * sizeof(int), hipMemcpyDeviceToDevice, stream_), "hmc backup");
+         hip_check(hipMemsetAsync(d_overflow_, 0, sizeof(int), stream_), "hmc overflow");
+         hipError_t e = (params.precision == 64)
+            ? orc_launch_hmc_plan_f64(d_mt_, d_hmc_next_, n_runs, n_iter, cap, mn, params.hmc_resample_lambda, (double *) d_noise_, d_hmc_iters_, d_overflow_, stream_)
+            : orc_launch_hmc_plan_f32(d_mt_, d_hmc_next_, n_runs, n_iter, cap, mn, params.hmc_resample_lambda, (float *) d_noise_, d_hmc_iters_, d_overflow_, stream_);
+         hip_check(e, "hmc plan");
+         int over = 0;
+         hip_check(hipMemcpyAsync(&over, d_overflow_, sizeof(int), hipMemcpyDeviceToHost, stream_), "hmc overflow");
+         hip_check(hipStreamSynchronize(stream_), "hmc plan sync");
+         if (!over) { max_resamples_ = cap; return; }
+         hip_check(hipMemcpyAsync(d_mt_, d_mt_bak_, (size_t) 625 * n_runs * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream_), "hmc restore");
+         hip_check(hipMemcpyAsync(d_hmc_next_, d_hmc_next_bak_, n_runs * sizeof(int), hipMemcpyDeviceToDevice, stream_), "hmc restore");
+         cap *= 2;
+      }
+   }
    std::vector<std::vector<int>> iters(n_runs);
    std::vector<std::vector<double>> noise(n_runs);
    int maxr = 0;
@@ -919,6 +971,7 @@ void Batch::set_traj(const double * traj)
 
 void Batch::set_noise(const double * noise, int n_blocks)
 {
+   if (hmc_on_device_) throw std::runtime_error("caller-supplied noise needs the host noise streams (ORC_HMC_HOST=1, or fewer than 256 runs)!");
    ext_noise_blocks_ = n_blocks;
    ext_noise_.assign(noise, noise + (size_t) n_runs * n_blocks * m * n);
 }

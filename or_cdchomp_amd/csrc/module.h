@@ -6,6 +6,7 @@
 // third party; the pieces of it the hot path reads are held here explicitly.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdint>
 #include <map>
 #include <memory>
 #include <string>
@@ -128,6 +129,9 @@ private:
    std::vector<double> jl_lo_, jl_hi_;
    // hmc host state per run (src/orcdchomp_mod.cpp:948-952)
    std::vector<GslRng> rng_;
+   // ... or, for large batches, on the device (hmc_kernels.hip): mt19937 state [625][n_runs], next resample iteration [n_runs]
+   bool hmc_on_device_ = false;
+   uint32_t * d_mt_ = nullptr; uint32_t * d_mt_bak_ = nullptr; int * d_hmc_next_ = nullptr; int * d_hmc_next_bak_ = nullptr; int * d_overflow_ = nullptr;
    std::vector<int> hmc_resample_iter_;
    std::vector<double> ext_noise_; int ext_noise_blocks_ = 0;
 };
