@@ -15,9 +15,16 @@ def _mk_module():
     return or_cdchomp_amd.Module(0)
 
 
-def test_floating_base_momentum_hmc(oracle):
+@pytest.mark.parametrize("device_streams", [False, True])
+def test_floating_base_momentum_hmc(oracle, monkeypatch, device_streams):
     """config 4 shape: base pose columns 0..6, all spheres active, hmc resampling from the
-    module's own mt19937 stream (seed = run index), quaternion renormalisation per iteration"""
+    module's own mt19937 stream (seed = run index), quaternion renormalisation per iteration.
+    The streams of a batch live on the host (small batches) or on the device (hmc_kernels.hip,
+    batches of 256 runs and more; forced here): both reproduce the oracle's GSL streams"""
+    if device_streams:
+        monkeypatch.setenv("ORC_HMC_DEVICE", "1")
+    else:
+        monkeypatch.setenv("ORC_HMC_HOST", "1")
     mod = _mk_module()
     model = common.setup_product_wam(mod)
     prob = common.tabletop_problem(oracle)
