@@ -864,6 +864,62 @@ void chomp_iterate_kernel(const DevBatch<real> b)
                const bool row_ok = (item < items);
                const int gi = ts + wl;               // moving waypoint index
 #ifndef ORC_ABLATE_JT
+               if (mod.jt_scan && GS >= 32)
+               {
+                  // as in cost_gs16.h: one suffix scan of the wrench [p x f ; f] over the lanes of the
+                  // waypoint, then lane r finishes joint r from the sums over the range of spheres it moves
+                  real w6[6];
+                  w6[0] = p[1]*f[2] - p[2]*f[1];
+                  w6[1] = p[2]*f[0] - p[0]*f[2];
+                  w6[2] = p[0]*f[1] - p[1]*f[0];
+                  w6[3] = f[0]; w6[4] = f[1]; w6[5] = f[2];
+#pragma unroll
+                  for (int k=0; k<6; k++)
+                  {
+                     real v = live ? w6[k] : (real)0;
+                     if (GS == 64) v = wave_suffix_incl(v);
+                     else
+                     {
+                        // two waypoints per wavefront: suffix inside the 16-lane rows, then the upper row of each half
+                        v += dpp_move<0x101>(v); v += dpp_move<0x102>(v); v += dpp_move<0x104>(v); v += dpp_move<0x108>(v);
+                        const real t16 = read_lane(v, 16), t48 = read_lane(v, 48);
+                        const int ln = tid & 63;
+                        v += (ln < 16) ? t16 : ((ln >= 32 && ln < 48) ? t48 : (real)0);
+                     }
+                     w6[k] = v;
+                  }
+                  for (int j0=0; j0<nj; j0+=GS)
+                  {
+                     const int j = j0 + s;
+                     const bool jok = (j < nj);
+                     const DevJoint<real> & J = mod.joints[jok ? j : 0];
+                     const int ab = J.aff_begin, ae = J.aff_end;
+                     real W[6];
+#pragma unroll
+                     for (int k=0; k<6; k++)
+                     {
+                        const real hi = __shfl(w6[k], ab & (GS-1), GS);
+                        W[k] = (ab < GS) ? hi : (real)0;
+                     }
+                     if (mod.jt_scan == 2)
+                     {
+#pragma unroll
+                        for (int k=0; k<6; k++)
+                        {
+                           const real lo = __shfl(w6[k], ae & (GS-1), GS);
+                           W[k] -= (ae < GS) ? lo : (real)0;
+                        }
+                     }
+                     const real * ax = ax_s + l*astr + (jok ? j : 0)*6;
+                     const real c0 = W[0] - (ax[4]*W[5] - ax[5]*W[4]);
+                     const real c1 = W[1] - (ax[5]*W[3] - ax[3]*W[5]);
+                     const real c2 = W[2] - (ax[3]*W[4] - ax[4]*W[3]);
+                     const real crev = ax[0]*c0 + ax[1]*c1 + ax[2]*c2;
+                     const real cpri = ax[0]*W[3] + ax[1]*W[4] + ax[2]*W[5];
+                     if (jok && row_ok) G_s[gi*n + J.col] = (J.type == 1) ? crev : cpri;
+                  }
+               }
+               else
                for (int j=0; j<nj; j++)
                {
                   real cg = 0;
