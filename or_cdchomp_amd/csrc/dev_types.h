@@ -38,7 +38,7 @@ struct DevJoint
    int aff_begin;     // the active spheres this joint moves are [aff_begin, aff_end) when DevModel::jt_scan != 0
    int aff_end;
    int packed;        // the walk's control word in one LDS read: type | axis_kind<<2 | rfix_identity<<4 | (axis_sign<0)<<5 | sph_begin<<8 | sph_end<<16 | col<<24
-   int pad_;
+   int packed2;       // (load_slot + 2) | (save_slot + 2) << 4: the tree's frame traffic, scalar like `packed`
 };
 
 template <typename real>

@@ -44,7 +44,28 @@ __device__ __forceinline__ void sincos_joint(double x, double * sn, double * cs)
    *sn = (q & 2) ? -sa : sa;
    *cs = ((q + 1) & 2) ? -ca : ca;
 }
-__device__ __forceinline__ void sincos_joint(float x, float * sn, float * cs) { ::sincosf(x, sn, cs); }
+// single precision: 3-part Cody-Waite reduction by pi/2 and the cephes minimax kernels on
+// [-pi/4, pi/4] (published constants); ~1e-7 for |x| < 1e3, far inside the fp32 tolerance (1e-3).
+// The library sincosf carries a large-argument path that costs several times this.
+__device__ __forceinline__ void sincos_joint(float x, float * sn, float * cs)
+{
+   const float k = __builtin_rintf(x * 6.36619772367581382433e-01f);      // 2/pi
+   float r = fmaf(-k, 1.5703125f, x);
+   r = fmaf(-k, 4.837512969970703125e-4f, r);
+   r = fmaf(-k, 7.54978995489188e-8f, r);
+   const float z = r * r;
+   float ps = fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+   ps = fmaf(z, ps, -1.6666654611e-1f);
+   const float s0 = fmaf(r * z, ps, r);
+   float pc = fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+   pc = fmaf(z, pc, 4.166664568298827e-2f);
+   const float c0 = fmaf(z * z, pc, fmaf(z, -0.5f, 1.0f));
+   const int q = ((int) k) & 3;
+   const float sa = (q & 1) ? c0 : s0;
+   const float ca = (q & 1) ? s0 : c0;
+   *sn = (q & 2) ? -sa : sa;
+   *cs = ((q + 1) & 2) ? -ca : ca;
+}
 
 // one row of a frame: R[k][0..2] and t[k]
 template <typename real>
@@ -205,22 +226,25 @@ __device__ __forceinline__ void fk_waypoint_quad(const ModelView<real> & mod, co
          {
             const DevJoint<real> & J = mod.joints[j];
             const int pk = __builtin_amdgcn_readfirstlane(J.packed);
+            const int pk2 = TREE ? __builtin_amdgcn_readfirstlane(J.packed2) : 0;
             if (TREE)
             {
                // continue from the previous joint's frame unless the tree branches here
-               if (J.load_slot == -2) cur = base;
-               else if (J.load_slot == 0) cur = sv0;
-               else if (J.load_slot == 1) cur = sv1;
-               else if (J.load_slot == 2) cur = sv2;
-               else if (J.load_slot == 3) cur = sv3;
+               const int load_slot = (pk2 & 15) - 2;
+               if (load_slot == -2) cur = base;
+               else if (load_slot == 0) cur = sv0;
+               else if (load_slot == 1) cur = sv1;
+               else if (load_slot == 2) cur = sv2;
+               else if (load_slot == 3) cur = sv3;
             }
             fk_joint_row(mod, J, pk, cur, qv[jj], sn[jj], cs[jj], store, ax_wp + j*6 + kk, pos_k);
             if (TREE)
             {
-               if (J.save_slot == 0) sv0 = cur;
-               else if (J.save_slot == 1) sv1 = cur;
-               else if (J.save_slot == 2) sv2 = cur;
-               else if (J.save_slot == 3) sv3 = cur;
+               const int save_slot = ((pk2 >> 4) & 15) - 2;
+               if (save_slot == 0) sv0 = cur;
+               else if (save_slot == 1) sv1 = cur;
+               else if (save_slot == 2) sv2 = cur;
+               else if (save_slot == 3) sv3 = cur;
             }
          }
       }
