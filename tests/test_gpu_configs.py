@@ -243,3 +243,46 @@ def test_two_link_arm_single_tile(oracle):
         run.destroy()
     assert errs and max(errs) <= 1e-6, errs
     print("two-link arm worst rel L2 %.3e" % max(errs))
+
+
+def test_ten_link_chain_two_waypoints_per_wavefront(oracle):
+    """a 10-dof serial chain with 20 spheres: the generic cost path with 32 lanes per waypoint (two
+    waypoints share a wavefront; the J^T suffix scan spans two DPP rows per waypoint)"""
+    mod = _mk_module()
+    model = robots.RobotModel("chain10")
+    R = robots.JOINT_REVOLUTE
+    model.add_link("base")
+    prev = "base"
+    for i in range(10):
+        nm = "c%d" % i
+        model.add_link(nm, prev, (0, 0, 0.12 if i else 0.5), joint=R, axis=(0, 0, 1) if i % 2 == 0 else (0, 1, 0), limits=(-1.8, 1.8))
+        model.add_sphere(nm, (0, 0, 0.03), 0.045)
+        model.add_sphere(nm, (0, 0, 0.09), 0.045)
+        prev = nm
+    base = [-0.9, 0.1, 0.0, 0.0, 0.0, 0.0, 1.0]
+    dofvals = np.zeros(10); dofvals[1] = 0.9; dofvals[3] = 0.7
+    adofs = list(range(10))
+    mod.add_robot(model, transform=base, dof_values=dofvals, active_dofs=adofs)
+    scenes.add_tabletop(mod)
+    mod.SendCommand("computedistancefield kinbody table")
+    prob = common.tabletop_problem(oracle)
+    n_runs, n_points, n_iter = 5, 50, 25
+    goals = np.random.default_rng(12).uniform(-1.2, 1.2, size=(n_runs, 10))
+    kw = dict(n_points=n_points, lambda_=150.0, obs_factor=200.0)
+    bid = mod.batch_create(model.name, goals, **kw)
+    costs, status = mod.batch_iterate(bid, n_iter)
+    traj = mod.batch_gettraj(bid)
+    mod.batch_destroy(bid)
+    rob = oracle.OraRobot(model)
+    errs = []
+    for k in range(n_runs):
+        run = oracle.OraRun(rob, base, dofvals, adofs, goals[k], [prob["sdf"]], [prob["pose"]], oracle.default_params(**kw))
+        assert run.n == 10 and run.Sa == 20
+        st, ocosts = run.iterate(n_iter)
+        assert st == status[k]
+        if st == 0:
+            errs.append(common.rel_l2(traj[k], run.traj()))
+            assert np.allclose(costs[k], ocosts, rtol=1e-6, atol=0), (costs[k], ocosts)
+        run.destroy()
+    assert errs and max(errs) <= 1e-6, errs
+    print("10-link chain (20 spheres, 32 lanes per waypoint) worst rel L2 %.3e" % max(errs))
