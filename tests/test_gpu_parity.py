@@ -136,3 +136,22 @@ def test_send_command_surface(wam, oracle):
         mod.SendCommand("iterate n_iter 3")
     with pytest.raises(RuntimeError, match="We already have an sdf for this kinbody!"):
         mod.SendCommand("computedistancefield kinbody table")
+
+
+def test_e2e_config1_golden(wam):
+    """BASELINE configs[0] against the committed end-to-end fixture (tests/golden/e2e_wam_config1.npz,
+    written by the oracle): trajectories within 1e-6 relative L2 after 1, 10 and 100 iterations"""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "e2e_wam_config1.npz"))
+    mod, model = wam["mod"], wam["model"]
+    kw = dict(n_points=101, lambda_=100.0, obs_factor=500.0)
+    for n_iter in (1, 10, 100):
+        bid = mod.batch_create(model.name, g["goal"], **kw)
+        if n_iter == 1:
+            assert np.array_equal(mod.batch_gettraj(bid)[0], g["seed_traj"])
+        costs, status = mod.batch_iterate(bid, n_iter)
+        traj = mod.batch_gettraj(bid)[0]
+        mod.batch_destroy(bid)
+        assert status[0] == 0
+        assert common.rel_l2(traj, g["traj_%d" % n_iter]) <= TRAJ_TOL
+        assert np.allclose(costs[0], g["costs_%d" % n_iter], rtol=COST_TOL, atol=0)

@@ -237,3 +237,26 @@ def test_oracle_fk_jacobian_finite_difference(oracle):
         affected = sl >= link
         Jcol = np.cross(ax[link], P0[wp, s] - an[link]) if affected else np.zeros(3)
         assert np.allclose(dP[s], Jcol, atol=1e-5)
+
+
+def test_e2e_config1_regression(oracle):
+    """BASELINE configs[0] end to end (tests/golden/make_e2e_golden.py): the oracle reproduces its
+    committed trajectories and costs after 1, 10 and 100 iterations"""
+    import common
+    from or_cdchomp_amd import robots
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "e2e_wam_config1.npz"))
+    model, base, dofvals, adofs = common.wam_state()
+    prob = common.tabletop_problem(oracle)
+    assert list(prob["sizes"]) == list(g["sdf_sizes"]) and np.array_equal(prob["lengths"], g["sdf_lengths"])
+    assert np.array_equal(np.asarray(robots.WAM_GOAL), g["goal"])
+    rob = oracle.OraRobot(model)
+    kw = dict(n_points=101, lambda_=100.0, obs_factor=500.0)
+    for n_iter in (1, 10, 100):
+        run = oracle.OraRun(rob, base, dofvals, adofs, g["goal"], [prob["sdf"]], [prob["pose"]], oracle.default_params(**kw))
+        if n_iter == 1:
+            assert np.array_equal(run.traj(), g["seed_traj"])
+        st, costs = run.iterate(n_iter)
+        assert st == 0
+        assert np.allclose(run.traj(), g["traj_%d" % n_iter], rtol=0, atol=1e-12)
+        assert np.allclose(costs, g["costs_%d" % n_iter], rtol=1e-12, atol=0)
+        run.destroy()
