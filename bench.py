@@ -156,7 +156,13 @@ def main():
             _, _, _, threads = O.batch_run(rob, base, dofvals, adofs, goals0[:sample], [prob["sdf"]],
                                            [prob["pose"]], p, N_ITER, max_threads=0)
             c1 = time.perf_counter()
+            # the same code on ONE core (SURVEY.md 8d asks for both): 8 runs
+            one = min(8, n_runs)
+            s0 = time.perf_counter()
+            O.batch_run(rob, base, dofvals, adofs, goals0[:one], [prob["sdf"]], [prob["pose"]], p, N_ITER, max_threads=1)
+            s1 = time.perf_counter()
             cpu = {"value": sample * N_ITER / (c1 - c0), "unit": "CHOMP iterations/s", "cores": int(threads),
+                   "value_1_core": one * N_ITER / (s1 - s0), "host_cores": int(cores),
                    "kind": "port",
                    "sample": "%d of the %d runs of step 0 x %d iterations, oracle (C restatement of libcd + "
                              "sphere cost, dense A^-1 as the reference), OpenMP over runs, %.1f s wall"
