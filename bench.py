@@ -149,12 +149,19 @@ def main():
 
         if not args.no_cpu_baseline and world == 1:         # the CPU baseline is reported at N=1 only
             cores = os.cpu_count() or 1
+            try:                                  # the container's CPU quota (cgroup v2), when there is one
+                quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+                if quota != "max":
+                    cores = max(1, min(cores, int(round(int(quota) / int(period)))))
+            except (OSError, ValueError):
+                pass
+            cores = min(cores, len(os.sched_getaffinity(0)))
             # ~0.1 s per run (100 iterations) on one core; aim for 10-20 s of wall time
-            sample = args.cpu_runs or int(min(n_runs, max(8, 128 * cores // 1)))
+            sample = args.cpu_runs or int(min(n_runs, max(8, 48 * cores)))
             sample = min(sample, n_runs)
             c0 = time.perf_counter()
             _, _, _, threads = O.batch_run(rob, base, dofvals, adofs, goals0[:sample], [prob["sdf"]],
-                                           [prob["pose"]], p, N_ITER, max_threads=0)
+                                           [prob["pose"]], p, N_ITER, max_threads=cores)
             c1 = time.perf_counter()
             # the same code on ONE core (SURVEY.md 8d asks for both): 8 runs
             one = min(8, n_runs)
