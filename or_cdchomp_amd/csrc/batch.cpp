@@ -733,7 +733,7 @@ void Batch::collision_verdict(const std::vector<int> & offs, const std::vector<i
 static void parallel_for_runs(int count, const std::function<void(int, int)> & body)
 {
    unsigned hw = std::thread::hardware_concurrency();
-   int nt = (int) std::min<unsigned>(hw ? hw : 1u, 64u);
+   int nt = (int) std::min<unsigned>(hw ? hw : 1u, 16u);      // containers often grant far fewer cores than they list
    if (count < 64 || nt < 2) { body(0, count); return; }
    nt = std::min(nt, count / 16);
    std::vector<std::thread> pool;
