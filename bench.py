@@ -142,7 +142,7 @@ def main():
         p = O.default_params(**kw)
         goals0 = common.wam_goals(n_runs, seed=20250101)
         traj0 = mod.batch_gettraj(timed[0])
-        k_check = min(4, n_runs)
+        k_check = min(16, n_runs)
         otraj, ocosts, ost, _ = O.batch_run(rob, base, dofvals, adofs, goals0[:k_check], [prob["sdf"]],
                                             [prob["pose"]], p, N_ITER, max_threads=k_check)
         parity = max(common.rel_l2(traj0[k], otraj[k]) for k in range(k_check))
