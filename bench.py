@@ -132,6 +132,8 @@ def main():
 
     # ---- parity spot check against the oracle on the first timed batch (untimed) ----
     parity = None
+    parity_ill = []
+    k_check = 0
     cpu = None
     if rank == 0:
         from oracle import oracle_py as O
@@ -145,7 +147,19 @@ def main():
         k_check = min(16, n_runs)
         otraj, ocosts, ost, _ = O.batch_run(rob, base, dofvals, adofs, goals0[:k_check], [prob["sdf"]],
                                             [prob["pose"]], p, N_ITER, max_threads=k_check)
-        parity = max(common.rel_l2(traj0[k], otraj[k]) for k in range(k_check))
+        # Some runs of this workload are chaotic in the reference algorithm itself (momentum-free
+        # CHOMP bouncing off joint limits amplifies rounding x4 per projection):
+        # the oracle run again with the goals moved by ONE ulp shows which, and how far such a run
+        # may legitimately drift.  Parity is quoted over the well-conditioned runs; the others are
+        # listed with both figures.
+        ptraj, _, _, _ = O.batch_run(rob, base, dofvals, adofs, goals0[:k_check] * (1.0 + 2.0 ** -52), [prob["sdf"]],
+                                     [prob["pose"]], p, N_ITER, max_threads=k_check)
+        errs = [common.rel_l2(traj0[k], otraj[k]) for k in range(k_check)]
+        self_amp = [common.rel_l2(ptraj[k], otraj[k]) for k in range(k_check)]
+        well = [k for k in range(k_check) if self_amp[k] < 1e-9 and ost[k] == 0]
+        parity = max(errs[k] for k in well) if well else None
+        parity_ill = [{"run": k, "hip_vs_oracle": errs[k], "oracle_vs_oracle_goal_plus_one_ulp": self_amp[k]}
+                      for k in range(k_check) if k not in well]
 
         if not args.no_cpu_baseline and world == 1:         # the CPU baseline is reported at N=1 only
             cores = os.cpu_count() or 1
@@ -227,6 +241,7 @@ def main():
                                          "algorithmic_flop_per_iteration_per_run": FLOP_PER_ITERATION}},
             "cpu_baseline": cpu,
             "parity_rel_l2_max_vs_oracle": parity,
+            "parity_runs_checked": k_check, "parity_ill_conditioned_runs": parity_ill,
             "runs_outside_joint_limits": status_bad,
         }
         print(json.dumps(out))
