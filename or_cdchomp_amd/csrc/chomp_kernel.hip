@@ -666,6 +666,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
          const int nfk = te - ts + 2;          // waypoints ts .. te+1 (global index)
 
          // ================= FK phase: lane = (waypoint, world axis) ===========
+         __builtin_amdgcn_s_setprio(3);          // latency-bound phases go first when they have something to issue
          for (int w0=0; w0<nfk; w0+=ORC_BLOCK/4)
          {
             const int w = w0 + (tid >> 2);
@@ -677,6 +678,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
          ORC_MARK(0);
 
          // ================= cost phase: lane = (waypoint, sphere) =============
+         __builtin_amdgcn_s_setprio(0);
          if constexpr (GS16)
             cost_tile_gs16<real, ORC_U>(b, mod, sdfs, ts, te, do_iteration, T_s, G_s, pos_s, ax_s, srad_s, sinact_s, r2_s,
                                         slink_s, jtype_s, jcol_s, inv_eps, inv_eps_self, cost_lane);
@@ -992,6 +994,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
       if (do_iteration)
       {
          // ================= update phase ======================================
+         __builtin_amdgcn_s_setprio(3);
          // G = G/m + A T + B   (chomp.c:492, 515-522)
          for (int e=tid; e<mn; e+=ORC_BLOCK)
          {
