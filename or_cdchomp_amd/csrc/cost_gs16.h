@@ -144,6 +144,8 @@ __device__ __forceinline__ void cost_tile_gs16(const DevBatch<real> & b, const M
    for (int base_item=0; base_item<items; base_item+=ORC_BLOCK)
    {
       if (base_item + (tid & ~63) >= items) continue;      // a wavefront without a waypoint in this round (wave-uniform)
+      // the last round of a tile goes first: it is what the tile's barrier waits for
+      if (base_item + ORC_BLOCK >= items) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
       const int item = base_item + tid;
       const int g = item >> 4, s = item & 15;
       const bool lane_ok = (item < items) && (((mod.live_mask >> s) & 1ull) != 0);
