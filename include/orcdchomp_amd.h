@@ -31,13 +31,20 @@ typedef struct orc_module orc_module;
  * (src/orcdchomp.cpp:50-74) and the mod constructor/destructor
  * (src/orcdchomp_mod.h:45-75).  device = HIP device ordinal (one process per GPU). */
 orc_module * orc_module_new(int device);
+/* one module over several GPUs of the node, inside one process: every batch is cut into contiguous
+ * blocks of runs, one per entry of `devices` (an ordinal may repeat: its blocks then run on streams
+ * of their own), each block iterates on its device and copies its results straight into the
+ * caller's arrays -- the host-side gather; no collective.  Fields and the robot model
+ * are replicated to every device at create.  orc_module_new(d) is the list {d}. */
+orc_module * orc_module_new_multi(const int * devices, int n_devices);
 void orc_module_free(orc_module * mod);
 const char * orc_last_error(const orc_module * mod);
 /* HIP stream all kernels and copies of this module are issued on (a hipStream_t,
  * e.g. torch.cuda.current_stream().cuda_stream); NULL = the default stream. */
 int orc_set_stream(orc_module * mod, void * hip_stream);
-/* give the module a pool of n internal streams: batches created afterwards are bound to them
- * round-robin, so launches of independent batches overlap on the GPU (0 = back to one stream) */
+/* give the module a pool of n internal streams per device: batches created afterwards are bound to
+ * them round-robin, so launches of independent batches overlap on the GPU (0 = back to one stream).
+ * Fails while batches exist: they hold the streams they were bound to. */
 int orc_set_num_streams(orc_module * mod, int n);
 
 /* ---- SendCommand -------------------------------------------------------------
@@ -46,7 +53,12 @@ int orc_set_num_streams(orc_module * mod, int n);
  * iterate / gettraj / destroy (src/orcdchomp_mod.h:58-66).  Same command names,
  * same argv grammar (shell-style quoting, src/libcd/util_shparse.c), same textual
  * returns.  out receives the reply (NUL terminated, truncated to out_cap).
- * Batch extensions (additive): createbatch, iteratebatch, gettrajbatch. */
+ * Batch extensions (additive): createbatch, iteratebatch, gettrajbatch.
+ * create ... dat_filename PATH writes the reference's per-iteration log "%d %f %f %f %f\n"
+ * (iteration, seconds, cost_total, cost_obs, cost_smooth; mod.cpp:2306-2310, 2811-2818); the seconds
+ * are wall seconds since the iterate call began (the reference: thread CPU seconds), a fused launch's
+ * interval divided evenly over its iterations.  createbatch takes a pattern with %d = run index, and
+ * `devices 'i j ...'` to shard one batch over GPUs (see orc_module_new_multi). */
 int orc_send_command(orc_module * mod, const char * cmd, char * out, size_t out_cap);
 /* size in bytes (without NUL) of the full reply of the last successful command */
 size_t orc_last_reply_size(const orc_module * mod);
@@ -134,10 +146,16 @@ int orc_batch_create(orc_module * mod, const char * robot, const orc_batch_param
  * cost evaluation.  costs_out [n_runs][3] = total, obs, smooth (may be NULL);
  * status_out [n_runs]: 0 ok, -1 "Resulting trajectory is outside of joint limits!". */
 int orc_batch_iterate(orc_module * mod, int batch_id, int n_iter, double * costs_out, int * status_out);
+/* A run that leaves its joint limits stops iterating for the rest of THAT call (the reference throws
+ * out of mod::iterate, src/orcdchomp_mod.cpp:2799-2803) and reports status -1 and the costs of its
+ * last complete iteration; the run stays usable and a later call iterates it again, as in the
+ * reference.  Iterations each run completed in the last call: iters_out [n_runs]. */
+int orc_batch_iterations_done(orc_module * mod, int batch_id, int * iters_out);
 /* asynchronous form for measurement: enqueue only, results stay on the device */
 int orc_batch_iterate_async(orc_module * mod, int batch_id, int n_iter);
 int orc_batch_sync(orc_module * mod, int batch_id, double * costs_out, int * status_out);
-/* per-iteration cost trace of the last iterate call: [n_runs][n_iter][3] */
+/* per-iteration cost trace of the last iterate call: [n_runs][n_iter][3] (total, obs, smooth as the
+ * reference logs them, mod.cpp:2798); rows of iterations an aborted run did not complete are NaN */
 int orc_batch_get_trace(orc_module * mod, int batch_id, double * trace_out, size_t cap_doubles);
 /* momentum noise for HMC resampling supplied by the caller instead of the module's
  * own mt19937 stream: noise [n_runs][n_blocks][m][n] (used in resample order) */
@@ -177,6 +195,12 @@ int orc_host_bin_sdf(const int sizes[3], const double lengths[3], const double *
 /* flood fill from cell `start`, 1.0 -> 0.0, axis neighbours: replaces cd_grid_flood_fill with
  * replace_1_to_0 (src/libcd/grid_flood.c:30-111, src/orcdchomp_mod.cpp:160-168); in place */
 int orc_host_flood_fill(const int sizes[3], double * cells, size_t start);
+/* occupancy the way computedistancefield forms it (src/orcdchomp_mod.cpp:462-531): a cube of
+ * half-extent cube_extent swept over the cell centres of a grid rooted at pose_world_gsdf against
+ * oriented boxes given in the world (box_world_poses [n_boxes][7], half_extents [n_boxes][3]; the
+ * stand-in for OpenRAVE's CheckCollision): occupancy_out gets HUGE_VAL where it touches, 1.0 elsewhere */
+int orc_host_voxelize_boxes(const int sizes[3], const double lengths[3], const double pose_world_gsdf[7], double cube_extent,
+   int n_boxes, const double * box_world_poses, const double * half_extents, double * occupancy_out);
 /* tokenizer of the command grammar: replaces cd_util_shparse (src/libcd/util_shparse.c:37-128).
  * tokens are written NUL-separated into out; returns the token count or -1 if out is too small */
 int orc_host_shparse(const char * in, char * out, size_t out_cap);

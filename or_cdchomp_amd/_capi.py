@@ -34,6 +34,7 @@ class BatchParams(C.Structure):
 # every symbol include/orcdchomp_amd.h declares: (name, restype, argtypes)
 SYMBOLS = [
     ("orc_module_new", C.c_void_p, [C.c_int]),
+    ("orc_module_new_multi", C.c_void_p, [c_int_p, C.c_int]),
     ("orc_module_free", None, [C.c_void_p]),
     ("orc_last_error", C.c_char_p, [C.c_void_p]),
     ("orc_set_stream", C.c_int, [C.c_void_p, C.c_void_p]),
@@ -57,6 +58,7 @@ SYMBOLS = [
     ("orc_batch_iterate", C.c_int, [C.c_void_p, C.c_int, C.c_int, c_double_p, c_int_p]),
     ("orc_batch_iterate_async", C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     ("orc_batch_sync", C.c_int, [C.c_void_p, C.c_int, c_double_p, c_int_p]),
+    ("orc_batch_iterations_done", C.c_int, [C.c_void_p, C.c_int, c_int_p]),
     ("orc_batch_get_trace", C.c_int, [C.c_void_p, C.c_int, c_double_p, C.c_size_t]),
     ("orc_batch_set_noise", C.c_int, [C.c_void_p, C.c_int, c_double_p, C.c_int]),
     ("orc_batch_gettraj", C.c_int, [C.c_void_p, C.c_int, c_double_p, C.c_size_t]),
@@ -69,6 +71,8 @@ SYMBOLS = [
     ("orc_kernel_time", C.c_int, [C.c_void_p, c_double_p, c_int_p, C.c_int]),
     ("orc_host_bin_sdf", C.c_int, [c_int_p, c_double_p, c_double_p, c_double_p]),
     ("orc_host_flood_fill", C.c_int, [c_int_p, c_double_p, C.c_size_t]),
+    ("orc_host_voxelize_boxes", C.c_int, [c_int_p, c_double_p, c_double_p, C.c_double, C.c_int, c_double_p, c_double_p,
+                                          c_double_p]),
     ("orc_host_shparse", C.c_int, [C.c_char_p, C.c_char_p, C.c_size_t]),
     ("orc_host_metric", C.c_int, [C.c_int, C.c_int, C.c_double, c_double_p, c_double_p, c_double_p, c_double_p,
                                   c_double_p, C.c_int, c_double_p]),

@@ -9,6 +9,7 @@
 #include <functional>
 #include <stdexcept>
 #include <thread>
+#include <exception>
 #include <cstdlib>
 
 // launch wrappers implemented in chomp_kernel.hip
@@ -20,9 +21,9 @@ hipError_t orc_launch_verdict_f64(const DevVerdict<double> & v, size_t lds, hipS
 hipError_t orc_launch_verdict_f32(const DevVerdict<float> & v, size_t lds, hipStream_t stream, int tree);
 size_t orc_verdict_lds_bytes(int n, int Sa, int Sa_real, int nj, size_t real_size);
 hipError_t orc_launch_hmc_seed(uint32_t * state, int * next, const unsigned int * seeds, int n_runs, hipStream_t stream);
-hipError_t orc_launch_hmc_plan_f64(uint32_t * state, int * next, int n_runs, int n_iter, int cap, size_t mn, double lambda,
+hipError_t orc_launch_hmc_plan_f64(uint32_t * state, int * next, int n_runs, int iter_begin, int iter_end, int cap, size_t mn, double lambda,
    double * noise, int * iters, int * overflow, hipStream_t stream);
-hipError_t orc_launch_hmc_plan_f32(uint32_t * state, int * next, int n_runs, int n_iter, int cap, size_t mn, double lambda,
+hipError_t orc_launch_hmc_plan_f32(uint32_t * state, int * next, int n_runs, int iter_begin, int iter_end, int cap, size_t mn, double lambda,
    float * noise, int * iters, int * overflow, hipStream_t stream);
 hipError_t orc_launch_seed_f64(double * traj, const double * starts, const double * goals,
    int n_runs, int n_points, int n, int floating, hipStream_t stream);
@@ -51,18 +52,20 @@ real * upload(const std::vector<double> & v, hipStream_t s)
    return d;
 }
 
-void dev_free(void * p) { if (p) hipFree(p); }
+void dev_free(void * p) { if (p) (void) hipFree(p); }
 
 // Placement of the active spheres (given by XML index, sorted by joint) on the 16 lanes of a DPP
 // row.  Rotation K of the self-collision term costs its force evaluation whenever some pair of
 // spheres K lanes apart is within range in any of the four waypoints of a wavefront; pairs are
 // within range mostly for structural reasons (neighbouring links, a hand's fingers), so their
-// frequencies are estimated from configurations on the batch's own seed lines (line_q: values of the
-// active dofs, topped up with random ones when the batch is small) and a seeded annealing run looks
-// for the placement with the fewest expected evaluations.  Returns slot[k] for the k-th
-// sphere; the identity when nothing better than the sorted order is found.  Purely a performance
-// choice: every pair is visited exactly once whatever the placement.
-std::vector<int> place_spheres_on_row(const Robot & robot, const std::vector<double> & line_q, double eps_self, const std::vector<int> & xml)
+// frequencies are estimated from fixed-seed configurations of the active dofs inside their limits
+// (the other dofs frozen where the robot has them) and a seeded annealing run looks for the
+// placement with the fewest expected evaluations.  Returns slot[k] for the k-th sphere; the
+// identity when nothing better than the sorted order is found.  The placement fixes the order in
+// which a sphere's pair forces are added up, so it must not depend on what shares the batch: it is a
+// pure function of the robot (geometry, limits, frozen dof values), the active dofs and eps_self.
+// Every pair is visited exactly once whatever the placement.
+std::vector<int> place_spheres_on_row(const Robot & robot, double eps_self, const std::vector<int> & xml)
 {
    const int Sa = (int) xml.size();
    std::vector<int> ident(Sa);
@@ -72,24 +75,23 @@ std::vector<int> place_spheres_on_row(const Robot & robot, const std::vector<dou
    auto next = [&rng]() { rng = rng * 6364136223846793005ull + 1442695040888963407ull; return (double)(rng >> 11) * (1.0 / 9007199254740992.0); };
    // frequencies of "within range" per pair
    const int n_adof = (int) robot.active_dofs.size();
-   const int n_line = n_adof ? (int)(line_q.size() / n_adof) : 0;
-   const int n_samples = (n_line >= 32) ? n_line : n_line + 64;
+   const int n_samples = 384;
    std::vector<double> freq((size_t) Sa * Sa, 0.0);
    std::vector<double> q = robot.dof_values;
    std::vector<Xform> frames;
    std::vector<double> pw((size_t) Sa * 3);
+   Pose origin;                                  // the base pose moves all spheres alike
    for (int it=0; it<n_samples; it++)
    {
       for (int j=0; j<n_adof; j++)
       {
          const int d = robot.active_dofs[j];
-         if (it < n_line) { q[d] = line_q[(size_t) it*n_adof + j]; continue; }
          double lo = robot.limit_lower[d], hi = robot.limit_upper[d];
          if (!(lo > -1e30)) lo = -3.14159265358979;
          if (!(hi < 1e30)) hi = 3.14159265358979;
          q[d] = lo + (hi - lo) * next();
       }
-      robot.fk(robot.transform, q, frames);
+      robot.fk(origin, q, frames);
       for (int s=0; s<Sa; s++)
       {
          const Robot::Sphere & sp = robot.spheres[xml[s]];
@@ -164,11 +166,19 @@ hipError_t launch_typed(const DevBatch<float> & b, size_t lds, hipStream_t s, in
 
 } // namespace
 
-Batch::Batch(Module * mod, const Robot & robot, const BatchParams & p, int nruns,
+BatchShard::BatchShard(Module * mod, int dev, hipStream_t stream, const Robot & robot, const BatchParams & p, int nruns,
    const double * starts, const double * goals, const double * basegoals, const unsigned int * seeds)
-   : n_runs(nruns), params(p), mod_(mod)
+   : n_runs(nruns), params(p), device(dev), mod_(mod), stream_(stream)
 {
-   stream_ = mod_->pick_stream();
+   DeviceGuard guard(device);
+   try { construct(robot, starts, goals, basegoals, seeds); }
+   catch (...) { release(); throw; }
+}
+
+void BatchShard::construct(const Robot & robot, const double * starts, const double * goals, const double * basegoals,
+   const unsigned int * seeds)
+{
+   const BatchParams & p = params;
    if (p.precision != 64 && p.precision != 32) throw std::runtime_error("precision must be 32 or 64!");
    const int n_adof = (int) robot.active_dofs.size();
    n_points = p.n_points;
@@ -188,19 +198,6 @@ Batch::Batch(Module * mod, const Robot & robot, const BatchParams & p, int nruns
    }
 
    build_metric(m, p.derivative, 1.0/(n_points-1), metric_);       // dt: mod.cpp:2567
-
-   // configurations on the seed lines of (up to 48 of) the runs: what place_spheres_on_row samples
-   placement_q_.clear();
-   for (int i=0, cnt=(n_runs < 48 ? n_runs : 48); i<cnt; i++)
-   {
-      const size_t k = (size_t) i * n_runs / cnt;
-      for (int f=0; f<=5; f++)
-         for (int j=0; j<n_adof; j++)
-         {
-            const double a = starts ? starts[k*n_adof+j] : robot.dof_values[robot.active_dofs[j]];
-            placement_q_.push_back(a + (goals[k*n_adof+j] - a) * (f / 5.0));
-         }
-   }
 
    if (p.precision == 64) build_device<double>(robot); else build_device<float>(robot);
 
@@ -243,15 +240,17 @@ Batch::Batch(Module * mod, const Robot & robot, const BatchParams & p, int nruns
    }
    d_costs_ = dev_alloc<double>((size_t) n_runs * 3);
    d_status_ = dev_alloc<int>(n_runs);
+   d_iters_done_ = dev_alloc<int>(n_runs);
    d_leap_ = dev_alloc<int>(n_runs);
    hip_check(hipMemsetAsync(d_costs_, 0, (size_t) n_runs*3*sizeof(double), st), "memset");
    hip_check(hipMemsetAsync(d_status_, 0, n_runs*sizeof(int), st), "memset");
+   hip_check(hipMemsetAsync(d_iters_done_, 0, n_runs*sizeof(int), st), "memset");
    {
       std::vector<int> ones(n_runs, 1);                              // leapfrog_first = 1, chomp.c:80
       hip_check(hipMemcpyAsync(d_leap_, ones.data(), n_runs*sizeof(int), hipMemcpyHostToDevice, st), "leap");
       hip_check(hipStreamSynchronize(st), "sync");
    }
-   hipFree(d_s); hipFree(d_g);
+   dev_free(d_s); dev_free(d_g);
 
    if (getenv("ORC_PHASE_TIMERS")) d_phase_ = dev_alloc<long long>((size_t) n_runs * 8);
    debug_state_ = getenv("ORC_DEBUG_STATE") != nullptr;
@@ -279,23 +278,55 @@ Batch::Batch(Module * mod, const Robot & robot, const BatchParams & p, int nruns
       for (int k=0; k<(int) rng_.size(); k++) rng_[k].set(seeds ? seeds[k] : 0);
    }
    hmc_resample_iter_.assign(n_runs, 0);
+   ext_noise_used_.assign(n_runs, 0);
+   stagger_mode_ = getenv("ORC_STAGGER_MODE") ? atoi(getenv("ORC_STAGGER_MODE")) : 0;
+   stagger_sleeps_ = getenv("ORC_STAGGER_SLEEPS") ? atoi(getenv("ORC_STAGGER_SLEEPS")) : 10;
 }
 
-Batch::~Batch()
+BatchShard::~BatchShard()
 {
-   hipStreamSynchronize(stream_);
-   dev_free(d_model_); dev_free(d_sdfs_); dev_free(d_traj_); dev_free(d_AG_); dev_free(d_G_);
-   dev_free(d_mt_); dev_free(d_mt_bak_); dev_free(d_hmc_next_); dev_free(d_hmc_next_bak_); dev_free(d_overflow_);
-   dev_free(d_costs_); dev_free(d_trace_); dev_free(d_status_); dev_free(d_leap_);
-   dev_free(d_Aband_); dev_free(d_beta_s_); dev_free(d_beta_g_); dev_free(d_pcr_); dev_free(d_Ainv_);
-   dev_free(d_jl_lo_); dev_free(d_jl_hi_); dev_free(d_hmc_iters_); dev_free(d_noise_); dev_free(d_phase_);
+   DeviceGuard guard(device);
+   (void) hipStreamSynchronize(stream_);
+   try { harvest_events(true); } catch (...) {}
+   release();
+}
+
+void BatchShard::release()
+{
+   void ** all[] = { &d_model_, &d_sdfs_, &d_traj_, &d_AG_, &d_G_, (void **) &d_mt_, (void **) &d_mt_bak_, (void **) &d_hmc_next_,
+                     (void **) &d_hmc_next_bak_, (void **) &d_overflow_, (void **) &d_costs_, (void **) &d_trace_, (void **) &d_status_,
+                     (void **) &d_iters_done_, (void **) &d_leap_, &d_Aband_, &d_beta_s_, &d_beta_g_, &d_pcr_, &d_Ainv_, &d_jl_lo_, &d_jl_hi_,
+                     (void **) &d_hmc_iters_, &d_noise_, (void **) &d_phase_ };
+   for (void ** p : all) { dev_free(*p); *p = nullptr; }
+   sdf_refs_.clear();
+   for (auto & ev : pending_events_) { mod_->event_pool(device).push_back(ev.first); mod_->event_pool(device).push_back(ev.second); }
+   pending_events_.clear();
+}
+
+// kernel timing: a launch is bracketed by two events on the shard's stream
+void BatchShard::harvest_events(bool wait)
+{
+   DeviceGuard guard(device);
+   size_t kept = 0;
+   for (auto & ev : pending_events_)
+   {
+      if (!wait && hipEventQuery(ev.second) != hipSuccess) { pending_events_[kept++] = ev; continue; }
+      hip_check(hipEventSynchronize(ev.second), "hipEventSynchronize");
+      float ms = 0.f;
+      hip_check(hipEventElapsedTime(&ms, ev.first, ev.second), "hipEventElapsedTime");
+      mod_->kernel_ms_total += ms;
+      mod_->kernel_launches++;
+      mod_->event_pool(device).push_back(ev.first);
+      mod_->event_pool(device).push_back(ev.second);
+   }
+   pending_events_.resize(kept);
 }
 
 // Fold the robot into the device model: only optimized joints remain, every other
 // joint is frozen at its current value inside the fixed transforms; active spheres are
 // sorted by the joint they ride on (SURVEY 8a T2 for the active/inactive split).
 template <typename real>
-void Batch::build_device(const Robot & robot)
+void BatchShard::build_device(const Robot & robot)
 {
    const int n_adof = (int) robot.active_dofs.size();
    const int col0 = params.floating_base ? 7 : 0;
@@ -509,11 +540,21 @@ void Batch::build_device(const Robot & robot)
    {
       std::vector<int> xml_of(Sa);
       for (int s=0; s<Sa; s++) xml_of[s] = act[s].xml;
+      // the key holds everything the placement is a function of (the frozen dofs by their bit patterns)
       std::string key = robot.name + (params.floating_base ? "|f|" : "|a|") + std::to_string(params.epsilon_self);
       for (int d : robot.active_dofs) key += "," + std::to_string(d);
+      key += "|";
+      for (int d=0; d<robot.n_dof; d++)
+      {
+         bool act = false;
+         for (int a : robot.active_dofs) if (a == d) act = true;
+         unsigned long long bits = 0; const double v = act ? 0.0 : robot.dof_values[d];
+         std::memcpy(&bits, &v, sizeof(bits));
+         key += std::to_string(bits) + ",";
+      }
       auto hit = mod_->placement_cache.find(key);
       if (hit == mod_->placement_cache.end() || (int) hit->second.size() != Sa)
-         hit = mod_->placement_cache.insert_or_assign(key, place_spheres_on_row(robot, placement_q_, params.epsilon_self, xml_of)).first;
+         hit = mod_->placement_cache.insert_or_assign(key, place_spheres_on_row(robot, params.epsilon_self, xml_of)).first;
       const std::vector<int> & placed = hit->second;
       bool ident = true;
       for (int s=0; s<Sa; s++) if (placed[s] != s) ident = false;
@@ -564,22 +605,26 @@ void Batch::build_device(const Robot & robot)
       const size_t nc = s.grid.ncells();
       if (sizeof(real) == 8)
       {
-         if (!s.d_data64)
+         std::shared_ptr<void> & buf = s.dev64[device];
+         if (!buf)
          {
-            s.d_data64 = dev_alloc<double>(nc);
-            hip_check(hipMemcpy(s.d_data64, s.grid.data.data(), nc*sizeof(double), hipMemcpyHostToDevice), "sdf upload");
+            buf = device_buffer(device, nc*sizeof(double));
+            hip_check(hipMemcpy(buf.get(), s.grid.data.data(), nc*sizeof(double), hipMemcpyHostToDevice), "sdf upload");
          }
-         hs[i].data = (const real *) s.d_data64;
+         hs[i].data = (const real *) buf.get();
+         sdf_refs_.push_back(buf);
       }
       else
       {
-         if (!s.d_data32)
+         std::shared_ptr<void> & buf = s.dev32[device];
+         if (!buf)
          {
             std::vector<float> tmp(s.grid.data.begin(), s.grid.data.end());
-            s.d_data32 = dev_alloc<float>(nc);
-            hip_check(hipMemcpy(s.d_data32, tmp.data(), nc*sizeof(float), hipMemcpyHostToDevice), "sdf upload");
+            buf = device_buffer(device, nc*sizeof(float));
+            hip_check(hipMemcpy(buf.get(), tmp.data(), nc*sizeof(float), hipMemcpyHostToDevice), "sdf upload");
          }
-         hs[i].data = (const real *) s.d_data32;
+         hs[i].data = (const real *) buf.get();
+         sdf_refs_.push_back(buf);
       }
       const Pose pose_world_gsdf = pose_compose(mod_->body_transform(s.kinbody_name), s.pose);
       const Pose pose_gsdf_world = pose_invert(pose_world_gsdf);
@@ -688,9 +733,10 @@ void Batch::build_device(const Robot & robot)
               (m + tile_m_ - 1) / tile_m_, lds_bytes_, (int)(lds_cu / ((lds_bytes_ + 1279) / 1280 * 1280)), pcr_in_lds_, ag_in_lds_, solve_mode_);
 }
 
-void Batch::collision_verdict(const std::vector<int> & offs, const std::vector<int> & seg, const std::vector<double> & u,
+void BatchShard::collision_verdict(const std::vector<int> & offs, const std::vector<int> & seg, const std::vector<double> & u,
    int * key_out, double * depth_out)
 {
+   DeviceGuard guard(device);
    hipStream_t st = stream_;
    hip_check(hipStreamSynchronize(st), "verdict: pending work");
    const size_t ns = seg.size();
@@ -745,9 +791,12 @@ static void parallel_for_runs(int count, const std::function<void(int, int)> & b
    for (std::thread & th : pool) th.join();
 }
 
-void Batch::plan_hmc(int n_iter)
+// Resamples of the iterations [iter_begin, iter_end) of an iterate call; the kernel gets their
+// positions relative to iter_begin, the noise scale uses the call's own counter (mod.cpp:2757).
+void BatchShard::plan_hmc(int iter_begin, int iter_end)
 {
    const size_t mn = (size_t) m * n;
+   const int n_iter = iter_end - iter_begin;
    if (hmc_on_device_)
    {
       const size_t rsize = (params.precision == 64) ? 8 : 4;
@@ -762,8 +811,8 @@ void Batch::plan_hmc(int n_iter)
          hip_check(hipMemcpyAsync(d_hmc_next_bak_, d_hmc_next_, n_runs * sizeof(int), hipMemcpyDeviceToDevice, stream_), "hmc backup");
          hip_check(hipMemsetAsync(d_overflow_, 0, sizeof(int), stream_), "hmc overflow");
          hipError_t e = (params.precision == 64)
-            ? orc_launch_hmc_plan_f64(d_mt_, d_hmc_next_, n_runs, n_iter, cap, mn, params.hmc_resample_lambda, (double *) d_noise_, d_hmc_iters_, d_overflow_, stream_)
-            : orc_launch_hmc_plan_f32(d_mt_, d_hmc_next_, n_runs, n_iter, cap, mn, params.hmc_resample_lambda, (float *) d_noise_, d_hmc_iters_, d_overflow_, stream_);
+            ? orc_launch_hmc_plan_f64(d_mt_, d_hmc_next_, n_runs, iter_begin, iter_end, cap, mn, params.hmc_resample_lambda, (double *) d_noise_, d_hmc_iters_, d_overflow_, stream_)
+            : orc_launch_hmc_plan_f32(d_mt_, d_hmc_next_, n_runs, iter_begin, iter_end, cap, mn, params.hmc_resample_lambda, (float *) d_noise_, d_hmc_iters_, d_overflow_, stream_);
          hip_check(e, "hmc plan");
          int over = 0;
          hip_check(hipMemcpyAsync(&over, d_overflow_, sizeof(int), hipMemcpyDeviceToHost, stream_), "hmc overflow");
@@ -780,8 +829,8 @@ void Batch::plan_hmc(int n_iter)
    parallel_for_runs(n_runs, [&](int k_lo, int k_hi) {
    for (int k=k_lo; k<k_hi; k++)
    {
-      int used_ext = 0;
-      for (int it=0; it<n_iter; it++)
+      int & used_ext = ext_noise_used_[k];
+      for (int it=iter_begin; it<iter_end; it++)
       {
          if (it != hmc_resample_iter_[k]) continue;
          const double alpha = 100.0 * std::exp(0.02 * it);
@@ -792,7 +841,7 @@ void Batch::plan_hmc(int n_iter)
          if (ext_noise_blocks_ > 0 && used_ext < ext_noise_blocks_)
             std::memcpy(&noise[k][off], &ext_noise_[((size_t) k * ext_noise_blocks_ + used_ext) * mn], mn*sizeof(double));
          used_ext++;
-         iters[k].push_back(it);
+         iters[k].push_back(it - iter_begin);
          hmc_resample_iter_[k] += 1 + (int)(-std::log(rng_[k].uniform()) / params.hmc_resample_lambda);
       }
    }
@@ -833,7 +882,7 @@ void Batch::plan_hmc(int n_iter)
 }
 
 template <typename real>
-void Batch::launch(int n_iter)
+void BatchShard::launch(int n_iter, bool final_eval)
 {
    DevBatch<real> b;
    std::memset(&b, 0, sizeof(b));
@@ -843,7 +892,7 @@ void Batch::launch(int n_iter)
    b.n_runs = n_runs; b.n_points = n_points; b.m = m; b.n = n;
    b.tile_m = tile_m_;
    b.traj = (real *) d_traj_; b.AG = (real *) d_AG_; b.Gdbg = (real *) d_G_;
-   b.costs = d_costs_; b.trace = d_trace_; b.status = d_status_; b.leapfrog_first = d_leap_;
+   b.costs = d_costs_; b.trace = d_trace_; b.status = d_status_; b.iters_done = d_iters_done_; b.leapfrog_first = d_leap_;
    const double dt = 1.0/(n_points-1);
    b.dt = (real) dt;
    b.inv_2dt = (real)(1.0/(2.0*dt));
@@ -860,11 +909,10 @@ void Batch::launch(int n_iter)
    b.pcr = (const real *) d_pcr_; b.Ainv = (const real *) d_Ainv_;
    b.jl_lo = (const real *) d_jl_lo_; b.jl_hi = (const real *) d_jl_hi_;
    b.hmc_iters = d_hmc_iters_; b.noise = (const real *) d_noise_; b.max_resamples = max_resamples_;
-   b.n_iter = n_iter; b.final_eval = 1;
+   b.n_iter = n_iter; b.final_eval = final_eval ? 1 : 0;
    b.phase_cycles = d_phase_;
    b.pcr_in_lds = pcr_in_lds_; b.pcr_sym = pcr_sym_; b.pcr_rows = pcr_rows_; b.ag_in_lds = ag_in_lds_;
-   b.stagger_mode = getenv("ORC_STAGGER_MODE") ? atoi(getenv("ORC_STAGGER_MODE")) : 0;
-   b.stagger_sleeps = getenv("ORC_STAGGER_SLEEPS") ? atoi(getenv("ORC_STAGGER_SLEEPS")) : 10;
+   b.stagger_mode = stagger_mode_; b.stagger_sleeps = stagger_sleeps_;
    if (params.derivative == 1 && m >= 2)
    {
       b.a_diag = (real) metric_.Adense[(size_t) 1*m + 1];
@@ -876,15 +924,24 @@ void Batch::launch(int n_iter)
       b.a_off = (real) metric_.beta_s[0];
    }
    b.Gdbg = debug_state_ ? (real *) d_G_ : nullptr;
-   mod_->time_begin(stream_);
+   std::vector<hipEvent_t> & pool = mod_->event_pool(device);
+   hipEvent_t ev[2];
+   for (int k=0; k<2; k++)
+   {
+      if (!pool.empty()) { ev[k] = pool.back(); pool.pop_back(); }
+      else hip_check(hipEventCreate(&ev[k]), "hipEventCreate");
+   }
+   hip_check(hipEventRecord(ev[0], stream_), "hipEventRecord");
    hipError_t e = launch_typed(b, lds_bytes_, stream_, tree_);
    hip_check(e, "chomp_iterate_kernel launch");
-   mod_->time_end(stream_);
+   hip_check(hipEventRecord(ev[1], stream_), "hipEventRecord");
+   pending_events_.push_back(std::make_pair(ev[0], ev[1]));
 }
 
-void Batch::iterate_async(int n_iter)
+void BatchShard::iterate_async(int n_iter, int iter_begin, bool final_eval)
 {
    if (n_iter < 0) throw std::runtime_error("n_iter must be >=0!");
+   DeviceGuard guard(device);
    last_n_iter = n_iter;
    const size_t tneed = (size_t) n_runs * (n_iter ? n_iter : 1) * 3;
    if (tneed > trace_cap_)
@@ -893,17 +950,25 @@ void Batch::iterate_async(int n_iter)
       dev_free(d_trace_); d_trace_ = dev_alloc<double>(tneed); trace_cap_ = tneed;
    }
    max_resamples_ = 0;
-   if (params.use_hmc) plan_hmc(n_iter);
-   if (params.precision == 64) launch<double>(n_iter); else launch<float>(n_iter);
+   if (iter_begin == 0) std::fill(ext_noise_used_.begin(), ext_noise_used_.end(), 0);
+   if (params.use_hmc && n_iter > 0) plan_hmc(iter_begin, iter_begin + n_iter);
+   if (params.precision == 64) launch<double>(n_iter, final_eval); else launch<float>(n_iter, final_eval);
 }
 
-void Batch::sync(double * costs_out, int * status_out)
+void BatchShard::sync_begin(double * costs_out, int * status_out, int * iters_out)
 {
+   DeviceGuard guard(device);
    hipStream_t st = stream_;
    if (costs_out) hip_check(hipMemcpyAsync(costs_out, d_costs_, (size_t) n_runs*3*sizeof(double), hipMemcpyDeviceToHost, st), "costs");
    if (status_out) hip_check(hipMemcpyAsync(status_out, d_status_, n_runs*sizeof(int), hipMemcpyDeviceToHost, st), "status");
-   hip_check(hipStreamSynchronize(st), "hipStreamSynchronize");
-   mod_->time_collect();
+   if (iters_out) hip_check(hipMemcpyAsync(iters_out, d_iters_done_, n_runs*sizeof(int), hipMemcpyDeviceToHost, st), "iters_done");
+}
+
+void BatchShard::sync_end()
+{
+   DeviceGuard guard(device);
+   hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
+   harvest_events(false);
 }
 
 namespace {
@@ -924,13 +989,15 @@ void download(void * d, size_t count, int precision, double * out, hipStream_t s
 }
 }
 
-void Batch::gettraj(double * out)
+void BatchShard::gettraj(double * out)
 {
+   DeviceGuard guard(device);
    download(d_traj_, (size_t) n_runs * n_points * n, params.precision, out, stream_);
 }
 
-void Batch::get_state(const std::string & which, double * out)
+void BatchShard::get_state(const std::string & which, double * out)
 {
+   DeviceGuard guard(device);
    const size_t mcount = (size_t) n_runs * m * n;
    if (which == "G") download(d_G_, mcount, params.precision, out, stream_);
    else if (which == "AG") download(d_AG_, mcount, params.precision, out, stream_);
@@ -944,20 +1011,23 @@ void Batch::get_state(const std::string & which, double * out)
    else throw std::runtime_error("unknown state name");
 }
 
-void Batch::get_trace(double * out)
+void BatchShard::get_trace(double * out)
 {
+   DeviceGuard guard(device);
    hip_check(hipMemcpyAsync(out, d_trace_, (size_t) n_runs * last_n_iter * 3 * sizeof(double), hipMemcpyDeviceToHost, stream_), "trace");
    hip_check(hipStreamSynchronize(stream_), "sync");
 }
 
-void Batch::get_phase_cycles(long long * out)
+void BatchShard::get_phase_cycles(long long * out)
 {
+   DeviceGuard guard(device);
    if (!d_phase_) throw std::runtime_error("phase timers are off (set ORC_PHASE_TIMERS=1 before create)");
    hip_check(hipMemcpy(out, d_phase_, (size_t) n_runs*8*sizeof(long long), hipMemcpyDeviceToHost), "phase");
 }
 
-void Batch::set_traj(const double * traj)
+void BatchShard::set_traj(const double * traj)
 {
+   DeviceGuard guard(device);
    const size_t count = (size_t) n_runs * n_points * n;
    if (params.precision == 64)
       hip_check(hipMemcpyAsync(d_traj_, traj, count*sizeof(double), hipMemcpyHostToDevice, stream_), "set_traj");
@@ -969,14 +1039,160 @@ void Batch::set_traj(const double * traj)
    hip_check(hipStreamSynchronize(stream_), "set_traj sync");
 }
 
-void Batch::set_noise(const double * noise, int n_blocks)
+void BatchShard::set_noise(const double * noise, int n_blocks)
 {
    if (hmc_on_device_) throw std::runtime_error("caller-supplied noise needs the host noise streams (ORC_HMC_HOST=1, or fewer than 256 runs)!");
    ext_noise_blocks_ = n_blocks;
    ext_noise_.assign(noise, noise + (size_t) n_runs * n_blocks * m * n);
 }
 
-template void Batch::build_device<double>(const Robot &);
-template void Batch::build_device<float>(const Robot &);
+template void BatchShard::build_device<double>(const Robot &);
+template void BatchShard::build_device<float>(const Robot &);
+
+// ================================================================ Batch ===
+// the runs of a batch in contiguous blocks over the module's devices: no collective,
+// every shard copies its block straight into the caller's arrays (the host-side gather)
+Batch::Batch(Module * mod, const std::vector<int> & devices, const Robot & robot, const BatchParams & p, int nruns,
+   const double * starts, const double * goals, const double * basegoals, const unsigned int * seeds)
+   : n_runs(nruns), params(p)
+{
+   const int n_adof = (int) robot.active_dofs.size();
+   int world = (int) devices.size();
+   if (world < 1) throw std::runtime_error("a batch needs at least one device!");
+   if (world > n_runs) world = n_runs;
+   offs.assign(world + 1, 0);
+   for (int r=0; r<world; r++)
+   {
+      // the first n_runs % world shards get one extra run (or_cdchomp_amd/sharding.py: shard_bounds)
+      const int base = n_runs / world, extra = n_runs % world;
+      offs[r+1] = offs[r] + base + (r < extra ? 1 : 0);
+   }
+   for (int r=0; r<world; r++)
+   {
+      const size_t lo = (size_t) offs[r];
+      bool repeated = false;                      // a device listed twice: its shards get streams of their own
+      for (int q=0; q<world; q++) if (q != r && devices[q] == devices[r]) repeated = true;
+      shards.emplace_back(new BatchShard(mod, devices[r], mod->pick_stream(devices[r], repeated), robot, p, offs[r+1] - offs[r],
+         starts ? starts + lo * n_adof : nullptr, goals + lo * n_adof, basegoals ? basegoals + lo * 7 : nullptr,
+         seeds ? seeds + lo : nullptr));
+   }
+   const BatchShard & s0 = *shards[0];
+   n_points = s0.n_points; n = s0.n; m = s0.m;
+   robot_name = s0.robot_name; adofindices = s0.adofindices;
+   device_sphere_order = s0.device_sphere_order; slot_xml = s0.slot_xml;
+}
+
+Batch::~Batch()
+{
+   for (FILE * f : dat_) if (f) std::fclose(f);
+}
+
+// body(k) for every shard; on host threads when the bodies block (each asserts its own device)
+void Batch::for_shards(const std::function<void(size_t)> & body, bool threads)
+{
+   if (!threads || shards.size() < 2) { for (size_t k=0; k<shards.size(); k++) body(k); return; }
+   std::vector<std::thread> pool;
+   std::vector<std::exception_ptr> errs(shards.size());
+   for (size_t k=0; k<shards.size(); k++)
+      pool.emplace_back([&body, &errs, k]() { try { body(k); } catch (...) { errs[k] = std::current_exception(); } });
+   for (std::thread & th : pool) th.join();
+   for (std::exception_ptr & e : errs) if (e) std::rethrow_exception(e);
+}
+
+void Batch::iterate_async(int n_iter, int iter_begin, bool final_eval)
+{
+   if (n_iter < 0) throw std::runtime_error("n_iter must be >=0!");
+   last_n_iter = n_iter;
+   // the hmc plan of a shard waits for its device: those go on one host thread per shard
+   for_shards([&](size_t k) { shards[k]->iterate_async(n_iter, iter_begin, final_eval); }, params.use_hmc != 0);
+}
+
+void Batch::sync(double * costs_out, int * status_out, int * iters_out)
+{
+   for (size_t k=0; k<shards.size(); k++)
+      shards[k]->sync_begin(costs_out ? costs_out + (size_t) offs[k]*3 : nullptr, status_out ? status_out + offs[k] : nullptr,
+                            iters_out ? iters_out + offs[k] : nullptr);
+   for (size_t k=0; k<shards.size(); k++) shards[k]->sync_end();
+}
+
+void Batch::gettraj(double * out)
+{
+   for_shards([&](size_t k) { shards[k]->gettraj(out + (size_t) offs[k] * n_points * n); }, true);
+}
+
+void Batch::get_state(const std::string & which, double * out)
+{
+   for_shards([&](size_t k) { shards[k]->get_state(which, out + (size_t) offs[k] * m * n); }, true);
+}
+
+void Batch::get_trace(double * out)
+{
+   for_shards([&](size_t k) { shards[k]->get_trace(out + (size_t) offs[k] * last_n_iter * 3); }, true);
+}
+
+void Batch::set_noise(const double * noise, int n_blocks)
+{
+   for (size_t k=0; k<shards.size(); k++) shards[k]->set_noise(noise + (size_t) offs[k] * n_blocks * m * n, n_blocks);
+}
+
+void Batch::set_traj(const double * traj)
+{
+   for_shards([&](size_t k) { shards[k]->set_traj(traj + (size_t) offs[k] * n_points * n); }, true);
+}
+
+void Batch::get_phase_cycles(long long * out)
+{
+   for (size_t k=0; k<shards.size(); k++) shards[k]->get_phase_cycles(out + (size_t) offs[k] * 8);
+}
+
+void Batch::collision_verdict(const std::vector<int> & soffs, const std::vector<int> & seg, const std::vector<double> & u,
+   int * key_out, double * depth_out)
+{
+   for_shards([&](size_t k) {
+      const int r0 = offs[k], r1 = offs[k+1];
+      std::vector<int> so(r1 - r0 + 1);
+      for (int r=r0; r<=r1; r++) so[r - r0] = soffs[r] - soffs[r0];
+      const std::vector<int> sg(seg.begin() + soffs[r0], seg.begin() + soffs[r1]);
+      const std::vector<double> su(u.begin() + soffs[r0], u.begin() + soffs[r1]);
+      shards[k]->collision_verdict(so, sg, su, key_out + r0, depth_out + r0);
+   }, true);
+}
+
+// create's dat_filename (src/orcdchomp_mod.cpp:2306-2310): one file per run; a batch of several
+// runs takes a printf pattern with one %d (the run index)
+void Batch::open_dat(const std::string & pattern)
+{
+   for (int k=0; k<n_runs; k++)
+   {
+      char name[1024];
+      if (n_runs > 1) std::snprintf(name, sizeof(name), pattern.c_str(), k);
+      else std::snprintf(name, sizeof(name), "%s", pattern.c_str());
+      FILE * f = std::fopen(name, "w");
+      if (!f) throw std::runtime_error("could not open dat_filename for writing!");
+      dat_.push_back(f);
+   }
+}
+
+// "%d %f %f %f %f\n" = iteration, seconds, cost_total, cost_obs, cost_smooth (mod.cpp:2811-2818) for
+// the iterations [iter_begin, iter_begin + iters_done) a launch completed, from the launch's trace.
+// The reference's second column is the thread CPU time since the iterate call began; the fused kernel
+// has no per-iteration host clock, so the launch's wall interval [t_begin, t_end] (seconds since the
+// call began) is divided evenly over its iterations.
+void Batch::write_dat(int iter_begin, int n_iter, const int * iters_done, double t_begin, double t_end)
+{
+   if (dat_.empty() || n_iter <= 0) return;
+   std::vector<double> tr((size_t) n_runs * n_iter * 3);
+   get_trace(tr.data());
+   for (int k=0; k<n_runs; k++)
+   {
+      const int done = iters_done ? iters_done[k] : n_iter;
+      for (int it=0; it<done; it++)
+      {
+         const double * row = &tr[((size_t) k * n_iter + it) * 3];
+         std::fprintf(dat_[k], "%d %f %f %f %f\n", iter_begin + it, t_begin + (t_end - t_begin) * (it + 1) / n_iter, row[0], row[1], row[2]);
+      }
+      std::fflush(dat_[k]);
+   }
+}
 
 } // namespace orc

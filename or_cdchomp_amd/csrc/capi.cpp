@@ -18,7 +18,9 @@ template <typename F>
 int guarded(orc_module * mod, F f)
 {
    if (!mod) return 2;
-   try { f(); mod->last_error.clear(); return 0; }
+   // every entry point asserts the module's (first) device for the calling thread: modules on
+   // different GPUs may share a process, and callers may come from any thread
+   try { orc::DeviceGuard guard(mod->impl->device); f(); mod->last_error.clear(); return 0; }
    catch (const std::exception & e) { mod->last_error = e.what(); return 1; }
    catch (...) { mod->last_error = "unknown error"; return 1; }
 }
@@ -32,6 +34,18 @@ orc_module * orc_module_new(int device)
    {
       orc_module * m = new orc_module;
       m->impl = new orc::Module(device);
+      return m;
+   }
+   catch (const std::exception & e) { g_new_error = e.what(); return nullptr; }
+}
+
+orc_module * orc_module_new_multi(const int * devices, int n_devices)
+{
+   try
+   {
+      if (!devices || n_devices < 1) throw std::runtime_error("orcdchomp_amd: empty device list");
+      orc_module * m = new orc_module;
+      m->impl = new orc::Module(std::vector<int>(devices, devices + n_devices));
       return m;
    }
    catch (const std::exception & e) { g_new_error = e.what(); return nullptr; }
@@ -252,6 +266,11 @@ int orc_batch_sync(orc_module * mod, int id, double * costs_out, int * status_ou
    return guarded(mod, [&] { mod->impl->batch(id).sync(costs_out, status_out); });
 }
 
+int orc_batch_iterations_done(orc_module * mod, int id, int * iters_out)
+{
+   return guarded(mod, [&] { mod->impl->batch(id).sync(nullptr, nullptr, iters_out); });
+}
+
 int orc_batch_get_trace(orc_module * mod, int id, double * out, size_t cap)
 {
    return guarded(mod, [&] {
@@ -360,6 +379,26 @@ int orc_host_flood_fill(const int sizes[3], double * cells, size_t start)
       g.data.assign(cells, cells + g.ncells());
       orc::grid_flood_1_to_0(g, start);
       std::memcpy(cells, g.data.data(), g.ncells() * sizeof(double));
+      return 0;
+   }
+   catch (...) { return 1; }
+}
+
+int orc_host_voxelize_boxes(const int sizes[3], const double lengths[3], const double pose_world_gsdf[7], double cube_extent,
+   int n_boxes, const double * box_world_poses, const double * half_extents, double * occupancy_out)
+{
+   try
+   {
+      orc::Grid g;
+      for (int i=0; i<3; i++) { g.sizes[i] = sizes[i]; g.lengths[i] = lengths[i]; }
+      std::vector<orc::Box> boxes(n_boxes);
+      for (int k=0; k<n_boxes; k++)
+      {
+         boxes[k].world = orc::xform_from_pose(orc::Pose(box_world_poses + 7*k));
+         for (int q=0; q<3; q++) boxes[k].half[q] = half_extents[3*k+q];
+      }
+      orc::voxelize_boxes(g, orc::Pose(pose_world_gsdf), cube_extent, boxes);
+      std::memcpy(occupancy_out, g.data.data(), g.ncells() * sizeof(double));
       return 0;
    }
    catch (...) { return 1; }

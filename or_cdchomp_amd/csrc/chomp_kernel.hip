@@ -22,6 +22,7 @@
 // a self-collision pair on the other sphere is evaluated in that sphere's lane.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <atomic>
 #include "dev_types.h"
 
 // the device arithmetic may fuse a*b+c (the host files are built with -ffp-contract=off so that
@@ -600,7 +601,9 @@ void chomp_iterate_kernel(const DevBatch<real> b)
    const real inv_eps = (real)1 / b.epsilon, inv_eps_self = (real)1 / b.epsilon_self;
    if (b.use_momentum && b.ag_in_lds) for (int e=tid; e<mn; e+=ORC_BLOCK) AG_s[e] = AG_g[e];
    int leapfrog_first = b.leapfrog_first[run];
-   int status = b.status[run];
+   // every iterate call starts afresh: the reference throws out of the call in which a run leaves
+   // its joint limits, the run itself stays usable (src/orcdchomp_mod.cpp:2799-2803)
+   int status = 0;
    int next_resample = 0;      // index into this call's resample list
    __syncthreads();
 
@@ -640,12 +643,15 @@ void chomp_iterate_kernel(const DevBatch<real> b)
    }
 
    double cost_obs = 0.0, cost_smooth = 0.0;
+   // costs of the last pass that ran to its end, and the iterations completed by this launch
+   double done_obs = 0.0, done_smooth = 0.0;
+   bool have_costs = false;
+   int iters_done = 0;
    const int total_passes = b.n_iter + (b.final_eval ? 1 : 0);
 
    for (int it=0; it<total_passes; it++)
    {
       const bool do_iteration = (it < b.n_iter);
-      if (status != 0) break;
 
       // ---- hmc momentum resample (src/orcdchomp_mod.cpp:2755-2768) ----------
       if (do_iteration && b.use_hmc && b.use_momentum && next_resample < b.max_resamples
@@ -1170,6 +1176,10 @@ void chomp_iterate_kernel(const DevBatch<real> b)
          if (b.phase_cycles && tid == 0) { ph[6] += num_limadjs; }   // rounds (ph[7]: violated entries summed over the sparse rounds)
 
       }
+      // "ran too many joint limit fixes! aborting ..." (chomp.c:651-655): cd_chomp_iterate returns
+      // before the smoothness cost, mod::iterate throws before the quaternion renormalisation and
+      // the log line; the trajectory keeps what the limit rounds made of it (workgroup-uniform)
+      if (status != 0) break;
 
       // smoothness cost of the (updated) trajectory (chomp.c:660-677):
       // 0.5 tr(T^T A T) + tr(B^T T) + trC
@@ -1197,7 +1207,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
       ORC_MARK(5);
 
       // floating base: renormalise the quaternion of every row (mod.cpp:2806-2808)
-      if (do_iteration && mod.floating && status == 0)
+      if (do_iteration && mod.floating)
       {
          for (int w=tid; w<np; w+=ORC_BLOCK)
          {
@@ -1214,6 +1224,8 @@ void chomp_iterate_kernel(const DevBatch<real> b)
          double * tr = b.trace + ((size_t) run * b.n_iter + it) * 3;
          tr[0] = cost_obs + cost_smooth; tr[1] = cost_obs; tr[2] = cost_smooth;
       }
+      done_obs = cost_obs; done_smooth = cost_smooth; have_costs = true;
+      if (do_iteration) iters_done++;
    }
 
    // ---- write back ---------------------------------------------------------
@@ -1223,12 +1235,21 @@ void chomp_iterate_kernel(const DevBatch<real> b)
    if (tid == 0)
    {
       if (b.phase_cycles) for (int k=0; k<8; k++) b.phase_cycles[(size_t) run*8 + k] = ph[k];
-      b.costs[(size_t) run*3 + 0] = cost_obs + cost_smooth;
-      b.costs[(size_t) run*3 + 1] = cost_obs;
-      b.costs[(size_t) run*3 + 2] = cost_smooth;
+      // an aborted run reports the costs of its last complete pass (none in this launch: what it had)
+      if (have_costs)
+      {
+         b.costs[(size_t) run*3 + 0] = done_obs + done_smooth;
+         b.costs[(size_t) run*3 + 1] = done_obs;
+         b.costs[(size_t) run*3 + 2] = done_smooth;
+      }
       b.status[run] = status;
+      b.iters_done[run] = iters_done;
       b.leapfrog_first[run] = leapfrog_first;
    }
+   // the iterations an aborted run did not make have no log line in the reference: NaN rows
+   if (b.trace && status != 0)
+      for (int e=iters_done*3 + tid; e<b.n_iter*3; e+=ORC_BLOCK)
+         b.trace[(size_t) run * b.n_iter * 3 + e] = __longlong_as_double(0x7ff8000000000000LL);
 }
 
 // straight-line seeding of every run (src/orcdchomp_mod.cpp:2417-2464):
@@ -1382,13 +1403,16 @@ size_t orc_chomp_lds_bytes(int n_points, int n, int Sa, int S, int nj, int tile_
 template <typename real, bool TREE, bool GS16>
 static hipError_t launch_iterate_tt(const DevBatch<real> & b, size_t lds, hipStream_t stream)
 {
-   static bool attr_set = false;
-   if (!attr_set)
+   // the attribute is per device (and per kernel instantiation)
+   static std::atomic<unsigned long long> attr_set{0ull};
+   int dev = 0;
+   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+   if (!((attr_set.load() >> dev) & 1ull))
    {
       hipError_t e = hipFuncSetAttribute((const void *) chomp_iterate_kernel<real, TREE, GS16>,
          hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256);
       if (e != hipSuccess) return e;
-      attr_set = true;
+      attr_set.fetch_or(1ull << dev);
    }
    hipLaunchKernelGGL((chomp_iterate_kernel<real, TREE, GS16>), dim3(b.n_runs), dim3(ORC_BLOCK), lds, stream, b);
    return hipGetLastError();
@@ -1432,13 +1456,15 @@ hipError_t orc_launch_seed_f32(float * traj, const double * starts, const double
 template <typename real>
 static hipError_t launch_verdict_t(const DevVerdict<real> & v, size_t lds, hipStream_t stream, int tree)
 {
-   static bool attr_set = false;
-   if (!attr_set)
+   static std::atomic<unsigned long long> attr_set{0ull};
+   int dev = 0;
+   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+   if (!((attr_set.load() >> dev) & 1ull))
    {
       hipError_t e = hipFuncSetAttribute((const void *) collision_verdict_kernel<real, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256);
       if (e == hipSuccess) e = hipFuncSetAttribute((const void *) collision_verdict_kernel<real, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256);
       if (e != hipSuccess) return e;
-      attr_set = true;
+      attr_set.fetch_or(1ull << dev);
    }
    if (lds > 160*1024 - 256) return hipErrorInvalidValue;
    if (tree) hipLaunchKernelGGL((collision_verdict_kernel<real, true>), dim3(v.n_runs), dim3(ORC_BLOCK), lds, stream, v);

@@ -98,7 +98,8 @@ struct DevBatch
    real * Gdbg;            // [n_runs][m][n] or null: last gradient, for tests
    double * costs;         // [n_runs][3] total, obs, smooth
    double * trace;         // [n_runs][n_iter][3] or null
-   int * status;           // [n_runs]
+   int * status;           // [n_runs] of this launch: 0, or -1 "outside of joint limits"
+   int * iters_done;       // [n_runs] iterations this launch completed (n_iter unless the run aborted)
    int * leapfrog_first;   // [n_runs]
    // run parameters
    real dt, inv_2dt, inv_dt2, lambda, inv_m;

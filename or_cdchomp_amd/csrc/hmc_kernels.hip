@@ -69,13 +69,15 @@ __global__ void hmc_seed_kernel(uint32_t * state, int * next, const unsigned int
    next[k] = 0;
 }
 
-// the plan of one iterate call: iterations it < n_iter at which run k resamples, and the noise.
+// the plan of the iterations [iter_begin, iter_end) of one iterate call: which of them resample run
+// k's momentum (written relative to iter_begin; the comparison of the reference is `iter ==
+// hmc_resample_iter` with iter restarting at 0 in every call), and the noise.
 // ORC_HMC_TPB runs per workgroup; their states are staged in LDS ([624][ORC_HMC_TPB] words: every
 // draw is a dependent read of the state, a global-memory round trip each otherwise).
 #define ORC_HMC_TPB 32
 template <typename real>
 __global__ __launch_bounds__(ORC_HMC_TPB)
-void hmc_plan_kernel(uint32_t * state, int * next, int n_runs, int n_iter, int cap, size_t mn,
+void hmc_plan_kernel(uint32_t * state, int * next, int n_runs, int iter_begin, int iter_end, int cap, size_t mn,
    double lambda, real * noise, int * iters, int * overflow)
 {
    __shared__ uint32_t lst[624 * ORC_HMC_TPB];
@@ -87,14 +89,14 @@ void hmc_plan_kernel(uint32_t * state, int * next, int n_runs, int n_iter, int c
    Mt mt; mt.st = lst + threadIdx.x; mt.stride = ORC_HMC_TPB; mt.mti = (int) state[(size_t) 624 * n_runs + k];
    int nx = next[k], r = 0;
    for (int q=0; q<cap; q++) iters[(size_t) k * cap + q] = -1;
-   while (nx < n_iter)
+   while (nx >= iter_begin && nx < iter_end)
    {
       if (r >= cap) { atomicOr(overflow, 1); break; }
       const double alpha = 100.0 * exp(0.02 * nx);                 // src/orcdchomp_mod.cpp:2759-2762
       const double sigma = 1.0 / sqrt(alpha);
       real * out = noise + ((size_t) k * cap + r) * mn;
       for (size_t e=0; e<mn; e++) out[e] = (real) mt.gaussian(sigma);
-      iters[(size_t) k * cap + r] = nx;
+      iters[(size_t) k * cap + r] = nx - iter_begin;
       r++;
       nx += 1 + (int)(-log(mt.uniform()) / lambda);
    }
@@ -110,15 +112,15 @@ hipError_t orc_launch_hmc_seed(uint32_t * state, int * next, const unsigned int 
    hipLaunchKernelGGL(hmc_seed_kernel, dim3((n_runs + 63) / 64), dim3(64), 0, stream, state, next, seeds, n_runs);
    return hipGetLastError();
 }
-hipError_t orc_launch_hmc_plan_f64(uint32_t * state, int * next, int n_runs, int n_iter, int cap, size_t mn, double lambda,
+hipError_t orc_launch_hmc_plan_f64(uint32_t * state, int * next, int n_runs, int iter_begin, int iter_end, int cap, size_t mn, double lambda,
    double * noise, int * iters, int * overflow, hipStream_t stream)
 {
-   hipLaunchKernelGGL(hmc_plan_kernel<double>, dim3((n_runs + ORC_HMC_TPB - 1) / ORC_HMC_TPB), dim3(ORC_HMC_TPB), 0, stream, state, next, n_runs, n_iter, cap, mn, lambda, noise, iters, overflow);
+   hipLaunchKernelGGL(hmc_plan_kernel<double>, dim3((n_runs + ORC_HMC_TPB - 1) / ORC_HMC_TPB), dim3(ORC_HMC_TPB), 0, stream, state, next, n_runs, iter_begin, iter_end, cap, mn, lambda, noise, iters, overflow);
    return hipGetLastError();
 }
-hipError_t orc_launch_hmc_plan_f32(uint32_t * state, int * next, int n_runs, int n_iter, int cap, size_t mn, double lambda,
+hipError_t orc_launch_hmc_plan_f32(uint32_t * state, int * next, int n_runs, int iter_begin, int iter_end, int cap, size_t mn, double lambda,
    float * noise, int * iters, int * overflow, hipStream_t stream)
 {
-   hipLaunchKernelGGL(hmc_plan_kernel<float>, dim3((n_runs + ORC_HMC_TPB - 1) / ORC_HMC_TPB), dim3(ORC_HMC_TPB), 0, stream, state, next, n_runs, n_iter, cap, mn, lambda, noise, iters, overflow);
+   hipLaunchKernelGGL(hmc_plan_kernel<float>, dim3((n_runs + ORC_HMC_TPB - 1) / ORC_HMC_TPB), dim3(ORC_HMC_TPB), 0, stream, state, next, n_runs, iter_begin, iter_end, cap, mn, lambda, noise, iters, overflow);
    return hipGetLastError();
 }

@@ -295,6 +295,22 @@ bool obb_overlap(const Xform & a, const double ha[3], const Xform & b, const dou
    return true;
 }
 
+void voxelize_boxes(Grid & g, const Pose & pose_world_gsdf, double cube_extent, const std::vector<Box> & obstacles)
+{
+   const double hc[3] = { cube_extent, cube_extent, cube_extent };
+   const size_t nc = g.ncells();
+   g.data.assign(nc, 1.0);
+   for (size_t idx=0; idx<nc; idx++)
+   {
+      Pose pc;
+      g.center(idx, pc.v);
+      const Pose pw = pose_compose(pose_world_gsdf, pc);
+      const Xform xc = xform_from_pose(pw);
+      for (const Box & b : obstacles)
+         if (obb_overlap(xc, hc, b.world, b.half, 1e-9)) { g.data[idx] = HUGE_VAL; break; }
+   }
+}
+
 // =============================================================== metric ===
 namespace {
 

@@ -63,6 +63,10 @@ int grid_interp(const Grid & g, const double p[3], double * value);
 struct Box { Xform world; double half[3]; };
 // true when two oriented boxes overlap by more than `tol` (separating axis test)
 bool obb_overlap(const Xform & a, const double ha[3], const Xform & b, const double hb[3], double tol);
+// occupancy of a grid rooted at pose_world_gsdf: a cube of half-extent cube_extent is swept over the
+// cell centres (src/orcdchomp_mod.cpp:462-531, OpenRAVE's CheckCollision replaced by the box-box
+// test above): HUGE_VAL where it touches a box, 1.0 elsewhere.  g.data is overwritten.
+void voxelize_boxes(Grid & g, const Pose & pose_world_gsdf, double cube_extent, const std::vector<Box> & obstacles);
 
 // --------------------------------------------------------------- metric ---
 // Band form of the smoothness metric of cd_chomp_add_KEs / cd_chomp_init

@@ -14,6 +14,8 @@
 
 hipError_t orc_sdf_from_occupancy_device(const double * occ, double * sdf_out, const int sizes[3], const double lengths[3],
    hipStream_t st);
+hipError_t orc_sdf_build_device(const int sizes[3], const double lengths[3], const double grid_xform[12], const double grid_pose[7],
+   double cube_extent, int n_boxes, const double * boxes, double * sdf_out, hipStream_t st);
 
 namespace orc {
 
@@ -66,76 +68,112 @@ void Robot::fk(const Pose & base, const std::vector<double> & q, std::vector<Xfo
 }
 
 // =============================================================== Module ===
-Module::Module(int dev) : device(dev)
+DeviceGuard::DeviceGuard(int device)
+{
+   if (hipGetDevice(&prev_) != hipSuccess) prev_ = -1;
+   if (prev_ != device)
+   {
+      hip_check(hipSetDevice(device), "hipSetDevice");
+      changed_ = true;
+   }
+}
+
+DeviceGuard::~DeviceGuard()
+{
+   if (changed_ && prev_ >= 0) (void) hipSetDevice(prev_);
+}
+
+std::shared_ptr<void> device_buffer(int device, size_t bytes)
+{
+   DeviceGuard guard(device);
+   void * p = nullptr;
+   hip_check(hipMalloc(&p, bytes ? bytes : 1), "hipMalloc");
+   return std::shared_ptr<void>(p, [device](void * q) {
+      int prev = -1;
+      const bool have = hipGetDevice(&prev) == hipSuccess;
+      (void) hipSetDevice(device);
+      (void) hipFree(q);
+      if (have && prev != device) (void) hipSetDevice(prev);
+   });
+}
+
+Module::Module(int dev) : Module(std::vector<int>(1, dev)) {}
+
+Module::Module(const std::vector<int> & devs) : device(devs.empty() ? 0 : devs[0]), devices(devs)
 {
    int count = 0;
    hipError_t e = hipGetDeviceCount(&count);
    if (e != hipSuccess || count <= 0)
       throw std::runtime_error("orcdchomp_amd: no HIP device available (the MI355X path has no CPU fallback)");
-   if (dev < 0 || dev >= count) throw std::runtime_error("orcdchomp_amd: bad device ordinal");
-   hip_check(hipSetDevice(dev), "hipSetDevice");
+   if (devices.empty()) throw std::runtime_error("orcdchomp_amd: empty device list");
+   for (int d : devices) if (d < 0 || d >= count) throw std::runtime_error("orcdchomp_amd: bad device ordinal");
+   hip_check(hipSetDevice(device), "hipSetDevice");
 }
 
 Module::~Module()
 {
    batches_.clear();
-   for (auto & s : sdfs) { if (s->d_data64) hipFree(s->d_data64); if (s->d_data32) hipFree(s->d_data32); }
-   for (auto & p : pending_events_) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
-   for (auto & e : event_pool_) hipEventDestroy(e);
-   for (hipStream_t st : stream_pool) hipStreamDestroy(st);
+   sdfs.clear();
+   for (auto & kv : event_pool_)
+   {
+      DeviceGuard guard(kv.first);
+      for (hipEvent_t ev : kv.second) (void) hipEventDestroy(ev);
+   }
+   for (auto & kv : stream_pool)
+   {
+      DeviceGuard guard(kv.first);
+      for (hipStream_t st : kv.second) (void) hipStreamDestroy(st);
+   }
 }
 
+// a pool of n streams on every device of the module; live batches hold the streams they were bound
+// to, so the pool only changes while no batch exists
 void Module::set_num_streams(int n)
 {
-   for (hipStream_t st : stream_pool) hipStreamDestroy(st);
-   stream_pool.clear();
-   for (int k=0; k<n; k++)
+   if (!batches_.empty())
+      throw std::runtime_error("orc_set_num_streams: destroy the existing batches first (they hold the pool's streams)");
+   for (auto & kv : stream_pool)
    {
-      hipStream_t st;
-      hip_check(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate");
-      stream_pool.push_back(st);
+      DeviceGuard guard(kv.first);
+      for (hipStream_t st : kv.second) (void) hipStreamDestroy(st);
    }
-   next_pool_stream = 0;
+   stream_pool.clear();
+   next_pool_stream.clear();
+   num_streams = n;
 }
 
-hipStream_t Module::pick_stream()
+// the stream a new shard on `dev` is bound to: round-robin over the device's pool when there is one
+// (created on first use), else the module's stream on the first device and the default stream
+// elsewhere.  `distinct`: the shard shares its device with another shard of the same batch and must
+// not queue behind it.
+hipStream_t Module::pick_stream(int dev, bool distinct)
 {
-   if (stream_pool.empty()) return stream;
-   return stream_pool[next_pool_stream++ % stream_pool.size()];
-}
-
-void Module::time_begin(hipStream_t st)
-{
-   hipEvent_t a;
-   if (!event_pool_.empty()) { a = event_pool_.back(); event_pool_.pop_back(); }
-   else hip_check(hipEventCreate(&a), "hipEventCreate");
-   hip_check(hipEventRecord(a, st), "hipEventRecord");
-   ev_begin_ = a;
-}
-
-void Module::time_end(hipStream_t st)
-{
-   hipEvent_t b;
-   if (!event_pool_.empty()) { b = event_pool_.back(); event_pool_.pop_back(); }
-   else hip_check(hipEventCreate(&b), "hipEventCreate");
-   hip_check(hipEventRecord(b, st), "hipEventRecord");
-   pending_events_.push_back(std::make_pair(ev_begin_, b));
-   ev_begin_ = nullptr;
+   int want = num_streams;
+   if (distinct && want < 2)
+   {
+      int same = 0;
+      for (int d : devices) if (d == dev) same++;
+      want = same > 2 ? same : 2;
+   }
+   if (want <= 0) return dev == device ? stream : nullptr;
+   std::vector<hipStream_t> & pool = stream_pool[dev];
+   if ((int) pool.size() < want)
+   {
+      DeviceGuard guard(dev);
+      while ((int) pool.size() < want)
+      {
+         hipStream_t st;
+         hip_check(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate");
+         pool.push_back(st);
+      }
+   }
+   return pool[next_pool_stream[dev]++ % pool.size()];
 }
 
 void Module::time_collect()
 {
-   for (auto & p : pending_events_)
-   {
-      hip_check(hipEventSynchronize(p.second), "hipEventSynchronize");
-      float ms = 0.f;
-      hip_check(hipEventElapsedTime(&ms, p.first, p.second), "hipEventElapsedTime");
-      kernel_ms_total += ms;
-      kernel_launches++;
-      event_pool_.push_back(p.first);
-      event_pool_.push_back(p.second);
-   }
-   pending_events_.clear();
+   for (auto & kv : batches_)
+      for (auto & sh : kv.second->shards) sh->harvest_events(false);
 }
 
 void Module::add_robot(const Robot & r)
@@ -197,10 +235,17 @@ void Module::add_sdf(const std::string & kb, const Grid & g, const Pose & pose)
 }
 
 int Module::create_batch(const std::string & rname, const BatchParams & p, int n_runs,
-   const double * starts, const double * goals, const double * basegoals, const unsigned int * seeds)
+   const double * starts, const double * goals, const double * basegoals, const unsigned int * seeds,
+   const std::vector<int> * devices_override)
 {
    Robot & r = robot(rname);
-   std::unique_ptr<Batch> b(new Batch(this, r, p, n_runs, starts, goals, basegoals, seeds));
+   if (devices_override)
+   {
+      int count = 0;
+      hip_check(hipGetDeviceCount(&count), "hipGetDeviceCount");
+      for (int d : *devices_override) if (d < 0 || d >= count) throw std::runtime_error("orcdchomp_amd: bad device ordinal");
+   }
+   std::unique_ptr<Batch> b(new Batch(this, devices_override ? *devices_override : devices, r, p, n_runs, starts, goals, basegoals, seeds));
    const int id = next_batch_id_++;
    batches_[id] = std::move(b);
    return id;
@@ -429,22 +474,38 @@ std::string Module::cmd_computedistancefield(const std::vector<std::string> & ar
             obstacles.push_back(b);
          }
       }
-      const double hc[3] = { cube_extent, cube_extent, cube_extent };
-      const size_t nc = g.ncells();
-      for (size_t idx=0; idx<nc; idx++)
+      // voxelize -> flood fill from cell 0 (reachable 1.0 -> 0.0, the rest becomes obstacle,
+      // mod.cpp:540-548) -> signed distance field (mod.cpp:560): on the GPU for large grids
+      // (or ORC_SDF_DEVICE=1), on the host otherwise; both give the same cells bit for bit
+      const char * env = getenv("ORC_SDF_DEVICE");
+      const bool on_device = env ? (atoi(env) != 0) : (g.ncells() >= (size_t) 1 << 18);
+      if (on_device)
       {
-         Pose pc;
-         g.center(idx, pc.v);
-         const Pose pw = pose_compose(pose_world_gsdf, pc);
-         const Xform xc = xform_from_pose(pw);
+         DeviceGuard guard(device);
+         std::vector<double> bx;                       // per box: R[9] t[3] half[3]
          for (const Box & b : obstacles)
-            if (obb_overlap(xc, hc, b.world, b.half, 1e-9)) { g.data[idx] = HUGE_VAL; break; }
+         {
+            bx.insert(bx.end(), b.world.R.m, b.world.R.m + 9);
+            bx.insert(bx.end(), b.world.t, b.world.t + 3);
+            bx.insert(bx.end(), b.half, b.half + 3);
+         }
+         const Xform xg = xform_from_pose(pose_world_gsdf);
+         double gx[12];
+         for (int q=0; q<9; q++) gx[q] = xg.R.m[q];
+         for (int q=0; q<3; q++) gx[9+q] = xg.t[q];
+         hip_check(orc_sdf_build_device(g.sizes, g.lengths, gx, pose_world_gsdf.v, cube_extent, (int) obstacles.size(), bx.data(),
+                                        g.data.data(), stream), "sdf build");
       }
-      grid_flood_1_to_0(g, 0);                                                   // mod.cpp:540-548
-      for (size_t idx=0; idx<nc; idx++) if (g.data[idx] == 1.0) g.data[idx] = HUGE_VAL;
-      Grid sdf;
-      bin_sdf_any(g, sdf, stream);                                               // mod.cpp:560
-      g = sdf;
+      else
+      {
+         voxelize_boxes(g, pose_world_gsdf, cube_extent, obstacles);
+         grid_flood_1_to_0(g, 0);                                                   // mod.cpp:540-548
+         const size_t nc = g.ncells();
+         for (size_t idx=0; idx<nc; idx++) if (g.data[idx] == 1.0) g.data[idx] = HUGE_VAL;
+         Grid sdf;
+         grid_bin_sdf(g, sdf);                                                      // mod.cpp:560
+         g = sdf;
+      }
       if (have_cache)
       {
          std::ofstream fp(cache_filename.c_str(), std::ios::binary);
@@ -532,9 +593,7 @@ std::string Module::cmd_removefield(const std::vector<std::string> & argv)
    for (size_t k=0; k<sdfs.size(); k++)
       if (sdfs[k]->kinbody_name == kb)
       {
-         if (sdfs[k]->d_data64) hipFree(sdfs[k]->d_data64);
-         if (sdfs[k]->d_data32) hipFree(sdfs[k]->d_data32);
-         sdfs.erase(sdfs.begin() + k);
+         sdfs.erase(sdfs.begin() + k);      // device copies live on while a batch still reads them
          return "";
       }
    throw std::runtime_error("No sdf for that kinbody!");
@@ -550,6 +609,8 @@ std::string Module::cmd_create(const std::vector<std::string> & argv, bool batch
    BatchParams p;
    unsigned int seed = 0;
    int n_runs = 1;
+   std::string dat_filename;
+   std::vector<int> devs; bool have_devs = false;
    const double * goals_ptr = nullptr, * starts_ptr = nullptr, * basegoals_ptr = nullptr;
    const unsigned int * seeds_ptr = nullptr;
    const int argc = (int) argv.size();
@@ -589,8 +650,7 @@ std::string Module::cmd_create(const std::vector<std::string> & argv, bool batch
       else if (a == "obs_factor" && i+1 < argc) p.obs_factor = std::atof(argv[++i].c_str());
       else if (a == "obs_factor_self" && i+1 < argc) p.obs_factor_self = std::atof(argv[++i].c_str());
       else if (a == "no_report_cost") { /* emitted by the python layer, ignored */ }
-      else if (a == "dat_filename" && i+1 < argc)
-         throw std::runtime_error("dat_filename is not supported by this build (per-iteration costs: iteratebatch trace)");
+      else if (a == "dat_filename" && i+1 < argc) dat_filename = argv[++i];
       else if (a == "starttraj" && i+1 < argc)
       {
          if (have_starttraj) throw std::runtime_error("Only one starttraj can be passed!");
@@ -608,6 +668,12 @@ std::string Module::cmd_create(const std::vector<std::string> & argv, bool batch
       else if (batchmode && a == "basegoals" && i+1 < argc) basegoals_ptr = (const double *) parse_pointer(argv[++i]);
       else if (batchmode && a == "seeds" && i+1 < argc) seeds_ptr = (const unsigned int *) parse_pointer(argv[++i]);
       else if (batchmode && a == "precision" && i+1 < argc) p.precision = std::atoi(argv[++i].c_str());
+      else if (batchmode && a == "devices" && i+1 < argc)
+      {
+         for (const std::string & t : shparse(argv[++i])) devs.push_back(std::atoi(t.c_str()));
+         if (devs.empty()) throw std::runtime_error("devices must name at least one device!");
+         have_devs = true;
+      }
       else break;
    }
    if (i < argc) bad_arguments();
@@ -672,7 +738,12 @@ std::string Module::cmd_create(const std::vector<std::string> & argv, bool batch
       if (have_starttraj) batch(id).set_traj(sampled.data());
    }
    else
-      id = create_batch(rname, p, n_runs, starts_ptr, goals_ptr, basegoals_ptr, seeds_ptr);
+      id = create_batch(rname, p, n_runs, starts_ptr, goals_ptr, basegoals_ptr, seeds_ptr, have_devs ? &devs : nullptr);
+   if (!dat_filename.empty())
+   {
+      try { batch(id).open_dat(dat_filename); }
+      catch (...) { destroy_batch(id); throw; }
+   }
    std::ostringstream o;
    o << id;
    return o.str();
@@ -714,41 +785,66 @@ std::string Module::cmd_iterate(const std::vector<std::string> & argv, bool batc
    if (n_iter < 0) throw std::runtime_error("n_iter must be >=0!");
    Batch & b = batch(run);
    std::vector<double> costs((size_t) b.n_runs * 3, 0.0);
-   std::vector<int> status(b.n_runs, 0);
+   std::vector<int> status(b.n_runs, 0), iters(b.n_runs, 0);
    if (have_fileform && b.params.floating_base)
       throw std::runtime_error("Error: trajs_fileformstr and floating_base combined is not yet implemented!");
+   // seconds since the call began, without the time spent writing trajectory dumps (mod.cpp:2748-2750,
+   // 2781-2795: the reference stops its clock around the dump)
+   auto t_last = std::chrono::steady_clock::now();
+   double ticks = 0.0;
+   auto clock_now = [&]() {
+      const auto now = std::chrono::steady_clock::now();
+      ticks += std::chrono::duration<double>(now - t_last).count();
+      t_last = now;
+      return ticks;
+   };
    if (!have_fileform && max_time == HUGE_VAL)
    {
       b.iterate_async(n_iter);
-      b.sync(costs.data(), status.data());
+      b.sync(costs.data(), status.data(), iters.data());
+      if (b.has_dat()) b.write_dat(0, n_iter, iters.data(), 0.0, clock_now());
    }
    else
    {
-      // the trajectory dump before each iteration and the time limit need the host
-      // between iterations: one iteration per launch.  Note r->iter restarts at 0 for
-      // every iterate call in the reference (mod.cpp:2752); hmc schedules are planned
-      // per call, so chunking is only offered without use_hmc.
-      if (b.params.use_hmc) throw std::runtime_error("max_time/trajs_fileformstr with use_hmc is not supported by this build");
-      const auto t0 = std::chrono::steady_clock::now();
+      // the trajectory dump before each iteration and the time limit need the host between
+      // iterations: one iteration per launch, the cost-only pass once at the end (mod.cpp:2830).
+      // r->iter restarts at 0 in every iterate call while hmc_resample_iter persists (mod.cpp:2752,
+      // 2755): the launches pass their position in the call on to the hmc schedule.
       std::vector<double> traj((size_t) b.n_runs * b.n_points * b.n);
+      std::vector<int> st1(b.n_runs, 0);
+      bool aborted = false;
       for (int it=0; it<n_iter; it++)
       {
          if (have_fileform)
          {
-            b.gettraj(traj.data());
-            char fname[1024];
-            std::snprintf(fname, sizeof(fname), fileform.c_str(), it);
-            std::ofstream f(fname);
-            f << serialize_traj(b.robot_name, b.adofindices, traj.data(), b.n_points, b.n, 0,
-                                std::vector<double>(b.n_points, 0.0));
+            clock_now();
+            for (int k=0; k<b.n_runs; k++)
+            {
+               if (k == 0) b.gettraj(traj.data());
+               char fname[1024];
+               // one run: the reference's file name; a batch: the pattern takes (iteration, run)
+               std::snprintf(fname, sizeof(fname), fileform.c_str(), it, k);
+               std::ofstream f(fname);
+               f << serialize_traj(b.robot_name, b.adofindices, &traj[(size_t) k * b.n_points * b.n], b.n_points, b.n, 0,
+                                   std::vector<double>(b.n_points, 0.0));
+            }
+            t_last = std::chrono::steady_clock::now();        // the dump is off the clock
          }
-         b.iterate_async(1);
-         b.sync(costs.data(), status.data());
-         if (status[0] != 0) break;
-         const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-         if (el > max_time) break;
+         const double t_begin = ticks;
+         b.iterate_async(1, it, false);
+         b.sync(costs.data(), st1.data(), iters.data());
+         const double t_end = clock_now();
+         if (b.has_dat()) b.write_dat(it, 1, iters.data(), t_begin, t_end);
+         for (int k=0; k<b.n_runs; k++) if (st1[k] != 0) { status[k] = st1[k]; aborted = true; }
+         // a single run stops where the reference throws; a batch goes on for its other runs
+         if (aborted && b.n_runs == 1) break;
+         if (t_end > max_time) break;
       }
-      if (n_iter == 0) { b.iterate_async(0); b.sync(costs.data(), status.data()); }
+      if (!(aborted && b.n_runs == 1))
+      {
+         b.iterate_async(0, 0, true);                          // cd_chomp_iterate(c, 0, ...) (mod.cpp:2830)
+         b.sync(costs.data(), st1.data(), nullptr);
+      }
    }
    if (costs_ptr) std::memcpy(costs_ptr, costs.data(), costs.size() * sizeof(double));
    if (status_ptr) std::memcpy(status_ptr, status.data(), status.size() * sizeof(int));

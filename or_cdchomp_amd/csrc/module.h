@@ -7,6 +7,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <cstdio>
+#include <functional>
 #include <map>
 #include <memory>
 #include <string>
@@ -48,14 +50,32 @@ struct KinBody                    // box-only kinbody (InitFromBoxes style)
    std::vector<B> boxes;
 };
 
+// makes `device` the calling thread's current HIP device for the lifetime of the object
+// (every entry point of a batch asserts its device: several modules, or the shards of one batch,
+// may live on different GPUs of the node inside one process)
+class DeviceGuard
+{
+public:
+   explicit DeviceGuard(int device);
+   ~DeviceGuard();
+   DeviceGuard(const DeviceGuard &) = delete;
+   DeviceGuard & operator=(const DeviceGuard &) = delete;
+private:
+   int prev_ = -1;
+   bool changed_ = false;
+};
+
+// device memory released on the device it was allocated on
+std::shared_ptr<void> device_buffer(int device, size_t bytes);
+
 struct Sdf                        // struct sdf, src/orcdchomp_mod.cpp:148-153
 {
    std::string kinbody_name;
    Pose pose;                     // grid wrt kinbody frame
    Grid grid;
-   // device copies, created on demand
-   double * d_data64 = nullptr;
-   float * d_data32 = nullptr;
+   // device copies per device ordinal, created on demand; batches that read a copy share its
+   // ownership, so removefield while a run exists does not pull the cells from under it
+   std::map<int, std::shared_ptr<void>> dev64, dev32;
 };
 
 struct BatchParams
@@ -73,16 +93,21 @@ struct BatchParams
 
 class Module;
 
-// n_runs independent runs sharing robot, fields and parameters
-// (struct run, src/orcdchomp_mod.cpp:887-966, once per run in the reference)
-class Batch
+// a contiguous block of the runs of a batch on ONE device: n_runs independent runs sharing robot,
+// fields and parameters (struct run, src/orcdchomp_mod.cpp:887-966, once per run in the reference)
+class BatchShard
 {
 public:
-   Batch(Module * mod, const Robot & robot, const BatchParams & p, int n_runs,
+   BatchShard(Module * mod, int device, hipStream_t stream, const Robot & robot, const BatchParams & p, int n_runs,
       const double * starts, const double * goals, const double * basegoals, const unsigned int * seeds);
-   ~Batch();
-   void iterate_async(int n_iter);
-   void sync(double * costs_out, int * status_out);
+   ~BatchShard();
+   BatchShard(const BatchShard &) = delete;
+   BatchShard & operator=(const BatchShard &) = delete;
+   // iterations [iter_begin, iter_begin + n_iter) of an iterate call (r->iter restarts at 0 in every
+   // call, src/orcdchomp_mod.cpp:2752: the hmc schedule compares against it), then the cost-only pass
+   void iterate_async(int n_iter, int iter_begin = 0, bool final_eval = true);
+   void sync_begin(double * costs_out, int * status_out, int * iters_out);   // enqueue the copies
+   void sync_end();                                                          // wait for them
    void gettraj(double * out);
    void get_state(const std::string & which, double * out);
    void get_trace(double * out);
@@ -92,26 +117,34 @@ public:
    void collision_verdict(const std::vector<int> & offs, const std::vector<int> & seg, const std::vector<double> & u,
                           int * key_out, double * depth_out);
    void get_phase_cycles(long long * out);   // [n_runs][8], diagnostics (ORC_PHASE_TIMERS=1)
+   // kernel timing: completed event pairs are added to the module's totals (all of them when `wait`)
+   void harvest_events(bool wait);
 
    int n_runs, n_points, n, m;
    BatchParams params;
    int last_n_iter = 0;
+   int device;
    std::string robot_name;
    std::vector<int> adofindices;
    std::vector<int> device_sphere_order;    // XML index of device sphere k
    std::vector<int> slot_xml;               // XML index of the sphere in lane/slot q of the active block, -1: empty
 private:
    template <typename real> void build_device(const Robot & robot);
-   template <typename real> void launch(int n_iter);
-   void plan_hmc(int n_iter);
+   template <typename real> void launch(int n_iter, bool final_eval);
+   void plan_hmc(int iter_begin, int iter_end);
+   void construct(const Robot & robot, const double * starts, const double * goals, const double * basegoals,
+      const unsigned int * seeds);
+   void release();                  // frees every device buffer (destructor and failed construction)
    Module * mod_;
-   hipStream_t stream_ = nullptr;   // the stream all work of this batch is issued on
+   hipStream_t stream_ = nullptr;   // the stream all work of this shard is issued on
+   std::vector<std::shared_ptr<void>> sdf_refs_;   // the field copies the device descriptors point at
+   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events_;
    Metric metric_;
    // device buffers (typed by params.precision)
    void * d_model_ = nullptr; void * d_sdfs_ = nullptr;
    void * d_traj_ = nullptr; void * d_AG_ = nullptr; void * d_G_ = nullptr;
    double * d_costs_ = nullptr; double * d_trace_ = nullptr; size_t trace_cap_ = 0;
-   int * d_status_ = nullptr; int * d_leap_ = nullptr; long long * d_phase_ = nullptr;
+   int * d_status_ = nullptr; int * d_iters_done_ = nullptr; int * d_leap_ = nullptr; long long * d_phase_ = nullptr;
    void * d_Aband_ = nullptr; void * d_beta_s_ = nullptr; void * d_beta_g_ = nullptr;
    void * d_pcr_ = nullptr; void * d_Ainv_ = nullptr; void * d_jl_lo_ = nullptr; void * d_jl_hi_ = nullptr;
    int * d_hmc_iters_ = nullptr; void * d_noise_ = nullptr; size_t hmc_cap_iters_ = 0, noise_cap_ = 0;
@@ -124,7 +157,6 @@ private:
    int pcr_in_lds_ = 0;
    int tree_ = 0;
    int pcr_rows_ = 0, pcr_sym_ = 0, solve_mode_ = 0, ag_in_lds_ = 1, GS_ = 0;
-   std::vector<double> placement_q_;   // [samples][n_adof] configurations on the seed lines (sphere placement)
    size_t lds_bytes_ = 0;
    std::vector<double> jl_lo_, jl_hi_;
    // hmc host state per run (src/orcdchomp_mod.cpp:948-952)
@@ -134,12 +166,53 @@ private:
    uint32_t * d_mt_ = nullptr; uint32_t * d_mt_bak_ = nullptr; int * d_hmc_next_ = nullptr; int * d_hmc_next_bak_ = nullptr; int * d_overflow_ = nullptr;
    std::vector<int> hmc_resample_iter_;
    std::vector<double> ext_noise_; int ext_noise_blocks_ = 0;
+   std::vector<int> ext_noise_used_;   // caller-supplied blocks consumed by the current iterate call, per run
+   int stagger_mode_ = 0, stagger_sleeps_ = 10;
+};
+
+// A batch as the boundary sees it: its runs are cut into contiguous blocks, one BatchShard per
+// entry of the module's device list (no collective, the caller's arrays are the
+// gather).  One device: one shard.
+class Batch
+{
+public:
+   Batch(Module * mod, const std::vector<int> & devices, const Robot & robot, const BatchParams & p, int n_runs,
+      const double * starts, const double * goals, const double * basegoals, const unsigned int * seeds);
+   ~Batch();
+   void iterate_async(int n_iter, int iter_begin = 0, bool final_eval = true);
+   void sync(double * costs_out, int * status_out, int * iters_out = nullptr);
+   void gettraj(double * out);
+   void get_state(const std::string & which, double * out);
+   void get_trace(double * out);
+   void set_noise(const double * noise, int n_blocks);
+   void set_traj(const double * traj);
+   void collision_verdict(const std::vector<int> & offs, const std::vector<int> & seg, const std::vector<double> & u,
+                          int * key_out, double * depth_out);
+   void get_phase_cycles(long long * out);
+   // the per-iteration log of create's dat_filename (src/orcdchomp_mod.cpp:2306-2310, 2811-2818)
+   void open_dat(const std::string & pattern);
+   void write_dat(int iter_begin, int n_iter, const int * iters_done, double t_begin, double t_end);
+
+   int n_runs, n_points, n, m;
+   BatchParams params;
+   int last_n_iter = 0;
+   std::string robot_name;
+   std::vector<int> adofindices;
+   std::vector<int> device_sphere_order;
+   std::vector<int> slot_xml;
+   std::vector<std::unique_ptr<BatchShard>> shards;
+   std::vector<int> offs;            // first run of every shard, then n_runs
+   bool has_dat() const { return !dat_.empty(); }
+private:
+   void for_shards(const std::function<void(size_t)> & body, bool threads);
+   std::vector<FILE *> dat_;         // one per run (a single run: the reference's fp_dat)
 };
 
 class Module
 {
 public:
    explicit Module(int device);
+   explicit Module(const std::vector<int> & devices);     // batches are sharded over these (repeats allowed)
    ~Module();
    // the SendCommand surface (src/orcdchomp_mod.h:58-66); throws std::runtime_error
    // with the reference's message strings
@@ -158,33 +231,35 @@ public:
    Sdf * find_sdf(const std::string & kinbody);
    std::vector<std::unique_ptr<Sdf>> sdfs;
 
-   // lane placement of a robot's active spheres (place_spheres_on_row), found once per
-   // (robot, active dofs, floating base, epsilon_self) from the first batch's seed lines
+   // lane placement of a robot's active spheres (place_spheres_on_row): a pure function of the robot
+   // (geometry, limits, frozen dof values), the active dofs, floating base and epsilon_self
    std::map<std::string, std::vector<int>> placement_cache;
 
    // batches
    int create_batch(const std::string & robot, const BatchParams & p, int n_runs,
-      const double * starts, const double * goals, const double * basegoals, const unsigned int * seeds);
+      const double * starts, const double * goals, const double * basegoals, const unsigned int * seeds,
+      const std::vector<int> * devices_override = nullptr);
    Batch & batch(int id);
    void destroy_batch(int id);
    // collision verdict of all runs of a batch (gettraj's re-check, batched on the device): per run
    // collides (0/1), time of the first contact on the retimed trajectory, XML sphere, field, depth
    void batch_collision_verdict(int id, int * collides, double * time, int * sphere, int * field, double * depth);
 
-   hipStream_t stream = nullptr;
-   int device;
-   // optional pool of streams: batches are bound round-robin to one of them at creation so that
-   // independent batches overlap on the GPU (the tail of one launch fills with the next)
-   std::vector<hipStream_t> stream_pool;
-   size_t next_pool_stream = 0;
+   hipStream_t stream = nullptr;     // orc_set_stream: the stream of the first device's work (NULL: its default stream)
+   int device;                       // first entry of `devices`
+   std::vector<int> devices;
+   // optional pool of streams per device: shards are bound round-robin to one of them at creation so
+   // that independent batches overlap on the GPU (the tail of one launch fills with the next)
+   std::map<int, std::vector<hipStream_t>> stream_pool;
+   std::map<int, size_t> next_pool_stream;
+   int num_streams = 0;
    void set_num_streams(int n);
-   hipStream_t pick_stream();
-   // kernel timing (HIP events on `stream`)
-   void time_begin(hipStream_t st);
-   void time_end(hipStream_t st);
+   hipStream_t pick_stream(int device, bool distinct);
+   // kernel timing (HIP events on the shards' streams), harvested from the shards
    void time_collect();
    double kernel_ms_total = 0.0;
    int kernel_launches = 0;
+   std::vector<hipEvent_t> & event_pool(int device) { return event_pool_[device]; }
    std::string last_error;
    std::string last_reply;
    std::string last_collision_details;   // what the reference logs with RAVELOG_ERROR in gettraj
@@ -201,9 +276,7 @@ private:
    std::map<std::string, KinBody> kinbodies_;
    std::map<int, std::unique_ptr<Batch>> batches_;
    int next_batch_id_ = 1;
-   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events_;
-   std::vector<hipEvent_t> event_pool_;
-   hipEvent_t ev_begin_ = nullptr;
+   std::map<int, std::vector<hipEvent_t>> event_pool_;
 };
 
 void hip_check(hipError_t e, const char * what);

@@ -27,8 +27,14 @@ def _f64(a):
 
 class Module:
     def __init__(self, device=0):
+        """device: one HIP ordinal, or a list of them (batches are then sharded over the list inside
+        this process, host-side gather, no collective)."""
         self._lib = _capi.lib()
-        self._h = self._lib.orc_module_new(int(device))
+        if isinstance(device, (list, tuple)):
+            devs = np.ascontiguousarray(device, dtype=np.int32)
+            self._h = self._lib.orc_module_new_multi(_ip(devs), len(devs))
+        else:
+            self._h = self._lib.orc_module_new(int(device))
         if not self._h:
             raise RuntimeError(self._lib.orc_last_error(None).decode())
         self._keep = []
@@ -188,6 +194,13 @@ class Module:
         costs = np.zeros((n_runs, 3)); status = np.zeros(n_runs, dtype=np.int32)
         self._check(self._lib.orc_batch_sync(self._h, bid, _dp(costs), _ip(status)))
         return costs, status
+
+    def batch_iterations_done(self, bid):
+        """iterations every run completed in the last iterate call (n_iter unless it left its joint limits)"""
+        n_runs = self.batch_dims(bid)[0]
+        it = np.zeros(n_runs, dtype=np.int32)
+        self._check(self._lib.orc_batch_iterations_done(self._h, bid, _ip(it)))
+        return it
 
     def batch_trace(self, bid, n_iter):
         n_runs = self.batch_dims(bid)[0]

@@ -613,6 +613,119 @@ int ora_run_n_spheres(const ora_run * r) { return r->n_spheres; }
 double * ora_run_traj(ora_run * r) { return r->traj; }
 ora_chomp * ora_run_chomp(ora_run * r) { return r->c; }
 int ora_run_hmc_resample_iter(const ora_run * r) { return r->hmc_resample_iter; }
+int ora_run_iter(const ora_run * r) { return r->iter; }
+void ora_run_set_traj(ora_run * r, const double * traj) { memcpy(r->traj, traj, (size_t) r->n_points * r->c->n * sizeof(double)); }
+
+/* ---------------------------------------------------------------- gettraj */
+/* The re-check of mod::gettraj, src/orcdchomp_mod.cpp:2958-3006: total C-space length over the
+ * active dofs of the waypoints (2968-2984), step_time = duration * 0.04 / total_dist (2986-2987),
+ * for (time=0; time<duration; time+=step_time) Sample + collision query (2989-3003).
+ * Third party and therefore stand-ins, the same ones the product states:
+ *   - the timing (RetimeActiveDOFTrajectory with LinearTrajectoryRetimer, 2905-2911): every segment
+ *     takes max_j |dq_j| / vmax_j;
+ *   - Sample(): linear interpolation on the segment that holds `time`;
+ *   - the collision query (CheckCollision / CheckSelfCollision, 2998-2999): an active sphere whose
+ *     centre reads a field value below its radius (the optimizer's own model, first field in list
+ *     order).  The reference's loop stops at the first colliding sample unless
+ *     no_collision_exception: the first contact in (sample, XML sphere, field) order is reported.
+ * Floating base: the base columns are interpolated like the joints and renormalised.
+ * Returns the number of samples walked; *collides 0/1 and the contact's time / XML sphere / field /
+ * depth (radius - value). */
+int ora_run_collision_recheck(ora_run * r, const double * vmax /* [n_adof] */, int * collides, double * time_out,
+   int * sphere_out, int * field_out, double * depth_out)
+{
+   const int n = r->c->n, np = r->n_points, col0 = r->floating_base ? 7 : 0;
+   double * tcum = (double *) malloc((size_t) np * sizeof(double));
+   double * q = (double *) malloc((size_t) r->robot->n_dof * sizeof(double));
+   double total_dist = 0.0, duration, step_time, time;
+   int i, j, samples = 0, seg = 0;
+   *collides = 0; *time_out = -1.0; *sphere_out = -1; *field_out = -1; *depth_out = 0.0;
+   tcum[0] = 0.0;
+   for (i=1; i<np; i++)
+   {
+      double dt = 0.0, d2 = 0.0;
+      for (j=col0; j<n; j++)
+      {
+         const double d = r->traj[i*n+j] - r->traj[(i-1)*n+j];
+         const double v = vmax[j-col0] > 0.0 ? vmax[j-col0] : 1.0;
+         if (fabs(d) / v > dt) dt = fabs(d) / v;
+      }
+      tcum[i] = tcum[i-1] + dt;
+      for (j=col0; j<n; j++) d2 += pow(r->traj[(i-1)*n+j] - r->traj[i*n+j], 2);
+      total_dist += sqrt(d2);
+   }
+   duration = tcum[np-1];
+   step_time = duration * 0.04 / total_dist;                      /* mod.cpp:2986-2987 */
+   memcpy(q, r->dofvals, (size_t) r->robot->n_dof * sizeof(double));
+   for (time=0.0; time<duration && !*collides; time+=step_time)
+   {
+      double u, base[7];
+      int si, fi, k;
+      while (seg < np-2 && tcum[seg+1] < time) seg++;
+      u = (tcum[seg+1] > tcum[seg]) ? (time - tcum[seg]) / (tcum[seg+1] - tcum[seg]) : 0.0;
+      memcpy(base, r->base_pose, sizeof(base));
+      if (col0)
+      {
+         for (k=0; k<7; k++) base[k] = r->traj[seg*n+k] + (r->traj[(seg+1)*n+k] - r->traj[seg*n+k]) * u;
+         ora_kin_pose_normalize(base);
+      }
+      for (j=0; j<r->n_adof; j++)
+         q[r->adofindices[j]] = r->traj[seg*n+col0+j] + (r->traj[(seg+1)*n+col0+j] - r->traj[seg*n+col0+j]) * u;
+      ora_robot_fk(r->robot, base, q, r->fkR, r->fkt, 0, 0);
+      /* spheres in XML order */
+      for (si=0; si<r->robot->n_spheres && !*collides; si++)
+      {
+         double pw[3];
+         int li = r->robot->sphere_link[si], active = r->floating_base;
+         for (j=0; j<r->n_adof && !active; j++) active = ora_robot_does_affect(r->robot, r->adofindices[j], li);
+         if (!active) continue;
+         mat3_vec(r->fkR + 9*li, r->robot->sphere_pos + 3*si, pw);
+         for (k=0; k<3; k++) pw[k] += r->fkt[3*li+k];
+         for (fi=0; fi<r->n_rsdfs; fi++)
+         {
+            double pg[3], val;
+            ora_kin_pose_compos(r->rsdfs[fi].pose_gsdf_world, pw, pg);
+            if (ora_grid_double_interp(r->rsdfs[fi].grid, pg, &val)) continue;
+            if (val - r->robot->sphere_radius[si] < 0.0)
+            {
+               *collides = 1; *time_out = time; *sphere_out = si; *field_out = fi;
+               *depth_out = r->robot->sphere_radius[si] - val;
+               break;
+            }
+         }
+      }
+      samples++;
+   }
+   free(tcum); free(q);
+   return samples;
+}
+
+/* create's starttraj branch, src/orcdchomp_mod.cpp:2375-2416 (fixed base): row i of the run's
+ * trajectory is starttraj->Sample(i * duration / (n_points-1)) over the active dofs.  The document
+ * is `count` waypoints with deltatimes (OpenRAVE's trajectory class is third party: linear
+ * interpolation between the waypoints that bracket the time).  out [n_points][dof]. */
+void ora_sample_starttraj(int count, int dof, const double * wp, const double * deltatime, int n_points, double * out)
+{
+   double * tcum = (double *) malloc((size_t) count * sizeof(double));
+   double duration;
+   int i, j, seg = 0;
+   tcum[0] = 0.0;
+   for (i=1; i<count; i++) tcum[i] = tcum[i-1] + deltatime[i];
+   duration = tcum[count-1];
+   for (i=0; i<n_points; i++)
+   {
+      const double t = i * duration / (n_points - 1);             /* mod.cpp:2412 */
+      double u;
+      while (seg < count-2 && tcum[seg+1] < t) seg++;
+      u = (count > 1 && tcum[seg+1] > tcum[seg]) ? (t - tcum[seg]) / (tcum[seg+1] - tcum[seg]) : 0.0;
+      for (j=0; j<dof; j++)
+      {
+         const double a0 = wp[seg*dof+j], a1 = wp[(count > 1 ? seg+1 : seg)*dof+j];
+         out[i*dof+j] = a0 + (a1 - a0) * u;
+      }
+   }
+   free(tcum);
+}
 
 void ora_run_sphere_order(const ora_run * r, int * idx)
 {

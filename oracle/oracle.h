@@ -186,6 +186,13 @@ int ora_run_n_spheres(const ora_run * r);
 double * ora_run_traj(ora_run * r);          /* [n_points][n] */
 ora_chomp * ora_run_chomp(ora_run * r);
 int ora_run_hmc_resample_iter(const ora_run * r);
+int ora_run_iter(const ora_run * r);          /* r->iter: where the last iterate call stopped */
+void ora_run_set_traj(ora_run * r, const double * traj);   /* overwrite [n_points][n] (tests) */
+/* the collision re-check of mod::gettraj (src/orcdchomp_mod.cpp:2958-3006), see ora_run.c */
+int ora_run_collision_recheck(ora_run * r, const double * vmax, int * collides, double * time_out,
+   int * sphere_out, int * field_out, double * depth_out);
+/* the starttraj sampling of mod::create (src/orcdchomp_mod.cpp:2375-2416), see ora_run.c */
+void ora_sample_starttraj(int count, int dof, const double * wp, const double * deltatime, int n_points, double * out);
 /* one evaluation of sphere_cost_pre + sphere_cost for every moving point on the
  * current trajectory: G[m][n] (unscaled, as the callback leaves it), costs[m],
  * sphere_poss_all[n_points][S_a][3] */

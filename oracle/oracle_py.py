@@ -107,8 +107,11 @@ def lib():
         L.ora_run_iterate.argtypes = [C.c_void_p, C.c_int, c_double_p, c_double_p]
         L.ora_run_iterate_noise.argtypes = [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p, C.c_int]
         L.ora_run_destroy.argtypes = [C.c_void_p]
+        L.ora_run_set_traj.argtypes = [C.c_void_p, c_double_p]
+        L.ora_run_collision_recheck.argtypes = [C.c_void_p, c_double_p, c_int_p, c_double_p, c_int_p, c_int_p, c_double_p]
+        L.ora_sample_starttraj.argtypes = [C.c_int, C.c_int, c_double_p, c_double_p, C.c_int, c_double_p]
         for nm in ("ora_run_n", "ora_run_m", "ora_run_n_points", "ora_run_n_spheres_active",
-                   "ora_run_n_spheres", "ora_run_hmc_resample_iter"):
+                   "ora_run_n_spheres", "ora_run_hmc_resample_iter", "ora_run_iter"):
             getattr(L, nm).argtypes = [C.c_void_p]
         L.ora_run_traj.restype = c_double_p
         L.ora_run_traj.argtypes = [C.c_void_p]
@@ -276,6 +279,21 @@ class OraRun:
                                              dp(noise), noise.shape[0])
         return (st, costs, tr) if trace else (st, costs)
 
+    def iter(self):
+        return lib().ora_run_iter(self.h)
+
+    def set_traj(self, traj):
+        t = f64(traj)
+        assert t.shape == (self.n_points, self.n)
+        lib().ora_run_set_traj(self.h, dp(t))
+
+    def collision_recheck(self, vmax):
+        """gettraj's re-check (reference src/orcdchomp_mod.cpp:2958-3006): dict(collides, time, sphere, field, depth, samples)"""
+        col = C.c_int(); sph = C.c_int(); fld = C.c_int(); tim = C.c_double(); dep = C.c_double()
+        n = lib().ora_run_collision_recheck(self.h, dp(f64(vmax)), C.byref(col), C.byref(tim), C.byref(sph), C.byref(fld),
+                                            C.byref(dep))
+        return dict(collides=col.value, time=tim.value, sphere=sph.value, field=fld.value, depth=dep.value, samples=n)
+
     def eval_obstacle(self):
         G = np.zeros((self.m, self.n)); costs = np.zeros(self.m)
         P = np.zeros((self.n_points, self.Sa, 3))
@@ -297,6 +315,14 @@ class OraRun:
             self.destroy()
         except Exception:
             pass
+
+
+def sample_starttraj(wp, deltatime, n_points):
+    """create's starttraj sampling (reference src/orcdchomp_mod.cpp:2375-2416)"""
+    wp = f64(wp); dtm = f64(deltatime)
+    out = np.zeros((n_points, wp.shape[1]))
+    lib().ora_sample_starttraj(wp.shape[0], wp.shape[1], dp(wp), dp(dtm), n_points, dp(out))
+    return out
 
 
 def batch_run(robot, base_pose, dofvals, adofindices, adofgoals, grids, poses_world_gsdf, params,

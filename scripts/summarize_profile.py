@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
-"""Condense a gpurun_out/prof_<tag>/ directory (written by scripts/profile_r01.sh) into the
-tracked summaries under profiles/: the kernel-trace stats CSV, a PMC summary JSON, and
-profiles/traffic_latest.json (HBM bytes per iterate launch, read by bench.py)."""
+"""Condense a gpurun_out/prof_<tag>/ directory (written by scripts/profile_round.sh) into the
+tracked summaries under profiles/: the kernel-trace stats CSV, a PMC summary JSON, and the entry of
+profiles/counters_latest.json that bench.py reads (HBM bytes per iterate launch, vector
+wave-instructions per run-iteration).
+
+    python scripts/summarize_profile.py <tag> <name> [config=2] [batch] [n_iter=100]"""
 import collections
 import csv
 import glob
@@ -10,19 +13,29 @@ import os
 import shutil
 import sys
 
-tag, name = sys.argv[1], sys.argv[2]          # e.g.  a  r01_baseline
+tag, name = sys.argv[1], sys.argv[2]          # e.g.  a  r02_config2
+config = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+batch = int(sys.argv[4]) if len(sys.argv) > 4 else {2: 1024, 4: 4096, 5: 4096}[config]
+n_iter = int(sys.argv[5]) if len(sys.argv) > 5 else 100
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
 stats = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))[0]
 shutil.copy(stats, os.path.join(dst, name + "_kernel_stats.csv"))
-summary = {"source": "rocprofv3 on `python3 bench.py --steps N --warmup 1 --no-cpu-baseline` (scripts/profile_r01.sh)",
-           "kernel": "chomp_iterate_kernel<double>", "counters": {}}
+summary = {"source": "rocprofv3 on `python3 bench.py --config %d --no-cpu-baseline --serial-steps 0 --steps N --warmup W` "
+                     "(scripts/profile_round.sh): --kernel-trace --stats with 20 steps; one --pmc pass per counter group with 2 steps" % config,
+           "config": config, "batch": batch, "n_iter": n_iter, "counters": {}}
 for row in csv.DictReader(open(stats)):
     if "chomp_iterate" in row["Name"]:
+        summary["kernel"] = row["Name"][:120]
         summary["kernel_trace"] = {"calls": int(row["Calls"]), "avg_ns": float(row["AverageNs"]),
                                    "min_ns": float(row["MinNs"]), "max_ns": float(row["MaxNs"])}
+log = os.path.join(src, "bench_trace.log")
+if os.path.exists(log):
+    for line in open(log):
+        if line.startswith("{"):
+            summary["bench_line_of_the_traced_run"] = json.loads(line)
 for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
     files = glob.glob(os.path.join(src, sub, "*", "*counter_collection.csv"))
     if not files:
@@ -39,14 +52,21 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
         summary["counters"][k] = {"mean_per_launch": sum(v) / len(v), "launches": len(v)}
     summary["dispatch"] = meta
 c = summary["counters"]
+entry = {"batch": batch, "n_iter": n_iter, "from": name, "source": "profiles/%s_summary.json" % name}
 if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
     # MI355X_MICROARCH.md "HBM": FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half
-    # of a wide coalesced read -> doubled (our gathers are 8-byte, so this is an upper estimate)
+    # of a wide coalesced read -> doubled (our gathers are narrow, so this is an upper estimate)
     fetch = c["FETCH_SIZE"]["mean_per_launch"] * 1024 * 2
     write = c["WRITE_SIZE"]["mean_per_launch"] * 1024
     summary["hbm_bytes_per_launch"] = fetch + write
-    json.dump({"batch": 1024, "n_iter": 100, "hbm_bytes_per_launch": fetch + write,
-               "fetch_bytes_corrected": fetch, "write_bytes": write, "from": name},
-              open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1)
+    entry.update(hbm_bytes_per_launch=fetch + write, fetch_bytes_corrected=fetch, write_bytes=write)
+if "SQ_INSTS_VALU" in c:
+    # the final cost-only pass of a launch is charged to its n_iter iterations
+    entry["valu_insts_per_run_iteration"] = c["SQ_INSTS_VALU"]["mean_per_launch"] / (batch * n_iter)
+    summary["valu_insts_per_run_iteration"] = entry["valu_insts_per_run_iteration"]
+path = os.path.join(dst, "counters_latest.json")
+allc = json.load(open(path)) if os.path.exists(path) else {}
+allc["config%d" % config] = entry
+json.dump(allc, open(path, "w"), indent=1)
 json.dump(summary, open(os.path.join(dst, name + "_summary.json"), "w"), indent=1)
-print(json.dumps(summary, indent=1))
+print(json.dumps({k: v for k, v in summary.items() if k != "bench_line_of_the_traced_run"}, indent=1))

@@ -78,3 +78,122 @@ def setup_product_wam(mod, name="BarrettWAM"):
 def rel_l2(a, b):
     a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json configurations at their full size, shared by the -m gpu tests,
+# bench.py and tests/golden/make_fullsize_golden.py
+CONFIG2_KW = dict(n_points=100, lambda_=100.0, obs_factor=500.0)
+
+
+def config3_goals(rank=0, world=8, n_total=65536, seed=20250102):
+    """config 3: 65 536 WAM goals drawn run-major with one seed, cut into contiguous blocks per GPU"""
+    from or_cdchomp_amd import sharding
+    lo, hi = sharding.shard_bounds(n_total, rank, world)
+    return wam_goals(n_total, seed=seed)[lo:hi]
+
+
+def config4_problem(n_runs=4096):
+    """config 4: floating base + WAM arm, n=14, n_points=200, momentum + hmc, seed = run index"""
+    _, base, _, _ = wam_state()
+    rng = np.random.default_rng(20250103)
+    goals = wam_goals(n_runs, seed=20250103)
+    basegoals = np.tile(np.asarray(base, dtype=np.float64), (n_runs, 1))
+    basegoals[:, :3] += rng.uniform(-0.3, 0.3, size=(n_runs, 3))
+    seeds = np.arange(n_runs, dtype=np.uint32)
+    kw = dict(n_points=200, lambda_=100.0, obs_factor=500.0, floating_base=1, use_momentum=1, use_hmc=1,
+              hmc_resample_lambda=0.02)
+    return goals, basegoals, seeds, kw
+
+
+CONFIG5_KW = dict(n_points=200, lambda_=200.0, obs_factor=100.0)
+CONFIG5_CUBE = 0.005
+CONFIG5_PADDING = 0.15
+
+
+def config5_goals(n_runs=4096):
+    return np.random.default_rng(5).uniform(-0.8, 0.8, size=(n_runs, 30))
+
+
+def config5_bodies():
+    """the four box kinbodies of config 5: {name: ([(pose7, half3)], kinbody pose7)}"""
+    return scenes.random_boxes(np.random.default_rng(20250104))
+
+
+def config5_field_dims(boxes, cube_extent=CONFIG5_CUBE, padding=CONFIG5_PADDING):
+    """grid of computedistancefield for a kinbody made of boxes at identity in its frame
+    (reference src/orcdchomp_mod.cpp:377-409): sizes, lengths, grid pose in the kinbody frame"""
+    lo = np.min([np.asarray(p[:3]) - np.asarray(h) for p, h in boxes], axis=0)
+    hi = np.max([np.asarray(p[:3]) + np.asarray(h) for p, h in boxes], axis=0)
+    apos = 0.5 * (lo + hi)
+    aext = hi - apos
+    return grid_dims(list(apos), list(aext), cube_extent, padding)
+
+
+def pose_compose_np(ab, bc):
+    """cd_kin_pose_compose (reference src/libcd/kin.c:136-178) in numpy, for test inputs"""
+    ax, ay, az, aw = ab[3:7]
+    bx, by, bz, bw = bc[3:7]
+    q = [aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx,
+         aw * bz + ax * by - ay * bx + az * bw, aw * bw - ax * bx - ay * by - az * bz]
+    x, y, z = bc[:3]
+    qx, qy, qz, qw = ax, ay, az, aw
+    px = x * (qx * qx - qy * qy - qz * qz + qw * qw) + 2 * y * (qx * qy - qz * qw) + 2 * z * (qx * qz + qy * qw)
+    py = 2 * x * (qx * qy + qz * qw) + y * (-qx * qx + qy * qy - qz * qz + qw * qw) + 2 * z * (qy * qz - qx * qw)
+    pz = 2 * x * (qx * qz - qy * qw) + 2 * y * (qy * qz + qx * qw) + z * (-qx * qx - qy * qy + qz * qz + qw * qw)
+    return np.array([px + ab[0], py + ab[1], pz + ab[2]] + q)
+
+
+def config5_occupancy(cube_extent=CONFIG5_CUBE, padding=CONFIG5_PADDING):
+    """occupancy of the four fields through the product's HOST voxelizer (the stand-in for OpenRAVE's
+    collision checker; no GPU needed): [(name, occupancy, lengths, grid pose in the body frame, body pose)]"""
+    import ctypes as C
+    from or_cdchomp_amd import _capi
+    lib = _capi.lib()
+    bodies = config5_bodies()
+    world_poses, halfs = [], []
+    for name, (boxes, bpose) in bodies.items():
+        for p, h in boxes:
+            world_poses.append(pose_compose_np(np.asarray(bpose, dtype=np.float64), np.asarray(p, dtype=np.float64)))
+            halfs.append(h)
+    wp = np.ascontiguousarray(world_poses, dtype=np.float64)
+    hf = np.ascontiguousarray(halfs, dtype=np.float64)
+    out = []
+    for name, (boxes, bpose) in bodies.items():
+        sizes, lengths, gpose = config5_field_dims(boxes, cube_extent, padding)
+        pw = pose_compose_np(np.asarray(bpose, dtype=np.float64), np.asarray(gpose, dtype=np.float64))
+        occ = np.zeros(sizes)
+        rc = lib.orc_host_voxelize_boxes(np.asarray(sizes, dtype=np.int32).ctypes.data_as(_capi.c_int_p),
+                                         np.asarray(lengths, dtype=np.float64).ctypes.data_as(_capi.c_double_p),
+                                         np.ascontiguousarray(pw).ctypes.data_as(_capi.c_double_p), C.c_double(cube_extent),
+                                         len(wp), wp.ctypes.data_as(_capi.c_double_p), hf.ctypes.data_as(_capi.c_double_p),
+                                         occ.ctypes.data_as(_capi.c_double_p))
+        assert rc == 0
+        out.append((name, occ, lengths, gpose, bpose))
+    return out
+
+
+def config5_oracle_fields(oracle_py, cube_extent=CONFIG5_CUBE, padding=CONFIG5_PADDING):
+    """the four fields by the oracle (flood fill + signed distance transform of the occupancy above)"""
+    grids, poses, names = [], [], []
+    for name, occ, lengths, gpose, bpose in config5_occupancy(cube_extent, padding):
+        g = oracle_py.OraGrid(occ, lengths)
+        g.flood_fill(0)
+        g.data[g.data == 1.0] = HUGE
+        grids.append(g.bin_sdf())
+        out = np.zeros(7)
+        oracle_py.lib().ora_kin_pose_compose(oracle_py.dp(oracle_py.f64(bpose)), oracle_py.dp(oracle_py.f64(gpose)),
+                                             oracle_py.dp(out))
+        poses.append(out)
+        names.append(name)
+    return names, grids, poses
+
+
+def setup_product_tree30(mod, cube_extent=CONFIG5_CUBE, padding=CONFIG5_PADDING):
+    model = robots.tree30()
+    mod.add_robot(model, transform=[0.0] * 6 + [1.0], dof_values=np.zeros(model.n_dof), active_dofs=list(range(model.n_dof)))
+    for name, (boxes, pose) in config5_bodies().items():
+        mod.add_kinbody_boxes(name, boxes, transform=pose)
+    for name in config5_bodies():
+        mod.SendCommand("computedistancefield kinbody %s cube_extent %f aabb_padding %f" % (name, cube_extent, padding))
+    return model

@@ -218,6 +218,21 @@ def test_batched_collision_verdict_matches_gettraj(oracle):
     assert np.array_equal(out, mod.batch_gettraj(bid))
     mod.batch_destroy(bid)
     assert 0 < got["collides"].sum() < n_runs, got["collides"]
+    # against the oracle's restatement of the re-check loop (oracle/ora_run.c: ora_run_collision_recheck,
+    # reference src/orcdchomp_mod.cpp:2958-3006) walking the very trajectories the device walked
+    prob = common.tabletop_problem(oracle)
+    _, base, dofvals, adofs = common.wam_state()
+    rob = oracle.OraRobot(model)
+    for k in range(n_runs):
+        orun = oracle.OraRun(rob, base, dofvals, adofs, goals[k], [prob["sdf"]], [prob["pose"]], oracle.default_params(**kw))
+        orun.set_traj(out[k])
+        want = orun.collision_recheck(vmax[:7])
+        orun.destroy()
+        assert want["collides"] == got["collides"][k], (k, want)
+        if want["collides"]:
+            assert want["sphere"] == got["sphere"][k] and want["field"] == got["field"][k], (k, want)
+            assert np.isclose(want["time"], got["time"][k], rtol=1e-12, atol=1e-15), (k, want, got["time"][k])
+            assert np.isclose(want["depth"], got["depth"][k], rtol=1e-9, atol=1e-13), (k, want, got["depth"][k])
     for k in range(n_runs):
         run = mod.create(robot=model.name, adofgoal=list(goals[k]), **kw)
         mod.iterate(run=run, n_iter=3)
@@ -256,6 +271,17 @@ def test_starttraj_seeding(oracle):
     run2 = mod.create(robot=model.name, starttraj=_doc(wp, [0.0, 1.0, 1.0]), n_points=5)
     t2 = mod.batch_gettraj(int(run2))[0]
     assert np.allclose(t2[:, 0], [0.0, 0.5, 1.0, 2.0, 3.0])
+    # against the oracle's restatement of the sampling (oracle/ora_run.c: ora_sample_starttraj, reference
+    # src/orcdchomp_mod.cpp:2375-2416): random waypoints inside the limits, irregular deltatimes (one zero)
+    rng = np.random.default_rng(23)
+    lo = np.asarray(model.limit_lower[:7]) + 0.2; hi = np.asarray(model.limit_upper[:7]) - 0.2
+    wp3 = rng.uniform(lo, hi, size=(9, 7))
+    dt3 = np.r_[0.0, rng.uniform(0.05, 0.9, size=8)]; dt3[4] = 0.0
+    for npts in (5, 33, 101):
+        run3 = mod.create(robot=model.name, starttraj=_doc(wp3, dt3), n_points=npts)
+        t3 = mod.batch_gettraj(int(run3))[0]
+        mod.destroy(run=run3)
+        assert np.allclose(t3, oracle.sample_starttraj(wp3, dt3, npts), rtol=1e-14, atol=1e-15)
     with pytest.raises(RuntimeError, match="Cannot pass both adofgoal and starttraj!"):
         mod.SendCommand("create robot %s adofgoal '0 0 0 0 0 0 0' starttraj 'x'" % model.name)
     # orc_batch_set_traj: warm start of a whole batch

@@ -1,0 +1,187 @@
+"""-m gpu: the BASELINE.json configurations at their FULL size.
+
+config 3's per-GPU block (8 192 WAM runs of the 65 536, seed 20250102), config 4 (floating base +
+arm, n=14, n_points=200, momentum + hmc, batch 4096, seed = run index), config 5 (30-dof tree, four
+fields at 1 cm cells, n_points=200, batch 4096, fp32).  A fixed sample of every batch is held to the
+oracle's outputs committed in tests/golden/fullsize_config*.npz (written by
+tests/golden/make_fullsize_golden.py; 1e-6 relative L2 in fp64, 1e-3 in fp32); the
+whole batch is held to the properties the domain offers: a run's bits do not depend on what shares
+its batch or on how the batch is cut over devices, two calls are one, every run reports the
+iterations it made.
+
+Runs the golden file marks as ill conditioned (`self_amp`: how far the ORACLE's own trajectory moves
+when the goal changes by one ulp) are chaotic in the reference algorithm itself; they are held to
+their measured amplification instead of 1e-6 and listed in the test output."""
+import os
+
+import numpy as np
+import pytest
+
+import common
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+N_ITER = 100
+
+
+def _module(devices=0):
+    import or_cdchomp_amd
+    return or_cdchomp_amd.Module(devices)
+
+
+def _check_sample(tag, gold, traj, costs, status, tol):
+    idx = gold["index"]
+    worst, ill = 0.0, []
+    for j, k in enumerate(idx):
+        amp = float(gold["self_amp"][j])
+        gst = int(gold["status"][j])
+        conditioned = amp < 1e-9 and gst == int(gold["status_goal_plus_one_ulp"][j])
+        if conditioned:
+            assert status[k] == gst, (tag, k, status[k], gst)
+        if gst != 0 or status[k] != 0:
+            continue                                  # aborted in the reference: no trajectory to compare
+        err = common.rel_l2(traj[k], gold["traj"][j])
+        if conditioned:
+            worst = max(worst, err)
+            assert err <= tol, (tag, int(k), err)
+            assert np.allclose(costs[k], gold["costs"][j], rtol=max(tol, 1e-6) * (100 if tol > 1e-6 else 1), atol=0), (tag, int(k))
+        else:
+            ill.append((int(k), err, amp))
+            assert err <= max(tol, 5000.0 * amp), (tag, int(k), err, amp)
+    print("%s: worst rel L2 vs golden oracle %.3e over the well-conditioned sample runs; ill-conditioned (run, err, oracle self-amp): %s"
+          % (tag, worst, ill))
+    return worst
+
+
+def _properties(mod, robot, full, create, pick, two_calls=True):
+    """a scattered subset on its own == the same runs inside the full batch, bit for bit; and
+    iterate(37) + iterate(63) == iterate(100) on that subset"""
+    bid = create(pick)
+    c, s = mod.batch_iterate(bid, N_ITER)
+    it = mod.batch_iterations_done(bid)
+    t = mod.batch_gettraj(bid)
+    mod.batch_destroy(bid)
+    assert np.array_equal(s, full["status"][pick])
+    assert np.array_equal(it, full["iters"][pick])
+    assert np.array_equal(t, full["traj"][pick])
+    ok = s == 0
+    assert np.array_equal(c[ok], full["costs"][pick][ok])
+    if two_calls:
+        bid = create(pick)
+        _, s1 = mod.batch_iterate(bid, 37)
+        c2, s2 = mod.batch_iterate(bid, 63)
+        t2 = mod.batch_gettraj(bid)
+        mod.batch_destroy(bid)
+        both = (s1 == 0) & (s2 == 0)
+        assert np.array_equal(np.minimum(s1, s2), s)
+        assert np.array_equal(t2[both], t[both])
+        assert np.array_equal(c2[both], c[both])
+
+
+def test_config3_shard_8192_runs():
+    gold = np.load(os.path.join(GOLDEN, "fullsize_config3.npz"))
+    mod = _module()
+    model = common.setup_product_wam(mod)
+    goals = common.config3_goals(rank=0, world=8)
+    assert goals.shape == (8192, 7)
+    bid = mod.batch_create(model.name, goals, **common.CONFIG2_KW)
+    costs, status = mod.batch_iterate(bid, N_ITER)
+    iters = mod.batch_iterations_done(bid)
+    traj = mod.batch_gettraj(bid)
+    mod.batch_destroy(bid)
+    _check_sample("config 3 block of GPU 0 (8192 WAM runs)", gold, traj, costs, status, 1e-6)
+    # every run reports what it did: n_iter iterations unless it left its joint limits
+    assert np.array_equal(iters == N_ITER, status == 0)
+    assert (iters[status != 0] < N_ITER).all()
+    frac_bad = float((status != 0).mean())
+    assert frac_bad < 0.10, frac_bad
+    ok = status == 0
+    assert np.isfinite(costs[ok]).all() and np.isfinite(traj[ok]).all()
+    lo = np.asarray(model.limit_lower[:7]); hi = np.asarray(model.limit_upper[:7])
+    assert ((traj[ok] >= lo - 1e-12) & (traj[ok] <= hi + 1e-12)).all()
+    full = dict(traj=traj, costs=costs, status=status, iters=iters)
+    pick = np.sort(np.random.default_rng(3).permutation(8192)[:256])
+    _properties(mod, model, full, lambda p: mod.batch_create(model.name, goals[p], **common.CONFIG2_KW), pick)
+    # the same block cut over two shards inside one process (devices '0 0': the in-process multi-GPU
+    # path of the C ABI on the one GPU of this box): bit-equal to the unsharded batch
+    mod2 = _module([0, 0])
+    common.setup_product_wam(mod2)
+    bid = mod2.batch_create(model.name, goals, **common.CONFIG2_KW)
+    c2, s2 = mod2.batch_iterate(bid, N_ITER)
+    t2 = mod2.batch_gettraj(bid)
+    i2 = mod2.batch_iterations_done(bid)
+    mod2.batch_destroy(bid)
+    assert np.array_equal(s2, status) and np.array_equal(i2, iters)
+    assert np.array_equal(t2, traj)
+    assert np.array_equal(c2[ok], costs[ok])
+    print("config 3 block: %d of 8192 runs left their joint limits (status -1)" % int((status != 0).sum()))
+
+
+def test_config4_floating_base_momentum_hmc_4096():
+    gold = np.load(os.path.join(GOLDEN, "fullsize_config4.npz"))
+    mod = _module()
+    model = common.setup_product_wam(mod)
+    goals, basegoals, seeds, kw = common.config4_problem(4096)
+    bid = mod.batch_create(model.name, goals, basegoals=basegoals, seeds=seeds, **kw)
+    costs, status = mod.batch_iterate(bid, N_ITER)
+    iters = mod.batch_iterations_done(bid)
+    traj = mod.batch_gettraj(bid)
+    trace = mod.batch_trace(bid, N_ITER)
+    mod.batch_destroy(bid)
+    assert mod.batch_dims is not None and traj.shape == (4096, 200, 14)
+    _check_sample("config 4 (floating base + arm, momentum + hmc, 4096 runs)", gold, traj, costs, status, 1e-6)
+    assert np.array_equal(iters == N_ITER, status == 0)
+    ok = status == 0
+    # unit quaternions after the per-iteration renormalisation (src/orcdchomp_mod.cpp:2806-2808)
+    qn = np.linalg.norm(traj[ok][:, :, 3:7], axis=2)
+    assert np.abs(qn - 1.0).max() < 1e-12
+    assert np.isfinite(trace[ok]).all()
+    # rows of the iterations an aborted run did not make are NaN, the ones it made are numbers
+    for k in np.where(~ok)[0][:8]:
+        assert np.isfinite(trace[k, :iters[k]]).all() and np.isnan(trace[k, iters[k]:]).all()
+    full = dict(traj=traj, costs=costs, status=status, iters=iters)
+    pick = np.sort(np.random.default_rng(4).permutation(4096)[:300])          # >= 256: the device hmc streams, as the full batch
+    _properties(mod, model, full,
+                lambda p: mod.batch_create(model.name, goals[p], basegoals=basegoals[p], seeds=seeds[p], **kw), pick,
+                two_calls=False)       # r->iter restarts at 0 in every call: two hmc calls are not one (mod.cpp:2752-2768)
+    print("config 4: %d of 4096 runs left their joint limits (status -1)" % int((~ok).sum()))
+
+
+def test_config5_tree30_four_fields_fp32_4096(oracle):
+    gold = np.load(os.path.join(GOLDEN, "fullsize_config5.npz"))
+    mod = _module()
+    model = common.setup_product_tree30(mod)
+    # the product's fields (voxelizer + flood fill + distance transform, on the GPU for grids of this
+    # size) against the oracle's flood fill + distance transform of the golden occupancy: bit for bit
+    for k, name in enumerate(common.config5_bodies()):
+        data, lengths, gpose = mod.get_sdf(name)
+        shape = tuple(int(v) for v in gold["occ_shape_%d" % k])
+        assert data.shape == shape
+        occ = np.where(np.unpackbits(gold["occ_bits_%d" % k])[:data.size].reshape(shape) == 1, np.inf, 1.0)
+        g = oracle.OraGrid(occ, lengths)
+        g.flood_fill(0)
+        g.data[g.data == 1.0] = np.inf
+        ref = g.bin_sdf().data
+        assert np.array_equal(data, ref), name
+        chk = gold["sdf_checksum_%d" % k]
+        assert data.min() == chk[2] and data.max() == chk[3]
+    goals = common.config5_goals(4096)
+    results = {}
+    for precision, tol, n_runs in ((32, 1e-3, 4096), (64, 1e-6, 4096)):
+        g = goals[:n_runs]
+        bid = mod.batch_create(model.name, g, precision=precision, **common.CONFIG5_KW)
+        costs, status = mod.batch_iterate(bid, N_ITER)
+        iters = mod.batch_iterations_done(bid)
+        traj = mod.batch_gettraj(bid)
+        mod.batch_destroy(bid)
+        assert traj.shape == (4096, 200, 30)
+        _check_sample("config 5 (30-dof tree, 4 fields at 1 cm, 4096 runs, fp%d)" % precision, gold, traj, costs, status, tol)
+        assert (status == 0).all() and (iters == N_ITER).all()
+        results[precision] = dict(traj=traj, costs=costs, status=status, iters=iters)
+    # fp32 against fp64 of the product itself over the WHOLE batch (the golden sample is 8 runs)
+    e = np.array([common.rel_l2(results[32]["traj"][k], results[64]["traj"][k]) for k in range(4096)])
+    assert e.max() <= 1e-3, e.max()
+    pick = np.sort(np.random.default_rng(5).permutation(4096)[:128])
+    _properties(mod, model, results[32], lambda p: mod.batch_create(model.name, goals[p], precision=32, **common.CONFIG5_KW), pick)
+    print("config 5: fp32 vs fp64 over 4096 runs: worst rel L2 %.3e" % e.max())
