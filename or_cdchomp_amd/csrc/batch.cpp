@@ -279,6 +279,7 @@ void BatchShard::construct(const Robot & robot, const double * starts, const dou
    }
    hmc_resample_iter_.assign(n_runs, 0);
    ext_noise_used_.assign(n_runs, 0);
+   lim_generic_ = getenv("ORC_LIM_GENERIC") ? 1 : 0;
    stagger_mode_ = getenv("ORC_STAGGER_MODE") ? atoi(getenv("ORC_STAGGER_MODE")) : 0;
    stagger_sleeps_ = getenv("ORC_STAGGER_SLEEPS") ? atoi(getenv("ORC_STAGGER_SLEEPS")) : 10;
 }
@@ -689,16 +690,27 @@ void BatchShard::build_device(const Robot & robot)
    // the WAM workload, scripts/phase_profile.py).
    const int pcr_rows = pcr_rows_;
    const size_t lds_cu = 160*1024;
-   int force_t = 0, force_pcr = -1, force_ag = -1, max_wgs = ORC_WGS_PER_CU;
+   int force_t = 0, force_pcr = -1, force_ag = -1, max_wgs = ORC_WGS_PER_CU, force_block = 0;
    if (const char * e = getenv("ORC_TILE_M")) force_t = atoi(e);          // experiments
    if (const char * e = getenv("ORC_PCR_LDS")) force_pcr = atoi(e);
    if (const char * e = getenv("ORC_AG_LDS")) force_ag = atoi(e);
    if (const char * e = getenv("ORC_WGS")) max_wgs = atoi(e);
+   if (const char * e = getenv("ORC_BLOCK_THREADS")) force_block = atoi(e);
    const int lanes_per_wp = (GS_ == 16) ? 16 : GS_;
    tile_m_ = 0;
+   block_ = 256;
    double best_score = -1.0;
-   for (int wgs=max_wgs; wgs>=1; wgs--)
+   // workgroup shapes: 256 threads (four wavefronts) at up to three workgroups per CU, or 192 threads
+   // (three wavefronts) at four per CU: the same twelve wavefronts and register budget, a quarter
+   // less LDS per run, and the 1024 runs of BASELINE configs[1] resident at once on 256 CUs
+   struct Shape { int block, wgs; };
+   std::vector<Shape> shapes;
+   for (int wgs=max_wgs; wgs>=1; wgs--) shapes.push_back({ 256, wgs });
+   if (max_wgs >= 3) shapes.push_back({ 192, 4 });
+   for (const Shape & sh : shapes)
    {
+      const int wgs = sh.wgs, block = sh.block;
+      if (force_block && block != force_block) continue;
       // LDS is handed out in 1280-byte granules (measured: three 53512-byte workgroups share a CU, three 54184-byte ones do not)
       const size_t budget = (lds_cu / wgs / 1280) * 1280 - (wgs == 1 ? 1024 : 0);
       for (int with_pcr=1; with_pcr>=0; with_pcr--)
@@ -708,20 +720,21 @@ void BatchShard::build_device(const Robot & robot)
             if (force_pcr >= 0 && with_pcr != force_pcr && pcr_rows) continue;
             if (!ag_lds && !params.use_momentum) continue;
             if (force_ag >= 0 && ag_lds != force_ag && params.use_momentum) continue;
-            for (int t=(m < ORC_BLOCK - 2 ? m : ORC_BLOCK - 2); t>=1; t--)
+            for (int t=(m < 254 ? m : 254); t>=1; t--)
             {
                if (force_t > 0 && t != (force_t < m ? force_t : m)) continue;
                const size_t need = orc_chomp_lds_bytes(n_points, n, Sa_, S_, nj, t, with_pcr ? pcr_rows : 0, sizeof(real),
                                                        params.use_momentum && ag_lds, n_sdfs_);
                if (need > budget) continue;
                const int tiles = (m + t - 1) / t;
-               const double fk_passes = tiles * std::ceil((t + 2) / 64.0);
-               const double rounds = tiles * std::ceil(t * (double) lanes_per_wp / ORC_BLOCK);
-               const double cycles = 12e3 * fk_passes + 11e3 * rounds + 30e3 + (with_pcr ? 0.0 : 1e3) + (ag_lds ? 0.0 : 2e3);
-               const double score = wgs * (1.0 - 0.05 * (wgs - 1)) / cycles;
+               const double fk_passes = tiles * std::ceil((t + 2) / (block / 4.0));
+               const double rounds = tiles * std::ceil(t * (double) lanes_per_wp / block);
+               const double cycles = 12e3 * fk_passes + 11e3 * rounds + 30e3 * (256.0 / block) + (with_pcr ? 0.0 : 1e3) + (ag_lds ? 0.0 : 2e3);
+               const double waves_per_simd = wgs * block / 256.0;
+               const double score = wgs * (1.0 - 0.05 * (waves_per_simd - 1.0)) / cycles;
                if (score > best_score)
                {
-                  best_score = score; tile_m_ = t; pcr_in_lds_ = with_pcr; ag_in_lds_ = ag_lds; lds_bytes_ = need;
+                  best_score = score; tile_m_ = t; pcr_in_lds_ = with_pcr; ag_in_lds_ = ag_lds; lds_bytes_ = need; block_ = block;
                }
                break;                                   // largest tile of this plan
             }
@@ -729,7 +742,7 @@ void BatchShard::build_device(const Robot & robot)
    }
    if (!tile_m_) throw std::runtime_error("run does not fit the LDS of one CU!");
    if (getenv("ORC_DEBUG_PLAN"))
-      fprintf(stderr, "orc plan: tile_m %d (%d tiles) lds %zu bytes (%d workgroups per CU) pcr_in_lds %d ag_in_lds %d solve_mode %d\n", tile_m_,
+      fprintf(stderr, "orc plan: %d threads per workgroup, tile_m %d (%d tiles) lds %zu bytes (%d workgroups per CU) pcr_in_lds %d ag_in_lds %d solve_mode %d\n", block_, tile_m_,
               (m + tile_m_ - 1) / tile_m_, lds_bytes_, (int)(lds_cu / ((lds_bytes_ + 1279) / 1280 * 1280)), pcr_in_lds_, ag_in_lds_, solve_mode_);
 }
 
@@ -912,7 +925,7 @@ void BatchShard::launch(int n_iter, bool final_eval)
    b.n_iter = n_iter; b.final_eval = final_eval ? 1 : 0;
    b.phase_cycles = d_phase_;
    b.pcr_in_lds = pcr_in_lds_; b.pcr_sym = pcr_sym_; b.pcr_rows = pcr_rows_; b.ag_in_lds = ag_in_lds_;
-   b.stagger_mode = stagger_mode_; b.stagger_sleeps = stagger_sleeps_;
+   b.stagger_mode = stagger_mode_; b.stagger_sleeps = stagger_sleeps_; b.lim_generic = lim_generic_;
    if (params.derivative == 1 && m >= 2)
    {
       b.a_diag = (real) metric_.Adense[(size_t) 1*m + 1];
@@ -932,7 +945,7 @@ void BatchShard::launch(int n_iter, bool final_eval)
       else hip_check(hipEventCreate(&ev[k]), "hipEventCreate");
    }
    hip_check(hipEventRecord(ev[0], stream_), "hipEventRecord");
-   hipError_t e = launch_typed(b, lds_bytes_, stream_, tree_);
+   hipError_t e = launch_typed(b, lds_bytes_, stream_, tree_ | (block_ == 192 ? 4 : 0));
    hip_check(e, "chomp_iterate_kernel launch");
    hip_check(hipEventRecord(ev[1], stream_), "hipEventRecord");
    pending_events_.push_back(std::make_pair(ev[0], ev[1]));

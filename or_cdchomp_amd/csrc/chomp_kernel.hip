@@ -169,13 +169,15 @@ __device__ __forceinline__ real dpp_row_max(real v);   // defined after dpp_move
 template <typename real>
 __device__ __forceinline__ void wave_argmax(real & best, int & best_e);
 
-// sum over the whole workgroup; every thread receives the result.
+// sum over the whole workgroup (3 or 4 wavefronts); every thread receives the result.
+template <int BLOCK>
 __device__ __forceinline__ double block_sum(double v, double * red)
 {
    v = wave_sum(v);
    __syncthreads();
    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
    __syncthreads();
+   if (BLOCK == 192) return (red[0] + red[1]) + red[2];
    return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
@@ -242,7 +244,7 @@ __device__ __forceinline__ int div_n(int e, float rn) { return (int)(((float) e 
 // columns at once.  src holds d [m][n]; the result ends up in the returned
 // buffer (src or tmp).  Coefficients: pcr[l][0][i] (towards i-s), pcr[l][1][i]
 // (towards i+s), then the inverse of the reduced diagonal.
-template <typename real>
+template <typename real, int BLOCK>
 __device__ __forceinline__ real * pcr_solve(const DevBatch<real> & b, const real * tab, real * src, real * tmp)
 {
    const int m = b.m, n = b.n, mn = m*n;
@@ -254,7 +256,7 @@ __device__ __forceinline__ real * pcr_solve(const DevBatch<real> & b, const real
    {
       const real * ka = tab + (size_t)(b.pcr_sym ? l : 2*l) * m;
       const real * kc = ka + m;
-      for (int e=threadIdx.x; e<mn; e+=ORC_BLOCK)
+      for (int e=threadIdx.x; e<mn; e+=BLOCK)
       {
          const int i = div_n(e, rn);
          real d = cur[e];
@@ -267,18 +269,18 @@ __device__ __forceinline__ real * pcr_solve(const DevBatch<real> & b, const real
       stride <<= 1;
    }
    const real * invb = tab + (size_t)(b.pcr_rows - 1) * m;
-   for (int e=threadIdx.x; e<mn; e+=ORC_BLOCK)
+   for (int e=threadIdx.x; e<mn; e+=BLOCK)
       cur[e] *= invb[div_n(e, rn)];
    __syncthreads();
    return cur;
 }
 
 // dense fallback (derivative D >= 2): x = Ainv d
-template <typename real>
+template <typename real, int BLOCK>
 __device__ __forceinline__ real * dense_solve(const DevBatch<real> & b, real * src, real * tmp)
 {
    const int m = b.m, n = b.n, mn = m*n;
-   for (int e=threadIdx.x; e<mn; e+=ORC_BLOCK)
+   for (int e=threadIdx.x; e<mn; e+=BLOCK)
    {
       const int i = e / n, c = e - i*n;
       real s = (real)0;
@@ -328,14 +330,14 @@ __device__ __forceinline__ real wave_suffix_incl(real v)
 // (m <= 64 ORC_SCAN_RPL); the sums across lanes are wave scans, so the whole solve costs one barrier
 // where cyclic reduction costs one per level.  (The reference multiplies by the dense inverse,
 // src/libcd/chomp.c:525-548: the same products, summed in another order.)
-template <typename real>
+template <typename real, int BLOCK>
 __device__ __forceinline__ real * toeplitz_scan_solve(const DevBatch<real> & b, real * buf)
 {
    const int m = b.m, n = b.n;
    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
    const int rpl = (m + 63) >> 6;
    const real kinv = (real)(-1) / ((real)(m + 1) * b.a_off);      // 1/((m+1) ca), ca = -a_off
-   for (int c=wave; c<n; c+=ORC_BLOCK/64)
+   for (int c=wave; c<n; c+=BLOCK/64)
    {
       real g[ORC_SCAN_RPL], wp[ORC_SCAN_RPL], wq[ORC_SCAN_RPL];
       real sp = 0, sq = 0;
@@ -492,11 +494,206 @@ __device__ __forceinline__ int limit_rounds_wave(const DevBatch<real> & b, real 
    return rounds;
 }
 
-template <typename real>
+
+// The joint-limit rounds with the violated columns held in REGISTERS.  A round only changes the
+// columns that have a violated entry (Gjlimit, and with it A^-1 Gjlimit, is zero in every other
+// column), so no column can join the set found after the step, and the rounds need nothing but
+// those columns: lane = RPL consecutive waypoints of each of the NC columns.  A round is then
+// violations -> wave arg-max (ties to the first row-major index, as the reference's scan) -> the
+// closed-form A^-1 by one prefix and one suffix wave scan per column -> T += 1.01 Gjl[l]/GA[l] GA,
+// without a single LDS access.  Same operations on the same values as limit_rounds_wave.
+// cols: the columns (ascending); returns the number of rounds made (1000: the caller sets the status).
+template <typename real, int NC, int RPL>
+__device__ __forceinline__ int limit_rounds_regs(real * T_s, const real * jl_s, int m, int n, real kinv, unsigned long long cols, long long * dbg)
+{
+   const int lane = threadIdx.x & 63;
+   int col[NC]; real lo[NC], hi[NC];
+   {
+      unsigned long long rest = cols;
+#pragma unroll
+      for (int ci=0; ci<NC; ci++)
+      {
+         col[ci] = __builtin_ctzll(rest); rest &= rest - 1;
+         lo[ci] = jl_s[col[ci]]; hi[ci] = jl_s[n + col[ci]];
+      }
+   }
+   real T[NC][RPL], wp[RPL], wq[RPL];
+   bool valid[RPL];
+#pragma unroll
+   for (int r=0; r<RPL; r++)
+   {
+      const int row = lane*RPL + r;
+      valid[r] = row < m;
+      wp[r] = (real)(row + 1); wq[r] = (real)(m - row);
+#pragma unroll
+      for (int ci=0; ci<NC; ci++) T[ci][r] = valid[r] ? T_s[n + row*n + col[ci]] : (real)0;
+   }
+   int rounds;
+   for (rounds=0; rounds<1000; rounds++)
+   {
+      real g[NC][RPL];
+      // violations, and which lanes hold one (per register slot: scalar masks)
+      unsigned long long mk[NC][RPL];
+      int total = 0;
+#pragma unroll
+      for (int r=0; r<RPL; r++)
+#pragma unroll
+         for (int ci=0; ci<NC; ci++)
+         {
+            const real t = T[ci][r];
+            real v = M<real>::max_(lo[ci] - t, (real)0) + M<real>::min_(hi[ci] - t, (real)0);
+            v = valid[r] ? v : (real)0;
+            g[ci][r] = v;
+            mk[ci][r] = __ballot(v != (real)0);
+            total += __popcll(mk[ci][r]);
+         }
+      if (total == 0) break;                          // nothing violated
+      if (dbg) *dbg += (total <= 2) ? 1LL : (1LL << 20);       // diagnostics: closed-form rounds | scan rounds << 20 | general-loop rounds << 40
+      if (total <= 2)
+      {
+         // One or two violated entries (nearly every round): A^-1 Gjlimit from the closed form of the
+         // inverse's columns, x_i = kinv (wq_i P_i + wp_i Q_i) with P_i / Q_i the sums of g wp / g wq over
+         // the violated rows at or before / after row i -- what the scans compute, without the scans.
+         int e_lane[2] = {0, 0}, e_r[2] = {0, 0}, e_ci[2] = {0, 0}, cnt = 0;
+#pragma unroll
+         for (int r=0; r<RPL; r++)
+#pragma unroll
+            for (int ci=0; ci<NC; ci++)
+            {
+               unsigned long long mm = mk[ci][r];
+               while (mm && cnt < 2)
+               {
+                  e_lane[cnt] = __builtin_ctzll(mm); e_r[cnt] = r; e_ci[cnt] = ci; cnt++;
+                  mm &= mm - 1;
+               }
+            }
+         real gk[2], wpk[2], wqk[2]; int rowk[2], ek[2];
+#pragma unroll
+         for (int k=0; k<2; k++)
+         {
+            real sel = 0;
+#pragma unroll
+            for (int r=0; r<RPL; r++)
+#pragma unroll
+               for (int ci=0; ci<NC; ci++) sel = (ci == e_ci[k] && r == e_r[k]) ? g[ci][r] : sel;
+            gk[k] = (k < total) ? read_lane(sel, e_lane[k]) : (real)0;
+            rowk[k] = e_lane[k]*RPL + e_r[k];
+            int ck = 0;
+#pragma unroll
+            for (int ci=0; ci<NC; ci++) ck = (ci == e_ci[k]) ? col[ci] : ck;
+            ek[k] = rowk[k]*n + ck;
+            wpk[k] = (real)(rowk[k] + 1); wqk[k] = (real)(m - rowk[k]);
+         }
+         // the largest violation; ties to the first row-major index (chomp.c:621-638)
+         const real a0 = M<real>::fabs_(gk[0]), a1 = M<real>::fabs_(gk[1]);
+         const bool second = (total == 2) && (a1 > a0 || (a1 == a0 && ek[1] < ek[0]));
+         const int w = second ? 1 : 0;
+         const real gl = second ? gk[1] : gk[0];
+         const int roww = second ? rowk[1] : rowk[0];
+         const int ciw = second ? e_ci[1] : e_ci[0];
+         const real gp0 = gk[0] * wpk[0], gq0 = gk[0] * wqk[0], gp1 = gk[1] * wpk[1], gq1 = gk[1] * wqk[1];
+         // GA at the winner
+         real Pw = 0, Qw = 0;
+         {
+            const bool same0 = (e_ci[0] == ciw), same1 = (total == 2) && (e_ci[1] == ciw);
+            Pw += (same0 && rowk[0] <= roww) ? gp0 : (real)0;  Qw += (same0 && rowk[0] > roww) ? gq0 : (real)0;
+            Pw += (same1 && rowk[1] <= roww) ? gp1 : (real)0;  Qw += (same1 && rowk[1] > roww) ? gq1 : (real)0;
+         }
+         const real ga = kinv * ((real)(m - roww) * Pw + (real)(roww + 1) * Qw);
+         const real sc = ((real)1.01 * gl) * rcp_fast(ga);
+         (void) w;
+#pragma unroll
+         for (int ci=0; ci<NC; ci++)
+         {
+            const bool in0 = (e_ci[0] == ci), in1 = (total == 2) && (e_ci[1] == ci);
+            if (!(in0 || in1)) continue;                 // wave-uniform: this column has no violated entry
+#pragma unroll
+            for (int r=0; r<RPL; r++)
+            {
+               const int row = lane*RPL + r;
+               real P = 0, Q = 0;
+               P += (in0 && rowk[0] <= row) ? gp0 : (real)0;  Q += (in0 && rowk[0] > row) ? gq0 : (real)0;
+               P += (in1 && rowk[1] <= row) ? gp1 : (real)0;  Q += (in1 && rowk[1] > row) ? gq1 : (real)0;
+               const real x = kinv * (wq[r] * P + wp[r] * Q);
+               T[ci][r] += sc * x;
+            }
+         }
+         continue;
+      }
+      real best = 0, best_g = 0; int best_e = 0x7fffffff;
+#pragma unroll
+      for (int r=0; r<RPL; r++)
+#pragma unroll
+         for (int ci=0; ci<NC; ci++)
+         {
+            const real v = g[ci][r];
+            const real a = M<real>::fabs_(v);
+            const int e = (lane*RPL + r)*n + col[ci];                 // row-major index: ascending in (r, ci)
+            const bool better = a > best;                              // later entries of the lane win only when strictly larger
+            best = better ? a : best; best_g = better ? v : best_g; best_e = better ? e : best_e;
+         }
+      wave_argmax(best, best_e);
+      const int ge = __builtin_amdgcn_readfirstlane(best_e);
+      const int gi = ge / n, gc = ge - gi*n;
+      const int owner = gi / RPL;
+      // the owner's own best is the winner (its key is the global one), so its signed value is Gjlimit[largest]
+      const real gl = read_lane(best_g, owner);
+      // GA = A^-1 Gjlimit column by column; the winner's entry is picked up on the way
+      real x[NC][RPL];
+      real ga_mine = 0;
+#pragma unroll
+      for (int ci=0; ci<NC; ci++)
+      {
+         real sp = 0, sq = 0;
+#pragma unroll
+         for (int r=0; r<RPL; r++) { sp += g[ci][r] * wp[r]; sq += g[ci][r] * wq[r]; }
+         const real ip = wave_prefix_incl(sp), is = wave_suffix_incl(sq);
+         real run_p = __shfl_up(ip, 1, 64);   if (lane == 0) run_p = 0;
+         real run_q = __shfl_down(is, 1, 64); if (lane == 63) run_q = 0;
+         real q[RPL];
+#pragma unroll
+         for (int r=RPL-1; r>=0; r--) { q[r] = run_q; run_q += g[ci][r] * wq[r]; }
+#pragma unroll
+         for (int r=0; r<RPL; r++)
+         {
+            run_p += g[ci][r] * wp[r];
+            x[ci][r] = kinv * (wq[r] * run_p + wp[r] * q[r]);
+            ga_mine = (col[ci] == gc && lane*RPL + r == gi) ? x[ci][r] : ga_mine;
+         }
+      }
+      const real ga = read_lane(ga_mine, owner);
+      const real sc = ((real)1.01 * gl) * rcp_fast(ga);
+#pragma unroll
+      for (int ci=0; ci<NC; ci++)
+#pragma unroll
+         for (int r=0; r<RPL; r++) T[ci][r] += sc * x[ci][r];
+   }
+#pragma unroll
+   for (int r=0; r<RPL; r++)
+#pragma unroll
+      for (int ci=0; ci<NC; ci++)
+         if (valid[r]) T_s[n + (lane*RPL + r)*n + col[ci]] = T[ci][r];
+   return rounds;
+}
+
+template <typename real, int NC>
+__device__ __forceinline__ int limit_rounds_regs_rpl(real * T_s, const real * jl_s, int m, int n, real kinv, unsigned long long cols, long long * dbg)
+{
+   const int rpl = (m + 63) >> 6;
+   switch (rpl)
+   {
+   case 1: return limit_rounds_regs<real, NC, 1>(T_s, jl_s, m, n, kinv, cols, dbg);
+   case 2: return limit_rounds_regs<real, NC, 2>(T_s, jl_s, m, n, kinv, cols, dbg);
+   case 3: return limit_rounds_regs<real, NC, 3>(T_s, jl_s, m, n, kinv, cols, dbg);
+   default: return limit_rounds_regs<real, NC, 4>(T_s, jl_s, m, n, kinv, cols, dbg);
+   }
+}
+
+template <typename real, int BLOCK>
 __device__ __forceinline__ real * metric_solve(const DevBatch<real> & b, const real * tab, real * src, real * tmp)
 {
-   if (b.solve_mode == 2) return toeplitz_scan_solve(b, src);
-   return b.solve_mode == 0 ? pcr_solve(b, tab, src, tmp) : dense_solve(b, src, tmp);
+   if (b.solve_mode == 2) return toeplitz_scan_solve<real, BLOCK>(b, src);
+   return b.solve_mode == 0 ? pcr_solve<real, BLOCK>(b, tab, src, tmp) : dense_solve<real, BLOCK>(b, src, tmp);
 }
 
 // (A T + B)[i][c] from the band of A and the endpoint couplings of B.
@@ -525,8 +722,8 @@ __device__ __forceinline__ real smooth_grad(const DevBatch<real> & b, const real
 #endif
 
 // ---------------------------------------------------------------------------
-template <typename real, bool TREE, bool GS16>
-__global__ __launch_bounds__(ORC_BLOCK, ORC_WGS_PER_CU)
+template <typename real, bool TREE, bool GS16, int BLOCK>
+__global__ __launch_bounds__(BLOCK, ORC_WGS_PER_CU)      // second argument: wavefronts per SIMD (3 x 4 SIMDs = 12 per CU, as 3 x 256 or 4 x 192 threads)
 void chomp_iterate_kernel(const DevBatch<real> b)
 {
    extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -544,6 +741,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
                                   b.use_momentum && b.ag_in_lds, b.n_sdfs, (int) sizeof(DevJoint<real>), (int) sizeof(DevSdf<real>));
    double * red = (double *) smem_raw;                  // [8] reduction scratch
    int * redi = (int *)(red + 8);                       // [8]
+   unsigned int * colmask_s = (unsigned int *)(redi + 8);   // [2] columns with an entry outside its joint limits after the step
    real * lds = (real *)(smem_raw + 128);
    real * T_s  = lds + L.T;                             // [np][n]
    real * G_s  = lds + L.G;                             // [m][n]
@@ -576,35 +774,36 @@ void chomp_iterate_kernel(const DevBatch<real> b)
    real * traj_g = b.traj + (size_t) run * np * n;
    real * AG_g = b.AG + (size_t) run * mn;
    // momentum: in LDS for the launch, or in place in global memory (every entry is read and written
-   // by the same thread, e = tid + k ORC_BLOCK, in all loops that touch it)
+   // by the same thread, e = tid + k BLOCK, in all loops that touch it)
    real * AG_s = b.ag_in_lds ? lds + L.AG : AG_g;       // [m][n]
 
-   for (int e=tid; e<np*n; e+=ORC_BLOCK) T_s[e] = traj_g[e];
-   for (int e=tid; e<S; e+=ORC_BLOCK) { srad_s[e] = gmod.sph_radius[e]; slink_s[e] = gmod.sph_link[e]; }
-   for (int e=tid; e<(S-Sa)*3; e+=ORC_BLOCK) sinact_s[e] = gmod.sph_inactive_pos[e/3][e%3];
-   for (int e=tid; e<nj; e+=ORC_BLOCK) { jtype_s[e] = gmod.joints[e].type; jcol_s[e] = gmod.joints[e].col; }
-   for (int e=tid; e<Sa*3; e+=ORC_BLOCK) sphpos_s[e] = gmod.sph_pos[e/3][e%3];
-   for (int e=tid; e<gmod.Sa_real; e+=ORC_BLOCK) slot_s[e] = gmod.slot_of[e];
-   for (int e=tid; e<Sa; e+=ORC_BLOCK) saff_s[e] = gmod.sph_affects[e];
-   for (int e=tid; e<12; e+=ORC_BLOCK) base_s[e] = (e < 9) ? gmod.base_R[e] : gmod.base_t[e-9];
+   for (int e=tid; e<np*n; e+=BLOCK) T_s[e] = traj_g[e];
+   for (int e=tid; e<S; e+=BLOCK) { srad_s[e] = gmod.sph_radius[e]; slink_s[e] = gmod.sph_link[e]; }
+   for (int e=tid; e<(S-Sa)*3; e+=BLOCK) sinact_s[e] = gmod.sph_inactive_pos[e/3][e%3];
+   for (int e=tid; e<nj; e+=BLOCK) { jtype_s[e] = gmod.joints[e].type; jcol_s[e] = gmod.joints[e].col; }
+   for (int e=tid; e<Sa*3; e+=BLOCK) sphpos_s[e] = gmod.sph_pos[e/3][e%3];
+   for (int e=tid; e<gmod.Sa_real; e+=BLOCK) slot_s[e] = gmod.slot_of[e];
+   for (int e=tid; e<Sa; e+=BLOCK) saff_s[e] = gmod.sph_affects[e];
+   for (int e=tid; e<12; e+=BLOCK) base_s[e] = (e < 9) ? gmod.base_R[e] : gmod.base_t[e-9];
    {
       // word-wise copies of the joint and field descriptors
       const int * src = (const int *) gmod.joints; int * dst = (int *) joints_s;
-      for (int e=tid; e<nj*(int)(sizeof(DevJoint<real>)/4); e+=ORC_BLOCK) dst[e] = src[e];
+      for (int e=tid; e<nj*(int)(sizeof(DevJoint<real>)/4); e+=BLOCK) dst[e] = src[e];
       const int * src2 = (const int *) b.sdfs; int * dst2 = (int *) sdfs_s;
-      for (int e=tid; e<b.n_sdfs*(int)(sizeof(DevSdf<real>)/4); e+=ORC_BLOCK) dst2[e] = src2[e];
+      for (int e=tid; e<b.n_sdfs*(int)(sizeof(DevSdf<real>)/4); e+=BLOCK) dst2[e] = src2[e];
    }
-   for (int e=tid; e<n; e+=ORC_BLOCK) { jl_s[e] = b.jl_lo[e]; jl_s[n+e] = b.jl_hi[e]; }
+   for (int e=tid; e<n; e+=BLOCK) { jl_s[e] = b.jl_lo[e]; jl_s[n+e] = b.jl_hi[e]; }
    if (b.pcr_in_lds)
-      for (int e=tid; e<b.pcr_rows*m; e+=ORC_BLOCK) pcr_s[e] = b.pcr[e];
+      for (int e=tid; e<b.pcr_rows*m; e+=BLOCK) pcr_s[e] = b.pcr[e];
    const real * pcr_tab = b.pcr_in_lds ? pcr_s : b.pcr;
    const real inv_eps = (real)1 / b.epsilon, inv_eps_self = (real)1 / b.epsilon_self;
-   if (b.use_momentum && b.ag_in_lds) for (int e=tid; e<mn; e+=ORC_BLOCK) AG_s[e] = AG_g[e];
+   if (b.use_momentum && b.ag_in_lds) for (int e=tid; e<mn; e+=BLOCK) AG_s[e] = AG_g[e];
    int leapfrog_first = b.leapfrog_first[run];
    // every iterate call starts afresh: the reference throws out of the call in which a run leaves
    // its joint limits, the run itself stays usable (src/orcdchomp_mod.cpp:2799-2803)
    int status = 0;
    int next_resample = 0;      // index into this call's resample list
+   if (tid < 2) colmask_s[tid] = 0u;
    __syncthreads();
 
    if (GS16 && tid < 64)
@@ -658,7 +857,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
           && b.hmc_iters[(size_t) run * b.max_resamples + next_resample] == it)
       {
          const real * nz = b.noise + ((size_t) run * b.max_resamples + next_resample) * mn;
-         for (int e=tid; e<mn; e+=ORC_BLOCK) AG_s[e] = nz[e];
+         for (int e=tid; e<mn; e+=BLOCK) AG_s[e] = nz[e];
          leapfrog_first = 1;
          next_resample++;
          __syncthreads();
@@ -673,7 +872,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
 
          // ================= FK phase: lane = (waypoint, world axis) ===========
          __builtin_amdgcn_s_setprio(3);          // latency-bound phases go first when they have something to issue
-         for (int w0=0; w0<nfk; w0+=ORC_BLOCK/4)
+         for (int w0=0; w0<nfk; w0+=BLOCK/4)
          {
             const int w = w0 + (tid >> 2);
             const bool valid = (w < nfk);
@@ -686,12 +885,12 @@ void chomp_iterate_kernel(const DevBatch<real> b)
          // ================= cost phase: lane = (waypoint, sphere) =============
          __builtin_amdgcn_s_setprio(0);
          if constexpr (GS16)
-            cost_tile_gs16<real, ORC_U>(b, mod, sdfs, ts, te, do_iteration, T_s, G_s, pos_s, ax_s, srad_s, sinact_s, r2_s,
+            cost_tile_gs16<real, ORC_U, BLOCK>(b, mod, sdfs, ts, te, do_iteration, T_s, G_s, pos_s, ax_s, srad_s, sinact_s, r2_s,
                                         slink_s, jtype_s, jcol_s, inv_eps, inv_eps_self, cost_lane);
          else
          {
          const int items = (te - ts) * GS;
-         for (int base_item=0; base_item<items; base_item+=ORC_BLOCK)
+         for (int base_item=0; base_item<items; base_item+=BLOCK)
          {
             const int item = base_item + tid;
             const int wl = item / GS;               // waypoint within the tile
@@ -994,15 +1193,16 @@ void chomp_iterate_kernel(const DevBatch<real> b)
       } // tiles
 
       // obstacle cost of the trajectory the gradient was taken at (chomp.c:484-491)
-      cost_obs = block_sum(cost_lane, red) / (double) m;
+      cost_obs = block_sum<BLOCK>(cost_lane, red) / (double) m;
       ORC_MARK(2);
 
       if (do_iteration)
       {
          // ================= update phase ======================================
          __builtin_amdgcn_s_setprio(3);
+         if (tid < 2) colmask_s[tid] = 0u;       // read last after the previous step's barrier, set again after the next one
          // G = G/m + A T + B   (chomp.c:492, 515-522)
-         for (int e=tid; e<mn; e+=ORC_BLOCK)
+         for (int e=tid; e<mn; e+=BLOCK)
          {
             const int i = div_n(e, rn_f), c = e - i*n;
             real g = G_s[e];
@@ -1012,32 +1212,46 @@ void chomp_iterate_kernel(const DevBatch<real> b)
          }
          __syncthreads();
          if (b.Gdbg)
-            for (int e=tid; e<mn; e+=ORC_BLOCK) b.Gdbg[(size_t) run*mn + e] = G_s[e];
+            for (int e=tid; e<mn; e+=BLOCK) b.Gdbg[(size_t) run*mn + e] = G_s[e];
          // X = A^-1 G   (chomp.c:525-548)
-         real * X = metric_solve(b, pcr_tab, G_s, W_s);
+         real * X = metric_solve<real, BLOCK>(b, pcr_tab, G_s, W_s);
          // T -= AG/lambda   (chomp.c:604-605)
          const real step = (real)(-1) / b.lambda;
+         // the step also notes which columns left their limits (what the first scan of the
+         // joint-limit loop would find, chomp.c:615-639): bit c of colmask_s
+         unsigned long long viol = 0ull;
          if (!b.use_momentum)
          {
             // AG = X is not carried between iterations: keep only the last one (read-back state)
             const bool keep = (it == b.n_iter - 1) || (b.Gdbg != nullptr);
-            for (int e=tid; e<mn; e+=ORC_BLOCK)
+            for (int e=tid; e<mn; e+=BLOCK)
             {
                const real x = X[e];
                if (keep) AG_g[e] = x;
-               T_s[n + e] += step * x;
+               const real t = T_s[n + e] + step * x;
+               T_s[n + e] = t;
+               const int c = e - div_n(e, rn_f)*n;
+               viol |= (t < jl_s[c] || t > jl_s[n+c]) ? (1ull << c) : 0ull;
             }
          }
          else
          {
             const real sc = (leapfrog_first ? (real)0.5 : (real)1) / b.lambda;
-            for (int e=tid; e<mn; e+=ORC_BLOCK)
+            for (int e=tid; e<mn; e+=BLOCK)
             {
                const real ag = AG_s[e] + sc * X[e];
                AG_s[e] = ag;
-               T_s[n + e] += step * ag;
+               const real t = T_s[n + e] + step * ag;
+               T_s[n + e] = t;
+               const int c = e - div_n(e, rn_f)*n;
+               viol |= (t < jl_s[c] || t > jl_s[n+c]) ? (1ull << c) : 0ull;
             }
             leapfrog_first = 0;
+         }
+         if (viol)
+         {
+            if ((unsigned int) viol) atomicOr(&colmask_s[0], (unsigned int) viol);
+            if ((unsigned int)(viol >> 32)) atomicOr(&colmask_s[1], (unsigned int)(viol >> 32));
          }
          __syncthreads();
 
@@ -1045,24 +1259,37 @@ void chomp_iterate_kernel(const DevBatch<real> b)
          // joint-limit projection (chomp.c:608-655)
          int num_limadjs = 0;
          bool lim_done = false;
-         if (b.solve_mode == 2 && n <= 64)
+         const unsigned long long viol_cols = ((unsigned long long) colmask_s[1] << 32) | colmask_s[0];      // workgroup-uniform
+         if (b.solve_mode == 2 && n <= 64 && !b.lim_generic)
          {
-            // one wavefront makes all rounds (no barrier inside them), the others wait here
-            if (tid < 64)
-            {
-               const int rounds = limit_rounds_wave<real>(b, T_s, G_s, jl_s, m, n, (b.phase_cycles && tid == 0) ? &ph[7] : nullptr);
-               if (tid == 0) redi[0] = rounds;
-            }
-            __syncthreads();
-            num_limadjs = redi[0];
             lim_done = true;
-            __syncthreads();             // redi is reused by the reductions below
+            if (viol_cols != 0ull)
+            {
+               // one wavefront makes all rounds (no barrier inside them), the others wait here
+               if (tid < 64)
+               {
+                  const int nc = __popcll(viol_cols);
+                  const real kinv = (real)(-1) / ((real)(m + 1) * b.a_off);      // 1/((m+1) ca), ca = -a_off
+                  int rounds;
+                  switch (nc)
+                  {
+                  case 1: rounds = limit_rounds_regs_rpl<real, 1>(T_s, jl_s, m, n, kinv, viol_cols, (b.phase_cycles && tid == 0) ? &ph[7] : nullptr); break;
+                  case 2: rounds = limit_rounds_regs_rpl<real, 2>(T_s, jl_s, m, n, kinv, viol_cols, (b.phase_cycles && tid == 0) ? &ph[7] : nullptr); break;
+                  case 3: rounds = limit_rounds_regs_rpl<real, 3>(T_s, jl_s, m, n, kinv, viol_cols, (b.phase_cycles && tid == 0) ? &ph[7] : nullptr); break;
+                  default: rounds = limit_rounds_wave<real>(b, T_s, G_s, jl_s, m, n, nullptr); if (b.phase_cycles && tid == 0) ph[7] += (long long) rounds << 40; break;
+                  }
+                  if (tid == 0) redi[0] = rounds;
+               }
+               __syncthreads();
+               num_limadjs = redi[0];
+               __syncthreads();             // redi is reused by the reductions below
+            }
          }
          if (!lim_done)
          for (; num_limadjs<1000; num_limadjs++)
          {
             real best = 0; int best_e = 0x7fffffff;
-            for (int e=tid; e<mn; e+=ORC_BLOCK)
+            for (int e=tid; e<mn; e+=BLOCK)
             {
                const int i = div_n(e, rn_f), c = e - i*n;
                const real t = T_s[n + e];
@@ -1080,7 +1307,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
             __syncthreads();
             double gb = red[0]; int ge = redi[0];
 #pragma unroll
-            for (int w=1; w<4; w++)
+            for (int w=1; w<BLOCK/64; w++)
                if (red[w] > gb || (red[w] == gb && redi[w] < ge)) { gb = red[w]; ge = redi[w]; }
             if (gb == 0.0) break;                  // nothing violated anywhere in the workgroup
             const int gi = div_n(ge, rn_f), gc = ge - gi*n;
@@ -1093,8 +1320,8 @@ void chomp_iterate_kernel(const DevBatch<real> b)
             bool sparse_done = false;
             if (b.D == 1 && b.solve_mode != 1)
             {
-               const int K = (mn + ORC_BLOCK - 1) / ORC_BLOCK;       // elements per thread
-               int * cnt = (int *) W_s;                               // [K][4] counts per (slice, wave)
+               const int K = (mn + BLOCK - 1) / BLOCK;       // elements per thread
+               int * cnt = (int *) W_s;                               // [K][waves] counts per (slice, wave)
                int * lst = cnt + 64;                                  // [64][2]  (row, column) of a violated entry
                real * lval = (real *)(lst + 128);                     // [64] its Gjlimit value
                const int lane = tid & 63, wave = tid >> 6;
@@ -1102,25 +1329,25 @@ void chomp_iterate_kernel(const DevBatch<real> b)
                {
                   for (int k=0; k<K; k++)
                   {
-                     const int e = tid + k*ORC_BLOCK;
+                     const int e = tid + k*BLOCK;
                      const bool v = (e < mn) && (G_s[e] != (real)0);
                      const unsigned long long mask = __ballot(v);
-                     if (lane == 0) cnt[k*4 + wave] = __popcll(mask);
+                     if (lane == 0) cnt[k*(BLOCK/64) + wave] = __popcll(mask);
                   }
                   __syncthreads();
                   int total = 0;
-                  for (int q=0; q<K*4; q++) total += cnt[q];
+                  for (int q=0; q<K*(BLOCK/64); q++) total += cnt[q];
                   if (total <= 64)
                   {
                      for (int k=0; k<K; k++)
                      {
-                        const int e = tid + k*ORC_BLOCK;
+                        const int e = tid + k*BLOCK;
                         const bool v = (e < mn) && (G_s[e] != (real)0);
                         const unsigned long long mask = __ballot(v);
                         if (v)
                         {
                            int off = 0;
-                           for (int q=0; q<k*4 + wave; q++) off += cnt[q];
+                           for (int q=0; q<k*(BLOCK/64) + wave; q++) off += cnt[q];
                            off += __popcll(mask & ((1ull << lane) - 1ull));
                            const int i = div_n(e, rn_f);
                            lst[2*off] = i; lst[2*off+1] = e - i*n;
@@ -1141,7 +1368,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
                         }
                      }
                      const real sc = (real)1.01 * gl / (ga_l * kinv);
-                     for (int e=tid; e<mn; e+=ORC_BLOCK)
+                     for (int e=tid; e<mn; e+=BLOCK)
                      {
                         const int i = div_n(e, rn_f), c = e - i*n;
                         real ga = 0;
@@ -1164,10 +1391,10 @@ void chomp_iterate_kernel(const DevBatch<real> b)
             if (!sparse_done)
             {
                __syncthreads();
-               real * GA = metric_solve(b, pcr_tab, G_s, W_s);
+               real * GA = metric_solve<real, BLOCK>(b, pcr_tab, G_s, W_s);
                const real sc = (real)1.01 * gl / GA[ge];
                __syncthreads();
-               for (int e=tid; e<mn; e+=ORC_BLOCK) T_s[n + e] += sc * GA[e];
+               for (int e=tid; e<mn; e+=BLOCK) T_s[n + e] += sc * GA[e];
                __syncthreads();
             }
          }
@@ -1187,7 +1414,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
       // the reference (cd_chomp_iterate returns before mod.cpp:2806-2808 runs)
       {
          double acc = 0.0;
-         for (int e=tid; e<mn; e+=ORC_BLOCK)
+         for (int e=tid; e<mn; e+=BLOCK)
          {
             const int i = div_n(e, rn_f), c = e - i*n;
             const real sg = smooth_grad(b, T_s, i, c);           // (A T + B)
@@ -1202,14 +1429,14 @@ void chomp_iterate_kernel(const DevBatch<real> b)
             ss = s0*s0; sg2 = s0*g0; gg = g0*g0;
          }
          acc += 0.5 * (b.kss*ss + 2.0*b.ksg*sg2 + b.kgg*gg);
-         cost_smooth = block_sum(acc, red);
+         cost_smooth = block_sum<BLOCK>(acc, red);
       }
       ORC_MARK(5);
 
       // floating base: renormalise the quaternion of every row (mod.cpp:2806-2808)
       if (do_iteration && mod.floating)
       {
-         for (int w=tid; w<np; w+=ORC_BLOCK)
+         for (int w=tid; w<np; w+=BLOCK)
          {
             real * row = T_s + w*n;
             const real len = M<real>::sqrt_(row[3]*row[3] + row[4]*row[4] + row[5]*row[5] + row[6]*row[6]);
@@ -1230,8 +1457,8 @@ void chomp_iterate_kernel(const DevBatch<real> b)
 
    // ---- write back ---------------------------------------------------------
    __syncthreads();
-   for (int e=tid; e<np*n; e+=ORC_BLOCK) traj_g[e] = T_s[e];
-   if (b.use_momentum && b.ag_in_lds) for (int e=tid; e<mn; e+=ORC_BLOCK) AG_g[e] = AG_s[e];
+   for (int e=tid; e<np*n; e+=BLOCK) traj_g[e] = T_s[e];
+   if (b.use_momentum && b.ag_in_lds) for (int e=tid; e<mn; e+=BLOCK) AG_g[e] = AG_s[e];
    if (tid == 0)
    {
       if (b.phase_cycles) for (int k=0; k<8; k++) b.phase_cycles[(size_t) run*8 + k] = ph[k];
@@ -1248,7 +1475,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
    }
    // the iterations an aborted run did not make have no log line in the reference: NaN rows
    if (b.trace && status != 0)
-      for (int e=iters_done*3 + tid; e<b.n_iter*3; e+=ORC_BLOCK)
+      for (int e=iters_done*3 + tid; e<b.n_iter*3; e+=BLOCK)
          b.trace[(size_t) run * b.n_iter * 3 + e] = __longlong_as_double(0x7ff8000000000000LL);
 }
 
@@ -1400,7 +1627,7 @@ size_t orc_chomp_lds_bytes(int n_points, int n, int Sa, int S, int nj, int tile_
    return (size_t) lds_layout(n_points, n, Sa, S, nj, tile_m, pcr_rows, (int) real_size, use_momentum, n_sdfs, js, ss).total_bytes;
 }
 
-template <typename real, bool TREE, bool GS16>
+template <typename real, bool TREE, bool GS16, int BLOCK>
 static hipError_t launch_iterate_tt(const DevBatch<real> & b, size_t lds, hipStream_t stream)
 {
    // the attribute is per device (and per kernel instantiation)
@@ -1409,25 +1636,30 @@ static hipError_t launch_iterate_tt(const DevBatch<real> & b, size_t lds, hipStr
    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
    if (!((attr_set.load() >> dev) & 1ull))
    {
-      hipError_t e = hipFuncSetAttribute((const void *) chomp_iterate_kernel<real, TREE, GS16>,
+      hipError_t e = hipFuncSetAttribute((const void *) chomp_iterate_kernel<real, TREE, GS16, BLOCK>,
          hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256);
       if (e != hipSuccess) return e;
       attr_set.fetch_or(1ull << dev);
    }
-   hipLaunchKernelGGL((chomp_iterate_kernel<real, TREE, GS16>), dim3(b.n_runs), dim3(ORC_BLOCK), lds, stream, b);
+   hipLaunchKernelGGL((chomp_iterate_kernel<real, TREE, GS16, BLOCK>), dim3(b.n_runs), dim3(BLOCK), lds, stream, b);
    return hipGetLastError();
 }
 
-// variant: bit 0 the joint tree branches, bit 1 the robot has <= 16 active spheres (DPP-row cost phase)
+// variant: bit 0 the joint tree branches, bit 1 the robot has <= 16 active spheres (DPP-row cost
+// phase), bit 2 workgroups of 192 threads (three wavefronts, four workgroups per CU) instead of 256
 template <typename real>
 static hipError_t launch_iterate_t(const DevBatch<real> & b, size_t lds, hipStream_t stream, int variant)
 {
-   switch (variant & 3)
+   switch (variant & 7)
    {
-   case 0: return launch_iterate_tt<real, false, false>(b, lds, stream);
-   case 1: return launch_iterate_tt<real, true, false>(b, lds, stream);
-   case 2: return launch_iterate_tt<real, false, true>(b, lds, stream);
-   default: return launch_iterate_tt<real, true, true>(b, lds, stream);
+   case 0: return launch_iterate_tt<real, false, false, 256>(b, lds, stream);
+   case 1: return launch_iterate_tt<real, true, false, 256>(b, lds, stream);
+   case 2: return launch_iterate_tt<real, false, true, 256>(b, lds, stream);
+   case 3: return launch_iterate_tt<real, true, true, 256>(b, lds, stream);
+   case 4: return launch_iterate_tt<real, false, false, 192>(b, lds, stream);
+   case 5: return launch_iterate_tt<real, true, false, 192>(b, lds, stream);
+   case 6: return launch_iterate_tt<real, false, true, 192>(b, lds, stream);
+   default: return launch_iterate_tt<real, true, true, 192>(b, lds, stream);
    }
 }
 

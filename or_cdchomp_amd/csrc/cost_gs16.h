@@ -127,7 +127,7 @@ __device__ __forceinline__ void self_sym_step16(const real * prow, const real * 
    }
 }
 
-template <typename real, int U>
+template <typename real, int U, int BLOCK>
 __device__ __forceinline__ void cost_tile_gs16(const DevBatch<real> & b, const ModelView<real> & mod,
    const DevSdf<real> * sdfs, int ts, int te, bool do_iteration, const real * T_s, real * G_s, const real * pos_s, const real * ax_s,
    const real * srad_s, const real * sinact_s, const real * r2_s, const int * slink_s, const int * jtype_s, const int * jcol_s,
@@ -141,11 +141,11 @@ __device__ __forceinline__ void cost_tile_gs16(const DevBatch<real> & b, const M
    const int items = ngroups * 16;
    const real inf = M<real>::inf();
 
-   for (int base_item=0; base_item<items; base_item+=ORC_BLOCK)
+   for (int base_item=0; base_item<items; base_item+=BLOCK)
    {
       if (base_item + (tid & ~63) >= items) continue;      // a wavefront without a waypoint in this round (wave-uniform)
       // the last round of a tile goes first: it is what the tile's barrier waits for
-      if (base_item + ORC_BLOCK >= items) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+      if (base_item + BLOCK >= items) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
       const int item = base_item + tid;
       const int g = item >> 4, s = item & 15;
       const bool lane_ok = (item < items) && (((mod.live_mask >> s) & 1ull) != 0);

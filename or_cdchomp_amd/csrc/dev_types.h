@@ -129,6 +129,7 @@ struct DevBatch
    int ag_in_lds;          // the momentum AG lives in LDS for the launch (else it is updated in place in global memory)
    int pcr_sym;            // compact tables: pcr[l][m] (towards i-s; towards i+s is the mirrored entry), then [m] inverse diagonal
    int pcr_rows;           // rows of m entries in the table
+   int lim_generic;        // diagnostics: joint-limit rounds by the general (workgroup, any metric) loop
    int stagger_mode;       // 0 none; 1 odd workgroups, 2 every other group of 256: start half an iteration late
    int stagger_sleeps;     // length of that delay in s_sleep(127) units (~8k cycles each)
 };

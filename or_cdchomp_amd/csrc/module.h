@@ -154,6 +154,7 @@ private:
    int Sa_real_ = 0;                  // active spheres
    int nj_ = 0, Sa_ = 0, S_ = 0;      // optimized joints; lanes of the active sphere block; lanes + inactive spheres
    int tile_m_ = 0;
+   int block_ = 256;                  // threads per workgroup of the iterate kernel (256 or 192)
    int pcr_in_lds_ = 0;
    int tree_ = 0;
    int pcr_rows_ = 0, pcr_sym_ = 0, solve_mode_ = 0, ag_in_lds_ = 1, GS_ = 0;
@@ -167,7 +168,7 @@ private:
    std::vector<int> hmc_resample_iter_;
    std::vector<double> ext_noise_; int ext_noise_blocks_ = 0;
    std::vector<int> ext_noise_used_;   // caller-supplied blocks consumed by the current iterate call, per run
-   int stagger_mode_ = 0, stagger_sleeps_ = 10;
+   int stagger_mode_ = 0, stagger_sleeps_ = 10, lim_generic_ = 0;
 };
 
 // A batch as the boundary sees it: its runs are cut into contiguous blocks, one BatchShard per

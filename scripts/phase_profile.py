@@ -29,11 +29,13 @@ print("per-WG total Mcycles: min %.1f p10 %.1f median %.1f p90 %.1f p99 %.1f max
 jl = out[:, 4]
 print("joint-limit Mcycles: median %.2f p90 %.2f p99 %.2f max %.2f ; share of runs with >20%% of time there: %.1f %%" % (
     np.median(jl)/1e6, np.percentile(jl, 90)/1e6, np.percentile(jl, 99)/1e6, jl.max()/1e6, 100*np.mean(jl > 0.2*tot_all)))
-rounds = out[:, 6]; its = out[:, 7]
-print("limit rounds per run (100 iterations): mean %.0f median %.0f p90 %.0f p99 %.0f max %.0f ; violated entries per round: mean %.1f, per-run mean: median %.1f p90 %.1f max %.1f" % (
-    rounds.mean(), np.median(rounds), np.percentile(rounds, 90), np.percentile(rounds, 99), rounds.max(), its.sum() / rounds.sum(),
-    np.median(its / np.maximum(rounds, 1)), np.percentile(its / np.maximum(rounds, 1), 90), (its / np.maximum(rounds, 1)).max()))
-print("cycles per round (joint-limit cycles / (rounds + 101 checks)): %.0f" % (jl.sum() / (rounds.sum() + 101*n_runs)))
-A = np.stack([np.full(n_runs, 101.0), rounds, its], axis=1)
-coef, *_ = np.linalg.lstsq(A, jl, rcond=None)
-print("fit: joint-limit cycles = %.0f per iteration + %.0f per round + %.0f per violated entry" % tuple(coef))
+rounds = out[:, 6]
+print("limit rounds per run (100 iterations): mean %.0f median %.0f p90 %.0f p99 %.0f max %.0f" % (
+    rounds.mean(), np.median(rounds), np.percentile(rounds, 90), np.percentile(rounds, 99), rounds.max()))
+# kinds of joint-limit rounds (ph[7] packs three 20-bit counts): closed form (<= 2 violated entries), scans on register columns, general loop (>= 4 columns)
+pk = out[:, 7].astype(np.int64)
+fast = pk & 0xFFFFF; scan = (pk >> 20) & 0xFFFFF; old = pk >> 40
+heavy = np.argsort(-rounds)[:8]
+print("round kinds over all runs: closed form %d, register scans %d, general loop %d" % (fast.sum(), scan.sum(), old.sum()))
+for k in heavy:
+    print("  run %4d: rounds %5d = closed %4d + scans %4d + general %4d ; limit Mcycles %.2f of %.2f" % (k, rounds[k], fast[k], scan[k], old[k], jl[k] / 1e6, tot_all[k] / 1e6))

@@ -96,7 +96,7 @@ def test_dat_filename_log(oracle, tmp_path):
     # a batch takes a pattern with the run index
     goals = common.wam_goals(3, seed=32)
     g = np.ascontiguousarray(goals)
-    bid = int(mod.SendCommand("createbatch robot %s n_runs 3 adofgoals 0x%x n_points 60 dat_filename '%s'"
+    bid = int(mod.SendCommand("createbatch robot %s n_runs 3 adofgoals 0x%x n_points 60 lambda 100 dat_filename '%s'"
                               % (model.name, g.ctypes.data, str(tmp_path / "run%d.dat"))))
     mod.SendCommand("iteratebatch run %d n_iter 4" % bid)
     mod.batch_destroy(bid)
@@ -139,7 +139,7 @@ def test_iterate_max_time_and_trajs_fileformstr(oracle, tmp_path, hmc):
         assert common.rel_l2(dumped, oracle_after(k)[0]) <= 1e-6, k
     t12, c12 = oracle_after(12)
     assert common.rel_l2(final, t12) <= 1e-6
-    assert np.isclose(cost[0], c12[0], rtol=1e-6)
+    assert np.isclose(cost[0], c12[0], rtol=1e-5)          # `sout << cost_total`: six significant digits (mod.cpp:2849)
     mod.destroy(run=run)
     # the launches of that path against ONE fused launch of the same call
     a = mod.create(robot=model.name, adofgoal=list(goal), **dict(kw, **extra))
