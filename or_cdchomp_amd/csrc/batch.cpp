@@ -14,7 +14,7 @@
 
 // launch wrappers implemented in chomp_kernel.hip
 size_t orc_chomp_lds_bytes(int n_points, int n, int Sa, int S, int nj, int tile_m, int pcr_rows, size_t real_size,
-   int use_momentum, int n_sdfs);
+   int use_momentum, int n_sdfs, int flags);
 hipError_t orc_launch_iterate_f64(const DevBatch<double> & b, size_t lds, hipStream_t stream, int tree);
 hipError_t orc_launch_iterate_f32(const DevBatch<float> & b, size_t lds, hipStream_t stream, int tree);
 hipError_t orc_launch_verdict_f64(const DevVerdict<double> & v, size_t lds, hipStream_t stream, int tree);
@@ -279,7 +279,7 @@ void BatchShard::construct(const Robot & robot, const double * starts, const dou
    }
    hmc_resample_iter_.assign(n_runs, 0);
    ext_noise_used_.assign(n_runs, 0);
-   lim_generic_ = getenv("ORC_LIM_GENERIC") ? 1 : 0;
+   lim_generic_ = getenv("ORC_LIM_GENERIC") ? atoi(getenv("ORC_LIM_GENERIC")) : 0;
    stagger_mode_ = getenv("ORC_STAGGER_MODE") ? atoi(getenv("ORC_STAGGER_MODE")) : 0;
    stagger_sleeps_ = getenv("ORC_STAGGER_SLEEPS") ? atoi(getenv("ORC_STAGGER_SLEEPS")) : 10;
 }
@@ -297,7 +297,7 @@ void BatchShard::release()
    void ** all[] = { &d_model_, &d_sdfs_, &d_traj_, &d_AG_, &d_G_, (void **) &d_mt_, (void **) &d_mt_bak_, (void **) &d_hmc_next_,
                      (void **) &d_hmc_next_bak_, (void **) &d_overflow_, (void **) &d_costs_, (void **) &d_trace_, (void **) &d_status_,
                      (void **) &d_iters_done_, (void **) &d_leap_, &d_Aband_, &d_beta_s_, &d_beta_g_, &d_pcr_, &d_Ainv_, &d_jl_lo_, &d_jl_hi_,
-                     (void **) &d_hmc_iters_, &d_noise_, (void **) &d_phase_ };
+                     (void **) &d_hmc_iters_, &d_noise_, (void **) &d_phase_, &d_Gcost_ };
    for (void ** p : all) { dev_free(*p); *p = nullptr; }
    sdf_refs_.clear();
    for (auto & ev : pending_events_) { mod_->event_pool(device).push_back(ev.first); mod_->event_pool(device).push_back(ev.second); }
@@ -696,6 +696,9 @@ void BatchShard::build_device(const Robot & robot)
    if (const char * e = getenv("ORC_AG_LDS")) force_ag = atoi(e);
    if (const char * e = getenv("ORC_WGS")) max_wgs = atoi(e);
    if (const char * e = getenv("ORC_BLOCK_THREADS")) force_block = atoi(e);
+   int force_g = -1, force_tl = -1;
+   if (const char * e = getenv("ORC_G_LDS")) force_g = atoi(e);
+   if (const char * e = getenv("ORC_T_LDS")) force_tl = atoi(e);
    const int lanes_per_wp = (GS_ == 16) ? 16 : GS_;
    tile_m_ = 0;
    block_ = 256;
@@ -715,7 +718,13 @@ void BatchShard::build_device(const Robot & robot)
       const size_t budget = (lds_cu / wgs / 1280) * 1280 - (wgs == 1 ? 1024 : 0);
       for (int with_pcr=1; with_pcr>=0; with_pcr--)
          for (int ag_lds=1; ag_lds>=0; ag_lds--)
+         for (int g_lds=1; g_lds>=0; g_lds--)
+         for (int t_lds=1; t_lds>=0; t_lds--)
          {
+            if (force_g >= 0 && g_lds != force_g) continue;
+            if (!t_lds && (GS_ == 16 || g_lds)) continue;      // the trajectory in global memory: generic cost path, after G went there
+            if (force_tl >= 0 && t_lds != force_tl && GS_ != 16 && !g_lds) continue;
+            const int flags = (solve_mode_ == 2 ? ORC_LDS_SMALL_WORK : 0) | (g_lds ? 0 : ORC_LDS_G_GLOBAL) | (t_lds ? 0 : ORC_LDS_T_GLOBAL);
             if (with_pcr && !pcr_rows) continue;
             if (force_pcr >= 0 && with_pcr != force_pcr && pcr_rows) continue;
             if (!ag_lds && !params.use_momentum) continue;
@@ -724,17 +733,23 @@ void BatchShard::build_device(const Robot & robot)
             {
                if (force_t > 0 && t != (force_t < m ? force_t : m)) continue;
                const size_t need = orc_chomp_lds_bytes(n_points, n, Sa_, S_, nj, t, with_pcr ? pcr_rows : 0, sizeof(real),
-                                                       params.use_momentum && ag_lds, n_sdfs_);
+                                                       params.use_momentum && ag_lds, n_sdfs_, flags);
                if (need > budget) continue;
                const int tiles = (m + t - 1) / t;
                const double fk_passes = tiles * std::ceil((t + 2) / (block / 4.0));
                const double rounds = tiles * std::ceil(t * (double) lanes_per_wp / block);
-               const double cycles = 12e3 * fk_passes + 11e3 * rounds + 30e3 * (256.0 / block) + (with_pcr ? 0.0 : 1e3) + (ag_lds ? 0.0 : 2e3);
+               // measured: an FK pass costs ~1.7k cycles per joint, a round of the 16-lane cost phase ~11k,
+               // of the generic one ~350 per active sphere (WAM / 30-dof tree, scripts/phase_profile*.py)
+               const double fk_pass = 1.7e3 * nj, round_cycles = (GS_ == 16) ? 11e3 : 350.0 * Sa_;
+               const double cycles = fk_pass * fk_passes + round_cycles * rounds + 30e3 * (256.0 / block) + (with_pcr ? 0.0 : 1e3) + (ag_lds ? 0.0 : 2e3)
+                                   + (g_lds ? 0.0 : 2e3) + (t_lds ? 0.0 : 6e3);
                const double waves_per_simd = wgs * block / 256.0;
-               const double score = wgs * (1.0 - 0.05 * (waves_per_simd - 1.0)) / cycles;
+               // (four workgroups of three wavefronts measured 7-10 % below three of four at equal wavefronts per SIMD)
+               const double score = wgs * (1.0 - 0.05 * (waves_per_simd - 1.0)) * (block == 192 ? 0.90 : 1.0) / cycles;
                if (score > best_score)
                {
                   best_score = score; tile_m_ = t; pcr_in_lds_ = with_pcr; ag_in_lds_ = ag_lds; lds_bytes_ = need; block_ = block;
+                  g_in_lds_ = g_lds; lds_flags_ = flags; t_in_lds_ = t_lds;
                }
                break;                                   // largest tile of this plan
             }
@@ -742,8 +757,8 @@ void BatchShard::build_device(const Robot & robot)
    }
    if (!tile_m_) throw std::runtime_error("run does not fit the LDS of one CU!");
    if (getenv("ORC_DEBUG_PLAN"))
-      fprintf(stderr, "orc plan: %d threads per workgroup, tile_m %d (%d tiles) lds %zu bytes (%d workgroups per CU) pcr_in_lds %d ag_in_lds %d solve_mode %d\n", block_, tile_m_,
-              (m + tile_m_ - 1) / tile_m_, lds_bytes_, (int)(lds_cu / ((lds_bytes_ + 1279) / 1280 * 1280)), pcr_in_lds_, ag_in_lds_, solve_mode_);
+      fprintf(stderr, "orc plan: %d threads per workgroup, tile_m %d (%d tiles) lds %zu bytes (%d workgroups per CU) pcr_in_lds %d ag_in_lds %d g_in_lds %d t_in_lds %d solve_mode %d\n", block_, tile_m_,
+              (m + tile_m_ - 1) / tile_m_, lds_bytes_, (int)(lds_cu / ((lds_bytes_ + 1279) / 1280 * 1280)), pcr_in_lds_, ag_in_lds_, g_in_lds_, t_in_lds_, solve_mode_);
 }
 
 void BatchShard::collision_verdict(const std::vector<int> & offs, const std::vector<int> & seg, const std::vector<double> & u,
@@ -904,7 +919,8 @@ void BatchShard::launch(int n_iter, bool final_eval)
    b.n_sdfs = n_sdfs_;
    b.n_runs = n_runs; b.n_points = n_points; b.m = m; b.n = n;
    b.tile_m = tile_m_;
-   b.traj = (real *) d_traj_; b.AG = (real *) d_AG_; b.Gdbg = (real *) d_G_;
+   b.traj = (real *) d_traj_; b.AG = (real *) d_AG_; b.Gdbg = (real *) d_G_; b.Gcost = (real *) d_Gcost_;
+   b.g_in_lds = g_in_lds_; b.lds_flags = lds_flags_; b.t_in_lds = t_in_lds_;
    b.costs = d_costs_; b.trace = d_trace_; b.status = d_status_; b.iters_done = d_iters_done_; b.leapfrog_first = d_leap_;
    const double dt = 1.0/(n_points-1);
    b.dt = (real) dt;
@@ -937,6 +953,11 @@ void BatchShard::launch(int n_iter, bool final_eval)
       b.a_off = (real) metric_.beta_s[0];
    }
    b.Gdbg = debug_state_ ? (real *) d_G_ : nullptr;
+   if (!g_in_lds_ && !d_Gcost_)
+   {
+      d_Gcost_ = dev_alloc<real>((size_t) n_runs * m * n);
+      b.Gcost = (real *) d_Gcost_;
+   }
    std::vector<hipEvent_t> & pool = mod_->event_pool(device);
    hipEvent_t ev[2];
    for (int k=0; k<2; k++)

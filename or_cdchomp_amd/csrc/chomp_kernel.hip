@@ -715,6 +715,7 @@ __device__ __forceinline__ real smooth_grad(const DevBatch<real> & b, const real
 }
 
 #include "cost_gs16.h"
+#include "cost_generic.h"
 #include "fk.h"
 
 #ifndef ORC_U
@@ -738,13 +739,18 @@ void chomp_iterate_kernel(const DevBatch<real> b)
 
    // ---- LDS carve-up ------------------------------------------------------
    const LdsLayout L = lds_layout(np, n, Sa, S, nj, tile_m, b.pcr_in_lds ? b.pcr_rows : 0, (int) sizeof(real),
-                                  b.use_momentum && b.ag_in_lds, b.n_sdfs, (int) sizeof(DevJoint<real>), (int) sizeof(DevSdf<real>));
+                                  b.use_momentum && b.ag_in_lds, b.n_sdfs, (int) sizeof(DevJoint<real>), (int) sizeof(DevSdf<real>), b.lds_flags);
    double * red = (double *) smem_raw;                  // [8] reduction scratch
    int * redi = (int *)(red + 8);                       // [8]
    unsigned int * colmask_s = (unsigned int *)(redi + 8);   // [2] columns with an entry outside its joint limits after the step
    real * lds = (real *)(smem_raw + 128);
-   real * T_s  = lds + L.T;                             // [np][n]
-   real * G_s  = lds + L.G;                             // [m][n]
+   real * traj_g = b.traj + (size_t) run * np * n;
+   // [np][n]; the kernels of the generic cost path may leave it in global memory (large robots: the
+   // LDS then holds tiles only and a third workgroup fits the CU); __syncthreads orders the accesses
+   // of a workgroup's wavefronts to it
+   real * T_s  = (!GS16 && !b.t_in_lds) ? traj_g : lds + L.T;
+   real * G_s  = lds + L.G;                             // [m][n] (inside the tile buffers when !g_in_lds: update phase only)
+   real * Gc = b.g_in_lds ? G_s : b.Gcost + (size_t) run * mn;   // where the cost phase puts its gradient rows
    real * W_s  = lds + L.W;                             // [m][n] work
    real * pos_s = lds + L.pos;                          // [tile_m+2][Sa][3]
    real * ax_s = lds + L.ax;                            // [tile_m+2][nj][6]
@@ -771,13 +777,12 @@ void chomp_iterate_kernel(const DevBatch<real> b)
    mod.joints = joints_s; mod.sph_pos = (const real (*)[3]) sphpos_s; mod.sph_affects = saff_s;
    const DevSdf<real> * sdfs = sdfs_s;
 
-   real * traj_g = b.traj + (size_t) run * np * n;
    real * AG_g = b.AG + (size_t) run * mn;
    // momentum: in LDS for the launch, or in place in global memory (every entry is read and written
    // by the same thread, e = tid + k BLOCK, in all loops that touch it)
    real * AG_s = b.ag_in_lds ? lds + L.AG : AG_g;       // [m][n]
 
-   for (int e=tid; e<np*n; e+=BLOCK) T_s[e] = traj_g[e];
+   if (GS16 || b.t_in_lds) for (int e=tid; e<np*n; e+=BLOCK) T_s[e] = traj_g[e];
    for (int e=tid; e<S; e+=BLOCK) { srad_s[e] = gmod.sph_radius[e]; slink_s[e] = gmod.sph_link[e]; }
    for (int e=tid; e<(S-Sa)*3; e+=BLOCK) sinact_s[e] = gmod.sph_inactive_pos[e/3][e%3];
    for (int e=tid; e<nj; e+=BLOCK) { jtype_s[e] = gmod.joints[e].type; jcol_s[e] = gmod.joints[e].col; }
@@ -829,6 +834,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
 
    // optional per-phase cycle counters (diagnostics: b.phase_cycles == null in production)
    long long ph[8] = {0,0,0,0,0,0,0,0};
+   long long gdbg[4] = {0,0,0,0};           // diagnostics: parts of the generic cost path (ORC_LIM_GENERIC=2 with ORC_PHASE_TIMERS)
    long long tmark = 0;
 #define ORC_MARK(slot) do { if (b.phase_cycles && tid == 0) { const long long now_ = clock64(); ph[slot] += now_ - tmark; tmark = now_; } } while (0)
    if (b.phase_cycles && tid == 0) tmark = clock64();
@@ -885,309 +891,12 @@ void chomp_iterate_kernel(const DevBatch<real> b)
          // ================= cost phase: lane = (waypoint, sphere) =============
          __builtin_amdgcn_s_setprio(0);
          if constexpr (GS16)
-            cost_tile_gs16<real, ORC_U, BLOCK>(b, mod, sdfs, ts, te, do_iteration, T_s, G_s, pos_s, ax_s, srad_s, sinact_s, r2_s,
+            cost_tile_gs16<real, ORC_U, BLOCK>(b, mod, sdfs, ts, te, do_iteration, T_s, Gc, pos_s, ax_s, srad_s, sinact_s, r2_s,
                                         slink_s, jtype_s, jcol_s, inv_eps, inv_eps_self, cost_lane);
          else
-         {
-         const int items = (te - ts) * GS;
-         for (int base_item=0; base_item<items; base_item+=BLOCK)
-         {
-            const int item = base_item + tid;
-            const int wl = item / GS;               // waypoint within the tile
-            const int s = item - wl*GS;             // sphere slot
-            const bool live = (item < items) && (s < Sa);
-            const int l = wl + 1;                   // row of pos_s / ax_s
-            real p[3] = {0,0,0}, vel[3] = {0,0,0}, acc[3] = {0,0,0};
-            real f[3] = {0,0,0};                    // total workspace force on this sphere
-            real vnorm = 0;
-            double cost_sphere = 0.0;
-            real radius = 0, inv_vn2 = 0;
-            int mylink = -1;
-            bool moving = false;
-            if (live)
-            {
-               const real * pc = pos_s + l*pstr + s*3;
-               const real * pp = pos_s + (l-1)*pstr + s*3;
-               const real * pn = pos_s + (l+1)*pstr + s*3;
-               radius = srad_s[s];
-               mylink = slink_s[s];
-#pragma unroll
-               for (int k=0; k<3; k++)
-               {
-                  p[k] = pc[k];
-                  // src/orcdchomp_mod.cpp:1104-1106, 1120-1124
-                  real v = pn[k]; v -= pp[k]; v *= b.inv_2dt; vel[k] = v;
-                  real a = pc[k]; a *= (real)(-2); a += pp[k]; a += pn[k]; a *= b.inv_dt2; acc[k] = a;
-               }
-               const real vn2 = vel[0]*vel[0] + vel[1]*vel[1] + vel[2]*vel[2];
-               real inv_vn;
-               vnorm = sqrt_rsq(vn2, &inv_vn);
-               inv_vn2 = inv_vn * inv_vn;                     // only used when vnorm > 1e-6
-               moving = vnorm > (real)0.000001;
-
-               // ---- obstacle term (src/orcdchomp_mod.cpp:1171-1246) ----
-               real best = inf; int best_i = -1; real bgrad[3] = {0,0,0};
-#ifndef ORC_ABLATE_SDF
-               for (int i=0; i<b.n_sdfs; i++)
-               {
-                  const DevSdf<real> & F = sdfs[i];
-                  real g[3], gg[3], val;
-#pragma unroll
-                  for (int k=0; k<3; k++)
-                     g[k] = F.Rgw[k*3+0]*p[0] + F.Rgw[k*3+1]*p[1] + F.Rgw[k*3+2]*p[2] + F.tgw[k];
-                  if (sdf_lookup(F, g, val, gg)) continue;
-                  if (val < best) { best = val; best_i = i; bgrad[0] = gg[0]; bgrad[1] = gg[1]; bgrad[2] = gg[2]; }
-               }
-#endif
-               if (best_i != -1)
-               {
-                  const DevSdf<real> & F = sdfs[best_i];
-                  const real dist = best - radius;
-                  real cs = 0;
-                  if (dist < (real)0)
-                     cs = vnorm * b.obs_factor * ((real)0.5 * b.epsilon - dist);
-                  else if (dist < b.epsilon)
-                     cs = vnorm * b.obs_factor * ((real)0.5 * inv_eps) * (dist - b.epsilon) * (dist - b.epsilon);
-                  cost_sphere += (double) cs;
-                  if (do_iteration && vnorm != (real)0)
-                  {
-                     real xg[3], xc[3];
-                     real scale;
-                     if (dist < (real)0) scale = (real)(-1);
-                     else if (dist < b.epsilon) scale = dist * inv_eps - (real)1;
-                     else scale = (real)0;
-                     const real sc2 = scale * (vnorm * b.obs_factor);
-#pragma unroll
-                     for (int k=0; k<3; k++)
-                     {
-                        const real gw = F.Rwg[k*3+0]*bgrad[0] + F.Rwg[k*3+1]*bgrad[1] + F.Rwg[k*3+2]*bgrad[2];
-                        xg[k] = (scale == (real)0) ? (real)0 : gw * sc2;
-                        xc[k] = acc[k];
-                     }
-                     if (moving)
-                     {
-                        real proj = (xg[0]*vel[0] + xg[1]*vel[1] + xg[2]*vel[2]) * inv_vn2;
-#pragma unroll
-                        for (int k=0; k<3; k++) xg[k] -= proj * vel[k];
-                        proj = (xc[0]*vel[0] + xc[1]*vel[1] + xc[2]*vel[2]) * inv_vn2;
-#pragma unroll
-                        for (int k=0; k<3; k++) xc[k] -= proj * vel[k];
-                     }
-                     // x_grad -= cost * curvature, curvature = xc / |v|^2; then c_grad += |v| J^T x_grad
-                     const real cw = cs * inv_vn2;
-#pragma unroll
-                     for (int k=0; k<3; k++) f[k] += vnorm * (xg[k] - cw * xc[k]);
-                  }
-               }
-            }
-
-            // ---- self collision (src/orcdchomp_mod.cpp:1251-1317) ----
-            if (live)
-            {
-               // pass 1: which spheres are within range (uniform loop, squared distances)
-               unsigned long long near = 0ull;
-#ifndef ORC_ABLATE_PASS1
-#pragma unroll 4
-               for (int o=0; o<S; o++)
-               {
-                  const real * po = (o < Sa) ? pos_s + l*pstr + o*3 : sinact_s + (o - Sa)*3;
-                  const real dx = p[0]-po[0], dy = p[1]-po[1], dz = p[2]-po[2];
-                  const real d2 = dx*dx + dy*dy + dz*dz;
-                  const real R = radius + srad_s[o] + b.epsilon_self;
-                  const bool skip = (slink_s[o] == mylink) || (d2 > R*R);
-                  if (!skip) near |= (1ull << o);
-               }
-#endif
-#ifdef ORC_ABLATE_PASS2
-               near = 0ull;
-#endif
-               // pass 2: only the pairs in range
-               const real wself = vnorm * b.obs_factor_self;
-               while (near)
-               {
-                  const int o = __builtin_ctzll(near);
-                  near &= near - 1;
-                  const real * po = (o < Sa) ? pos_s + l*pstr + o*3 : sinact_s + (o - Sa)*3;
-                  const real ro = srad_s[o];
-                  const real d[3] = { p[0]-po[0], p[1]-po[1], p[2]-po[2] };
-                  real inv_d;
-                  real dist = sqrt_rsq(d[0]*d[0] + d[1]*d[1] + d[2]*d[2], &inv_d);
-                  dist -= radius + ro;
-                  const real de = dist - b.epsilon_self;
-                  const real cself = (dist < (real)0) ? ((real)0.5 * b.epsilon_self - dist)
-                                                      : ((real)0.5 * inv_eps_self) * de * de;
-                  cost_sphere += (double)(wself * cself);
-                  if (do_iteration)
-                  {
-                     real scale = (real)1;
-                     if (dist < (real)0) scale = (real)(-1);
-                     else if (dist < b.epsilon_self) scale = dist * inv_eps_self - (real)1;
-                     const real sd = scale * inv_d;              // x = (d/|d|) * scale * weight
-                     // my side of the pair: + J_me^T x
-                     real x[3];
-#pragma unroll
-                     for (int k=0; k<3; k++) x[k] = d[k] * (sd * wself);
-                     if (moving)
-                     {
-                        const real proj = (x[0]*vel[0] + x[1]*vel[1] + x[2]*vel[2]) * inv_vn2;
-#pragma unroll
-                        for (int k=0; k<3; k++) x[k] -= proj * vel[k];
-                     }
-#pragma unroll
-                     for (int k=0; k<3; k++) f[k] += x[k];
-                     // the other sphere's side (it is active and visits this pair too):
-                     // its term (J_o - J_me)^T x_o puts -x_o on this sphere
-                     if (o < Sa)
-                     {
-                        const real * opp = pos_s + (l-1)*pstr + o*3;
-                        const real * opn = pos_s + (l+1)*pstr + o*3;
-                        real vo[3];
-#pragma unroll
-                        for (int k=0; k<3; k++) { real v = opn[k]; v -= opp[k]; v *= b.inv_2dt; vo[k] = v; }
-                        real inv_von;
-                        const real von = sqrt_rsq(vo[0]*vo[0] + vo[1]*vo[1] + vo[2]*vo[2], &inv_von);
-                        real xo[3];
-                        const real so = -sd * (von * b.obs_factor_self);
-#pragma unroll
-                        for (int k=0; k<3; k++) xo[k] = d[k] * so;
-                        if (von > (real)0.000001)
-                        {
-                           const real proj = (xo[0]*vo[0] + xo[1]*vo[1] + xo[2]*vo[2]) * (inv_von * inv_von);
-#pragma unroll
-                           for (int k=0; k<3; k++) xo[k] -= proj * vo[k];
-                        }
-#pragma unroll
-                        for (int k=0; k<3; k++) f[k] -= xo[k];
-                     }
-                  }
-               }
-            }
-            if (live) cost_lane += cost_sphere;
-
-            // ---- J^T contraction and reduction over the spheres of a waypoint ----
-            if (do_iteration)
-            {
-               const unsigned long long aff = live ? mod.sph_affects[s] : 0ull;
-               const bool row_ok = (item < items);
-               const int gi = ts + wl;               // moving waypoint index
-#ifndef ORC_ABLATE_JT
-               if (mod.jt_scan && GS >= 32)
-               {
-                  // as in cost_gs16.h: one suffix scan of the wrench [p x f ; f] over the lanes of the
-                  // waypoint, then lane r finishes joint r from the sums over the range of spheres it moves
-                  real w6[6];
-                  w6[0] = p[1]*f[2] - p[2]*f[1];
-                  w6[1] = p[2]*f[0] - p[0]*f[2];
-                  w6[2] = p[0]*f[1] - p[1]*f[0];
-                  w6[3] = f[0]; w6[4] = f[1]; w6[5] = f[2];
-#pragma unroll
-                  for (int k=0; k<6; k++)
-                  {
-                     real v = live ? w6[k] : (real)0;
-                     if (GS == 64) v = wave_suffix_incl(v);
-                     else
-                     {
-                        // two waypoints per wavefront: suffix inside the 16-lane rows, then the upper row of each half
-                        v += dpp_move<0x101>(v); v += dpp_move<0x102>(v); v += dpp_move<0x104>(v); v += dpp_move<0x108>(v);
-                        const real t16 = read_lane(v, 16), t48 = read_lane(v, 48);
-                        const int ln = tid & 63;
-                        v += (ln < 16) ? t16 : ((ln >= 32 && ln < 48) ? t48 : (real)0);
-                     }
-                     w6[k] = v;
-                  }
-                  for (int j0=0; j0<nj; j0+=GS)
-                  {
-                     const int j = j0 + s;
-                     const bool jok = (j < nj);
-                     const DevJoint<real> & J = mod.joints[jok ? j : 0];
-                     const int ab = J.aff_begin, ae = J.aff_end;
-                     real W[6];
-#pragma unroll
-                     for (int k=0; k<6; k++)
-                     {
-                        const real hi = __shfl(w6[k], ab & (GS-1), GS);
-                        W[k] = (ab < GS) ? hi : (real)0;
-                     }
-                     if (mod.jt_scan == 2)
-                     {
-#pragma unroll
-                        for (int k=0; k<6; k++)
-                        {
-                           const real lo = __shfl(w6[k], ae & (GS-1), GS);
-                           W[k] -= (ae < GS) ? lo : (real)0;
-                        }
-                     }
-                     const real * ax = ax_s + l*astr + (jok ? j : 0)*6;
-                     const real c0 = W[0] - (ax[4]*W[5] - ax[5]*W[4]);
-                     const real c1 = W[1] - (ax[5]*W[3] - ax[3]*W[5]);
-                     const real c2 = W[2] - (ax[3]*W[4] - ax[4]*W[3]);
-                     const real crev = ax[0]*c0 + ax[1]*c1 + ax[2]*c2;
-                     const real cpri = ax[0]*W[3] + ax[1]*W[4] + ax[2]*W[5];
-                     if (jok && row_ok) G_s[gi*n + J.col] = (J.type == 1) ? crev : cpri;
-                  }
-               }
-               else
-               for (int j=0; j<nj; j++)
-               {
-                  real cg = 0;
-                  if ((aff >> j) & 1ull)
-                  {
-                     const real * ax = ax_s + l*astr + j*6;
-                     if (jtype_s[j] == 1)
-                     {
-                        const real r0 = p[0]-ax[3], r1 = p[1]-ax[4], r2 = p[2]-ax[5];
-                        const real c0 = r1*f[2] - r2*f[1];
-                        const real c1 = r2*f[0] - r0*f[2];
-                        const real c2 = r0*f[1] - r1*f[0];
-                        cg = ax[0]*c0 + ax[1]*c1 + ax[2]*c2;
-                     }
-                     else cg = ax[0]*f[0] + ax[1]*f[1] + ax[2]*f[2];
-                  }
-                  cg = group_sum(cg, GS);
-                  if (row_ok && s == 0) G_s[gi*n + jcol_s[j]] = cg;
-               }
-#endif
-               if (mod.floating)
-               {
-                  // base block: 0.01 * Jsp^T [p x f ; f] summed over all spheres
-                  // (src/orcdchomp_mod.cpp:1050-1080, src/libcd/spatial.c:295-337)
-                  real w6[6];
-                  w6[0] = p[1]*f[2] - p[2]*f[1];
-                  w6[1] = p[2]*f[0] - p[0]*f[2];
-                  w6[2] = p[0]*f[1] - p[1]*f[0];
-                  w6[3] = f[0]; w6[4] = f[1]; w6[5] = f[2];
-#pragma unroll
-                  for (int k=0; k<6; k++) w6[k] = group_sum(w6[k], GS);
-                  if (row_ok && s == 0)
-                  {
-                     const real * row = T_s + (gi+1)*n;
-                     const real x = row[0], y = row[1], z = row[2];
-                     const real qx = 2*row[3], qy = 2*row[4], qz = 2*row[5], qw = 2*row[6];
-                     real Jsp[6][7];
-#pragma unroll
-                     for (int a=0; a<6; a++)
-#pragma unroll
-                        for (int c=0; c<7; c++) Jsp[a][c] = 0;
-                     Jsp[3][0] = 1; Jsp[4][1] = 1; Jsp[5][2] = 1;
-                     Jsp[0][3] =  qw; Jsp[0][4] = -qz; Jsp[0][5] =  qy; Jsp[0][6] = -qx;
-                     Jsp[1][3] =  qz; Jsp[1][4] =  qw; Jsp[1][5] = -qx; Jsp[1][6] = -qy;
-                     Jsp[2][3] = -qy; Jsp[2][4] =  qx; Jsp[2][5] =  qw; Jsp[2][6] = -qz;
-                     Jsp[3][3] = -z*qz - y*qy; Jsp[3][4] = -z*qw + y*qx; Jsp[3][5] =  z*qx + y*qw; Jsp[3][6] =  z*qy - y*qz;
-                     Jsp[4][3] =  z*qw + x*qy; Jsp[4][4] = -z*qz - x*qx; Jsp[4][5] =  z*qy - x*qw; Jsp[4][6] = -z*qx + x*qz;
-                     Jsp[5][3] = -y*qw + x*qz; Jsp[5][4] =  y*qz + x*qw; Jsp[5][5] = -y*qy - x*qx; Jsp[5][6] =  y*qx - x*qy;
-#pragma unroll
-                     for (int c=0; c<7; c++)
-                     {
-                        real sum = 0;
-#pragma unroll
-                        for (int a=0; a<6; a++) sum += Jsp[a][c] * w6[a];
-                        G_s[gi*n + c] = (real)0.01 * sum;
-                     }
-                  }
-               }
-            }
-         }
-         }
+            cost_tile_generic<real, BLOCK>(b, mod, sdfs, ts, te, do_iteration, T_s, Gc, pos_s, ax_s, srad_s, sinact_s,
+                                           slink_s, jtype_s, jcol_s, pstr, astr, inv_eps, inv_eps_self, cost_lane,
+                                           (b.phase_cycles && tid == 0 && b.lim_generic == 2) ? gdbg : nullptr);
          __syncthreads();
          ORC_MARK(1);
       } // tiles
@@ -1205,7 +914,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
          for (int e=tid; e<mn; e+=BLOCK)
          {
             const int i = div_n(e, rn_f), c = e - i*n;
-            real g = G_s[e];
+            real g = Gc[e];
             g *= b.inv_m;
             g += smooth_grad(b, T_s, i, c);
             G_s[e] = g;
@@ -1457,11 +1166,12 @@ void chomp_iterate_kernel(const DevBatch<real> b)
 
    // ---- write back ---------------------------------------------------------
    __syncthreads();
-   for (int e=tid; e<np*n; e+=BLOCK) traj_g[e] = T_s[e];
+   if (GS16 || b.t_in_lds) for (int e=tid; e<np*n; e+=BLOCK) traj_g[e] = T_s[e];
    if (b.use_momentum && b.ag_in_lds) for (int e=tid; e<mn; e+=BLOCK) AG_g[e] = AG_s[e];
    if (tid == 0)
    {
       if (b.phase_cycles) for (int k=0; k<8; k++) b.phase_cycles[(size_t) run*8 + k] = ph[k];
+      if (b.phase_cycles && b.lim_generic == 2) for (int k=0; k<4; k++) b.phase_cycles[(size_t) run*8 + 2 + k] = gdbg[k];
       // an aborted run reports the costs of its last complete pass (none in this launch: what it had)
       if (have_costs)
       {
@@ -1620,11 +1330,11 @@ void collision_verdict_kernel(DevVerdict<real> v)
 // ---------------------------------------------------------------------------
 // host-side launch wrappers (called from module.cpp)
 size_t orc_chomp_lds_bytes(int n_points, int n, int Sa, int S, int nj, int tile_m, int pcr_rows, size_t real_size,
-   int use_momentum, int n_sdfs)
+   int use_momentum, int n_sdfs, int flags)
 {
    const int js = real_size == 8 ? (int) sizeof(DevJoint<double>) : (int) sizeof(DevJoint<float>);
    const int ss = real_size == 8 ? (int) sizeof(DevSdf<double>) : (int) sizeof(DevSdf<float>);
-   return (size_t) lds_layout(n_points, n, Sa, S, nj, tile_m, pcr_rows, (int) real_size, use_momentum, n_sdfs, js, ss).total_bytes;
+   return (size_t) lds_layout(n_points, n, Sa, S, nj, tile_m, pcr_rows, (int) real_size, use_momentum, n_sdfs, js, ss, flags).total_bytes;
 }
 
 template <typename real, bool TREE, bool GS16, int BLOCK>

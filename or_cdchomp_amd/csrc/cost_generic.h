@@ -1,0 +1,424 @@
+// cost_generic.h -- cost phase of the CHOMP iteration for robots with more than 16 active spheres.
+//
+// Included by chomp_kernel.hip.  Lane = (waypoint, sphere): GS = 32 or 64 lanes per waypoint (a
+// power of two >= the active spheres), so a wavefront holds two waypoints or one.
+//
+// Reference: sphere_cost, src/orcdchomp_mod.cpp:1134-1327 (obstacle term 1171-1246, self collision
+// 1251-1317), velocities/accelerations src/orcdchomp_mod.cpp:1099-1127.
+//
+// Self collision.  The reference visits every pair from both sides; here
+//   (1) the range test walks the ROTATIONS of the waypoint's lane group: in step K (1 .. GS/2) lane s
+//       tests the sphere K lanes on, so every pair is tested once; the pairs found travel to the
+//       other side as ballots (one scalar mask per rotation), and every lane ends up with the set of
+//       spheres it is in range of;
+//   (2) every lane then walks ITS set and evaluates, per partner, the NET force of the pair on its own
+//       sphere in one go: x_ab - x_ba = s (w_a + w_b) d - p_a v_a - p_b v_b (the reference's two
+//       visits of the pair; cost_gs16.h has the derivation).  The partner's velocity, weight and
+//       1/|v|^2 come from the partner's lane through ds_bpermute instead of being recomputed from
+//       the position buffer.  Both lanes of a pair compute it (mirrored): no scatter, no atomics,
+//       a fixed summation order.
+#pragma once
+
+template <typename real, int BLOCK>
+__device__ __forceinline__ void cost_tile_generic(const DevBatch<real> & b, const ModelView<real> & mod,
+   const DevSdf<real> * sdfs, int ts, int te, bool do_iteration, const real * T_s, real * Gc, const real * pos_s, const real * ax_s,
+   const real * srad_s, const real * sinact_s, const int * slink_s, const int * jtype_s, const int * jcol_s,
+   int pstr, int astr, real inv_eps, real inv_eps_self, double & cost_lane, long long * dbg)
+{
+   long long tm = 0;
+#define ORC_GMARK(slot) do { if (dbg) { const long long now_ = clock64(); dbg[slot] += now_ - tm; tm = now_; } } while (0)
+
+   const int tid = threadIdx.x;
+   const int Sa = mod.Sa, S = mod.S, nj = mod.nj, n = b.n, GS = mod.GS;
+   const real inf = M<real>::inf();
+   const int items = (te - ts) * GS;
+   for (int base_item=0; base_item<items; base_item+=BLOCK)
+   {
+      if (base_item + (tid & ~63) >= items) continue;      // a wavefront without a waypoint in this round (wave-uniform)
+      const int item = base_item + tid;
+      const int wl = item / GS;               // waypoint within the tile
+      const int s = item - wl*GS;             // sphere slot
+      const bool live = (item < items) && (s < Sa);
+      const int l = ((item < items) ? wl : 0) + 1;          // row of pos_s / ax_s (lanes past the tile read row 1: valid memory)
+      const int ss = live ? s : 0;
+      const int gbase = (tid & 63) & ~(GS - 1);             // first lane of this waypoint's group inside the wavefront
+      real p[3], vel[3], acc[3];
+      real f[3] = {0,0,0};                    // total workspace force on this sphere
+      double cost_sphere = 0.0;
+      const real radius = srad_s[ss];
+      const int mylink = live ? slink_s[ss] : -1 - s;
+      {
+         const real * pc = pos_s + l*pstr + ss*3;
+         const real * pp = pc - pstr;
+         const real * pn = pc + pstr;
+#pragma unroll
+         for (int k=0; k<3; k++)
+         {
+            p[k] = pc[k];
+            // src/orcdchomp_mod.cpp:1104-1106, 1120-1124
+            real v = pn[k]; v -= pp[k]; v *= b.inv_2dt; vel[k] = v;
+            real a = pc[k]; a *= (real)(-2); a += pp[k]; a += pn[k]; a *= b.inv_dt2; acc[k] = a;
+         }
+      }
+      if (dbg) tm = clock64();
+      const real vn2 = vel[0]*vel[0] + vel[1]*vel[1] + vel[2]*vel[2];
+      real inv_vn;
+      const real vnorm = sqrt_rsq(vn2, &inv_vn);
+      const real inv_vn2 = inv_vn * inv_vn;                  // only used when vnorm > 1e-6
+      const bool moving = vnorm > (real)0.000001;
+      const real wself = vnorm * b.obs_factor_self;
+
+      // ---- obstacle term (src/orcdchomp_mod.cpp:1171-1246) ----
+      {
+         real best = inf; bool has = false; real bgrad[3] = {0,0,0};
+#ifndef ORC_ABLATE_SDF
+         // the cell reads of up to four fields are issued before any is used (a field per trip would
+         // wait for its four reads, an L2 round trip, before the next field's addresses are formed)
+         for (int i0=0; i0<b.n_sdfs; i0+=4)
+         {
+            SdfCells<real> cells[4];
+            real v0[4], vn[4][3];
+#pragma unroll
+            for (int q=0; q<4; q++)
+            {
+               if (i0 + q >= b.n_sdfs) continue;                       // wave-uniform
+               const DevSdf<real> & F = sdfs[i0 + q];
+               real gp[3];
+#pragma unroll
+               for (int k=0; k<3; k++)
+                  gp[k] = F.Rgw[k*3+0]*p[0] + F.Rgw[k*3+1]*p[1] + F.Rgw[k*3+2]*p[2] + F.tgw[k];
+               cells[q] = sdf_cells(F, gp);
+               v0[q] = F.data[cells[q].index];
+#pragma unroll
+               for (int k=0; k<3; k++) vn[q][k] = F.data[cells[q].nidx[k]];
+            }
+#pragma unroll
+            for (int q=0; q<4; q++)
+            {
+               if (i0 + q >= b.n_sdfs) continue;
+               const DevSdf<real> & F = sdfs[i0 + q];
+               real gg[3], val;
+               sdf_combine(F, cells[q], v0[q], vn[q], val, gg);
+               const bool better = cells[q].inb && (val < best);       // strict <: HUGE_VAL never wins
+               best = better ? val : best;
+               has = has || better;
+#pragma unroll
+               for (int k=0; k<3; k++)
+               {
+                  const real gw = F.Rwg[k*3+0]*gg[0] + F.Rwg[k*3+1]*gg[1] + F.Rwg[k*3+2]*gg[2];      // grid -> world
+                  bgrad[k] = better ? gw : bgrad[k];
+               }
+            }
+         }
+#endif
+         const bool on = live && has;
+         const real dist = best - radius;
+         const real de = dist - b.epsilon;
+         real cs = (dist < (real)0) ? ((real)0.5 * b.epsilon - dist)
+                 : ((dist < b.epsilon) ? ((real)0.5 * inv_eps) * de * de : (real)0);
+         cs *= vnorm * b.obs_factor;
+         cs = on ? cs : (real)0;
+         cost_sphere += (double) cs;
+         const real scale = (dist < (real)0) ? (real)(-1) : ((dist < b.epsilon) ? dist * inv_eps - (real)1 : (real)0);
+         const real sc2 = scale * (vnorm * b.obs_factor);
+         real xg[3], xc[3];
+#pragma unroll
+         for (int k=0; k<3; k++) { xg[k] = (scale == (real)0) ? (real)0 : bgrad[k] * sc2; xc[k] = acc[k]; }
+         const real pg = moving ? (xg[0]*vel[0] + xg[1]*vel[1] + xg[2]*vel[2]) * inv_vn2 : (real)0;
+         const real pc2 = moving ? (xc[0]*vel[0] + xc[1]*vel[1] + xc[2]*vel[2]) * inv_vn2 : (real)0;
+         // x_grad -= cost * curvature, curvature = xc/|v|^2; then c_grad += |v| J^T x_grad.  |v| == 0:
+         // the reference's dgemv(alpha=0) leaves c_grad untouched, so the sphere is skipped
+         const real cw = cs * inv_vn2;
+         const bool push = on && do_iteration && (vnorm != (real)0);
+#pragma unroll
+         for (int k=0; k<3; k++)
+         {
+            const real val = vnorm * ((xg[k] - pg * vel[k]) - cw * (xc[k] - pc2 * vel[k]));
+            f[k] = push ? val : (real)0;
+         }
+      }
+
+      ORC_GMARK(0);
+      // ---- self collision (src/orcdchomp_mod.cpp:1251-1317) ----
+      // inactive spheres have no lane: only this lane's side of the pair
+      for (int o=Sa; o<S; o++)
+      {
+         const real * po = sinact_s + (o - Sa)*3;
+         const real ro = srad_s[o];
+         const real R = radius + ro + b.epsilon_self;
+         const real d[3] = { p[0]-po[0], p[1]-po[1], p[2]-po[2] };
+         const real d2 = d[0]*d[0] + d[1]*d[1] + d[2]*d[2];
+         const bool near = live && (slink_s[o] != mylink) && !(d2 > R*R);
+         if (__ballot(near) == 0ull) continue;
+         real inv_d;
+         real dist = sqrt_rsq(near ? d2 : (real)1, &inv_d);
+         dist -= radius + ro;
+         const real de = dist - b.epsilon_self;
+         const real cself = (dist < (real)0) ? ((real)0.5 * b.epsilon_self - dist) : ((real)0.5 * inv_eps_self) * de * de;
+         cost_sphere += near ? (double)(wself * cself) : 0.0;
+         const real scale = (dist < (real)0) ? (real)(-1) : ((dist < b.epsilon_self) ? dist * inv_eps_self - (real)1 : (real)1);
+         const real sd = scale * inv_d * wself;
+         real xx[3];
+#pragma unroll
+         for (int k=0; k<3; k++) xx[k] = d[k] * sd;
+         const real proj = moving ? (xx[0]*vel[0] + xx[1]*vel[1] + xx[2]*vel[2]) * inv_vn2 : (real)0;
+#pragma unroll
+         for (int k=0; k<3; k++) f[k] += (near && do_iteration) ? (xx[k] - proj * vel[k]) : (real)0;
+      }
+      // (1) which active spheres this lane's sphere is in range of: bit o of `near`
+      unsigned long long near = 0ull;
+#ifndef ORC_ABLATE_PASS1
+      if (GS == 64)
+      {
+         // one waypoint per wavefront: the partner's centre, radius and link come round by the
+         // wavefront rotation of the DPP unit (wave_rol:1, lane i takes lane i+1; K applications bring
+         // sphere s+K), no LDS access and no address arithmetic in the loop
+         // Two chains: one starts here, the other 16 lanes on (one ds_bpermute per value), so step K
+         // tests the spheres K and K + 16 lanes away and the two dependent DPP chains overlap.
+         const real reps = radius + b.epsilon_self;
+         real rp[2][3], rrad[2]; int rlink[2];
+         const int lane16 = ((tid & 63) + 16) & 63;
+#pragma unroll
+         for (int k=0; k<3; k++) { rp[0][k] = p[k]; rp[1][k] = __shfl(p[k], lane16, 64); }
+         rrad[0] = radius; rrad[1] = __shfl(radius, lane16, 64);
+         rlink[0] = live ? mylink : -1;                                   // -1: a lane without a sphere (never a link index)
+         rlink[1] = __shfl(rlink[0], lane16, 64);
+         for (int K=1; K<=16; K++)
+         {
+            bool hit[2]; unsigned long long bal[2];
+#pragma unroll
+            for (int c=0; c<2; c++)
+            {
+#pragma unroll
+               for (int k=0; k<3; k++) rp[c][k] = dpp_move<0x134>(rp[c][k]);
+               rrad[c] = dpp_move<0x134>(rrad[c]);
+               rlink[c] = dpp_move<0x134>(rlink[c]);
+               const real dx = p[0]-rp[c][0], dy = p[1]-rp[c][1], dz = p[2]-rp[c][2];
+               const real d2 = dx*dx + dy*dy + dz*dz;
+               const real R = reps + rrad[c];
+               hit[c] = live && (rlink[c] >= 0) && (rlink[c] != mylink) && !(d2 > R*R);
+            }
+            bal[0] = __ballot(hit[0]); bal[1] = __ballot(hit[1]);          // scalar: the pairs of these two rotations
+#pragma unroll
+            for (int c=0; c<2; c++)
+            {
+               if (bal[c] == 0ull) continue;
+               const int KK = K + 16*c;
+               const int backs = (s - KK) & 63;                            // this lane is the partner of the lane KK back
+               const bool hit_back = ((bal[c] >> backs) & 1ull) != 0ull;
+               near |= hit[c] ? (1ull << ((s + KK) & 63)) : 0ull;
+               near |= hit_back ? (1ull << backs) : 0ull;
+            }
+         }
+      }
+      else
+      {
+         const real * prow = pos_s + l*pstr;
+         const real reps = radius + b.epsilon_self;
+         // four rotations per trip: their LDS reads are issued together (one rotation per trip pays the
+         // full read latency each time)
+         for (int K0=1; K0<=GS/2; K0+=4)
+         {
+            bool hit[4]; unsigned long long bal[4];
+#pragma unroll
+            for (int q=0; q<4; q++)
+            {
+               const int K = K0 + q;
+               const int o = (s + K) & (GS - 1);
+               const int oo = (o < Sa) ? o : 0;
+               const real * po = prow + oo*3;
+               const real dx = p[0]-po[0], dy = p[1]-po[1], dz = p[2]-po[2];
+               const real d2 = dx*dx + dy*dy + dz*dz;
+               const real R = reps + srad_s[oo];
+               hit[q] = live && (K <= GS/2) && (o < Sa) && (slink_s[oo] != mylink) && !(d2 > R*R);
+            }
+#pragma unroll
+            for (int q=0; q<4; q++) bal[q] = __ballot(hit[q]);          // scalar: the pairs of this rotation
+#pragma unroll
+            for (int q=0; q<4; q++)
+            {
+               if (bal[q] == 0ull) continue;
+               const int K = K0 + q;
+               // the other side of the pairs: lane s is the partner of the lane K back in its group
+               const int backs = (s - K) & (GS - 1);
+               const bool hit_back = ((bal[q] >> (gbase + backs)) & 1ull) != 0ull;
+               near |= hit[q] ? (1ull << ((s + K) & (GS - 1))) : 0ull;
+               near |= hit_back ? (1ull << backs) : 0ull;
+            }
+         }
+      }
+#endif
+#ifdef ORC_ABLATE_PASS2
+      near = 0ull;
+#endif
+      ORC_GMARK(1);
+      // (2) the net force of every pair in the set on this lane's sphere
+      const int mflag = moving ? 1 : 0;
+      while (__ballot(near != 0ull) != 0ull)
+      {
+         const bool act = near != 0ull;
+         const int o = act ? __builtin_ctzll(near) : ss;                // (lanes that are done look at themselves: valid memory, masked)
+         near &= near - 1ull;
+         const int src = gbase + o;                                     // the partner's lane
+         real vo[3];
+#pragma unroll
+         for (int k=0; k<3; k++) vo[k] = __shfl(vel[k], src, 64);
+         const real wo = __shfl(wself, src, 64);
+         const real ivo = __shfl(inv_vn2, src, 64);
+         const bool mo = __shfl(mflag, src, 64) != 0;
+         const real * po = pos_s + l*pstr + o*3;
+         const real ro = srad_s[o];
+         const real d[3] = { p[0]-po[0], p[1]-po[1], p[2]-po[2] };
+         const real d2 = d[0]*d[0] + d[1]*d[1] + d[2]*d[2];
+         real inv_d;
+         real dist = sqrt_rsq(act ? d2 : (real)1, &inv_d);
+         dist -= radius + ro;
+         const real de = dist - b.epsilon_self;
+         const real cself = (dist < (real)0) ? ((real)0.5 * b.epsilon_self - dist) : ((real)0.5 * inv_eps_self) * de * de;
+         cost_sphere += act ? (double)(wself * cself) : 0.0;             // this sphere's visit of the pair; the partner adds its own
+         if (do_iteration)
+         {
+            const real scale = (dist < (real)0) ? (real)(-1) : ((dist < b.epsilon_self) ? dist * inv_eps_self - (real)1 : (real)1);
+            const real sdi = scale * inv_d;
+            real pa = d[0]*vel[0] + d[1]*vel[1] + d[2]*vel[2];
+            real pb = d[0]*vo[0] + d[1]*vo[1] + d[2]*vo[2];
+            pa = moving ? pa * (sdi * wself) * inv_vn2 : (real)0;
+            pb = mo ? pb * (sdi * wo) * ivo : (real)0;
+            const real sboth = sdi * (wself + wo);
+#pragma unroll
+            for (int k=0; k<3; k++)
+            {
+               const real inc = d[k] * sboth - (pa * vel[k] + pb * vo[k]);
+               f[k] += act ? inc : (real)0;
+            }
+         }
+      }
+      ORC_GMARK(2);
+      if (live) cost_lane += cost_sphere;
+
+      // ---- J^T contraction and reduction over the spheres of a waypoint ----
+      if (do_iteration)
+      {
+         const unsigned long long aff = live ? mod.sph_affects[ss] : 0ull;
+         const bool row_ok = (item < items);
+         const int gi = ts + wl;               // moving waypoint index
+#ifndef ORC_ABLATE_JT
+         if (mod.jt_scan && GS >= 32)
+         {
+            // as in cost_gs16.h: one suffix scan of the wrench [p x f ; f] over the lanes of the
+            // waypoint, then lane r finishes joint r from the sums over the range of spheres it moves
+            real w6[6];
+            w6[0] = p[1]*f[2] - p[2]*f[1];
+            w6[1] = p[2]*f[0] - p[0]*f[2];
+            w6[2] = p[0]*f[1] - p[1]*f[0];
+            w6[3] = f[0]; w6[4] = f[1]; w6[5] = f[2];
+#pragma unroll
+            for (int k=0; k<6; k++)
+            {
+               real v = live ? w6[k] : (real)0;
+               if (GS == 64) v = wave_suffix_incl(v);
+               else
+               {
+                  // two waypoints per wavefront: suffix inside the 16-lane rows, then the upper row of each half
+                  v += dpp_move<0x101>(v); v += dpp_move<0x102>(v); v += dpp_move<0x104>(v); v += dpp_move<0x108>(v);
+                  const real t16 = read_lane(v, 16), t48 = read_lane(v, 48);
+                  const int ln = tid & 63;
+                  v += (ln < 16) ? t16 : ((ln >= 32 && ln < 48) ? t48 : (real)0);
+               }
+               w6[k] = v;
+            }
+            for (int j0=0; j0<nj; j0+=GS)
+            {
+               const int j = j0 + s;
+               const bool jok = (j < nj);
+               const DevJoint<real> & J = mod.joints[jok ? j : 0];
+               const int ab = J.aff_begin, ae = J.aff_end;
+               real W[6];
+#pragma unroll
+               for (int k=0; k<6; k++)
+               {
+                  const real hi = __shfl(w6[k], ab & (GS-1), GS);
+                  W[k] = (ab < GS) ? hi : (real)0;
+               }
+               if (mod.jt_scan == 2)
+               {
+#pragma unroll
+                  for (int k=0; k<6; k++)
+                  {
+                     const real lo = __shfl(w6[k], ae & (GS-1), GS);
+                     W[k] -= (ae < GS) ? lo : (real)0;
+                  }
+               }
+               const real * ax = ax_s + l*astr + (jok ? j : 0)*6;
+               const real c0 = W[0] - (ax[4]*W[5] - ax[5]*W[4]);
+               const real c1 = W[1] - (ax[5]*W[3] - ax[3]*W[5]);
+               const real c2 = W[2] - (ax[3]*W[4] - ax[4]*W[3]);
+               const real crev = ax[0]*c0 + ax[1]*c1 + ax[2]*c2;
+               const real cpri = ax[0]*W[3] + ax[1]*W[4] + ax[2]*W[5];
+               if (jok && row_ok) Gc[gi*n + J.col] = (J.type == 1) ? crev : cpri;
+            }
+         }
+         else
+         for (int j=0; j<nj; j++)
+         {
+            real cg = 0;
+            if ((aff >> j) & 1ull)
+            {
+               const real * ax = ax_s + l*astr + j*6;
+               if (jtype_s[j] == 1)
+               {
+                  const real r0 = p[0]-ax[3], r1 = p[1]-ax[4], r2 = p[2]-ax[5];
+                  const real c0 = r1*f[2] - r2*f[1];
+                  const real c1 = r2*f[0] - r0*f[2];
+                  const real c2 = r0*f[1] - r1*f[0];
+                  cg = ax[0]*c0 + ax[1]*c1 + ax[2]*c2;
+               }
+               else cg = ax[0]*f[0] + ax[1]*f[1] + ax[2]*f[2];
+            }
+            cg = group_sum(cg, GS);
+            if (row_ok && s == 0) Gc[gi*n + jcol_s[j]] = cg;
+         }
+#endif
+         if (mod.floating)
+         {
+            // base block: 0.01 * Jsp^T [p x f ; f] summed over all spheres
+            // (src/orcdchomp_mod.cpp:1050-1080, src/libcd/spatial.c:295-337)
+            real w6[6];
+            w6[0] = p[1]*f[2] - p[2]*f[1];
+            w6[1] = p[2]*f[0] - p[0]*f[2];
+            w6[2] = p[0]*f[1] - p[1]*f[0];
+            w6[3] = f[0]; w6[4] = f[1]; w6[5] = f[2];
+#pragma unroll
+            for (int k=0; k<6; k++) w6[k] = group_sum(live ? w6[k] : (real)0, GS);
+            if (row_ok && s == 0)
+            {
+               const real * row = T_s + (gi+1)*n;
+               const real x = row[0], y = row[1], z = row[2];
+               const real qx = 2*row[3], qy = 2*row[4], qz = 2*row[5], qw = 2*row[6];
+               real Jsp[6][7];
+#pragma unroll
+               for (int a=0; a<6; a++)
+#pragma unroll
+                  for (int c=0; c<7; c++) Jsp[a][c] = 0;
+               Jsp[3][0] = 1; Jsp[4][1] = 1; Jsp[5][2] = 1;
+               Jsp[0][3] =  qw; Jsp[0][4] = -qz; Jsp[0][5] =  qy; Jsp[0][6] = -qx;
+               Jsp[1][3] =  qz; Jsp[1][4] =  qw; Jsp[1][5] = -qx; Jsp[1][6] = -qy;
+               Jsp[2][3] = -qy; Jsp[2][4] =  qx; Jsp[2][5] =  qw; Jsp[2][6] = -qz;
+               Jsp[3][3] = -z*qz - y*qy; Jsp[3][4] = -z*qw + y*qx; Jsp[3][5] =  z*qx + y*qw; Jsp[3][6] =  z*qy - y*qz;
+               Jsp[4][3] =  z*qw + x*qy; Jsp[4][4] = -z*qz - x*qx; Jsp[4][5] =  z*qy - x*qw; Jsp[4][6] = -z*qx + x*qz;
+               Jsp[5][3] = -y*qw + x*qz; Jsp[5][4] =  y*qz + x*qw; Jsp[5][5] = -y*qy - x*qx; Jsp[5][6] =  y*qx - x*qy;
+#pragma unroll
+               for (int c=0; c<7; c++)
+               {
+                  real sum = 0;
+#pragma unroll
+                  for (int a=0; a<6; a++) sum += Jsp[a][c] * w6[a];
+                  Gc[gi*n + c] = (real)0.01 * sum;
+               }
+            }
+         }
+      }
+      ORC_GMARK(3);
+   }
+#undef ORC_GMARK
+}

@@ -56,6 +56,59 @@ __device__ __forceinline__ bool sdf_lookup_pred(const DevSdf<real> & f, const re
    return inb;
 }
 
+// The same lookup in two halves, so that the cell reads of several fields are in flight together:
+// sdf_cells() finds the four cells, sdf_combine() forms value and gradient from their contents.
+template <typename real>
+struct SdfCells { int index, nidx[3]; real off[3]; bool prev[3]; bool inb; };
+
+template <typename real>
+__device__ __forceinline__ SdfCells<real> sdf_cells(const DevSdf<real> & f, const real p[3])
+{
+   SdfCells<real> c;
+   int sub[3];
+   bool inb = true;
+#pragma unroll
+   for (int d=0; d<3; d++)
+   {
+      const real x = p[d] * f.inv_length[d];
+      inb = inb && !(x < (real)0) && !(x > (real)1);
+      int sb = (int) M<real>::floor_(x * (real) f.size[d]);
+      sb = sb < 0 ? 0 : sb;
+      sb = sb > f.size[d]-1 ? f.size[d]-1 : sb;
+      sub[d] = inb ? sb : 0;
+   }
+   const int stride[3] = { f.size[1] * f.size[2], f.size[2], 1 };
+   c.index = sub[0]*stride[0] + sub[1]*stride[1] + sub[2];
+#pragma unroll
+   for (int d=0; d<3; d++)
+   {
+      const real center = ((real)0.5 + (real) sub[d]) * f.cell[d];
+      c.prev[d] = (sub[d] == 0) ? false : ((sub[d] == f.size[d]-1) ? true : (p[d] < center));
+      c.nidx[d] = c.prev[d] ? c.index - stride[d] : c.index + stride[d];
+      c.off[d] = p[d] - center;
+   }
+   c.inb = inb;
+   return c;
+}
+
+template <typename real>
+__device__ __forceinline__ void sdf_combine(const DevSdf<real> & f, const SdfCells<real> & c, real v0, const real vn[3], real & value, real grad[3])
+{
+   const real inf = M<real>::inf();
+   real v = v0;
+   bool poisoned = (v0 == inf);
+#pragma unroll
+   for (int d=2; d>=0; d--)                     // the reference walks the axes z, y, x
+   {
+      poisoned = poisoned || (vn[d] == inf);
+      const real diff = c.prev[d] ? (v0 - vn[d]) : (vn[d] - v0);      // after - before
+      const real slope = diff * f.size_over_len[d];
+      grad[d] = slope;
+      v += slope * c.off[d];
+   }
+   value = poisoned ? inf : v;
+}
+
 // One SYMMETRIC rotation step K (1..8) of the self-collision term (src/orcdchomp_mod.cpp:1251-1317).
 // A pair of spheres {a, b} is visited twice by the reference, once from each side.  Here lane a
 // looks at the sphere K lanes away in its 16-lane row, evaluates the shared part once (distance,

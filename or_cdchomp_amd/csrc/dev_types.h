@@ -96,6 +96,7 @@ struct DevBatch
    real * traj;            // [n_runs][n_points][n]
    real * AG;              // [n_runs][m][n]   (A^-1 G, doubles as momentum)
    real * Gdbg;            // [n_runs][m][n] or null: last gradient, for tests
+   real * Gcost;           // [n_runs][m][n]: where the cost phase puts its gradient rows when !g_in_lds
    double * costs;         // [n_runs][3] total, obs, smooth
    double * trace;         // [n_runs][n_iter][3] or null
    int * status;           // [n_runs] of this launch: 0, or -1 "outside of joint limits"
@@ -126,6 +127,9 @@ struct DevBatch
    long long * phase_cycles; // [n_runs][8] or null: diagnostics (cycles per phase, wave 0)
    real a_diag, a_off;     // D == 1: A = tridiag(a_off, a_diag, a_off), B couples the end rows with a_off
    int pcr_in_lds;         // the cyclic-reduction tables are staged in LDS
+   int t_in_lds;           // the trajectory lives in LDS for the launch (else it is iterated in place in global memory)
+   int g_in_lds;           // the cost phase writes its gradient rows to LDS (else to Gcost; the update phase stages them)
+   int lds_flags;          // ORC_LDS_* flags of the layout
    int ag_in_lds;          // the momentum AG lives in LDS for the launch (else it is updated in place in global memory)
    int pcr_sym;            // compact tables: pcr[l][m] (towards i-s; towards i+s is the mirrored entry), then [m] inverse diagonal
    int pcr_rows;           // rows of m entries in the table
@@ -183,8 +187,14 @@ struct ModelView
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
+// flags: ORC_LDS_SMALL_WORK the solve works in place (closed-form scan solve): the work buffer only
+// holds the sparse joint-limit lists; ORC_LDS_G_GLOBAL the gradient rows of the cost phase go to
+// global memory and the update phase keeps G in the (then dead) tile buffers
+#define ORC_LDS_SMALL_WORK 1
+#define ORC_LDS_G_GLOBAL   2
+#define ORC_LDS_T_GLOBAL   4      // the trajectory stays in global memory (updated in place through L2): generic cost path only
 inline LdsLayout lds_layout(int np, int n, int Sa, int S, int nj, int tile_m, int pcr_rows, int real_size,
-   int use_ag, int n_sdfs, int joint_size, int sdf_size)
+   int use_ag, int n_sdfs, int joint_size, int sdf_size, int flags)
 {
    const int m = np - 2, mn = m*n;
    LdsLayout L;
@@ -194,17 +204,20 @@ inline LdsLayout lds_layout(int np, int n, int Sa, int S, int nj, int tile_m, in
    L.astr = (nj*6) | 1;
    // the work buffer of the update phase (solve ping-pong, joint-limit scratch) lives in the tile
    // buffers pos/ax, which are dead by then, when they are large enough
-   const int lim_reals = (ORC_LIM_SCRATCH + real_size - 1) / real_size;
-   const int work_reals = ((mn > 1280/real_size ? mn : 1280/real_size) + 3) & ~3;
+   const int lim_reals = ((ORC_LIM_SCRATCH + real_size - 1) / real_size + 3) & ~3;
+   const int work_min = 1280/real_size;
+   const int work_reals = ((((flags & ORC_LDS_SMALL_WORK) || mn <= work_min) ? work_min : mn) + 3) & ~3;
    const int tile_reals = (((tile_m+2)*L.pstr + 3) & ~3) + (((tile_m+2)*L.astr + 3) & ~3);
-   const bool alias = tile_reals >= work_reals + lim_reals;
-   L.T = take(np*n);
-   L.G = take(mn);
+   const bool g_global = (flags & ORC_LDS_G_GLOBAL) != 0;
+   const bool alias = tile_reals >= work_reals + lim_reals + (g_global ? ((mn + 3) & ~3) : 0);
+   L.T = (flags & ORC_LDS_T_GLOBAL) ? 0 : take(np*n);
+   L.G = g_global ? 0 : take(mn);
    L.W = alias ? 0 : take(work_reals);
    L.AG = take(use_ag ? mn : 0);
    L.pos = take((tile_m+2)*L.pstr);
    L.ax = take((tile_m+2)*L.astr);
    if (alias) L.W = L.pos;
+   if (g_global) L.G = L.pos + work_reals + lim_reals;      // (only valid when alias: checked below)
    L.srad = take(S);
    L.sinact = take((S-Sa)*3 + 1);
    L.jl = take(2*n);
@@ -220,6 +233,6 @@ inline LdsLayout lds_layout(int np, int n, int Sa, int S, int nj, int tile_m, in
    L.saff_bytes = bytes;   bytes += Sa * 8;
    if (alias) L.lim_bytes = 128 + (L.pos + work_reals) * real_size;
    else { L.lim_bytes = bytes; bytes += ORC_LIM_SCRATCH; }
-   L.total_bytes = bytes;
+   L.total_bytes = (g_global && !alias) ? (1 << 30) : bytes;      // G in the tile buffers needs tiles that hold it
    return L;
 }

@@ -142,7 +142,7 @@ private:
    Metric metric_;
    // device buffers (typed by params.precision)
    void * d_model_ = nullptr; void * d_sdfs_ = nullptr;
-   void * d_traj_ = nullptr; void * d_AG_ = nullptr; void * d_G_ = nullptr;
+   void * d_traj_ = nullptr; void * d_AG_ = nullptr; void * d_G_ = nullptr; void * d_Gcost_ = nullptr;
    double * d_costs_ = nullptr; double * d_trace_ = nullptr; size_t trace_cap_ = 0;
    int * d_status_ = nullptr; int * d_iters_done_ = nullptr; int * d_leap_ = nullptr; long long * d_phase_ = nullptr;
    void * d_Aband_ = nullptr; void * d_beta_s_ = nullptr; void * d_beta_g_ = nullptr;
@@ -157,7 +157,7 @@ private:
    int block_ = 256;                  // threads per workgroup of the iterate kernel (256 or 192)
    int pcr_in_lds_ = 0;
    int tree_ = 0;
-   int pcr_rows_ = 0, pcr_sym_ = 0, solve_mode_ = 0, ag_in_lds_ = 1, GS_ = 0;
+   int pcr_rows_ = 0, pcr_sym_ = 0, solve_mode_ = 0, ag_in_lds_ = 1, g_in_lds_ = 1, t_in_lds_ = 1, lds_flags_ = 0, GS_ = 0;
    size_t lds_bytes_ = 0;
    std::vector<double> jl_lo_, jl_hi_;
    // hmc host state per run (src/orcdchomp_mod.cpp:948-952)
