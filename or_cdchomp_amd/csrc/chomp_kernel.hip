@@ -29,6 +29,15 @@
 // the SDF build stays bit-identical to the reference; the kernels are held to a tolerance)
 #pragma clang fp contract(fast)
 
+// NS1 ceiling experiment (scripts/ns1_ceiling.sh): with ORC_ABLATE_SDFLDS the four cell reads of a
+// lookup go to LDS (the tile's position buffer stands in for a staged field: wrong values, the same
+// instruction stream), which bounds from above what ANY LDS staging of the field could gain
+#ifdef ORC_ABLATE_SDFLDS
+#define ORC_SDF_IDX(i) ((i) & 1023)
+#else
+#define ORC_SDF_IDX(i) (i)
+#endif
+
 namespace {
 
 template <typename real> struct M;
@@ -203,7 +212,7 @@ __device__ __forceinline__ int sdf_lookup(const DevSdf<real> & f, const real p[3
    }
    const int stride[3] = { f.size[1] * f.size[2], f.size[2], 1 };
    const int index = sub[0]*stride[0] + sub[1]*stride[1] + sub[2];
-   const real v0 = f.data[index];
+   const real v0 = f.data[ORC_SDF_IDX(index)];
    real va[3], vb[3], center[3];
 #pragma unroll
    for (int d=0; d<3; d++)
@@ -213,7 +222,7 @@ __device__ __forceinline__ int sdf_lookup(const DevSdf<real> & f, const real p[3
       if (sub[d] == 0) prev = false;
       else if (sub[d] == f.size[d]-1) prev = true;
       else prev = (p[d] < center[d]);
-      const real vn = f.data[prev ? index - stride[d] : index + stride[d]];
+      const real vn = f.data[ORC_SDF_IDX(prev ? index - stride[d] : index + stride[d])];
       va[d] = prev ? v0 : vn;      // "after"
       vb[d] = prev ? vn : v0;      // "before"
    }
@@ -797,6 +806,10 @@ void chomp_iterate_kernel(const DevBatch<real> b)
       const int * src2 = (const int *) b.sdfs; int * dst2 = (int *) sdfs_s;
       for (int e=tid; e<b.n_sdfs*(int)(sizeof(DevSdf<real>)/4); e+=BLOCK) dst2[e] = src2[e];
    }
+#ifdef ORC_ABLATE_SDFLDS
+   __syncthreads();
+   if (tid < b.n_sdfs) sdfs_s[tid].data = pos_s;
+#endif
    for (int e=tid; e<n; e+=BLOCK) { jl_s[e] = b.jl_lo[e]; jl_s[n+e] = b.jl_hi[e]; }
    if (b.pcr_in_lds)
       for (int e=tid; e<b.pcr_rows*m; e+=BLOCK) pcr_s[e] = b.pcr[e];

@@ -88,9 +88,9 @@ __device__ __forceinline__ void cost_tile_generic(const DevBatch<real> & b, cons
                for (int k=0; k<3; k++)
                   gp[k] = F.Rgw[k*3+0]*p[0] + F.Rgw[k*3+1]*p[1] + F.Rgw[k*3+2]*p[2] + F.tgw[k];
                cells[q] = sdf_cells(F, gp);
-               v0[q] = F.data[cells[q].index];
+               v0[q] = F.data[ORC_SDF_IDX(cells[q].index)];
 #pragma unroll
-               for (int k=0; k<3; k++) vn[q][k] = F.data[cells[q].nidx[k]];
+               for (int k=0; k<3; k++) vn[q][k] = F.data[ORC_SDF_IDX(cells[q].nidx[k])];
             }
 #pragma unroll
             for (int q=0; q<4; q++)

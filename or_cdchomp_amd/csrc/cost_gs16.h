@@ -37,8 +37,8 @@ __device__ __forceinline__ bool sdf_lookup_pred(const DevSdf<real> & f, const re
       prev[d] = (sub[d] == 0) ? false : ((sub[d] == f.size[d]-1) ? true : (p[d] < center[d]));
       nidx[d] = prev[d] ? index - stride[d] : index + stride[d];
    }
-   const real v0 = f.data[index];
-   const real vn0 = f.data[nidx[0]], vn1 = f.data[nidx[1]], vn2 = f.data[nidx[2]];
+   const real v0 = f.data[ORC_SDF_IDX(index)];
+   const real vn0 = f.data[ORC_SDF_IDX(nidx[0])], vn1 = f.data[ORC_SDF_IDX(nidx[1])], vn2 = f.data[ORC_SDF_IDX(nidx[2])];
    const real vn[3] = { vn0, vn1, vn2 };
    const real inf = M<real>::inf();
    real v = v0;

@@ -14,7 +14,7 @@ if which == 4:
     bid = mod.batch_create(model.name, goals, basegoals=basegoals, seeds=seeds, **kw)
 else:
     model = common.setup_product_tree30(mod)
-    bid = mod.batch_create(model.name, common.config5_goals(n_runs), precision=int(os.environ.get("PRECISION", "32")), **common.CONFIG5_KW)
+    bid = mod.batch_create(model.name, common.config5_goals(n_runs), precision=int(os.environ.get("PRECISION", "32")), **dict(common.CONFIG5_KW, obs_factor=float(os.environ.get('OBS_FACTOR', '100.0'))))
 mod.kernel_time(reset=True)
 t0 = time.time(); costs, status = mod.batch_iterate(bid, n_iter); t1 = time.time()
 ms, n = mod.kernel_time()
@@ -31,3 +31,6 @@ q = np.percentile(tot, [0, 10, 50, 90, 99, 100]) / 1e6
 print("per-WG total Mcycles: min %.1f p10 %.1f median %.1f p90 %.1f p99 %.1f max %.1f" % tuple(q))
 rounds = out[:, 6]
 print("limit rounds per run: mean %.0f median %.0f p90 %.0f p99 %.0f max %.0f" % (rounds.mean(), np.median(rounds), np.percentile(rounds, 90), np.percentile(rounds, 99), rounds.max()))
+pk = out[:, 7].astype(np.int64)
+fast = pk & 0xFFFFF; scan = (pk >> 20) & 0xFFFFF; old = pk >> 40
+print("joint-limit round kinds over all runs: closed form (<= 2 violated entries) %d, scans on register columns %d, general loop (>= 4 columns) %d" % (fast.sum(), scan.sum(), old.sum()))

@@ -10,7 +10,7 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 mod = or_cdchomp_amd.Module(0)
 model = common.setup_product_wam(mod)
 mod.set_num_streams(int(os.environ.get('NSTREAMS', '0')))
-kw = dict(n_points=100, lambda_=100.0, obs_factor=500.0)
+kw = dict(n_points=100, lambda_=100.0, obs_factor=float(os.environ.get('OBS_FACTOR', '500.0')))
 tag = " ".join("%s=%s" % (k, v) for k, v in sorted(os.environ.items()) if k.startswith("ORC_") or k == "NSTREAMS")
 for n_runs in sizes:
     r = reps if n_runs <= 4096 else max(2, reps // 3)
