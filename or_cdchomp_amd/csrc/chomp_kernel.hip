@@ -381,8 +381,8 @@ __device__ __forceinline__ real * toeplitz_scan_solve(const DevBatch<real> & b, 
 }
 
 // one column of toeplitz_scan_solve, by the calling wavefront: buf[:, c] <- A^-1 buf[:, c]
-template <typename real>
-__device__ __forceinline__ void toeplitz_scan_column(real * buf, int m, int n, int c, int rpl, real kinv)
+template <typename real, typename PT>
+__device__ __forceinline__ void toeplitz_scan_column(PT buf, int m, int n, int c, int rpl, real kinv)
 {
    const int lane = threadIdx.x & 63;
    real g[ORC_SCAN_RPL], wp[ORC_SCAN_RPL], wq[ORC_SCAN_RPL];
@@ -420,13 +420,11 @@ __device__ __forceinline__ void toeplitz_scan_column(real * buf, int m, int n, i
 // to the first row-major index) -> GA = A^-1 Gjlimit by the scan solve, only for the columns that
 // have a violation -> T += 1.01 Gjlimit[l]/GA[l] * GA on those columns.
 // Returns the number of rounds made (1000: the caller sets the status).
-template <typename real>
-__device__ __forceinline__ int limit_rounds_wave(const DevBatch<real> & b, real * T_s, real * G_s, const real * jl_s, int m, int n,
-   long long * dbg_total)
+template <typename real, typename PT, typename PG, typename PJ>
+__device__ __forceinline__ int limit_rounds_wave(PT T_s, PG G_s, PJ jl_s, int m, int n, real kinv, long long * dbg_total)
 {
    const int lane = threadIdx.x & 63;
    const int rpl = (m + 63) >> 6;
-   const real kinv = (real)(-1) / ((real)(m + 1) * b.a_off);      // 1/((m+1) ca), ca = -a_off
    const float rn = 1.0f / (float) n;
    const int mn = m*n;
    int rounds;
@@ -487,7 +485,7 @@ __device__ __forceinline__ int limit_rounds_wave(const DevBatch<real> & b, real 
       const real gl = G_s[ge];                        // Gjlimit[largest]
       if (dbg_total) *dbg_total += __popcll(cols);
       for (int c=0; c<n; c++)
-         if ((cols >> c) & 1ull) toeplitz_scan_column(G_s, m, n, c, rpl, kinv);
+         if ((cols >> c) & 1ull) toeplitz_scan_column<real>(G_s, m, n, c, rpl, kinv);
       const real sc = ((real)1.01 * gl) * rcp_fast(G_s[gi*n + gc]);
       for (int c=0; c<n; c++)
          if ((cols >> c) & 1ull)
@@ -512,8 +510,8 @@ __device__ __forceinline__ int limit_rounds_wave(const DevBatch<real> & b, real 
 // closed-form A^-1 by one prefix and one suffix wave scan per column -> T += 1.01 Gjl[l]/GA[l] GA,
 // without a single LDS access.  Same operations on the same values as limit_rounds_wave.
 // cols: the columns (ascending); returns the number of rounds made (1000: the caller sets the status).
-template <typename real, int NC, int RPL>
-__device__ __forceinline__ int limit_rounds_regs(real * T_s, const real * jl_s, int m, int n, real kinv, unsigned long long cols, long long * dbg)
+template <typename real, int NC, int RPL, typename PT, typename PJ>
+__device__ __forceinline__ int limit_rounds_regs(PT T_s, PJ jl_s, int m, int n, real kinv, unsigned long long cols, long long * dbg)
 {
    const int lane = threadIdx.x & 63;
    int col[NC]; real lo[NC], hi[NC];
@@ -653,6 +651,16 @@ __device__ __forceinline__ int limit_rounds_regs(real * T_s, const real * jl_s, 
 #pragma unroll
       for (int ci=0; ci<NC; ci++)
       {
+         // a column without a violated entry in this round: A^-1 Gjlimit is zero there (wave-uniform)
+         unsigned long long anyc = 0ull;
+#pragma unroll
+         for (int r=0; r<RPL; r++) anyc |= mk[ci][r];
+         if (NC > 3 && anyc == 0ull)
+         {
+#pragma unroll
+            for (int r=0; r<RPL; r++) x[ci][r] = 0;
+            continue;
+         }
          real sp = 0, sq = 0;
 #pragma unroll
          for (int r=0; r<RPL; r++) { sp += g[ci][r] * wp[r]; sq += g[ci][r] * wq[r]; }
@@ -685,8 +693,8 @@ __device__ __forceinline__ int limit_rounds_regs(real * T_s, const real * jl_s, 
    return rounds;
 }
 
-template <typename real, int NC>
-__device__ __forceinline__ int limit_rounds_regs_rpl(real * T_s, const real * jl_s, int m, int n, real kinv, unsigned long long cols, long long * dbg)
+template <typename real, int NC, typename PT, typename PJ>
+__device__ __forceinline__ int limit_rounds_regs_rpl(PT T_s, PJ jl_s, int m, int n, real kinv, unsigned long long cols, long long * dbg)
 {
    const int rpl = (m + 63) >> 6;
    switch (rpl)
@@ -696,6 +704,63 @@ __device__ __forceinline__ int limit_rounds_regs_rpl(real * T_s, const real * jl
    case 3: return limit_rounds_regs<real, NC, 3>(T_s, jl_s, m, n, kinv, cols, dbg);
    default: return limit_rounds_regs<real, NC, 4>(T_s, jl_s, m, n, kinv, cols, dbg);
    }
+}
+
+// The joint-limit rounds of one iteration as a FUNCTION CALL of the wavefront that makes them: the
+// rounds are long, rare, branchy code with a register appetite of their own; inlined into the
+// iterate kernel they take part in its register allocation and cost the cost phase its registers
+// (measured: +6 % kernel time when the variants for 4..8 columns were added inline).  One copy per
+// precision serves every kernel variant.  T_s / G_s / jl_s are LDS addresses.
+struct LimResult { int rounds; long long kinds; };      // kinds: closed-form | register scans << 20 | general loop << 40
+template <typename real, typename PT>
+__device__ __forceinline__ LimResult limit_rounds_body(PT T_s, real * G_gen, const real * jl_gen, int m, int n, real kinv,
+   unsigned long long viol_cols)
+{
+   typedef __attribute__((address_space(3))) real * lds_ptr;
+   typedef const __attribute__((address_space(3))) real * lds_cptr;
+   lds_ptr G_s = (lds_ptr) G_gen; lds_cptr jl_s = (lds_cptr) jl_gen;
+   LimResult res; res.rounds = 0; res.kinds = 0;
+   long long * dg = &res.kinds;
+   const int nc = __popcll(viol_cols);
+   switch (nc)
+   {
+   case 1: res.rounds = limit_rounds_regs_rpl<real, 1>(T_s, jl_s, m, n, kinv, viol_cols, dg); break;
+   case 2: res.rounds = limit_rounds_regs_rpl<real, 2>(T_s, jl_s, m, n, kinv, viol_cols, dg); break;
+   case 3: res.rounds = limit_rounds_regs_rpl<real, 3>(T_s, jl_s, m, n, kinv, viol_cols, dg); break;
+   default:
+      // four to eight columns (a trajectory that is leaving its limits for good, the 1000-round
+      // aborts among them): still register-resident when a lane holds at most two waypoints
+      if (m <= 128 && nc <= 8)
+      {
+         switch (nc)
+         {
+         case 4: res.rounds = limit_rounds_regs<real, 4, 2>(T_s, jl_s, m, n, kinv, viol_cols, dg); break;
+         case 5: res.rounds = limit_rounds_regs<real, 5, 2>(T_s, jl_s, m, n, kinv, viol_cols, dg); break;
+         case 6: res.rounds = limit_rounds_regs<real, 6, 2>(T_s, jl_s, m, n, kinv, viol_cols, dg); break;
+         case 7: res.rounds = limit_rounds_regs<real, 7, 2>(T_s, jl_s, m, n, kinv, viol_cols, dg); break;
+         default: res.rounds = limit_rounds_regs<real, 8, 2>(T_s, jl_s, m, n, kinv, viol_cols, dg); break;
+         }
+         break;
+      }
+      res.rounds = limit_rounds_wave<real>(T_s, G_s, jl_s, m, n, kinv, nullptr);
+      res.kinds += (long long) res.rounds << 40;
+      break;
+   }
+   return res;
+}
+// the trajectory in LDS (every kernel but the large-robot plans that leave it in global memory)
+template <typename real>
+__device__ __attribute__((noinline)) LimResult limit_rounds_call(real * T_gen, real * G_gen, const real * jl_gen, int m, int n, real kinv,
+   unsigned long long viol_cols)
+{
+   typedef __attribute__((address_space(3))) real * lds_ptr;
+   return limit_rounds_body<real>((lds_ptr) T_gen, G_gen, jl_gen, m, n, kinv, viol_cols);
+}
+template <typename real>
+__device__ __attribute__((noinline)) LimResult limit_rounds_call_global(real * T_gen, real * G_gen, const real * jl_gen, int m, int n, real kinv,
+   unsigned long long viol_cols)
+{
+   return limit_rounds_body<real>(T_gen, G_gen, jl_gen, m, n, kinv, viol_cols);
 }
 
 template <typename real, int BLOCK>
@@ -981,7 +1046,11 @@ void chomp_iterate_kernel(const DevBatch<real> b)
          // joint-limit projection (chomp.c:608-655)
          int num_limadjs = 0;
          bool lim_done = false;
+#ifdef ORC_ABLATE_LIM
+         const unsigned long long viol_cols = 0ull;      // timing experiments: no joint-limit rounds
+#else
          const unsigned long long viol_cols = ((unsigned long long) colmask_s[1] << 32) | colmask_s[0];      // workgroup-uniform
+#endif
          if (b.solve_mode == 2 && n <= 64 && !b.lim_generic)
          {
             lim_done = true;
@@ -990,16 +1059,11 @@ void chomp_iterate_kernel(const DevBatch<real> b)
                // one wavefront makes all rounds (no barrier inside them), the others wait here
                if (tid < 64)
                {
-                  const int nc = __popcll(viol_cols);
                   const real kinv = (real)(-1) / ((real)(m + 1) * b.a_off);      // 1/((m+1) ca), ca = -a_off
-                  int rounds;
-                  switch (nc)
-                  {
-                  case 1: rounds = limit_rounds_regs_rpl<real, 1>(T_s, jl_s, m, n, kinv, viol_cols, (b.phase_cycles && tid == 0) ? &ph[7] : nullptr); break;
-                  case 2: rounds = limit_rounds_regs_rpl<real, 2>(T_s, jl_s, m, n, kinv, viol_cols, (b.phase_cycles && tid == 0) ? &ph[7] : nullptr); break;
-                  case 3: rounds = limit_rounds_regs_rpl<real, 3>(T_s, jl_s, m, n, kinv, viol_cols, (b.phase_cycles && tid == 0) ? &ph[7] : nullptr); break;
-                  default: rounds = limit_rounds_wave<real>(b, T_s, G_s, jl_s, m, n, nullptr); if (b.phase_cycles && tid == 0) ph[7] += (long long) rounds << 40; break;
-                  }
+                  const LimResult lr = (GS16 || b.t_in_lds) ? limit_rounds_call<real>(T_s, G_s, jl_s, m, n, kinv, viol_cols)
+                                                            : limit_rounds_call_global<real>(T_s, G_s, jl_s, m, n, kinv, viol_cols);
+                  const int rounds = lr.rounds;
+                  if (b.phase_cycles && tid == 0) ph[7] += lr.kinds;
                   if (tid == 0) redi[0] = rounds;
                }
                __syncthreads();

@@ -140,6 +140,9 @@ __device__ __forceinline__ void self_sym_step16(const real * prow, const real * 
    const real R2 = r2row[(K-1)*16 + srow];
    const bool near = (flags & 1) && (d2 <= R2);
    if (__ballot(near) == 0ull) return;                     // wave-uniform
+#ifdef ORC_ABLATE_ROTF
+   { const unsigned long long bl_ = __ballot(near); __asm__ volatile("" :: "s"(bl_)); return; }      // timing experiments: range tests only
+#endif
    const real ro = dpp_move<F>(radius);
    real vo[3];
 #pragma unroll
@@ -369,7 +372,9 @@ __device__ __forceinline__ void cost_tile_gs16(const DevBatch<real> & b, const M
          bool row_ok[U];
 #pragma unroll
          for (int u=0; u<U; u++) row_ok[u] = (item < items) && (wl[u] < nw) && (s == 0);
-#ifndef ORC_ABLATE_JT
+#ifdef ORC_ABLATE_JT
+         real w6[U][6] = {};
+#else
          // Wrench of the lane's force about the world origin [p x f ; f].  When the spheres a joint
          // moves are a contiguous range of the row (chains: a suffix), the sums over those spheres
          // come from ONE suffix scan of the wrench over the row, and lane r of the row finishes
