@@ -253,8 +253,8 @@ __device__ __forceinline__ int div_n(int e, float rn) { return (int)(((float) e 
 // columns at once.  src holds d [m][n]; the result ends up in the returned
 // buffer (src or tmp).  Coefficients: pcr[l][0][i] (towards i-s), pcr[l][1][i]
 // (towards i+s), then the inverse of the reduced diagonal.
-template <typename real, int BLOCK>
-__device__ __forceinline__ real * pcr_solve(const DevBatch<real> & b, const real * tab, real * src, real * tmp)
+template <typename real, int BLOCK, typename BT>
+__device__ __forceinline__ real * pcr_solve(const BT & b, const real * tab, real * src, real * tmp)
 {
    const int m = b.m, n = b.n, mn = m*n;
    const float rn = 1.0f / (float) n;
@@ -285,8 +285,8 @@ __device__ __forceinline__ real * pcr_solve(const DevBatch<real> & b, const real
 }
 
 // dense fallback (derivative D >= 2): x = Ainv d
-template <typename real, int BLOCK>
-__device__ __forceinline__ real * dense_solve(const DevBatch<real> & b, real * src, real * tmp)
+template <typename real, int BLOCK, typename BT>
+__device__ __forceinline__ real * dense_solve(const BT & b, real * src, real * tmp)
 {
    const int m = b.m, n = b.n, mn = m*n;
    for (int e=threadIdx.x; e<mn; e+=BLOCK)
@@ -339,8 +339,8 @@ __device__ __forceinline__ real wave_suffix_incl(real v)
 // (m <= 64 ORC_SCAN_RPL); the sums across lanes are wave scans, so the whole solve costs one barrier
 // where cyclic reduction costs one per level.  (The reference multiplies by the dense inverse,
 // src/libcd/chomp.c:525-548: the same products, summed in another order.)
-template <typename real, int BLOCK>
-__device__ __forceinline__ real * toeplitz_scan_solve(const DevBatch<real> & b, real * buf)
+template <typename real, int BLOCK, typename BT>
+__device__ __forceinline__ real * toeplitz_scan_solve(const BT & b, real * buf)
 {
    const int m = b.m, n = b.n;
    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -712,10 +712,22 @@ __device__ __forceinline__ int limit_rounds_regs_rpl(PT T_s, PJ jl_s, int m, int
 // (measured: +6 % kernel time when the variants for 4..8 columns were added inline).  One copy per
 // precision serves every kernel variant.  T_s / G_s / jl_s are LDS addresses.
 struct LimResult { int rounds; long long kinds; };      // kinds: closed-form | register scans << 20 | general loop << 40
-template <typename real, typename PT>
-__device__ __forceinline__ LimResult limit_rounds_body(PT T_s, real * G_gen, const real * jl_gen, int m, int n, real kinv,
-   unsigned long long viol_cols)
+__device__ __forceinline__ unsigned long long uni64(unsigned long long v)
 {
+   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned) v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+   return ((unsigned long long) hi << 32) | lo;
+}
+__device__ __forceinline__ double unir(double v) { return __longlong_as_double((long long) uni64((unsigned long long) __double_as_longlong(v))); }
+__device__ __forceinline__ float unir(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+
+template <typename real, typename PT>
+__device__ __forceinline__ LimResult limit_rounds_body(PT T_s, real * G_gen, const real * jl_gen, int m_in, int n_in, real kinv_in,
+   unsigned long long viol_cols_in)
+{
+   // arguments arrive in vector registers: tell the compiler they are wave-uniform
+   const int m = __builtin_amdgcn_readfirstlane(m_in), n = __builtin_amdgcn_readfirstlane(n_in);
+   const real kinv = unir(kinv_in);
+   const unsigned long long viol_cols = uni64(viol_cols_in);
    typedef __attribute__((address_space(3))) real * lds_ptr;
    typedef const __attribute__((address_space(3))) real * lds_cptr;
    lds_ptr G_s = (lds_ptr) G_gen; lds_cptr jl_s = (lds_cptr) jl_gen;
@@ -763,8 +775,8 @@ __device__ __attribute__((noinline)) LimResult limit_rounds_call_global(real * T
    return limit_rounds_body<real>(T_gen, G_gen, jl_gen, m, n, kinv, viol_cols);
 }
 
-template <typename real, int BLOCK>
-__device__ __forceinline__ real * metric_solve(const DevBatch<real> & b, const real * tab, real * src, real * tmp)
+template <typename real, int BLOCK, typename BT>
+__device__ __forceinline__ real * metric_solve(const BT & b, const real * tab, real * src, real * tmp)
 {
    if (b.solve_mode == 2) return toeplitz_scan_solve<real, BLOCK>(b, src);
    return b.solve_mode == 0 ? pcr_solve<real, BLOCK>(b, tab, src, tmp) : dense_solve<real, BLOCK>(b, src, tmp);
@@ -772,8 +784,8 @@ __device__ __forceinline__ real * metric_solve(const DevBatch<real> & b, const r
 
 // (A T + B)[i][c] from the band of A and the endpoint couplings of B.
 // T_s holds all n_points rows (row 0 = start, row n_points-1 = goal).
-template <typename real>
-__device__ __forceinline__ real smooth_grad(const DevBatch<real> & b, const real * T_s, int i, int c)
+template <typename real, typename BT>
+__device__ __forceinline__ real smooth_grad(const BT & b, const real * T_s, int i, int c)
 {
    const int m = b.m, n = b.n, D = b.D;
    if (D == 1)       // tridiagonal Toeplitz: the end rows couple to the fixed endpoints with a_off
@@ -788,105 +800,153 @@ __device__ __forceinline__ real smooth_grad(const DevBatch<real> & b, const real
    return s;
 }
 
-#include "cost_gs16.h"
-#include "cost_generic.h"
-#include "fk.h"
-
 #ifndef ORC_U
 #define ORC_U 1          // waypoints per lane in the 16-sphere cost phase (1: registers go to a third workgroup per CU instead)
 #endif
 
-// ---------------------------------------------------------------------------
-template <typename real, bool TREE, bool GS16, int BLOCK>
-__global__ __launch_bounds__(BLOCK, ORC_WGS_PER_CU)      // second argument: wavefronts per SIMD (3 x 4 SIMDs = 12 per CU, as 3 x 256 or 4 x 192 threads)
-void chomp_iterate_kernel(const DevBatch<real> b)
-{
-   extern __shared__ __align__(16) unsigned char smem_raw[];
-   const DevModel<real> & gmod = *b.model;      // global copy: read once, staged into LDS below
-   const int run = blockIdx.x;
-   const int tid = threadIdx.x;
-   const int n = b.n, m = b.m, np = b.n_points, mn = m*n;
-   const int nj = gmod.nj, Sa = gmod.Sa, S = gmod.S, GS = gmod.GS;
-   const int tile_m = b.tile_m;
-   const real inf = M<real>::inf();
-   const float rn_f = 1.0f / (float) n;        // for div_n
+#include "cost_gs16.h"
+#include "cost_generic.h"
+#include "fk.h"
 
-   // ---- LDS carve-up ------------------------------------------------------
-   const LdsLayout L = lds_layout(np, n, Sa, S, nj, tile_m, b.pcr_in_lds ? b.pcr_rows : 0, (int) sizeof(real),
+// ---------------------------------------------------------------------------
+// The iterate kernel is a thin loop around PHASE FUNCTIONS (real calls, not inlined): every phase
+// gets a register allocation of its own, as if it were a kernel, while the run's state stays in LDS
+// across them.  Inlined into one function the phases took part in each other's allocation: values
+// of the update phase lived across the cost phase, the SGPR tuples of the kernarg block were spilled
+// and reloaded in its inner loops, and any change to a rare path moved the spills of the hot one.
+// A phase function receives the address of the kernarg block (DevBatch, read with scalar loads where
+// it is used) and a few wave-uniform scalars, and derives the LDS carve-up again (scalar arithmetic).
+template <typename real> using KArg = const __attribute__((address_space(4))) DevBatch<real>;
+template <typename real> using KModel = const __attribute__((address_space(4))) DevModel<real>;
+
+template <typename real>
+__device__ __forceinline__ KArg<real> * uniform_kernarg(const void * p)
+{
+   const unsigned long long v = (unsigned long long) p;
+   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned) v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+   return (KArg<real> *)(((unsigned long long) hi << 32) | lo);
+}
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// the LDS carve-up and the views derived from it (everything here is wave-uniform)
+template <typename real>
+struct Env
+{
+   double * red; int * redi; unsigned int * colmask_s;
+   long long * phc_s;                      // [8] per-phase cycle counters (diagnostics), thread 0
+   real * T_s, * G_s, * Gc, * W_s, * pos_s, * ax_s, * srad_s, * sinact_s, * jl_s, * r2_s, * pcr_s, * sphpos_s, * base_s;
+   int * slink_s, * jtype_s, * jcol_s, * slot_s;
+   DevJoint<real> * joints_s; DevSdf<real> * sdfs_s; unsigned long long * saff_s;
+   real * traj_g, * AG_g, * AG_s;
+   const real * pcr_tab;
+   int pstr, astr;
+   ModelView<real> mod;
+};
+
+template <typename real, bool GS16, typename BT>
+__device__ __forceinline__ Env<real> make_env(const BT & b, unsigned char * smem_raw)
+{
+   Env<real> E;
+   KModel<real> & gmod = *(KModel<real> *) b.model;      // scalar loads
+   const int run = blockIdx.x;
+   const int n = b.n, m = b.m, np = b.n_points, mn = m*n;
+   const int nj = gmod.nj, Sa = gmod.Sa, S = gmod.S;
+   const LdsLayout L = lds_layout(np, n, Sa, S, nj, b.tile_m, b.pcr_in_lds ? b.pcr_rows : 0, (int) sizeof(real),
                                   b.use_momentum && b.ag_in_lds, b.n_sdfs, (int) sizeof(DevJoint<real>), (int) sizeof(DevSdf<real>), b.lds_flags);
-   double * red = (double *) smem_raw;                  // [8] reduction scratch
-   int * redi = (int *)(red + 8);                       // [8]
-   unsigned int * colmask_s = (unsigned int *)(redi + 8);   // [2] columns with an entry outside its joint limits after the step
-   real * lds = (real *)(smem_raw + 128);
-   real * traj_g = b.traj + (size_t) run * np * n;
+   E.red = (double *) smem_raw;                            // [8] reduction scratch
+   E.redi = (int *)(E.red + 8);                            // [8]
+   E.colmask_s = (unsigned int *)(E.redi + 8);             // [2] columns with an entry outside its joint limits after the step
+   E.phc_s = (long long *)(smem_raw + ORC_LDS_HEADER - 64);
+   real * lds = (real *)(smem_raw + ORC_LDS_HEADER);
+   E.traj_g = b.traj + (size_t) run * np * n;
    // [np][n]; the kernels of the generic cost path may leave it in global memory (large robots: the
    // LDS then holds tiles only and a third workgroup fits the CU); __syncthreads orders the accesses
    // of a workgroup's wavefronts to it
-   real * T_s  = (!GS16 && !b.t_in_lds) ? traj_g : lds + L.T;
-   real * G_s  = lds + L.G;                             // [m][n] (inside the tile buffers when !g_in_lds: update phase only)
-   real * Gc = b.g_in_lds ? G_s : b.Gcost + (size_t) run * mn;   // where the cost phase puts its gradient rows
-   real * W_s  = lds + L.W;                             // [m][n] work
-   real * pos_s = lds + L.pos;                          // [tile_m+2][Sa][3]
-   real * ax_s = lds + L.ax;                            // [tile_m+2][nj][6]
-   const int pstr = L.pstr, astr = L.astr;              // padded waypoint strides of pos_s / ax_s
-   real * srad_s = lds + L.srad;                        // [S] sphere radii
-   real * sinact_s = lds + L.sinact;                    // [S-Sa][3] inactive sphere centres
-   real * jl_s = lds + L.jl;                            // [2][n] joint limits
-   real * r2_s = lds + L.r2;                            // [8][16] squared ranges of the self-collision row rotations
-   real * pcr_s = lds + L.pcr;                          // cyclic-reduction tables (when staged)
-   int * slink_s = (int *)(smem_raw + L.ints_bytes);    // [S] link of each sphere
-   int * jtype_s = slink_s + S;                         // [nj]
-   int * jcol_s = jtype_s + nj;                         // [nj]
-   int * slot_s = jcol_s + nj;                          // [Sa_real] slot of the k-th active sphere (sorted order)
-   real * sphpos_s = pcr_s + (((b.pcr_in_lds ? b.pcr_rows : 0)*m + 3) & ~3);   // [Sa][3] + base frame [12]
-   real * base_s = sphpos_s + Sa*3;
-   DevJoint<real> * joints_s = (DevJoint<real> *)(smem_raw + L.joints_bytes);
-   DevSdf<real> * sdfs_s = (DevSdf<real> *)(smem_raw + L.sdfs_bytes);
-   unsigned long long * saff_s = (unsigned long long *)(smem_raw + L.saff_bytes);
-   ModelView<real> mod;
-   mod.nj = nj; mod.n = n; mod.floating = gmod.floating; mod.tree = gmod.tree; mod.Sa = Sa; mod.S = S; mod.GS = GS; mod.jt_scan = gmod.jt_scan;
-   mod.Sa_real = gmod.Sa_real; mod.placed = gmod.placed; mod.live_mask = gmod.live_mask; mod.slot_of = slot_s;
+   E.T_s  = (!GS16 && !b.t_in_lds) ? E.traj_g : lds + L.T;
+   E.G_s  = lds + L.G;                                     // [m][n] (inside the tile buffers when !g_in_lds: update phase only)
+   E.Gc = b.g_in_lds ? E.G_s : b.Gcost + (size_t) run * mn;   // where the cost phase puts its gradient rows
+   E.W_s  = lds + L.W;                                     // [m][n] work
+   E.pos_s = lds + L.pos;                                  // [tile_m+2][Sa][3]
+   E.ax_s = lds + L.ax;                                    // [tile_m+2][nj][6]
+   E.pstr = L.pstr; E.astr = L.astr;                       // padded waypoint strides of pos_s / ax_s
+   E.srad_s = lds + L.srad;                                // [S] sphere radii
+   E.sinact_s = lds + L.sinact;                            // [S-Sa][3] inactive sphere centres
+   E.jl_s = lds + L.jl;                                    // [2][n] joint limits
+   E.r2_s = lds + L.r2;                                    // [8][16] squared ranges of the self-collision row rotations
+   E.pcr_s = lds + L.pcr;                                  // cyclic-reduction tables (when staged)
+   E.slink_s = (int *)(smem_raw + L.ints_bytes);           // [S] link of each sphere
+   E.jtype_s = E.slink_s + S;                              // [nj]
+   E.jcol_s = E.jtype_s + nj;                              // [nj]
+   E.slot_s = E.jcol_s + nj;                               // [Sa_real] slot of the k-th active sphere (sorted order)
+   E.sphpos_s = E.pcr_s + (((b.pcr_in_lds ? b.pcr_rows : 0)*m + 3) & ~3);   // [Sa][3] + base frame [12]
+   E.base_s = E.sphpos_s + Sa*3;
+   E.joints_s = (DevJoint<real> *)(smem_raw + L.joints_bytes);
+   E.sdfs_s = (DevSdf<real> *)(smem_raw + L.sdfs_bytes);
+   E.saff_s = (unsigned long long *)(smem_raw + L.saff_bytes);
+   ModelView<real> & mod = E.mod;
+   mod.nj = nj; mod.n = n; mod.floating = gmod.floating; mod.tree = gmod.tree; mod.Sa = Sa; mod.S = S; mod.GS = gmod.GS; mod.jt_scan = gmod.jt_scan;
+   mod.Sa_real = gmod.Sa_real; mod.placed = gmod.placed; mod.live_mask = gmod.live_mask; mod.slot_of = E.slot_s;
    mod.base_sph_begin = gmod.base_sph_begin; mod.base_sph_end = gmod.base_sph_end;
-   mod.base_R = base_s; mod.base_t = base_s + 9;
-   mod.joints = joints_s; mod.sph_pos = (const real (*)[3]) sphpos_s; mod.sph_affects = saff_s;
-   const DevSdf<real> * sdfs = sdfs_s;
-
-   real * AG_g = b.AG + (size_t) run * mn;
+   mod.base_R = E.base_s; mod.base_t = E.base_s + 9;
+   mod.joints = E.joints_s; mod.sph_pos = (const real (*)[3]) E.sphpos_s; mod.sph_affects = E.saff_s;
+   E.AG_g = b.AG + (size_t) run * mn;
    // momentum: in LDS for the launch, or in place in global memory (every entry is read and written
    // by the same thread, e = tid + k BLOCK, in all loops that touch it)
-   real * AG_s = b.ag_in_lds ? lds + L.AG : AG_g;       // [m][n]
+   E.AG_s = b.ag_in_lds ? lds + L.AG : E.AG_g;             // [m][n]
+   E.pcr_tab = b.pcr_in_lds ? E.pcr_s : b.pcr;
+   return E;
+}
 
-   if (GS16 || b.t_in_lds) for (int e=tid; e<np*n; e+=BLOCK) T_s[e] = traj_g[e];
-   for (int e=tid; e<S; e+=BLOCK) { srad_s[e] = gmod.sph_radius[e]; slink_s[e] = gmod.sph_link[e]; }
-   for (int e=tid; e<(S-Sa)*3; e+=BLOCK) sinact_s[e] = gmod.sph_inactive_pos[e/3][e%3];
-   for (int e=tid; e<nj; e+=BLOCK) { jtype_s[e] = gmod.joints[e].type; jcol_s[e] = gmod.joints[e].col; }
-   for (int e=tid; e<Sa*3; e+=BLOCK) sphpos_s[e] = gmod.sph_pos[e/3][e%3];
-   for (int e=tid; e<gmod.Sa_real; e+=BLOCK) slot_s[e] = gmod.slot_of[e];
-   for (int e=tid; e<Sa; e+=BLOCK) saff_s[e] = gmod.sph_affects[e];
-   for (int e=tid; e<12; e+=BLOCK) base_s[e] = (e < 9) ? gmod.base_R[e] : gmod.base_t[e-9];
+extern __shared__ __align__(16) unsigned char orc_smem[];
+
+// per-phase cycle counters (diagnostics: b.phase_cycles == null in production), kept in the LDS header
+template <typename real, typename BT>
+__device__ __forceinline__ void phase_mark(const BT & b, const Env<real> & E, int slot)
+{
+   if (b.phase_cycles && threadIdx.x == 0)
+   {
+      long long * tm = (long long *)((unsigned char *) E.red + 104);
+      const long long now = clock64();
+      if (slot >= 0) E.phc_s[slot] += now - *tm;
+      *tm = now;
+   }
+}
+
+// ---- staging: the run's trajectory and everything read-only the iteration touches, into LDS ----
+template <typename real, bool TREE, bool GS16, int BLOCK>
+__device__ __attribute__((noinline)) void phase_setup(const void * kp)
+{
+   KArg<real> & b = *uniform_kernarg<real>(kp);
+   const Env<real> E = make_env<real, GS16>(b, orc_smem);
+   const DevModel<real> & gmod = *b.model;      // global copy: read once
+   const int tid = threadIdx.x;
+   const int n = b.n, m = b.m, np = b.n_points, mn = m*n;
+   const int nj = E.mod.nj, Sa = E.mod.Sa, S = E.mod.S;
+   if (GS16 || b.t_in_lds) for (int e=tid; e<np*n; e+=BLOCK) E.T_s[e] = E.traj_g[e];
+   for (int e=tid; e<S; e+=BLOCK) { E.srad_s[e] = gmod.sph_radius[e]; E.slink_s[e] = gmod.sph_link[e]; }
+   for (int e=tid; e<(S-Sa)*3; e+=BLOCK) E.sinact_s[e] = gmod.sph_inactive_pos[e/3][e%3];
+   for (int e=tid; e<nj; e+=BLOCK) { E.jtype_s[e] = gmod.joints[e].type; E.jcol_s[e] = gmod.joints[e].col; }
+   for (int e=tid; e<Sa*3; e+=BLOCK) E.sphpos_s[e] = gmod.sph_pos[e/3][e%3];
+   for (int e=tid; e<E.mod.Sa_real; e+=BLOCK) E.slot_s[e] = gmod.slot_of[e];
+   for (int e=tid; e<Sa; e+=BLOCK) E.saff_s[e] = gmod.sph_affects[e];
+   for (int e=tid; e<12; e+=BLOCK) E.base_s[e] = (e < 9) ? gmod.base_R[e] : gmod.base_t[e-9];
    {
       // word-wise copies of the joint and field descriptors
-      const int * src = (const int *) gmod.joints; int * dst = (int *) joints_s;
+      const int * src = (const int *) gmod.joints; int * dst = (int *) E.joints_s;
       for (int e=tid; e<nj*(int)(sizeof(DevJoint<real>)/4); e+=BLOCK) dst[e] = src[e];
-      const int * src2 = (const int *) b.sdfs; int * dst2 = (int *) sdfs_s;
+      const int * src2 = (const int *) b.sdfs; int * dst2 = (int *) E.sdfs_s;
       for (int e=tid; e<b.n_sdfs*(int)(sizeof(DevSdf<real>)/4); e+=BLOCK) dst2[e] = src2[e];
    }
 #ifdef ORC_ABLATE_SDFLDS
    __syncthreads();
-   if (tid < b.n_sdfs) sdfs_s[tid].data = pos_s;
+   if (tid < b.n_sdfs) E.sdfs_s[tid].data = E.pos_s;
 #endif
-   for (int e=tid; e<n; e+=BLOCK) { jl_s[e] = b.jl_lo[e]; jl_s[n+e] = b.jl_hi[e]; }
+   for (int e=tid; e<n; e+=BLOCK) { E.jl_s[e] = b.jl_lo[e]; E.jl_s[n+e] = b.jl_hi[e]; }
    if (b.pcr_in_lds)
-      for (int e=tid; e<b.pcr_rows*m; e+=BLOCK) pcr_s[e] = b.pcr[e];
-   const real * pcr_tab = b.pcr_in_lds ? pcr_s : b.pcr;
-   const real inv_eps = (real)1 / b.epsilon, inv_eps_self = (real)1 / b.epsilon_self;
-   if (b.use_momentum && b.ag_in_lds) for (int e=tid; e<mn; e+=BLOCK) AG_s[e] = AG_g[e];
-   int leapfrog_first = b.leapfrog_first[run];
-   // every iterate call starts afresh: the reference throws out of the call in which a run leaves
-   // its joint limits, the run itself stays usable (src/orcdchomp_mod.cpp:2799-2803)
-   int status = 0;
-   int next_resample = 0;      // index into this call's resample list
-   if (tid < 2) colmask_s[tid] = 0u;
+      for (int e=tid; e<b.pcr_rows*m; e+=BLOCK) E.pcr_s[e] = b.pcr[e];
+   if (b.use_momentum && b.ag_in_lds) for (int e=tid; e<mn; e+=BLOCK) E.AG_s[e] = E.AG_g[e];
+   if (tid < 2) E.colmask_s[tid] = 0u;
+   if (tid < 8) E.phc_s[tid] = 0;
    __syncthreads();
 
    if (GS16 && tid < 64)
@@ -895,360 +955,374 @@ void chomp_iterate_kernel(const DevBatch<real> b)
       // self-collision term; -1: the pair never counts (same link, or a lane without a sphere).
       // The partner's identity comes through the same DPP rotation the cost phase uses.
       const int srow = tid & 15;
-      const bool has = ((gmod.live_mask >> srow) & 1ull) != 0;
-      const real rad = has ? srad_s[srow] : (real)0;
-      const int link = has ? slink_s[srow] : -1 - srow;
+      const unsigned long long live_mask = E.mod.live_mask;
+      const bool has = ((live_mask >> srow) & 1ull) != 0;
+      const real rad = has ? E.srad_s[srow] : (real)0;
+      const int link = has ? E.slink_s[srow] : -1 - srow;
+      const real eps_self = b.epsilon_self;
 #define ORC_R2(K) do { \
          const int sp_ = dpp_move<0x120 + K>(srow); \
          const real ro_ = dpp_move<0x120 + K>(rad); \
          const int lo_ = dpp_move<0x120 + K>(link); \
-         const real R_ = rad + ro_ + b.epsilon_self; \
-         if (tid < 16) r2_s[(K-1)*16 + srow] = (has && ((gmod.live_mask >> sp_) & 1ull) && lo_ != link) ? R_ * R_ : (real)(-1); \
+         const real R_ = rad + ro_ + eps_self; \
+         if (tid < 16) E.r2_s[(K-1)*16 + srow] = (has && ((live_mask >> sp_) & 1ull) && lo_ != link) ? R_ * R_ : (real)(-1); \
       } while (0)
       ORC_R2(1); ORC_R2(2); ORC_R2(3); ORC_R2(4); ORC_R2(5); ORC_R2(6); ORC_R2(7); ORC_R2(8);
 #undef ORC_R2
    }
    __syncthreads();
+   phase_mark<real>(b, E, -1);
+}
 
-   // optional per-phase cycle counters (diagnostics: b.phase_cycles == null in production)
-   long long ph[8] = {0,0,0,0,0,0,0,0};
-   long long gdbg[4] = {0,0,0,0};           // diagnostics: parts of the generic cost path (ORC_LIM_GENERIC=2 with ORC_PHASE_TIMERS)
-   long long tmark = 0;
-#define ORC_MARK(slot) do { if (b.phase_cycles && tid == 0) { const long long now_ = clock64(); ph[slot] += now_ - tmark; tmark = now_; } } while (0)
-   if (b.phase_cycles && tid == 0) tmark = clock64();
-
-   // co-resident workgroups that start in lockstep stay in lockstep (all in the one-wave FK phase
-   // together, then all in the cost phase): delaying every other one interleaves their phases
-   if (b.stagger_mode)
-   {
-      const bool late = (b.stagger_mode == 1) ? (blockIdx.x & 1) : ((blockIdx.x >> 8) & 1);
-      if (late) for (int k=0; k<b.stagger_sleeps; k++) __builtin_amdgcn_s_sleep(127);
-   }
-
-   double cost_obs = 0.0, cost_smooth = 0.0;
-   // costs of the last pass that ran to its end, and the iterations completed by this launch
-   double done_obs = 0.0, done_smooth = 0.0;
-   bool have_costs = false;
-   int iters_done = 0;
-   const int total_passes = b.n_iter + (b.final_eval ? 1 : 0);
-
-   for (int it=0; it<total_passes; it++)
-   {
-      const bool do_iteration = (it < b.n_iter);
-
-      // ---- hmc momentum resample (src/orcdchomp_mod.cpp:2755-2768) ----------
-      if (do_iteration && b.use_hmc && b.use_momentum && next_resample < b.max_resamples
-          && b.hmc_iters[(size_t) run * b.max_resamples + next_resample] == it)
-      {
-         const real * nz = b.noise + ((size_t) run * b.max_resamples + next_resample) * mn;
-         for (int e=tid; e<mn; e+=BLOCK) AG_s[e] = nz[e];
-         leapfrog_first = 1;
-         next_resample++;
-         __syncthreads();
-      }
-
-      double cost_lane = 0.0;
-
-      for (int ts=0; ts<m; ts+=tile_m)
-      {
-         const int te = (ts + tile_m < m) ? ts + tile_m : m;
-         const int nfk = te - ts + 2;          // waypoints ts .. te+1 (global index)
-
-         // ================= FK phase: lane = (waypoint, world axis) ===========
-         __builtin_amdgcn_s_setprio(3);          // latency-bound phases go first when they have something to issue
-         for (int w0=0; w0<nfk; w0+=BLOCK/4)
-         {
-            const int w = w0 + (tid >> 2);
-            const bool valid = (w < nfk);
-            const int wr = valid ? w : 0;
-            fk_waypoint_quad<real, TREE>(mod, T_s + (ts + wr)*n, nj, tid & 3, valid, pos_s + wr*pstr, ax_s + wr*astr);
-         }
-         __syncthreads();
-         ORC_MARK(0);
-
-         // ================= cost phase: lane = (waypoint, sphere) =============
-         __builtin_amdgcn_s_setprio(0);
-         if constexpr (GS16)
-            cost_tile_gs16<real, ORC_U, BLOCK>(b, mod, sdfs, ts, te, do_iteration, T_s, Gc, pos_s, ax_s, srad_s, sinact_s, r2_s,
-                                        slink_s, jtype_s, jcol_s, inv_eps, inv_eps_self, cost_lane);
-         else
-            cost_tile_generic<real, BLOCK>(b, mod, sdfs, ts, te, do_iteration, T_s, Gc, pos_s, ax_s, srad_s, sinact_s,
-                                           slink_s, jtype_s, jcol_s, pstr, astr, inv_eps, inv_eps_self, cost_lane,
-                                           (b.phase_cycles && tid == 0 && b.lim_generic == 2) ? gdbg : nullptr);
-         __syncthreads();
-         ORC_MARK(1);
-      } // tiles
-
-      // obstacle cost of the trajectory the gradient was taken at (chomp.c:484-491)
-      cost_obs = block_sum<BLOCK>(cost_lane, red) / (double) m;
-      ORC_MARK(2);
-
-      if (do_iteration)
-      {
-         // ================= update phase ======================================
-         __builtin_amdgcn_s_setprio(3);
-         if (tid < 2) colmask_s[tid] = 0u;       // read last after the previous step's barrier, set again after the next one
-         // G = G/m + A T + B   (chomp.c:492, 515-522)
-         for (int e=tid; e<mn; e+=BLOCK)
-         {
-            const int i = div_n(e, rn_f), c = e - i*n;
-            real g = Gc[e];
-            g *= b.inv_m;
-            g += smooth_grad(b, T_s, i, c);
-            G_s[e] = g;
-         }
-         __syncthreads();
-         if (b.Gdbg)
-            for (int e=tid; e<mn; e+=BLOCK) b.Gdbg[(size_t) run*mn + e] = G_s[e];
-         // X = A^-1 G   (chomp.c:525-548)
-         real * X = metric_solve<real, BLOCK>(b, pcr_tab, G_s, W_s);
-         // T -= AG/lambda   (chomp.c:604-605)
-         const real step = (real)(-1) / b.lambda;
-         // the step also notes which columns left their limits (what the first scan of the
-         // joint-limit loop would find, chomp.c:615-639): bit c of colmask_s
-         unsigned long long viol = 0ull;
-         if (!b.use_momentum)
-         {
-            // AG = X is not carried between iterations: keep only the last one (read-back state)
-            const bool keep = (it == b.n_iter - 1) || (b.Gdbg != nullptr);
-            for (int e=tid; e<mn; e+=BLOCK)
-            {
-               const real x = X[e];
-               if (keep) AG_g[e] = x;
-               const real t = T_s[n + e] + step * x;
-               T_s[n + e] = t;
-               const int c = e - div_n(e, rn_f)*n;
-               viol |= (t < jl_s[c] || t > jl_s[n+c]) ? (1ull << c) : 0ull;
-            }
-         }
-         else
-         {
-            const real sc = (leapfrog_first ? (real)0.5 : (real)1) / b.lambda;
-            for (int e=tid; e<mn; e+=BLOCK)
-            {
-               const real ag = AG_s[e] + sc * X[e];
-               AG_s[e] = ag;
-               const real t = T_s[n + e] + step * ag;
-               T_s[n + e] = t;
-               const int c = e - div_n(e, rn_f)*n;
-               viol |= (t < jl_s[c] || t > jl_s[n+c]) ? (1ull << c) : 0ull;
-            }
-            leapfrog_first = 0;
-         }
-         if (viol)
-         {
-            if ((unsigned int) viol) atomicOr(&colmask_s[0], (unsigned int) viol);
-            if ((unsigned int)(viol >> 32)) atomicOr(&colmask_s[1], (unsigned int)(viol >> 32));
-         }
-         __syncthreads();
-
-         ORC_MARK(3);
-         // joint-limit projection (chomp.c:608-655)
-         int num_limadjs = 0;
-         bool lim_done = false;
-#ifdef ORC_ABLATE_LIM
-         const unsigned long long viol_cols = 0ull;      // timing experiments: no joint-limit rounds
-#else
-         const unsigned long long viol_cols = ((unsigned long long) colmask_s[1] << 32) | colmask_s[0];      // workgroup-uniform
-#endif
-         if (b.solve_mode == 2 && n <= 64 && !b.lim_generic)
-         {
-            lim_done = true;
-            if (viol_cols != 0ull)
-            {
-               // one wavefront makes all rounds (no barrier inside them), the others wait here
-               if (tid < 64)
-               {
-                  const real kinv = (real)(-1) / ((real)(m + 1) * b.a_off);      // 1/((m+1) ca), ca = -a_off
-                  const LimResult lr = (GS16 || b.t_in_lds) ? limit_rounds_call<real>(T_s, G_s, jl_s, m, n, kinv, viol_cols)
-                                                            : limit_rounds_call_global<real>(T_s, G_s, jl_s, m, n, kinv, viol_cols);
-                  const int rounds = lr.rounds;
-                  if (b.phase_cycles && tid == 0) ph[7] += lr.kinds;
-                  if (tid == 0) redi[0] = rounds;
-               }
-               __syncthreads();
-               num_limadjs = redi[0];
-               __syncthreads();             // redi is reused by the reductions below
-            }
-         }
-         if (!lim_done)
-         for (; num_limadjs<1000; num_limadjs++)
-         {
-            real best = 0; int best_e = 0x7fffffff;
-            for (int e=tid; e<mn; e+=BLOCK)
-            {
-               const int i = div_n(e, rn_f), c = e - i*n;
-               const real t = T_s[n + e];
-               real gj = 0;
-               if (t < jl_s[c]) gj = jl_s[c] - t;
-               if (t > jl_s[n+c]) gj = jl_s[n+c] - t;
-               G_s[e] = gj;
-               const real a = M<real>::fabs_(gj);
-               if (a > best) { best = a; best_e = e; }
-            }
-            // workgroup arg-max, ties to the smallest index (first in row-major scan)
-            wave_argmax(best, best_e);
-            __syncthreads();
-            if ((tid & 63) == 0) { red[tid >> 6] = (double) best; redi[tid >> 6] = best_e; }
-            __syncthreads();
-            double gb = red[0]; int ge = redi[0];
-#pragma unroll
-            for (int w=1; w<BLOCK/64; w++)
-               if (red[w] > gb || (red[w] == gb && redi[w] < ge)) { gb = red[w]; ge = redi[w]; }
-            if (gb == 0.0) break;                  // nothing violated anywhere in the workgroup
-            const int gi = div_n(ge, rn_f), gc = ge - gi*n;
-            const real gl = G_s[ge];               // Gjlimit[largest]
-
-            // GA = A^-1 Gjlimit.  Gjlimit is sparse (a few violated entries): for the tridiagonal
-            // Toeplitz metric (D == 1) the columns of A^-1 are known in closed form,
-            //    Ainv[i][k] = (min(i,k)+1) (m - max(i,k)) / ((m+1) ca),   A = ca tridiag(-1,2,-1),
-            // so GA is a short sum per element instead of a full solve.
-            bool sparse_done = false;
-            if (b.D == 1 && b.solve_mode != 1)
-            {
-               const int K = (mn + BLOCK - 1) / BLOCK;       // elements per thread
-               int * cnt = (int *) W_s;                               // [K][waves] counts per (slice, wave)
-               int * lst = cnt + 64;                                  // [64][2]  (row, column) of a violated entry
-               real * lval = (real *)(lst + 128);                     // [64] its Gjlimit value
-               const int lane = tid & 63, wave = tid >> 6;
-               if (K <= 16)
-               {
-                  for (int k=0; k<K; k++)
-                  {
-                     const int e = tid + k*BLOCK;
-                     const bool v = (e < mn) && (G_s[e] != (real)0);
-                     const unsigned long long mask = __ballot(v);
-                     if (lane == 0) cnt[k*(BLOCK/64) + wave] = __popcll(mask);
-                  }
-                  __syncthreads();
-                  int total = 0;
-                  for (int q=0; q<K*(BLOCK/64); q++) total += cnt[q];
-                  if (total <= 64)
-                  {
-                     for (int k=0; k<K; k++)
-                     {
-                        const int e = tid + k*BLOCK;
-                        const bool v = (e < mn) && (G_s[e] != (real)0);
-                        const unsigned long long mask = __ballot(v);
-                        if (v)
-                        {
-                           int off = 0;
-                           for (int q=0; q<k*(BLOCK/64) + wave; q++) off += cnt[q];
-                           off += __popcll(mask & ((1ull << lane) - 1ull));
-                           const int i = div_n(e, rn_f);
-                           lst[2*off] = i; lst[2*off+1] = e - i*n;
-                           lval[off] = G_s[e];
-                        }
-                     }
-                     __syncthreads();
-                     const real kinv = (real)(-1) / ((real)(m + 1) * b.a_off);     // 1/((m+1) ca), ca = -a_off
-                     // the entry the scale is taken from
-                     real ga_l = 0;
-                     for (int v=0; v<total; v++)
-                     {
-                        const int iv = lst[2*v], cv = lst[2*v+1];
-                        if (cv == gc)
-                        {
-                           const int lo = iv < gi ? iv : gi, hi = iv < gi ? gi : iv;
-                           ga_l += lval[v] * (real)((lo + 1) * (m - hi));
-                        }
-                     }
-                     const real sc = (real)1.01 * gl / (ga_l * kinv);
-                     for (int e=tid; e<mn; e+=BLOCK)
-                     {
-                        const int i = div_n(e, rn_f), c = e - i*n;
-                        real ga = 0;
-                        for (int v=0; v<total; v++)
-                        {
-                           const int iv = lst[2*v], cv = lst[2*v+1];
-                           if (cv == c)
-                           {
-                              const int lo = iv < i ? iv : i, hi = iv < i ? i : iv;
-                              ga += lval[v] * (real)((lo + 1) * (m - hi));
-                           }
-                        }
-                        T_s[n + e] += sc * (ga * kinv);
-                     }
-                     __syncthreads();
-                     sparse_done = true;
-                  }
-               }
-            }
-            if (!sparse_done)
-            {
-               __syncthreads();
-               real * GA = metric_solve<real, BLOCK>(b, pcr_tab, G_s, W_s);
-               const real sc = (real)1.01 * gl / GA[ge];
-               __syncthreads();
-               for (int e=tid; e<mn; e+=BLOCK) T_s[n + e] += sc * GA[e];
-               __syncthreads();
-            }
-         }
-         if (!(num_limadjs < 1000)) status = -1;
-         ORC_MARK(4);
-         if (b.phase_cycles && tid == 0) { ph[6] += num_limadjs; }   // rounds (ph[7]: violated entries summed over the sparse rounds)
-
-      }
-      // "ran too many joint limit fixes! aborting ..." (chomp.c:651-655): cd_chomp_iterate returns
-      // before the smoothness cost, mod::iterate throws before the quaternion renormalisation and
-      // the log line; the trajectory keeps what the limit rounds made of it (workgroup-uniform)
-      if (status != 0) break;
-
-      // smoothness cost of the (updated) trajectory (chomp.c:660-677):
-      // 0.5 tr(T^T A T) + tr(B^T T) + trC
-      // evaluated before the quaternion renormalisation of the same iteration, as in
-      // the reference (cd_chomp_iterate returns before mod.cpp:2806-2808 runs)
-      {
-         double acc = 0.0;
-         for (int e=tid; e<mn; e+=BLOCK)
-         {
-            const int i = div_n(e, rn_f), c = e - i*n;
-            const real sg = smooth_grad(b, T_s, i, c);           // (A T + B)
-            const real bt = (b.D == 1) ? b.a_off * ((i == 0 ? T_s[c] : (real)0) + (i == m-1 ? T_s[(np-1)*n + c] : (real)0))
-                                       : b.beta_s[i] * T_s[c] + b.beta_g[i] * T_s[(np-1)*n + c];
-            acc += (double) T_s[n + e] * (0.5 * ((double) sg + (double) bt));
-         }
-         double ss = 0.0, sg2 = 0.0, gg = 0.0;
-         if (tid < n)
-         {
-            const double s0 = (double) T_s[tid], g0 = (double) T_s[(np-1)*n + tid];
-            ss = s0*s0; sg2 = s0*g0; gg = g0*g0;
-         }
-         acc += 0.5 * (b.kss*ss + 2.0*b.ksg*sg2 + b.kgg*gg);
-         cost_smooth = block_sum<BLOCK>(acc, red);
-      }
-      ORC_MARK(5);
-
-      // floating base: renormalise the quaternion of every row (mod.cpp:2806-2808)
-      if (do_iteration && mod.floating)
-      {
-         for (int w=tid; w<np; w+=BLOCK)
-         {
-            real * row = T_s + w*n;
-            const real len = M<real>::sqrt_(row[3]*row[3] + row[4]*row[4] + row[5]*row[5] + row[6]*row[6]);
-            const real inv = (real)1 / len;
-            row[3] *= inv; row[4] *= inv; row[5] *= inv; row[6] *= inv;
-         }
-         __syncthreads();
-      }
-
-      if (tid == 0 && b.trace && do_iteration)
-      {
-         double * tr = b.trace + ((size_t) run * b.n_iter + it) * 3;
-         tr[0] = cost_obs + cost_smooth; tr[1] = cost_obs; tr[2] = cost_smooth;
-      }
-      done_obs = cost_obs; done_smooth = cost_smooth; have_costs = true;
-      if (do_iteration) iters_done++;
-   }
-
-   // ---- write back ---------------------------------------------------------
+// ---- hmc momentum resample (src/orcdchomp_mod.cpp:2755-2768): AG <- the call's noise slot ----
+template <typename real, bool GS16, int BLOCK>
+__device__ __attribute__((noinline)) void phase_hmc(const void * kp, int slot_in)
+{
+   KArg<real> & b = *uniform_kernarg<real>(kp);
+   const int slot = uni(slot_in);
+   const Env<real> E = make_env<real, GS16>(b, orc_smem);
+   const int mn = b.m * b.n;
+   const real * nz = b.noise + ((size_t) blockIdx.x * b.max_resamples + slot) * mn;
+   for (int e=threadIdx.x; e<mn; e+=BLOCK) E.AG_s[e] = nz[e];
    __syncthreads();
-   if (GS16 || b.t_in_lds) for (int e=tid; e<np*n; e+=BLOCK) traj_g[e] = T_s[e];
-   if (b.use_momentum && b.ag_in_lds) for (int e=tid; e<mn; e+=BLOCK) AG_g[e] = AG_s[e];
+}
+
+// ---- FK phase of one tile: lane = (waypoint, world axis) (sphere_cost_pre, src/orcdchomp_mod.cpp:988-1093) ----
+template <typename real, bool TREE, bool GS16, int BLOCK>
+__device__ __attribute__((noinline)) void phase_fk(const void * kp, int ts_in, int te_in)
+{
+   KArg<real> & b = *uniform_kernarg<real>(kp);
+   const int ts = uni(ts_in), te = uni(te_in);
+   const Env<real> E = make_env<real, GS16>(b, orc_smem);
+   const int tid = threadIdx.x, n = b.n;
+   const int nfk = te - ts + 2;          // waypoints ts .. te+1 (global index)
+   __builtin_amdgcn_s_setprio(3);          // latency-bound phases go first when they have something to issue
+   for (int w0=0; w0<nfk; w0+=BLOCK/4)
+   {
+      const int w = w0 + (tid >> 2);
+      const bool valid = (w < nfk);
+      const int wr = valid ? w : 0;
+      fk_waypoint_quad<real, TREE>(E.mod, E.T_s + (ts + wr)*n, E.mod.nj, tid & 3, valid, E.pos_s + wr*E.pstr, E.ax_s + wr*E.astr);
+   }
+   __syncthreads();
+   phase_mark<real>(b, E, 0);
+}
+
+// ---- cost phase of one tile: lane = (waypoint, sphere) (sphere_cost, src/orcdchomp_mod.cpp:1134-1327) ----
+template <typename real, bool TREE, bool GS16, int BLOCK>
+__device__ __attribute__((noinline)) double phase_cost(const void * kp, int ts_in, int te_in, int do_iteration_in, double cost_lane)
+{
+   KArg<real> & b = *uniform_kernarg<real>(kp);
+   const int ts = uni(ts_in), te = uni(te_in);
+   const bool do_iteration = uni(do_iteration_in) != 0;
+   const Env<real> E = make_env<real, GS16>(b, orc_smem);
+   const real inv_eps = (real)1 / b.epsilon, inv_eps_self = (real)1 / b.epsilon_self;
+   __builtin_amdgcn_s_setprio(0);
+   if constexpr (GS16)
+      cost_tile_gs16<real, ORC_U, BLOCK>(b, E.mod, E.sdfs_s, ts, te, do_iteration, E.T_s, E.Gc, E.pos_s, E.ax_s, E.srad_s, E.sinact_s, E.r2_s,
+                                         E.slink_s, E.jtype_s, E.jcol_s, inv_eps, inv_eps_self, cost_lane);
+   else
+      cost_tile_generic<real, BLOCK>(b, E.mod, E.sdfs_s, ts, te, do_iteration, E.T_s, E.Gc, E.pos_s, E.ax_s, E.srad_s, E.sinact_s,
+                                     E.slink_s, E.jtype_s, E.jcol_s, E.pstr, E.astr, inv_eps, inv_eps_self, cost_lane, nullptr);
+   __syncthreads();
+   phase_mark<real>(b, E, 1);
+   return cost_lane;
+}
+
+// ---- update phase (cd_chomp_iterate, src/libcd/chomp.c:490-655): G/m + A T + B, A^-1 G, the step,
+// the joint-limit rounds.  Returns the number of limit rounds made (1000: "ran too many joint limit fixes").
+template <typename real, bool TREE, bool GS16, int BLOCK>
+__device__ __attribute__((noinline)) int phase_update(const void * kp, int it_in, int leapfrog_first_in)
+{
+   KArg<real> & b = *uniform_kernarg<real>(kp);
+   const int it = uni(it_in), leapfrog_first = uni(leapfrog_first_in);
+   const Env<real> E = make_env<real, GS16>(b, orc_smem);
+   const int run = blockIdx.x, tid = threadIdx.x;
+   const int n = b.n, m = b.m, mn = m*n;
+   const float rn_f = 1.0f / (float) n;        // for div_n
+   double * red = E.red; int * redi = E.redi; unsigned int * colmask_s = E.colmask_s;
+   real * T_s = E.T_s, * G_s = E.G_s, * Gc = E.Gc, * W_s = E.W_s, * jl_s = E.jl_s, * AG_g = E.AG_g, * AG_s = E.AG_s;
+   const real * pcr_tab = E.pcr_tab;
+
+   __builtin_amdgcn_s_setprio(3);
+   if (tid < 2) colmask_s[tid] = 0u;       // read last after the previous step's barrier, set again after the next one
+   // G = G/m + A T + B   (chomp.c:492, 515-522)
+   for (int e=tid; e<mn; e+=BLOCK)
+   {
+      const int i = div_n(e, rn_f), c = e - i*n;
+      real g = Gc[e];
+      g *= b.inv_m;
+      g += smooth_grad<real>(b, T_s, i, c);
+      G_s[e] = g;
+   }
+   __syncthreads();
+   if (b.Gdbg)
+      for (int e=tid; e<mn; e+=BLOCK) b.Gdbg[(size_t) run*mn + e] = G_s[e];
+   // X = A^-1 G   (chomp.c:525-548)
+   real * X = metric_solve<real, BLOCK>(b, pcr_tab, G_s, W_s);
+   // T -= AG/lambda   (chomp.c:604-605)
+   const real step = (real)(-1) / b.lambda;
+   // the step also notes which columns left their limits (what the first scan of the
+   // joint-limit loop would find, chomp.c:615-639): bit c of colmask_s
+   unsigned long long viol = 0ull;
+   if (!b.use_momentum)
+   {
+      // AG = X is not carried between iterations: keep only the last one (read-back state)
+      const bool keep = (it == b.n_iter - 1) || (b.Gdbg != nullptr);
+      for (int e=tid; e<mn; e+=BLOCK)
+      {
+         const real x = X[e];
+         if (keep) AG_g[e] = x;
+         const real t = T_s[n + e] + step * x;
+         T_s[n + e] = t;
+         const int c = e - div_n(e, rn_f)*n;
+         viol |= (t < jl_s[c] || t > jl_s[n+c]) ? (1ull << c) : 0ull;
+      }
+   }
+   else
+   {
+      const real sc = (leapfrog_first ? (real)0.5 : (real)1) / b.lambda;
+      for (int e=tid; e<mn; e+=BLOCK)
+      {
+         const real ag = AG_s[e] + sc * X[e];
+         AG_s[e] = ag;
+         const real t = T_s[n + e] + step * ag;
+         T_s[n + e] = t;
+         const int c = e - div_n(e, rn_f)*n;
+         viol |= (t < jl_s[c] || t > jl_s[n+c]) ? (1ull << c) : 0ull;
+      }
+   }
+   if (viol)
+   {
+      if ((unsigned int) viol) atomicOr(&colmask_s[0], (unsigned int) viol);
+      if ((unsigned int)(viol >> 32)) atomicOr(&colmask_s[1], (unsigned int)(viol >> 32));
+   }
+   __syncthreads();
+   phase_mark<real>(b, E, 3);
+
+   // joint-limit projection (chomp.c:608-655)
+   int num_limadjs = 0;
+   bool lim_done = false;
+#ifdef ORC_ABLATE_LIM
+   const unsigned long long viol_cols = 0ull;      // timing experiments: no joint-limit rounds
+#else
+   const unsigned long long viol_cols = ((unsigned long long) colmask_s[1] << 32) | colmask_s[0];      // workgroup-uniform
+#endif
+   if (b.solve_mode == 2 && n <= 64 && !b.lim_generic)
+   {
+      lim_done = true;
+      if (viol_cols != 0ull)
+      {
+         // one wavefront makes all rounds (no barrier inside them), the others wait here
+         if (tid < 64)
+         {
+            const real kinv = (real)(-1) / ((real)(m + 1) * b.a_off);      // 1/((m+1) ca), ca = -a_off
+            const LimResult lr = (GS16 || b.t_in_lds) ? limit_rounds_call<real>(T_s, G_s, jl_s, m, n, kinv, viol_cols)
+                                                      : limit_rounds_call_global<real>(T_s, G_s, jl_s, m, n, kinv, viol_cols);
+            if (b.phase_cycles && tid == 0) E.phc_s[7] += lr.kinds;
+            if (tid == 0) redi[0] = lr.rounds;
+         }
+         __syncthreads();
+         num_limadjs = redi[0];
+         __syncthreads();             // redi is reused by the reductions below
+      }
+   }
+   if (!lim_done)
+   for (; num_limadjs<1000; num_limadjs++)
+   {
+      real best = 0; int best_e = 0x7fffffff;
+      for (int e=tid; e<mn; e+=BLOCK)
+      {
+         const int i = div_n(e, rn_f), c = e - i*n;
+         const real t = T_s[n + e];
+         real gj = 0;
+         if (t < jl_s[c]) gj = jl_s[c] - t;
+         if (t > jl_s[n+c]) gj = jl_s[n+c] - t;
+         G_s[e] = gj;
+         const real a = M<real>::fabs_(gj);
+         if (a > best) { best = a; best_e = e; }
+      }
+      // workgroup arg-max, ties to the smallest index (first in row-major scan)
+      wave_argmax(best, best_e);
+      __syncthreads();
+      if ((tid & 63) == 0) { red[tid >> 6] = (double) best; redi[tid >> 6] = best_e; }
+      __syncthreads();
+      double gb = red[0]; int ge = redi[0];
+#pragma unroll
+      for (int w=1; w<BLOCK/64; w++)
+         if (red[w] > gb || (red[w] == gb && redi[w] < ge)) { gb = red[w]; ge = redi[w]; }
+      if (gb == 0.0) break;                  // nothing violated anywhere in the workgroup
+      const int gi = div_n(ge, rn_f), gc = ge - gi*n;
+      const real gl = G_s[ge];               // Gjlimit[largest]
+
+      // GA = A^-1 Gjlimit.  Gjlimit is sparse (a few violated entries): for the tridiagonal
+      // Toeplitz metric (D == 1) the columns of A^-1 are known in closed form,
+      //    Ainv[i][k] = (min(i,k)+1) (m - max(i,k)) / ((m+1) ca),   A = ca tridiag(-1,2,-1),
+      // so GA is a short sum per element instead of a full solve.
+      bool sparse_done = false;
+      if (b.D == 1 && b.solve_mode != 1)
+      {
+         const int K = (mn + BLOCK - 1) / BLOCK;       // elements per thread
+         int * cnt = (int *) W_s;                               // [K][waves] counts per (slice, wave)
+         int * lst = cnt + 64;                                  // [64][2]  (row, column) of a violated entry
+         real * lval = (real *)(lst + 128);                     // [64] its Gjlimit value
+         const int lane = tid & 63, wave = tid >> 6;
+         if (K <= 16)
+         {
+            for (int k=0; k<K; k++)
+            {
+               const int e = tid + k*BLOCK;
+               const bool v = (e < mn) && (G_s[e] != (real)0);
+               const unsigned long long mask = __ballot(v);
+               if (lane == 0) cnt[k*(BLOCK/64) + wave] = __popcll(mask);
+            }
+            __syncthreads();
+            int total = 0;
+            for (int q=0; q<K*(BLOCK/64); q++) total += cnt[q];
+            if (total <= 64)
+            {
+               for (int k=0; k<K; k++)
+               {
+                  const int e = tid + k*BLOCK;
+                  const bool v = (e < mn) && (G_s[e] != (real)0);
+                  const unsigned long long mask = __ballot(v);
+                  if (v)
+                  {
+                     int off = 0;
+                     for (int q=0; q<k*(BLOCK/64) + wave; q++) off += cnt[q];
+                     off += __popcll(mask & ((1ull << lane) - 1ull));
+                     const int i = div_n(e, rn_f);
+                     lst[2*off] = i; lst[2*off+1] = e - i*n;
+                     lval[off] = G_s[e];
+                  }
+               }
+               __syncthreads();
+               const real kinv = (real)(-1) / ((real)(m + 1) * b.a_off);     // 1/((m+1) ca), ca = -a_off
+               // the entry the scale is taken from
+               real ga_l = 0;
+               for (int v=0; v<total; v++)
+               {
+                  const int iv = lst[2*v], cv = lst[2*v+1];
+                  if (cv == gc)
+                  {
+                     const int lo = iv < gi ? iv : gi, hi = iv < gi ? gi : iv;
+                     ga_l += lval[v] * (real)((lo + 1) * (m - hi));
+                  }
+               }
+               const real sc = (real)1.01 * gl / (ga_l * kinv);
+               for (int e=tid; e<mn; e+=BLOCK)
+               {
+                  const int i = div_n(e, rn_f), c = e - i*n;
+                  real ga = 0;
+                  for (int v=0; v<total; v++)
+                  {
+                     const int iv = lst[2*v], cv = lst[2*v+1];
+                     if (cv == c)
+                     {
+                        const int lo = iv < i ? iv : i, hi = iv < i ? i : iv;
+                        ga += lval[v] * (real)((lo + 1) * (m - hi));
+                     }
+                  }
+                  T_s[n + e] += sc * (ga * kinv);
+               }
+               __syncthreads();
+               sparse_done = true;
+            }
+         }
+      }
+      if (!sparse_done)
+      {
+         __syncthreads();
+         real * GA = metric_solve<real, BLOCK>(b, pcr_tab, G_s, W_s);
+         const real sc = (real)1.01 * gl / GA[ge];
+         __syncthreads();
+         for (int e=tid; e<mn; e+=BLOCK) T_s[n + e] += sc * GA[e];
+         __syncthreads();
+      }
+   }
+   phase_mark<real>(b, E, 4);
+   if (b.phase_cycles && tid == 0) E.phc_s[6] += num_limadjs;   // rounds (phc[7]: kinds of rounds, see LimResult)
+   return num_limadjs;
+}
+
+// ---- the two costs of a pass: obstacle cost of the trajectory the gradient was taken at
+// (chomp.c:484-491: the sum the cost phase left in the lanes, over m) and smoothness cost of the
+// (updated) trajectory (chomp.c:660-677): 0.5 tr(T^T A T) + tr(B^T T) + trC, evaluated before the
+// quaternion renormalisation of the same iteration, as in the reference (cd_chomp_iterate returns
+// before mod.cpp:2806-2808 runs); then that renormalisation.
+struct PassCosts { double obs, smooth; };
+template <typename real, bool GS16, int BLOCK>
+__device__ __attribute__((noinline)) PassCosts phase_costs(const void * kp, int do_iteration_in, double cost_lane)
+{
+   KArg<real> & b = *uniform_kernarg<real>(kp);
+   const bool do_iteration = uni(do_iteration_in) != 0;
+   const Env<real> E = make_env<real, GS16>(b, orc_smem);
+   const int tid = threadIdx.x;
+   const int n = b.n, m = b.m, np = b.n_points, mn = m*n;
+   const float rn_f = 1.0f / (float) n;
+   const real * T_s = E.T_s;
+   PassCosts pc;
+   __builtin_amdgcn_s_setprio(3);
+   {
+      double acc = 0.0;
+      for (int e=tid; e<mn; e+=BLOCK)
+      {
+         const int i = div_n(e, rn_f), c = e - i*n;
+         const real sg = smooth_grad<real>(b, T_s, i, c);     // (A T + B)
+         const real bt = (b.D == 1) ? b.a_off * ((i == 0 ? T_s[c] : (real)0) + (i == m-1 ? T_s[(np-1)*n + c] : (real)0))
+                                    : b.beta_s[i] * T_s[c] + b.beta_g[i] * T_s[(np-1)*n + c];
+         acc += (double) T_s[n + e] * (0.5 * ((double) sg + (double) bt));
+      }
+      double ss = 0.0, sg2 = 0.0, gg = 0.0;
+      if (tid < n)
+      {
+         const double s0 = (double) T_s[tid], g0 = (double) T_s[(np-1)*n + tid];
+         ss = s0*s0; sg2 = s0*g0; gg = g0*g0;
+      }
+      acc += 0.5 * (b.kss*ss + 2.0*b.ksg*sg2 + b.kgg*gg);
+      // both sums through one pair of barriers
+      const double a = wave_sum(cost_lane), c2 = wave_sum(acc);
+      __syncthreads();
+      if ((tid & 63) == 0) { E.red[tid >> 6] = a; E.red[4 + (tid >> 6)] = c2; }
+      __syncthreads();
+      if (BLOCK == 192) { pc.obs = (E.red[0] + E.red[1]) + E.red[2]; pc.smooth = (E.red[4] + E.red[5]) + E.red[6]; }
+      else { pc.obs = (E.red[0] + E.red[1]) + (E.red[2] + E.red[3]); pc.smooth = (E.red[4] + E.red[5]) + (E.red[6] + E.red[7]); }
+      pc.obs /= (double) m;
+   }
+   phase_mark<real>(b, E, 5);
+
+   // floating base: renormalise the quaternion of every row (mod.cpp:2806-2808)
+   if (do_iteration && E.mod.floating)
+   {
+      real * Tw = E.T_s;
+      for (int w=tid; w<np; w+=BLOCK)
+      {
+         real * row = Tw + w*n;
+         const real len = M<real>::sqrt_(row[3]*row[3] + row[4]*row[4] + row[5]*row[5] + row[6]*row[6]);
+         const real inv = (real)1 / len;
+         row[3] *= inv; row[4] *= inv; row[5] *= inv; row[6] *= inv;
+      }
+      __syncthreads();
+   }
+   return pc;
+}
+
+// ---- write back: trajectory, momentum, costs, status ----
+template <typename real, bool GS16, int BLOCK>
+__device__ __attribute__((noinline)) void phase_finish(const void * kp, int status_in, int iters_done_in, int leapfrog_first_in, int have_costs_in,
+   double done_obs, double done_smooth)
+{
+   KArg<real> & b = *uniform_kernarg<real>(kp);
+   const int status = uni(status_in), iters_done = uni(iters_done_in), leapfrog_first = uni(leapfrog_first_in), have_costs = uni(have_costs_in);
+   const Env<real> E = make_env<real, GS16>(b, orc_smem);
+   const int run = blockIdx.x, tid = threadIdx.x;
+   const int n = b.n, m = b.m, np = b.n_points, mn = m*n;
+   __syncthreads();
+   if (GS16 || b.t_in_lds) for (int e=tid; e<np*n; e+=BLOCK) E.traj_g[e] = E.T_s[e];
+   if (b.use_momentum && b.ag_in_lds) for (int e=tid; e<mn; e+=BLOCK) E.AG_g[e] = E.AG_s[e];
    if (tid == 0)
    {
-      if (b.phase_cycles) for (int k=0; k<8; k++) b.phase_cycles[(size_t) run*8 + k] = ph[k];
-      if (b.phase_cycles && b.lim_generic == 2) for (int k=0; k<4; k++) b.phase_cycles[(size_t) run*8 + 2 + k] = gdbg[k];
+      if (b.phase_cycles) for (int k=0; k<8; k++) b.phase_cycles[(size_t) run*8 + k] = E.phc_s[k];
       // an aborted run reports the costs of its last complete pass (none in this launch: what it had)
       if (have_costs)
       {
@@ -1264,6 +1338,86 @@ void chomp_iterate_kernel(const DevBatch<real> b)
    if (b.trace && status != 0)
       for (int e=iters_done*3 + tid; e<b.n_iter*3; e+=BLOCK)
          b.trace[(size_t) run * b.n_iter * 3 + e] = __longlong_as_double(0x7ff8000000000000LL);
+}
+
+// ---------------------------------------------------------------------------
+// The kernel: one workgroup = one run for all iterations of the launch; the loop below only
+// sequences the phase functions and carries the few scalars that cross iterations.
+template <typename real, bool TREE, bool GS16, int BLOCK>
+__global__ __launch_bounds__(BLOCK, ORC_WGS_PER_CU)      // second argument: wavefronts per SIMD (3 x 4 SIMDs = 12 per CU, as 3 x 256 or 4 x 192 threads)
+void chomp_iterate_kernel(const DevBatch<real> b)
+{
+   const void * kp = (const void *) __builtin_amdgcn_kernarg_segment_ptr();      // DevBatch b is the kernel's only argument
+   const int run = blockIdx.x;
+   const int tid = threadIdx.x;
+   const int m = b.m, tile_m = b.tile_m;
+
+   phase_setup<real, TREE, GS16, BLOCK>(kp);
+
+   int leapfrog_first = b.leapfrog_first[run];
+   // every iterate call starts afresh: the reference throws out of the call in which a run leaves
+   // its joint limits, the run itself stays usable (src/orcdchomp_mod.cpp:2799-2803)
+   int status = 0;
+   int next_resample = 0;      // index into this call's resample list
+
+   // co-resident workgroups that start in lockstep stay in lockstep (all in the one-wave FK phase
+   // together, then all in the cost phase): delaying every other one interleaves their phases
+   if (b.stagger_mode)
+   {
+      const bool late = (b.stagger_mode == 1) ? (blockIdx.x & 1) : ((blockIdx.x >> 8) & 1);
+      if (late) for (int k=0; k<b.stagger_sleeps; k++) __builtin_amdgcn_s_sleep(127);
+   }
+
+   // costs of the last pass that ran to its end, and the iterations completed by this launch
+   double done_obs = 0.0, done_smooth = 0.0;
+   int have_costs = 0;
+   int iters_done = 0;
+   const int total_passes = b.n_iter + (b.final_eval ? 1 : 0);
+
+   for (int it=0; it<total_passes; it++)
+   {
+      const bool do_iteration = (it < b.n_iter);
+
+      // ---- hmc momentum resample (src/orcdchomp_mod.cpp:2755-2768) ----------
+      if (do_iteration && b.use_hmc && b.use_momentum && next_resample < b.max_resamples
+          && b.hmc_iters[(size_t) run * b.max_resamples + next_resample] == it)
+      {
+         phase_hmc<real, GS16, BLOCK>(kp, next_resample);
+         leapfrog_first = 1;
+         next_resample++;
+      }
+
+      double cost_lane = 0.0;
+      for (int ts=0; ts<m; ts+=tile_m)
+      {
+         const int te = (ts + tile_m < m) ? ts + tile_m : m;
+         phase_fk<real, TREE, GS16, BLOCK>(kp, ts, te);
+         cost_lane = phase_cost<real, TREE, GS16, BLOCK>(kp, ts, te, do_iteration ? 1 : 0, cost_lane);
+      } // tiles
+
+      if (do_iteration)
+      {
+         const int num_limadjs = phase_update<real, TREE, GS16, BLOCK>(kp, it, leapfrog_first);
+         if (b.use_momentum) leapfrog_first = 0;
+         if (!(num_limadjs < 1000)) status = -1;
+      }
+      // "ran too many joint limit fixes! aborting ..." (chomp.c:651-655): cd_chomp_iterate returns
+      // before the smoothness cost, mod::iterate throws before the quaternion renormalisation and
+      // the log line; the trajectory keeps what the limit rounds made of it (workgroup-uniform)
+      if (status != 0) break;
+
+      const PassCosts pc = phase_costs<real, GS16, BLOCK>(kp, do_iteration ? 1 : 0, cost_lane);
+
+      if (tid == 0 && b.trace && do_iteration)
+      {
+         double * tr = b.trace + ((size_t) run * b.n_iter + it) * 3;
+         tr[0] = pc.obs + pc.smooth; tr[1] = pc.obs; tr[2] = pc.smooth;
+      }
+      done_obs = pc.obs; done_smooth = pc.smooth; have_costs = 1;
+      if (do_iteration) iters_done++;
+   }
+
+   phase_finish<real, GS16, BLOCK>(kp, status, iters_done, leapfrog_first, have_costs, done_obs, done_smooth);
 }
 
 // straight-line seeding of every run (src/orcdchomp_mod.cpp:2417-2464):

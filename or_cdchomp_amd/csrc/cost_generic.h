@@ -19,8 +19,8 @@
 //       a fixed summation order.
 #pragma once
 
-template <typename real, int BLOCK>
-__device__ __forceinline__ void cost_tile_generic(const DevBatch<real> & b, const ModelView<real> & mod,
+template <typename real, int BLOCK, typename BT>
+__device__ __forceinline__ void cost_tile_generic(const BT & b, const ModelView<real> & mod,
    const DevSdf<real> * sdfs, int ts, int te, bool do_iteration, const real * T_s, real * Gc, const real * pos_s, const real * ax_s,
    const real * srad_s, const real * sinact_s, const int * slink_s, const int * jtype_s, const int * jcol_s,
    int pstr, int astr, real inv_eps, real inv_eps_self, double & cost_lane, long long * dbg)

@@ -183,8 +183,8 @@ __device__ __forceinline__ void self_sym_step16(const real * prow, const real * 
    }
 }
 
-template <typename real, int U, int BLOCK>
-__device__ __forceinline__ void cost_tile_gs16(const DevBatch<real> & b, const ModelView<real> & mod,
+template <typename real, int U, int BLOCK, typename BT>
+__device__ __forceinline__ void cost_tile_gs16(const BT & b, const ModelView<real> & mod,
    const DevSdf<real> * sdfs, int ts, int te, bool do_iteration, const real * T_s, real * G_s, const real * pos_s, const real * ax_s,
    const real * srad_s, const real * sinact_s, const real * r2_s, const int * slink_s, const int * jtype_s, const int * jcol_s,
    real inv_eps, real inv_eps_self, double & cost_lane)

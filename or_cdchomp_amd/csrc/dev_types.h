@@ -15,6 +15,7 @@
 #define ORC_WGS_PER_CU    3       // resident workgroups per CU the kernels' register budget is sized for (launch bounds)
 #endif
 #define ORC_SCAN_RPL      4       // rows per lane of the scan solve: m <= 64*ORC_SCAN_RPL
+#define ORC_LDS_HEADER    192     // bytes in front of the LDS carve-up: reduction scratch [8] doubles + [8] ints, column masks, phase counters [8]
 #define ORC_LIM_LIST      64      // violated entries the sparse joint-limit rounds handle
 #define ORC_LIM_SCRATCH  (256 + ORC_LIM_LIST*16)   // bytes: 4 wave records + header, entry list
 
@@ -157,7 +158,7 @@ struct DevVerdict
 };
 
 // LDS carve-up of one workgroup, shared by the kernel and the host-side size computation.
-// Offsets are in units of `real` after a 128-byte header (reduction scratch).
+// Offsets are in units of `real` after a header of ORC_LDS_HEADER bytes (reduction scratch).
 struct LdsLayout
 {
    int T, G, W, AG, pos, ax, srad, sinact, jl, pcr, r2, end_reals;
@@ -225,13 +226,13 @@ inline LdsLayout lds_layout(int np, int n, int Sa, int S, int nj, int tile_m, in
    L.pcr = take(pcr_rows*m);
    (void) take(Sa*3 + 12);                 // staged sphere local positions + base frame (after pcr)
    L.end_reals = o;
-   L.ints_bytes = 128 + o*real_size;
+   L.ints_bytes = ORC_LDS_HEADER + o*real_size;
    int bytes = L.ints_bytes + (S + 2*nj + 4 + Sa) * (int) sizeof(int);     // slink, jtype, jcol, slot_of
    bytes = (bytes + 15) & ~15;
    L.joints_bytes = bytes; bytes += nj * joint_size; bytes = (bytes + 15) & ~15;
    L.sdfs_bytes = bytes;   bytes += n_sdfs * sdf_size; bytes = (bytes + 15) & ~15;
    L.saff_bytes = bytes;   bytes += Sa * 8;
-   if (alias) L.lim_bytes = 128 + (L.pos + work_reals) * real_size;
+   if (alias) L.lim_bytes = ORC_LDS_HEADER + (L.pos + work_reals) * real_size;
    else { L.lim_bytes = bytes; bytes += ORC_LIM_SCRATCH; }
    L.total_bytes = (g_global && !alias) ? (1 << 30) : bytes;      // G in the tile buffers needs tiles that hold it
    return L;
