@@ -591,6 +591,9 @@ void BatchShard::build_device(const Robot & robot)
    nj_ = nj; Sa_ = lanes; S_ = lanes + (int) inact.size(); GS_ = M.GS; tree_ = M.tree | ((M.GS == 16) ? 2 : 0);     // kernel variant bits
 
    hipStream_t st = stream_;
+   ms_.nj = M.nj; ms_.floating = M.floating; ms_.tree = M.tree; ms_.Sa = M.Sa; ms_.S = M.S; ms_.Sa_real = M.Sa_real; ms_.placed = M.placed;
+   ms_.GS = M.GS; ms_.base_sph_begin = M.base_sph_begin; ms_.base_sph_end = M.base_sph_end; ms_.jt_scan = M.jt_scan; ms_.pad_ = 0;
+   ms_.live_mask = M.live_mask;
    DevModel<real> * dm = dev_alloc<DevModel<real>>(1);
    hip_check(hipMemcpyAsync(dm, &M, sizeof(M), hipMemcpyHostToDevice, st), "model");
    hip_check(hipStreamSynchronize(st), "model sync");
@@ -921,6 +924,9 @@ void BatchShard::launch(int n_iter, bool final_eval)
    b.tile_m = tile_m_;
    b.traj = (real *) d_traj_; b.AG = (real *) d_AG_; b.Gdbg = (real *) d_G_; b.Gcost = (real *) d_Gcost_;
    b.g_in_lds = g_in_lds_; b.lds_flags = lds_flags_; b.t_in_lds = t_in_lds_;
+   b.ms = ms_;
+   b.lay = lds_layout(n_points, n, Sa_, S_, nj_, tile_m_, pcr_in_lds_ ? pcr_rows_ : 0, (int) sizeof(real),
+                      params.use_momentum && ag_in_lds_, n_sdfs_, (int) sizeof(DevJoint<real>), (int) sizeof(DevSdf<real>), lds_flags_);
    b.costs = d_costs_; b.trace = d_trace_; b.status = d_status_; b.iters_done = d_iters_done_; b.leapfrog_first = d_leap_;
    const double dt = 1.0/(n_points-1);
    b.dt = (real) dt;

@@ -847,12 +847,10 @@ template <typename real, bool GS16, typename BT>
 __device__ __forceinline__ Env<real> make_env(const BT & b, unsigned char * smem_raw)
 {
    Env<real> E;
-   KModel<real> & gmod = *(KModel<real> *) b.model;      // scalar loads
    const int run = blockIdx.x;
    const int n = b.n, m = b.m, np = b.n_points, mn = m*n;
-   const int nj = gmod.nj, Sa = gmod.Sa, S = gmod.S;
-   const LdsLayout L = lds_layout(np, n, Sa, S, nj, b.tile_m, b.pcr_in_lds ? b.pcr_rows : 0, (int) sizeof(real),
-                                  b.use_momentum && b.ag_in_lds, b.n_sdfs, (int) sizeof(DevJoint<real>), (int) sizeof(DevSdf<real>), b.lds_flags);
+   const int nj = b.ms.nj, Sa = b.ms.Sa, S = b.ms.S;
+   const auto & L = b.lay;          // computed on the host (lds_layout, dev_types.h)
    E.red = (double *) smem_raw;                            // [8] reduction scratch
    E.redi = (int *)(E.red + 8);                            // [8]
    E.colmask_s = (unsigned int *)(E.redi + 8);             // [2] columns with an entry outside its joint limits after the step
@@ -884,9 +882,9 @@ __device__ __forceinline__ Env<real> make_env(const BT & b, unsigned char * smem
    E.sdfs_s = (DevSdf<real> *)(smem_raw + L.sdfs_bytes);
    E.saff_s = (unsigned long long *)(smem_raw + L.saff_bytes);
    ModelView<real> & mod = E.mod;
-   mod.nj = nj; mod.n = n; mod.floating = gmod.floating; mod.tree = gmod.tree; mod.Sa = Sa; mod.S = S; mod.GS = gmod.GS; mod.jt_scan = gmod.jt_scan;
-   mod.Sa_real = gmod.Sa_real; mod.placed = gmod.placed; mod.live_mask = gmod.live_mask; mod.slot_of = E.slot_s;
-   mod.base_sph_begin = gmod.base_sph_begin; mod.base_sph_end = gmod.base_sph_end;
+   mod.nj = nj; mod.n = n; mod.floating = b.ms.floating; mod.tree = b.ms.tree; mod.Sa = Sa; mod.S = S; mod.GS = b.ms.GS; mod.jt_scan = b.ms.jt_scan;
+   mod.Sa_real = b.ms.Sa_real; mod.placed = b.ms.placed; mod.live_mask = b.ms.live_mask; mod.slot_of = E.slot_s;
+   mod.base_sph_begin = b.ms.base_sph_begin; mod.base_sph_end = b.ms.base_sph_end;
    mod.base_R = E.base_s; mod.base_t = E.base_s + 9;
    mod.joints = E.joints_s; mod.sph_pos = (const real (*)[3]) E.sphpos_s; mod.sph_affects = E.saff_s;
    E.AG_g = b.AG + (size_t) run * mn;
@@ -1391,8 +1389,12 @@ void chomp_iterate_kernel(const DevBatch<real> b)
       for (int ts=0; ts<m; ts+=tile_m)
       {
          const int te = (ts + tile_m < m) ? ts + tile_m : m;
+#ifndef ORC_ABLATE_FK
          phase_fk<real, TREE, GS16, BLOCK>(kp, ts, te);
+#endif
+#ifndef ORC_ABLATE_COST
          cost_lane = phase_cost<real, TREE, GS16, BLOCK>(kp, ts, te, do_iteration ? 1 : 0, cost_lane);
+#endif
       } // tiles
 
       if (do_iteration)

@@ -126,8 +126,8 @@ __device__ __forceinline__ void sdf_combine(const DevSdf<real> & f, const SdfCel
 // flags: bit 0 live, bit 1 moving.  The obstacle cost of both sides is summed where it is
 // computed (the per-run cost is a sum over all lanes anyway).
 template <typename real, int K>
-__device__ __forceinline__ void self_sym_step16(const real * prow, const real * r2row, int srow, int flags, const real p[3],
-   real radius, const real vel[3], real inv_vn2, real wself, real eps_self, real inv_eps_self, bool do_iteration,
+__device__ __forceinline__ void self_sym_step16(const real * prow, const real * r2row, int srow, unsigned long long live_lanes, const real p[3],
+   real radius, const real u[3], real wself, real eps_self, real inv_eps_self, bool do_iteration,
    real f[3], double & cost_sphere)
 {
    constexpr int F = 0x120 + K, B = 0x120 + (16 - K);     // row_ror:K and its inverse
@@ -138,18 +138,17 @@ __device__ __forceinline__ void self_sym_step16(const real * prow, const real * 
    for (int k=0; k<3; k++) d[k] = p[k] - pp[k];
    const real d2 = d[0]*d[0] + d[1]*d[1] + d[2]*d[2];
    const real R2 = r2row[(K-1)*16 + srow];
-   const bool near = (flags & 1) && (d2 <= R2);
-   if (__ballot(near) == 0ull) return;                     // wave-uniform
+   const unsigned long long near_lanes = __builtin_amdgcn_ballot_w64(d2 <= R2) & live_lanes;      // wave-uniform
+   if (near_lanes == 0ull) return;
 #ifdef ORC_ABLATE_ROTF
-   { const unsigned long long bl_ = __ballot(near); __asm__ volatile("" :: "s"(bl_)); return; }      // timing experiments: range tests only
+   { __asm__ volatile("" :: "s"(near_lanes)); return; }      // timing experiments: range tests only
 #endif
+   const bool near = (near_lanes >> (threadIdx.x & 63)) & 1ull;
    const real ro = dpp_move<F>(radius);
-   real vo[3];
+   real uo[3];
 #pragma unroll
-   for (int k=0; k<3; k++) vo[k] = dpp_move<F>(vel[k]);
+   for (int k=0; k<3; k++) uo[k] = dpp_move<F>(u[k]);
    const real wo = dpp_move<F>(wself);
-   const real ivo = dpp_move<F>(inv_vn2);
-   const bool mo = (dpp_move<F>(flags) & 2) != 0;
    // shared part of the pair
    real inv_d;
    real dist = sqrt_rsq(near ? d2 : (real)1, &inv_d);
@@ -164,20 +163,18 @@ __device__ __forceinline__ void self_sym_step16(const real * prow, const real * 
    if (do_iteration)
    {
       // forces of both sides, x_ab = s w_a (d - (d.v_a) v_a/|v_a|^2) on this sphere and
-      // x_ba = -s w_b (d - (d.v_b) v_b/|v_b|^2) on the partner; the net force on this lane's sphere is
-      // x_ab - x_ba = s (w_a + w_b) d - pa v_a - pb v_b, and the partner receives the opposite
-      real pa = d[0]*vel[0], pb = d[0]*vo[0];
-      pa = fma(d[1], vel[1], pa); pb = fma(d[1], vo[1], pb);
-      pa = fma(d[2], vel[2], pa); pb = fma(d[2], vo[2], pb);
-      // projections (d . v) s w / |v|^2, zero when that sphere is (nearly) at rest
-      pa = (flags & 2) ? pa * (sdi * wself) * inv_vn2 : (real)0;
-      pb = mo ? pb * (sdi * wo) * ivo : (real)0;
-      const real sboth = sdi * wboth;
+      // x_ba = -s w_b (d - (d.v_b) v_b/|v_b|^2) on the partner.  With u = v sqrt(w/|v|^2) (zero for a
+      // sphere (nearly) at rest) the net force on this lane's sphere is
+      //    x_ab - x_ba = s/|d| ((w_a + w_b) d - (d.u_a) u_a - (d.u_b) u_b),
+      // and the partner receives the opposite
+      real qa = d[0]*u[0], qb = d[0]*uo[0];
+      qa = fma(d[1], u[1], qa); qb = fma(d[1], uo[1], qb);
+      qa = fma(d[2], u[2], qa); qb = fma(d[2], uo[2], qb);
 #pragma unroll
       for (int k=0; k<3; k++)
       {
          // (selected, not multiplied by zero: lanes without a pair may hold anything, an empty slot's centre included)
-         const real inc = near ? fma(d[k], sboth, -fma(pa, vel[k], pb * vo[k])) : (real)0;
+         const real inc = near ? sdi * fma(d[k], wboth, -fma(qa, u[k], qb * uo[k])) : (real)0;
          f[k] += (K == 8) ? inc : (inc - dpp_move<B>(inc));
       }
    }
@@ -210,7 +207,7 @@ __device__ __forceinline__ void cost_tile_gs16(const BT & b, const ModelView<rea
       const int mylink = lane_ok ? slink_s[ss] : -1 - s;
       bool live[U]; int wl[U], l[U];
       real p[U][3], vel[U][3], acc[U][3], f[U][3];
-      real vnorm[U], inv_vn2[U], wself[U];
+      real vnorm[U], inv_vn2[U], wself[U], uvec[U][3];
       bool moving[U];
       double cost_sphere[U];
 #pragma unroll
@@ -238,6 +235,12 @@ __device__ __forceinline__ void cost_tile_gs16(const BT & b, const ModelView<rea
          moving[u] = vnorm[u] > (real)0.000001;
          wself[u] = vnorm[u] * b.obs_factor_self;
          cost_sphere[u] = 0.0;
+         // u = v sqrt(w/|v|^2) = v sqrt(obs_factor_self/|v|): (d.u) u = w (d.v) v/|v|^2, the projection
+         // term of the self-collision forces (src/orcdchomp_mod.cpp:1299-1303); zero at rest
+         real sinv;
+         const real su = sqrt_rsq(moving[u] ? b.obs_factor_self * inv_vn : (real)0, &sinv);
+#pragma unroll
+         for (int k=0; k<3; k++) uvec[u][k] = vel[u][k] * su;
       }
 
       // ---- obstacle term (src/orcdchomp_mod.cpp:1171-1246) ----
@@ -353,9 +356,9 @@ __device__ __forceinline__ void cost_tile_gs16(const BT & b, const ModelView<rea
 #pragma unroll
       for (int u=0; u<U; u++)
       {
-         const int flags = (live[u] ? 1 : 0) | (moving[u] ? 2 : 0);
+         const unsigned long long live_lanes = __builtin_amdgcn_ballot_w64(live[u]);
          const real * prow = pos_s + l[u]*pstr;
-#define ORC_STEP(K) self_sym_step16<real, K>(prow, r2_s, s, flags, p[u], radius, vel[u], inv_vn2[u], wself[u], \
+#define ORC_STEP(K) self_sym_step16<real, K>(prow, r2_s, s, live_lanes, p[u], radius, uvec[u], wself[u], \
                        b.epsilon_self, inv_eps_self, do_iteration, f[u], cost_sphere[u])
          ORC_STEP(1); ORC_STEP(2); ORC_STEP(3); ORC_STEP(4); ORC_STEP(5); ORC_STEP(6); ORC_STEP(7); ORC_STEP(8);
 #undef ORC_STEP

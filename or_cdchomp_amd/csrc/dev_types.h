@@ -85,9 +85,30 @@ struct DevSdf
    real Rwg[9];            // grid -> world rotation (pose_world_gsdf), for the gradient
 };
 
+// the scalars of DevModel the phase functions branch on, and the LDS carve-up: carried in the
+// kernarg block so that a phase function has them after one scalar load (LdsLayout is declared below)
+struct ModelScalars
+{
+   int nj, floating, tree, Sa, S, Sa_real, placed, GS, base_sph_begin, base_sph_end, jt_scan, pad_;
+   unsigned long long live_mask;
+};
+struct LdsLayout
+{
+   int T, G, W, AG, pos, ax, srad, sinact, jl, pcr, r2, end_reals;
+   int lim_bytes;          // byte offset of the joint-limit scratch (ORC_LIM_SCRATCH bytes)
+   int pstr, astr;         // waypoint strides of pos / ax: odd, so that lane = waypoint accesses (FK) hit distinct LDS banks
+   int ints_bytes;         // byte offset of the int tables (slink, jtype, jcol)
+   int joints_bytes;       // byte offset of the staged DevJoint[nj]
+   int sdfs_bytes;         // byte offset of the staged DevSdf[n_sdfs]
+   int saff_bytes;         // byte offset of the staged affects masks [Sa]
+   int total_bytes;
+};
+
 template <typename real>
 struct DevBatch
 {
+   ModelScalars ms;        // = the scalars of *model
+   LdsLayout lay;          // = lds_layout(...) of this launch
    const DevModel<real> * model;
    const DevSdf<real> * sdfs;
    int n_sdfs;
@@ -157,19 +178,9 @@ struct DevVerdict
    double * depth_out;         // [n_runs] penetration depth of that contact
 };
 
-// LDS carve-up of one workgroup, shared by the kernel and the host-side size computation.
+// LDS carve-up of one workgroup (struct LdsLayout above), computed on the host (lds_layout below)
+// and handed to the kernels in the kernarg block.
 // Offsets are in units of `real` after a header of ORC_LDS_HEADER bytes (reduction scratch).
-struct LdsLayout
-{
-   int T, G, W, AG, pos, ax, srad, sinact, jl, pcr, r2, end_reals;
-   int lim_bytes;          // byte offset of the joint-limit scratch (ORC_LIM_SCRATCH bytes)
-   int pstr, astr;         // waypoint strides of pos / ax: odd, so that lane = waypoint accesses (FK) hit distinct LDS banks
-   int ints_bytes;         // byte offset of the int tables (slink, jtype, jcol)
-   int joints_bytes;       // byte offset of the staged DevJoint[nj]
-   int sdfs_bytes;         // byte offset of the staged DevSdf[n_sdfs]
-   int saff_bytes;         // byte offset of the staged affects masks [Sa]
-   int total_bytes;
-};
 
 // what the kernels read of the robot, staged in LDS at kernel start (global reads of the
 // model inside the iteration loop cost a full memory round trip each)

@@ -151,6 +151,7 @@ private:
    int max_resamples_ = 0;
    bool debug_state_ = false;   // ORC_DEBUG_STATE=1: keep the last gradient readable (get_state "G")
    int n_sdfs_ = 0;
+   ModelScalars ms_ = {};             // the device model's scalars (carried in the kernarg block)
    int Sa_real_ = 0;                  // active spheres
    int nj_ = 0, Sa_ = 0, S_ = 0;      // optimized joints; lanes of the active sphere block; lanes + inactive spheres
    int tile_m_ = 0;
