@@ -513,6 +513,7 @@ void BatchShard::build_device(const Robot & robot)
       J.packed = (J.type & 3) | ((J.axis_kind & 3) << 2) | ((J.rfix_identity & 1) << 4) | ((J.axis_sign < 0 ? 1 : 0) << 5)
                | ((J.sph_begin & 255) << 8) | ((J.sph_end & 255) << 16) | ((J.col & 127) << 24);
       J.packed2 = ((J.load_slot + 2) & 15) | (((J.save_slot + 2) & 15) << 4);
+      M.jpacked[k] = J.packed; M.jpacked2[k] = J.packed2;
    }
    // which spheres a joint moves, as a range of the device order (J^T through wrench suffix sums)
    M.jt_scan = 1;

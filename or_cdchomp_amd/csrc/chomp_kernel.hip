@@ -887,6 +887,10 @@ __device__ __forceinline__ Env<real> make_env(const BT & b, unsigned char * smem
    mod.base_sph_begin = b.ms.base_sph_begin; mod.base_sph_end = b.ms.base_sph_end;
    mod.base_R = E.base_s; mod.base_t = E.base_s + 9;
    mod.joints = E.joints_s; mod.sph_pos = (const real (*)[3]) E.sphpos_s; mod.sph_affects = E.saff_s;
+   mod.jpk = (const __attribute__((address_space(4))) int *) b.model->jpacked;
+   mod.jpk2 = (const __attribute__((address_space(4))) int *) b.model->jpacked2;
+   mod.sph_pos_c = (const __attribute__((address_space(4))) real (*)[3]) b.model->sph_pos;
+   mod.slot_c = (const __attribute__((address_space(4))) int *) b.model->slot_of;
    E.AG_g = b.AG + (size_t) run * mn;
    // momentum: in LDS for the launch, or in place in global memory (every entry is read and written
    // by the same thread, e = tid + k BLOCK, in all loops that touch it)
@@ -1493,6 +1497,10 @@ void collision_verdict_kernel(DevVerdict<real> v)
    mod.Sa_real = gmod.Sa_real; mod.placed = gmod.placed; mod.live_mask = gmod.live_mask; mod.slot_of = slot_s;
    mod.base_R = base_s; mod.base_t = base_s + 9;
    mod.joints = joints_s; mod.sph_pos = (const real (*)[3]) sphpos_s; mod.sph_affects = nullptr;
+   mod.jpk = (const __attribute__((address_space(4))) int *) gmod.jpacked;
+   mod.jpk2 = (const __attribute__((address_space(4))) int *) gmod.jpacked2;
+   mod.sph_pos_c = (const __attribute__((address_space(4))) real (*)[3]) gmod.sph_pos;
+   mod.slot_c = (const __attribute__((address_space(4))) int *) gmod.slot_of;
    __syncthreads();
 
    const real * traj = v.traj + (size_t) run * np * n;

@@ -62,6 +62,8 @@ struct DevModel
    real base_R[9];         // base frame when not floating
    real base_t[3];
    DevJoint<real> joints[ORC_MAX_JOINTS];
+   int jpacked[ORC_MAX_JOINTS];          // joints[j].packed / packed2 as arrays: the FK walk reads its control words
+   int jpacked2[ORC_MAX_JOINTS];         // with scalar loads (no LDS round trip in front of every branch)
    real sph_pos[ORC_MAX_SPHERES][3];     // active, SORTED order: in the attach frame
    real sph_radius[ORC_MAX_SPHERES];
    int sph_link[ORC_MAX_SPHERES];        // robot link index (same-link test)
@@ -195,6 +197,10 @@ struct ModelView
    const DevJoint<real> * joints;          // [nj]
    const real (* sph_pos)[3];              // [Sa][3]
    const unsigned long long * sph_affects; // [Sa]
+   const __attribute__((address_space(4))) int * jpk;    // [nj] DevModel::jpacked (global memory, scalar loads)
+   const __attribute__((address_space(4))) int * jpk2;   // [nj] DevModel::jpacked2
+   const __attribute__((address_space(4))) real (* sph_pos_c)[3];   // DevModel::sph_pos (scalar loads: the FK walk's sphere tables)
+   const __attribute__((address_space(4))) int * slot_c;            // DevModel::slot_of
 };
 #if defined(__HIPCC__)
 __host__ __device__

@@ -143,23 +143,30 @@ __device__ __forceinline__ void fk_joint_row(const ModelView<real> & mod, const 
    else
       cur.t = tj + q*aw;
 #ifndef ORC_ABLATE_FKSPH
-   // four spheres per step: their table reads are issued together (one LDS round trip per step
-   // where one sphere per step pays one each)
-   for (int s0=s_begin; s0<s_end; s0+=4)
+   // The spheres riding on the joint's link.  Their table entries (centre in the link frame, slot of
+   // the position buffer) are the same for every lane: they come by scalar loads from the model in
+   // global memory, four spheres per batch, and enter the products as scalar operands.
+   // (Measured, scripts/ablate_time.sh and one workgroup alone on the chip: the walk is a chain of
+   // round trips -- 10 k cycles per pass for 1.3 k instructions; fetching the next joint's numbers
+   // and sphere tables a step ahead cost more registers and scalar code than it hid: reverted.)
+   if (store)
    {
-      real lp[4][3]; int slot[4];
-#pragma unroll
-      for (int u=0; u<4; u++)
+      for (int s0=s_begin; s0<s_end; s0+=4)
       {
-         const int su = (s0 + u < s_end) ? s0 + u : s_end - 1;
-         lp[u][0] = mod.sph_pos[su][0]; lp[u][1] = mod.sph_pos[su][1]; lp[u][2] = mod.sph_pos[su][2];
-         slot[u] = mod.slot_of[su];
-      }
+         real lp[4][3]; int slot[4];
 #pragma unroll
-      for (int u=0; u<4; u++)
-      {
-         const real o = cur.r[0]*lp[u][0] + cur.r[1]*lp[u][1] + cur.r[2]*lp[u][2] + cur.t;
-         if (store && (s0 + u < s_end)) pos_k[slot[u]*3] = o;
+         for (int u=0; u<4; u++)
+         {
+            const int su = (s0 + u < s_end) ? s0 + u : s_end - 1;
+            lp[u][0] = mod.sph_pos_c[su][0]; lp[u][1] = mod.sph_pos_c[su][1]; lp[u][2] = mod.sph_pos_c[su][2];
+            slot[u] = mod.slot_c[su];
+         }
+#pragma unroll
+         for (int u=0; u<4; u++)
+         {
+            const real o = cur.r[0]*lp[u][0] + cur.r[1]*lp[u][1] + cur.r[2]*lp[u][2] + cur.t;
+            if (s0 + u < s_end) pos_k[slot[u]*3] = o;
+         }
       }
    }
 #endif
@@ -225,8 +232,8 @@ __device__ __forceinline__ void fk_waypoint_quad(const ModelView<real> & mod, co
          if (j < nj)
          {
             const DevJoint<real> & J = mod.joints[j];
-            const int pk = __builtin_amdgcn_readfirstlane(J.packed);
-            const int pk2 = TREE ? __builtin_amdgcn_readfirstlane(J.packed2) : 0;
+            const int pk = mod.jpk[j];                    // scalar loads: the walk's branches do not wait for LDS
+            const int pk2 = TREE ? mod.jpk2[j] : 0;
             if (TREE)
             {
                // continue from the previous joint's frame unless the tree branches here
