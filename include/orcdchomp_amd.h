@@ -98,6 +98,14 @@ int orc_robot_set_active_dofs(orc_module * mod, const char * name, const int * i
 /* GetDOFVelocityLimits: used by the linear retimer of gettraj (default 1 for every dof) */
 int orc_robot_set_velocity_limits(orc_module * mod, const char * name, const double * limits, int n);
 
+/* What the TSR constraints of `create` address on the robot (src/orcdchomp_mod.cpp:1957-1976):
+ * GetLink(name) for `con_tsr 'all link NAME'`; GetManipulators() / GetActiveManipulator() and their
+ * GetEndEffectorTransform() (= end-effector link transform o tool_pose) for `'all manipee NAME'`,
+ * `'all'` and `everyn_tsr`.  The first manipulator added is the active one. */
+int orc_robot_set_link_names(orc_module * mod, const char * name, const char * const * names, int n);
+int orc_robot_add_manipulator(orc_module * mod, const char * name, const char * manip, int ee_link, const double tool_pose[7]);
+int orc_robot_set_active_manipulator(orc_module * mod, const char * name, const char * manip);
+
 /* a kinbody made of oriented boxes (InitFromBoxes-style); box_poses [n_boxes][7]
  * in the kinbody frame, half_extents [n_boxes][3] */
 int orc_env_add_kinbody_boxes(orc_module * mod, const char * name, int n_boxes,

@@ -297,7 +297,7 @@ void BatchShard::release()
    void ** all[] = { &d_model_, &d_sdfs_, &d_traj_, &d_AG_, &d_G_, (void **) &d_mt_, (void **) &d_mt_bak_, (void **) &d_hmc_next_,
                      (void **) &d_hmc_next_bak_, (void **) &d_overflow_, (void **) &d_costs_, (void **) &d_trace_, (void **) &d_status_,
                      (void **) &d_iters_done_, (void **) &d_leap_, &d_Aband_, &d_beta_s_, &d_beta_g_, &d_pcr_, &d_Ainv_, &d_jl_lo_, &d_jl_hi_,
-                     (void **) &d_hmc_iters_, &d_noise_, (void **) &d_phase_, &d_Gcost_ };
+                     (void **) &d_hmc_iters_, &d_noise_, (void **) &d_phase_, &d_Gcost_, &d_tsrs_, &d_tsr_ws_, (void **) &d_tsr_err_ };
    for (void ** p : all) { dev_free(*p); *p = nullptr; }
    sdf_refs_.clear();
    for (auto & ev : pending_events_) { mod_->event_pool(device).push_back(ev.first); mod_->event_pool(device).push_back(ev.second); }
@@ -592,6 +592,53 @@ void BatchShard::build_device(const Robot & robot)
    nj_ = nj; Sa_ = lanes; S_ = lanes + (int) inact.size(); GS_ = M.GS; tree_ = M.tree | ((M.GS == 16) ? 2 : 0);     // kernel variant bits
 
    hipStream_t st = stream_;
+   // TSR hard constraints, folded onto the device's joint order (csrc/tsr.h)
+   n_tsrs_ = (int) params.tsrs.size(); cons_k_ = 0;
+   if (n_tsrs_ > 0)
+   {
+      std::vector<DevTsr<real>> ht(n_tsrs_);
+      for (int c=0; c<n_tsrs_; c++)
+      {
+         const TsrSpec & sp = params.tsrs[c];
+         DevTsr<real> & T = ht[c];
+         std::memset(&T, 0, sizeof(T));
+         const int at = attach_of(sp.ee_link);
+         for (int jk=at; jk>=0; jk=jparent[jk]) T.chain_mask |= (1u << pos_in_order[jk]);
+         // the link's frame in the moved frame of its last chain joint's link (the base frame for -1)
+         Xform x; for (int q=0; q<9; q++) x.R.m[q] = (q % 4 == 0) ? 1.0 : 0.0;
+         x.t[0] = x.t[1] = x.t[2] = 0.0;
+         const int from_link = (at < 0) ? -1 : jlink[at];
+         for (int cur=sp.ee_link; cur!=from_link && cur>=0; cur=robot.parent[cur]) x = xform_mul(local_moved(cur), x);
+         for (int q=0; q<9; q++) T.Xl_R[q] = (real) x.R.m[q];
+         for (int q=0; q<3; q++) T.Xl_t[q] = (real) x.t[q];
+         const Pose tw = pose_invert(sp.T0w), eo = pose_invert(sp.Twe);
+         for (int q=0; q<7; q++) { T.tool[q] = (real) sp.tool.v[q]; T.table_world[q] = (real) tw.v[q]; T.ee_obj[q] = (real) eo.v[q]; }
+         T.k = 0;
+         for (int q=0; q<6; q++)      // src/orcdchomp_mod.cpp:2466-2480
+         {
+            T.enabled[q] = (sp.Bw[q][0] == 0.0 && sp.Bw[q][1] == 0.0) ? 1 : 0;
+            T.k += T.enabled[q];
+         }
+         if (T.k == 0) throw std::runtime_error("TSR constraint with no fixed dimension (every Bw row has a range)!");
+      }
+      // rows in the reference's list order: the last constraint added comes first (src/libcd/chomp.c:231-232,418-424)
+      int base = 0;
+      for (int c=n_tsrs_-1; c>=0; c--) { ht[c].row_base = base; base += ht[c].k * m; }
+      cons_k_ = base;
+      const int NB = n_tsrs_ * m;
+      tsr_ws_stride_ = (size_t) 2*cons_k_ + (size_t) cons_k_ * n + (size_t) NB * n + (size_t) cons_k_ * cons_k_;
+      const double gbytes = (double) tsr_ws_stride_ * n_runs * sizeof(real) / 1e9;
+      if (cons_k_ > 2048 || gbytes > 64.0)
+         throw std::runtime_error("TSR constraints: the constraint system is too large for this build (" + std::to_string(cons_k_)
+                                  + " rows, " + std::to_string(gbytes) + " GB of workspace)!");
+      DevTsr<real> * dt = dev_alloc<DevTsr<real>>(n_tsrs_);
+      hip_check(hipMemcpy(dt, ht.data(), ht.size()*sizeof(DevTsr<real>), hipMemcpyHostToDevice), "tsrs");
+      d_tsrs_ = dt;
+      d_tsr_ws_ = dev_alloc<real>(tsr_ws_stride_ * n_runs);
+      d_tsr_err_ = dev_alloc<int>(n_runs);
+      hip_check(hipMemset(d_tsr_err_, 0, sizeof(int) * n_runs), "tsr err");
+   }
+
    ms_.nj = M.nj; ms_.floating = M.floating; ms_.tree = M.tree; ms_.Sa = M.Sa; ms_.S = M.S; ms_.Sa_real = M.Sa_real; ms_.placed = M.placed;
    ms_.GS = M.GS; ms_.base_sph_begin = M.base_sph_begin; ms_.base_sph_end = M.base_sph_end; ms_.jt_scan = M.jt_scan; ms_.pad_ = 0;
    ms_.live_mask = M.live_mask;
@@ -681,6 +728,12 @@ void BatchShard::build_device(const Robot & robot)
          d_pcr_ = upload<real>(metric_.pcr, st);
          pcr_rows_ = 2*metric_.pcr_levels + 1; pcr_sym_ = 0;
       }
+   }
+   if (metric_.Ainv.empty() && n_tsrs_ > 0)
+   {
+      // the constraint step multiplies by entries of the dense inverse (src/libcd/chomp.c:567-575,592-599)
+      metric_.Ainv = metric_.Adense;
+      invert_matrix(metric_.Ainv, m);
    }
    if (!metric_.Ainv.empty()) d_Ainv_ = upload<real>(metric_.Ainv, st);
    d_jl_lo_ = upload<real>(jl_lo_, st);
@@ -959,6 +1012,8 @@ void BatchShard::launch(int n_iter, bool final_eval)
       b.a_diag = (real) metric_.Adense[0];
       b.a_off = (real) metric_.beta_s[0];
    }
+   b.tsrs = (const DevTsr<real> *) d_tsrs_; b.n_tsrs = n_tsrs_; b.cons_k = cons_k_;
+   b.tsr_ws = (real *) d_tsr_ws_; b.tsr_ws_stride = tsr_ws_stride_; b.tsr_err = d_tsr_err_;
    b.Gdbg = debug_state_ ? (real *) d_G_ : nullptr;
    if (!g_in_lds_ && !d_Gcost_)
    {

@@ -163,6 +163,37 @@ int orc_robot_set_velocity_limits(orc_module * mod, const char * name, const dou
    });
 }
 
+int orc_robot_set_link_names(orc_module * mod, const char * name, const char * const * names, int n)
+{
+   return guarded(mod, [&] {
+      orc::Robot & r = mod->impl->robot(name);
+      if (n != r.n_links) throw std::runtime_error("wrong number of link names!");
+      r.link_names.assign(names, names + n);
+   });
+}
+
+int orc_robot_add_manipulator(orc_module * mod, const char * name, const char * manip, int ee_link, const double tool_pose[7])
+{
+   return guarded(mod, [&] {
+      orc::Robot & r = mod->impl->robot(name);
+      if (ee_link < 0 || ee_link >= r.n_links) throw std::runtime_error("manipulator end-effector link out of range!");
+      orc::Robot::Manip m;
+      m.name = manip; m.link = ee_link;
+      if (tool_pose) m.tool = orc::Pose(tool_pose);
+      r.manips.push_back(m);
+   });
+}
+
+int orc_robot_set_active_manipulator(orc_module * mod, const char * name, const char * manip)
+{
+   return guarded(mod, [&] {
+      orc::Robot & r = mod->impl->robot(name);
+      for (size_t k=0; k<r.manips.size(); k++)
+         if (r.manips[k].name == manip) { r.active_manip = (int) k; return; }
+      throw std::runtime_error("manipulator not found!");
+   });
+}
+
 int orc_env_add_kinbody_boxes(orc_module * mod, const char * name, int n_boxes, const double * box_poses, const double * half_extents)
 {
    return guarded(mod, [&] {

@@ -901,6 +901,8 @@ __device__ __forceinline__ Env<real> make_env(const BT & b, unsigned char * smem
 
 extern __shared__ __align__(16) unsigned char orc_smem[];
 
+#include "tsr.h"
+
 // per-phase cycle counters (diagnostics: b.phase_cycles == null in production), kept in the LDS header
 template <typename real, typename BT>
 __device__ __forceinline__ void phase_mark(const BT & b, const Env<real> & E, int slot)
@@ -1067,7 +1069,30 @@ __device__ __attribute__((noinline)) int phase_update(const void * kp, int it_in
    // the step also notes which columns left their limits (what the first scan of the
    // joint-limit loop would find, chomp.c:615-639): bit c of colmask_s
    unsigned long long viol = 0ull;
-   if (!b.use_momentum)
+   if (b.n_tsrs > 0)
+   {
+      // hard constraints (chomp.c:550-600): the unconstrained update AG is completed first, the
+      // constraint step moves the trajectory itself, then T -= AG/lambda as always
+      if (!b.use_momentum)
+         for (int e=tid; e<mn; e+=BLOCK) AG_g[e] = X[e];
+      else
+      {
+         const real sc = (leapfrog_first ? (real)0.5 : (real)1) / b.lambda;
+         for (int e=tid; e<mn; e+=BLOCK) AG_s[e] = AG_s[e] + sc * X[e];
+      }
+      __threadfence_block();
+      __syncthreads();
+      phase_tsr<real, GS16, BLOCK>(kp);
+      const real * AGc = b.use_momentum ? AG_s : AG_g;
+      for (int e=tid; e<mn; e+=BLOCK)
+      {
+         const real t = T_s[n + e] + step * AGc[e];
+         T_s[n + e] = t;
+         const int c = e - div_n(e, rn_f)*n;
+         viol |= (t < jl_s[c] || t > jl_s[n+c]) ? (1ull << c) : 0ull;
+      }
+   }
+   else if (!b.use_momentum)
    {
       // AG = X is not carried between iterations: keep only the last one (read-back state)
       const bool keep = (it == b.n_iter - 1) || (b.Gdbg != nullptr);

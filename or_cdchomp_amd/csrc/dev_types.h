@@ -87,6 +87,21 @@ struct DevSdf
    real Rwg[9];            // grid -> world rotation (pose_world_gsdf), for the gradient
 };
 
+// a TSR hard constraint on every moving point (struct run_contsr + struct tsr of the reference,
+// src/orcdchomp_mod.cpp:873-885, src/orcdchomp_mod.h:80-87), folded onto the device's joint order
+template <typename real>
+struct DevTsr
+{
+   unsigned int chain_mask;   // bit j: device joint j moves the end effector's link
+   int k;                     // rows = enabled entries of xyzrpy (Bw row == [0 0], mod.cpp:2466-2480)
+   int enabled[6];
+   int row_base;              // first row of this constraint's blocks in the system (list order: the last constraint first)
+   real Xl_R[9], Xl_t[3];     // the link in the moved frame of its last chain joint (in the base frame when the chain is empty)
+   real tool[7];              // end effector in the link frame
+   real table_world[7];       // cd_kin_pose_invert(T0w)
+   real ee_obj[7];            // cd_kin_pose_invert(Twe)
+};
+
 // the scalars of DevModel the phase functions branch on, and the LDS carve-up: carried in the
 // kernarg block so that a phase function has them after one scalar load (LdsLayout is declared below)
 struct ModelScalars
@@ -160,6 +175,12 @@ struct DevBatch
    int lim_generic;        // diagnostics: joint-limit rounds by the general (workgroup, any metric) loop
    int stagger_mode;       // 0 none; 1 odd workgroups, 2 every other group of 256: start half an iteration late
    int stagger_sleeps;     // length of that delay in s_sleep(127) units (~8k cycles each)
+   // TSR hard constraints (tsr.h): n_tsrs == 0 when there are none
+   const DevTsr<real> * tsrs;
+   int n_tsrs, cons_k;        // constraints; rows of the system over all moving points
+   real * tsr_ws;             // [n_runs][tsr_ws_stride] workspace: h, h0, J, J^T x, the cons_k x cons_k system
+   size_t tsr_ws_stride;
+   int * tsr_err;             // [n_runs] 1 after a singular system ("constraint inversion error!")
 };
 
 // Collision verdict of the trajectories of a batch (the step after the path: gettraj's re-check,

@@ -473,6 +473,47 @@ void build_metric(int m, int D, double dt, Metric & out)
    }
 }
 
+void invert_matrix(std::vector<double> & Mx, int n) { invert_dense(Mx, n); }
+
+// src/libcd/kin.c:418-459, 510-517
+Pose pose_from_dR(const double d[3], const Mat3 & Rm)
+{
+   const double (*Rr)[3] = (const double (*)[3]) Rm.m;
+   double q[4];
+   const double xx4 = 1.0 + Rr[0][0] - Rr[1][1] - Rr[2][2];
+   const double yy4 = 1.0 - Rr[0][0] + Rr[1][1] - Rr[2][2];
+   const double zz4 = 1.0 - Rr[0][0] - Rr[1][1] + Rr[2][2];
+   const double ww4 = 1.0 + Rr[0][0] + Rr[1][1] + Rr[2][2];
+   if (xx4 > yy4 && xx4 > zz4 && xx4 > ww4)
+   {
+      q[0] = std::sqrt(0.25*xx4);
+      const double v4 = 0.25 / q[0];
+      q[1] = v4 * (Rr[1][0] + Rr[0][1]); q[2] = v4 * (Rr[0][2] + Rr[2][0]); q[3] = v4 * (Rr[2][1] - Rr[1][2]);
+   }
+   else if (yy4 > zz4 && yy4 > ww4)
+   {
+      q[1] = std::sqrt(0.25*yy4);
+      const double v4 = 0.25 / q[1];
+      q[0] = v4 * (Rr[1][0] + Rr[0][1]); q[2] = v4 * (Rr[2][1] + Rr[1][2]); q[3] = v4 * (Rr[0][2] - Rr[2][0]);
+   }
+   else if (zz4 > ww4)
+   {
+      q[2] = std::sqrt(0.25*zz4);
+      const double v4 = 0.25 / q[2];
+      q[0] = v4 * (Rr[0][2] + Rr[2][0]); q[1] = v4 * (Rr[2][1] + Rr[1][2]); q[3] = v4 * (Rr[1][0] - Rr[0][1]);
+   }
+   else
+   {
+      q[3] = std::sqrt(0.25*ww4);
+      const double v4 = 0.25 / q[3];
+      q[0] = v4 * (Rr[2][1] - Rr[1][2]); q[1] = v4 * (Rr[0][2] - Rr[2][0]); q[2] = v4 * (Rr[1][0] - Rr[0][1]);
+   }
+   Pose p;
+   for (int i=0; i<3; i++) p.v[i] = d[i];
+   for (int i=0; i<4; i++) p.v[3+i] = q[i];
+   return p;
+}
+
 // ================================================================== rng ===
 void GslRng::set(unsigned long seed)
 {

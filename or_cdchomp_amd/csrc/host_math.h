@@ -36,6 +36,10 @@ Xform xform_mul(const Xform & a, const Xform & b);
 Mat3 mat3_mul(const Mat3 & a, const Mat3 & b);
 void mat3_vec(const Mat3 & a, const double v[3], double out[3]);
 Mat3 axis_angle(const double axis[3], double q);
+// rotation matrix + translation to a pose (cd_kin_quat_from_R / cd_kin_pose_from_dR, src/libcd/kin.c:418-459,510-517)
+Pose pose_from_dR(const double d[3], const Mat3 & Rm);
+// in-place inverse of a dense [n][n] matrix (Gauss-Jordan with partial pivoting)
+void invert_matrix(std::vector<double> & Mx, int n);
 
 // ----------------------------------------------------------------- grid ---
 // 3-d double grid, C order [x][y][z]   (struct cd_grid, src/libcd/grid.h:29-41)

@@ -599,6 +599,32 @@ std::string Module::cmd_removefield(const std::vector<std::string> & argv)
    throw std::runtime_error("No sdf for that kinbody!");
 }
 
+// tsr_create_parse, src/orcdchomp_mod.cpp:3068-3111: "manipindex bodyandlink" + T0w (rotation column
+// by column, then translation) + Twe (the same) + Bw [6][2]; 38 fields
+static bool parse_tsr(const std::string & str, TsrSpec & t)
+{
+   int manipindex; char bodyandlink[32];
+   double AR[3][3], Ad[3], BR[3][3], Bd[3];
+   const int ret = std::sscanf(str.c_str(),
+      "%d %31s"
+      " %lf %lf %lf %lf %lf %lf %lf %lf %lf %lf %lf %lf"
+      " %lf %lf %lf %lf %lf %lf %lf %lf %lf %lf %lf %lf"
+      " %lf %lf %lf %lf %lf %lf %lf %lf %lf %lf %lf %lf",
+      &manipindex, bodyandlink,
+      &AR[0][0], &AR[1][0], &AR[2][0], &AR[0][1], &AR[1][1], &AR[2][1], &AR[0][2], &AR[1][2], &AR[2][2],
+      &Ad[0], &Ad[1], &Ad[2],
+      &BR[0][0], &BR[1][0], &BR[2][0], &BR[0][1], &BR[1][1], &BR[2][1], &BR[0][2], &BR[1][2], &BR[2][2],
+      &Bd[0], &Bd[1], &Bd[2],
+      &t.Bw[0][0], &t.Bw[0][1], &t.Bw[1][0], &t.Bw[1][1], &t.Bw[2][0], &t.Bw[2][1],
+      &t.Bw[3][0], &t.Bw[3][1], &t.Bw[4][0], &t.Bw[4][1], &t.Bw[5][0], &t.Bw[5][1]);
+   if (ret != 38) return false;
+   Mat3 A, B;
+   for (int r=0; r<3; r++) for (int c=0; c<3; c++) { A.m[3*r+c] = AR[r][c]; B.m[3*r+c] = BR[r][c]; }
+   t.T0w = pose_from_dR(Ad, A);
+   t.Twe = pose_from_dR(Bd, B);
+   return true;
+}
+
 // src/orcdchomp_mod.cpp:1800-2688 (argument grammar 1888-2085)
 std::string Module::cmd_create(const std::vector<std::string> & argv, bool batchmode)
 {
@@ -611,6 +637,7 @@ std::string Module::cmd_create(const std::vector<std::string> & argv, bool batch
    int n_runs = 1;
    std::string dat_filename;
    std::vector<int> devs; bool have_devs = false;
+   std::vector<TsrSpec> con_tsrs, everyn_tsr;
    const double * goals_ptr = nullptr, * starts_ptr = nullptr, * basegoals_ptr = nullptr;
    const unsigned int * seeds_ptr = nullptr;
    const int argc = (int) argv.size();
@@ -657,11 +684,53 @@ std::string Module::cmd_create(const std::vector<std::string> & argv, bool batch
          if (have_adofgoal) throw std::runtime_error("Cannot pass both adofgoal and starttraj!");
          starttraj = argv[++i]; have_starttraj = true;
       }
-      else if ((a == "start_tsr" || a == "everyn_tsr" || a == "start_cost"
-                || a == "ee_force" || a == "ee_force_at" || a == "ee_torque_weights") && i+1 < argc)
-         throw std::runtime_error("argument " + a + " is outside the scope of this build (SURVEY.md section 2)");
       else if (a == "con_tsr" && i+2 < argc)
-         throw std::runtime_error("argument con_tsr is outside the scope of this build (SURVEY.md section 2)");
+      {
+         // src/orcdchomp_mod.cpp:1930-1987: TYPE | TYPE manipee NAME | TYPE link NAME, then the TSR
+         if (rname.empty()) throw std::runtime_error("You must pass robot before any con_tsrs!");
+         Robot & rb = robot(rname);
+         const std::vector<std::string> head = shparse(argv[++i]);
+         if (head.size() != 1 && head.size() != 3) throw std::runtime_error("con_tsr first argument must be length 1 or 3!");
+         if (head[0] != "all") throw std::runtime_error("con_tsr first arg must be start, end, or all!");
+         TsrSpec t;
+         if (head.size() != 3)
+         {
+            if (rb.manips.empty()) throw std::runtime_error("con_tsr manip not found!");
+            t.ee_link = rb.manips[rb.active_manip].link; t.tool = rb.manips[rb.active_manip].tool;
+         }
+         else if (head[1] == "manipee")
+         {
+            size_t ui = 0;
+            for (; ui<rb.manips.size(); ui++) if (rb.manips[ui].name == head[2]) break;
+            if (!(ui < rb.manips.size())) throw std::runtime_error("con_tsr manip not found!");
+            t.ee_link = rb.manips[ui].link; t.tool = rb.manips[ui].tool;
+         }
+         else if (head[1] == "link")
+         {
+            for (int li=0; li<rb.n_links; li++)
+               if ((li < (int) rb.link_names.size() ? rb.link_names[li] : "link" + std::to_string(li)) == head[2]) t.ee_link = li;
+            if (t.ee_link < 0) throw std::runtime_error("con_tsr link not found!");
+         }
+         else throw std::runtime_error("con_tsr first arg must be empty, manipee, or link!");
+         if (!parse_tsr(argv[++i], t)) throw std::runtime_error("Cannot parse constraint TSR!");
+         con_tsrs.push_back(t);
+      }
+      else if (a == "everyn_tsr" && i+1 < argc)
+      {
+         // src/orcdchomp_mod.cpp:1993-1997; applied to the active manipulator's end effector (mod.cpp:1548)
+         if (rname.empty()) throw std::runtime_error("You must pass robot before any con_tsrs!");
+         Robot & rb = robot(rname);
+         TsrSpec t;
+         if (!parse_tsr(argv[++i], t)) throw std::runtime_error("Cannot parse everyn_tsr TSR!");
+         if (rb.manips.empty()) throw std::runtime_error("everyn_tsr needs an active manipulator!");
+         t.ee_link = rb.manips[rb.active_manip].link; t.tool = rb.manips[rb.active_manip].tool;
+         everyn_tsr.clear(); everyn_tsr.push_back(t);
+      }
+      else if (a == "start_tsr" && i+1 < argc)
+         // makes the start point a variable (m = n_points-1, src/orcdchomp_mod.cpp:2316-2323,2571-2576): not in this build
+         throw std::runtime_error("start_tsr is not supported by this build!");
+      else if ((a == "start_cost" || a == "ee_force" || a == "ee_force_at" || a == "ee_torque_weights") && i+1 < argc)
+         throw std::runtime_error("argument " + a + " is outside the scope of this build (SURVEY.md section 2)");
       else if (batchmode && a == "n_runs" && i+1 < argc) n_runs = std::atoi(argv[++i].c_str());
       else if (batchmode && a == "adofgoals" && i+1 < argc) goals_ptr = (const double *) parse_pointer(argv[++i]);
       else if (batchmode && a == "adofstarts" && i+1 < argc) starts_ptr = (const double *) parse_pointer(argv[++i]);
@@ -694,6 +763,9 @@ std::string Module::cmd_create(const std::vector<std::string> & argv, bool batch
    if (sdfs.empty()) throw std::runtime_error("No signed distance fields have yet been computed!");
    if (p.lambda < 0.01) throw std::runtime_error("lambda must be >=0.01!");
    if (p.n_points < 3) throw std::runtime_error("n_points must be >=3!");
+   // the constraints in the reference's order of addition (src/orcdchomp_mod.cpp:2582-2612)
+   p.tsrs = everyn_tsr;
+   p.tsrs.insert(p.tsrs.end(), con_tsrs.begin(), con_tsrs.end());
    Robot & r = robot(rname);
    // initialisation from a passed trajectory (src/orcdchomp_mod.cpp:2375-2416): sampled at
    // i * duration / (n_points-1), linear interpolation between its waypoints

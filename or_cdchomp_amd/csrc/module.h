@@ -32,6 +32,11 @@ struct Robot                      // what the path reads from an OpenRAVE::Robot
    std::vector<double> limit_vel;   // GetDOFVelocityLimits, used by the retimer of gettraj (default 1)
    struct Sphere { int link; double pos[3]; double radius; };   // struct sphere, src/orcdchomp_kdata.h:33-39
    std::vector<Sphere> spheres;   // XML order
+   // what the TSR constraints address (`con_tsr 'all link NAME'`, `'all manipee NAME'`, src/orcdchomp_mod.cpp:1957-1976)
+   std::vector<std::string> link_names;        // GetLink(name); empty: links are addressed as "link<i>"
+   struct Manip { std::string name; int link; Pose tool; };   // GetEndEffectorTransform = link transform o tool
+   std::vector<Manip> manips;
+   int active_manip = 0;                       // GetActiveManipulator
    // state
    Pose transform;
    std::vector<double> dof_values;
@@ -78,8 +83,19 @@ struct Sdf                        // struct sdf, src/orcdchomp_mod.cpp:148-153
    std::map<int, std::shared_ptr<void>> dev64, dev32;
 };
 
+// a TSR hard constraint on every moving point (`con_tsr all ...` or `everyn_tsr`; struct tsr,
+// src/orcdchomp_mod.h:80-87, struct run_contsr, src/orcdchomp_mod.cpp:873-885)
+struct TsrSpec
+{
+   int ee_link = -1;
+   Pose tool;                 // end effector in the link frame (identity for `link NAME`)
+   Pose T0w, Twe;
+   double Bw[6][2];
+};
+
 struct BatchParams
 {
+   std::vector<TsrSpec> tsrs; // in the reference's order of addition: everyn_tsr first, then the con_tsrs (mod.cpp:2582-2612)
    int n_points = 101;
    int floating_base = 0;
    double lambda = 10.0;
@@ -147,6 +163,9 @@ private:
    int * d_status_ = nullptr; int * d_iters_done_ = nullptr; int * d_leap_ = nullptr; long long * d_phase_ = nullptr;
    void * d_Aband_ = nullptr; void * d_beta_s_ = nullptr; void * d_beta_g_ = nullptr;
    void * d_pcr_ = nullptr; void * d_Ainv_ = nullptr; void * d_jl_lo_ = nullptr; void * d_jl_hi_ = nullptr;
+   // TSR hard constraints (csrc/tsr.h): the device copies of the constraints, the per-run workspace
+   void * d_tsrs_ = nullptr; void * d_tsr_ws_ = nullptr; int * d_tsr_err_ = nullptr;
+   int n_tsrs_ = 0, cons_k_ = 0; size_t tsr_ws_stride_ = 0;
    int * d_hmc_iters_ = nullptr; void * d_noise_ = nullptr; size_t hmc_cap_iters_ = 0, noise_cap_ = 0;
    int max_resamples_ = 0;
    bool debug_state_ = false;   // ORC_DEBUG_STATE=1: keep the last gradient readable (get_state "G")

@@ -1,0 +1,463 @@
+// tsr.h -- TSR hard constraints of the CHOMP update (included by chomp_kernel.hip).
+//
+// Reference: the constraint step of cd_chomp_iterate, src/libcd/chomp.c:550-600 (evaluate every point
+// constraint into h and J; h -= 1/lambda J AG_i; build J Ainv J^T; LAPACKE_dgesv; push the update
+// back through Ainv into the trajectory), and the constraint function con_tsr / con_everyn_tsr,
+// src/orcdchomp_mod.cpp:1330-1657 (end-effector pose -> object pose in the TSR's frame as xyzypr;
+// Jacobian = xyzypr-Jacobian . pose-Jacobian-inverse . spatial transform . spatial Jacobian), with
+// libcd's helpers kin.c:136-178,418-459,615-717 and spatial.c:71-102,295-375.
+//
+// One workgroup = one run, like every other phase.  The K x K system (K = constraint rows of all
+// moving points together, a dense matrix because Ainv couples all points) lives in a per-run global
+// workspace; it is factored in place by LU with partial pivoting (rows swapped for the largest
+// magnitude of the column, first one on ties: what dgesv does), one column per step.  This phase is
+// the slow path of a rarely used feature: it is written for equality with the reference's
+// arithmetic, not for speed.
+#pragma once
+
+template <typename real> struct TM;
+template <> struct TM<double>
+{
+   static __device__ __forceinline__ double atan2_(double y, double x) { return ::atan2(y, x); }
+   static __device__ __forceinline__ double asin_(double x) { return ::asin(x); }
+};
+template <> struct TM<float>
+{
+   static __device__ __forceinline__ float atan2_(float y, float x) { return ::atan2f(y, x); }
+   static __device__ __forceinline__ float asin_(float x) { return ::asinf(x); }
+};
+
+// the expanded quaternion rotation of kin.c:160-172
+template <typename real>
+__device__ __forceinline__ void t_quat_rotate(real qx, real qy, real qz, real qw, real x, real y, real z, real out[3])
+{
+   const real qx2 = qx*qx, qy2 = qy*qy, qz2 = qz*qz, qw2 = qw*qw;
+   const real qxqy = qx*qy, qxqz = qx*qz, qxqw = qx*qw, qyqz = qy*qz, qyqw = qy*qw, qzqw = qz*qw;
+   out[0] = x*(qx2-qy2-qz2+qw2) + 2*y*(qxqy-qzqw) + 2*z*(qxqz+qyqw);
+   out[1] = 2*x*(qxqy+qzqw) + y*(-qx2+qy2-qz2+qw2) + 2*z*(qyqz-qxqw);
+   out[2] = 2*x*(qxqz-qyqw) + 2*y*(qyqz+qxqw) + z*(-qx2-qy2+qz2+qw2);
+}
+// cd_kin_pose_compose, kin.c:136-178
+template <typename real>
+__device__ __forceinline__ void t_pose_compose(const real ab[7], const real bc[7], real ac[7])
+{
+   const real ax = ab[3], ay = ab[4], az = ab[5], aw = ab[6];
+   const real bx = bc[3], by = bc[4], bz = bc[5], bw = bc[6];
+   real rot[3];
+   ac[3] = aw*bx + ax*bw + ay*bz - az*by;
+   ac[4] = aw*by - ax*bz + ay*bw + az*bx;
+   ac[5] = aw*bz + ax*by - ay*bx + az*bw;
+   ac[6] = aw*bw - ax*bx - ay*by - az*bz;
+   t_quat_rotate(ax, ay, az, aw, bc[0], bc[1], bc[2], rot);
+   ac[0] = rot[0] + ab[0]; ac[1] = rot[1] + ab[1]; ac[2] = rot[2] + ab[2];
+}
+// cd_kin_quat_to_R, kin.c:348-370
+template <typename real>
+__device__ __forceinline__ void t_quat_to_R(const real q[4], real R[9])
+{
+   const real xx = q[0]*q[0], xy = q[0]*q[1], xz = q[0]*q[2], xw = q[0]*q[3];
+   const real yy = q[1]*q[1], yz = q[1]*q[2], yw = q[1]*q[3], zz = q[2]*q[2], zw = q[2]*q[3];
+   R[0] = 1 - 2*(yy+zz); R[1] = 2*(xy-zw);     R[2] = 2*(xz+yw);
+   R[3] = 2*(xy+zw);     R[4] = 1 - 2*(xx+zz); R[5] = 2*(yz-xw);
+   R[6] = 2*(xz-yw);     R[7] = 2*(yz+xw);     R[8] = 1 - 2*(xx+yy);
+}
+// cd_kin_quat_from_R, kin.c:418-459 (R row major)
+template <typename real>
+__device__ __forceinline__ void t_quat_from_R(const real R[9], real quat[4])
+{
+   const real xx4 = 1 + R[0] - R[4] - R[8], yy4 = 1 - R[0] + R[4] - R[8], zz4 = 1 - R[0] - R[4] + R[8], ww4 = 1 + R[0] + R[4] + R[8];
+   if (xx4 > yy4 && xx4 > zz4 && xx4 > ww4)
+   {
+      quat[0] = M<real>::sqrt_((real)0.25*xx4);
+      const real v4 = (real)0.25 / quat[0];
+      quat[1] = v4 * (R[3] + R[1]); quat[2] = v4 * (R[2] + R[6]); quat[3] = v4 * (R[7] - R[5]);
+   }
+   else if (yy4 > zz4 && yy4 > ww4)
+   {
+      quat[1] = M<real>::sqrt_((real)0.25*yy4);
+      const real v4 = (real)0.25 / quat[1];
+      quat[0] = v4 * (R[3] + R[1]); quat[2] = v4 * (R[7] + R[5]); quat[3] = v4 * (R[2] - R[6]);
+   }
+   else if (zz4 > ww4)
+   {
+      quat[2] = M<real>::sqrt_((real)0.25*zz4);
+      const real v4 = (real)0.25 / quat[2];
+      quat[0] = v4 * (R[2] + R[6]); quat[1] = v4 * (R[7] + R[5]); quat[3] = v4 * (R[3] - R[1]);
+   }
+   else
+   {
+      quat[3] = M<real>::sqrt_((real)0.25*ww4);
+      const real v4 = (real)0.25 / quat[3];
+      quat[0] = v4 * (R[7] - R[5]); quat[1] = v4 * (R[2] - R[6]); quat[2] = v4 * (R[3] - R[1]);
+   }
+}
+// cd_kin_pose_to_xyzypr, kin.c:615-646
+template <typename real>
+__device__ __forceinline__ void t_pose_to_xyzypr(const real pose[7], real o[6])
+{
+   const real qx = pose[3], qy = pose[4], qz = pose[5], qw = pose[6];
+   const real tau = (real) 6.283185307179586476925286766559;
+   o[0] = pose[0]; o[1] = pose[1]; o[2] = pose[2];
+   const real sinp2 = qw*qy-qz*qx;
+   if (sinp2 > (real)0.49999) { o[3] = (real)(-2)*TM<real>::atan2_(qx,qw); o[4] = (real)0.25*tau; o[5] = 0; }
+   else if (sinp2 < (real)(-0.49999)) { o[3] = (real)2*TM<real>::atan2_(qx,qw); o[4] = (real)(-0.25)*tau; o[5] = 0; }
+   else
+   {
+      o[3] = TM<real>::atan2_(2*(qw*qz+qx*qy), 1 - 2*(qy*qy+qz*qz));
+      o[4] = TM<real>::asin_(2*sinp2);
+      o[5] = TM<real>::atan2_(2*(qw*qx+qy*qz), 1 - 2*(qx*qx+qy*qy));
+   }
+}
+// cd_kin_pose_to_xyzypr_J, kin.c:682-717
+template <typename real>
+__device__ __forceinline__ void t_xyzypr_J(const real pose[7], real J[6][7])
+{
+   const real qx = pose[3], qy = pose[4], qz = pose[5], qw = pose[6];
+   for (int i=0; i<6; i++) for (int j=0; j<7; j++) J[i][j] = 0;
+   J[0][0] = 1; J[1][1] = 1; J[2][2] = 1;
+   real nu = 2*(qw*qz+qx*qy), de = 1 - 2*(qy*qy+qz*qz);
+   J[3][3] = de/(de*de+nu*nu)*(2*qy);
+   J[3][4] = de/(de*de+nu*nu)*(2*qx) - nu/(de*de+nu*nu)*((real)(-4)*qy);
+   J[3][5] = de/(de*de+nu*nu)*(2*qw) - nu/(de*de+nu*nu)*((real)(-4)*qz);
+   J[3][6] = de/(de*de+nu*nu)*(2*qz);
+   const real as = 2 * (qw*qy-qz*qx);
+   const real ia = (real)1/M<real>::sqrt_(1-as*as);
+   J[4][3] = ia*2*(-qz); J[4][4] = ia*2*qw; J[4][5] = ia*2*(-qx); J[4][6] = ia*2*qy;
+   nu = 2*(qw*qx+qy*qz); de = 1 - 2*(qx*qx+qy*qy);
+   J[5][3] = de/(de*de+nu*nu)*(2*qw) - nu/(de*de+nu*nu)*((real)(-4)*qx);
+   J[5][4] = de/(de*de+nu*nu)*(2*qz) - nu/(de*de+nu*nu)*((real)(-4)*qy);
+   J[5][5] = de/(de*de+nu*nu)*(2*qy);
+   J[5][6] = de/(de*de+nu*nu)*(2*qx);
+}
+// cd_spatial_pose_jac_inverse, spatial.c:339-375
+template <typename real>
+__device__ __forceinline__ void t_jac_inverse(const real pose[7], real Ji[7][6])
+{
+   const real x = pose[0], y = pose[1], z = pose[2];
+   const real qxd2 = (real)0.5*pose[3], qyd2 = (real)0.5*pose[4], qzd2 = (real)0.5*pose[5], qwd2 = (real)0.5*pose[6];
+   for (int i=0; i<7; i++) for (int j=0; j<6; j++) Ji[i][j] = 0;
+   Ji[0][1] =  z; Ji[0][2] = -y; Ji[1][0] = -z; Ji[1][2] =  x; Ji[2][0] =  y; Ji[2][1] = -x;
+   Ji[0][3] = 1; Ji[1][4] = 1; Ji[2][5] = 1;
+   Ji[3][0] =  qwd2; Ji[3][1] =  qzd2; Ji[3][2] = -qyd2;
+   Ji[4][0] = -qzd2; Ji[4][1] =  qwd2; Ji[4][2] =  qxd2;
+   Ji[5][0] =  qyd2; Ji[5][1] = -qxd2; Ji[5][2] =  qwd2;
+   Ji[6][0] = -qxd2; Ji[6][1] = -qyd2; Ji[6][2] = -qzd2;
+}
+// cd_spatial_xm_from_pose, spatial.c:71-102: [R 0; [r]x R  R]
+template <typename real>
+__device__ __forceinline__ void t_xm_from_pose(real xm[6][6], const real pose[7])
+{
+   real R[9];
+   t_quat_to_R(pose+3, R);
+   for (int i=0; i<6; i++) for (int j=0; j<6; j++) xm[i][j] = 0;
+   for (int i=0; i<3; i++) for (int j=0; j<3; j++) { xm[i][j] = R[3*i+j]; xm[3+i][3+j] = R[3*i+j]; }
+   const real rx[3][3] = { { 0, -pose[2], pose[1] }, { pose[2], 0, -pose[0] }, { -pose[1], pose[0], 0 } };
+   for (int i=0; i<3; i++) for (int j=0; j<3; j++)
+   {
+      real s = 0;
+      for (int k=0; k<3; k++) s += rx[i][k] * R[3*k+j];
+      xm[3+i][j] = s;
+   }
+}
+
+// a frame walking the joints of the end effector's chain (the build's own kinematic model, the one
+// fk.h walks for the spheres): cur <- cur o (Rfix, tfix); world axis and anchor; cur <- cur o motion(q)
+template <typename real>
+struct TFrame { real R[9], t[3]; };
+template <typename real>
+__device__ __forceinline__ void t_apply_joint(const DevJoint<real> & J, real q, TFrame<real> & cur, real axis_w[3], real anchor[3])
+{
+   real Rj[9], tj[3];
+   for (int r=0; r<3; r++)
+   {
+      for (int c=0; c<3; c++) Rj[3*r+c] = cur.R[3*r+0]*J.Rfix[0*3+c] + cur.R[3*r+1]*J.Rfix[1*3+c] + cur.R[3*r+2]*J.Rfix[2*3+c];
+      tj[r] = cur.R[3*r+0]*J.tfix[0] + cur.R[3*r+1]*J.tfix[1] + cur.R[3*r+2]*J.tfix[2] + cur.t[r];
+   }
+   for (int r=0; r<3; r++)
+   {
+      axis_w[r] = Rj[3*r+0]*J.axis[0] + Rj[3*r+1]*J.axis[1] + Rj[3*r+2]*J.axis[2];
+      anchor[r] = tj[r];
+   }
+   if (J.type == 1)
+   {
+      real sn, cs;
+      M<real>::sincos_(q, &sn, &cs);
+      const real v = (real)1 - cs;
+      const real a0 = J.axis[0], a1 = J.axis[1], a2 = J.axis[2];
+      real Rm[9];
+      Rm[0] = cs + a0*a0*v;    Rm[1] = a0*a1*v - a2*sn; Rm[2] = a0*a2*v + a1*sn;
+      Rm[3] = a1*a0*v + a2*sn; Rm[4] = cs + a1*a1*v;    Rm[5] = a1*a2*v - a0*sn;
+      Rm[6] = a2*a0*v - a1*sn; Rm[7] = a2*a1*v + a0*sn; Rm[8] = cs + a2*a2*v;
+      for (int r=0; r<3; r++)
+         for (int c=0; c<3; c++) cur.R[3*r+c] = Rj[3*r+0]*Rm[0*3+c] + Rj[3*r+1]*Rm[1*3+c] + Rj[3*r+2]*Rm[2*3+c];
+      for (int r=0; r<3; r++) cur.t[r] = tj[r];
+   }
+   else
+   {
+      for (int e=0; e<9; e++) cur.R[e] = Rj[e];
+      for (int r=0; r<3; r++) cur.t[r] = tj[r] + q*axis_w[r];
+   }
+}
+
+// con_tsr (src/orcdchomp_mod.cpp:1330-1497) at one trajectory row: h[k] and J[k][n] of the enabled rows
+template <typename real>
+__device__ void tsr_eval_point(const DevModel<real> & gm, const DevTsr<real> & ts, const real * point, int n, real * hrow, real * Jrows)
+{
+   TFrame<real> base, cur;
+   if (gm.floating)
+   {
+      t_quat_to_R(point+3, base.R);
+      base.t[0] = point[0]; base.t[1] = point[1]; base.t[2] = point[2];
+   }
+   else
+   {
+      for (int e=0; e<9; e++) base.R[e] = gm.base_R[e];
+      for (int e=0; e<3; e++) base.t[e] = gm.base_t[e];
+   }
+   // the end-effector link's frame: walk its chain, then the fixed transform to the link
+   cur = base;
+   real aw[3], an[3];
+   for (int j=0; j<gm.nj; j++)
+      if ((ts.chain_mask >> j) & 1u) t_apply_joint(gm.joints[j], point[gm.joints[j].col], cur, aw, an);
+   real Rl[9], tl[3];
+   for (int r=0; r<3; r++)
+   {
+      for (int c=0; c<3; c++) Rl[3*r+c] = cur.R[3*r+0]*ts.Xl_R[0*3+c] + cur.R[3*r+1]*ts.Xl_R[1*3+c] + cur.R[3*r+2]*ts.Xl_R[2*3+c];
+      tl[r] = cur.R[3*r+0]*ts.Xl_t[0] + cur.R[3*r+1]*ts.Xl_t[1] + cur.R[3*r+2]*ts.Xl_t[2] + cur.t[r];
+   }
+   real pose_link[7], pose_ee[7], pose_obj[7], pose_table_obj[7], xyzypr[6];
+   pose_link[0] = tl[0]; pose_link[1] = tl[1]; pose_link[2] = tl[2];
+   t_quat_from_R(Rl, pose_link+3);
+   t_pose_compose(pose_link, ts.tool, pose_ee);                 // GetEndEffectorTransform (mod.cpp:1382-1394)
+   t_pose_compose(pose_ee, ts.ee_obj, pose_obj);                // mod.cpp:1396-1398
+   t_pose_compose(ts.table_world, pose_obj, pose_table_obj);    // mod.cpp:1400-1404
+   t_pose_to_xyzypr(pose_table_obj, xyzypr);
+   {
+      int ki = 0;
+      for (int tsri=0; tsri<6; tsri++) if (ts.enabled[tsri]) hrow[ki++] = xyzypr[tsri<3?tsri:8-tsri];
+   }
+   // xyzypr-Jacobian . pose-Jacobian-inverse . spatial transform (mod.cpp:1466-1480)
+   real xm[6][6], Ji[7][6], Jx[6][7], A6[6][6], B6[6][6];
+   t_xm_from_pose(xm, ts.table_world);
+   t_jac_inverse(pose_table_obj, Ji);
+   t_xyzypr_J(pose_table_obj, Jx);
+   for (int i=0; i<6; i++) for (int j=0; j<6; j++) { real s = 0; for (int k=0; k<7; k++) s += Jx[i][k] * Ji[k][j]; A6[i][j] = s; }
+   for (int i=0; i<6; i++) for (int j=0; j<6; j++) { real s = 0; for (int k=0; k<6; k++) s += A6[i][k] * xm[k][j]; B6[i][j] = s; }
+   for (int e=0; e<ts.k*n; e++) Jrows[e] = 0;
+   // . spatial Jacobian, column by column (mod.cpp:1432-1464, 1481-1491)
+   if (gm.floating)
+   {
+      // cd_spatial_pose_jac(point), spatial.c:295-337: the first seven columns
+      const real x = point[0], y = point[1], z = point[2];
+      const real qx = 2*point[3], qy = 2*point[4], qz = 2*point[5], qw = 2*point[6];
+      real Jsp[6][7];
+      for (int a=0; a<6; a++) for (int c=0; c<7; c++) Jsp[a][c] = 0;
+      Jsp[3][0] = 1; Jsp[4][1] = 1; Jsp[5][2] = 1;
+      Jsp[0][3] =  qw; Jsp[0][4] = -qz; Jsp[0][5] =  qy; Jsp[0][6] = -qx;
+      Jsp[1][3] =  qz; Jsp[1][4] =  qw; Jsp[1][5] = -qx; Jsp[1][6] = -qy;
+      Jsp[2][3] = -qy; Jsp[2][4] =  qx; Jsp[2][5] =  qw; Jsp[2][6] = -qz;
+      Jsp[3][3] = -z*qz - y*qy; Jsp[3][4] = -z*qw + y*qx; Jsp[3][5] =  z*qx + y*qw; Jsp[3][6] =  z*qy - y*qz;
+      Jsp[4][3] =  z*qw + x*qy; Jsp[4][4] = -z*qz - x*qx; Jsp[4][5] =  z*qy - x*qw; Jsp[4][6] = -z*qx + x*qz;
+      Jsp[5][3] = -y*qw + x*qz; Jsp[5][4] =  y*qz + x*qw; Jsp[5][5] = -y*qy - x*qx; Jsp[5][6] =  y*qx - x*qy;
+      for (int c=0; c<7; c++)
+      {
+         int ki = 0;
+         for (int tsri=0; tsri<6; tsri++) if (ts.enabled[tsri])
+         {
+            const int row = tsri<3?tsri:8-tsri;
+            real s = 0;
+            for (int k=0; k<6; k++) s += B6[row][k] * Jsp[k][c];
+            Jrows[ki*n + c] = s;
+            ki++;
+         }
+      }
+   }
+   cur = base;
+   for (int j=0; j<gm.nj; j++)
+      if ((ts.chain_mask >> j) & 1u)
+      {
+         const DevJoint<real> & J = gm.joints[j];
+         t_apply_joint(J, point[J.col], cur, aw, an);
+         real col6[6];
+         if (J.type == 1)
+         {
+            // angular part: the axis; linear part: velocity of the link's point at the world origin, axis x (0 - anchor)
+            col6[0] = aw[0]; col6[1] = aw[1]; col6[2] = aw[2];
+            col6[3] = aw[1]*(-an[2]) - aw[2]*(-an[1]);
+            col6[4] = aw[2]*(-an[0]) - aw[0]*(-an[2]);
+            col6[5] = aw[0]*(-an[1]) - aw[1]*(-an[0]);
+         }
+         else { col6[0] = 0; col6[1] = 0; col6[2] = 0; col6[3] = aw[0]; col6[4] = aw[1]; col6[5] = aw[2]; }
+         int ki = 0;
+         for (int tsri=0; tsri<6; tsri++) if (ts.enabled[tsri])
+         {
+            const int row = tsri<3?tsri:8-tsri;
+            real s = 0;
+            for (int k=0; k<6; k++) s += B6[row][k] * col6[k];
+            Jrows[ki*n + J.col] = s;
+            ki++;
+         }
+      }
+}
+
+// (constraint, point) of block o in the reference's list order (the list grows at its head,
+// chomp.c:231-232: the last constraint added comes first, its points from m-1 down to 0)
+template <typename real, typename BT>
+__device__ __forceinline__ void tsr_block(const BT & b, int o, int & c, int & i, int & row0)
+{
+   const int m = b.m;
+   c = b.n_tsrs - 1 - o / m;
+   i = m - 1 - (o - (o / m) * m);
+   row0 = b.tsrs[c].row_base + (m - 1 - i) * b.tsrs[c].k;
+}
+// block and row-in-block of row r of the system
+template <typename real, typename BT>
+__device__ __forceinline__ void tsr_row(const BT & b, int r, int & i, int & a)
+{
+   const int m = b.m;
+   int c = b.n_tsrs - 1;
+   while (c > 0 && r >= b.tsrs[c].row_base + m * b.tsrs[c].k) c--;
+   const int k = b.tsrs[c].k;
+   const int local = (r - b.tsrs[c].row_base) / k;
+   a = (r - b.tsrs[c].row_base) - local * k;
+   i = m - 1 - local;
+}
+
+// The constraint step.  AG holds the unconstrained update (chomp.c:525-548), T_s the trajectory before it.
+template <typename real, bool GS16, int BLOCK>
+__device__ __attribute__((noinline)) void phase_tsr(const void * kp)
+{
+   KArg<real> & b = *uniform_kernarg<real>(kp);
+   const Env<real> E = make_env<real, GS16>(b, orc_smem);
+   const DevModel<real> & gm = *b.model;
+   const int tid = threadIdx.x, run = blockIdx.x;
+   const int n = b.n, m = b.m, K = b.cons_k, NB = b.n_tsrs * m;
+   real * ws = b.tsr_ws + (size_t) run * b.tsr_ws_stride;
+   real * hws = ws;                          // [K]  h, then the solution
+   real * h0 = hws + K;                      // [K]  h as built (dgesv leaves b alone when the matrix is singular)
+   real * Jws = h0 + K;                      // [K][n]
+   real * dws = Jws + (size_t) K * n;        // [NB][n] J^T x per block
+   real * Mws = dws + (size_t) NB * n;       // [K][K]
+   const real * AG = b.use_momentum ? E.AG_s : E.AG_g;
+   const real * T_s = E.T_s;
+   const real inv_lambda = (real)(-1) / b.lambda;
+
+   // ---- every point constraint into h and J; h += -1/lambda J AG_i (chomp.c:558-565) ----
+   for (int o=tid; o<NB; o+=BLOCK)
+   {
+      int c, i, row0;
+      tsr_block<real>(b, o, c, i, row0);
+      const DevTsr<real> & ts = b.tsrs[c];
+      real point[ORC_MAX_JOINTS + 7];
+      for (int q=0; q<n; q++) point[q] = T_s[(i+1)*n + q];
+      tsr_eval_point<real>(gm, ts, point, n, hws + row0, Jws + (size_t) row0 * n);
+      for (int a=0; a<ts.k; a++)
+      {
+         real s = 0;
+         for (int q=0; q<n; q++) s += Jws[(size_t)(row0 + a) * n + q] * AG[i*n + q];
+         const real hv = hws[row0 + a] + inv_lambda * s;
+         hws[row0 + a] = hv; h0[row0 + a] = hv;
+      }
+   }
+   __syncthreads();
+   // ---- J Ainv J^T (chomp.c:567-575) ----
+   for (long e=tid; e<(long) K*K; e+=BLOCK)
+   {
+      const int r = (int)(e / K), cidx = (int)(e - (long) r * K);
+      int i1, a1, i2, a2;
+      tsr_row<real>(b, r, i1, a1); tsr_row<real>(b, cidx, i2, a2);
+      real s = 0;
+      for (int q=0; q<n; q++) s += Jws[(size_t) r * n + q] * Jws[(size_t) cidx * n + q];
+      Mws[e] = b.Ainv[(size_t) i1 * m + i2] * s;
+   }
+   __syncthreads();
+   // ---- LU with partial pivoting, forward elimination of h on the way (chomp.c:579-581) ----
+   bool singular = false;
+   for (int k=0; k<K; k++)
+   {
+      real best = (real)(-1); int best_r = 0x7fffffff;
+      for (int r=k+tid; r<K; r+=BLOCK)
+      {
+         const real v = M<real>::fabs_(Mws[(size_t) r * K + k]);
+         if (v > best) { best = v; best_r = r; }
+      }
+      // workgroup arg-max, the first row on ties
+      for (int off=32; off>0; off>>=1)
+      {
+         const real ob = __shfl_xor(best, off, 64); const int orow = __shfl_xor(best_r, off, 64);
+         if (ob > best || (ob == best && orow < best_r)) { best = ob; best_r = orow; }
+      }
+      __syncthreads();
+      if ((tid & 63) == 0) { E.red[tid >> 6] = (double) best; E.redi[tid >> 6] = best_r; }
+      __syncthreads();
+      double gb = E.red[0]; int p = E.redi[0];
+      for (int w=1; w<BLOCK/64; w++)
+         if (E.red[w] > gb || (E.red[w] == gb && E.redi[w] < p)) { gb = E.red[w]; p = E.redi[w]; }
+      if (!(gb > 0.0)) { singular = true; continue; }      // dgetrf notes the zero pivot and goes on (workgroup-uniform)
+      if (p != k)
+      {
+         for (int j=tid; j<K; j+=BLOCK)
+         {
+            const real t0 = Mws[(size_t) k * K + j];
+            Mws[(size_t) k * K + j] = Mws[(size_t) p * K + j];
+            Mws[(size_t) p * K + j] = t0;
+         }
+         if (tid == 0) { const real t0 = hws[k]; hws[k] = hws[p]; hws[p] = t0; }
+      }
+      __syncthreads();
+      const real piv = Mws[(size_t) k * K + k];
+      for (int r=k+1+tid; r<K; r+=BLOCK) Mws[(size_t) r * K + k] = Mws[(size_t) r * K + k] / piv;
+      __syncthreads();
+      const int rem = K - k - 1;
+      for (long e=tid; e<(long) rem*rem; e+=BLOCK)
+      {
+         const int r = k + 1 + (int)(e / rem), j = k + 1 + (int)(e - (long)(e / rem) * rem);
+         Mws[(size_t) r * K + j] -= Mws[(size_t) r * K + k] * Mws[(size_t) k * K + j];
+      }
+      const real hk = hws[k];
+      for (int r=k+1+tid; r<K; r+=BLOCK) hws[r] -= Mws[(size_t) r * K + k] * hk;
+      __syncthreads();
+   }
+   if (singular)
+   {
+      // "constraint inversion error!" (chomp.c:582-590): dgesv leaves the right-hand side as it was
+      for (int r=tid; r<K; r+=BLOCK) hws[r] = h0[r];
+      if (tid == 0 && b.tsr_err) b.tsr_err[run] = 1;
+      __syncthreads();
+   }
+   else
+   {
+      for (int k=K-1; k>=0; k--)
+      {
+         const real xk = hws[k] / Mws[(size_t) k * K + k];
+         __syncthreads();
+         if (tid == 0) hws[k] = xk;
+         for (int r=tid; r<k; r+=BLOCK) hws[r] -= Mws[(size_t) r * K + k] * xk;
+         __syncthreads();
+      }
+   }
+   // ---- back through Ainv to the trajectory (chomp.c:592-599) ----
+   for (int e=tid; e<NB*n; e+=BLOCK)
+   {
+      const int o = e / n, q = e - o*n;
+      int c, i, row0;
+      tsr_block<real>(b, o, c, i, row0);
+      real s = 0;
+      for (int a=0; a<b.tsrs[c].k; a++) s += Jws[(size_t)(row0 + a) * n + q] * hws[row0 + a];
+      dws[e] = s;
+   }
+   __syncthreads();
+   real * Tw = E.T_s;
+   for (int e=tid; e<m*n; e+=BLOCK)
+   {
+      const int r = e / n, q = e - r*n;
+      real t = Tw[n + e];
+      for (int o=0; o<NB; o++)
+      {
+         const int i = m - 1 - (o - (o / m) * m);
+         t += (real)(-1) * b.Ainv[(size_t) r * m + i] * dws[o*n + q];
+      }
+      Tw[n + e] = t;
+   }
+   __syncthreads();
+}

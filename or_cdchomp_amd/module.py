@@ -84,12 +84,24 @@ class Module:
         d.sphere_link = _ip(a["sphere_link"]); d.sphere_pos = _dp(a["sphere_pos"])
         d.sphere_radius = _dp(a["sphere_radius"])
         self._check(self._lib.orc_env_add_robot(self._h, model.name.encode(), C.byref(d)))
+        names = (C.c_char_p * len(model.link_names))(*[nm.encode() for nm in model.link_names])
+        self._check(self._lib.orc_robot_set_link_names(self._h, model.name.encode(), names, len(model.link_names)))
+        for mname, link, tool in getattr(model, "manipulators", []):
+            self.add_manipulator(model.name, mname, model.link_names.index(link), tool)
         if transform is not None:
             self.set_robot_transform(model.name, transform)
         if dof_values is not None:
             self.set_dof_values(model.name, dof_values)
         if active_dofs is not None:
             self.set_active_dofs(model.name, active_dofs)
+
+    def add_manipulator(self, robot, name, ee_link, tool_pose=(0, 0, 0, 0, 0, 0, 1)):
+        """a manipulator: end-effector link index + local tool transform (GetEndEffectorTransform = link o tool);
+        the first one added is the active manipulator"""
+        self._check(self._lib.orc_robot_add_manipulator(self._h, robot.encode(), name.encode(), int(ee_link), _dp(_f64(tool_pose))))
+
+    def set_active_manipulator(self, robot, name):
+        self._check(self._lib.orc_robot_set_active_manipulator(self._h, robot.encode(), name.encode()))
 
     def set_robot_transform(self, name, pose):
         self._check(self._lib.orc_robot_set_transform(self._h, name.encode(), _dp(_f64(pose))))

@@ -50,6 +50,7 @@ class RobotModel:
         self.limit_lower = []
         self.limit_upper = []
         self.spheres = []          # (link name, [x y z], radius), XML order
+        self.manipulators = []     # (name, end-effector link name, tool pose [x y z qx qy qz qw]); the first is the active one
 
     def add_link(self, name, parent=None, xyz=(0, 0, 0), quat=(0, 0, 0, 1),
                  joint=JOINT_FIXED, axis=(0, 0, 1), limits=None, dof=None):
@@ -163,6 +164,8 @@ def wam7():
     r.limit_lower.append(0.0)
     r.limit_upper.append(math.pi)
     r.add_spheres_xml(WAM_SPHERES_XML)
+    # the arm's manipulator: end effector = the hand's base, tool frame 0.16 m along the arm
+    r.manipulators.append(("arm", "handbase", [0.0, 0.0, 0.16, 0.0, 0.0, 0.0, 1.0]))
     return r
 
 
@@ -194,3 +197,26 @@ def tree30():
         r.add_sphere(nm, (0, 0, 0.04), 0.05)
         r.add_sphere(nm, (0, 0, 0.11), 0.05)
     return r
+
+
+class Tsr:
+    """A task space region in the wire format `create` parses (tsr_create_parse, reference
+    src/orcdchomp_mod.cpp:3068-3111): "manipindex bodyandlink" + T0w (rotation column by column, then
+    translation) + Twe (the same) + Bw [6][2] (x y z roll pitch yaw; a row [0 0] is a hard constraint)."""
+
+    def __init__(self, T0w_R=None, T0w_d=(0, 0, 0), Twe_R=None, Twe_d=(0, 0, 0), Bw=None, manipindex=0, bodyandlink="NULL"):
+        self.T0w_R = np.eye(3) if T0w_R is None else np.asarray(T0w_R, dtype=np.float64).reshape(3, 3)
+        self.T0w_d = np.asarray(T0w_d, dtype=np.float64)
+        self.Twe_R = np.eye(3) if Twe_R is None else np.asarray(Twe_R, dtype=np.float64).reshape(3, 3)
+        self.Twe_d = np.asarray(Twe_d, dtype=np.float64)
+        self.Bw = np.zeros((6, 2)) if Bw is None else np.asarray(Bw, dtype=np.float64).reshape(6, 2)
+        self.manipindex = manipindex
+        self.bodyandlink = bodyandlink
+
+    def serialize(self):
+        vals = []
+        for Rm, d in ((self.T0w_R, self.T0w_d), (self.Twe_R, self.Twe_d)):
+            vals += [repr(float(Rm[r, c])) for c in range(3) for r in range(3)]
+            vals += [repr(float(v)) for v in d]
+        vals += [repr(float(v)) for v in self.Bw.reshape(12)]
+        return "%d %s %s" % (self.manipindex, self.bodyandlink, " ".join(vals))

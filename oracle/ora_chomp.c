@@ -123,7 +123,87 @@ void ora_chomp_free(ora_chomp * c)
    free(c->cost_nxn); free(c->cost_mxn); free(c->vels);
    free(c->jlimit_lower); free(c->jlimit_upper); free(c->Gjlimit); free(c->GjlimitAinv);
    free(c->Kvels); free(c->Evels);
+   free(c->cons_h); free(c->cons_Jcol); free(c->cons_JAJT); free(c->cons_ipiv); free(c->cons_delta);
+   while (c->cons) { ora_chomp_con * con = c->cons; c->cons = con->next; free(con); }
    free(c);
+}
+
+/* src/libcd/chomp.c:219-234 (the list grows at its head) */
+int ora_chomp_add_constraint(ora_chomp * c, int k, int i, void * cptr,
+   int (*con_eval)(void * cptr, struct ora_chomp * c, int i, double * point, double * con_val, double * con_jacobian))
+{
+   ora_chomp_con * con = (ora_chomp_con *) malloc(sizeof(ora_chomp_con));
+   if (!con) return -1;
+   con->k = k; con->i = i; con->cptr = cptr; con->con_eval = con_eval;
+   con->h = 0; con->J = 0;
+   con->next = c->cons;
+   c->cons = con;
+   return 0;
+}
+
+/* src/libcd/chomp.c:405-425 (tail of cd_chomp_init) */
+int ora_chomp_alloc_constraints(ora_chomp * c)
+{
+   ora_chomp_con * con;
+   free(c->cons_h); free(c->cons_Jcol); free(c->cons_JAJT); free(c->cons_ipiv); free(c->cons_delta);
+   c->cons_h = c->cons_Jcol = c->cons_JAJT = c->cons_delta = 0; c->cons_ipiv = 0;
+   c->cons_k = 0;
+   for (con=c->cons; con; con=con->next) c->cons_k += con->k;
+   if (c->cons_k)
+   {
+      c->cons_h = (double *) malloc((size_t) c->cons_k * sizeof(double));
+      c->cons_Jcol = (double *) malloc((size_t) c->cons_k * c->n * sizeof(double));
+      c->cons_JAJT = (double *) malloc((size_t) c->cons_k * c->cons_k * sizeof(double));
+      c->cons_ipiv = (int *) malloc((size_t) c->cons_k * sizeof(int));
+      c->cons_delta = (double *) malloc((size_t) c->n * sizeof(double));
+      if (!c->cons_h || !c->cons_Jcol || !c->cons_JAJT || !c->cons_ipiv || !c->cons_delta) return -1;
+      c->cons_k = 0;
+      for (con=c->cons; con; con=con->next)
+      {
+         con->h = c->cons_h + c->cons_k;
+         con->J = c->cons_Jcol + (size_t) c->cons_k * c->n;
+         c->cons_k += con->k;
+      }
+   }
+   return 0;
+}
+
+/* A x = b for one right-hand side, LU with partial pivoting (rows swapped for the largest
+ * magnitude of the column, first one on ties), then the two triangular solves: what
+ * LAPACKE_dgesv(LAPACK_ROW_MAJOR, n, 1, ...) computes (chomp.c:579-581; LAPACK's blocked update
+ * order differs in rounding only).  A [n][n] row-major is overwritten by its factors, b by x.
+ * Returns the 1-based column of a zero pivot, 0 when there is none. */
+static int dgesv_one(int n, double * A, int * ipiv, double * b)
+{
+   int i, j, k, info = 0;
+   for (k=0; k<n; k++)
+   {
+      int p = k; double big = fabs(A[(size_t) k*n+k]);
+      for (i=k+1; i<n; i++) if (fabs(A[(size_t) i*n+k]) > big) { big = fabs(A[(size_t) i*n+k]); p = i; }
+      ipiv[k] = p;
+      if (A[(size_t) p*n+k] == 0.0) { if (!info) info = k+1; continue; }
+      if (p != k)
+      {
+         double t;
+         for (j=0; j<n; j++) { t = A[(size_t) k*n+j]; A[(size_t) k*n+j] = A[(size_t) p*n+j]; A[(size_t) p*n+j] = t; }
+         t = b[k]; b[k] = b[p]; b[p] = t;
+      }
+      for (i=k+1; i<n; i++)
+      {
+         const double l = A[(size_t) i*n+k] / A[(size_t) k*n+k];
+         A[(size_t) i*n+k] = l;
+         for (j=k+1; j<n; j++) A[(size_t) i*n+j] -= l * A[(size_t) k*n+j];
+         b[i] -= l * b[k];
+      }
+   }
+   if (info) return info;        /* dgesv does not solve a singular system */
+   for (k=n-1; k>=0; k--)
+   {
+      double sum = b[k];
+      for (j=k+1; j<n; j++) sum -= A[(size_t) k*n+j] * b[j];
+      b[k] = sum / A[(size_t) k*n+k];
+   }
+   return 0;
 }
 
 /* src/libcd/chomp.c:239-340: A = sum_d wds[d]/N_d K_d^T K_d etc. */
@@ -262,6 +342,53 @@ int ora_chomp_iterate(ora_chomp * c, int do_iteration, double * costp_total, dou
       }
       else
          gemm(0, m, n, m, 1.0/c->lambda, c->Ainv, m, c->G, n, 1.0, c->AG, n);
+
+      /* hard constraints (chomp.c:550-600): takes the unconstrained update AG and moves the trajectory itself */
+      if (c->cons_k)
+      {
+         ora_chomp_con * con1, * con2;
+         int a, b2, q, err;
+         /* each point constraint into h and J */
+         for (con1=c->cons; con1; con1=con1->next)
+            con1->con_eval(con1->cptr, c, con1->i, c->T_points[con1->i], con1->h, con1->J);
+         /* h += -1/lambda J AG_i */
+         for (con1=c->cons; con1; con1=con1->next)
+            for (a=0; a<con1->k; a++)
+            {
+               double sum = 0.0;
+               for (q=0; q<n; q++) sum += con1->J[a*n+q] * c->AG_points[con1->i][q];
+               con1->h[a] += (-1.0/c->lambda) * sum;
+            }
+         /* J Ainv J^T */
+         for (con1=c->cons; con1; con1=con1->next)
+         for (con2=c->cons; con2; con2=con2->next)
+         {
+            const double ainv = c->Ainv[con1->i * m + con2->i];
+            double * blk = &c->cons_JAJT[(size_t)((con1->h)-(c->cons_h))*c->cons_k + ((con2->h)-(c->cons_h))];
+            for (a=0; a<con1->k; a++)
+            for (b2=0; b2<con2->k; b2++)
+            {
+               double sum = 0.0;
+               for (q=0; q<n; q++) sum += con1->J[a*n+q] * con2->J[b2*n+q];
+               blk[(size_t) a*c->cons_k + b2] = ainv * sum;
+            }
+         }
+         err = dgesv_one(c->cons_k, c->cons_JAJT, c->cons_ipiv, c->cons_h);
+         if (err) c->cons_error = err;       /* "constraint inversion error!" and on it goes */
+         /* back through Ainv to the trajectory */
+         for (con1=c->cons; con1; con1=con1->next)
+         {
+            for (q=0; q<n; q++)
+            {
+               double sum = 0.0;
+               for (a=0; a<con1->k; a++) sum += con1->J[a*n+q] * con1->h[a];
+               c->cons_delta[q] = sum;
+            }
+            for (i=0; i<m; i++)
+               for (q=0; q<n; q++)
+                  c->T[i*c->ldt+q] += -1.0 * c->Ainv[i*m + con1->i] * c->cons_delta[q];
+         }
+      }
 
       /* T -= AG/lambda  (chomp.c:604-605) */
       for (i=0; i<m; i++)

@@ -262,3 +262,133 @@ int ora_util_shparse(char * in, int * argcp, char *** argvp)
    *argvp = argv;
    return 0;
 }
+
+
+/* src/libcd/kin.c:418-459 */
+int ora_kin_quat_from_R(double quat[4], double R[3][3])
+{
+   double xx4, yy4, zz4, ww4, v4;
+   xx4 = 1.0 + R[0][0] - R[1][1] - R[2][2];
+   yy4 = 1.0 - R[0][0] + R[1][1] - R[2][2];
+   zz4 = 1.0 - R[0][0] - R[1][1] + R[2][2];
+   ww4 = 1.0 + R[0][0] + R[1][1] + R[2][2];
+   if (xx4 > yy4 && xx4 > zz4 && xx4 > ww4)
+   {
+      quat[0] = sqrt(0.25*xx4);
+      v4 = 0.25 / quat[0];
+      quat[1] = v4 * (R[1][0] + R[0][1]);
+      quat[2] = v4 * (R[0][2] + R[2][0]);
+      quat[3] = v4 * (R[2][1] - R[1][2]);
+   }
+   else if (yy4 > zz4 && yy4 > ww4)
+   {
+      quat[1] = sqrt(0.25*yy4);
+      v4 = 0.25 / quat[1];
+      quat[0] = v4 * (R[1][0] + R[0][1]);
+      quat[2] = v4 * (R[2][1] + R[1][2]);
+      quat[3] = v4 * (R[0][2] - R[2][0]);
+   }
+   else if (zz4 > ww4)
+   {
+      quat[2] = sqrt(0.25*zz4);
+      v4 = 0.25 / quat[2];
+      quat[0] = v4 * (R[0][2] + R[2][0]);
+      quat[1] = v4 * (R[2][1] + R[1][2]);
+      quat[3] = v4 * (R[1][0] - R[0][1]);
+   }
+   else
+   {
+      quat[3] = sqrt(0.25*ww4);
+      v4 = 0.25 / quat[3];
+      quat[0] = v4 * (R[2][1] - R[1][2]);
+      quat[1] = v4 * (R[0][2] - R[2][0]);
+      quat[2] = v4 * (R[1][0] - R[0][1]);
+   }
+   return 0;
+}
+
+/* src/libcd/kin.c:510-517 */
+int ora_kin_pose_from_dR(double pose[7], const double d[3], double R[3][3])
+{
+   ora_kin_quat_from_R(pose+3, R);
+   pose[0] = d[0]; pose[1] = d[1]; pose[2] = d[2];
+   return 0;
+}
+
+#define ORA_TAU 6.283185307179586476925286766559
+
+/* src/libcd/kin.c:615-646 */
+int ora_kin_pose_to_xyzypr(const double pose[7], double xyzypr[6])
+{
+   double qx = pose[3], qy = pose[4], qz = pose[5], qw = pose[6], sinp2;
+   xyzypr[0] = pose[0]; xyzypr[1] = pose[1]; xyzypr[2] = pose[2];
+   sinp2 = qw*qy-qz*qx;
+   if (sinp2 > 0.49999)
+   {
+      xyzypr[3] = -2.0*atan2(qx,qw);
+      xyzypr[4] = 0.25*ORA_TAU;
+      xyzypr[5] = 0.0;
+   }
+   else if (sinp2 < -0.49999)
+   {
+      xyzypr[3] = 2.0*atan2(qx,qw);
+      xyzypr[4] = -0.25*ORA_TAU;
+      xyzypr[5] = 0.0;
+   }
+   else
+   {
+      xyzypr[3] = atan2(2.0*(qw*qz+qx*qy), 1.0 - 2.0*(qy*qy+qz*qz));
+      xyzypr[4] = asin(2.0*sinp2);
+      xyzypr[5] = atan2(2.0*(qw*qx+qy*qz), 1.0 - 2.0*(qx*qx+qy*qy));
+   }
+   return 0;
+}
+
+/* src/libcd/kin.c:682-717 */
+int ora_kin_pose_to_xyzypr_J(const double pose[7], double J[6][7])
+{
+   double qx = pose[3], qy = pose[4], qz = pose[5], qw = pose[6];
+   double nu, de, as;
+   int i, j;
+   for (i=0; i<6; i++) for (j=0; j<7; j++) J[i][j] = 0.0;
+   J[0][0] = 1.0; J[1][1] = 1.0; J[2][2] = 1.0;
+   /* yaw */
+   nu = 2.0*(qw*qz+qx*qy);
+   de = 1.0 - 2.0*(qy*qy+qz*qz);
+   J[3][3] = de/(de*de+nu*nu)*(2.0*qy);
+   J[3][4] = de/(de*de+nu*nu)*(2.0*qx) - nu/(de*de+nu*nu)*(-2.0*2.0*qy);
+   J[3][5] = de/(de*de+nu*nu)*(2.0*qw) - nu/(de*de+nu*nu)*(-2.0*2.0*qz);
+   J[3][6] = de/(de*de+nu*nu)*(2.0*qz);
+   /* pitch */
+   as = 2.0 * (qw*qy-qz*qx);
+   J[4][3] = 1.0/sqrt(1.0-as*as)*2.0*(-qz);
+   J[4][4] = 1.0/sqrt(1.0-as*as)*2.0*( qw);
+   J[4][5] = 1.0/sqrt(1.0-as*as)*2.0*(-qx);
+   J[4][6] = 1.0/sqrt(1.0-as*as)*2.0*( qy);
+   /* roll */
+   nu = 2.0*(qw*qx+qy*qz);
+   de = 1.0 - 2.0*(qx*qx+qy*qy);
+   J[5][3] = de/(de*de+nu*nu)*(2.0*qw) - nu/(de*de+nu*nu)*(-2.0*2.0*qx);
+   J[5][4] = de/(de*de+nu*nu)*(2.0*qz) - nu/(de*de+nu*nu)*(-2.0*2.0*qy);
+   J[5][5] = de/(de*de+nu*nu)*(2.0*qy);
+   J[5][6] = de/(de*de+nu*nu)*(2.0*qx);
+   return 0;
+}
+
+/* src/libcd/spatial.c:339-375 */
+int ora_spatial_pose_jac_inverse(const double pose[7], double jac_inverse[7][6])
+{
+   double x = pose[0], y = pose[1], z = pose[2];
+   double qxd2 = 0.5 * pose[3], qyd2 = 0.5 * pose[4], qzd2 = 0.5 * pose[5], qwd2 = 0.5 * pose[6];
+   int i, j;
+   for (i=0; i<7; i++) for (j=0; j<6; j++) jac_inverse[i][j] = 0.0;
+   jac_inverse[0][1] =  z; jac_inverse[0][2] = -y;
+   jac_inverse[1][0] = -z; jac_inverse[1][2] =  x;
+   jac_inverse[2][0] =  y; jac_inverse[2][1] = -x;
+   jac_inverse[0][3] = 1.0; jac_inverse[1][4] = 1.0; jac_inverse[2][5] = 1.0;
+   jac_inverse[3][0] =  qwd2; jac_inverse[3][1] =  qzd2; jac_inverse[3][2] = -qyd2;
+   jac_inverse[4][0] = -qzd2; jac_inverse[4][1] =  qwd2; jac_inverse[4][2] =  qxd2;
+   jac_inverse[5][0] =  qyd2; jac_inverse[5][1] = -qxd2; jac_inverse[5][2] =  qwd2;
+   jac_inverse[6][0] = -qxd2; jac_inverse[6][1] = -qyd2; jac_inverse[6][2] = -qzd2;
+   return 0;
+}

@@ -132,7 +132,19 @@ struct ora_run              /* src/orcdchomp_mod.cpp:887-966 */
    int iter;
    /* FK scratch */
    double * fkR, * fkt, * fkaxis, * fkanchor;
+   /* tsr constraints applied (struct run_contsr, src/orcdchomp_mod.cpp:873-885) */
+   int n_contsrs;
+   struct run_contsr ** contsrs;
 };
+
+typedef struct run_contsr
+{
+   ora_run * r;
+   int ee_link; double tool[7];      /* manip->GetEndEffectorTransform() = link transform o tool; identity for a link */
+   double T0w[7], Twe[7], Bw[6][2];  /* struct tsr, src/orcdchomp_mod.h:80-87 */
+   int tsr_enabled[6];               /* xyzrpy */
+   int k;
+} run_contsr;
 
 void ora_run_params_default(ora_run_params * p)   /* src/orcdchomp_mod.cpp:1824-1826,1838-1885 */
 {
@@ -395,8 +407,161 @@ static void run_free(ora_run * r)
    free(r->sphere_poss_inactive); free(r->sphere_poss_all); free(r->sphere_vels);
    free(r->sphere_accs); free(r->sphere_jacs); free(r->J2); free(r->rsdfs);
    free(r->fkR); free(r->fkt); free(r->fkaxis); free(r->fkanchor);
+   { int j; for (j=0; j<r->n_contsrs; j++) free(r->contsrs[j]); free(r->contsrs); }
    ora_chomp_free(r->c);
    free(r);
+}
+
+/* ------------------------------------------------------------------ TSR constraint
+ * con_tsr, src/orcdchomp_mod.cpp:1330-1497 (con_everyn_tsr, 1500-1657, is the same body with the
+ * active manipulator's end effector).  The end-effector transform and the two OpenRAVE Jacobians
+ * (CalculateAngularVelocityJacobian; CalculateJacobian at the world origin, i.e. the spatial
+ * velocity convention) come from the build's own kinematic model. */
+static void small_gemm(int M, int N, int K, const double * A, int lda, const double * B, int ldb, double * C, int ldc)
+{
+   int i, j, k;
+   for (i=0; i<M; i++) for (j=0; j<N; j++)
+   {
+      double sum = 0.0;
+      for (k=0; k<K; k++) sum += A[i*lda+k] * B[k*ldb+j];
+      C[i*ldc+j] = sum;
+   }
+}
+
+static int con_tsr(void * vptr, ora_chomp * c, int ti, double * point, double * con_val, double * con_jacobian)
+{
+   run_contsr * contsr = (run_contsr *) vptr;
+   ora_run * r = contsr->r;
+   const ora_robot * rob = r->robot;
+   int n = c->n, tsri, ki, i, j;
+   double base[7], pose_link[7], pose_ee[7], pose_obj[7], pose_ee_obj[7], pose_table_world[7], pose_table_obj[7];
+   double xyzypr_table_obj[7];
+   double Rl[3][3];
+   (void) ti;
+
+   /* put the arm in this configuration (mod.cpp:1357-1376) */
+   if (r->floating_base)
+   {
+      for (i=0; i<7; i++) base[i] = point[i];
+      for (j=0; j<r->n_adof; j++) r->dofvals[r->adofindices[j]] = point[7+j];
+   }
+   else
+   {
+      for (i=0; i<7; i++) base[i] = r->base_pose[i];
+      for (j=0; j<r->n_adof; j++) r->dofvals[r->adofindices[j]] = point[j];
+   }
+   ora_robot_fk(rob, base, r->dofvals, r->fkR, r->fkt, r->fkaxis, r->fkanchor);
+
+   /* the end-effector transform (mod.cpp:1382-1394) */
+   for (i=0; i<3; i++) for (j=0; j<3; j++) Rl[i][j] = r->fkR[9*contsr->ee_link + 3*i + j];
+   ora_kin_pose_from_dR(pose_link, r->fkt + 3*contsr->ee_link, Rl);
+   ora_kin_pose_compose(pose_link, contsr->tool, pose_ee);
+
+   /* object pose, world wrt the table, object wrt the table, as xyzypr (mod.cpp:1396-1407) */
+   ora_kin_pose_invert(contsr->Twe, pose_ee_obj);
+   ora_kin_pose_compose(pose_ee, pose_ee_obj, pose_obj);
+   ora_kin_pose_invert(contsr->T0w, pose_table_world);
+   ora_kin_pose_compose(pose_table_world, pose_obj, pose_table_obj);
+   ora_kin_pose_to_xyzypr(pose_table_obj, xyzypr_table_obj);
+
+   /* the constraint value vector (mod.cpp:1409-1415) */
+   ki = 0;
+   for (tsri=0; tsri<6; tsri++) if (contsr->tsr_enabled[tsri])
+   {
+      con_val[ki] = xyzypr_table_obj[tsri<3?tsri:8-tsri];
+      ki++;
+   }
+
+   if (con_jacobian)
+   {
+      double * spajac_world = (double *) calloc((size_t) 6*n, sizeof(double));
+      double * full_result = (double *) calloc((size_t) 6*n, sizeof(double));
+      double Jsp[6][7], xm_table_world[6][6], jac_inverse[7][6], pose_to_xyzypr_jac[6][7];
+      double temp6x6a[6][6], temp6x6b[6][6];
+      int col0 = r->floating_base ? 7 : 0;
+      if (r->floating_base)
+      {
+         /* floating base: first seven columns of the spatial velocity jacobian (mod.cpp:1434-1437) */
+         ora_spatial_pose_jac(point, Jsp);
+         for (i=0; i<6; i++) for (j=0; j<7; j++) spajac_world[i*n+j] = Jsp[i][j];
+      }
+      /* active columns: rows 0..2 the angular velocity Jacobian of the link, rows 3..5 the Jacobian
+       * of the link's point that sits at the world origin (mod.cpp:1439-1464) */
+      for (j=0; j<r->n_adof; j++)
+      {
+         int dof = r->adofindices[j], lj, found = -1;
+         if (!ora_robot_does_affect(rob, dof, contsr->ee_link)) continue;
+         for (lj=contsr->ee_link; lj>=0; lj=rob->parent[lj])
+            if (rob->joint_type[lj] != 0 && rob->dof_index[lj] == dof) { found = lj; break; }
+         if (found < 0) continue;
+         {
+            const double * ax = r->fkaxis + 3*found;
+            const double * an = r->fkanchor + 3*found;
+            if (rob->joint_type[found] == 1)
+            {
+               for (i=0; i<3; i++) spajac_world[i*n + col0+j] = ax[i];
+               /* axis x (0 - anchor) */
+               spajac_world[3*n + col0+j] = ax[1]*(-an[2]) - ax[2]*(-an[1]);
+               spajac_world[4*n + col0+j] = ax[2]*(-an[0]) - ax[0]*(-an[2]);
+               spajac_world[5*n + col0+j] = ax[0]*(-an[1]) - ax[1]*(-an[0]);
+            }
+            else
+               for (i=0; i<3; i++) spajac_world[(3+i)*n + col0+j] = ax[i];
+         }
+      }
+      /* velocities in the table frame, the pose derivative, the xyzypr Jacobian (mod.cpp:1466-1474) */
+      ora_spatial_xm_from_pose(xm_table_world, pose_table_world);
+      ora_spatial_pose_jac_inverse(pose_table_obj, jac_inverse);
+      ora_kin_pose_to_xyzypr_J(pose_table_obj, pose_to_xyzypr_jac);
+      /* the three products (mod.cpp:1476-1482) */
+      small_gemm(6, 6, 7, &pose_to_xyzypr_jac[0][0], 7, &jac_inverse[0][0], 6, &temp6x6a[0][0], 6);
+      small_gemm(6, 6, 6, &temp6x6a[0][0], 6, &xm_table_world[0][0], 6, &temp6x6b[0][0], 6);
+      small_gemm(6, n, 6, &temp6x6b[0][0], 6, spajac_world, n, full_result, n);
+      /* the enabled rows (mod.cpp:1484-1491) */
+      ki = 0;
+      for (tsri=0; tsri<6; tsri++) if (contsr->tsr_enabled[tsri])
+      {
+         memcpy(con_jacobian + ki*n, full_result + (tsri<3?tsri:8-tsri)*n, (size_t) n*sizeof(double));
+         ki++;
+      }
+      free(spajac_world); free(full_result);
+   }
+   return 0;
+}
+
+/* `con_tsr all ...` / `everyn_tsr`: the mask and dimension (mod.cpp:2466-2480,2502-2518), one
+ * constraint per moving point (mod.cpp:2582-2612) */
+int ora_run_add_contsr(ora_run * r, int ee_link, const double tool[7], const double T0w[7], const double Twe[7], const double * Bw)
+{
+   run_contsr * ct = (run_contsr *) calloc(1, sizeof(run_contsr));
+   int i;
+   if (!ct) return -1;
+   ct->r = r; ct->ee_link = ee_link;
+   for (i=0; i<7; i++) { ct->tool[i] = tool[i]; ct->T0w[i] = T0w[i]; ct->Twe[i] = Twe[i]; }
+   ct->k = 0;
+   for (i=0; i<6; i++)
+   {
+      ct->Bw[i][0] = Bw[2*i]; ct->Bw[i][1] = Bw[2*i+1];
+      if (ct->Bw[i][0] == 0.0 && ct->Bw[i][1] == 0.0) { ct->tsr_enabled[i] = 1; ct->k++; }
+      else ct->tsr_enabled[i] = 0;
+   }
+   r->contsrs = (run_contsr **) realloc(r->contsrs, (size_t)(r->n_contsrs+1) * sizeof(run_contsr *));
+   r->contsrs[r->n_contsrs++] = ct;
+   for (i=0; i<r->c->m; i++)
+      if (ora_chomp_add_constraint(r->c, ct->k, i, ct, con_tsr)) return -1;
+   return ora_chomp_alloc_constraints(r->c);
+}
+
+int ora_run_eval_contsr(ora_run * r, int which, const double * point, double * h, double * J)
+{
+   double * pt;
+   int i;
+   if (which < 0 || which >= r->n_contsrs) return -1;
+   pt = (double *) malloc((size_t) r->c->n * sizeof(double));
+   for (i=0; i<r->c->n; i++) pt[i] = point[i];
+   con_tsr(r->contsrs[which], r->c, 0, pt, h, J);
+   free(pt);
+   return r->contsrs[which]->k;
 }
 
 /* src/orcdchomp_mod.cpp:1800-2688 */

@@ -67,6 +67,12 @@ int ora_kin_pose_invert(const double pose_in[7], double pose_out[7]);
 int ora_kin_quat_to_R(const double quat[4], double R[3][3]);
 int ora_spatial_xm_from_pose(double xm[6][6], const double pose[7]);
 int ora_spatial_pose_jac(const double pose[7], double jac[6][7]);
+/* the pieces the TSR constraint needs (src/libcd/kin.c:418-459,510-517,615-646,682-717; spatial.c:339-375) */
+int ora_kin_quat_from_R(double quat[4], double R[3][3]);
+int ora_kin_pose_from_dR(double pose[7], const double d[3], double R[3][3]);
+int ora_kin_pose_to_xyzypr(const double pose[7], double xyzypr[6]);
+int ora_kin_pose_to_xyzypr_J(const double pose[7], double J[6][7]);
+int ora_spatial_pose_jac_inverse(const double pose[7], double jac_inverse[7][6]);
 
 /* ------------------------------------------------------------------- rng */
 /* GSL gsl_rng_mt19937 / gsl_rng_uniform / gsl_ran_gaussian restated */
@@ -77,7 +83,18 @@ double ora_rng_uniform(ora_rng * r);
 double ora_ran_gaussian(ora_rng * r, double sigma);
 
 /* ----------------------------------------------------------------- chomp */
-/* src/libcd/chomp.h:38-101 (constraints omitted: out of scope) */
+/* a per-point hard constraint (struct cd_chomp_con, src/libcd/chomp.h:27-36) */
+struct ora_chomp;
+typedef struct ora_chomp_con
+{
+   struct ora_chomp_con * next;
+   int k, i;
+   void * cptr;
+   int (*con_eval)(void * cptr, struct ora_chomp * c, int i, double * point, double * con_val, double * con_jacobian);
+   double * h, * J;
+} ora_chomp_con;
+
+/* src/libcd/chomp.h:38-101 */
 typedef struct ora_chomp
 {
    int m, n;
@@ -104,11 +121,22 @@ typedef struct ora_chomp
    int use_momentum;
    int leapfrog_first;
    int last_num_limadjs;   /* instrumentation only: rounds of the joint-limit loop */
+   /* hard constraints (chomp.h:83-90); the list is LIFO like the reference's */
+   ora_chomp_con * cons;
+   int cons_k;
+   double * cons_h, * cons_Jcol, * cons_JAJT, * cons_delta;
+   int * cons_ipiv;
+   int cons_error;         /* instrumentation only: LU met a zero pivot ("constraint inversion error!") */
 } ora_chomp;
 
 int ora_chomp_create(ora_chomp ** cp, int m, int n, int D, double * T, int ldt);
 void ora_chomp_free(ora_chomp * c);
 int ora_chomp_init(ora_chomp * c);
+/* src/libcd/chomp.c:219-234; ora_chomp_alloc_constraints is the tail of cd_chomp_init (chomp.c:405-425),
+ * callable again after constraints were added to an initialised solver */
+int ora_chomp_add_constraint(ora_chomp * c, int k, int i, void * cptr,
+   int (*con_eval)(void * cptr, struct ora_chomp * c, int i, double * point, double * con_val, double * con_jacobian));
+int ora_chomp_alloc_constraints(ora_chomp * c);
 int ora_chomp_iterate(ora_chomp * c, int do_iteration, double * costp_total, double * costp_obs, double * costp_smooth);
 
 /* ----------------------------------------------------------- robot model */
@@ -171,6 +199,13 @@ ora_run * ora_run_create(const ora_robot * rob, const double base_pose[7], const
 /* iterate: src/orcdchomp_mod.cpp:2690-2852.  costs_out[3] = total, obs, smooth of the
  * FINAL evaluation (do_iteration=0); trace (optional) [n_iter][3] per-iteration costs.
  * returns 0, or -1 if the joint-limit loop ran out ("Resulting trajectory is outside of joint limits!") */
+/* TSR hard constraint on every moving point (`con_tsr all ...` / `everyn_tsr`, src/orcdchomp_mod.cpp:1330-1657,
+ * 2466-2480,2582-2612).  ee_link + tool[7] (pose of the end effector in that link: identity for `link NAME`,
+ * the manipulator's local tool transform for `manipee`), T0w[7], Twe[7] and Bw[6][2] of the TSR
+ * (tsr_create_parse, mod.cpp:3068-3111).  Call in the reference's order: everyn_tsr first, then the con_tsrs. */
+int ora_run_add_contsr(ora_run * r, int ee_link, const double tool[7], const double T0w[7], const double Twe[7], const double * Bw);
+/* the constraint value and Jacobian of constraint `which` (order of addition) at a trajectory row: h[k], J[k][n] */
+int ora_run_eval_contsr(ora_run * r, int which, const double * point, double * h, double * J);
 int ora_run_iterate(ora_run * r, int n_iter, double * costs_out, double * trace);
 /* as above but with externally supplied momentum noise: noise[k][m][n] is used for the
  * k-th resample of this call instead of the run's own rng stream */

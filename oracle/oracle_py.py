@@ -118,6 +118,10 @@ def lib():
         L.ora_run_chomp.restype = C.POINTER(Chomp)
         L.ora_run_chomp.argtypes = [C.c_void_p]
         L.ora_run_eval_obstacle.argtypes = [C.c_void_p, c_double_p, c_double_p, c_double_p]
+        L.ora_run_add_contsr.argtypes = [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p]
+        L.ora_run_eval_contsr.argtypes = [C.c_void_p, C.c_int, c_double_p, c_double_p, c_double_p]
+        L.ora_kin_pose_from_dR.argtypes = [c_double_p, c_double_p, c_double_p]
+        L.ora_kin_pose_to_xyzypr.argtypes = [c_double_p, c_double_p]
         L.ora_run_sphere_order.argtypes = [C.c_void_p, c_int_p]
         L.ora_batch_run.argtypes = [C.POINTER(Robot), c_double_p, c_double_p, C.c_int, c_int_p, C.c_int,
                                     c_double_p, c_double_p, C.c_int, C.POINTER(C.POINTER(Grid)), c_double_p,
@@ -294,6 +298,18 @@ class OraRun:
                                             C.byref(dep))
         return dict(collides=col.value, time=tim.value, sphere=sph.value, field=fld.value, depth=dep.value, samples=n)
 
+    def add_contsr(self, ee_link, tool, T0w, Twe, Bw):
+        """`con_tsr all ...` / `everyn_tsr` (reference src/orcdchomp_mod.cpp:2466-2480, 2582-2612): a TSR hard
+        constraint on every moving point; Bw [6][2].  Returns the constraint's dimension k."""
+        err = lib().ora_run_add_contsr(self.h, int(ee_link), dp(f64(tool)), dp(f64(T0w)), dp(f64(Twe)), dp(f64(Bw).reshape(12)))
+        assert err == 0
+        return int(sum(1 for row in np.asarray(Bw, dtype=float).reshape(6, 2) if row[0] == 0.0 and row[1] == 0.0))
+
+    def eval_contsr(self, which, point):
+        h = np.zeros(6); J = np.zeros((6, self.n))
+        k = lib().ora_run_eval_contsr(self.h, which, dp(f64(point)), dp(h), dp(J))
+        return h[:k].copy(), J[:k].copy()
+
     def eval_obstacle(self):
         G = np.zeros((self.m, self.n)); costs = np.zeros(self.m)
         P = np.zeros((self.n_points, self.Sa, 3))
@@ -315,6 +331,13 @@ class OraRun:
             self.destroy()
         except Exception:
             pass
+
+
+def pose_from_dR(d, R):
+    """cd_kin_pose_from_dR (reference src/libcd/kin.c:510-517): [x y z qx qy qz qw] from a translation and a 3x3 rotation"""
+    pose = np.zeros(7)
+    lib().ora_kin_pose_from_dR(dp(pose), dp(f64(d)), dp(f64(R).reshape(9)))
+    return pose
 
 
 def sample_starttraj(wp, deltatime, n_points):

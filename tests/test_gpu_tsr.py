@@ -1,0 +1,176 @@
+"""TSR hard constraints (`con_tsr 'all ...'`, `everyn_tsr`) on the GPU against the
+oracle's restatement of src/libcd/chomp.c:550-600 and src/orcdchomp_mod.cpp:1330-1657, through the
+command layer (`createbatch ... con_tsr ...`), the way the reference's python layer issues them."""
+import numpy as np
+import pytest
+
+import common
+import or_cdchomp_amd
+from or_cdchomp_amd import robots
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import oracle_py as O
+    O.build(ref=False)
+    return O
+
+
+def _start_frame(O, model, base, dofvals, link, tool):
+    """pose pieces of the end effector at the start configuration (rotation, translation)"""
+    rob = O.OraRobot(model)
+    R, t, _, _ = rob.fk(base, dofvals)
+    li = model.link_names.index(link)
+    Rt = np.array(tool[3:])
+    # tool rotation is the identity in these tests: the frame is the link's, moved by the tool offset
+    assert np.allclose(Rt, [0, 0, 0, 1])
+    return R[li], t[li] + R[li] @ np.array(tool[:3]), li
+
+
+def _near_goals(n_runs, seed, spread=0.4):
+    rng = np.random.default_rng(seed)
+    return np.array(robots.WAM_START)[None, :] + spread * rng.uniform(-1, 1, size=(n_runs, 7))
+
+
+def _unit_base():
+    s2 = np.sqrt(0.5)
+    return [-1.0, 0.0, 1.0, 0.0, s2, 0.0, s2]
+
+
+def _setup(mod, base):
+    model, _, dofvals, adofs = common.wam_state()
+    mod.add_robot(model, transform=base, dof_values=dofvals, active_dofs=adofs)
+    from or_cdchomp_amd import scenes
+    scenes.add_tabletop(mod)
+    mod.SendCommand("computedistancefield kinbody table")
+    return model, dofvals, adofs
+
+
+@pytest.mark.parametrize("spec,link,tool", [("all link wam7", "wam7", [0, 0, 0, 0, 0, 0, 1]),
+                                            ("all manipee arm", "handbase", [0, 0, 0.16, 0, 0, 0, 1]),
+                                            ("all", "handbase", [0, 0, 0.16, 0, 0, 0, 1])])
+def test_con_tsr_all_matches_oracle(oracle, spec, link, tool):
+    """keep the end effector's height and two of its angles: three rows on every moving point"""
+    O = oracle
+    base = _unit_base()
+    mod = or_cdchomp_amd.Module(0)
+    model, dofvals, adofs = _setup(mod, base)
+    Ree, tee, li = _start_frame(O, model, base, dofvals, link, tool)
+    Bw = [[-1, 1], [-1, 1], [0, 0], [0, 0], [0, 0], [-3, 3]]      # z, roll, pitch fixed
+    tsr = robots.Tsr(T0w_R=Ree, T0w_d=tee, Bw=Bw)
+    n_runs, n_points, n_iter = 4, 40, 25
+    goals = _near_goals(n_runs, 3)
+    bid = int(mod.SendCommand("createbatch robot %s n_runs %d adofgoals 0x%x n_points %d lambda 100 obs_factor 200 con_tsr '%s' '%s'"
+                              % (model.name, n_runs, goals.ctypes.data, n_points, spec, tsr.serialize())))
+    costs, status = mod.batch_iterate(bid, n_iter)
+    traj = mod.batch_gettraj(bid)
+    mod.batch_destroy(bid)
+    prob = common.tabletop_problem(O)
+    rob = O.OraRobot(model)
+    T0w = O.pose_from_dR(tee, Ree)
+    worst = 0.0
+    for k in range(n_runs):
+        run = O.OraRun(rob, base, dofvals, adofs, goals[k], [prob["sdf"]], [prob["pose"]],
+                       O.default_params(n_points=n_points, lambda_=100.0, obs_factor=200.0))
+        assert run.add_contsr(li, tool, T0w, [0, 0, 0, 0, 0, 0, 1], Bw) == 3
+        before = max(np.abs(run.eval_contsr(0, run.traj()[i])[0]).max() for i in range(1, n_points - 1))
+        st, oc = run.iterate(n_iter)
+        assert st == 0 and status[k] == 0
+        err = common.rel_l2(traj[k], run.traj())
+        worst = max(worst, err)
+        assert np.allclose(costs[k], oc, rtol=1e-6, atol=0)
+        # and the constraint is doing its job: the straight line violates it, the result does not
+        after = max(np.abs(run.eval_contsr(0, traj[k][i])[0]).max() for i in range(1, n_points - 1))
+        assert before > 1e-2 and after < 0.02 * before, (before, after)
+        run.destroy()
+    assert worst <= 1e-6, worst
+
+
+def test_everyn_tsr_with_con_tsr_and_momentum(oracle):
+    """everyn_tsr (active manipulator) together with a con_tsr on a link, momentum on: two constraints
+    per point, the reference's list order (the con_tsr's blocks first)"""
+    O = oracle
+    base = _unit_base()
+    mod = or_cdchomp_amd.Module(0)
+    model, dofvals, adofs = _setup(mod, base)
+    tool = [0, 0, 0.16, 0, 0, 0, 1]
+    Re, te, le = _start_frame(O, model, base, dofvals, "handbase", tool)
+    Rl, tl, ll = _start_frame(O, model, base, dofvals, "wam4", [0, 0, 0, 0, 0, 0, 1])
+    Bw_e = [[-1, 1], [-1, 1], [0, 0], [-3, 3], [-3, 3], [-3, 3]]      # hand height
+    Bw_l = [[0, 0], [-1, 1], [-1, 1], [-3, 3], [-3, 3], [-3, 3]]      # elbow x
+    tsr_e = robots.Tsr(T0w_R=Re, T0w_d=te, Bw=Bw_e)
+    tsr_l = robots.Tsr(T0w_R=Rl, T0w_d=tl, Bw=Bw_l)
+    n_runs, n_points, n_iter = 3, 30, 20
+    goals = _near_goals(n_runs, 7, spread=0.3)
+    bid = int(mod.SendCommand("createbatch robot %s n_runs %d adofgoals 0x%x n_points %d lambda 100 use_momentum "
+                              "everyn_tsr '%s' con_tsr 'all link wam4' '%s'"
+                              % (model.name, n_runs, goals.ctypes.data, n_points, tsr_e.serialize(), tsr_l.serialize())))
+    costs, status = mod.batch_iterate(bid, n_iter)
+    traj = mod.batch_gettraj(bid)
+    mod.batch_destroy(bid)
+    prob = common.tabletop_problem(O)
+    rob = O.OraRobot(model)
+    for k in range(n_runs):
+        run = O.OraRun(rob, base, dofvals, adofs, goals[k], [prob["sdf"]], [prob["pose"]],
+                       O.default_params(n_points=n_points, lambda_=100.0, use_momentum=1))
+        run.add_contsr(le, tool, O.pose_from_dR(te, Re), [0, 0, 0, 0, 0, 0, 1], Bw_e)      # everyn_tsr is added first
+        run.add_contsr(ll, [0, 0, 0, 0, 0, 0, 1], O.pose_from_dR(tl, Rl), [0, 0, 0, 0, 0, 0, 1], Bw_l)
+        st, oc = run.iterate(n_iter)
+        assert st == 0 and status[k] == 0
+        assert common.rel_l2(traj[k], run.traj()) <= 1e-6
+        assert np.allclose(costs[k], oc, rtol=1e-6, atol=0)
+        run.destroy()
+
+
+def test_con_tsr_floating_base(oracle):
+    """floating base: the base pose columns of the constraint Jacobian come from cd_spatial_pose_jac"""
+    O = oracle
+    base = _unit_base()
+    mod = or_cdchomp_amd.Module(0)
+    model, dofvals, adofs = _setup(mod, base)
+    tool = [0, 0, 0, 0, 0, 0, 1]
+    Re, te, le = _start_frame(O, model, base, dofvals, "wam7", tool)
+    Bw = [[-1, 1], [-1, 1], [0, 0], [-3, 3], [-3, 3], [-3, 3]]
+    tsr = robots.Tsr(T0w_R=Re, T0w_d=te, Bw=Bw)
+    n_runs, n_points, n_iter = 2, 24, 12
+    goals = _near_goals(n_runs, 11, spread=0.25)
+    rng = np.random.default_rng(5)
+    basegoals = np.tile(np.array(base), (n_runs, 1)); basegoals[:, :3] += rng.uniform(-0.1, 0.1, size=(n_runs, 3))
+    bid = int(mod.SendCommand("createbatch robot %s n_runs %d adofgoals 0x%x basegoals 0x%x floating_base n_points %d lambda 100 "
+                              "con_tsr 'all link wam7' '%s'"
+                              % (model.name, n_runs, goals.ctypes.data, basegoals.ctypes.data, n_points, tsr.serialize())))
+    costs, status = mod.batch_iterate(bid, n_iter)
+    traj = mod.batch_gettraj(bid)
+    mod.batch_destroy(bid)
+    prob = common.tabletop_problem(O)
+    rob = O.OraRobot(model)
+    for k in range(n_runs):
+        run = O.OraRun(rob, base, dofvals, adofs, goals[k], [prob["sdf"]], [prob["pose"]],
+                       O.default_params(n_points=n_points, lambda_=100.0, floating_base=1), basegoal=basegoals[k])
+        run.add_contsr(le, tool, O.pose_from_dR(te, Re), [0, 0, 0, 0, 0, 0, 1], Bw)
+        st, oc = run.iterate(n_iter)
+        assert st == status[k]
+        if st == 0:
+            assert common.rel_l2(traj[k], run.traj()) <= 1e-6
+            assert np.allclose(costs[k], oc, rtol=1e-6, atol=0)
+        run.destroy()
+
+
+def test_tsr_argument_errors():
+    mod = or_cdchomp_amd.Module(0)
+    model, dofvals, adofs = _setup(mod, _unit_base())
+    tsr = robots.Tsr().serialize()
+    with pytest.raises(RuntimeError, match="con_tsr first arg must be start, end, or all!"):
+        mod.SendCommand("create robot %s adofgoal '0 0 0 0 0 0 0' con_tsr 'start' '%s'" % (model.name, tsr))
+    with pytest.raises(RuntimeError, match="con_tsr link not found!"):
+        mod.SendCommand("create robot %s adofgoal '0 0 0 0 0 0 0' con_tsr 'all link nope' '%s'" % (model.name, tsr))
+    with pytest.raises(RuntimeError, match="con_tsr manip not found!"):
+        mod.SendCommand("create robot %s adofgoal '0 0 0 0 0 0 0' con_tsr 'all manipee nope' '%s'" % (model.name, tsr))
+    with pytest.raises(RuntimeError, match="Cannot parse constraint TSR!"):
+        mod.SendCommand("create robot %s adofgoal '0 0 0 0 0 0 0' con_tsr 'all' '0 NULL 1 2 3'" % model.name)
+    with pytest.raises(RuntimeError, match="You must pass robot before any con_tsrs!"):
+        mod.SendCommand("create con_tsr 'all' '%s' robot %s adofgoal '0 0 0 0 0 0 0'" % (tsr, model.name))
+    with pytest.raises(RuntimeError, match="start_tsr is not supported by this build!"):
+        mod.SendCommand("create robot %s adofgoal '0 0 0 0 0 0 0' start_tsr '%s'" % (model.name, tsr))

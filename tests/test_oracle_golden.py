@@ -260,3 +260,40 @@ def test_e2e_config1_regression(oracle):
         assert np.allclose(run.traj(), g["traj_%d" % n_iter], rtol=0, atol=1e-12)
         assert np.allclose(costs, g["costs_%d" % n_iter], rtol=1e-12, atol=0)
         run.destroy()
+
+
+def test_oracle_tsr_constraint_jacobian_and_effect():
+    """con_tsr restated (reference src/orcdchomp_mod.cpp:1330-1497, src/libcd/chomp.c:550-600): the constraint
+    Jacobian against central differences of the constraint value, and the constraint step pulling a
+    violating straight line onto the constraint.  (Parity unpinned: OpenRAVE's end-effector transform and
+    Jacobians are the build's own kinematic model.)"""
+    from oracle import oracle_py as O
+    O.build(ref=False)
+    model, _, dofvals, adofs = common.wam_state()
+    s2 = np.sqrt(0.5)
+    base = [-1.0, 0.0, 1.0, 0.0, s2, 0.0, s2]
+    prob = common.tabletop_problem(O)
+    rob = O.OraRobot(model)
+    rng = np.random.default_rng(3)
+    goal = np.array(dofvals[:7]) + 0.4 * rng.uniform(-1, 1, 7)
+    run = O.OraRun(rob, base, dofvals, adofs, goal, [prob["sdf"]], [prob["pose"]],
+                   O.default_params(n_points=40, lambda_=100.0, obs_factor=200.0))
+    ee = model.link_names.index("wam7")
+    R, t, _, _ = rob.fk(base, dofvals)
+    Bw = [[-1, 1], [-1, 1], [0, 0], [0, 0], [0, 0], [-3, 3]]
+    assert run.add_contsr(ee, [0, 0, 0, 0, 0, 0, 1], O.pose_from_dR(t[ee], R[ee]), [0, 0, 0, 0, 0, 0, 1], Bw) == 3
+    T = run.traj().copy()
+    assert np.allclose(run.eval_contsr(0, T[0])[0], 0.0, atol=1e-12)          # the frame is the start's own
+    pt = T[17]
+    h, J = run.eval_contsr(0, pt)
+    Jfd = np.zeros_like(J)
+    for c in range(7):
+        d = np.zeros(7); d[c] = 1e-6
+        Jfd[:, c] = (run.eval_contsr(0, pt + d)[0] - run.eval_contsr(0, pt - d)[0]) / 2e-6
+    assert np.abs(J - Jfd).max() < 1e-8
+    before = max(np.abs(run.eval_contsr(0, T[i])[0]).max() for i in range(1, 39))
+    st, _ = run.iterate(30)
+    T2 = run.traj()
+    after = max(np.abs(run.eval_contsr(0, T2[i])[0]).max() for i in range(1, 39))
+    assert st == 0 and before > 0.1 and after < 1e-5
+    run.destroy()
