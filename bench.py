@@ -205,6 +205,9 @@ def main():
     def timed_leg(steps, warmup, streams):
         """(elapsed seconds max over ranks, iterations made by this rank, batch ids, per-step results)"""
         mod.set_num_streams(streams if streams > 1 else 0)
+        # one launch at a time of 769..1024 runs: all of them resident at once with four 192-thread
+        # workgroups per CU (orc_set_workgroup_threads); overlapping launches keep the default shape
+        mod.set_workgroup_threads(192 if (streams <= 1 and config in (2, 3) and 768 < n_runs <= 1024) else 0)
         warm = [wl.create(mod, 900000 + k, rank) for k in range(warmup)]
         timed = [wl.create(mod, k, rank) for k in range(steps)]
         for bid in warm:
@@ -375,7 +378,9 @@ def main():
             "runs_total": int(whole["status"].size),
             "value_serial": value_serial,
             "value_serial_note": None if serial is None else
-                "%d steps, strictly serial launches on one stream, avg kernel %.2f ms" % (serial_steps, serial_ms),
+                "%d steps, strictly serial launches on one stream, avg kernel %.2f ms%s" % (serial_steps, serial_ms,
+                    " (192-thread workgroups, four per CU: the %d runs of a launch are resident at once)" % n_runs
+                    if (config in (2, 3) and 768 < n_runs <= 1024) else ""),
             "roofline": {"bound": "valu" if valu else "hbm",
                          "yardstick": "hbm: SURVEY.md 8(d) algorithmic bytes per launch / average launch duration vs the 8 TB/s peak "
                                       "(the contract's figure); `bound` names what the counters say binds the kernel",

@@ -98,6 +98,13 @@ int orc_robot_set_active_dofs(orc_module * mod, const char * name, const int * i
 /* GetDOFVelocityLimits: used by the linear retimer of gettraj (default 1 for every dof) */
 int orc_robot_set_velocity_limits(orc_module * mod, const char * name, const double * limits, int n);
 
+/* Workgroup shape of the iterate kernel for the batches created from now on: 0 = the planner's choice
+ * (256 threads, three workgroups per CU for the WAM), 192 = three wavefronts, four workgroups per CU:
+ * 1024 runs are then resident at once on 256 CUs and ONE launch of 1024 runs ends ~10 % earlier; large
+ * or overlapping batches are ~5 % slower with it.  The shape never depends on the batch itself, so that a
+ * run's result does not depend on what shares its batch. */
+int orc_set_workgroup_threads(orc_module * mod, int threads);
+
 /* What the TSR constraints of `create` address on the robot (src/orcdchomp_mod.cpp:1957-1976):
  * GetLink(name) for `con_tsr 'all link NAME'`; GetManipulators() / GetActiveManipulator() and their
  * GetEndEffectorTransform() (= end-effector link transform o tool_pose) for `'all manipee NAME'`,

@@ -752,6 +752,12 @@ void BatchShard::build_device(const Robot & robot)
    if (const char * e = getenv("ORC_PCR_LDS")) force_pcr = atoi(e);
    if (const char * e = getenv("ORC_AG_LDS")) force_ag = atoi(e);
    if (const char * e = getenv("ORC_WGS")) max_wgs = atoi(e);
+   // The shape is a function of the robot and the run parameters only, never of the batch (a run's bits
+   // must not depend on what shares its batch).  A caller that knows its batches fit the chip in one
+   // wave of four workgroups per CU but not of three (769..1024 runs: the 1024 of BASELINE configs[1])
+   // can ask for the 192-thread shape for the whole module: orc_set_workgroup_threads (measured, one
+   // launch of 1024 WAM runs: 9.3 M it/s against 8.4 M; from 4096 runs on the order is reversed).
+   force_block = mod_->workgroup_threads;
    if (const char * e = getenv("ORC_BLOCK_THREADS")) force_block = atoi(e);
    int force_g = -1, force_tl = -1;
    if (const char * e = getenv("ORC_G_LDS")) force_g = atoi(e);

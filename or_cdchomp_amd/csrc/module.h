@@ -274,6 +274,7 @@ public:
    std::map<int, std::vector<hipStream_t>> stream_pool;
    std::map<int, size_t> next_pool_stream;
    int num_streams = 0;
+   int workgroup_threads = 0;       // 0: the planner's choice; 192 or 256: the workgroup shape of every batch created from now on
    void set_num_streams(int n);
    hipStream_t pick_stream(int device, bool distinct);
    // kernel timing (HIP events on the shards' streams), harvested from the shards

@@ -68,6 +68,10 @@ class Module:
     def set_stream(self, hip_stream):
         self._check(self._lib.orc_set_stream(self._h, C.c_void_p(hip_stream)))
 
+    def set_workgroup_threads(self, threads):
+        """0 (default plan), 192 or 256 threads per workgroup for the batches created from now on"""
+        self._check(self._lib.orc_set_workgroup_threads(self._h, int(threads)))
+
     def set_num_streams(self, n):
         self._check(self._lib.orc_set_num_streams(self._h, int(n)))
 
