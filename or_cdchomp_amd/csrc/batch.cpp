@@ -773,6 +773,8 @@ void BatchShard::build_device(const Robot & robot)
    std::vector<Shape> shapes;
    for (int wgs=max_wgs; wgs>=1; wgs--) shapes.push_back({ 256, wgs });
    if (max_wgs >= 3) shapes.push_back({ 192, 4 });
+   // a caller that asked for the 192-thread shape gets it for runs that do not fit four to a CU as well
+   if (force_block == 192) for (int wgs=3; wgs>=1; wgs--) shapes.push_back({ 192, wgs });
    for (const Shape & sh : shapes)
    {
       const int wgs = sh.wgs, block = sh.block;
