@@ -645,9 +645,39 @@ __device__ __forceinline__ int limit_rounds_regs(PT T_s, PJ jl_s, int m, int n, 
       const int owner = gi / RPL;
       // the owner's own best is the winner (its key is the global one), so its signed value is Gjlimit[largest]
       const real gl = read_lane(best_g, owner);
-      // GA = A^-1 Gjlimit column by column; the winner's entry is picked up on the way
-      real x[NC][RPL];
+      // GA = A^-1 Gjlimit by one prefix and one suffix wave scan per column.  The winner's column comes
+      // first: its entry at the winner is the scale of the round; then every column with a violated entry
+      // is solved and applied at once (nothing of GA is kept: registers for up to 8 columns x 4 rows)
+      auto scan_column = [&](const real (& gc_)[RPL], real (& xo)[RPL])
+      {
+         real sp = 0, sq = 0;
+#pragma unroll
+         for (int r=0; r<RPL; r++) { sp += gc_[r] * wp[r]; sq += gc_[r] * wq[r]; }
+         const real ip = wave_prefix_incl(sp), is = wave_suffix_incl(sq);
+         real run_p = __shfl_up(ip, 1, 64);   if (lane == 0) run_p = 0;
+         real run_q = __shfl_down(is, 1, 64); if (lane == 63) run_q = 0;
+         real q[RPL];
+#pragma unroll
+         for (int r=RPL-1; r>=0; r--) { q[r] = run_q; run_q += gc_[r] * wq[r]; }
+#pragma unroll
+         for (int r=0; r<RPL; r++)
+         {
+            run_p += gc_[r] * wp[r];
+            xo[r] = kinv * (wq[r] * run_p + wp[r] * q[r]);
+         }
+      };
       real ga_mine = 0;
+#pragma unroll
+      for (int ci=0; ci<NC; ci++)
+      {
+         if (col[ci] != gc) continue;                  // wave-uniform
+         real xw[RPL];
+         scan_column(g[ci], xw);
+#pragma unroll
+         for (int r=0; r<RPL; r++) ga_mine = (lane*RPL + r == gi) ? xw[r] : ga_mine;
+      }
+      const real ga = read_lane(ga_mine, owner);
+      const real sc = ((real)1.01 * gl) * rcp_fast(ga);
 #pragma unroll
       for (int ci=0; ci<NC; ci++)
       {
@@ -655,35 +685,12 @@ __device__ __forceinline__ int limit_rounds_regs(PT T_s, PJ jl_s, int m, int n, 
          unsigned long long anyc = 0ull;
 #pragma unroll
          for (int r=0; r<RPL; r++) anyc |= mk[ci][r];
-         if (NC > 3 && anyc == 0ull)
-         {
+         if (anyc == 0ull) continue;
+         real xc[RPL];
+         scan_column(g[ci], xc);
 #pragma unroll
-            for (int r=0; r<RPL; r++) x[ci][r] = 0;
-            continue;
-         }
-         real sp = 0, sq = 0;
-#pragma unroll
-         for (int r=0; r<RPL; r++) { sp += g[ci][r] * wp[r]; sq += g[ci][r] * wq[r]; }
-         const real ip = wave_prefix_incl(sp), is = wave_suffix_incl(sq);
-         real run_p = __shfl_up(ip, 1, 64);   if (lane == 0) run_p = 0;
-         real run_q = __shfl_down(is, 1, 64); if (lane == 63) run_q = 0;
-         real q[RPL];
-#pragma unroll
-         for (int r=RPL-1; r>=0; r--) { q[r] = run_q; run_q += g[ci][r] * wq[r]; }
-#pragma unroll
-         for (int r=0; r<RPL; r++)
-         {
-            run_p += g[ci][r] * wp[r];
-            x[ci][r] = kinv * (wq[r] * run_p + wp[r] * q[r]);
-            ga_mine = (col[ci] == gc && lane*RPL + r == gi) ? x[ci][r] : ga_mine;
-         }
+         for (int r=0; r<RPL; r++) T[ci][r] += sc * xc[r];
       }
-      const real ga = read_lane(ga_mine, owner);
-      const real sc = ((real)1.01 * gl) * rcp_fast(ga);
-#pragma unroll
-      for (int ci=0; ci<NC; ci++)
-#pragma unroll
-         for (int r=0; r<RPL; r++) T[ci][r] += sc * x[ci][r];
    }
 #pragma unroll
    for (int r=0; r<RPL; r++)
@@ -751,6 +758,17 @@ __device__ __forceinline__ LimResult limit_rounds_body(PT T_s, real * G_gen, con
          case 6: res.rounds = limit_rounds_regs<real, 6, 2>(T_s, jl_s, m, n, kinv, viol_cols, dg); break;
          case 7: res.rounds = limit_rounds_regs<real, 7, 2>(T_s, jl_s, m, n, kinv, viol_cols, dg); break;
          default: res.rounds = limit_rounds_regs<real, 8, 2>(T_s, jl_s, m, n, kinv, viol_cols, dg); break;
+         }
+         break;
+      }
+      if (m <= 256 && nc <= 7)      // 200-waypoint runs (BASELINE configs[3]: seven arm columns can leave their limits)
+      {
+         switch (nc)
+         {
+         case 4: res.rounds = limit_rounds_regs<real, 4, 4>(T_s, jl_s, m, n, kinv, viol_cols, dg); break;
+         case 5: res.rounds = limit_rounds_regs<real, 5, 4>(T_s, jl_s, m, n, kinv, viol_cols, dg); break;
+         case 6: res.rounds = limit_rounds_regs<real, 6, 4>(T_s, jl_s, m, n, kinv, viol_cols, dg); break;
+         default: res.rounds = limit_rounds_regs<real, 7, 4>(T_s, jl_s, m, n, kinv, viol_cols, dg); break;
          }
          break;
       }

@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 import common
+import or_cdchomp_amd
 from or_cdchomp_amd import bindings
 
 pytestmark = pytest.mark.gpu
@@ -252,3 +253,33 @@ def test_one_batch_over_two_shards_in_one_process(monkeypatch):
     with pytest.raises(RuntimeError, match="bad device ordinal"):
         one.SendCommand("createbatch robot %s n_runs 37 adofgoals 0x%x basegoals 0x%x floating_base devices '0 99'"
                         % (model.name, g.ctypes.data, bg.ctypes.data))
+
+
+def test_workgroup_shape_is_a_module_setting(oracle):
+    """orc_set_workgroup_threads: 192-thread workgroups (four per CU) give the trajectories of the default
+    shape (the same arithmetic per waypoint and per column; only the cost sums are grouped differently),
+    and the shape of a module's batches does not depend on their size"""
+    mod = or_cdchomp_amd.Module(0)
+    model = common.setup_product_wam(mod)
+    goals = common.wam_goals(96, seed=77)
+    kw = dict(n_points=100, lambda_=100.0, obs_factor=500.0)
+    a = mod.batch_create(model.name, goals, **kw)
+    ca, sa = mod.batch_iterate(a, 60)
+    ta = mod.batch_gettraj(a)
+    mod.batch_destroy(a)
+    mod.set_workgroup_threads(192)
+    b = mod.batch_create(model.name, goals, **kw)
+    cb, sb = mod.batch_iterate(b, 60)
+    tb = mod.batch_gettraj(b)
+    # a subset in a batch of its own: bit for bit the same under the module's shape
+    c = mod.batch_create(model.name, goals[10:30], **kw)
+    cc, sc = mod.batch_iterate(c, 60)
+    tc = mod.batch_gettraj(c)
+    mod.batch_destroy(b); mod.batch_destroy(c)
+    mod.set_workgroup_threads(0)
+    assert np.array_equal(sa, sb)
+    assert np.array_equal(ta, tb)
+    assert np.allclose(ca, cb, rtol=1e-13, atol=0)
+    assert np.array_equal(tc, tb[10:30]) and np.array_equal(cc, cb[10:30]) and np.array_equal(sc, sb[10:30])
+    with pytest.raises(RuntimeError, match="workgroup threads must be 0"):
+        mod.set_workgroup_threads(128)
