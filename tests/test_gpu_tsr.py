@@ -174,3 +174,42 @@ def test_tsr_argument_errors():
         mod.SendCommand("create con_tsr 'all' '%s' robot %s adofgoal '0 0 0 0 0 0 0'" % (tsr, model.name))
     with pytest.raises(RuntimeError, match="start_tsr is not supported by this build!"):
         mod.SendCommand("create robot %s adofgoal '0 0 0 0 0 0 0' start_tsr '%s'" % (model.name, tsr))
+
+
+def test_con_tsr_full_trajectory_length(oracle):
+    """BASELINE configs[1] shapes with a constraint: 100 waypoints, 64 runs, two constrained rows per moving
+    point (a 196 x 196 system per run and iteration), three runs of the batch against the oracle"""
+    O = oracle
+    base = _unit_base()
+    mod = or_cdchomp_amd.Module(0)
+    model, dofvals, adofs = _setup(mod, base)
+    tool = [0, 0, 0, 0, 0, 0, 1]
+    Re, te, le = _start_frame(O, model, base, dofvals, "wam7", tool)
+    Bw = [[-1, 1], [-1, 1], [0, 0], [0, 0], [-3, 3], [-3, 3]]      # height and roll
+    tsr = robots.Tsr(T0w_R=Re, T0w_d=te, Bw=Bw)
+    n_runs, n_points, n_iter = 64, 100, 30
+    goals = _near_goals(n_runs, 21, spread=0.35)
+    bid = int(mod.SendCommand("createbatch robot %s n_runs %d adofgoals 0x%x n_points %d lambda 100 obs_factor 500 con_tsr 'all link wam7' '%s'"
+                              % (model.name, n_runs, goals.ctypes.data, n_points, tsr.serialize())))
+    costs, status = mod.batch_iterate(bid, n_iter)
+    traj = mod.batch_gettraj(bid)
+    mod.batch_destroy(bid)
+    prob = common.tabletop_problem(O)
+    rob = O.OraRobot(model)
+    for k in (0, 31, 63):
+        run = O.OraRun(rob, base, dofvals, adofs, goals[k], [prob["sdf"]], [prob["pose"]],
+                       O.default_params(n_points=n_points, lambda_=100.0, obs_factor=500.0))
+        assert run.add_contsr(le, tool, O.pose_from_dR(te, Re), [0, 0, 0, 0, 0, 0, 1], Bw) == 2
+        st, oc = run.iterate(n_iter)
+        assert st == status[k]
+        if st == 0:
+            assert common.rel_l2(traj[k], run.traj()) <= 1e-6
+            assert np.allclose(costs[k], oc, rtol=1e-6, atol=0)
+        run.destroy()
+    # a subset on its own: bit for bit (the constraint workspace is per run)
+    bid = int(mod.SendCommand("createbatch robot %s n_runs %d adofgoals 0x%x n_points %d lambda 100 obs_factor 500 con_tsr 'all link wam7' '%s'"
+                              % (model.name, 8, np.ascontiguousarray(goals[8:16]).ctypes.data, n_points, tsr.serialize())))
+    mod.batch_iterate(bid, n_iter)
+    sub = mod.batch_gettraj(bid)
+    mod.batch_destroy(bid)
+    assert np.array_equal(sub, traj[8:16])
