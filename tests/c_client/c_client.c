@@ -100,6 +100,28 @@ int main(void)
    else printf("error path: \"%s\"\n", orc_last_error(m));
    if (strcmp(orc_last_error(m), "Did not pass either adofgoal or starttraj!") != 0) bad++;
 
+   /* a TSR hard constraint through the command layer: keep the tool's height (link names and a
+    * manipulator are what `con_tsr 'all manipee NAME'` addresses; identity frames, z row fixed) */
+   {
+      const char * names[NL] = { "base", "upper", "fore", "hand" };
+      const double tool[7] = { 0.15, 0, 0, 0, 0, 0, 1 };
+      CHECK(orc_robot_set_link_names(m, "arm3", names, NL));
+      CHECK(orc_robot_add_manipulator(m, "arm3", "gripper", 3, tool));
+      CHECK(orc_robot_set_active_manipulator(m, "arm3", "gripper"));
+      CHECK(orc_set_workgroup_threads(m, 0));
+      snprintf(cmd, sizeof cmd, "create robot arm3 adofgoal '%.17g %.17g %.17g' lambda 50.0000 n_points %d obs_factor 300.000000 "
+               "con_tsr 'all manipee gripper' '0 NULL 1 0 0 0 1 0 0 0 1 0 0 0  1 0 0 0 1 0 0 0 1 0 0 0  -9 9 -9 9 0 0 -9 9 -9 9 -9 9'",
+               -1.0, 0.4, 0.3, NP);      /* goal = start: the constraint pins the tool at z = 0 of the world, which it is not at */
+      CHECK(orc_send_command(m, cmd, handle, sizeof handle));
+      snprintf(cmd, sizeof cmd, "iterate run %s n_iter 5", handle);
+      CHECK(orc_send_command(m, cmd, reply, sizeof reply));
+      printf("a TSR-constrained run through create/iterate: cost %s\n", reply);
+      snprintf(cmd, sizeof cmd, "destroy run %s", handle);
+      CHECK(orc_send_command(m, cmd, reply, sizeof reply));
+      if (orc_send_command(m, "create robot arm3 adofgoal '0 0 0' con_tsr 'all link nope' '0 NULL 1 0 0 0 1 0 0 0 1 0 0 0  1 0 0 0 1 0 0 0 1 0 0 0  0 0 0 0 0 0 0 0 0 0 0 0'",
+                           reply, sizeof reply) == 0 || strcmp(orc_last_error(m), "con_tsr link not found!") != 0) bad++;
+   }
+
    int collides[NR];
    CHECK(orc_batch_collision_verdict(m, bid, collides, NULL, NULL, NULL, NULL));
    int nc = 0; for (int k=0; k<NR; k++) nc += collides[k];
