@@ -17,7 +17,8 @@ Every step works on its own freshly created batch (created before the timed regi
 trajectories are resident in HBM when it starts).  `value` = iterations the runs actually made
 (the kernel counts them per run: a run that leaves its joint limits stops for the rest of the call,
 as the reference throws) / wall time of the K steps, which are issued round-robin on `--streams`
-HIP streams (default 3) so that the tail of one launch overlaps the head of the next.
+HIP streams (default 2: two launches overlap, so that the tail of one -- a few slow runs -- is filled by
+the next; more streams give the same throughput and longer launches) .
 `value_serial` is the same workload with strictly serial launches on one stream.
 
 `roofline`: the contract's yardstick -- ALGORITHMIC bytes of SURVEY.md 8(d) per launch / the fused
@@ -158,7 +159,7 @@ def main():
     ap.add_argument("--config", type=int, default=0, help="BASELINE configuration: 2 (default at --gpus 1), 3 (default at "
                                                           "--gpus > 1), 4 or 5")
     ap.add_argument("--batch", type=int, default=0, help="runs per GPU (default: the configuration's own size)")
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the steps are issued on round-robin: consecutive steps are independent batches, "
                          "so the tail of one launch (a few slow runs) is filled by the next; 1 = strictly serial launches")
     ap.add_argument("--serial-steps", type=int, default=-1, help="steps of the strictly serial leg (value_serial); default min(steps, 10)")

@@ -21,7 +21,9 @@ root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
-stats = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))[0]
+# gpurun merges every call's files into the same directory: the newest file is this call's
+newest = lambda pattern: max(glob.glob(pattern), key=os.path.getmtime)
+stats = newest(os.path.join(src, "trace", "*", "*kernel_stats.csv"))
 shutil.copy(stats, os.path.join(dst, name + "_kernel_stats.csv"))
 summary = {"source": "rocprofv3 on `python3 bench.py --config %d --no-cpu-baseline --serial-steps 0 --steps N --warmup W` "
                      "(scripts/profile_round.sh): --kernel-trace --stats with 20 steps; one --pmc pass per counter group with 2 steps" % config,
@@ -40,6 +42,7 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
     files = glob.glob(os.path.join(src, sub, "*", "*counter_collection.csv"))
     if not files:
         continue
+    files = [max(files, key=os.path.getmtime)]
     agg = collections.defaultdict(list)
     meta = {}
     for r in csv.DictReader(open(files[0])):
