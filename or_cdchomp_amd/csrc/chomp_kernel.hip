@@ -96,6 +96,27 @@ __device__ __forceinline__ float sqrt_rsq(float x, float * inv)
    *inv = 1.0f / g;
    return g;
 }
+// the same for x > 0 known (pair distances: the caller substitutes 1 where there is no pair), without
+// the guards for x == 0.  (One Goldschmidt step would do for the square root -- 1.1e-16 over 2^20 values,
+// scripts/ubench/rsq_prec.hip -- but leaves its reciprocal at 4e-15, and the three instructions saved per
+// pair evaluation do not show in the throughput: kept at two.)
+__device__ __forceinline__ double sqrt_rsq_pos(double x, double * inv)
+{
+   double r = __builtin_amdgcn_rsq(x);
+   double g = x * r, h = 0.5 * r;
+#pragma unroll
+   for (int k=0; k<2; k++)
+   {
+      const double e = fma(-h, g, 0.5);
+      g = fma(g, e, g);
+      h = fma(h, e, h);
+   }
+   const double d = fma(-g, g, x);
+   g = fma(d, h, g);
+   *inv = 2.0 * h;
+   return g;
+}
+__device__ __forceinline__ float sqrt_rsq_pos(float x, float * inv) { return sqrt_rsq(x, inv); }
 
 // sum over aligned groups of GS lanes (GS a power of two <= 64); every lane of the group
 // receives the total.  Up to 16 lanes stay inside a DPP row (no LDS pipe).

@@ -151,7 +151,7 @@ __device__ __forceinline__ void self_sym_step16(const real * prow, const real * 
    const real wo = dpp_move<F>(wself);
    // shared part of the pair
    real inv_d;
-   real dist = sqrt_rsq(near ? d2 : (real)1, &inv_d);
+   real dist = sqrt_rsq_pos(near ? d2 : (real)1, &inv_d);      // (two coinciding centres: NaN, as in the reference)
    dist -= radius + ro;
    const real de = dist - eps_self;
    const real cself = (dist < (real)0) ? ((real)0.5 * eps_self - dist) : ((real)0.5 * inv_eps_self) * de * de;
