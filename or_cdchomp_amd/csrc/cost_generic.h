@@ -78,6 +78,7 @@ __device__ __forceinline__ void cost_tile_generic(const BT & b, const ModelView<
          {
             SdfCells<real> cells[4];
             real v0[4], vn[4][3];
+            bool use[4] = { false, false, false, false };              // wave-uniform: some sphere of the wavefront is inside the field
 #pragma unroll
             for (int q=0; q<4; q++)
             {
@@ -87,6 +88,13 @@ __device__ __forceinline__ void cost_tile_generic(const BT & b, const ModelView<
 #pragma unroll
                for (int k=0; k<3; k++)
                   gp[k] = F.Rgw[k*3+0]*p[0] + F.Rgw[k*3+1]*p[1] + F.Rgw[k*3+2]*p[2] + F.tgw[k];
+               // a field none of the wavefront's spheres is inside of contributes nothing (the reference
+               // skips an out-of-bounds lookup, src/orcdchomp_mod.cpp:1176-1183): no cells, no reads
+               bool inb = live;
+#pragma unroll
+               for (int k=0; k<3; k++) { const real x = gp[k] * F.inv_length[k]; inb = inb && !(x < (real)0) && !(x > (real)1); }
+               use[q] = (__builtin_amdgcn_ballot_w64(inb) != 0ull);
+               if (!use[q]) continue;
                cells[q] = sdf_cells(F, gp);
                v0[q] = F.data[ORC_SDF_IDX(cells[q].index)];
 #pragma unroll
@@ -95,7 +103,7 @@ __device__ __forceinline__ void cost_tile_generic(const BT & b, const ModelView<
 #pragma unroll
             for (int q=0; q<4; q++)
             {
-               if (i0 + q >= b.n_sdfs) continue;
+               if (i0 + q >= b.n_sdfs || !use[q]) continue;
                const DevSdf<real> & F = sdfs[i0 + q];
                real gg[3], val;
                sdf_combine(F, cells[q], v0[q], vn[q], val, gg);
