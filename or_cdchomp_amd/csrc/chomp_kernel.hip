@@ -1068,6 +1068,11 @@ __device__ __attribute__((noinline)) double phase_cost(const void * kp, int ts_i
       cost_tile_generic<real, BLOCK>(b, E.mod, E.sdfs_s, ts, te, do_iteration, E.T_s, E.Gc, E.pos_s, E.ax_s, E.srad_s, E.sinact_s,
                                      E.slink_s, E.jtype_s, E.jcol_s, E.pstr, E.astr, inv_eps, inv_eps_self, cost_lane, nullptr);
    __syncthreads();
+#ifdef ORC_COST_TIMERS
+   if constexpr (GS16) if (threadIdx.x == 0 && blockIdx.x == 0 && ts > 0 && !do_iteration)
+      printf("cost sections (cycles of wavefront 0, whole launch): setup %lld obstacle %lld self %lld jt %lld between %lld\n",
+             orc_cost_dbg[0], orc_cost_dbg[1], orc_cost_dbg[2], orc_cost_dbg[3], orc_cost_dbg[4]);
+#endif
    phase_mark<real>(b, E, 1);
    return cost_lane;
 }
@@ -1416,7 +1421,6 @@ void chomp_iterate_kernel(const DevBatch<real> b)
    const void * kp = (const void *) __builtin_amdgcn_kernarg_segment_ptr();      // DevBatch b is the kernel's only argument
    const int run = blockIdx.x;
    const int tid = threadIdx.x;
-   const int m = b.m, tile_m = b.tile_m;
 
    phase_setup<real, TREE, GS16, BLOCK>(kp);
 
@@ -1454,9 +1458,9 @@ void chomp_iterate_kernel(const DevBatch<real> b)
       }
 
       double cost_lane = 0.0;
-      for (int ts=0; ts<m; ts+=tile_m)
+      for (int tk=0; tk<b.n_tiles; tk++)
       {
-         const int te = (ts + tile_m < m) ? ts + tile_m : m;
+         const int ts = b.tile_start[tk], te = b.tile_start[tk+1];
 #ifndef ORC_ABLATE_FK
          phase_fk<real, TREE, GS16, BLOCK>(kp, ts, te);
 #endif

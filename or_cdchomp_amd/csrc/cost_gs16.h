@@ -10,6 +10,9 @@
 // SDF lookup src/libcd/grid.c:191-209, 331-454.
 #pragma once
 
+#ifdef ORC_COST_TIMERS
+__device__ long long orc_cost_dbg[8];   // [0] setup [1] obstacle [2] self collision [3] J^T [4] between rounds (thread 0 of every workgroup adds: use one run)
+#endif
 // SDF lookup without early exits: returns whether p is inside the field; value/grad are only
 // meaningful then (indices are clamped so that the loads stay inside the grid either way).
 template <typename real>
@@ -194,9 +197,16 @@ __device__ __forceinline__ void cost_tile_gs16(const BT & b, const ModelView<rea
    const int items = ngroups * 16;
    const real inf = M<real>::inf();
 
+#ifdef ORC_COST_TIMERS
+   long long ctm_ = clock64();
+#define ORC_CMARK(slot) do { if (tid == 0) { const long long now_ = clock64(); orc_cost_dbg[slot] += now_ - ctm_; ctm_ = now_; } } while (0)
+#else
+#define ORC_CMARK(slot) do { } while (0)
+#endif
    for (int base_item=0; base_item<items; base_item+=BLOCK)
    {
       if (base_item + (tid & ~63) >= items) continue;      // a wavefront without a waypoint in this round (wave-uniform)
+      ORC_CMARK(4);
       // the last round of a tile goes first: it is what the tile's barrier waits for
       if (base_item + BLOCK >= items) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
       const int item = base_item + tid;
@@ -243,6 +253,7 @@ __device__ __forceinline__ void cost_tile_gs16(const BT & b, const ModelView<rea
          for (int k=0; k<3; k++) uvec[u][k] = vel[u][k] * su;
       }
 
+      ORC_CMARK(0);
       // ---- obstacle term (src/orcdchomp_mod.cpp:1171-1246) ----
       real best[U], bgrad[U][3]; bool has[U];
 #pragma unroll
@@ -313,6 +324,7 @@ __device__ __forceinline__ void cost_tile_gs16(const BT & b, const ModelView<rea
          }
       }
 
+      ORC_CMARK(1);
       // ---- self collision (src/orcdchomp_mod.cpp:1251-1317) ----
       for (int o=Sa; o<S; o++)                 // inactive spheres have no lane: only this lane's side
       {
@@ -368,6 +380,7 @@ __device__ __forceinline__ void cost_tile_gs16(const BT & b, const ModelView<rea
 #pragma unroll
       for (int u=0; u<U; u++) cost_lane += live[u] ? cost_sphere[u] : 0.0;
 
+      ORC_CMARK(2);
       // ---- J^T contraction and reduction over the 16 spheres of a waypoint ----
       if (do_iteration)
       {
@@ -529,5 +542,6 @@ __device__ __forceinline__ void cost_tile_gs16(const BT & b, const ModelView<rea
             }
          }
       }
+      ORC_CMARK(3);
    }
 }
