@@ -101,8 +101,11 @@ int orc_robot_set_velocity_limits(orc_module * mod, const char * name, const dou
 /* Workgroup shape of the iterate kernel for the batches created from now on: 0 = the planner's choice
  * (256 threads, three workgroups per CU for the WAM), 192 = three wavefronts, four workgroups per CU:
  * 1024 runs are then resident at once on 256 CUs and ONE launch of 1024 runs ends ~10 % earlier; large
- * or overlapping batches are ~5 % slower with it.  The shape never depends on the batch itself, so that a
- * run's result does not depend on what shares its batch. */
+ * or overlapping batches are ~5 % slower with it; 512 = eight wavefronts on one run, one run per CU, the
+ * whole trajectory in one tile: the latency shape for batches smaller than the chip (one run: 34 k
+ * instead of 22 k iterations/s, 256 runs: 5.4 M instead of 4.2 M).  The single-run `create` command uses
+ * 512 unless a shape is set here.  The shape never depends on the batch itself, so that a run's result
+ * does not depend on what shares its batch (trajectories are bit-identical across shapes). */
 int orc_set_workgroup_threads(orc_module * mod, int threads);
 
 /* What the TSR constraints of `create` address on the robot (src/orcdchomp_mod.cpp:1957-1976):

@@ -757,7 +757,7 @@ void BatchShard::build_device(const Robot & robot)
    // wave of four workgroups per CU but not of three (769..1024 runs: the 1024 of BASELINE configs[1])
    // can ask for the 192-thread shape for the whole module: orc_set_workgroup_threads (measured, one
    // launch of 1024 WAM runs: 9.3 M it/s against 8.4 M; from 4096 runs on the order is reversed).
-   force_block = mod_->workgroup_threads;
+   force_block = mod_->workgroup_threads ? mod_->workgroup_threads : params.workgroup_threads;
    if (const char * e = getenv("ORC_BLOCK_THREADS")) force_block = atoi(e);
    int force_g = -1, force_tl = -1;
    if (const char * e = getenv("ORC_G_LDS")) force_g = atoi(e);
@@ -775,6 +775,9 @@ void BatchShard::build_device(const Robot & robot)
    if (max_wgs >= 3) shapes.push_back({ 192, 4 });
    // a caller that asked for the 192-thread shape gets it for runs that do not fit four to a CU as well
    if (force_block == 192) for (int wgs=3; wgs>=1; wgs--) shapes.push_back({ 192, wgs });
+   // the latency shape: eight wavefronts on one run, one run per CU (a lone wavefront issues a vector
+   // instruction every ~9 cycles: two per SIMD halve the time of an iteration; for batches smaller than the chip)
+   if (force_block == 512) shapes.push_back({ 512, 1 });
    for (const Shape & sh : shapes)
    {
       const int wgs = sh.wgs, block = sh.block;
@@ -1059,7 +1062,7 @@ void BatchShard::launch(int n_iter, bool final_eval)
       else hip_check(hipEventCreate(&ev[k]), "hipEventCreate");
    }
    hip_check(hipEventRecord(ev[0], stream_), "hipEventRecord");
-   hipError_t e = launch_typed(b, lds_bytes_, stream_, tree_ | (block_ == 192 ? 4 : 0));
+   hipError_t e = launch_typed(b, lds_bytes_, stream_, tree_ | (block_ == 192 ? 4 : 0) | (block_ == 512 ? 8 : 0));
    hip_check(e, "chomp_iterate_kernel launch");
    hip_check(hipEventRecord(ev[1], stream_), "hipEventRecord");
    pending_events_.push_back(std::make_pair(ev[0], ev[1]));

@@ -166,7 +166,8 @@ int orc_robot_set_velocity_limits(orc_module * mod, const char * name, const dou
 int orc_set_workgroup_threads(orc_module * mod, int threads)
 {
    return guarded(mod, [&] {
-      if (threads != 0 && threads != 192 && threads != 256) throw std::runtime_error("workgroup threads must be 0 (default), 192 or 256!");
+      if (threads != 0 && threads != 192 && threads != 256 && threads != 512)
+         throw std::runtime_error("workgroup threads must be 0 (default), 192, 256 or 512!");
       mod->impl->workgroup_threads = threads;
    });
 }

@@ -199,7 +199,15 @@ __device__ __forceinline__ real dpp_row_max(real v);   // defined after dpp_move
 template <typename real>
 __device__ __forceinline__ void wave_argmax(real & best, int & best_e);
 
-// sum over the whole workgroup (3 or 4 wavefronts); every thread receives the result.
+// the partial sums of a workgroup's wavefronts, added in a fixed pairwise order
+template <int BLOCK>
+__device__ __forceinline__ double sum_partials(const double * r)
+{
+   if (BLOCK == 192) return (r[0] + r[1]) + r[2];
+   if (BLOCK == 256) return (r[0] + r[1]) + (r[2] + r[3]);
+   return ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));      // 512 threads
+}
+// sum over the whole workgroup; every thread receives the result.
 template <int BLOCK>
 __device__ __forceinline__ double block_sum(double v, double * red)
 {
@@ -207,8 +215,7 @@ __device__ __forceinline__ double block_sum(double v, double * red)
    __syncthreads();
    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
    __syncthreads();
-   if (BLOCK == 192) return (red[0] + red[1]) + red[2];
-   return (red[0] + red[1]) + (red[2] + red[3]);
+   return sum_partials<BLOCK>(red);
 }
 
 // ---------------------------------------------------------------------------
@@ -800,14 +807,14 @@ __device__ __forceinline__ LimResult limit_rounds_body(PT T_s, real * G_gen, con
    return res;
 }
 // the trajectory in LDS (every kernel but the large-robot plans that leave it in global memory)
-template <typename real>
+template <typename real, int SHAPE>      // SHAPE: a copy per register budget of the calling kernels (the budget follows the callers')
 __device__ __attribute__((noinline)) LimResult limit_rounds_call(real * T_gen, real * G_gen, const real * jl_gen, int m, int n, real kinv,
    unsigned long long viol_cols)
 {
    typedef __attribute__((address_space(3))) real * lds_ptr;
    return limit_rounds_body<real>((lds_ptr) T_gen, G_gen, jl_gen, m, n, kinv, viol_cols);
 }
-template <typename real>
+template <typename real, int SHAPE>
 __device__ __attribute__((noinline)) LimResult limit_rounds_call_global(real * T_gen, real * G_gen, const real * jl_gen, int m, int n, real kinv,
    unsigned long long viol_cols)
 {
@@ -891,7 +898,7 @@ __device__ __forceinline__ Env<real> make_env(const BT & b, unsigned char * smem
    const int nj = b.ms.nj, Sa = b.ms.Sa, S = b.ms.S;
    const auto & L = b.lay;          // computed on the host (lds_layout, dev_types.h)
    E.red = (double *) smem_raw;                            // [8] reduction scratch
-   E.redi = (int *)(E.red + 8);                            // [8]
+   E.redi = (int *)(E.red + 16);                           // [8] (red: [16] doubles, one or two per wavefront)
    E.colmask_s = (unsigned int *)(E.redi + 8);             // [2] columns with an entry outside its joint limits after the step
    E.phc_s = (long long *)(smem_raw + ORC_LDS_HEADER - 64);
    real * lds = (real *)(smem_raw + ORC_LDS_HEADER);
@@ -948,7 +955,7 @@ __device__ __forceinline__ void phase_mark(const BT & b, const Env<real> & E, in
 {
    if (b.phase_cycles && threadIdx.x == 0)
    {
-      long long * tm = (long long *)((unsigned char *) E.red + 104);
+      long long * tm = (long long *)((unsigned char *) E.red + 168);
       const long long now = clock64();
       if (slot >= 0) E.phc_s[slot] += now - *tm;
       *tm = now;
@@ -1188,8 +1195,8 @@ __device__ __attribute__((noinline)) int phase_update(const void * kp, int it_in
          if (tid < 64)
          {
             const real kinv = (real)(-1) / ((real)(m + 1) * b.a_off);      // 1/((m+1) ca), ca = -a_off
-            const LimResult lr = (GS16 || b.t_in_lds) ? limit_rounds_call<real>(T_s, G_s, jl_s, m, n, kinv, viol_cols)
-                                                      : limit_rounds_call_global<real>(T_s, G_s, jl_s, m, n, kinv, viol_cols);
+            const LimResult lr = (GS16 || b.t_in_lds) ? limit_rounds_call<real, (BLOCK == 512)>(T_s, G_s, jl_s, m, n, kinv, viol_cols)
+                                                      : limit_rounds_call_global<real, (BLOCK == 512)>(T_s, G_s, jl_s, m, n, kinv, viol_cols);
             if (b.phase_cycles && tid == 0) E.phc_s[7] += lr.kinds;
             if (tid == 0) redi[0] = lr.rounds;
          }
@@ -1238,7 +1245,7 @@ __device__ __attribute__((noinline)) int phase_update(const void * kp, int it_in
          int * lst = cnt + 64;                                  // [64][2]  (row, column) of a violated entry
          real * lval = (real *)(lst + 128);                     // [64] its Gjlimit value
          const int lane = tid & 63, wave = tid >> 6;
-         if (K <= 16)
+         if (K * (BLOCK/64) <= 64)
          {
             for (int k=0; k<K; k++)
             {
@@ -1354,10 +1361,10 @@ __device__ __attribute__((noinline)) PassCosts phase_costs(const void * kp, int 
       // both sums through one pair of barriers
       const double a = wave_sum(cost_lane), c2 = wave_sum(acc);
       __syncthreads();
-      if ((tid & 63) == 0) { E.red[tid >> 6] = a; E.red[4 + (tid >> 6)] = c2; }
+      if ((tid & 63) == 0) { E.red[tid >> 6] = a; E.red[8 + (tid >> 6)] = c2; }
       __syncthreads();
-      if (BLOCK == 192) { pc.obs = (E.red[0] + E.red[1]) + E.red[2]; pc.smooth = (E.red[4] + E.red[5]) + E.red[6]; }
-      else { pc.obs = (E.red[0] + E.red[1]) + (E.red[2] + E.red[3]); pc.smooth = (E.red[4] + E.red[5]) + (E.red[6] + E.red[7]); }
+      pc.obs = sum_partials<BLOCK>(E.red);
+      pc.smooth = sum_partials<BLOCK>(E.red + 8);
       pc.obs /= (double) m;
    }
    phase_mark<real>(b, E, 5);
@@ -1415,7 +1422,7 @@ __device__ __attribute__((noinline)) void phase_finish(const void * kp, int stat
 // The kernel: one workgroup = one run for all iterations of the launch; the loop below only
 // sequences the phase functions and carries the few scalars that cross iterations.
 template <typename real, bool TREE, bool GS16, int BLOCK>
-__global__ __launch_bounds__(BLOCK, ORC_WGS_PER_CU)      // second argument: wavefronts per SIMD (3 x 4 SIMDs = 12 per CU, as 3 x 256 or 4 x 192 threads)
+__global__ __launch_bounds__(BLOCK, (BLOCK == 512 ? 2 : ORC_WGS_PER_CU))      // second argument: wavefronts per SIMD (3 x 4 SIMDs = 12 per CU, as 3 x 256 or 4 x 192 threads; 2 for the one-run-per-CU shape of 512)
 void chomp_iterate_kernel(const DevBatch<real> b)
 {
    const void * kp = (const void *) __builtin_amdgcn_kernarg_segment_ptr();      // DevBatch b is the kernel's only argument
@@ -1665,10 +1672,19 @@ static hipError_t launch_iterate_tt(const DevBatch<real> & b, size_t lds, hipStr
 }
 
 // variant: bit 0 the joint tree branches, bit 1 the robot has <= 16 active spheres (DPP-row cost
-// phase), bit 2 workgroups of 192 threads (three wavefronts, four workgroups per CU) instead of 256
+// phase), bit 2 workgroups of 192 threads (three wavefronts, four workgroups per CU) instead of 256,
+// bit 3 workgroups of 512 threads (eight wavefronts, one workgroup per CU: the latency shape)
 template <typename real>
 static hipError_t launch_iterate_t(const DevBatch<real> & b, size_t lds, hipStream_t stream, int variant)
 {
+   if (variant & 8)
+      switch (variant & 3)
+      {
+      case 0: return launch_iterate_tt<real, false, false, 512>(b, lds, stream);
+      case 1: return launch_iterate_tt<real, true, false, 512>(b, lds, stream);
+      case 2: return launch_iterate_tt<real, false, true, 512>(b, lds, stream);
+      default: return launch_iterate_tt<real, true, true, 512>(b, lds, stream);
+      }
    switch (variant & 7)
    {
    case 0: return launch_iterate_tt<real, false, false, 256>(b, lds, stream);

@@ -763,6 +763,9 @@ std::string Module::cmd_create(const std::vector<std::string> & argv, bool batch
    if (sdfs.empty()) throw std::runtime_error("No signed distance fields have yet been computed!");
    if (p.lambda < 0.01) throw std::runtime_error("lambda must be >=0.01!");
    if (p.n_points < 3) throw std::runtime_error("n_points must be >=3!");
+   // a single run (the reference's `create`) gets the latency shape: eight wavefronts on the one run
+   // (its trajectory is the one it has in a batch, bit for bit; its cost sums are grouped differently)
+   if (!batchmode) p.workgroup_threads = 512;
    // the constraints in the reference's order of addition (src/orcdchomp_mod.cpp:2582-2612)
    p.tsrs = everyn_tsr;
    p.tsrs.insert(p.tsrs.end(), con_tsrs.begin(), con_tsrs.end());

@@ -105,6 +105,7 @@ struct BatchParams
    double hmc_resample_lambda = 0.02;
    double epsilon = 0.1, epsilon_self = 0.04, obs_factor = 200.0, obs_factor_self = 10.0;
    int precision = 64;
+   int workgroup_threads = 0;   // 0: the module's setting (orc_set_workgroup_threads); `create` asks for 512 for its single run
 };
 
 class Module;

@@ -283,3 +283,12 @@ def test_workgroup_shape_is_a_module_setting(oracle):
     assert np.array_equal(tc, tb[10:30]) and np.array_equal(cc, cb[10:30]) and np.array_equal(sc, sb[10:30])
     with pytest.raises(RuntimeError, match="workgroup threads must be 0"):
         mod.set_workgroup_threads(128)
+    # the latency shape (eight wavefronts on one run, the whole trajectory in one tile): the same trajectories
+    mod.set_workgroup_threads(512)
+    d = mod.batch_create(model.name, goals[:24], **kw)
+    cd, sd = mod.batch_iterate(d, 60)
+    td = mod.batch_gettraj(d)
+    mod.batch_destroy(d)
+    mod.set_workgroup_threads(0)
+    assert np.array_equal(sd, sa[:24]) and np.array_equal(td, ta[:24])
+    assert np.allclose(cd, ca[:24], rtol=1e-13, atol=0)

@@ -265,7 +265,8 @@ def test_starttraj_seeding(oracle):
     assert np.array_equal(tb, ta)
     ca, _ = mod.batch_iterate(a, 5)
     cb, _ = mod.batch_iterate(int(run), 5)
-    assert np.array_equal(mod.batch_gettraj(a)[0], mod.batch_gettraj(int(run))[0]) and np.array_equal(ca, cb)
+    # (`create` runs its one run on the latency shape: the same trajectory bit for bit, cost sums grouped differently)
+    assert np.array_equal(mod.batch_gettraj(a)[0], mod.batch_gettraj(int(run))[0]) and np.allclose(ca, cb, rtol=1e-13, atol=0)
     # timed document with non-uniform deltatimes, resampled to a different n_points
     wp = np.array([[0.0] * 7, [1.0] * 7, [3.0] * 7])
     run2 = mod.create(robot=model.name, starttraj=_doc(wp, [0.0, 1.0, 1.0]), n_points=5)
