@@ -829,25 +829,24 @@ void BatchShard::build_device(const Robot & robot)
    // (98 waypoints in tiles of at most 34 at 16 per round: 33 + 33 + 32 is 3 + 3 + 2 rounds, 34 + 32 + 32
    // is 3 + 2 + 2): whole rounds in all tiles but one, when that one still fits.
    {
-      const int n_tiles = (m + tile_m_ - 1) / tile_m_;
-      if (n_tiles > 16) throw std::runtime_error("trajectory too long for this build (more than 16 tiles)!");
-      std::vector<int> sizes(n_tiles, 0);
-      for (int k=0, left=m; k<n_tiles; k++) { sizes[k] = std::min(tile_m_, left); left -= sizes[k]; }
+      n_tiles_ = (m + tile_m_ - 1) / tile_m_;
+      tile_first_ = tile_rest_ = tile_m_;
       const int unit = std::max(1, block_ / lanes_per_wp);      // waypoints of one round
-      auto rounds = [&](const std::vector<int> & sz) { int r = 0; for (int v : sz) r += (v + unit - 1) / unit; return r; };
       const int full = (tile_m_ / unit) * unit;
-      if (full > 0 && n_tiles > 1)
+      if (full > 0 && n_tiles_ > 1)
       {
-         std::vector<int> alt(n_tiles, full);
-         alt[0] = m - full * (n_tiles - 1);
-         if (alt[0] > 0 && alt[0] <= tile_m_ && rounds(alt) < rounds(sizes)) sizes = alt;
+         const int first = m - full * (n_tiles_ - 1);
+         auto rounds = [&](int a, int rest) {
+            int r = (a + unit - 1) / unit, left = m - a;
+            for (int k=1; k<n_tiles_; k++) { const int v = std::min(rest, left); r += (v + unit - 1) / unit; left -= v; }
+            return r;
+         };
+         if (first > 0 && first <= tile_m_ && rounds(first, full) < rounds(tile_m_, tile_m_)) { tile_first_ = first; tile_rest_ = full; }
       }
-      tile_starts_.assign(1, 0);
-      for (int v : sizes) tile_starts_.push_back(tile_starts_.back() + v);
    }
    if (getenv("ORC_DEBUG_PLAN"))
       fprintf(stderr, "orc plan: %d threads per workgroup, tile_m %d (%d tiles, first of %d) lds %zu bytes (%d workgroups per CU) pcr_in_lds %d ag_in_lds %d g_in_lds %d t_in_lds %d solve_mode %d\n", block_, tile_m_,
-              (m + tile_m_ - 1) / tile_m_, tile_starts_[1], lds_bytes_, (int)(lds_cu / ((lds_bytes_ + 1279) / 1280 * 1280)), pcr_in_lds_, ag_in_lds_, g_in_lds_, t_in_lds_, solve_mode_);
+              n_tiles_, tile_first_, lds_bytes_, (int)(lds_cu / ((lds_bytes_ + 1279) / 1280 * 1280)), pcr_in_lds_, ag_in_lds_, g_in_lds_, t_in_lds_, solve_mode_);
 }
 
 void BatchShard::collision_verdict(const std::vector<int> & offs, const std::vector<int> & seg, const std::vector<double> & u,
@@ -1008,8 +1007,7 @@ void BatchShard::launch(int n_iter, bool final_eval)
    b.n_sdfs = n_sdfs_;
    b.n_runs = n_runs; b.n_points = n_points; b.m = m; b.n = n;
    b.tile_m = tile_m_;
-   b.n_tiles = (int) tile_starts_.size() - 1;
-   for (size_t k=0; k<tile_starts_.size(); k++) b.tile_start[k] = tile_starts_[k];
+   b.n_tiles = n_tiles_; b.tile_first = tile_first_; b.tile_rest = tile_rest_;
    b.traj = (real *) d_traj_; b.AG = (real *) d_AG_; b.Gdbg = (real *) d_G_; b.Gcost = (real *) d_Gcost_;
    b.g_in_lds = g_in_lds_; b.lds_flags = lds_flags_; b.t_in_lds = t_in_lds_;
    b.ms = ms_;

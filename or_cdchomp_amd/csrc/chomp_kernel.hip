@@ -1467,7 +1467,8 @@ void chomp_iterate_kernel(const DevBatch<real> b)
       double cost_lane = 0.0;
       for (int tk=0; tk<b.n_tiles; tk++)
       {
-         const int ts = b.tile_start[tk], te = b.tile_start[tk+1];
+         const int ts = (tk == 0) ? 0 : b.tile_first + (tk - 1) * b.tile_rest;
+         const int te = (tk == b.n_tiles - 1) ? b.m : b.tile_first + tk * b.tile_rest;
 #ifndef ORC_ABLATE_FK
          phase_fk<real, TREE, GS16, BLOCK>(kp, ts, te);
 #endif

@@ -131,8 +131,8 @@ struct DevBatch
    int n_sdfs;
    int n_runs, n_points, m, n;
    int tile_m;             // moving waypoints per tile (the largest tile: what the LDS carve-up holds)
-   int n_tiles;            // tiles of an iteration, tile k = moving waypoints [tile_start[k], tile_start[k+1])
-   int tile_start[17];
+   int n_tiles;            // tiles of an iteration: the first holds tile_first moving waypoints, the others tile_rest (the last what is left)
+   int tile_first, tile_rest;
    // per-run state in HBM, run-major
    real * traj;            // [n_runs][n_points][n]
    real * AG;              // [n_runs][m][n]   (A^-1 G, doubles as momentum)

@@ -171,7 +171,7 @@ private:
    int max_resamples_ = 0;
    bool debug_state_ = false;   // ORC_DEBUG_STATE=1: keep the last gradient readable (get_state "G")
    int n_sdfs_ = 0;
-   std::vector<int> tile_starts_;     // tile k of an iteration = moving waypoints [tile_starts_[k], tile_starts_[k+1])
+   int n_tiles_ = 1, tile_first_ = 0, tile_rest_ = 0;   // tiles of an iteration: the first of tile_first_ moving waypoints, the others of tile_rest_
    ModelScalars ms_ = {};             // the device model's scalars (carried in the kernarg block)
    int Sa_real_ = 0;                  // active spheres
    int nj_ = 0, Sa_ = 0, S_ = 0;      // optimized joints; lanes of the active sphere block; lanes + inactive spheres
