@@ -850,6 +850,20 @@ __device__ __forceinline__ real smooth_grad(const BT & b, const real * T_s, int 
 #define ORC_U 1          // waypoints per lane in the 16-sphere cost phase (1: registers go to a third workgroup per CU instead)
 #endif
 
+// wave priorities of the phases (s_setprio): the latency-bound ones go first when they have something to issue
+#ifndef ORC_PRIO_FK
+#define ORC_PRIO_FK 3
+#endif
+#ifndef ORC_PRIO_COST
+#define ORC_PRIO_COST 0
+#endif
+#ifndef ORC_PRIO_COST_LAST
+#define ORC_PRIO_COST_LAST 2      // the last round of a tile: it is what the tile's barrier waits for
+#endif
+#ifndef ORC_PRIO_UPDATE
+#define ORC_PRIO_UPDATE 3
+#endif
+
 #include "cost_gs16.h"
 #include "cost_generic.h"
 #include "fk.h"
@@ -1046,7 +1060,7 @@ __device__ __attribute__((noinline)) void phase_fk(const void * kp, int ts_in, i
    const Env<real> E = make_env<real, GS16>(b, orc_smem);
    const int tid = threadIdx.x, n = b.n;
    const int nfk = te - ts + 2;          // waypoints ts .. te+1 (global index)
-   __builtin_amdgcn_s_setprio(3);          // latency-bound phases go first when they have something to issue
+   __builtin_amdgcn_s_setprio(ORC_PRIO_FK);          // latency-bound phases go first when they have something to issue
    for (int w0=0; w0<nfk; w0+=BLOCK/4)
    {
       const int w = w0 + (tid >> 2);
@@ -1067,7 +1081,7 @@ __device__ __attribute__((noinline)) double phase_cost(const void * kp, int ts_i
    const bool do_iteration = uni(do_iteration_in) != 0;
    const Env<real> E = make_env<real, GS16>(b, orc_smem);
    const real inv_eps = (real)1 / b.epsilon, inv_eps_self = (real)1 / b.epsilon_self;
-   __builtin_amdgcn_s_setprio(0);
+   __builtin_amdgcn_s_setprio(ORC_PRIO_COST);
    if constexpr (GS16)
       cost_tile_gs16<real, ORC_U, BLOCK>(b, E.mod, E.sdfs_s, ts, te, do_iteration, E.T_s, E.Gc, E.pos_s, E.ax_s, E.srad_s, E.sinact_s, E.r2_s,
                                          E.slink_s, E.jtype_s, E.jcol_s, inv_eps, inv_eps_self, cost_lane);
@@ -1099,7 +1113,7 @@ __device__ __attribute__((noinline)) int phase_update(const void * kp, int it_in
    real * T_s = E.T_s, * G_s = E.G_s, * Gc = E.Gc, * W_s = E.W_s, * jl_s = E.jl_s, * AG_g = E.AG_g, * AG_s = E.AG_s;
    const real * pcr_tab = E.pcr_tab;
 
-   __builtin_amdgcn_s_setprio(3);
+   __builtin_amdgcn_s_setprio(ORC_PRIO_UPDATE);
    if (tid < 2) colmask_s[tid] = 0u;       // read last after the previous step's barrier, set again after the next one
    // G = G/m + A T + B   (chomp.c:492, 515-522)
    for (int e=tid; e<mn; e+=BLOCK)
@@ -1340,7 +1354,7 @@ __device__ __attribute__((noinline)) PassCosts phase_costs(const void * kp, int 
    const float rn_f = 1.0f / (float) n;
    const real * T_s = E.T_s;
    PassCosts pc;
-   __builtin_amdgcn_s_setprio(3);
+   __builtin_amdgcn_s_setprio(ORC_PRIO_UPDATE);
    {
       double acc = 0.0;
       for (int e=tid; e<mn; e+=BLOCK)

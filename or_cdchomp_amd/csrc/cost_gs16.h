@@ -208,7 +208,7 @@ __device__ __forceinline__ void cost_tile_gs16(const BT & b, const ModelView<rea
       if (base_item + (tid & ~63) >= items) continue;      // a wavefront without a waypoint in this round (wave-uniform)
       ORC_CMARK(4);
       // the last round of a tile goes first: it is what the tile's barrier waits for
-      if (base_item + BLOCK >= items) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+      if (base_item + BLOCK >= items) __builtin_amdgcn_s_setprio(ORC_PRIO_COST_LAST); else __builtin_amdgcn_s_setprio(ORC_PRIO_COST);
       const int item = base_item + tid;
       const int g = item >> 4, s = item & 15;
       const bool lane_ok = (item < items) && (((mod.live_mask >> s) & 1ull) != 0);
