@@ -1485,6 +1485,9 @@ void chomp_iterate_kernel(const DevBatch<real> b)
          const int te = (tk == b.n_tiles - 1) ? b.m : b.tile_first + tk * b.tile_rest;
 #ifndef ORC_ABLATE_FK
          phase_fk<real, TREE, GS16, BLOCK>(kp, ts, te);
+#ifdef ORC_ABLATE_FKTWICE      // timing experiments: the FK phase twice (what a 2x slower FK would cost)
+         phase_fk<real, TREE, GS16, BLOCK>(kp, ts, te);
+#endif
 #endif
 #ifndef ORC_ABLATE_COST
          cost_lane = phase_cost<real, TREE, GS16, BLOCK>(kp, ts, te, do_iteration ? 1 : 0, cost_lane);
