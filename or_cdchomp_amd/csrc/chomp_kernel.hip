@@ -1,25 +1,27 @@
 // chomp_kernel.hip -- the CHOMP iteration as one fused gfx950 kernel.
 //
-// One workgroup (256 threads = 4 wavefronts) owns one run for all n_iter
-// iterations of a launch.  The trajectory, gradient and momentum of the run stay
-// in LDS for the whole launch; HBM is touched for the trajectory/momentum at
-// launch start and end, for the SDF gathers, and for three cost doubles.
+// One workgroup (256 threads = 4 wavefronts; 192 or 512 on request) owns one run for all n_iter
+// iterations of a launch.  The trajectory, gradient and momentum of the run stay in LDS for the
+// whole launch; HBM is touched for the trajectory/momentum at launch start and end, for the SDF
+// gathers, and for three cost doubles.  The kernel itself is a thin loop around PHASE FUNCTIONS
+// (real calls: a register allocation per phase, see the comment at struct Env).
 //
 // Per iteration (reference call stack: SURVEY.md 3.3):
 //   tiles of waypoints {
-//     FK phase    lane = waypoint        sphere_cost_pre   src/orcdchomp_mod.cpp:988-1093
-//     cost phase  lane = (waypoint,sphere) sphere_cost     src/orcdchomp_mod.cpp:1134-1327
-//                 J^T contraction + reduce over the spheres of a waypoint -> G row
+//     phase_fk    lane = (waypoint, world axis)  sphere_cost_pre  src/orcdchomp_mod.cpp:988-1093  (fk.h)
+//     phase_cost  lane = (waypoint, sphere)      sphere_cost      src/orcdchomp_mod.cpp:1134-1327 (cost_gs16.h, cost_generic.h)
+//                 J^T by a wrench suffix scan over the spheres of a waypoint -> G row
 //   }
-//   update phase  lane = (waypoint,dof)  cd_chomp_iterate  src/libcd/chomp.c:490-677
-//                 G/m + A T + B, A^-1 G by parallel cyclic reduction, T -= AG/lambda,
-//                 joint-limit projection loop, smoothness cost
+//   phase_update  lane = (waypoint, dof)         cd_chomp_iterate src/libcd/chomp.c:490-655
+//                 G/m + A T + B; A^-1 G (closed-form Toeplitz scans, cyclic reduction or dense);
+//                 [phase_tsr: the hard constraints, src/libcd/chomp.c:550-600, tsr.h]; T -= AG/lambda;
+//                 limit_rounds_call: the joint-limit projection rounds by one wavefront
+//   phase_costs   obstacle and smoothness cost (chomp.c:484-491, 660-677), quaternion renormalisation
 //
-// Differences from the reference that are deliberate (all inside the stated
-// tolerance): the dense m x m products are replaced by the band
-// of A and a cyclic-reduction solve; the per-sphere 3 x n Jacobians are never
-// formed (J^T x is evaluated as axis . ((p - anchor) x force)); the reaction of
-// a self-collision pair on the other sphere is evaluated in that sphere's lane.
+// Differences from the reference that are deliberate (all inside the stated tolerance):
+// the dense m x m products are replaced by the band of A and a structured solve; the per-sphere
+// 3 x n Jacobians are never formed (J^T x is evaluated as axis . ((p - anchor) x force)); a
+// self-collision pair is evaluated once for both of its spheres.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <atomic>
