@@ -82,16 +82,18 @@ __device__ __forceinline__ void rot_cols(real * r, real c, real s)
 
 // apply joint J to row `cur` (in place); emit component k of the world axis / anchor and of the
 // centres of the spheres riding on the joint's link.  `store` is false on the idle lane.
-// pk = J.packed as a scalar: every branch of the walk is a scalar branch on it, and the joint's
-// numbers are fetched in one batch, so a joint costs one LDS round trip (a flag per branch, read
-// where it is tested, cost one each: 1.7 k cycles per joint measured).
+// The step is ONE instruction stream for every kind of joint (round 2; the walk used to branch on the
+// joint's type, on coordinate axes and on identity transforms -- a dozen scalar branches per joint, and
+// an FK pass is issue-bound on the length of its stream, two thirds of which were scalar):
+//    r' = r Rfix,  tj = r.tfix + t,  aw = r'.a                       (world axis, anchor)
+//    r  <- r' Rot(a, q) = r' c + (1 - c)(r'.a) a - s (a x r')          (Rodrigues for a row vector)
+//    t  <- tj + qp aw
+// with (s, c, qp) = (sin q, cos q, 0) for a revolute and (0, 1, q) for a prismatic joint, prepared with
+// the sin/cos.  pk = the joint's control word as a scalar: only the sphere range is read from it.
 template <typename real>
 __device__ __forceinline__ void fk_joint_row(const ModelView<real> & mod, const DevJoint<real> & J, int pk, FrameRow<real> & cur,
-   real q, real sn, real cs, bool store, real * axo_k, real * pos_k)
+   real qp, real sn, real cs, bool store, real * axo_k, real * pos_k)
 {
-   const int type = pk & 3, kind = (pk >> 2) & 3;          // kind 0 general, 1/2/3: +-x, +-y, +-z of the joint frame
-   const bool rfix_identity = (pk >> 4) & 1;
-   const real sign = ((pk >> 5) & 1) ? (real)(-1) : (real)1;
    const int s_begin = (pk >> 8) & 255, s_end = (pk >> 16) & 255;
    real Rf[9], tf[3], ax[3];
 #pragma unroll
@@ -100,72 +102,39 @@ __device__ __forceinline__ void fk_joint_row(const ModelView<real> & mod, const 
    for (int c=0; c<3; c++) { tf[c] = J.tfix[c]; ax[c] = J.axis[c]; }
    // joint frame in the world: cur o (Rfix, tfix)
    const real tj = cur.r[0]*tf[0] + cur.r[1]*tf[1] + cur.r[2]*tf[2] + cur.t;
-   if (!rfix_identity)
-   {
-      real rn[3];
+   real rp[3];
 #pragma unroll
-      for (int c=0; c<3; c++)
-         rn[c] = cur.r[0]*Rf[0*3+c] + cur.r[1]*Rf[1*3+c] + cur.r[2]*Rf[2*3+c];
-#pragma unroll
-      for (int c=0; c<3; c++) cur.r[c] = rn[c];
-   }
-   cur.t = tj;
-   real aw;
-   if (kind == 3) aw = sign*cur.r[2];
-   else if (kind == 2) aw = sign*cur.r[1];
-   else if (kind == 1) aw = sign*cur.r[0];
-   else aw = cur.r[0]*ax[0] + cur.r[1]*ax[1] + cur.r[2]*ax[2];
+   for (int c=0; c<3; c++)
+      rp[c] = cur.r[0]*Rf[0*3+c] + cur.r[1]*Rf[1*3+c] + cur.r[2]*Rf[2*3+c];
+   const real aw = rp[0]*ax[0] + rp[1]*ax[1] + rp[2]*ax[2];
    if (store) { axo_k[0] = aw; axo_k[3] = tj; }
-   if (type == 1)
-   {
-      if (kind != 0)
-      {
-         // R <- R * Rot(axis_kind, q): two columns mix, the third is the axis itself
-         const real s = sign * sn;
-         if (kind == 3) rot_cols<real, 0, 1>(cur.r, cs, s);
-         else if (kind == 2) rot_cols<real, 2, 0>(cur.r, cs, s);
-         else rot_cols<real, 1, 2>(cur.r, cs, s);
-      }
-      else
-      {
-         const real v = (real)1 - cs;
-         const real a0 = ax[0], a1 = ax[1], a2 = ax[2];
-         real Rm[9], rn[3];
-         Rm[0] = cs + a0*a0*v;    Rm[1] = a0*a1*v - a2*sn; Rm[2] = a0*a2*v + a1*sn;
-         Rm[3] = a1*a0*v + a2*sn; Rm[4] = cs + a1*a1*v;    Rm[5] = a1*a2*v - a0*sn;
-         Rm[6] = a2*a0*v - a1*sn; Rm[7] = a2*a1*v + a0*sn; Rm[8] = cs + a2*a2*v;
-#pragma unroll
-         for (int c=0; c<3; c++) rn[c] = cur.r[0]*Rm[0*3+c] + cur.r[1]*Rm[1*3+c] + cur.r[2]*Rm[2*3+c];
-#pragma unroll
-         for (int c=0; c<3; c++) cur.r[c] = rn[c];
-      }
-   }
-   else
-      cur.t = tj + q*aw;
+   const real d = aw * ((real)1 - cs);
+   const real x0 = ax[1]*rp[2] - ax[2]*rp[1], x1 = ax[2]*rp[0] - ax[0]*rp[2], x2 = ax[0]*rp[1] - ax[1]*rp[0];
+   cur.r[0] = (rp[0]*cs + d*ax[0]) - sn*x0;
+   cur.r[1] = (rp[1]*cs + d*ax[1]) - sn*x1;
+   cur.r[2] = (rp[2]*cs + d*ax[2]) - sn*x2;
+   cur.t = tj + qp*aw;
 #ifndef ORC_ABLATE_FKSPH
    // The spheres riding on the joint's link.  Their table entries (centre in the link frame, slot of
    // the position buffer) are the same for every lane: they come by scalar loads from the model in
-   // global memory, four spheres per batch, and enter the products as scalar operands.
-   // (Measured, scripts/ablate_time.sh and one workgroup alone on the chip: the walk is a chain of
-   // round trips -- 10 k cycles per pass for 1.3 k instructions; fetching the next joint's numbers
-   // and sphere tables a step ahead cost more registers and scalar code than it hid: reverted.)
+   // global memory, four spheres per batch (entries past the link's last sphere are read -- the tables
+   // are padded -- and not stored), and enter the products as scalar operands.
    if (store)
    {
       for (int s0=s_begin; s0<s_end; s0+=4)
       {
-         real lp[4][3]; int slot[4];
+         real lp[4][3]; int off[4];
 #pragma unroll
          for (int u=0; u<4; u++)
          {
-            const int su = (s0 + u < s_end) ? s0 + u : s_end - 1;
-            lp[u][0] = mod.sph_pos_c[su][0]; lp[u][1] = mod.sph_pos_c[su][1]; lp[u][2] = mod.sph_pos_c[su][2];
-            slot[u] = mod.slot_c[su];
+            lp[u][0] = mod.sph_pos_c[s0 + u][0]; lp[u][1] = mod.sph_pos_c[s0 + u][1]; lp[u][2] = mod.sph_pos_c[s0 + u][2];
+            off[u] = mod.slot_c[s0 + u];
          }
 #pragma unroll
          for (int u=0; u<4; u++)
          {
             const real o = cur.r[0]*lp[u][0] + cur.r[1]*lp[u][1] + cur.r[2]*lp[u][2] + cur.t;
-            if (s0 + u < s_end) pos_k[slot[u]*3] = o;
+            if (s0 + u < s_end) pos_k[off[u]*3] = o;
          }
       }
    }
@@ -213,13 +182,17 @@ __device__ __forceinline__ void fk_waypoint_quad(const ModelView<real> & mod, co
    for (int j0=0; j0<nj; j0+=4)
    {
       const int jm = (j0 + k < nj) ? j0 + k : nj - 1;
-      const real qm = row[(mod.joints[jm].packed >> 24) & 127];
+      const int pkm = mod.joints[jm].packed;
+      real qm = row[(pkm >> 24) & 127];
       real snm, csm;
 #ifdef ORC_ABLATE_FKSIN
       snm = qm; csm = (real)1 - qm;
 #else
       sincos_joint(qm, &snm, &csm);
 #endif
+      // a prismatic joint: no rotation, the frame moves q along the axis; a revolute one: no translation
+      const bool revolute = ((pkm & 3) == 1);
+      snm = revolute ? snm : (real)0; csm = revolute ? csm : (real)1; qm = revolute ? (real)0 : qm;
       real qv[4], sn[4], cs[4];
       qv[0] = dpp_move<0x00>(qm); sn[0] = dpp_move<0x00>(snm); cs[0] = dpp_move<0x00>(csm);   // quad_perm [0,0,0,0]
       qv[1] = dpp_move<0x55>(qm); sn[1] = dpp_move<0x55>(snm); cs[1] = dpp_move<0x55>(csm);   // quad_perm [1,1,1,1]
