@@ -952,6 +952,7 @@ __device__ __forceinline__ Env<real> make_env(const BT & b, unsigned char * smem
    mod.jpk = (const __attribute__((address_space(4))) int *) b.model->jpacked;
    mod.jpk2 = (const __attribute__((address_space(4))) int *) b.model->jpacked2;
    mod.sph_pos_c = (const __attribute__((address_space(4))) real (*)[3]) b.model->sph_pos;
+   mod.joints_c = (const __attribute__((address_space(4))) DevJoint<real> *) b.model->joints;
    mod.slot_c = (const __attribute__((address_space(4))) int *) b.model->slot_of;
    E.AG_g = b.AG + (size_t) run * mn;
    // momentum: in LDS for the launch, or in place in global memory (every entry is read and written
@@ -1063,12 +1064,16 @@ __device__ __attribute__((noinline)) void phase_fk(const void * kp, int ts_in, i
    const int tid = threadIdx.x, n = b.n;
    const int nfk = te - ts + 2;          // waypoints ts .. te+1 (global index)
    __builtin_amdgcn_s_setprio(ORC_PRIO_FK);          // latency-bound phases go first when they have something to issue
-   for (int w0=0; w0<nfk; w0+=BLOCK/4)
+   // a wavefront walks 20 waypoints: five triads of lanes (x, y, z rows) in each of its four rows of 16
+   const int lane16 = tid & 15, triad = (lane16 * 11) >> 5, wave0 = (tid >> 6) * 20;
+   const int wv = wave0 + ((tid >> 4) & 3) * 5 + triad;
+   for (int w0=0; w0<nfk; w0+=(BLOCK/64)*20)
    {
-      const int w = w0 + (tid >> 2);
-      const bool valid = (w < nfk);
+      if (w0 + wave0 >= nfk) continue;             // a wavefront without a waypoint in this round (wave-uniform)
+      const int w = w0 + wv;
+      const bool valid = (lane16 < 15) && (w < nfk);
       const int wr = valid ? w : 0;
-      fk_waypoint_quad<real, TREE>(E.mod, E.T_s + (ts + wr)*n, E.mod.nj, tid & 3, valid, E.pos_s + wr*E.pstr, E.ax_s + wr*E.astr);
+      fk_waypoint_triad<real, TREE>(E.mod, E.T_s + (ts + wr)*n, E.mod.nj, (lane16 < 15) ? lane16 - 3*triad : 0, valid, E.pos_s + wr*E.pstr, E.ax_s + wr*E.astr);
    }
    __syncthreads();
    phase_mark<real>(b, E, 0);
@@ -1595,6 +1600,7 @@ void collision_verdict_kernel(DevVerdict<real> v)
    mod.jpk = (const __attribute__((address_space(4))) int *) gmod.jpacked;
    mod.jpk2 = (const __attribute__((address_space(4))) int *) gmod.jpacked2;
    mod.sph_pos_c = (const __attribute__((address_space(4))) real (*)[3]) gmod.sph_pos;
+   mod.joints_c = (const __attribute__((address_space(4))) DevJoint<real> *) gmod.joints;
    mod.slot_c = (const __attribute__((address_space(4))) int *) gmod.slot_of;
    __syncthreads();
 
@@ -1623,10 +1629,12 @@ void collision_verdict_kernel(DevVerdict<real> v)
       }
       __syncthreads();
       {
-         const int s = tid >> 2;
-         const bool valid = (s < count);
+         // 20 samples per wavefront (fk.h: triads of lanes)
+         const int lane16 = tid & 15, triad = (lane16 * 11) >> 5;
+         const int s = (tid >> 6) * 20 + ((tid >> 4) & 3) * 5 + triad;
+         const bool valid = (lane16 < 15) && (s < count);
          const int sr = valid ? s : 0;
-         fk_waypoint_quad<real, TREE>(mod, rows_s + sr*n, nj, tid & 3, valid, pos_s + sr*pstr, ax_s + sr*astr);
+         fk_waypoint_triad<real, TREE>(mod, rows_s + sr*n, nj, (lane16 < 15) ? lane16 - 3*triad : 0, valid, pos_s + sr*pstr, ax_s + sr*astr);
       }
       __syncthreads();
       for (int item=tid; item<count*Sa; item+=ORC_BLOCK)

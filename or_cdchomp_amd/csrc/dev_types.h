@@ -224,6 +224,7 @@ struct ModelView
    const __attribute__((address_space(4))) int * jpk2;   // [nj] DevModel::jpacked2
    const __attribute__((address_space(4))) real (* sph_pos_c)[3];   // DevModel::sph_pos (scalar loads: the FK walk's sphere tables)
    const __attribute__((address_space(4))) int * slot_c;            // DevModel::slot_of
+   const __attribute__((address_space(4))) DevJoint<real> * joints_c;   // DevModel::joints (scalar loads: the walk's fixed transforms and axes)
 };
 #if defined(__HIPCC__)
 __host__ __device__

@@ -6,14 +6,13 @@
 //   pos_s[lane][sphere][3]   sphere centres in the world
 //   ax_s [lane][joint][6]    world joint axis and anchor (what J^T needs instead of 3 x n Jacobians)
 // Row k of a frame (R[k][0..2], t[k]) evolves independently of the other two rows under every
-// operation of the walk (R <- R*Rfix, R <- R*Rot(axis,q), t <- R*tfix + t, p = R*lp + t), so four
-// lanes share a waypoint: lanes 0..2 carry the x, y, z rows, lane 3 idles but evaluates its share
-// of the sin/cos (lane k of the quad evaluates joints k, k+4, ...; the values travel by quad
-// broadcast).  64 waypoints fill all four wavefronts with a third of the arithmetic each, where
-// one lane per waypoint left three wavefronts waiting (an fp64 instruction costs the same issue
-// time for 16 live lanes as for 64: scripts/ubench/lat.hip).  Joints whose axis is a coordinate
-// axis of their frame rotate two columns in place; sin/cos come from a short Cody-Waite + minimax
-// kernel (the angles are joint values).
+// operation of the walk (R <- R*Rfix, R <- R*Rot(axis,q), t <- R*tfix + t, p = R*lp + t), so three
+// lanes share a waypoint, one row each, and each evaluates its share of the sin/cos (lane k of the
+// triad evaluates joints k, k+3, ...; the values travel through the waypoint's ax_s slots).  A
+// wavefront walks 20 waypoints with a third of the arithmetic per lane, where one lane per waypoint
+// left three wavefronts waiting (an fp64 instruction costs the same issue time for 16 live lanes as
+// for 64: scripts/ubench/lat.hip).  sin/cos come from a short Cody-Waite + minimax kernel (the angles
+// are joint values).
 #pragma once
 
 // sin and cos of a joint angle.  3-part Cody-Waite reduction by pi/2 and the fdlibm minimax
@@ -71,15 +70,6 @@ __device__ __forceinline__ void sincos_joint(float x, float * sn, float * cs)
 template <typename real>
 struct FrameRow { real r[3]; real t; };
 
-// columns A and B of the row rotate into each other: a' = c a + s b, b' = c b - s a
-template <typename real, int A, int B>
-__device__ __forceinline__ void rot_cols(real * r, real c, real s)
-{
-   const real ua = r[A], ub = r[B];
-   r[A] = c*ua + s*ub;
-   r[B] = c*ub - s*ua;
-}
-
 // apply joint J to row `cur` (in place); emit component k of the world axis / anchor and of the
 // centres of the spheres riding on the joint's link.  `store` is false on the idle lane.
 // The step is ONE instruction stream for every kind of joint (round 2; the walk used to branch on the
@@ -90,8 +80,8 @@ __device__ __forceinline__ void rot_cols(real * r, real c, real s)
 //    t  <- tj + qp aw
 // with (s, c, qp) = (sin q, cos q, 0) for a revolute and (0, 1, q) for a prismatic joint, prepared with
 // the sin/cos.  pk = the joint's control word as a scalar: only the sphere range is read from it.
-template <typename real>
-__device__ __forceinline__ void fk_joint_row(const ModelView<real> & mod, const DevJoint<real> & J, int pk, FrameRow<real> & cur,
+template <typename real, typename JT>
+__device__ __forceinline__ void fk_joint_row(const ModelView<real> & mod, const JT & J, int pk, FrameRow<real> & cur,
    real qp, real sn, real cs, bool store, real * axo_k, real * pos_k)
 {
    const int s_begin = (pk >> 8) & 255, s_end = (pk >> 16) & 255;
@@ -141,16 +131,22 @@ __device__ __forceinline__ void fk_joint_row(const ModelView<real> & mod, const 
 #endif
 }
 
-// FK of one waypoint by the four lanes of a quad (k = lane & 3; row = its trajectory row).  Must be
-// executed by whole wavefronts (quad broadcasts); `valid` is false for lanes past the last
-// waypoint, which compute on a clamped row and store nothing.
+// FK of one waypoint by a triad of lanes (k = 0, 1, 2: the x, y, z rows; row = its trajectory row).
+// `valid` is false for lanes without a waypoint (a DPP row of 16 lanes holds five triads, its last lane
+// idles; and lanes past the last waypoint): they compute on a clamped row and store nothing.
+// The sin/cos of a waypoint's joints are shared by its triad: lane k evaluates joints k, k+3, ... and
+// leaves (s, c, qp) in the joint's own slot of ax_wp, which the walk overwrites with the joint's axis
+// and anchor when it gets there (the three lanes sit in one wavefront, whose LDS operations execute in
+// program order: every lane has read the slot before any lane writes it).  (Until round 2 a waypoint
+// took a quad with the fourth lane idle and the sin/cos travelling by quad broadcasts: 16 waypoints per
+// wavefront instead of 20, a quarter more FK instructions per iteration.)
 // TREE = the joint tree branches (saved frames).
 template <typename real, bool TREE>
-__device__ __forceinline__ void fk_waypoint_quad(const ModelView<real> & mod, const real * row, int nj, int k, bool valid,
+__device__ __forceinline__ void fk_waypoint_triad(const ModelView<real> & mod, const real * row, int nj, int k, bool valid,
    real * pos_wp, real * ax_wp)
 {
-   const bool store = valid && (k < 3);
-   const int kk = (k < 3) ? k : 0;
+   const bool store = valid;
+   const int kk = k;
    real * pos_k = pos_wp + kk;
    FrameRow<real> base, cur, sv0, sv1, sv2, sv3;
    if (mod.floating)
@@ -178,10 +174,11 @@ __device__ __forceinline__ void fk_waypoint_quad(const ModelView<real> & mod, co
    }
    cur = base;
    if (TREE) { sv0 = base; sv1 = base; sv2 = base; sv3 = base; }
-   // joints in chunks of four: lane k of the quad evaluates sin/cos of joint j0+k
-   for (int j0=0; j0<nj; j0+=4)
+   // the triad's sin/cos: lane k evaluates joints k, k+3, ...
+   for (int j0=0; j0<nj; j0+=3)
    {
-      const int jm = (j0 + k < nj) ? j0 + k : nj - 1;
+      const int j = j0 + kk;
+      const int jm = (j < nj) ? j : nj - 1;
       const int pkm = mod.joints[jm].packed;
       real qm = row[(pkm >> 24) & 127];
       real snm, csm;
@@ -193,40 +190,34 @@ __device__ __forceinline__ void fk_waypoint_quad(const ModelView<real> & mod, co
       // a prismatic joint: no rotation, the frame moves q along the axis; a revolute one: no translation
       const bool revolute = ((pkm & 3) == 1);
       snm = revolute ? snm : (real)0; csm = revolute ? csm : (real)1; qm = revolute ? (real)0 : qm;
-      real qv[4], sn[4], cs[4];
-      qv[0] = dpp_move<0x00>(qm); sn[0] = dpp_move<0x00>(snm); cs[0] = dpp_move<0x00>(csm);   // quad_perm [0,0,0,0]
-      qv[1] = dpp_move<0x55>(qm); sn[1] = dpp_move<0x55>(snm); cs[1] = dpp_move<0x55>(csm);   // quad_perm [1,1,1,1]
-      qv[2] = dpp_move<0xAA>(qm); sn[2] = dpp_move<0xAA>(snm); cs[2] = dpp_move<0xAA>(csm);   // quad_perm [2,2,2,2]
-      qv[3] = dpp_move<0xFF>(qm); sn[3] = dpp_move<0xFF>(snm); cs[3] = dpp_move<0xFF>(csm);   // quad_perm [3,3,3,3]
-#pragma unroll
-      for (int jj=0; jj<4; jj++)
+      if (store && j < nj) { real * st = ax_wp + jm*6; st[0] = snm; st[1] = csm; st[2] = qm; }
+   }
+   __builtin_amdgcn_wave_barrier();
+   for (int j=0; j<nj; j++)
+   {
+      const auto & J = mod.joints_c[j];             // scalar loads: fixed transform and axis enter the products as scalar operands
+      const int pk = mod.jpk[j];
+      const int pk2 = TREE ? mod.jpk2[j] : 0;
+      const real * st = ax_wp + j*6;
+      const real sn = st[0], cs = st[1], qp = st[2];
+      if (TREE)
       {
-         const int j = j0 + jj;
-         if (j < nj)
-         {
-            const DevJoint<real> & J = mod.joints[j];
-            const int pk = mod.jpk[j];                    // scalar loads: the walk's branches do not wait for LDS
-            const int pk2 = TREE ? mod.jpk2[j] : 0;
-            if (TREE)
-            {
-               // continue from the previous joint's frame unless the tree branches here
-               const int load_slot = (pk2 & 15) - 2;
-               if (load_slot == -2) cur = base;
-               else if (load_slot == 0) cur = sv0;
-               else if (load_slot == 1) cur = sv1;
-               else if (load_slot == 2) cur = sv2;
-               else if (load_slot == 3) cur = sv3;
-            }
-            fk_joint_row(mod, J, pk, cur, qv[jj], sn[jj], cs[jj], store, ax_wp + j*6 + kk, pos_k);
-            if (TREE)
-            {
-               const int save_slot = ((pk2 >> 4) & 15) - 2;
-               if (save_slot == 0) sv0 = cur;
-               else if (save_slot == 1) sv1 = cur;
-               else if (save_slot == 2) sv2 = cur;
-               else if (save_slot == 3) sv3 = cur;
-            }
-         }
+         // continue from the previous joint's frame unless the tree branches here
+         const int load_slot = (pk2 & 15) - 2;
+         if (load_slot == -2) cur = base;
+         else if (load_slot == 0) cur = sv0;
+         else if (load_slot == 1) cur = sv1;
+         else if (load_slot == 2) cur = sv2;
+         else if (load_slot == 3) cur = sv3;
+      }
+      fk_joint_row(mod, J, pk, cur, qp, sn, cs, store, ax_wp + j*6 + kk, pos_k);
+      if (TREE)
+      {
+         const int save_slot = ((pk2 >> 4) & 15) - 2;
+         if (save_slot == 0) sv0 = cur;
+         else if (save_slot == 1) sv1 = cur;
+         else if (save_slot == 2) sv2 = cur;
+         else if (save_slot == 3) sv3 = cur;
       }
    }
 }
