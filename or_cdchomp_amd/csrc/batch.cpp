@@ -1012,7 +1012,7 @@ void BatchShard::launch(int n_iter, bool final_eval)
    b.g_in_lds = g_in_lds_; b.lds_flags = lds_flags_; b.t_in_lds = t_in_lds_;
    b.ms = ms_;
    b.lay = lds_layout(n_points, n, Sa_, S_, nj_, tile_m_, pcr_in_lds_ ? pcr_rows_ : 0, (int) sizeof(real),
-                      params.use_momentum && ag_in_lds_, n_sdfs_, (int) sizeof(DevJoint<real>), (int) sizeof(DevSdf<real>), lds_flags_);
+                      params.use_momentum && ag_in_lds_, n_sdfs_, (int) sizeof(DevSdf<real>), lds_flags_);
    b.costs = d_costs_; b.trace = d_trace_; b.status = d_status_; b.iters_done = d_iters_done_; b.leapfrog_first = d_leap_;
    const double dt = 1.0/(n_points-1);
    b.dt = (real) dt;

@@ -898,7 +898,7 @@ struct Env
    long long * phc_s;                      // [8] per-phase cycle counters (diagnostics), thread 0
    real * T_s, * G_s, * Gc, * W_s, * pos_s, * ax_s, * srad_s, * sinact_s, * jl_s, * r2_s, * pcr_s, * sphpos_s, * base_s;
    int * slink_s, * jtype_s, * jcol_s, * slot_s;
-   DevJoint<real> * joints_s; DevSdf<real> * sdfs_s; unsigned long long * saff_s;
+   int * jctl_s; DevSdf<real> * sdfs_s; unsigned long long * saff_s;
    real * traj_g, * AG_g, * AG_s;
    const real * pcr_tab;
    int pstr, astr;
@@ -940,7 +940,7 @@ __device__ __forceinline__ Env<real> make_env(const BT & b, unsigned char * smem
    E.slot_s = E.jcol_s + nj;                               // [Sa_real] slot of the k-th active sphere (sorted order)
    E.sphpos_s = E.pcr_s + (((b.pcr_in_lds ? b.pcr_rows : 0)*m + 3) & ~3);   // [Sa][3] + base frame [12]
    E.base_s = E.sphpos_s + Sa*3;
-   E.joints_s = (DevJoint<real> *)(smem_raw + L.joints_bytes);
+   E.jctl_s = (int *)(smem_raw + L.joints_bytes);
    E.sdfs_s = (DevSdf<real> *)(smem_raw + L.sdfs_bytes);
    E.saff_s = (unsigned long long *)(smem_raw + L.saff_bytes);
    ModelView<real> & mod = E.mod;
@@ -948,7 +948,7 @@ __device__ __forceinline__ Env<real> make_env(const BT & b, unsigned char * smem
    mod.Sa_real = b.ms.Sa_real; mod.placed = b.ms.placed; mod.live_mask = b.ms.live_mask; mod.slot_of = E.slot_s;
    mod.base_sph_begin = b.ms.base_sph_begin; mod.base_sph_end = b.ms.base_sph_end;
    mod.base_R = E.base_s; mod.base_t = E.base_s + 9;
-   mod.joints = E.joints_s; mod.sph_pos = (const real (*)[3]) E.sphpos_s; mod.sph_affects = E.saff_s;
+   mod.jctl = E.jctl_s; mod.sph_pos = (const real (*)[3]) E.sphpos_s; mod.sph_affects = E.saff_s;
    mod.jpk = (const __attribute__((address_space(4))) int *) b.model->jpacked;
    mod.jpk2 = (const __attribute__((address_space(4))) int *) b.model->jpacked2;
    mod.sph_pos_c = (const __attribute__((address_space(4))) real (*)[3]) b.model->sph_pos;
@@ -992,15 +992,20 @@ __device__ __attribute__((noinline)) void phase_setup(const void * kp)
    if (GS16 || b.t_in_lds) for (int e=tid; e<np*n; e+=BLOCK) E.T_s[e] = E.traj_g[e];
    for (int e=tid; e<S; e+=BLOCK) { E.srad_s[e] = gmod.sph_radius[e]; E.slink_s[e] = gmod.sph_link[e]; }
    for (int e=tid; e<(S-Sa)*3; e+=BLOCK) E.sinact_s[e] = gmod.sph_inactive_pos[e/3][e%3];
-   for (int e=tid; e<nj; e+=BLOCK) { E.jtype_s[e] = gmod.joints[e].type; E.jcol_s[e] = gmod.joints[e].col; }
+   for (int e=tid; e<nj; e+=BLOCK)
+   {
+      // (the joints' fixed transforms and axes are read by scalar loads from the model: fk.h)
+      const DevJoint<real> & J = gmod.joints[e];
+      E.jtype_s[e] = J.type; E.jcol_s[e] = J.col;
+      E.jctl_s[2*e] = J.packed;
+      E.jctl_s[2*e+1] = (J.aff_begin & 255) | ((J.aff_end & 255) << 8) | ((J.type & 255) << 16) | ((J.col & 255) << 24);
+   }
    for (int e=tid; e<Sa*3; e+=BLOCK) E.sphpos_s[e] = gmod.sph_pos[e/3][e%3];
    for (int e=tid; e<E.mod.Sa_real; e+=BLOCK) E.slot_s[e] = gmod.slot_of[e];
    for (int e=tid; e<Sa; e+=BLOCK) E.saff_s[e] = gmod.sph_affects[e];
    for (int e=tid; e<12; e+=BLOCK) E.base_s[e] = (e < 9) ? gmod.base_R[e] : gmod.base_t[e-9];
    {
-      // word-wise copies of the joint and field descriptors
-      const int * src = (const int *) gmod.joints; int * dst = (int *) E.joints_s;
-      for (int e=tid; e<nj*(int)(sizeof(DevJoint<real>)/4); e+=BLOCK) dst[e] = src[e];
+      // word-wise copy of the field descriptors
       const int * src2 = (const int *) b.sdfs; int * dst2 = (int *) E.sdfs_s;
       for (int e=tid; e<b.n_sdfs*(int)(sizeof(DevSdf<real>)/4); e+=BLOCK) dst2[e] = src2[e];
    }
@@ -1581,22 +1586,19 @@ void collision_verdict_kernel(DevVerdict<real> v)
    real * srad_s = base_s + 12;                                      // [Sa]
    int * slot_s = (int *)(srad_s + ((Sa + 3) & ~3));                 // [Sa_real]
    int * xml_s = slot_s + ((gmod.Sa_real + 3) & ~3);                 // [Sa]
-   DevJoint<real> * joints_s = (DevJoint<real> *)(xml_s + ((Sa + 3) & ~3));
+   int * jctl_s = xml_s + ((Sa + 3) & ~3);                            // [nj][2]
    for (int e=tid; e<Sa*3; e+=ORC_BLOCK) sphpos_s[e] = gmod.sph_pos[e/3][e%3];
    for (int e=tid; e<12; e+=ORC_BLOCK) base_s[e] = (e < 9) ? gmod.base_R[e] : gmod.base_t[e-9];
    for (int e=tid; e<Sa; e+=ORC_BLOCK) { srad_s[e] = gmod.sph_radius[e]; xml_s[e] = v.slot_xml[e]; }
    for (int e=tid; e<gmod.Sa_real; e+=ORC_BLOCK) slot_s[e] = gmod.slot_of[e];
-   {
-      const int * src = (const int *) gmod.joints; int * dst = (int *) joints_s;
-      for (int e=tid; e<nj*(int)(sizeof(DevJoint<real>)/4); e+=ORC_BLOCK) dst[e] = src[e];
-   }
+   for (int e=tid; e<nj; e+=ORC_BLOCK) { jctl_s[2*e] = gmod.joints[e].packed; jctl_s[2*e+1] = 0; }
    if (tid == 0) key_s[0] = 0x7fffffff;
    ModelView<real> mod;
    mod.nj = nj; mod.n = n; mod.floating = gmod.floating; mod.tree = gmod.tree; mod.Sa = Sa; mod.S = gmod.S; mod.GS = gmod.GS;
    mod.base_sph_begin = gmod.base_sph_begin; mod.base_sph_end = gmod.base_sph_end; mod.jt_scan = 0;
    mod.Sa_real = gmod.Sa_real; mod.placed = gmod.placed; mod.live_mask = gmod.live_mask; mod.slot_of = slot_s;
    mod.base_R = base_s; mod.base_t = base_s + 9;
-   mod.joints = joints_s; mod.sph_pos = (const real (*)[3]) sphpos_s; mod.sph_affects = nullptr;
+   mod.jctl = jctl_s; mod.sph_pos = (const real (*)[3]) sphpos_s; mod.sph_affects = nullptr;
    mod.jpk = (const __attribute__((address_space(4))) int *) gmod.jpacked;
    mod.jpk2 = (const __attribute__((address_space(4))) int *) gmod.jpacked2;
    mod.sph_pos_c = (const __attribute__((address_space(4))) real (*)[3]) gmod.sph_pos;
@@ -1676,9 +1678,8 @@ void collision_verdict_kernel(DevVerdict<real> v)
 size_t orc_chomp_lds_bytes(int n_points, int n, int Sa, int S, int nj, int tile_m, int pcr_rows, size_t real_size,
    int use_momentum, int n_sdfs, int flags)
 {
-   const int js = real_size == 8 ? (int) sizeof(DevJoint<double>) : (int) sizeof(DevJoint<float>);
    const int ss = real_size == 8 ? (int) sizeof(DevSdf<double>) : (int) sizeof(DevSdf<float>);
-   return (size_t) lds_layout(n_points, n, Sa, S, nj, tile_m, pcr_rows, (int) real_size, use_momentum, n_sdfs, js, ss, flags).total_bytes;
+   return (size_t) lds_layout(n_points, n, Sa, S, nj, tile_m, pcr_rows, (int) real_size, use_momentum, n_sdfs, ss, flags).total_bytes;
 }
 
 template <typename real, bool TREE, bool GS16, int BLOCK>
@@ -1776,6 +1777,5 @@ size_t orc_verdict_lds_bytes(int n, int Sa, int Sa_real, int nj, size_t real_siz
    auto r4 = [](int x) { return (x + 3) & ~3; };
    size_t reals = (size_t) r4(64*n) + r4(64*pstr) + r4(64*astr) + r4(Sa*3) + 12 + r4(Sa);
    size_t ints = (size_t) r4(Sa_real) + r4(Sa);
-   const size_t js = real_size == 8 ? sizeof(DevJoint<double>) : sizeof(DevJoint<float>);
-   return 16 + reals * real_size + ints * 4 + (size_t) nj * js + 64;
+   return 16 + reals * real_size + ints * 4 + (size_t) nj * 8 + 64;
 }

@@ -339,8 +339,8 @@ __device__ __forceinline__ void cost_tile_generic(const BT & b, const ModelView<
             {
                const int j = j0 + s;
                const bool jok = (j < nj);
-               const DevJoint<real> & J = mod.joints[jok ? j : 0];
-               const int ab = J.aff_begin, ae = J.aff_end;
+               const int jw = mod.jctl[2*(jok ? j : 0) + 1];
+               const int ab = jw & 255, ae = (jw >> 8) & 255;
                real W[6];
 #pragma unroll
                for (int k=0; k<6; k++)
@@ -363,7 +363,7 @@ __device__ __forceinline__ void cost_tile_generic(const BT & b, const ModelView<
                const real c2 = W[2] - (ax[3]*W[4] - ax[4]*W[3]);
                const real crev = ax[0]*c0 + ax[1]*c1 + ax[2]*c2;
                const real cpri = ax[0]*W[3] + ax[1]*W[4] + ax[2]*W[5];
-               if (jok && row_ok) Gc[gi*n + J.col] = (J.type == 1) ? crev : cpri;
+               if (jok && row_ok) Gc[gi*n + ((jw >> 24) & 255)] = (((jw >> 16) & 255) == 1) ? crev : cpri;
             }
          }
          else

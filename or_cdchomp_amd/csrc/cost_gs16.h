@@ -444,10 +444,10 @@ __device__ __forceinline__ void cost_tile_gs16(const BT & b, const ModelView<rea
             {
                const int j = j0 + s;
                const bool jok = (j < nj);
-               const DevJoint<real> & J = mod.joints[jok ? j : 0];
-               const int ab = J.aff_begin, ae = J.aff_end;
-               const bool rev = (J.type == 1);
-               const int col = J.col;
+               const int jw = mod.jctl[2*(jok ? j : 0) + 1];
+               const int ab = jw & 255, ae = (jw >> 8) & 255;
+               const bool rev = (((jw >> 16) & 255) == 1);
+               const int col = (jw >> 24) & 255;
 #pragma unroll
                for (int u=0; u<U; u++)
                {

@@ -115,7 +115,7 @@ struct LdsLayout
    int lim_bytes;          // byte offset of the joint-limit scratch (ORC_LIM_SCRATCH bytes)
    int pstr, astr;         // waypoint strides of pos / ax: odd, so that lane = waypoint accesses (FK) hit distinct LDS banks
    int ints_bytes;         // byte offset of the int tables (slink, jtype, jcol)
-   int joints_bytes;       // byte offset of the staged DevJoint[nj]
+   int joints_bytes;       // byte offset of the staged joint control words [nj][2]
    int sdfs_bytes;         // byte offset of the staged DevSdf[n_sdfs]
    int saff_bytes;         // byte offset of the staged affects masks [Sa]
    int total_bytes;
@@ -217,7 +217,7 @@ struct ModelView
    const int * slot_of;                    // [Sa_real]
    const real * base_R;                    // [9]
    const real * base_t;                    // [3]
-   const DevJoint<real> * joints;          // [nj]
+   const int * jctl;                       // [nj][2] control words of a joint: DevJoint::packed, and aff_begin | aff_end << 8 | type << 16 | col << 24
    const real (* sph_pos)[3];              // [Sa][3]
    const unsigned long long * sph_affects; // [Sa]
    const __attribute__((address_space(4))) int * jpk;    // [nj] DevModel::jpacked (global memory, scalar loads)
@@ -236,7 +236,7 @@ __host__ __device__
 #define ORC_LDS_G_GLOBAL   2
 #define ORC_LDS_T_GLOBAL   4      // the trajectory stays in global memory (updated in place through L2): generic cost path only
 inline LdsLayout lds_layout(int np, int n, int Sa, int S, int nj, int tile_m, int pcr_rows, int real_size,
-   int use_ag, int n_sdfs, int joint_size, int sdf_size, int flags)
+   int use_ag, int n_sdfs, int sdf_size, int flags)
 {
    const int m = np - 2, mn = m*n;
    LdsLayout L;
@@ -270,7 +270,7 @@ inline LdsLayout lds_layout(int np, int n, int Sa, int S, int nj, int tile_m, in
    L.ints_bytes = ORC_LDS_HEADER + o*real_size;
    int bytes = L.ints_bytes + (S + 2*nj + 4 + Sa) * (int) sizeof(int);     // slink, jtype, jcol, slot_of
    bytes = (bytes + 15) & ~15;
-   L.joints_bytes = bytes; bytes += nj * joint_size; bytes = (bytes + 15) & ~15;
+   L.joints_bytes = bytes; bytes += nj * 8; bytes = (bytes + 15) & ~15;
    L.sdfs_bytes = bytes;   bytes += n_sdfs * sdf_size; bytes = (bytes + 15) & ~15;
    L.saff_bytes = bytes;   bytes += Sa * 8;
    if (alias) L.lim_bytes = ORC_LDS_HEADER + (L.pos + work_reals) * real_size;

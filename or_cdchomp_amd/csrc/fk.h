@@ -179,7 +179,7 @@ __device__ __forceinline__ void fk_waypoint_triad(const ModelView<real> & mod, c
    {
       const int j = j0 + kk;
       const int jm = (j < nj) ? j : nj - 1;
-      const int pkm = mod.joints[jm].packed;
+      const int pkm = mod.jctl[2*jm];
       real qm = row[(pkm >> 24) & 127];
       real snm, csm;
 #ifdef ORC_ABLATE_FKSIN
