@@ -228,6 +228,9 @@ int orc_host_shparse(const char * in, char * out, size_t out_cap);
  * inverse (D>=2) the device uses; any output may be NULL */
 int orc_host_metric(int m, int derivative, double dt, double * A_out, double * beta_s_out, double * beta_g_out,
    double kappa_out[3], const double * rhs, int ncols, double * solve_out);
+/* the same with the start point a variable (`start_tsr`: inits[0] == NULL, src/orcdchomp_mod.cpp:2572) */
+int orc_host_metric_free_start(int m, int derivative, double dt, double * A_out, double * beta_s_out, double * beta_g_out,
+   double kappa_out[3], const double * rhs, int ncols, double * solve_out);
 /* GSL's default generator restated (src/orcdchomp_mod.cpp:2303-2304,2763,2767): n gaussians with
  * the given sigma from seed, then one uniform; out_gauss[n], out_uniform[1] */
 int orc_host_gsl_stream(unsigned long seed, double sigma, int n, double * out_gauss, double * out_uniform);

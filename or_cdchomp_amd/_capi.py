@@ -80,6 +80,8 @@ SYMBOLS = [
     ("orc_host_shparse", C.c_int, [C.c_char_p, C.c_char_p, C.c_size_t]),
     ("orc_host_metric", C.c_int, [C.c_int, C.c_int, C.c_double, c_double_p, c_double_p, c_double_p, c_double_p,
                                   c_double_p, C.c_int, c_double_p]),
+    ("orc_host_metric_free_start", C.c_int, [C.c_int, C.c_int, C.c_double, c_double_p, c_double_p, c_double_p, c_double_p,
+                                  c_double_p, C.c_int, c_double_p]),
     ("orc_host_gsl_stream", C.c_int, [C.c_ulong, C.c_double, C.c_int, c_double_p, c_double_p]),
 ]
 

@@ -182,7 +182,7 @@ void BatchShard::construct(const Robot & robot, const double * starts, const dou
    if (p.precision != 64 && p.precision != 32) throw std::runtime_error("precision must be 32 or 64!");
    const int n_adof = (int) robot.active_dofs.size();
    n_points = p.n_points;
-   m = n_points - 2;                                              // mod.cpp:2315
+   m = n_points - 2 + (p.free_start ? 1 : 0);                     // mod.cpp:2315-2316
    n = (p.floating_base ? 7 : 0) + n_adof;                        // mod.cpp:2104-2105
    robot_name = robot.name;
    adofindices = robot.active_dofs;
@@ -197,7 +197,7 @@ void BatchShard::construct(const Robot & robot, const double * starts, const dou
       jl_hi_[(p.floating_base ? 7 : 0) + j] = robot.limit_upper[robot.active_dofs[j]];
    }
 
-   build_metric(m, p.derivative, 1.0/(n_points-1), metric_);       // dt: mod.cpp:2567
+   build_metric(m, p.derivative, 1.0/(n_points-1), metric_, p.free_start != 0);       // dt: mod.cpp:2567
 
    if (p.precision == 64) build_device<double>(robot); else build_device<float>(robot);
 
@@ -622,10 +622,17 @@ void BatchShard::build_device(const Robot & robot)
          if (T.k == 0) throw std::runtime_error("TSR constraint with no fixed dimension (every Bw row has a range)!");
       }
       // rows in the reference's list order: the last constraint added comes first (src/libcd/chomp.c:231-232,418-424)
-      int base = 0;
-      for (int c=n_tsrs_-1; c>=0; c--) { ht[c].row_base = base; base += ht[c].k * m; }
-      cons_k_ = base;
-      const int NB = n_tsrs_ * m;
+      int base = 0, blocks = 0;
+      for (int c=n_tsrs_-1; c>=0; c--)
+      {
+         ht[c].point = params.tsrs[c].point;
+         ht[c].npts = (ht[c].point < 0) ? m : 1;
+         if (ht[c].point >= m) throw std::runtime_error("TSR constraint on a point the trajectory does not have!");
+         ht[c].row_base = base; base += ht[c].k * ht[c].npts;
+         ht[c].blk_base = blocks; blocks += ht[c].npts;
+      }
+      cons_k_ = base; tsr_blocks_ = blocks;
+      const int NB = blocks;
       tsr_ws_stride_ = (size_t) 2*cons_k_ + (size_t) cons_k_ * n + (size_t) NB * n + (size_t) cons_k_ * cons_k_;
       const double gbytes = (double) tsr_ws_stride_ * n_runs * sizeof(real) / 1e9;
       if (cons_k_ > 2048 || gbytes > 64.0)
@@ -791,6 +798,7 @@ void BatchShard::build_device(const Robot & robot)
          {
             if (force_g >= 0 && g_lds != force_g) continue;
             if (!t_lds && (GS_ == 16 || g_lds)) continue;      // the trajectory in global memory: generic cost path, after G went there
+            if (!t_lds && params.free_start) continue;         // start_tsr: the workgroup's copy has a row the global rows do not
             if (force_tl >= 0 && t_lds != force_tl && GS_ != 16 && !g_lds) continue;
             const int flags = (solve_mode_ == 2 ? ORC_LDS_SMALL_WORK : 0) | (g_lds ? 0 : ORC_LDS_G_GLOBAL) | (t_lds ? 0 : ORC_LDS_T_GLOBAL);
             if (with_pcr && !pcr_rows) continue;
@@ -800,7 +808,7 @@ void BatchShard::build_device(const Robot & robot)
             for (int t=(m < 254 ? m : 254); t>=1; t--)
             {
                if (force_t > 0 && t != (force_t < m ? force_t : m)) continue;
-               const size_t need = orc_chomp_lds_bytes(n_points, n, Sa_, S_, nj, t, with_pcr ? pcr_rows : 0, sizeof(real),
+               const size_t need = orc_chomp_lds_bytes(m + 2, n, Sa_, S_, nj, t, with_pcr ? pcr_rows : 0, sizeof(real),
                                                        params.use_momentum && ag_lds, n_sdfs_, flags);
                if (need > budget) continue;
                const int tiles = (m + t - 1) / t;
@@ -1005,13 +1013,15 @@ void BatchShard::launch(int n_iter, bool final_eval)
    b.model = (const DevModel<real> *) d_model_;
    b.sdfs = (const DevSdf<real> *) d_sdfs_;
    b.n_sdfs = n_sdfs_;
-   b.n_runs = n_runs; b.n_points = n_points; b.m = m; b.n = n;
+   b.n_runs = n_runs; b.n_points = m + 2; b.np_global = n_points; b.free_start = params.free_start; b.m = m; b.n = n;
+   if (params.free_start && tile_first_ < 2)
+      throw std::runtime_error("start_tsr: the first tile must hold the two points after the start point!");
    b.tile_m = tile_m_;
    b.n_tiles = n_tiles_; b.tile_first = tile_first_; b.tile_rest = tile_rest_;
    b.traj = (real *) d_traj_; b.AG = (real *) d_AG_; b.Gdbg = (real *) d_G_; b.Gcost = (real *) d_Gcost_;
    b.g_in_lds = g_in_lds_; b.lds_flags = lds_flags_; b.t_in_lds = t_in_lds_;
    b.ms = ms_;
-   b.lay = lds_layout(n_points, n, Sa_, S_, nj_, tile_m_, pcr_in_lds_ ? pcr_rows_ : 0, (int) sizeof(real),
+   b.lay = lds_layout(m + 2, n, Sa_, S_, nj_, tile_m_, pcr_in_lds_ ? pcr_rows_ : 0, (int) sizeof(real),
                       params.use_momentum && ag_in_lds_, n_sdfs_, (int) sizeof(DevSdf<real>), lds_flags_);
    b.costs = d_costs_; b.trace = d_trace_; b.status = d_status_; b.iters_done = d_iters_done_; b.leapfrog_first = d_leap_;
    const double dt = 1.0/(n_points-1);
@@ -1044,7 +1054,7 @@ void BatchShard::launch(int n_iter, bool final_eval)
       b.a_diag = (real) metric_.Adense[0];
       b.a_off = (real) metric_.beta_s[0];
    }
-   b.tsrs = (const DevTsr<real> *) d_tsrs_; b.n_tsrs = n_tsrs_; b.cons_k = cons_k_;
+   b.tsrs = (const DevTsr<real> *) d_tsrs_; b.n_tsrs = n_tsrs_; b.cons_k = cons_k_; b.tsr_blocks = tsr_blocks_;
    b.tsr_ws = (real *) d_tsr_ws_; b.tsr_ws_stride = tsr_ws_stride_; b.tsr_err = d_tsr_err_;
    b.Gdbg = debug_state_ ? (real *) d_G_ : nullptr;
    if (!g_in_lds_ && !d_Gcost_)
@@ -1134,7 +1144,7 @@ void BatchShard::get_state(const std::string & which, double * out)
       std::vector<double> full((size_t) n_runs * n_points * n);
       gettraj(full.data());
       for (int k=0; k<n_runs; k++)
-         std::memcpy(out + (size_t) k*m*n, &full[((size_t) k*n_points + 1)*n], (size_t) m*n*sizeof(double));
+         std::memcpy(out + (size_t) k*m*n, &full[((size_t) k*n_points + (params.free_start ? 0 : 1))*n], (size_t) m*n*sizeof(double));
    }
    else throw std::runtime_error("unknown state name");
 }

@@ -455,13 +455,13 @@ int orc_host_shparse(const char * in, char * out, size_t out_cap)
    return (int) toks.size();
 }
 
-int orc_host_metric(int m, int derivative, double dt, double * A_out, double * beta_s_out, double * beta_g_out,
+static int host_metric_impl(bool free_start, int m, int derivative, double dt, double * A_out, double * beta_s_out, double * beta_g_out,
    double kappa_out[3], const double * rhs, int ncols, double * solve_out)
 {
    try
    {
       orc::Metric M;
-      orc::build_metric(m, derivative, dt, M);
+      orc::build_metric(m, derivative, dt, M, free_start);
       if (A_out) std::memcpy(A_out, M.Adense.data(), (size_t) m*m*sizeof(double));
       if (beta_s_out) std::memcpy(beta_s_out, M.beta_s.data(), m*sizeof(double));
       if (beta_g_out) std::memcpy(beta_g_out, M.beta_g.data(), m*sizeof(double));
@@ -501,6 +501,17 @@ int orc_host_metric(int m, int derivative, double dt, double * A_out, double * b
       return 0;
    }
    catch (...) { return 1; }
+}
+
+int orc_host_metric(int m, int derivative, double dt, double * A_out, double * beta_s_out, double * beta_g_out,
+   double kappa_out[3], const double * rhs, int ncols, double * solve_out)
+{
+   return host_metric_impl(false, m, derivative, dt, A_out, beta_s_out, beta_g_out, kappa_out, rhs, ncols, solve_out);
+}
+int orc_host_metric_free_start(int m, int derivative, double dt, double * A_out, double * beta_s_out, double * beta_g_out,
+   double kappa_out[3], const double * rhs, int ncols, double * solve_out)
+{
+   return host_metric_impl(true, m, derivative, dt, A_out, beta_s_out, beta_g_out, kappa_out, rhs, ncols, solve_out);
 }
 
 int orc_host_gsl_stream(unsigned long seed, double sigma, int n, double * out_gauss, double * out_uniform)

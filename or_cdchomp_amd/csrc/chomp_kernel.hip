@@ -836,7 +836,7 @@ template <typename real, typename BT>
 __device__ __forceinline__ real smooth_grad(const BT & b, const real * T_s, int i, int c)
 {
    const int m = b.m, n = b.n, D = b.D;
-   if (D == 1)       // tridiagonal Toeplitz: the end rows couple to the fixed endpoints with a_off
+   if (D == 1 && !b.free_start)       // tridiagonal Toeplitz: the end rows couple to the fixed endpoints with a_off
       return b.a_diag * T_s[(i+1)*n + c] + b.a_off * (T_s[i*n + c] + T_s[(i+2)*n + c]);
    real s = b.beta_s[i] * T_s[c] + b.beta_g[i] * T_s[(b.n_points-1)*n + c];
    for (int k=-D; k<=D; k++)
@@ -918,7 +918,7 @@ __device__ __forceinline__ Env<real> make_env(const BT & b, unsigned char * smem
    E.colmask_s = (unsigned int *)(E.redi + 8);             // [2] columns with an entry outside its joint limits after the step
    E.phc_s = (long long *)(smem_raw + ORC_LDS_HEADER - 64);
    real * lds = (real *)(smem_raw + ORC_LDS_HEADER);
-   E.traj_g = b.traj + (size_t) run * np * n;
+   E.traj_g = b.traj + (size_t) run * b.np_global * n;      // (np_global == n_points unless the start point is a variable)
    // [np][n]; the kernels of the generic cost path may leave it in global memory (large robots: the
    // LDS then holds tiles only and a third workgroup fits the CU); __syncthreads orders the accesses
    // of a workgroup's wavefronts to it
@@ -989,7 +989,13 @@ __device__ __attribute__((noinline)) void phase_setup(const void * kp)
    const int tid = threadIdx.x;
    const int n = b.n, m = b.m, np = b.n_points, mn = m*n;
    const int nj = E.mod.nj, Sa = E.mod.Sa, S = E.mod.S;
-   if (GS16 || b.t_in_lds) for (int e=tid; e<np*n; e+=BLOCK) E.T_s[e] = E.traj_g[e];
+   if (GS16 || b.t_in_lds)
+   {
+      // start_tsr: the start point is the first moving row; the row in front of it is never used
+      // (no start boundary in the metric, one-sided differences in the cost phase) and holds a copy of it
+      const int skip = b.free_start ? n : 0;
+      for (int e=tid; e<np*n; e+=BLOCK) E.T_s[e] = E.traj_g[(e < skip) ? e : e - skip];
+   }
    for (int e=tid; e<S; e+=BLOCK) { E.srad_s[e] = gmod.sph_radius[e]; E.slink_s[e] = gmod.sph_link[e]; }
    for (int e=tid; e<(S-Sa)*3; e+=BLOCK) E.sinact_s[e] = gmod.sph_inactive_pos[e/3][e%3];
    for (int e=tid; e<nj; e+=BLOCK)
@@ -1264,7 +1270,7 @@ __device__ __attribute__((noinline)) int phase_update(const void * kp, int it_in
       //    Ainv[i][k] = (min(i,k)+1) (m - max(i,k)) / ((m+1) ca),   A = ca tridiag(-1,2,-1),
       // so GA is a short sum per element instead of a full solve.
       bool sparse_done = false;
-      if (b.D == 1 && b.solve_mode != 1)
+      if (b.D == 1 && b.solve_mode != 1 && !b.free_start)
       {
          const int K = (mn + BLOCK - 1) / BLOCK;       // elements per thread
          int * cnt = (int *) W_s;                               // [K][waves] counts per (slice, wave)
@@ -1373,7 +1379,7 @@ __device__ __attribute__((noinline)) PassCosts phase_costs(const void * kp, int 
       {
          const int i = div_n(e, rn_f), c = e - i*n;
          const real sg = smooth_grad<real>(b, T_s, i, c);     // (A T + B)
-         const real bt = (b.D == 1) ? b.a_off * ((i == 0 ? T_s[c] : (real)0) + (i == m-1 ? T_s[(np-1)*n + c] : (real)0))
+         const real bt = (b.D == 1 && !b.free_start) ? b.a_off * ((i == 0 ? T_s[c] : (real)0) + (i == m-1 ? T_s[(np-1)*n + c] : (real)0))
                                     : b.beta_s[i] * T_s[c] + b.beta_g[i] * T_s[(np-1)*n + c];
          acc += (double) T_s[n + e] * (0.5 * ((double) sg + (double) bt));
       }
@@ -1422,7 +1428,11 @@ __device__ __attribute__((noinline)) void phase_finish(const void * kp, int stat
    const int run = blockIdx.x, tid = threadIdx.x;
    const int n = b.n, m = b.m, np = b.n_points, mn = m*n;
    __syncthreads();
-   if (GS16 || b.t_in_lds) for (int e=tid; e<np*n; e+=BLOCK) E.traj_g[e] = E.T_s[e];
+   if (GS16 || b.t_in_lds)
+   {
+      const int skip = b.free_start ? n : 0;
+      for (int e=skip+tid; e<np*n; e+=BLOCK) E.traj_g[e - skip] = E.T_s[e];
+   }
    if (b.use_momentum && b.ag_in_lds) for (int e=tid; e<mn; e+=BLOCK) E.AG_g[e] = E.AG_s[e];
    if (tid == 0)
    {

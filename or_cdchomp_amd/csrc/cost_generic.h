@@ -59,6 +59,19 @@ __device__ __forceinline__ void cost_tile_generic(const BT & b, const ModelView<
             real v = pn[k]; v -= pp[k]; v *= b.inv_2dt; vel[k] = v;
             real a = pc[k]; a *= (real)(-2); a += pp[k]; a += pn[k]; a *= b.inv_dt2; acc[k] = a;
          }
+         if (b.free_start && ts + wl == 0 && item < items)
+         {
+            // start_tsr: the start point's velocity is one-sided and its acceleration the next point's
+            // (src/orcdchomp_mod.cpp:1107-1112, 1125-1126); the row in front of it is not a trajectory point
+            const real * pnn = pn + pstr;
+            const real inv_dt = (real)1 / b.dt;
+#pragma unroll
+            for (int k=0; k<3; k++)
+            {
+               real v = pn[k]; v -= pc[k]; v *= inv_dt; vel[k] = v;
+               real a = pn[k]; a *= (real)(-2); a += pc[k]; a += pnn[k]; a *= b.inv_dt2; acc[k] = a;
+            }
+         }
       }
       if (dbg) tm = clock64();
       const real vn2 = vel[0]*vel[0] + vel[1]*vel[1] + vel[2]*vel[2];

@@ -238,6 +238,19 @@ __device__ __forceinline__ void cost_tile_gs16(const BT & b, const ModelView<rea
             real a = pc[k]; a *= (real)(-2); a += pp[k]; a += pn[k]; a *= b.inv_dt2; acc[u][k] = a;
             f[u][k] = 0;
          }
+         if (b.free_start && ts + wl[u] == 0 && item < items)
+         {
+            // start_tsr: the start point's velocity is one-sided and its acceleration the next point's
+            // (src/orcdchomp_mod.cpp:1107-1112, 1125-1126); the row in front of it is not a trajectory point
+            const real * pnn = pn + pstr;
+            const real inv_dt = (real)1 / b.dt;
+#pragma unroll
+            for (int k=0; k<3; k++)
+            {
+               real v = pn[k]; v -= pc[k]; v *= inv_dt; vel[u][k] = v;
+               real a = pn[k]; a *= (real)(-2); a += pc[k]; a += pnn[k]; a *= b.inv_dt2; acc[u][k] = a;
+            }
+         }
          const real vn2 = vel[u][0]*vel[u][0] + vel[u][1]*vel[u][1] + vel[u][2]*vel[u][2];
          real inv_vn;
          vnorm[u] = sqrt_rsq(vn2, &inv_vn);

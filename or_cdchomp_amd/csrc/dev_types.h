@@ -96,6 +96,9 @@ struct DevTsr
    int k;                     // rows = enabled entries of xyzrpy (Bw row == [0 0], mod.cpp:2466-2480)
    int enabled[6];
    int row_base;              // first row of this constraint's blocks in the system (list order: the last constraint first)
+   int npts;                  // points the constraint holds: all m moving points (`con_tsr all`, `everyn_tsr`), or 1
+   int point;                 // npts == 1: that moving point (`start_tsr`: 0)
+   int blk_base;              // first block (constraint, point) of this constraint in list order
    real Xl_R[9], Xl_t[3];     // the link in the moved frame of its last chain joint (in the base frame when the chain is empty)
    real tool[7];              // end effector in the link frame
    real table_world[7];       // cd_kin_pose_invert(T0w)
@@ -180,6 +183,11 @@ struct DevBatch
    // TSR hard constraints (tsr.h): n_tsrs == 0 when there are none
    const DevTsr<real> * tsrs;
    int n_tsrs, cons_k;        // constraints; rows of the system over all moving points
+   int tsr_blocks;            // (constraint, point) blocks of the system
+   // `start_tsr` (src/orcdchomp_mod.cpp:2316-2323, 2570-2576): the start point is a variable.  The workgroup's
+   // copy of the trajectory keeps its layout [fixed row][m moving rows][goal] with an unused row in front
+   // (n_points = m + 2 rows); the run's rows in global memory are np_global = m + 1: moving rows, goal.
+   int free_start, np_global;
    real * tsr_ws;             // [n_runs][tsr_ws_stride] workspace: h, h0, J, J^T x, the cons_k x cons_k system
    size_t tsr_ws_stride;
    int * tsr_err;             // [n_runs] 1 after a singular system ("constraint inversion error!")

@@ -358,7 +358,7 @@ void invert_dense(std::vector<double> & Mx, int n)
 
 } // namespace
 
-void build_metric(int m, int D, double dt, Metric & out)
+void build_metric(int m, int D, double dt, Metric & out, bool free_start)
 {
    if (D < 1) throw std::runtime_error("derivative must be >=1!");
    out.m = m; out.D = D;
@@ -370,16 +370,18 @@ void build_metric(int m, int D, double dt, Metric & out)
    double kss = 0.0, ksg = 0.0, kgg = 0.0;
    for (int d=0; d<D; d++)
    {
-      // every level has both an init and a final row (non-NULL inits/finals)
-      const int N = Nprev - 1 + 2;
+      // every level has a final row, and an init row unless the start point is a variable
+      // (`start_tsr`: inits[0] == NULL, src/orcdchomp_mod.cpp:2572; the higher inits stay zero vectors)
+      const int hi = (d == 0 && free_start) ? 0 : 1;
+      const int N = Nprev - 1 + hi + 1;
       std::vector<double> diff((size_t) N * Nprev, 0.0);
       std::vector<double> es(N, 0.0), eg(N, 0.0);
-      diff[0] = 1.0/dt;
-      if (d == 0) es[0] += -1.0/dt;             // Es[0] += (-1/dt)*inits[0]; higher inits are zero
+      if (hi) diff[0] = 1.0/dt;
+      if (d == 0 && hi) es[0] += -1.0/dt;       // Es[0] += (-1/dt)*inits[0]; higher inits are zero
       for (int i=0; i<Nprev-1; i++)
       {
-         diff[(size_t)(1+i)*Nprev + i]   = -1.0/dt;
-         diff[(size_t)(1+i)*Nprev + i+1] =  1.0/dt;
+         diff[(size_t)(hi+i)*Nprev + i]   = -1.0/dt;
+         diff[(size_t)(hi+i)*Nprev + i+1] =  1.0/dt;
       }
       diff[(size_t)(N-1)*Nprev + (Nprev-1)] = -1.0/dt;
       if (d == 0) eg[N-1] += 1.0/dt;

@@ -89,7 +89,7 @@ struct Metric
    std::vector<double> Ainv;    // dense [m][m], only when D >= 2
    std::vector<double> Adense;  // dense A (kept for tests / dense fallback)
 };
-void build_metric(int m, int D, double dt, Metric & out);
+void build_metric(int m, int D, double dt, Metric & out, bool free_start = false);   // free_start: no start boundary (`start_tsr`)
 
 // ------------------------------------------------------------------ rng ---
 // GSL's default generator and gaussian, restated from the published algorithm

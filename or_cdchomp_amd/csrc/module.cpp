@@ -637,7 +637,7 @@ std::string Module::cmd_create(const std::vector<std::string> & argv, bool batch
    int n_runs = 1;
    std::string dat_filename;
    std::vector<int> devs; bool have_devs = false;
-   std::vector<TsrSpec> con_tsrs, everyn_tsr;
+   std::vector<TsrSpec> con_tsrs, everyn_tsr, start_tsr;
    const double * goals_ptr = nullptr, * starts_ptr = nullptr, * basegoals_ptr = nullptr;
    const unsigned int * seeds_ptr = nullptr;
    const int argc = (int) argv.size();
@@ -727,8 +727,18 @@ std::string Module::cmd_create(const std::vector<std::string> & argv, bool batch
          everyn_tsr.clear(); everyn_tsr.push_back(t);
       }
       else if (a == "start_tsr" && i+1 < argc)
-         // makes the start point a variable (m = n_points-1, src/orcdchomp_mod.cpp:2316-2323,2571-2576): not in this build
-         throw std::runtime_error("start_tsr is not supported by this build!");
+      {
+         // src/orcdchomp_mod.cpp:1988-1992: the start point becomes a variable held on this TSR by a hard
+         // constraint (m = n_points-1; mod.cpp:2316-2323, 2570-2576); the active manipulator's end effector (mod.cpp:1704)
+         if (rname.empty()) throw std::runtime_error("You must pass robot before any con_tsrs!");
+         Robot & rb = robot(rname);
+         TsrSpec t;
+         if (!parse_tsr(argv[++i], t)) throw std::runtime_error("Cannot parse start_tsr TSR!");
+         if (rb.manips.empty()) throw std::runtime_error("start_tsr needs an active manipulator!");
+         t.ee_link = rb.manips[rb.active_manip].link; t.tool = rb.manips[rb.active_manip].tool;
+         t.point = 0;
+         start_tsr.clear(); start_tsr.push_back(t);
+      }
       else if ((a == "start_cost" || a == "ee_force" || a == "ee_force_at" || a == "ee_torque_weights") && i+1 < argc)
          throw std::runtime_error("argument " + a + " is outside the scope of this build (SURVEY.md section 2)");
       else if (batchmode && a == "n_runs" && i+1 < argc) n_runs = std::atoi(argv[++i].c_str());
@@ -767,7 +777,10 @@ std::string Module::cmd_create(const std::vector<std::string> & argv, bool batch
    // (its trajectory is the one it has in a batch, bit for bit; its cost sums are grouped differently)
    if (!batchmode) p.workgroup_threads = 512;
    // the constraints in the reference's order of addition (src/orcdchomp_mod.cpp:2582-2612)
-   p.tsrs = everyn_tsr;
+   if (p.floating_base && !start_tsr.empty()) throw std::runtime_error("floating_base and start_tsr together is not yet implemented!");   // mod.cpp:2100
+   p.free_start = start_tsr.empty() ? 0 : 1;
+   p.tsrs = start_tsr;
+   p.tsrs.insert(p.tsrs.end(), everyn_tsr.begin(), everyn_tsr.end());
    p.tsrs.insert(p.tsrs.end(), con_tsrs.begin(), con_tsrs.end());
    Robot & r = robot(rname);
    // initialisation from a passed trajectory (src/orcdchomp_mod.cpp:2375-2416): sampled at

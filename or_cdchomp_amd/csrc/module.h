@@ -91,11 +91,13 @@ struct TsrSpec
    Pose tool;                 // end effector in the link frame (identity for `link NAME`)
    Pose T0w, Twe;
    double Bw[6][2];
+   int point = -1;            // -1: every moving point (`con_tsr all`, `everyn_tsr`); >= 0: that moving point only (`start_tsr`: 0)
 };
 
 struct BatchParams
 {
-   std::vector<TsrSpec> tsrs; // in the reference's order of addition: everyn_tsr first, then the con_tsrs (mod.cpp:2582-2612)
+   std::vector<TsrSpec> tsrs; // in the reference's order of addition: start_tsr, everyn_tsr, then the con_tsrs (mod.cpp:2570-2612)
+   int free_start = 0;        // `start_tsr`: the start point is a variable (m = n_points - 1, no start boundary in the metric)
    int n_points = 101;
    int floating_base = 0;
    double lambda = 10.0;
@@ -174,6 +176,7 @@ private:
    int n_tiles_ = 1, tile_first_ = 0, tile_rest_ = 0;   // tiles of an iteration: the first of tile_first_ moving waypoints, the others of tile_rest_
    ModelScalars ms_ = {};             // the device model's scalars (carried in the kernarg block)
    int Sa_real_ = 0;                  // active spheres
+   int tsr_blocks_ = 0;               // (constraint, point) blocks of the TSR system
    int nj_ = 0, Sa_ = 0, S_ = 0;      // optimized joints; lanes of the active sphere block; lanes + inactive spheres
    int tile_m_ = 0;
    int block_ = 256;                  // threads per workgroup of the iterate kernel (256 or 192)

@@ -305,22 +305,22 @@ __device__ void tsr_eval_point(const DevModel<real> & gm, const DevTsr<real> & t
 template <typename real, typename BT>
 __device__ __forceinline__ void tsr_block(const BT & b, int o, int & c, int & i, int & row0)
 {
-   const int m = b.m;
-   c = b.n_tsrs - 1 - o / m;
-   i = m - 1 - (o - (o / m) * m);
-   row0 = b.tsrs[c].row_base + (m - 1 - i) * b.tsrs[c].k;
+   c = b.n_tsrs - 1;
+   while (c > 0 && o >= b.tsrs[c].blk_base + b.tsrs[c].npts) c--;
+   const int local = o - b.tsrs[c].blk_base;
+   i = (b.tsrs[c].npts == 1) ? b.tsrs[c].point : b.m - 1 - local;
+   row0 = b.tsrs[c].row_base + local * b.tsrs[c].k;
 }
 // block and row-in-block of row r of the system
 template <typename real, typename BT>
 __device__ __forceinline__ void tsr_row(const BT & b, int r, int & i, int & a)
 {
-   const int m = b.m;
    int c = b.n_tsrs - 1;
-   while (c > 0 && r >= b.tsrs[c].row_base + m * b.tsrs[c].k) c--;
+   while (c > 0 && r >= b.tsrs[c].row_base + b.tsrs[c].npts * b.tsrs[c].k) c--;
    const int k = b.tsrs[c].k;
    const int local = (r - b.tsrs[c].row_base) / k;
    a = (r - b.tsrs[c].row_base) - local * k;
-   i = m - 1 - local;
+   i = (b.tsrs[c].npts == 1) ? b.tsrs[c].point : b.m - 1 - local;
 }
 
 // The constraint step.  AG holds the unconstrained update (chomp.c:525-548), T_s the trajectory before it.
@@ -331,7 +331,7 @@ __device__ __attribute__((noinline)) void phase_tsr(const void * kp)
    const Env<real> E = make_env<real, GS16>(b, orc_smem);
    const DevModel<real> & gm = *b.model;
    const int tid = threadIdx.x, run = blockIdx.x;
-   const int n = b.n, m = b.m, K = b.cons_k, NB = b.n_tsrs * m;
+   const int n = b.n, m = b.m, K = b.cons_k, NB = b.tsr_blocks;
    real * ws = b.tsr_ws + (size_t) run * b.tsr_ws_stride;
    real * hws = ws;                          // [K]  h, then the solution
    real * h0 = hws + K;                      // [K]  h as built (dgesv leaves b alone when the matrix is singular)
@@ -452,10 +452,14 @@ __device__ __attribute__((noinline)) void phase_tsr(const void * kp)
    {
       const int r = e / n, q = e - r*n;
       real t = Tw[n + e];
-      for (int o=0; o<NB; o++)
+      for (int c=b.n_tsrs-1; c>=0; c--)
       {
-         const int i = m - 1 - (o - (o / m) * m);
-         t += (real)(-1) * b.Ainv[(size_t) r * m + i] * dws[o*n + q];
+         const int npts = b.tsrs[c].npts, o0 = b.tsrs[c].blk_base;
+         for (int local=0; local<npts; local++)
+         {
+            const int i = (npts == 1) ? b.tsrs[c].point : m - 1 - local;
+            t += (real)(-1) * b.Ainv[(size_t) r * m + i] * dws[(o0 + local)*n + q];
+         }
       }
       Tw[n + e] = t;
    }

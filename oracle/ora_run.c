@@ -135,6 +135,7 @@ struct ora_run              /* src/orcdchomp_mod.cpp:887-966 */
    /* tsr constraints applied (struct run_contsr, src/orcdchomp_mod.cpp:873-885) */
    int n_contsrs;
    struct run_contsr ** contsrs;
+   struct run_contsr * start_contsr;   /* start_tsr */
 };
 
 typedef struct run_contsr
@@ -160,6 +161,7 @@ void ora_run_params_default(ora_run_params * p)   /* src/orcdchomp_mod.cpp:1824-
    p->epsilon_self = 0.04;
    p->obs_factor = 200.0;
    p->obs_factor_self = 10.0;
+   p->start_tsr = 0;
 }
 
 static double nrm2_3(const double * v) { return sqrt(v[0]*v[0] + v[1]*v[1] + v[2]*v[2]); }
@@ -194,7 +196,7 @@ static int sphere_cost_pre(void * vptr, ora_chomp * c, int m, double ** T_points
       }
       ora_robot_fk(rob, pose, r->dofvals, r->fkR, r->fkt, r->fkaxis, r->fkanchor);
 
-      ti_mov = ti - 1;                                   /* mod.cpp:1040-1043, no start_tsr */
+      ti_mov = (c->m == r->n_points - 2) ? ti - 1 : ti;   /* mod.cpp:1040-1043 */
       for (sai=0; sai<Sa; sai++)
       {
          const run_sphere * s = &r->spheres[sai];
@@ -254,10 +256,14 @@ static int sphere_cost_pre(void * vptr, ora_chomp * c, int m, double ** T_points
       }
    }
 
-   /* central-difference sphere velocities and accelerations (mod.cpp:1099-1127) */
+   /* central-difference sphere velocities and accelerations (mod.cpp:1099-1127); with start_tsr the
+    * internal points follow the start point, whose velocity is one-sided and whose acceleration is
+    * the first internal one */
    {
       int rows = r->n_points - 2, cols = Sa*3;
       const double * P = r->sphere_poss_all;
+      double * vels = r->sphere_vels, * accs = r->sphere_accs;
+      if (c->m != r->n_points - 2) { vels += cols; accs += cols; }
       for (i=0; i<rows; i++) for (j=0; j<cols; j++)
       {
          double vel = P[(i+2)*cols+j];
@@ -268,9 +274,18 @@ static int sphere_cost_pre(void * vptr, ora_chomp * c, int m, double ** T_points
          acc += P[i*cols+j];
          acc += P[(i+2)*cols+j];
          acc *= 1.0/(c->dt * c->dt);
-         r->sphere_vels[i*cols+j] = vel;
-         r->sphere_accs[i*cols+j] = acc;
+         vels[i*cols+j] = vel;
+         accs[i*cols+j] = acc;
       }
+      if (c->m != r->n_points - 2)
+         for (j=0; j<cols; j++)
+         {
+            double vel = P[cols+j];
+            vel -= P[j];
+            vel *= 1.0/(c->dt);
+            r->sphere_vels[j] = vel;
+            r->sphere_accs[j] = r->sphere_accs[cols+j];
+         }
    }
    return 0;
 }
@@ -407,7 +422,7 @@ static void run_free(ora_run * r)
    free(r->sphere_poss_inactive); free(r->sphere_poss_all); free(r->sphere_vels);
    free(r->sphere_accs); free(r->sphere_jacs); free(r->J2); free(r->rsdfs);
    free(r->fkR); free(r->fkt); free(r->fkaxis); free(r->fkanchor);
-   { int j; for (j=0; j<r->n_contsrs; j++) free(r->contsrs[j]); free(r->contsrs); }
+   { int j; for (j=0; j<r->n_contsrs; j++) free(r->contsrs[j]); free(r->contsrs); free(r->start_contsr); }
    ora_chomp_free(r->c);
    free(r);
 }
@@ -583,6 +598,7 @@ ora_run * ora_run_create(const ora_robot * rob, const double base_pose[7], const
    if (!n_sdfs) { *errmsg = "No signed distance fields have yet been computed!"; return 0; }
    if (params->lambda < 0.01) { *errmsg = "lambda must be >=0.01!"; return 0; }
    if (params->n_points < 3) { *errmsg = "n_points must be >=3!"; return 0; }
+   if (params->floating_base && params->start_tsr) { *errmsg = "floating_base and start_tsr together is not yet implemented!"; return 0; }
 
    r = (ora_run *) calloc(1, sizeof(ora_run));
    r->robot = rob;
@@ -638,9 +654,10 @@ ora_run * ora_run_create(const ora_robot * rob, const double base_pose[7], const
    ora_rng_set(&r->rng, params->seed);                            /* mod.cpp:2303-2304 */
 
    m = r->n_points - 2;                                           /* mod.cpp:2315 */
+   if (params->start_tsr) m++;
    r->J2 = (double *) malloc(3*n*sizeof(double));
    r->sphere_poss_all = (double *) calloc((size_t) r->n_points * n_act * 3, sizeof(double));
-   r->sphere_poss = r->sphere_poss_all + n_act*3;                 /* mod.cpp:2323 */
+   r->sphere_poss = params->start_tsr ? r->sphere_poss_all : r->sphere_poss_all + n_act*3;   /* mod.cpp:2320-2323 */
    r->sphere_vels = (double *) calloc((size_t) m * n_act * 3, sizeof(double));
    r->sphere_accs = (double *) calloc((size_t) m * n_act * 3, sizeof(double));
    r->sphere_jacs = (double *) calloc((size_t) m * n_act * 3 * n, sizeof(double));
@@ -693,9 +710,26 @@ ora_run * ora_run_create(const ora_robot * rob, const double base_pose[7], const
          ora_kin_pose_normalize(&r->traj[i*n]);
 
    /* the optimizer (mod.cpp:2521, 2567-2663) */
-   if (ora_chomp_create(&r->c, m, n, params->D, &r->traj[1*n], n)) { run_free(r); *errmsg = "error creating chomp instance!"; return 0; }
+   if (ora_chomp_create(&r->c, m, n, params->D, &r->traj[(params->start_tsr?0:1)*n], n)) { run_free(r); *errmsg = "error creating chomp instance!"; return 0; }
    r->c->dt = 1.0/((r->n_points)-1);
-   r->c->inits[0] = &r->traj[0*n];
+   if (params->start_tsr)
+   {
+      /* mod.cpp:2570-2576: no start boundary in the metric, the start point held on the TSR */
+      run_contsr * ct = (run_contsr *) calloc(1, sizeof(run_contsr));
+      r->c->inits[0] = 0;
+      ct->r = r; ct->ee_link = params->start_ee_link;
+      for (i=0; i<7; i++) { ct->tool[i] = params->start_tool[i]; ct->T0w[i] = params->start_T0w[i]; ct->Twe[i] = params->start_Twe[i]; }
+      for (i=0; i<6; i++)
+      {
+         ct->Bw[i][0] = params->start_Bw[2*i]; ct->Bw[i][1] = params->start_Bw[2*i+1];
+         if (ct->Bw[i][0] == 0.0 && ct->Bw[i][1] == 0.0) { ct->tsr_enabled[i] = 1; ct->k++; }
+      }
+      r->start_contsr = ct;
+      if (ora_chomp_add_constraint(r->c, ct->k, 0, ct, con_tsr) || ora_chomp_alloc_constraints(r->c))
+         { run_free(r); *errmsg = "error adding the start_tsr constraint!"; return 0; }
+   }
+   else
+      r->c->inits[0] = &r->traj[0*n];
    r->c->finals[0] = &r->traj[((r->n_points)-1)*n];
    r->c->cptr = r;
    r->c->cost_pre = sphere_cost_pre;

@@ -183,6 +183,11 @@ typedef struct ora_run_params
    double hmc_resample_lambda; /* 0.02 */
    unsigned int seed;
    double epsilon, epsilon_self, obs_factor, obs_factor_self; /* 0.1 0.04 200 10 */
+   /* `start_tsr`: the start point becomes a variable held on a TSR by a hard constraint
+    * (src/orcdchomp_mod.cpp:1988-1992, 2316-2323, 2482-2499, 2570-2576); the fields as for ora_run_add_contsr */
+   int start_tsr;           /* default 0 */
+   int start_ee_link;
+   double start_tool[7], start_T0w[7], start_Twe[7], start_Bw[12];
 } ora_run_params;
 void ora_run_params_default(ora_run_params * p);
 

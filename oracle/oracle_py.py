@@ -42,7 +42,9 @@ class RunParams(C.Structure):
                 ("D", C.c_int), ("use_momentum", C.c_int), ("use_hmc", C.c_int),
                 ("hmc_resample_lambda", C.c_double), ("seed", C.c_uint),
                 ("epsilon", C.c_double), ("epsilon_self", C.c_double),
-                ("obs_factor", C.c_double), ("obs_factor_self", C.c_double)]
+                ("obs_factor", C.c_double), ("obs_factor_self", C.c_double),
+                ("start_tsr", C.c_int), ("start_ee_link", C.c_int), ("start_tool", C.c_double * 7),
+                ("start_T0w", C.c_double * 7), ("start_Twe", C.c_double * 7), ("start_Bw", C.c_double * 12)]
 
 
 class Rng(C.Structure):
@@ -231,13 +233,22 @@ class OraRobot:
         return R.reshape(n, 3, 3), t, ax, an
 
 
-def default_params(**kw):
+def default_params(start_tsr=None, **kw):
+    """start_tsr = (ee_link, tool[7], T0w[7], Twe[7], Bw[6][2]): `start_tsr` of create"""
     p = RunParams()
     lib().ora_run_params_default(C.byref(p))
     for k, v in kw.items():
         if k == "lambda":
             k = "lambda_"
         setattr(p, k, v)
+    if start_tsr is not None:
+        ee_link, tool, T0w, Twe, Bw = start_tsr
+        p.start_tsr = 1
+        p.start_ee_link = int(ee_link)
+        for i in range(7):
+            p.start_tool[i] = float(tool[i]); p.start_T0w[i] = float(T0w[i]); p.start_Twe[i] = float(Twe[i])
+        for i, v in enumerate(np.asarray(Bw, dtype=float).reshape(12)):
+            p.start_Bw[i] = float(v)
     return p
 
 

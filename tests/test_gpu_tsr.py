@@ -124,6 +124,81 @@ def test_everyn_tsr_with_con_tsr_and_momentum(oracle):
         run.destroy()
 
 
+@pytest.mark.parametrize("extra", ["", "momentum+con_tsr", "limits"])
+def test_start_tsr_matches_oracle(oracle, extra):
+    """`start_tsr` (reference src/orcdchomp_mod.cpp:1988-1992, 2316-2323, 2570-2576): the start point is a variable
+    (m = n_points - 1, no start boundary in the metric, one-sided sphere velocity) held on a TSR: here the
+    hand keeps its position while the arm's start configuration moves.  Second case: momentum and a
+    con_tsr on every point on top of it (three constraints' worth of blocks in the reference's list order).
+    Third case: goals near the joint limits, so that the joint-limit rounds run on the metric without a
+    start boundary (cyclic reduction instead of the closed forms of the default metric)."""
+    O = oracle
+    base = _unit_base()
+    mod = or_cdchomp_amd.Module(0)
+    model, dofvals, adofs = _setup(mod, base)
+    tool = [0, 0, 0.16, 0, 0, 0, 1]
+    Ree, tee, li = _start_frame(O, model, base, dofvals, "handbase", tool)
+    Bw_s = [[0, 0], [0, 0], [0, 0], [-3, 3], [-3, 3], [-3, 3]]      # hand position fixed, orientation free
+    tsr_s = robots.Tsr(T0w_R=Ree, T0w_d=tee, Bw=Bw_s)
+    Rl, tl, ll = _start_frame(O, model, base, dofvals, "wam4", [0, 0, 0, 0, 0, 0, 1])
+    Bw_l = [[-1, 1], [-1, 1], [0, 0], [-3, 3], [-3, 3], [-3, 3]]     # elbow height
+    tsr_l = robots.Tsr(T0w_R=Rl, T0w_d=tl, Bw=Bw_l)
+    n_runs, n_points, n_iter = 4, 30, 20
+    goals = _near_goals(n_runs, 11, spread=0.3)
+    if extra == "limits":
+        n_runs, n_points, n_iter = 12, 40, 40
+        goals = common.wam_goals(n_runs, seed=20250101)
+    with_con = (extra == "momentum+con_tsr")
+    more = ("use_momentum con_tsr 'all link wam4' '%s'" % tsr_l.serialize()) if with_con else ""
+    bid = int(mod.SendCommand("createbatch robot %s n_runs %d adofgoals 0x%x n_points %d lambda 100 obs_factor 200 start_tsr '%s' %s"
+                              % (model.name, n_runs, goals.ctypes.data, n_points, tsr_s.serialize(), more)))
+    seed = mod.batch_gettraj(bid)
+    costs, status = mod.batch_iterate(bid, n_iter)
+    traj = mod.batch_gettraj(bid)
+    assert traj.shape == (n_runs, n_points, 7)
+    mod.batch_destroy(bid)
+    prob = common.tabletop_problem(O)
+    rob = O.OraRobot(model)
+    T0w = O.pose_from_dR(tee, Ree)
+    limadjs = 0
+    for k in range(n_runs):
+        run = O.OraRun(rob, base, dofvals, adofs, goals[k], [prob["sdf"]], [prob["pose"]],
+                       O.default_params(n_points=n_points, lambda_=100.0, obs_factor=200.0, use_momentum=1 if with_con else 0,
+                                        start_tsr=(li, tool, T0w, [0, 0, 0, 0, 0, 0, 1], Bw_s)))
+        assert run.m == n_points - 1
+        if with_con:
+            run.add_contsr(ll, [0, 0, 0, 0, 0, 0, 1], O.pose_from_dR(tl, Rl), [0, 0, 0, 0, 0, 0, 1], Bw_l)
+        assert np.array_equal(seed[k], run.traj())
+        st, oc = run.iterate(n_iter)
+        limadjs += run.chomp().last_num_limadjs
+        assert st == status[k]
+        if st != 0:
+            run.destroy()
+            continue
+        assert common.rel_l2(traj[k], run.traj()) <= 1e-6, common.rel_l2(traj[k], run.traj())
+        assert np.allclose(costs[k], oc, rtol=1e-6, atol=0)
+        # the start configuration moved, the goal did not, and the hand is where it was
+        assert np.abs(traj[k][0] - seed[k][0]).max() > 1e-3 and np.array_equal(traj[k][-1], seed[k][-1])
+        _, t2, _, _ = rob.fk(base, [*traj[k][0], *dofvals[7:]])
+        R2 = rob.fk(base, [*traj[k][0], *dofvals[7:]])[0]
+        # (the joint-limit rounds come after the constraint step and pull the start off the TSR again)
+        assert extra == "limits" or np.abs(t2[li] + R2[li] @ np.array(tool[:3]) - tee).max() < 1e-4
+        run.destroy()
+    if extra == "limits":
+        assert limadjs > 0, "the workload is expected to make joint-limit rounds"
+
+
+def test_start_tsr_argument_errors():
+    mod = or_cdchomp_amd.Module(0)
+    model, dofvals, adofs = _setup(mod, _unit_base())
+    tsr = robots.Tsr(Bw=[[0, 0]] * 3 + [[-3, 3]] * 3)
+    with pytest.raises(RuntimeError, match="floating_base and start_tsr together is not yet implemented"):
+        mod.SendCommand("create robot %s adofgoal '%s' basegoal '0 0 0 0 0 0 1' floating_base start_tsr '%s'"
+                        % (model.name, " ".join(map(str, robots.WAM_GOAL)), tsr.serialize()))
+    with pytest.raises(RuntimeError, match="Cannot parse start_tsr TSR"):
+        mod.SendCommand("create robot %s adofgoal '%s' start_tsr '0 NULL 1 2 3'" % (model.name, " ".join(map(str, robots.WAM_GOAL))))
+
+
 def test_con_tsr_floating_base(oracle):
     """floating base: the base pose columns of the constraint Jacobian come from cd_spatial_pose_jac"""
     O = oracle
@@ -172,8 +247,6 @@ def test_tsr_argument_errors():
         mod.SendCommand("create robot %s adofgoal '0 0 0 0 0 0 0' con_tsr 'all' '0 NULL 1 2 3'" % model.name)
     with pytest.raises(RuntimeError, match="You must pass robot before any con_tsrs!"):
         mod.SendCommand("create con_tsr 'all' '%s' robot %s adofgoal '0 0 0 0 0 0 0'" % (tsr, model.name))
-    with pytest.raises(RuntimeError, match="start_tsr is not supported by this build!"):
-        mod.SendCommand("create robot %s adofgoal '0 0 0 0 0 0 0' start_tsr '%s'" % (model.name, tsr))
 
 
 def test_con_tsr_full_trajectory_length(oracle):

@@ -132,9 +132,10 @@ def test_survey_known_answers(oracle):
     L.ora_chomp_free(cp)
 
 
-@pytest.mark.parametrize("m,D", [(98, 1), (99, 1), (198, 1), (98, 2), (38, 3)])
-def test_product_metric_matches_oracle(oracle, m, D):
-    """band form + cyclic reduction tables of the product vs the dense A, B, trC, Ainv of the oracle"""
+@pytest.mark.parametrize("m,D,free", [(98, 1, 0), (99, 1, 0), (198, 1, 0), (98, 2, 0), (38, 3, 0), (99, 1, 1), (29, 1, 1), (40, 2, 1)])
+def test_product_metric_matches_oracle(oracle, m, D, free):
+    """band form + cyclic reduction tables of the product vs the dense A, B, trC, Ainv of the oracle;
+    free = the start point is a variable (`start_tsr`: inits[0] == NULL, reference src/orcdchomp_mod.cpp:2572)"""
     Lh = _host(); L = oracle.lib()
     n = 3
     rng = np.random.default_rng(m * 10 + D)
@@ -142,11 +143,11 @@ def test_product_metric_matches_oracle(oracle, m, D):
     cp = C.POINTER(oracle.Chomp)()
     L.ora_chomp_create(C.byref(cp), m, n, D, oracle.dp(T[1:].reshape(-1)), n)
     c = cp.contents
-    dt = 1.0 / (m + 1)
+    dt = 1.0 / (m + 1 - free)
     c.dt = dt
     Tflat = T.reshape(-1)
     inits = C.cast(c.inits, C.POINTER(oracle.c_double_p)); finals = C.cast(c.finals, C.POINTER(oracle.c_double_p))
-    inits[0] = C.cast(Tflat.ctypes.data, oracle.c_double_p)
+    inits[0] = C.cast(None if free else Tflat.ctypes.data, oracle.c_double_p)
     finals[0] = C.cast(Tflat.ctypes.data + (m + 1) * n * 8, oracle.c_double_p)
     assert L.ora_chomp_init(cp) == 0
     A = np.ctypeslib.as_array(c.A, shape=(m, m)); Ainv = np.ctypeslib.as_array(c.Ainv, shape=(m, m))
@@ -154,8 +155,11 @@ def test_product_metric_matches_oracle(oracle, m, D):
     Ah = np.zeros((m, m)); bs = np.zeros(m); bg = np.zeros(m); kap = np.zeros(3)
     rhs = rng.normal(size=(m, n)); sol = np.zeros((m, n))
     dp = oracle.dp
-    assert Lh.orc_host_metric(m, D, dt, dp(Ah), dp(bs), dp(bg), dp(kap), dp(rhs), n, dp(sol)) == 0
+    fn = Lh.orc_host_metric_free_start if free else Lh.orc_host_metric
+    assert fn(m, D, dt, dp(Ah), dp(bs), dp(bg), dp(kap), dp(rhs), n, dp(sol)) == 0
     assert np.allclose(Ah, A, rtol=1e-12, atol=1e-9 * np.abs(A).max())
+    if free:
+        assert not np.any(bs) and kap[0] == 0 and kap[1] == 0
     Bh = np.outer(bs, T[0]) + np.outer(bg, T[-1])
     assert np.allclose(Bh, B, rtol=1e-10, atol=1e-9 * np.abs(B).max())
     trC = 0.5 * (kap[0] * T[0] @ T[0] + 2 * kap[1] * T[0] @ T[-1] + kap[2] * T[-1] @ T[-1])
