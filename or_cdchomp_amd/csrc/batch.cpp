@@ -633,7 +633,16 @@ void BatchShard::build_device(const Robot & robot)
       }
       cons_k_ = base; tsr_blocks_ = blocks;
       const int NB = blocks;
-      tsr_ws_stride_ = (size_t) 2*cons_k_ + (size_t) cons_k_ * n + (size_t) NB * n + (size_t) cons_k_ * cons_k_;
+      tsr_ws_stride_ = (size_t) 2*cons_k_ + (size_t) cons_k_ * n + (size_t) NB * n + (size_t) cons_k_ * cons_k_
+                     + (size_t) m * n * (n + 1);      // the last term: delta rows of the structured solve (tsr.h)
+      // most constrained rows on one point
+      tsr_kmax_ = 0;
+      for (int i=0; i<m; i++)
+      {
+         int ki = 0;
+         for (int c=0; c<n_tsrs_; c++) if (ht[c].npts == m || ht[c].point == i) ki += ht[c].k;
+         tsr_kmax_ = std::max(tsr_kmax_, ki);
+      }
       const double gbytes = (double) tsr_ws_stride_ * n_runs * sizeof(real) / 1e9;
       if (cons_k_ > 2048 || gbytes > 64.0)
          throw std::runtime_error("TSR constraints: the constraint system is too large for this build (" + std::to_string(cons_k_)
@@ -1055,6 +1064,15 @@ void BatchShard::launch(int n_iter, bool final_eval)
       b.a_off = (real) metric_.beta_s[0];
    }
    b.tsrs = (const DevTsr<real> *) d_tsrs_; b.n_tsrs = n_tsrs_; b.cons_k = cons_k_; b.tsr_blocks = tsr_blocks_;
+   b.tsr_structured = 0; b.tsr_wcap = 0;
+   if (n_tsrs_ > 0 && params.derivative == 1 && !getenv("ORC_TSR_DENSE"))
+   {
+      // the structured solve keeps its augmented block in the axis tile buffer (dead during the update phase)
+      const int N = n + tsr_kmax_, Wd = N + n + 1;
+      const size_t need = (size_t) N * Wd + (size_t) n * (n + 1) + n + (size_t)(tsr_kmax_ + 2) * sizeof(int) / sizeof(real) + 2;
+      const size_t have = (size_t)(tile_m_ + 2) * b.lay.astr;
+      if (Wd <= 64 && need <= have) { b.tsr_structured = 1; b.tsr_wcap = N * Wd; }
+   }
    b.tsr_ws = (real *) d_tsr_ws_; b.tsr_ws_stride = tsr_ws_stride_; b.tsr_err = d_tsr_err_;
    b.Gdbg = debug_state_ ? (real *) d_G_ : nullptr;
    if (!g_in_lds_ && !d_Gcost_)

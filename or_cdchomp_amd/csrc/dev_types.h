@@ -184,6 +184,8 @@ struct DevBatch
    const DevTsr<real> * tsrs;
    int n_tsrs, cons_k;        // constraints; rows of the system over all moving points
    int tsr_blocks;            // (constraint, point) blocks of the system
+   int tsr_structured;        // the system is solved point by point (block tridiagonal KKT form, tsr.h) instead of by the dense LU
+   int tsr_wcap;              // reals of the augmented block [N][N + n + 1] of that solve at its largest
    // `start_tsr` (src/orcdchomp_mod.cpp:2316-2323, 2570-2576): the start point is a variable.  The workgroup's
    // copy of the trajectory keeps its layout [fixed row][m moving rows][goal] with an unused row in front
    // (n_points = m + 2 rows); the run's rows in global memory are np_global = m + 1: moving rows, goal.

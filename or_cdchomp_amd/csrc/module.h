@@ -177,6 +177,7 @@ private:
    ModelScalars ms_ = {};             // the device model's scalars (carried in the kernarg block)
    int Sa_real_ = 0;                  // active spheres
    int tsr_blocks_ = 0;               // (constraint, point) blocks of the TSR system
+   int tsr_kmax_ = 0;                 // most constrained rows on one point
    int nj_ = 0, Sa_ = 0, S_ = 0;      // optimized joints; lanes of the active sphere block; lanes + inactive spheres
    int tile_m_ = 0;
    int block_ = 256;                  // threads per workgroup of the iterate kernel (256 or 192)

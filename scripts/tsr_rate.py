@@ -1,5 +1,5 @@
 """Throughput of the TSR-constrained iteration (csrc/tsr.h): WAM, n_points=100, three constrained rows on every
-moving point (a 294 x 294 system per run and iteration).   python scripts/tsr_rate.py [n_runs] [k rows 1..3]"""
+moving point (a 294 x 294 system per run and iteration in the reference's dense form; ORC_TSR_DENSE=1 runs that form).   python scripts/tsr_rate.py [n_runs] [k rows 1..3]"""
 import sys, os, time
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..")); sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
 import numpy as np
