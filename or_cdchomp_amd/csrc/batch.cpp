@@ -1041,7 +1041,8 @@ void BatchShard::launch(int n_iter, bool final_eval)
    b.inv_m = (real)(1.0/m);
    b.epsilon = (real) params.epsilon; b.epsilon_self = (real) params.epsilon_self;
    b.obs_factor = (real) params.obs_factor; b.obs_factor_self = (real) params.obs_factor_self;
-   b.use_momentum = params.use_momentum; b.use_hmc = params.use_hmc && max_resamples_ > 0; b.D = params.derivative;
+   b.use_momentum = params.use_momentum; b.use_hmc = params.use_hmc && max_resamples_ > 0;
+   b.D = (params.derivative == 1 && params.free_start) ? -1 : params.derivative;
    b.Aband = (const real *) d_Aband_; b.beta_s = (const real *) d_beta_s_; b.beta_g = (const real *) d_beta_g_;
    b.kss = metric_.kss; b.ksg = metric_.ksg; b.kgg = metric_.kgg;
    b.solve_mode = solve_mode_;

@@ -835,9 +835,11 @@ __device__ __forceinline__ real * metric_solve(const BT & b, const real * tab, r
 template <typename real, typename BT>
 __device__ __forceinline__ real smooth_grad(const BT & b, const real * T_s, int i, int c)
 {
-   const int m = b.m, n = b.n, D = b.D;
-   if (D == 1 && !b.free_start)       // tridiagonal Toeplitz: the end rows couple to the fixed endpoints with a_off
+   const int m = b.m, n = b.n;
+   int D = b.D;
+   if (D == 1)       // tridiagonal Toeplitz: the end rows couple to the fixed endpoints with a_off
       return b.a_diag * T_s[(i+1)*n + c] + b.a_off * (T_s[i*n + c] + T_s[(i+2)*n + c]);
+   D = (D < 0) ? -D : D;      // (-1: tridiagonal without a start boundary, DevBatch::D)
    real s = b.beta_s[i] * T_s[c] + b.beta_g[i] * T_s[(b.n_points-1)*n + c];
    for (int k=-D; k<=D; k++)
    {
@@ -991,10 +993,11 @@ __device__ __attribute__((noinline)) void phase_setup(const void * kp)
    const int nj = E.mod.nj, Sa = E.mod.Sa, S = E.mod.S;
    if (GS16 || b.t_in_lds)
    {
-      // start_tsr: the start point is the first moving row; the row in front of it is never used
-      // (no start boundary in the metric, one-sided differences in the cost phase) and holds a copy of it
+      // start_tsr: the start point is the first moving row.  The row in front of it is not a trajectory
+      // point (no start boundary in the metric); it holds a copy of the point AFTER the start point, so that
+      // the regular cost pass sees the start point at rest (cost_gs16.h START)
       const int skip = b.free_start ? n : 0;
-      for (int e=tid; e<np*n; e+=BLOCK) E.T_s[e] = E.traj_g[(e < skip) ? e : e - skip];
+      for (int e=tid; e<np*n; e+=BLOCK) E.T_s[e] = E.traj_g[(e < skip) ? e + skip : e - skip];
    }
    for (int e=tid; e<S; e+=BLOCK) { E.srad_s[e] = gmod.sph_radius[e]; E.slink_s[e] = gmod.sph_link[e]; }
    for (int e=tid; e<(S-Sa)*3; e+=BLOCK) E.sinact_s[e] = gmod.sph_inactive_pos[e/3][e%3];
@@ -1088,6 +1091,26 @@ __device__ __attribute__((noinline)) void phase_fk(const void * kp, int ts_in, i
    }
    __syncthreads();
    phase_mark<real>(b, E, 0);
+}
+
+// ---- start_tsr: the cost pass of the start point alone (one-sided velocity; cost_gs16.h START), after the
+// regular pass of its tile.  A function of its own: inside phase_cost its registers and code were in the way
+// of the regular pass (1 % of config 2's throughput without ever running) ----
+template <typename real, bool TREE, bool GS16, int BLOCK>
+__device__ __attribute__((noinline)) double phase_cost_start(const void * kp, int do_iteration_in, double cost_lane)
+{
+   KArg<real> & b = *uniform_kernarg<real>(kp);
+   const bool do_iteration = uni(do_iteration_in) != 0;
+   const Env<real> E = make_env<real, GS16>(b, orc_smem);
+   const real inv_eps = (real)1 / b.epsilon, inv_eps_self = (real)1 / b.epsilon_self;
+   if constexpr (GS16)
+      cost_tile_gs16<real, ORC_U, BLOCK, KArg<real>, true>(b, E.mod, E.sdfs_s, 0, 1, do_iteration, E.T_s, E.Gc, E.pos_s, E.ax_s, E.srad_s, E.sinact_s, E.r2_s,
+                                                          E.slink_s, E.jtype_s, E.jcol_s, inv_eps, inv_eps_self, cost_lane);
+   else
+      cost_tile_generic<real, BLOCK, KArg<real>, true>(b, E.mod, E.sdfs_s, 0, 1, do_iteration, E.T_s, E.Gc, E.pos_s, E.ax_s, E.srad_s, E.sinact_s,
+                                                      E.slink_s, E.jtype_s, E.jcol_s, E.pstr, E.astr, inv_eps, inv_eps_self, cost_lane, nullptr);
+   __syncthreads();
+   return cost_lane;
 }
 
 // ---- cost phase of one tile: lane = (waypoint, sphere) (sphere_cost, src/orcdchomp_mod.cpp:1134-1327) ----
@@ -1270,7 +1293,7 @@ __device__ __attribute__((noinline)) int phase_update(const void * kp, int it_in
       //    Ainv[i][k] = (min(i,k)+1) (m - max(i,k)) / ((m+1) ca),   A = ca tridiag(-1,2,-1),
       // so GA is a short sum per element instead of a full solve.
       bool sparse_done = false;
-      if (b.D == 1 && b.solve_mode != 1 && !b.free_start)
+      if (b.D == 1 && b.solve_mode != 1)
       {
          const int K = (mn + BLOCK - 1) / BLOCK;       // elements per thread
          int * cnt = (int *) W_s;                               // [K][waves] counts per (slice, wave)
@@ -1379,7 +1402,7 @@ __device__ __attribute__((noinline)) PassCosts phase_costs(const void * kp, int 
       {
          const int i = div_n(e, rn_f), c = e - i*n;
          const real sg = smooth_grad<real>(b, T_s, i, c);     // (A T + B)
-         const real bt = (b.D == 1 && !b.free_start) ? b.a_off * ((i == 0 ? T_s[c] : (real)0) + (i == m-1 ? T_s[(np-1)*n + c] : (real)0))
+         const real bt = (b.D == 1) ? b.a_off * ((i == 0 ? T_s[c] : (real)0) + (i == m-1 ? T_s[(np-1)*n + c] : (real)0))
                                     : b.beta_s[i] * T_s[c] + b.beta_g[i] * T_s[(np-1)*n + c];
          acc += (double) T_s[n + e] * (0.5 * ((double) sg + (double) bt));
       }
@@ -1401,6 +1424,13 @@ __device__ __attribute__((noinline)) PassCosts phase_costs(const void * kp, int 
    }
    phase_mark<real>(b, E, 5);
 
+   // start_tsr: the row in front of the start point follows the point after it (see phase_setup)
+   if (do_iteration && b.free_start)
+   {
+      real * Tw = E.T_s;
+      if (tid < n) Tw[tid] = Tw[2*n + tid];
+      __syncthreads();
+   }
    // floating base: renormalise the quaternion of every row (mod.cpp:2806-2808)
    if (do_iteration && E.mod.floating)
    {
@@ -1513,6 +1543,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
 #endif
 #ifndef ORC_ABLATE_COST
          cost_lane = phase_cost<real, TREE, GS16, BLOCK>(kp, ts, te, do_iteration ? 1 : 0, cost_lane);
+         if (tk == 0 && b.free_start) cost_lane = phase_cost_start<real, TREE, GS16, BLOCK>(kp, do_iteration ? 1 : 0, cost_lane);
 #endif
       } // tiles
 

@@ -19,7 +19,8 @@
 //       a fixed summation order.
 #pragma once
 
-template <typename real, int BLOCK, typename BT>
+// START: the pass of the start point alone when it is a variable (`start_tsr`), see cost_gs16.h
+template <typename real, int BLOCK, typename BT, bool START = false>
 __device__ __forceinline__ void cost_tile_generic(const BT & b, const ModelView<real> & mod,
    const DevSdf<real> * sdfs, int ts, int te, bool do_iteration, const real * T_s, real * Gc, const real * pos_s, const real * ax_s,
    const real * srad_s, const real * sinact_s, const int * slink_s, const int * jtype_s, const int * jcol_s,
@@ -59,7 +60,7 @@ __device__ __forceinline__ void cost_tile_generic(const BT & b, const ModelView<
             real v = pn[k]; v -= pp[k]; v *= b.inv_2dt; vel[k] = v;
             real a = pc[k]; a *= (real)(-2); a += pp[k]; a += pn[k]; a *= b.inv_dt2; acc[k] = a;
          }
-         if (b.free_start && ts + wl == 0 && item < items)
+         if constexpr (START)
          {
             // start_tsr: the start point's velocity is one-sided and its acceleration the next point's
             // (src/orcdchomp_mod.cpp:1107-1112, 1125-1126); the row in front of it is not a trajectory point

@@ -183,7 +183,14 @@ __device__ __forceinline__ void self_sym_step16(const real * prow, const real * 
    }
 }
 
-template <typename real, int U, int BLOCK, typename BT>
+// START: the pass of the start point alone when it is a variable (`start_tsr`): its sphere velocity is
+// one-sided and its acceleration the next point's (src/orcdchomp_mod.cpp:1107-1112, 1125-1126).  The
+// regular pass of that tile runs first, as for any tile; the unused trajectory row in front of the start
+// point holds a copy of the point after it, so the regular pass sees the start point at rest (central
+// difference exactly zero) and adds exactly nothing to the cost for it; this pass then writes the point's
+// gradient row and adds its cost.  (Any trace of the case inside the regular pass -- a never-taken branch, one
+// more comparison -- cost 1 % of config 2's throughput: the pass has no register to spare.)
+template <typename real, int U, int BLOCK, typename BT, bool START = false>
 __device__ __forceinline__ void cost_tile_gs16(const BT & b, const ModelView<real> & mod,
    const DevSdf<real> * sdfs, int ts, int te, bool do_iteration, const real * T_s, real * G_s, const real * pos_s, const real * ax_s,
    const real * srad_s, const real * sinact_s, const real * r2_s, const int * slink_s, const int * jtype_s, const int * jcol_s,
@@ -238,10 +245,8 @@ __device__ __forceinline__ void cost_tile_gs16(const BT & b, const ModelView<rea
             real a = pc[k]; a *= (real)(-2); a += pp[k]; a += pn[k]; a *= b.inv_dt2; acc[u][k] = a;
             f[u][k] = 0;
          }
-         if (b.free_start && ts + wl[u] == 0 && item < items)
+         if constexpr (START)
          {
-            // start_tsr: the start point's velocity is one-sided and its acceleration the next point's
-            // (src/orcdchomp_mod.cpp:1107-1112, 1125-1126); the row in front of it is not a trajectory point
             const real * pnn = pn + pstr;
             const real inv_dt = (real)1 / b.dt;
 #pragma unroll

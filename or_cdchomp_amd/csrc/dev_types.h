@@ -149,7 +149,7 @@ struct DevBatch
    // run parameters
    real dt, inv_2dt, inv_dt2, lambda, inv_m;
    real epsilon, epsilon_self, obs_factor, obs_factor_self;
-   int use_momentum, use_hmc, D;
+   int use_momentum, use_hmc, D;      // D: the derivative; -1: derivative 1 without a start boundary (tridiagonal, not Toeplitz: none of the kernels' short forms for D == 1 apply)
    // metric: band of A, endpoint couplings of B and trC
    const real * Aband;     // [2D+1][m]
    const real * beta_s;    // [m]  B[i] = beta_s[i]*q_start + beta_g[i]*q_goal

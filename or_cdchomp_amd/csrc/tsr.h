@@ -471,6 +471,7 @@ __device__ __attribute__((noinline)) void phase_tsr(const void * kp)
       }
    }
    __syncthreads();
+#ifndef ORC_ABLATE_NOTH
    if (b.tsr_structured)
    {
       real * Cst = Mws + (size_t) K * K;        // [m][n][n+1]
@@ -484,6 +485,7 @@ __device__ __attribute__((noinline)) void phase_tsr(const void * kp)
       if (!failed) return;
       // a singular block: the dense path below treats the case the way the reference does
    }
+#endif
    // ---- J Ainv J^T (chomp.c:567-575) ----
    for (long e=tid; e<(long) K*K; e+=BLOCK)
    {

@@ -188,6 +188,56 @@ def test_start_tsr_matches_oracle(oracle, extra):
         assert limadjs > 0, "the workload is expected to make joint-limit rounds"
 
 
+def test_start_tsr_many_sphere_robot(oracle):
+    """`start_tsr` on the kernel variant for robots with more than 16 spheres (30-dof tree, 60 spheres): the
+    tip of the left arm keeps its position while the start configuration moves"""
+    O = oracle
+    from or_cdchomp_amd import scenes
+    mod = or_cdchomp_amd.Module(0)
+    model = robots.tree30()
+    base = [0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0]
+    rng = np.random.default_rng(3)
+    dofvals = rng.uniform(-0.3, 0.3, size=model.n_dof)
+    adofs = list(range(model.n_dof))
+    mod.add_robot(model, transform=base, dof_values=dofvals, active_dofs=adofs)
+    li = model.link_names.index("L13")
+    tool = [0, 0, 0.15, 0, 0, 0, 1]
+    mod.add_manipulator(model.name, "left", li, tool)
+    grids, poses = [], []
+    for name, (boxes, pose) in scenes.random_boxes(np.random.default_rng(20250104)).items():
+        mod.add_kinbody_boxes(name, boxes, transform=pose)
+        mod.SendCommand("computedistancefield kinbody %s cube_extent 0.02 aabb_padding 0.15" % name)
+        data, lengths, gpose = mod.get_sdf(name)
+        grids.append(O.OraGrid(data, lengths))
+        out = np.zeros(7)
+        O.lib().ora_kin_pose_compose(O.dp(O.f64(pose)), O.dp(O.f64(gpose)), O.dp(out))
+        poses.append(out)
+    rob = O.OraRobot(model)
+    R, t, _, _ = rob.fk(base, dofvals)
+    tee = t[li] + R[li] @ np.array(tool[:3])
+    Bw = [[0, 0], [0, 0], [0, 0], [-3, 3], [-3, 3], [-3, 3]]
+    tsr = robots.Tsr(T0w_R=R[li], T0w_d=tee, Bw=Bw)
+    n_runs, n_points, n_iter = 2, 24, 10
+    goals = dofvals[None, :] + rng.uniform(-0.4, 0.4, size=(n_runs, model.n_dof))
+    bid = int(mod.SendCommand("createbatch robot %s n_runs %d adofgoals 0x%x n_points %d lambda 200 obs_factor 100 start_tsr '%s'"
+                              % (model.name, n_runs, goals.ctypes.data, n_points, tsr.serialize())))
+    seed = mod.batch_gettraj(bid)
+    costs, status = mod.batch_iterate(bid, n_iter)
+    traj = mod.batch_gettraj(bid)
+    mod.batch_destroy(bid)
+    for k in range(n_runs):
+        run = O.OraRun(rob, base, dofvals, adofs, goals[k], grids, poses,
+                       O.default_params(n_points=n_points, lambda_=200.0, obs_factor=100.0,
+                                        start_tsr=(li, tool, O.pose_from_dR(tee, R[li]), [0, 0, 0, 0, 0, 0, 1], Bw)))
+        assert run.Sa == 60 and run.m == n_points - 1
+        st, oc = run.iterate(n_iter)
+        assert st == 0 and status[k] == 0
+        assert common.rel_l2(traj[k], run.traj()) <= 1e-6, common.rel_l2(traj[k], run.traj())
+        assert np.allclose(costs[k], oc, rtol=1e-6, atol=0)
+        assert np.abs(traj[k][0] - seed[k][0]).max() > 1e-4
+        run.destroy()
+
+
 def test_start_tsr_argument_errors():
     mod = or_cdchomp_amd.Module(0)
     model, dofvals, adofs = _setup(mod, _unit_base())
