@@ -1114,17 +1114,26 @@ __device__ __attribute__((noinline)) double phase_cost_start(const void * kp, in
 }
 
 // ---- cost phase of one tile: lane = (waypoint, sphere) (sphere_cost, src/orcdchomp_mod.cpp:1134-1327) ----
-template <typename real, bool TREE, bool GS16, int BLOCK>
+// KIND: what the kernel variant knows about the workload at compile time (bits; 0 = nothing).
+//   1  a fixed-base chain whose spheres are placed on the row (DevModel::floating == 0, jt_scan == 1,
+//      placed == 1: the WAM of the BASELINE configurations): the J^T code has one form instead of a
+//      branch over five
+//   2  one signed distance field whose axes are the world's (a kinbody that is only translated): no loop
+//      over fields, no best-of-N bookkeeping across it, no rotation of point and gradient
+// The pass has no register to spare, so what it need not keep alive is time: 122.4 -> 117.3 ms for 16 384
+// WAM runs with bit 1, -> 112.2 ms with both (instantiated: 0, 1, 3).
+template <typename real, bool TREE, bool GS16, int BLOCK, int KIND = 0>
 __device__ __attribute__((noinline)) double phase_cost(const void * kp, int ts_in, int te_in, int do_iteration_in, double cost_lane)
 {
    KArg<real> & b = *uniform_kernarg<real>(kp);
    const int ts = uni(ts_in), te = uni(te_in);
    const bool do_iteration = uni(do_iteration_in) != 0;
-   const Env<real> E = make_env<real, GS16>(b, orc_smem);
+   Env<real> E = make_env<real, GS16>(b, orc_smem);
+   if constexpr ((KIND & 1) != 0) { E.mod.floating = 0; E.mod.jt_scan = 1; E.mod.placed = 1; }
    const real inv_eps = (real)1 / b.epsilon, inv_eps_self = (real)1 / b.epsilon_self;
    __builtin_amdgcn_s_setprio(ORC_PRIO_COST);
    if constexpr (GS16)
-      cost_tile_gs16<real, ORC_U, BLOCK>(b, E.mod, E.sdfs_s, ts, te, do_iteration, E.T_s, E.Gc, E.pos_s, E.ax_s, E.srad_s, E.sinact_s, E.r2_s,
+      cost_tile_gs16<real, ORC_U, BLOCK, KArg<real>, false, (KIND & 2) != 0>(b, E.mod, E.sdfs_s, ts, te, do_iteration, E.T_s, E.Gc, E.pos_s, E.ax_s, E.srad_s, E.sinact_s, E.r2_s,
                                          E.slink_s, E.jtype_s, E.jcol_s, inv_eps, inv_eps_self, cost_lane);
    else
       cost_tile_generic<real, BLOCK>(b, E.mod, E.sdfs_s, ts, te, do_iteration, E.T_s, E.Gc, E.pos_s, E.ax_s, E.srad_s, E.sinact_s,
@@ -1487,7 +1496,7 @@ __device__ __attribute__((noinline)) void phase_finish(const void * kp, int stat
 // ---------------------------------------------------------------------------
 // The kernel: one workgroup = one run for all iterations of the launch; the loop below only
 // sequences the phase functions and carries the few scalars that cross iterations.
-template <typename real, bool TREE, bool GS16, int BLOCK>
+template <typename real, bool TREE, bool GS16, int BLOCK, int KIND = 0>
 __global__ __launch_bounds__(BLOCK, (BLOCK == 512 ? 2 : ORC_WGS_PER_CU))      // second argument: wavefronts per SIMD (3 x 4 SIMDs = 12 per CU, as 3 x 256 or 4 x 192 threads; 2 for the one-run-per-CU shape of 512)
 void chomp_iterate_kernel(const DevBatch<real> b)
 {
@@ -1542,7 +1551,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
 #endif
 #endif
 #ifndef ORC_ABLATE_COST
-         cost_lane = phase_cost<real, TREE, GS16, BLOCK>(kp, ts, te, do_iteration ? 1 : 0, cost_lane);
+         cost_lane = phase_cost<real, TREE, GS16, BLOCK, KIND>(kp, ts, te, do_iteration ? 1 : 0, cost_lane);
          if (tk == 0 && b.free_start) cost_lane = phase_cost_start<real, TREE, GS16, BLOCK>(kp, do_iteration ? 1 : 0, cost_lane);
 #endif
       } // tiles
@@ -1723,7 +1732,7 @@ size_t orc_chomp_lds_bytes(int n_points, int n, int Sa, int S, int nj, int tile_
    return (size_t) lds_layout(n_points, n, Sa, S, nj, tile_m, pcr_rows, (int) real_size, use_momentum, n_sdfs, ss, flags).total_bytes;
 }
 
-template <typename real, bool TREE, bool GS16, int BLOCK>
+template <typename real, bool TREE, bool GS16, int BLOCK, int KIND = 0>
 static hipError_t launch_iterate_tt(const DevBatch<real> & b, size_t lds, hipStream_t stream)
 {
    // the attribute is per device (and per kernel instantiation)
@@ -1732,21 +1741,35 @@ static hipError_t launch_iterate_tt(const DevBatch<real> & b, size_t lds, hipStr
    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
    if (!((attr_set.load() >> dev) & 1ull))
    {
-      hipError_t e = hipFuncSetAttribute((const void *) chomp_iterate_kernel<real, TREE, GS16, BLOCK>,
+      hipError_t e = hipFuncSetAttribute((const void *) chomp_iterate_kernel<real, TREE, GS16, BLOCK, KIND>,
          hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256);
       if (e != hipSuccess) return e;
       attr_set.fetch_or(1ull << dev);
    }
-   hipLaunchKernelGGL((chomp_iterate_kernel<real, TREE, GS16, BLOCK>), dim3(b.n_runs), dim3(BLOCK), lds, stream, b);
+   hipLaunchKernelGGL((chomp_iterate_kernel<real, TREE, GS16, BLOCK, KIND>), dim3(b.n_runs), dim3(BLOCK), lds, stream, b);
    return hipGetLastError();
 }
 
 // variant: bit 0 the joint tree branches, bit 1 the robot has <= 16 active spheres (DPP-row cost
 // phase), bit 2 workgroups of 192 threads (three wavefronts, four workgroups per CU) instead of 256,
-// bit 3 workgroups of 512 threads (eight wavefronts, one workgroup per CU: the latency shape)
+// bit 3 workgroups of 512 threads (eight wavefronts, one workgroup per CU: the latency shape),
+// bit 4 the robot is a fixed-base chain with its spheres placed on the row (with bit 1, without bit 0),
+// bit 5 (with bit 4) there is one field and its axes are the world's
 template <typename real>
 static hipError_t launch_iterate_t(const DevBatch<real> & b, size_t lds, hipStream_t stream, int variant)
 {
+   if ((variant & 48) == 48)      // phase_cost KIND 3: a fixed-base chain with placed spheres, one field with the world's axes
+   {
+      if (variant & 8) return launch_iterate_tt<real, false, true, 512, 3>(b, lds, stream);
+      if (variant & 4) return launch_iterate_tt<real, false, true, 192, 3>(b, lds, stream);
+      return launch_iterate_tt<real, false, true, 256, 3>(b, lds, stream);
+   }
+   if (variant & 16)              // KIND 1
+   {
+      if (variant & 8) return launch_iterate_tt<real, false, true, 512, 1>(b, lds, stream);
+      if (variant & 4) return launch_iterate_tt<real, false, true, 192, 1>(b, lds, stream);
+      return launch_iterate_tt<real, false, true, 256, 1>(b, lds, stream);
+   }
    if (variant & 8)
       switch (variant & 3)
       {

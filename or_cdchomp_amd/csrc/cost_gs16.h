@@ -190,7 +190,8 @@ __device__ __forceinline__ void self_sym_step16(const real * prow, const real * 
 // difference exactly zero) and adds exactly nothing to the cost for it; this pass then writes the point's
 // gradient row and adds its cost.  (Any trace of the case inside the regular pass -- a never-taken branch, one
 // more comparison -- cost 1 % of config 2's throughput: the pass has no register to spare.)
-template <typename real, int U, int BLOCK, typename BT, bool START = false>
+// ONEF: there is one field and its axes are the world's (DevSdf::rot_identity), known at compile time.
+template <typename real, int U, int BLOCK, typename BT, bool START = false, bool ONEF = false>
 __device__ __forceinline__ void cost_tile_gs16(const BT & b, const ModelView<real> & mod,
    const DevSdf<real> * sdfs, int ts, int te, bool do_iteration, const real * T_s, real * G_s, const real * pos_s, const real * ax_s,
    const real * srad_s, const real * sinact_s, const real * r2_s, const int * slink_s, const int * jtype_s, const int * jcol_s,
@@ -277,7 +278,7 @@ __device__ __forceinline__ void cost_tile_gs16(const BT & b, const ModelView<rea
 #pragma unroll
       for (int u=0; u<U; u++) { best[u] = inf; has[u] = false; bgrad[u][0] = 0; bgrad[u][1] = 0; bgrad[u][2] = 0; }
 #ifndef ORC_ABLATE_SDF
-      for (int i=0; i<b.n_sdfs; i++)
+      for (int i=0; i<(ONEF ? 1 : b.n_sdfs); i++)
       {
          const DevSdf<real> & F = sdfs[i];
 #pragma unroll
@@ -285,7 +286,7 @@ __device__ __forceinline__ void cost_tile_gs16(const BT & b, const ModelView<rea
          {
             real gp[3], gg[3], gw[3], val;
             // field axes = world axes (the field is only translated): the products with 0 and 1 are exact
-            const bool aligned = (__builtin_amdgcn_readfirstlane(F.rot_identity) != 0);
+            const bool aligned = ONEF || (__builtin_amdgcn_readfirstlane(F.rot_identity) != 0);
             if (aligned)
             {
 #pragma unroll
