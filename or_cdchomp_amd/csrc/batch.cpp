@@ -590,8 +590,8 @@ void BatchShard::build_device(const Robot & robot)
       device_sphere_order.push_back(inact[s].xml);
    }
    nj_ = nj; Sa_ = lanes; S_ = lanes + (int) inact.size(); GS_ = M.GS; tree_ = M.tree | ((M.GS == 16) ? 2 : 0);     // kernel variant bits
-   if (M.GS == 16 && !M.tree && !M.floating && M.jt_scan == 1 && M.placed && !getenv("ORC_NO_KIND"))
-      tree_ |= 16;      // the variant that knows all this at compile time (chomp_kernel.hip phase_cost KIND)
+   if (M.GS == 16 && !M.tree && M.jt_scan == 1 && M.placed && !getenv("ORC_NO_KIND"))
+      tree_ |= 16 | (M.floating ? 64 : 0);      // the variants that know all this at compile time (chomp_kernel.hip phase_cost KIND)
 
    hipStream_t st = stream_;
    // TSR hard constraints, folded onto the device's joint order (csrc/tsr.h)

@@ -1115,13 +1115,13 @@ __device__ __attribute__((noinline)) double phase_cost_start(const void * kp, in
 
 // ---- cost phase of one tile: lane = (waypoint, sphere) (sphere_cost, src/orcdchomp_mod.cpp:1134-1327) ----
 // KIND: what the kernel variant knows about the workload at compile time (bits; 0 = nothing).
-//   1  a fixed-base chain whose spheres are placed on the row (DevModel::floating == 0, jt_scan == 1,
-//      placed == 1: the WAM of the BASELINE configurations): the J^T code has one form instead of a
-//      branch over five
+//   1  a chain whose spheres are placed on the row (DevModel::jt_scan == 1, placed == 1: the WAM of the
+//      BASELINE configurations), with a fixed base unless bit 4 says it floats: the J^T code has one form
+//      instead of a branch over five
 //   2  one signed distance field whose axes are the world's (a kinbody that is only translated): no loop
 //      over fields, no best-of-N bookkeeping across it, no rotation of point and gradient
 // The pass has no register to spare, so what it need not keep alive is time: 122.4 -> 117.3 ms for 16 384
-// WAM runs with bit 1, -> 112.2 ms with both (instantiated: 0, 1, 3).
+// WAM runs with bit 1, -> 112.2 ms with both (instantiated: 0, 1, 3, and 5, 7 for the floating base).
 template <typename real, bool TREE, bool GS16, int BLOCK, int KIND = 0>
 __device__ __attribute__((noinline)) double phase_cost(const void * kp, int ts_in, int te_in, int do_iteration_in, double cost_lane)
 {
@@ -1129,7 +1129,7 @@ __device__ __attribute__((noinline)) double phase_cost(const void * kp, int ts_i
    const int ts = uni(ts_in), te = uni(te_in);
    const bool do_iteration = uni(do_iteration_in) != 0;
    Env<real> E = make_env<real, GS16>(b, orc_smem);
-   if constexpr ((KIND & 1) != 0) { E.mod.floating = 0; E.mod.jt_scan = 1; E.mod.placed = 1; }
+   if constexpr ((KIND & 1) != 0) { E.mod.floating = (KIND & 4) ? 1 : 0; E.mod.jt_scan = 1; E.mod.placed = 1; }
    const real inv_eps = (real)1 / b.epsilon, inv_eps_self = (real)1 / b.epsilon_self;
    __builtin_amdgcn_s_setprio(ORC_PRIO_COST);
    if constexpr (GS16)
@@ -1754,21 +1754,22 @@ static hipError_t launch_iterate_tt(const DevBatch<real> & b, size_t lds, hipStr
 // phase), bit 2 workgroups of 192 threads (three wavefronts, four workgroups per CU) instead of 256,
 // bit 3 workgroups of 512 threads (eight wavefronts, one workgroup per CU: the latency shape),
 // bit 4 the robot is a fixed-base chain with its spheres placed on the row (with bit 1, without bit 0),
-// bit 5 (with bit 4) there is one field and its axes are the world's
+// bit 5 (with bit 4) there is one field and its axes are the world's, bit 6 (with bit 4) the base floats
 template <typename real>
 static hipError_t launch_iterate_t(const DevBatch<real> & b, size_t lds, hipStream_t stream, int variant)
 {
-   if ((variant & 48) == 48)      // phase_cost KIND 3: a fixed-base chain with placed spheres, one field with the world's axes
+   if (variant & 16)      // phase_cost KIND: a chain with placed spheres (16), one field with the world's axes (32), floating base (64)
    {
-      if (variant & 8) return launch_iterate_tt<real, false, true, 512, 3>(b, lds, stream);
-      if (variant & 4) return launch_iterate_tt<real, false, true, 192, 3>(b, lds, stream);
-      return launch_iterate_tt<real, false, true, 256, 3>(b, lds, stream);
-   }
-   if (variant & 16)              // KIND 1
-   {
-      if (variant & 8) return launch_iterate_tt<real, false, true, 512, 1>(b, lds, stream);
-      if (variant & 4) return launch_iterate_tt<real, false, true, 192, 1>(b, lds, stream);
-      return launch_iterate_tt<real, false, true, 256, 1>(b, lds, stream);
+      const int kind = 1 | ((variant & 32) ? 2 : 0) | ((variant & 64) ? 4 : 0);
+#define ORC_KIND_CASE(K) case K: \
+         if (variant & 8) return launch_iterate_tt<real, false, true, 512, K>(b, lds, stream); \
+         if (variant & 4) return launch_iterate_tt<real, false, true, 192, K>(b, lds, stream); \
+         return launch_iterate_tt<real, false, true, 256, K>(b, lds, stream);
+      switch (kind)
+      {
+      ORC_KIND_CASE(1) ORC_KIND_CASE(3) ORC_KIND_CASE(5) ORC_KIND_CASE(7)
+      }
+#undef ORC_KIND_CASE
    }
    if (variant & 8)
       switch (variant & 3)
