@@ -534,16 +534,23 @@ void BatchShard::build_device(const Robot & robot)
    // are placed on the 16 lanes such that the pairs that are usually in range share few distances
    // (place_spheres_on_row).  Everything indexed by lane (pos, radius, link, affects) is in slot
    // order; FK and the J^T ranges keep the order sorted by joint and go through slot_of.
-   std::vector<int> slot_of(Sa);
-   for (int s=0; s<Sa; s++) slot_of[s] = s;
+   // Inactive spheres on free lanes of the row (DevModel::static_*): as many as fit, in XML order; the rest
+   // stay in the loop over inactive spheres.  (The J^T code drops a static lane's force with the lanes past
+   // the active spheres of the placed, scanned layout: only then.)
+   int n_static = 0;
+   if (M.GS == 16 && Sa >= 4 && M.jt_scan != 0 && !getenv("ORC_NO_PLACEMENT") && !getenv("ORC_NO_STATIC_LANES"))
+      n_static = std::min((int) inact.size(), 16 - Sa);
+   std::vector<int> slot_of(Sa + n_static);
+   for (int s=0; s<Sa+n_static; s++) slot_of[s] = s;
    int lanes = Sa;
    bool is_placed = false;
    if (M.GS == 16 && Sa >= 4 && !getenv("ORC_NO_PLACEMENT"))
    {
-      std::vector<int> xml_of(Sa);
+      std::vector<int> xml_of(Sa + n_static);
       for (int s=0; s<Sa; s++) xml_of[s] = act[s].xml;
+      for (int s=0; s<n_static; s++) xml_of[Sa + s] = inact[s].xml;
       // the key holds everything the placement is a function of (the frozen dofs by their bit patterns)
-      std::string key = robot.name + (params.floating_base ? "|f|" : "|a|") + std::to_string(params.epsilon_self);
+      std::string key = robot.name + (params.floating_base ? "|f|" : "|a|") + std::to_string(params.epsilon_self) + "|s" + std::to_string(n_static);
       for (int d : robot.active_dofs) key += "," + std::to_string(d);
       key += "|";
       for (int d=0; d<robot.n_dof; d++)
@@ -555,12 +562,12 @@ void BatchShard::build_device(const Robot & robot)
          key += std::to_string(bits) + ",";
       }
       auto hit = mod_->placement_cache.find(key);
-      if (hit == mod_->placement_cache.end() || (int) hit->second.size() != Sa)
+      if (hit == mod_->placement_cache.end() || (int) hit->second.size() != Sa + n_static)
          hit = mod_->placement_cache.insert_or_assign(key, place_spheres_on_row(robot, params.epsilon_self, xml_of)).first;
       const std::vector<int> & placed = hit->second;
       bool ident = true;
-      for (int s=0; s<Sa; s++) if (placed[s] != s) ident = false;
-      if (!ident) { slot_of = placed; lanes = 16; is_placed = true; }
+      for (int s=0; s<Sa+n_static; s++) if (placed[s] != s) ident = false;
+      if (!ident || n_static > 0) { slot_of = placed; lanes = 16; is_placed = true; }
    }
    {
       std::vector<real> rad(Sa); std::vector<int> link(Sa); std::vector<unsigned long long> aff(Sa);
@@ -574,7 +581,9 @@ void BatchShard::build_device(const Robot & robot)
          M.live_mask |= (1ull << q);
       }
    }
-   M.Sa_real = Sa; M.Sa = lanes; M.S = lanes + (int) inact.size();
+   if (!is_placed) n_static = 0;
+   M.n_static = n_static; M.static_mask = 0ull;
+   M.Sa_real = Sa; M.Sa = lanes; M.S = lanes + (int) inact.size() - n_static;
    slot_xml.assign(lanes, -1);
    for (int s=0; s<Sa; s++) slot_xml[slot_of[s]] = act[s].xml;
    Sa_real_ = Sa;
@@ -584,12 +593,23 @@ void BatchShard::build_device(const Robot & robot)
       const Xform & lf = frames[sp.link];
       double pw[3];
       mat3_vec(lf.R, sp.pos, pw);                                    // mod.cpp:2332-2345
-      for (int q=0; q<3; q++) M.sph_inactive_pos[s][q] = (real)(pw[q] + lf.t[q]);
-      M.sph_radius[lanes+s] = (real) sp.radius;
-      M.sph_link[lanes+s] = sp.link;
+      if (s < n_static)
+      {
+         const int q = slot_of[Sa + s];
+         M.static_slot[s] = q; M.static_mask |= (1ull << q);
+         for (int k=0; k<3; k++) M.static_pos[s][k] = (real)(pw[k] + lf.t[k]);
+         M.sph_radius[q] = (real) sp.radius; M.sph_link[q] = sp.link; M.sph_affects[q] = 0ull;
+      }
+      else
+      {
+         const int r = s - n_static;
+         for (int q=0; q<3; q++) M.sph_inactive_pos[r][q] = (real)(pw[q] + lf.t[q]);
+         M.sph_radius[lanes+r] = (real) sp.radius;
+         M.sph_link[lanes+r] = sp.link;
+      }
       device_sphere_order.push_back(inact[s].xml);
    }
-   nj_ = nj; Sa_ = lanes; S_ = lanes + (int) inact.size(); GS_ = M.GS; tree_ = M.tree | ((M.GS == 16) ? 2 : 0);     // kernel variant bits
+   nj_ = nj; Sa_ = lanes; S_ = lanes + (int) inact.size() - n_static; GS_ = M.GS; tree_ = M.tree | ((M.GS == 16) ? 2 : 0);     // kernel variant bits
    if (M.GS == 16 && !M.tree && M.jt_scan == 1 && M.placed && !getenv("ORC_NO_KIND"))
       tree_ |= 16 | (M.floating ? 64 : 0);      // the variants that know all this at compile time (chomp_kernel.hip phase_cost KIND)
 
@@ -658,8 +678,8 @@ void BatchShard::build_device(const Robot & robot)
    }
 
    ms_.nj = M.nj; ms_.floating = M.floating; ms_.tree = M.tree; ms_.Sa = M.Sa; ms_.S = M.S; ms_.Sa_real = M.Sa_real; ms_.placed = M.placed;
-   ms_.GS = M.GS; ms_.base_sph_begin = M.base_sph_begin; ms_.base_sph_end = M.base_sph_end; ms_.jt_scan = M.jt_scan; ms_.pad_ = 0;
-   ms_.live_mask = M.live_mask;
+   ms_.GS = M.GS; ms_.base_sph_begin = M.base_sph_begin; ms_.base_sph_end = M.base_sph_end; ms_.jt_scan = M.jt_scan; ms_.n_static = M.n_static;
+   ms_.live_mask = M.live_mask; ms_.static_mask = M.static_mask;
    DevModel<real> * dm = dev_alloc<DevModel<real>>(1);
    hip_check(hipMemcpyAsync(dm, &M, sizeof(M), hipMemcpyHostToDevice, st), "model");
    hip_check(hipStreamSynchronize(st), "model sync");

@@ -956,6 +956,9 @@ __device__ __forceinline__ Env<real> make_env(const BT & b, unsigned char * smem
    mod.sph_pos_c = (const __attribute__((address_space(4))) real (*)[3]) b.model->sph_pos;
    mod.joints_c = (const __attribute__((address_space(4))) DevJoint<real> *) b.model->joints;
    mod.slot_c = (const __attribute__((address_space(4))) int *) b.model->slot_of;
+   mod.n_static = b.ms.n_static;
+   mod.static_slot_c = (const __attribute__((address_space(4))) int *) b.model->static_slot;
+   mod.static_pos_c = (const __attribute__((address_space(4))) real (*)[3]) b.model->static_pos;
    E.AG_g = b.AG + (size_t) run * mn;
    // momentum: in LDS for the launch, or in place in global memory (every entry is read and written
    // by the same thread, e = tid + k BLOCK, in all loops that touch it)
@@ -1036,7 +1039,7 @@ __device__ __attribute__((noinline)) void phase_setup(const void * kp)
       // self-collision term; -1: the pair never counts (same link, or a lane without a sphere).
       // The partner's identity comes through the same DPP rotation the cost phase uses.
       const int srow = tid & 15;
-      const unsigned long long live_mask = E.mod.live_mask;
+      const unsigned long long live_mask = E.mod.live_mask | b.ms.static_mask;      // lanes that hold a sphere, static ones included
       const bool has = ((live_mask >> srow) & 1ull) != 0;
       const real rad = has ? E.srad_s[srow] : (real)0;
       const int link = has ? E.slink_s[srow] : -1 - srow;
@@ -1101,7 +1104,8 @@ __device__ __attribute__((noinline)) double phase_cost_start(const void * kp, in
 {
    KArg<real> & b = *uniform_kernarg<real>(kp);
    const bool do_iteration = uni(do_iteration_in) != 0;
-   const Env<real> E = make_env<real, GS16>(b, orc_smem);
+   Env<real> E = make_env<real, GS16>(b, orc_smem);
+   E.mod.live_mask |= b.ms.static_mask;
    const real inv_eps = (real)1 / b.epsilon, inv_eps_self = (real)1 / b.epsilon_self;
    if constexpr (GS16)
       cost_tile_gs16<real, ORC_U, BLOCK, KArg<real>, true>(b, E.mod, E.sdfs_s, 0, 1, do_iteration, E.T_s, E.Gc, E.pos_s, E.ax_s, E.srad_s, E.sinact_s, E.r2_s,
@@ -1130,6 +1134,7 @@ __device__ __attribute__((noinline)) double phase_cost(const void * kp, int ts_i
    const bool do_iteration = uni(do_iteration_in) != 0;
    Env<real> E = make_env<real, GS16>(b, orc_smem);
    if constexpr ((KIND & 1) != 0) { E.mod.floating = (KIND & 4) ? 1 : 0; E.mod.jt_scan = 1; E.mod.placed = 1; }
+   E.mod.live_mask |= b.ms.static_mask;      // the static spheres' lanes take part in the row's pairs
    const real inv_eps = (real)1 / b.epsilon, inv_eps_self = (real)1 / b.epsilon_self;
    __builtin_amdgcn_s_setprio(ORC_PRIO_COST);
    if constexpr (GS16)
@@ -1648,7 +1653,7 @@ void collision_verdict_kernel(DevVerdict<real> v)
    mod.base_sph_begin = gmod.base_sph_begin; mod.base_sph_end = gmod.base_sph_end; mod.jt_scan = 0;
    mod.Sa_real = gmod.Sa_real; mod.placed = gmod.placed; mod.live_mask = gmod.live_mask; mod.slot_of = slot_s;
    mod.base_R = base_s; mod.base_t = base_s + 9;
-   mod.jctl = jctl_s; mod.sph_pos = (const real (*)[3]) sphpos_s; mod.sph_affects = nullptr;
+   mod.jctl = jctl_s; mod.sph_pos = (const real (*)[3]) sphpos_s; mod.sph_affects = nullptr; mod.n_static = 0;
    mod.jpk = (const __attribute__((address_space(4))) int *) gmod.jpacked;
    mod.jpk2 = (const __attribute__((address_space(4))) int *) gmod.jpacked2;
    mod.sph_pos_c = (const __attribute__((address_space(4))) real (*)[3]) gmod.sph_pos;

@@ -69,6 +69,13 @@ struct DevModel
    int sph_link[ORC_MAX_SPHERES];        // robot link index (same-link test)
    unsigned long long sph_affects[ORC_MAX_SPHERES]; // bit j: joint j moves the sphere
    real sph_inactive_pos[ORC_MAX_SPHERES][3];       // world positions of inactive spheres [S-Sa]
+   // Inactive spheres carried on free lanes of the 16-lane row (cost_gs16.h): they stand still, so their own
+   // side of every pair is zero and the row rotations evaluate exactly the active sphere's side
+   // (src/orcdchomp_mod.cpp:1262-1263, 1310-1311); they do not go through the loop over inactive spheres.
+   int n_static;
+   int static_slot[16];
+   real static_pos[16][3];                          // world positions
+   unsigned long long static_mask;                  // bit s: lane/slot s holds one of them
 };
 
 // a rooted signed distance field (struct run_rsdf + struct cd_grid)
@@ -109,8 +116,8 @@ struct DevTsr
 // kernarg block so that a phase function has them after one scalar load (LdsLayout is declared below)
 struct ModelScalars
 {
-   int nj, floating, tree, Sa, S, Sa_real, placed, GS, base_sph_begin, base_sph_end, jt_scan, pad_;
-   unsigned long long live_mask;
+   int nj, floating, tree, Sa, S, Sa_real, placed, GS, base_sph_begin, base_sph_end, jt_scan, n_static;
+   unsigned long long live_mask, static_mask;
 };
 struct LdsLayout
 {
@@ -222,8 +229,8 @@ struct DevVerdict
 template <typename real>
 struct ModelView
 {
-   int nj, n, floating, tree, Sa, S, GS, base_sph_begin, base_sph_end, jt_scan, Sa_real, placed;
-   unsigned long long live_mask;
+   int nj, n, floating, tree, Sa, S, GS, base_sph_begin, base_sph_end, jt_scan, Sa_real, placed, n_static;
+   unsigned long long live_mask;           // (the cost phase adds the lanes of static spheres: DevModel::static_mask)
    const int * slot_of;                    // [Sa_real]
    const real * base_R;                    // [9]
    const real * base_t;                    // [3]
@@ -235,6 +242,8 @@ struct ModelView
    const __attribute__((address_space(4))) real (* sph_pos_c)[3];   // DevModel::sph_pos (scalar loads: the FK walk's sphere tables)
    const __attribute__((address_space(4))) int * slot_c;            // DevModel::slot_of
    const __attribute__((address_space(4))) DevJoint<real> * joints_c;   // DevModel::joints (scalar loads: the walk's fixed transforms and axes)
+   const __attribute__((address_space(4))) int * static_slot_c;         // DevModel::static_slot / static_pos (FK writes them into every row)
+   const __attribute__((address_space(4))) real (* static_pos_c)[3];
 };
 #if defined(__HIPCC__)
 __host__ __device__

@@ -220,4 +220,10 @@ __device__ __forceinline__ void fk_waypoint_triad(const ModelView<real> & mod, c
          else if (save_slot == 3) sv3 = cur;
       }
    }
+   // inactive spheres carried on free lanes of the row (DevModel::static_*): the same centre in every row
+   for (int q=0; q<mod.n_static; q++)
+   {
+      const real c0 = mod.static_pos_c[q][0], c1 = mod.static_pos_c[q][1], c2 = mod.static_pos_c[q][2];      // scalar loads
+      if (store) pos_k[mod.static_slot_c[q]*3] = (kk == 0) ? c0 : ((kk == 1) ? c1 : c2);
+   }
 }
