@@ -610,7 +610,7 @@ void BatchShard::build_device(const Robot & robot)
       device_sphere_order.push_back(inact[s].xml);
    }
    nj_ = nj; Sa_ = lanes; S_ = lanes + (int) inact.size() - n_static; GS_ = M.GS; tree_ = M.tree | ((M.GS == 16) ? 2 : 0);     // kernel variant bits
-   if (M.GS == 16 && !M.tree && M.jt_scan == 1 && M.placed && !getenv("ORC_NO_KIND"))
+   if (M.GS == 16 && !M.tree && M.jt_scan == 1 && M.placed && nj <= 16 && !getenv("ORC_NO_KIND"))
       tree_ |= 16 | (M.floating ? 64 : 0);      // the variants that know all this at compile time (chomp_kernel.hip phase_cost KIND)
 
    hipStream_t st = stream_;
@@ -737,7 +737,7 @@ void BatchShard::build_device(const Robot & robot)
    DevSdf<real> * ds = dev_alloc<DevSdf<real>>(n_sdfs_);
    hip_check(hipMemcpy(ds, hs.data(), hs.size()*sizeof(DevSdf<real>), hipMemcpyHostToDevice), "sdfs");
    d_sdfs_ = ds;
-   if ((tree_ & 16) && n_sdfs_ == 1 && hs[0].rot_identity) tree_ |= 32;      // one field with the world's axes: known at compile time (phase_cost KIND)
+   if ((tree_ & 16) && n_sdfs_ == 1 && hs[0].rot_identity) tree_ |= 32 | ((S_ == Sa_) ? 128 : 0);      // one field with the world's axes: known at compile time (phase_cost KIND)
 
    // metric tables
    d_Aband_ = upload<real>(metric_.Aband, st);

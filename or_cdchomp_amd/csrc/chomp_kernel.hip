@@ -1119,13 +1119,14 @@ __device__ __attribute__((noinline)) double phase_cost_start(const void * kp, in
 
 // ---- cost phase of one tile: lane = (waypoint, sphere) (sphere_cost, src/orcdchomp_mod.cpp:1134-1327) ----
 // KIND: what the kernel variant knows about the workload at compile time (bits; 0 = nothing).
-//   1  a chain whose spheres are placed on the row (DevModel::jt_scan == 1, placed == 1: the WAM of the
-//      BASELINE configurations), with a fixed base unless bit 4 says it floats: the J^T code has one form
-//      instead of a branch over five
+//   1  a chain of at most 16 joints whose spheres are placed on the row (DevModel::jt_scan == 1, placed == 1:
+//      the WAM of the BASELINE configurations), with a fixed base unless bit 4 says it floats: the J^T code
+//      has one form instead of a branch over five, and one lane group finishes all joints
 //   2  one signed distance field whose axes are the world's (a kinbody that is only translated): no loop
 //      over fields, no best-of-N bookkeeping across it, no rotation of point and gradient
+//   8  (with 1 and 2) no inactive sphere is left for the loop over them
 // The pass has no register to spare, so what it need not keep alive is time: 122.4 -> 117.3 ms for 16 384
-// WAM runs with bit 1, -> 112.2 ms with both (instantiated: 0, 1, 3, and 5, 7 for the floating base).
+// WAM runs with bit 1, -> 112.2 ms with both (instantiated: 0, 1, 3, 11, and 5, 7, 15 for the floating base).
 template <typename real, bool TREE, bool GS16, int BLOCK, int KIND = 0>
 __device__ __attribute__((noinline)) double phase_cost(const void * kp, int ts_in, int te_in, int do_iteration_in, double cost_lane)
 {
@@ -1138,7 +1139,7 @@ __device__ __attribute__((noinline)) double phase_cost(const void * kp, int ts_i
    const real inv_eps = (real)1 / b.epsilon, inv_eps_self = (real)1 / b.epsilon_self;
    __builtin_amdgcn_s_setprio(ORC_PRIO_COST);
    if constexpr (GS16)
-      cost_tile_gs16<real, ORC_U, BLOCK, KArg<real>, false, (KIND & 2) != 0>(b, E.mod, E.sdfs_s, ts, te, do_iteration, E.T_s, E.Gc, E.pos_s, E.ax_s, E.srad_s, E.sinact_s, E.r2_s,
+      cost_tile_gs16<real, ORC_U, BLOCK, KArg<real>, false, (KIND & 2) != 0, (KIND & 1) != 0, (KIND & 8) != 0>(b, E.mod, E.sdfs_s, ts, te, do_iteration, E.T_s, E.Gc, E.pos_s, E.ax_s, E.srad_s, E.sinact_s, E.r2_s,
                                          E.slink_s, E.jtype_s, E.jcol_s, inv_eps, inv_eps_self, cost_lane);
    else
       cost_tile_generic<real, BLOCK>(b, E.mod, E.sdfs_s, ts, te, do_iteration, E.T_s, E.Gc, E.pos_s, E.ax_s, E.srad_s, E.sinact_s,
@@ -1759,20 +1760,21 @@ static hipError_t launch_iterate_tt(const DevBatch<real> & b, size_t lds, hipStr
 // phase), bit 2 workgroups of 192 threads (three wavefronts, four workgroups per CU) instead of 256,
 // bit 3 workgroups of 512 threads (eight wavefronts, one workgroup per CU: the latency shape),
 // bit 4 the robot is a fixed-base chain with its spheres placed on the row (with bit 1, without bit 0),
-// bit 5 (with bit 4) there is one field and its axes are the world's, bit 6 (with bit 4) the base floats
+// bit 5 (with bit 4) there is one field and its axes are the world's, bit 6 (with bit 4) the base floats,
+// bit 7 (with bits 4 and 5) no inactive sphere is left for the loop over them
 template <typename real>
 static hipError_t launch_iterate_t(const DevBatch<real> & b, size_t lds, hipStream_t stream, int variant)
 {
    if (variant & 16)      // phase_cost KIND: a chain with placed spheres (16), one field with the world's axes (32), floating base (64)
    {
-      const int kind = 1 | ((variant & 32) ? 2 : 0) | ((variant & 64) ? 4 : 0);
+      const int kind = 1 | ((variant & 32) ? 2 : 0) | ((variant & 64) ? 4 : 0) | (((variant & 160) == 160) ? 8 : 0);
 #define ORC_KIND_CASE(K) case K: \
          if (variant & 8) return launch_iterate_tt<real, false, true, 512, K>(b, lds, stream); \
          if (variant & 4) return launch_iterate_tt<real, false, true, 192, K>(b, lds, stream); \
          return launch_iterate_tt<real, false, true, 256, K>(b, lds, stream);
       switch (kind)
       {
-      ORC_KIND_CASE(1) ORC_KIND_CASE(3) ORC_KIND_CASE(5) ORC_KIND_CASE(7)
+      ORC_KIND_CASE(1) ORC_KIND_CASE(3) ORC_KIND_CASE(5) ORC_KIND_CASE(7) ORC_KIND_CASE(11) ORC_KIND_CASE(15)
       }
 #undef ORC_KIND_CASE
    }

@@ -191,7 +191,9 @@ __device__ __forceinline__ void self_sym_step16(const real * prow, const real * 
 // gradient row and adds its cost.  (Any trace of the case inside the regular pass -- a never-taken branch, one
 // more comparison -- cost 1 % of config 2's throughput: the pass has no register to spare.)
 // ONEF: there is one field and its axes are the world's (DevSdf::rot_identity), known at compile time.
-template <typename real, int U, int BLOCK, typename BT, bool START = false, bool ONEF = false>
+// NJ16: the robot has at most 16 joints (one lane group finishes them all), known at compile time.
+// NOINACT: no inactive sphere is left for the loop over them (none, or all on free lanes of the row).
+template <typename real, int U, int BLOCK, typename BT, bool START = false, bool ONEF = false, bool NJ16 = false, bool NOINACT = false>
 __device__ __forceinline__ void cost_tile_gs16(const BT & b, const ModelView<real> & mod,
    const DevSdf<real> * sdfs, int ts, int te, bool do_iteration, const real * T_s, real * G_s, const real * pos_s, const real * ax_s,
    const real * srad_s, const real * sinact_s, const real * r2_s, const int * slink_s, const int * jtype_s, const int * jcol_s,
@@ -345,7 +347,7 @@ __device__ __forceinline__ void cost_tile_gs16(const BT & b, const ModelView<rea
 
       ORC_CMARK(1);
       // ---- self collision (src/orcdchomp_mod.cpp:1251-1317) ----
-      for (int o=Sa; o<S; o++)                 // inactive spheres have no lane: only this lane's side
+      for (int o=Sa; o<(NOINACT ? Sa : S); o++)                 // inactive spheres have no lane: only this lane's side
       {
          const real * po = sinact_s + (o - Sa)*3;
          const real ro = srad_s[o];
@@ -459,7 +461,7 @@ __device__ __forceinline__ void cost_tile_gs16(const BT & b, const ModelView<rea
                   v += dpp_move<0x108>(v);       // row_shl:8
                   w6[u][k] = v;                  // sum over the spheres s .. 15 of this waypoint
                }
-            for (int j0=0; j0<nj; j0+=16)
+            for (int j0=0; j0<(NJ16 ? 1 : nj); j0+=16)
             {
                const int j = j0 + s;
                const bool jok = (j < nj);
