@@ -1127,12 +1127,13 @@ __device__ __attribute__((noinline)) double phase_cost_start(const void * kp, in
 //   8  (with 1 and 2) no inactive sphere is left for the loop over them
 // The pass has no register to spare, so what it need not keep alive is time: 122.4 -> 117.3 ms for 16 384
 // WAM runs with bit 1, -> 112.2 ms with both (instantiated: 0, 1, 3, 11, and 5, 7, 15 for the floating base).
-template <typename real, bool TREE, bool GS16, int BLOCK, int KIND = 0>
-__device__ __attribute__((noinline)) double phase_cost(const void * kp, int ts_in, int te_in, int do_iteration_in, double cost_lane)
+// ITER: the pass belongs to an iteration (forces and gradient rows), or is the cost-only pass that ends a call.
+template <typename real, bool TREE, bool GS16, int BLOCK, int KIND = 0, bool ITER = true>
+__device__ __attribute__((noinline)) double phase_cost(const void * kp, int ts_in, int te_in, double cost_lane)
 {
    KArg<real> & b = *uniform_kernarg<real>(kp);
    const int ts = uni(ts_in), te = uni(te_in);
-   const bool do_iteration = uni(do_iteration_in) != 0;
+   const bool do_iteration = ITER;
    Env<real> E = make_env<real, GS16>(b, orc_smem);
    if constexpr ((KIND & 1) != 0) { E.mod.floating = (KIND & 4) ? 1 : 0; E.mod.jt_scan = 1; E.mod.placed = 1; }
    E.mod.live_mask |= b.ms.static_mask;      // the static spheres' lanes take part in the row's pairs
@@ -1557,7 +1558,8 @@ void chomp_iterate_kernel(const DevBatch<real> b)
 #endif
 #endif
 #ifndef ORC_ABLATE_COST
-         cost_lane = phase_cost<real, TREE, GS16, BLOCK, KIND>(kp, ts, te, do_iteration ? 1 : 0, cost_lane);
+         cost_lane = do_iteration ? phase_cost<real, TREE, GS16, BLOCK, KIND, true>(kp, ts, te, cost_lane)
+                                  : phase_cost<real, TREE, GS16, BLOCK, KIND, false>(kp, ts, te, cost_lane);
          if (tk == 0 && b.free_start) cost_lane = phase_cost_start<real, TREE, GS16, BLOCK>(kp, do_iteration ? 1 : 0, cost_lane);
 #endif
       } // tiles
