@@ -107,11 +107,12 @@ __device__ __forceinline__ void fk_joint_row(const ModelView<real> & mod, const 
 #ifndef ORC_ABLATE_FKSPH
    // The spheres riding on the joint's link.  Their table entries (centre in the link frame, slot of
    // the position buffer) are the same for every lane: they come by scalar loads from the model in
-   // global memory, four spheres per batch (entries past the link's last sphere are read -- the tables
-   // are padded -- and not stored), and enter the products as scalar operands.
+   // global memory, four spheres per batch and the rest one at a time, and enter the products as scalar
+   // operands.
    if (store)
    {
-      for (int s0=s_begin; s0<s_end; s0+=4)
+      int s0 = s_begin;
+      for (; s0+4<=s_end; s0+=4)
       {
          real lp[4][3]; int off[4];
 #pragma unroll
@@ -122,10 +123,12 @@ __device__ __forceinline__ void fk_joint_row(const ModelView<real> & mod, const 
          }
 #pragma unroll
          for (int u=0; u<4; u++)
-         {
-            const real o = cur.r[0]*lp[u][0] + cur.r[1]*lp[u][1] + cur.r[2]*lp[u][2] + cur.t;
-            if (s0 + u < s_end) pos_k[off[u]*3] = o;
-         }
+            pos_k[off[u]*3] = cur.r[0]*lp[u][0] + cur.r[1]*lp[u][1] + cur.r[2]*lp[u][2] + cur.t;
+      }
+      for (; s0<s_end; s0++)      // what is left of the link's spheres, one at a time
+      {
+         const real l0 = mod.sph_pos_c[s0][0], l1 = mod.sph_pos_c[s0][1], l2 = mod.sph_pos_c[s0][2];
+         pos_k[mod.slot_c[s0]*3] = cur.r[0]*l0 + cur.r[1]*l1 + cur.r[2]*l2 + cur.t;
       }
    }
 #endif
