@@ -957,6 +957,7 @@ __device__ __forceinline__ Env<real> make_env(const BT & b, unsigned char * smem
    mod.joints_c = (const __attribute__((address_space(4))) DevJoint<real> *) b.model->joints;
    mod.slot_c = (const __attribute__((address_space(4))) int *) b.model->slot_of;
    mod.n_static = b.ms.n_static;
+   mod.empty_mask = b.ms.placed ? (unsigned int)(~(b.ms.live_mask | b.ms.static_mask) & 0xFFFFull) : 0u;
    mod.static_slot_c = (const __attribute__((address_space(4))) int *) b.model->static_slot;
    mod.static_pos_c = (const __attribute__((address_space(4))) real (*)[3]) b.model->static_pos;
    E.AG_g = b.AG + (size_t) run * mn;
@@ -1656,7 +1657,7 @@ void collision_verdict_kernel(DevVerdict<real> v)
    mod.base_sph_begin = gmod.base_sph_begin; mod.base_sph_end = gmod.base_sph_end; mod.jt_scan = 0;
    mod.Sa_real = gmod.Sa_real; mod.placed = gmod.placed; mod.live_mask = gmod.live_mask; mod.slot_of = slot_s;
    mod.base_R = base_s; mod.base_t = base_s + 9;
-   mod.jctl = jctl_s; mod.sph_pos = (const real (*)[3]) sphpos_s; mod.sph_affects = nullptr; mod.n_static = 0;
+   mod.jctl = jctl_s; mod.sph_pos = (const real (*)[3]) sphpos_s; mod.sph_affects = nullptr; mod.n_static = 0; mod.empty_mask = 0u;
    mod.jpk = (const __attribute__((address_space(4))) int *) gmod.jpacked;
    mod.jpk2 = (const __attribute__((address_space(4))) int *) gmod.jpacked2;
    mod.sph_pos_c = (const __attribute__((address_space(4))) real (*)[3]) gmod.sph_pos;

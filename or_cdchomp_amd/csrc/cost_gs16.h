@@ -128,7 +128,7 @@ __device__ __forceinline__ void sdf_combine(const DevSdf<real> & f, const SdfCel
 // Must be executed by all lanes of the wave (DPP sources must be live lanes).
 // flags: bit 0 live, bit 1 moving.  The obstacle cost of both sides is summed where it is
 // computed (the per-run cost is a sum over all lanes anyway).
-template <typename real, int K>
+template <typename real, int K, bool FULL16 = false>
 __device__ __forceinline__ void self_sym_step16(const real * prow, const real * r2row, int srow, unsigned long long live_lanes, const real p[3],
    real radius, const real u[3], real wself, real eps_self, real inv_eps_self, bool do_iteration,
    real f[3], double & cost_sphere)
@@ -159,7 +159,9 @@ __device__ __forceinline__ void self_sym_step16(const real * prow, const real * 
    const real de = dist - eps_self;
    const real cself = (dist < (real)0) ? ((real)0.5 * eps_self - dist) : ((real)0.5 * inv_eps_self) * de * de;
    const real scale = (dist < (real)0) ? (real)(-1) : ((dist < eps_self) ? dist * inv_eps_self - (real)1 : (real)1);
-   const real sdi = scale * inv_d;
+   // FULL16 (the placed layout: the row has all 16 slots in memory and FK keeps the empty ones at zero, so every
+   // partner's numbers are finite): lanes without a pair are taken out by a zero factor instead of three selects
+   const real sdi = FULL16 ? (near ? scale * inv_d : (real)0) : scale * inv_d;
    const real wboth = wself + wo;
    const real wsum = (K == 8) ? wself : wboth;             // rotation 8: the partner adds its own side of the cost
    cost_sphere += near ? (double)(wsum * cself) : 0.0;
@@ -177,7 +179,8 @@ __device__ __forceinline__ void self_sym_step16(const real * prow, const real * 
       for (int k=0; k<3; k++)
       {
          // (selected, not multiplied by zero: lanes without a pair may hold anything, an empty slot's centre included)
-         const real inc = near ? sdi * fma(d[k], wboth, -fma(qa, u[k], qb * uo[k])) : (real)0;
+         const real val = sdi * fma(d[k], wboth, -fma(qa, u[k], qb * uo[k]));
+         const real inc = FULL16 ? val : (near ? val : (real)0);
          f[k] += (K == 8) ? inc : (inc - dpp_move<B>(inc));
       }
    }
@@ -391,7 +394,7 @@ __device__ __forceinline__ void cost_tile_gs16(const BT & b, const ModelView<rea
       {
          const unsigned long long live_lanes = __builtin_amdgcn_ballot_w64(live[u]);
          const real * prow = pos_s + l[u]*pstr;
-#define ORC_STEP(K) self_sym_step16<real, K>(prow, r2_s, s, live_lanes, p[u], radius, uvec[u], wself[u], \
+#define ORC_STEP(K) self_sym_step16<real, K, NJ16>(prow, r2_s, s, live_lanes, p[u], radius, uvec[u], wself[u], \
                        b.epsilon_self, inv_eps_self, do_iteration, f[u], cost_sphere[u])
          ORC_STEP(1); ORC_STEP(2); ORC_STEP(3); ORC_STEP(4); ORC_STEP(5); ORC_STEP(6); ORC_STEP(7); ORC_STEP(8);
 #undef ORC_STEP

@@ -230,6 +230,7 @@ template <typename real>
 struct ModelView
 {
    int nj, n, floating, tree, Sa, S, GS, base_sph_begin, base_sph_end, jt_scan, Sa_real, placed, n_static;
+   unsigned int empty_mask;                // placed row: slots without a sphere (FK keeps them at zero)
    unsigned long long live_mask;           // (the cost phase adds the lanes of static spheres: DevModel::static_mask)
    const int * slot_of;                    // [Sa_real]
    const real * base_R;                    // [9]

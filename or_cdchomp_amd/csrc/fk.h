@@ -223,6 +223,10 @@ __device__ __forceinline__ void fk_waypoint_triad(const ModelView<real> & mod, c
          else if (save_slot == 3) sv3 = cur;
       }
    }
+   // slots of the placed row that hold no sphere stay at zero (the cost phase may then multiply by what it
+   // finds there: cost_gs16.h FULL16)
+   for (unsigned int em=mod.empty_mask; em; em&=em-1u)
+      if (store) pos_k[(__builtin_ctz(em))*3] = (real)0;
    // inactive spheres carried on free lanes of the row (DevModel::static_*): the same centre in every row
    for (int q=0; q<mod.n_static; q++)
    {
