@@ -612,6 +612,8 @@ void BatchShard::build_device(const Robot & robot)
    nj_ = nj; Sa_ = lanes; S_ = lanes + (int) inact.size() - n_static; GS_ = M.GS; tree_ = M.tree | ((M.GS == 16) ? 2 : 0);     // kernel variant bits
    if (M.GS == 16 && !M.tree && M.jt_scan == 1 && M.placed && nj <= 16 && !getenv("ORC_NO_KIND"))
       tree_ |= 16 | (M.floating ? 64 : 0);      // the variants that know all this at compile time (chomp_kernel.hip phase_cost KIND)
+   if (M.GS != 16 && !M.floating && M.jt_scan == (M.tree ? 2 : 1) && !getenv("ORC_NO_KIND"))
+      tree_ |= 16;                              // many-sphere path: the J^T form is known
 
    hipStream_t st = stream_;
    // TSR hard constraints, folded onto the device's joint order (csrc/tsr.h)

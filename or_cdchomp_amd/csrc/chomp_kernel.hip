@@ -1136,7 +1136,9 @@ __device__ __attribute__((noinline)) double phase_cost(const void * kp, int ts_i
    const int ts = uni(ts_in), te = uni(te_in);
    const bool do_iteration = ITER;
    Env<real> E = make_env<real, GS16>(b, orc_smem);
-   if constexpr ((KIND & 1) != 0) { E.mod.floating = (KIND & 4) ? 1 : 0; E.mod.jt_scan = 1; E.mod.placed = 1; }
+   if constexpr (GS16 && (KIND & 1) != 0) { E.mod.floating = (KIND & 4) ? 1 : 0; E.mod.jt_scan = 1; E.mod.placed = 1; }
+   // the many-sphere path: bit 1 = a fixed base and the J^T ranges of a chain (1) or of a tree in depth-first order (2)
+   if constexpr (!GS16 && (KIND & 1) != 0) { E.mod.floating = 0; E.mod.jt_scan = TREE ? 2 : 1; }
    E.mod.live_mask |= b.ms.static_mask;      // the static spheres' lanes take part in the row's pairs
    const real inv_eps = (real)1 / b.epsilon, inv_eps_self = (real)1 / b.epsilon_self;
    __builtin_amdgcn_s_setprio(ORC_PRIO_COST);
@@ -1768,6 +1770,18 @@ static hipError_t launch_iterate_tt(const DevBatch<real> & b, size_t lds, hipStr
 template <typename real>
 static hipError_t launch_iterate_t(const DevBatch<real> & b, size_t lds, hipStream_t stream, int variant)
 {
+   if ((variant & 16) && !(variant & 2))      // the many-sphere path with its J^T form known (phase_cost KIND 1)
+   {
+      if (variant & 1)
+      {
+         if (variant & 8) return launch_iterate_tt<real, true, false, 512, 1>(b, lds, stream);
+         if (variant & 4) return launch_iterate_tt<real, true, false, 192, 1>(b, lds, stream);
+         return launch_iterate_tt<real, true, false, 256, 1>(b, lds, stream);
+      }
+      if (variant & 8) return launch_iterate_tt<real, false, false, 512, 1>(b, lds, stream);
+      if (variant & 4) return launch_iterate_tt<real, false, false, 192, 1>(b, lds, stream);
+      return launch_iterate_tt<real, false, false, 256, 1>(b, lds, stream);
+   }
    if (variant & 16)      // phase_cost KIND: a chain with placed spheres (16), one field with the world's axes (32), floating base (64)
    {
       const int kind = 1 | ((variant & 32) ? 2 : 0) | ((variant & 64) ? 4 : 0) | (((variant & 160) == 160) ? 8 : 0);
