@@ -3,6 +3,10 @@
 
   python bench.py --gpus N --steps K --warmup W [--config 2|3|4|5]
 
+With N > 1 and no WORLD_SIZE in the environment the command starts its own N ranks (`python -m
+torch.distributed.run`, a child process created before anything here touches the GPU) and exits with
+their code; under a launcher (WORLD_SIZE set) it is one of the ranks and WORLD_SIZE must equal --gpus.
+
 A *step* is one `iterate` of the hot path over one batch: n_iter=100 CHOMP iterations (costs every
 iteration, final cost pass included).  The workload:
 
@@ -11,7 +15,9 @@ iteration, final cost pass included).  The workload:
                     into contiguous blocks of 8 192 per GPU (rank r iterates block r; weak scaling in
                     N, no data-path collective); the trajectories of step 0 are gathered on the host
                     of rank 0 afterwards and that time is reported separately (`gather`)
-  --config 4 / 5    the other two single-GPU configurations as bench lines of their own
+  --config 4 / 5    the other two single-GPU configurations as bench lines of their own; the default
+                    run (N = 1, config 2) appends both as `other_configs` (5 steps each, with their own
+                    `roofline`, counter traffic and `cpu_baseline`) so that they sit under the same clock
 
 Every step works on its own freshly created batch (created before the timed region; the
 trajectories are resident in HBM when it starts).  `value` = iterations the runs actually made
@@ -151,49 +157,31 @@ class Workload:
                            O.default_params(**self.kw), N_ITER, max_threads=threads, **kw)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", type=int, default=0, help="BASELINE configuration: 2 (default at --gpus 1), 3 (default at "
-                                                          "--gpus > 1), 4 or 5")
-    ap.add_argument("--batch", type=int, default=0, help="runs per GPU (default: the configuration's own size)")
-    ap.add_argument("--streams", type=int, default=2,
-                    help="HIP streams the steps are issued on round-robin: consecutive steps are independent batches, "
-                         "so the tail of one launch (a few slow runs) is filled by the next; 1 = strictly serial launches")
-    ap.add_argument("--serial-steps", type=int, default=-1, help="steps of the strictly serial leg (value_serial); default min(steps, 10)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-runs", type=int, default=0, help="override the cpu baseline sample size")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for a "
-                                                      "single-GPU rehearsal of the multi-rank path)")
-    args = ap.parse_args()
+def free_port():
+    import socket
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    return port
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
-    config = args.config or (2 if world == 1 else 3)
 
+def launch_ranks(args, argv):
+    """`bench.py --gpus N` outside a launcher: start the N ranks as a CHILD process (torch.distributed.run,
+    one rank per GPU, rendezvous on 127.0.0.1) before this process has touched the GPU, and exit with its code."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // args.gpus)))
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def run_workload(config, args, rank, world, device, dist, steps, warmup, serial_steps, batch=0, want_gather=True):
+    """one bench line: K steps of one BASELINE configuration on this rank's GPU; returns (line or None, exit code)"""
     import torch
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    device = local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(device)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
-        else:
-            dist.init_process_group(backend=args.backend)
-
     import or_cdchomp_amd
     from or_cdchomp_amd import sharding
 
-    wl = Workload(config, rank, world, args.batch)
+    wl = Workload(config, rank, world, batch)
     mod = or_cdchomp_amd.Module(device)
     wl.setup(mod)
     n_runs = wl.n_runs
@@ -228,24 +216,24 @@ def main():
         elapsed = sharding.max_over_ranks(t1 - t0, dist)
         iters = [mod.batch_iterations_done(bid) for bid in timed]
         kernel_ms, launches = mod.kernel_time()
-        return dict(elapsed=elapsed, iters=iters, ids=timed, results=results, kernel_ms=kernel_ms, launches=launches)
+        return dict(elapsed=elapsed, own_elapsed=t1 - t0, iters=iters, ids=timed, results=results, kernel_ms=kernel_ms, launches=launches)
 
     # ---- strictly serial launches on one stream (reported beside the headline) --------------------
-    serial_steps = args.serial_steps if args.serial_steps >= 0 else min(args.steps, 10)
     serial = None
     if serial_steps > 0 and args.streams > 1:
-        serial = timed_leg(serial_steps, min(args.warmup, 2), 1)
+        serial = timed_leg(serial_steps, min(warmup, 2), 1)
         for bid in serial["ids"]:
             mod.batch_destroy(bid)
 
     # ---- the headline leg ----------------------------------------------------------------------------
-    main_leg = timed_leg(args.steps, args.warmup, args.streams)
+    main_leg = timed_leg(steps, warmup, args.streams)
     timed = main_leg["ids"]
     elapsed = main_leg["elapsed"]
 
     # iterations actually made, all ranks (host-side gather, gloo; no RCCL data path)
     local = {"status": np.concatenate([st for _, st in main_leg["results"]]),
-             "iters": np.concatenate(main_leg["iters"]).astype(np.int64)}
+             "iters": np.concatenate(main_leg["iters"]).astype(np.int64),
+             "rank_elapsed": np.asarray([main_leg["own_elapsed"]])}
     if serial is not None:
         local["iters_serial"] = np.concatenate(serial["iters"]).astype(np.int64)
     hg = sharding.host_group(dist)
@@ -253,7 +241,7 @@ def main():
 
     # ---- N > 1: the host-side gather of the trajectories of step 0, timed on its own -----
     gather = None
-    if world > 1:
+    if world > 1 and want_gather:
         barrier()
         g0 = time.perf_counter()
         traj_local = mod.batch_gettraj(timed[0])                         # device -> host of this rank
@@ -267,6 +255,8 @@ def main():
                       "device_to_host_s": d2h, "total_s": tot,
                       "note": "trajectories [runs][n_points][n] of step 0: hipMemcpy per rank, then a gloo gather_object on "
                               "rank 0; outside the timed region, reported separately"}
+            if args.dump_gather:
+                np.save(args.dump_gather, allt["traj"])
 
     # ---- parity spot check against the oracle on the first timed batch (untimed) ---------------------
     parity = None
@@ -324,20 +314,26 @@ def main():
                              "sphere cost, dense A^-1 as the reference, fp64), OpenMP over runs, %.1f s wall"
                              % (len(sidx), n_runs, N_ITER, c1 - c0)}
 
+    out = None
     if rank == 0:
         made = float(whole["iters"].sum())
-        nominal = float(world) * n_runs * N_ITER * args.steps
+        nominal = float(world) * n_runs * N_ITER * steps
         value = made / elapsed
         avg_ms = main_leg["kernel_ms"] / max(main_leg["launches"], 1)
         bytes_iter = wl.bytes_iter
         bytes_launch = bytes_iter * (float(main_leg["iters"][0].sum()) if main_leg["iters"] else 0.0)   # what launch 0 really made
         bytes_launch_nominal = bytes_iter * n_runs * N_ITER
-        achieved = bytes_iter * (made / world / args.steps) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        achieved = bytes_iter * (made / world / steps) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         value_serial = None
         serial_ms = None
         if serial is not None:
             value_serial = float(whole["iters_serial"].sum()) / serial["elapsed"]
             serial_ms = serial["kernel_ms"] / max(serial["launches"], 1)
+        per_rank = None
+        if world > 1:
+            per = whole["iters"].reshape(world, -1).sum(axis=1)
+            per_rank = [{"rank": r, "iterations_made": float(per[r]), "elapsed_s": float(whole["rank_elapsed"][r]),
+                         "value": float(per[r] / whole["rank_elapsed"][r])} for r in range(world)]
         # counters of profiles/ (rocprofv3 --pmc passes of this command, scripts/pmc_counters.sh)
         traffic = None
         valu = None
@@ -364,9 +360,9 @@ def main():
             "value": value,
             "unit": "CHOMP iterations/s",
             "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "steps": steps,
+            "warmup": warmup,
+            "ms_per_step": elapsed / steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -377,6 +373,7 @@ def main():
             "iterations_made": made, "iterations_nominal": nominal,
             "runs_outside_joint_limits": int((whole["status"] != 0).sum()),
             "runs_total": int(whole["status"].size),
+            "per_rank": per_rank,
             "value_serial": value_serial,
             "value_serial_note": None if serial is None else
                 "%d steps, strictly serial launches on one stream, avg kernel %.2f ms%s" % (serial_steps, serial_ms,
@@ -387,6 +384,9 @@ def main():
                                       "(the contract's figure); `bound` names what the counters say binds the kernel",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         # what the memory system really moved: counter bytes per launch / launch duration vs the peak
+                         # (well above `frac`: the kernel re-reads or spills; below: the state stays on chip)
+                         "hbm_measured_frac": None if not (traffic and avg_ms > 0) else traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                          "kernel": wl.kernel, "avg_kernel_ms": avg_ms, "launches": main_leg["launches"],
                          "concurrent_launches": max(1, args.streams),
                          "serial_avg_kernel_ms": serial_ms,
@@ -408,6 +408,72 @@ def main():
             out["roofline"]["fp64_vector"] = {"achieved": value * flop / 1e12 / world, "peak": FP64_VECTOR_PEAK_TFLOPS,
                                               "unit": "TFLOP/s", "frac": value * flop / 1e12 / world / FP64_VECTOR_PEAK_TFLOPS,
                                               "algorithmic_flop_per_iteration_per_run": flop}
+    for bid in timed:
+        mod.batch_destroy(bid)
+    mod.close()
+    return out, rc
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=0, help="BASELINE configuration: 2 (default at --gpus 1), 3 (default at "
+                                                          "--gpus > 1), 4 or 5")
+    ap.add_argument("--batch", type=int, default=0, help="runs per GPU (default: the configuration's own size)")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="HIP streams the steps are issued on round-robin: consecutive steps are independent batches, "
+                         "so the tail of one launch (a few slow runs) is filled by the next; 1 = strictly serial launches")
+    ap.add_argument("--serial-steps", type=int, default=-1, help="steps of the strictly serial leg (value_serial); default min(steps, 10)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-runs", type=int, default=0, help="override the cpu baseline sample size")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for a "
+                                                      "single-GPU rehearsal of the multi-rank path)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="default run only (N = 1, config 2): do not append the config 4 and config 5 lines")
+    ap.add_argument("--other-steps", type=int, default=5, help="steps of each `other_configs` line")
+    ap.add_argument("--dump-gather", default="", help="N > 1: rank 0 saves the gathered step-0 trajectories here (.npy)")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    # `--gpus N` outside a launcher starts its own ranks; nothing above or in launch_ranks touches the GPU
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args, sys.argv[1:])
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    config = args.config or (2 if world == 1 else 3)
+
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    device = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend=args.backend)
+
+    serial_steps = args.serial_steps if args.serial_steps >= 0 else min(args.steps, 10)
+    out, rc = run_workload(config, args, rank, world, device, dist, args.steps, args.warmup, serial_steps, batch=args.batch)
+    if world == 1 and not args.config and not args.batch and not args.no_other_configs:
+        # the other two single-GPU configurations under the same clock (a few steps each)
+        others = []
+        for c in (4, 5):
+            line, rc_c = run_workload(c, args, rank, world, device, dist, args.other_steps, 1, min(args.other_steps, 3))
+            others.append(line)
+            rc = rc or rc_c
+        out["other_configs"] = others
+    if rank == 0:
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

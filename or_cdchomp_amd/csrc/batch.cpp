@@ -294,13 +294,13 @@ BatchShard::~BatchShard()
 
 void BatchShard::release()
 {
-   void ** all[] = { &d_model_, &d_sdfs_, &d_traj_, &d_AG_, &d_G_, (void **) &d_mt_, (void **) &d_mt_bak_, (void **) &d_hmc_next_,
+   void ** all[] = { &d_model_, &d_sdfs_, &d_sdfc_, &d_traj_, &d_AG_, &d_G_, (void **) &d_mt_, (void **) &d_mt_bak_, (void **) &d_hmc_next_,
                      (void **) &d_hmc_next_bak_, (void **) &d_overflow_, (void **) &d_costs_, (void **) &d_trace_, (void **) &d_status_,
                      (void **) &d_iters_done_, (void **) &d_leap_, &d_Aband_, &d_beta_s_, &d_beta_g_, &d_pcr_, &d_Ainv_, &d_jl_lo_, &d_jl_hi_,
                      (void **) &d_hmc_iters_, &d_noise_, (void **) &d_phase_, &d_Gcost_, &d_tsrs_, &d_tsr_ws_, (void **) &d_tsr_err_ };
    for (void ** p : all) { dev_free(*p); *p = nullptr; }
    sdf_refs_.clear();
-   for (auto & ev : pending_events_) { mod_->event_pool(device).push_back(ev.first); mod_->event_pool(device).push_back(ev.second); }
+   for (auto & ev : pending_events_) { mod_->release_event(device, ev.first); mod_->release_event(device, ev.second); }
    pending_events_.clear();
 }
 
@@ -315,10 +315,9 @@ void BatchShard::harvest_events(bool wait)
       hip_check(hipEventSynchronize(ev.second), "hipEventSynchronize");
       float ms = 0.f;
       hip_check(hipEventElapsedTime(&ms, ev.first, ev.second), "hipEventElapsedTime");
-      mod_->kernel_ms_total += ms;
-      mod_->kernel_launches++;
-      mod_->event_pool(device).push_back(ev.first);
-      mod_->event_pool(device).push_back(ev.second);
+      mod_->add_kernel_time(ms);
+      mod_->release_event(device, ev.first);
+      mod_->release_event(device, ev.second);
    }
    pending_events_.resize(kept);
 }
@@ -691,6 +690,7 @@ void BatchShard::build_device(const Robot & robot)
    n_sdfs_ = (int) mod_->sdfs.size();
    if (n_sdfs_ > ORC_MAX_SDFS) throw std::runtime_error("too many signed distance fields for this build!");
    std::vector<DevSdf<real>> hs(n_sdfs_);
+   std::vector<DevSdfCell<real>> hc(n_sdfs_);
    for (int i=0; i<n_sdfs_; i++)
    {
       Sdf & s = *mod_->sdfs[i];
@@ -735,7 +735,27 @@ void BatchShard::build_device(const Robot & robot)
          hs[i].cell[q] = (real)(s.grid.lengths[q] / s.grid.sizes[q]);
          hs[i].size_over_len[q] = (real)(s.grid.sizes[q] / s.grid.lengths[q]);
       }
+      // the field in cell units (DevSdfCell), folded in double precision
+      for (int r=0; r<3; r++)
+      {
+         const double sol = s.grid.sizes[r] / s.grid.lengths[r];
+         for (int c=0; c<3; c++)
+         {
+            hc[i].M[r*3+c] = (real)(sol * Rgw.m[r*3+c]);
+            hc[i].W[c*3+r] = (real)(Rwg.m[c*3+r] * sol);
+         }
+         hc[i].t[r] = (real)(sol * pose_gsdf_world.v[r]);
+         hc[i].fsize[r] = (real) s.grid.sizes[r];
+         hc[i].fsize_m1[r] = (real)(s.grid.sizes[r] - 1);
+      }
+      hc[i].stride_b[0] = s.grid.sizes[1] * s.grid.sizes[2] * (int) sizeof(real);
+      hc[i].stride_b[1] = s.grid.sizes[2] * (int) sizeof(real);
+      hc[i].data = hs[i].data;
+      if (nc * sizeof(real) >= (size_t) 1 << 31) throw std::runtime_error("signed distance field too large for this build!");
    }
+   DevSdfCell<real> * dc = dev_alloc<DevSdfCell<real>>(n_sdfs_);
+   hip_check(hipMemcpy(dc, hc.data(), hc.size()*sizeof(DevSdfCell<real>), hipMemcpyHostToDevice), "sdfs (cell units)");
+   d_sdfc_ = dc;
    DevSdf<real> * ds = dev_alloc<DevSdf<real>>(n_sdfs_);
    hip_check(hipMemcpy(ds, hs.data(), hs.size()*sizeof(DevSdf<real>), hipMemcpyHostToDevice), "sdfs");
    d_sdfs_ = ds;
@@ -1046,6 +1066,7 @@ void BatchShard::launch(int n_iter, bool final_eval)
    std::memset(&b, 0, sizeof(b));
    b.model = (const DevModel<real> *) d_model_;
    b.sdfs = (const DevSdf<real> *) d_sdfs_;
+   b.sdfc = (const DevSdfCell<real> *) d_sdfc_;
    b.n_sdfs = n_sdfs_;
    b.n_runs = n_runs; b.n_points = m + 2; b.np_global = n_points; b.free_start = params.free_start; b.m = m; b.n = n;
    if (params.free_start && tile_first_ < 2)
@@ -1106,13 +1127,7 @@ void BatchShard::launch(int n_iter, bool final_eval)
       d_Gcost_ = dev_alloc<real>((size_t) n_runs * m * n);
       b.Gcost = (real *) d_Gcost_;
    }
-   std::vector<hipEvent_t> & pool = mod_->event_pool(device);
-   hipEvent_t ev[2];
-   for (int k=0; k<2; k++)
-   {
-      if (!pool.empty()) { ev[k] = pool.back(); pool.pop_back(); }
-      else hip_check(hipEventCreate(&ev[k]), "hipEventCreate");
-   }
+   hipEvent_t ev[2] = { mod_->acquire_event(device), mod_->acquire_event(device) };
    hip_check(hipEventRecord(ev[0], stream_), "hipEventRecord");
    hipError_t e = launch_typed(b, lds_bytes_, stream_, tree_ | (block_ == 192 ? 4 : 0) | (block_ == 512 ? 8 : 0));
    hip_check(e, "chomp_iterate_kernel launch");

@@ -850,6 +850,12 @@ __device__ __forceinline__ real smooth_grad(const BT & b, const real * T_s, int 
    return s;
 }
 
+// 1: the many-sphere cost pass of an iteration is part of the kernel function itself (see the kernel's tile loop);
+// 2: the 16-lane pass as well (no gain measured: it saves 2 callee-saved registers per call); 0: every pass is a call
+#ifndef ORC_INLINE_COST
+#define ORC_INLINE_COST 1
+#endif
+
 #ifndef ORC_U
 #define ORC_U 1          // waypoints per lane in the 16-sphere cost phase (1: registers go to a third workgroup per CU instead)
 #endif
@@ -1130,7 +1136,7 @@ __device__ __attribute__((noinline)) double phase_cost_start(const void * kp, in
 // WAM runs with bit 1, -> 112.2 ms with both (instantiated: 0, 1, 3, 11, and 5, 7, 15 for the floating base).
 // ITER: the pass belongs to an iteration (forces and gradient rows), or is the cost-only pass that ends a call.
 template <typename real, bool TREE, bool GS16, int BLOCK, int KIND = 0, bool ITER = true>
-__device__ __attribute__((noinline)) double phase_cost(const void * kp, int ts_in, int te_in, double cost_lane)
+__device__ __forceinline__ double phase_cost_body(const void * kp, int ts_in, int te_in, double cost_lane)
 {
    KArg<real> & b = *uniform_kernarg<real>(kp);
    const int ts = uni(ts_in), te = uni(te_in);
@@ -1146,16 +1152,31 @@ __device__ __attribute__((noinline)) double phase_cost(const void * kp, int ts_i
       cost_tile_gs16<real, ORC_U, BLOCK, KArg<real>, false, (KIND & 2) != 0, (KIND & 1) != 0, (KIND & 8) != 0>(b, E.mod, E.sdfs_s, ts, te, do_iteration, E.T_s, E.Gc, E.pos_s, E.ax_s, E.srad_s, E.sinact_s, E.r2_s,
                                          E.slink_s, E.jtype_s, E.jcol_s, inv_eps, inv_eps_self, cost_lane);
    else
+   {
+#ifdef ORC_COST_TIMERS
+      long long * gdbg = (blockIdx.x == 0 && threadIdx.x == 0) ? orc_cost_dbg : nullptr;
+#else
+      long long * gdbg = nullptr;
+#endif
       cost_tile_generic<real, BLOCK>(b, E.mod, E.sdfs_s, ts, te, do_iteration, E.T_s, E.Gc, E.pos_s, E.ax_s, E.srad_s, E.sinact_s,
-                                     E.slink_s, E.jtype_s, E.jcol_s, E.pstr, E.astr, inv_eps, inv_eps_self, cost_lane, nullptr);
+                                     E.slink_s, E.jtype_s, E.jcol_s, E.pstr, E.astr, inv_eps, inv_eps_self, cost_lane, gdbg);
+   }
    __syncthreads();
 #ifdef ORC_COST_TIMERS
+   if constexpr (!GS16) if (threadIdx.x == 0 && blockIdx.x == 0 && ts > 0 && !do_iteration && te == b.m)
+      printf("generic cost sections (cycles of wavefront 0 of run 0, whole launch): obstacle %lld inactive+pass1 %lld pass2 %lld jt %lld | pass-2 trips %lld fields used %lld wave passes %lld\n",
+             orc_cost_dbg[0], orc_cost_dbg[1], orc_cost_dbg[2], orc_cost_dbg[3], orc_cost_dbg[4], orc_cost_dbg[5], orc_cost_dbg[6]);
    if constexpr (GS16) if (threadIdx.x == 0 && blockIdx.x == 0 && ts > 0 && !do_iteration)
       printf("cost sections (cycles of wavefront 0, whole launch): setup %lld obstacle %lld self %lld jt %lld between %lld\n",
              orc_cost_dbg[0], orc_cost_dbg[1], orc_cost_dbg[2], orc_cost_dbg[3], orc_cost_dbg[4]);
 #endif
    phase_mark<real>(b, E, 1);
    return cost_lane;
+}
+template <typename real, bool TREE, bool GS16, int BLOCK, int KIND = 0, bool ITER = true>
+__device__ __attribute__((noinline)) double phase_cost(const void * kp, int ts_in, int te_in, double cost_lane)
+{
+   return phase_cost_body<real, TREE, GS16, BLOCK, KIND, ITER>(kp, ts_in, te_in, cost_lane);
 }
 
 // ---- update phase (cd_chomp_iterate, src/libcd/chomp.c:490-655): G/m + A T + B, A^-1 G, the step,
@@ -1561,6 +1582,13 @@ void chomp_iterate_kernel(const DevBatch<real> b)
 #endif
 #endif
 #ifndef ORC_ABLATE_COST
+#if ORC_INLINE_COST
+         // the pass of an iteration inside the kernel function itself: a kernel has no callee-saved registers to
+         // preserve (as a call the many-sphere pass saved and restored 67 of them per tile and wavefront: 2 x 198 GB
+         // of scratch traffic per launch of BASELINE configs[4], most of what the HBM counters saw)
+         if (do_iteration && (!GS16 || ORC_INLINE_COST > 1)) cost_lane = phase_cost_body<real, TREE, GS16, BLOCK, KIND, true>(kp, ts, te, cost_lane);
+         else
+#endif
          cost_lane = do_iteration ? phase_cost<real, TREE, GS16, BLOCK, KIND, true>(kp, ts, te, cost_lane)
                                   : phase_cost<real, TREE, GS16, BLOCK, KIND, false>(kp, ts, te, cost_lane);
          if (tk == 0 && b.free_start) cost_lane = phase_cost_start<real, TREE, GS16, BLOCK>(kp, do_iteration ? 1 : 0, cost_lane);

@@ -86,48 +86,84 @@ __device__ __forceinline__ void cost_tile_generic(const BT & b, const ModelView<
       {
          real best = inf; bool has = false; real bgrad[3] = {0,0,0};
 #ifndef ORC_ABLATE_SDF
-         // the cell reads of up to four fields are issued before any is used (a field per trip would
-         // wait for its four reads, an L2 round trip, before the next field's addresses are formed)
+         // The fields in cell units (DevSdfCell), their descriptors by scalar loads from global memory: the
+         // constants enter the products as scalar operands (staged in LDS, as the 16-lane path has them, every one
+         // of them was a broadcast read into a vector register: ~50 per field and lane).  The cell reads of up to
+         // four fields are issued before any is used (a field per trip would wait for its four reads, an L2
+         // round trip, before the next field's addresses are formed).
+         typedef const __attribute__((address_space(4))) DevSdfCell<real> CellDesc;
+         CellDesc * fc = (CellDesc *) b.sdfc;
          for (int i0=0; i0<b.n_sdfs; i0+=4)
          {
-            SdfCells<real> cells[4];
-            real v0[4], vn[4][3];
+            real v0[4], vn[4][3], fr[4][3];
+            bool prev[4][3], inbq[4];
             bool use[4] = { false, false, false, false };              // wave-uniform: some sphere of the wavefront is inside the field
 #pragma unroll
             for (int q=0; q<4; q++)
             {
                if (i0 + q >= b.n_sdfs) continue;                       // wave-uniform
-               const DevSdf<real> & F = sdfs[i0 + q];
-               real gp[3];
-#pragma unroll
-               for (int k=0; k<3; k++)
-                  gp[k] = F.Rgw[k*3+0]*p[0] + F.Rgw[k*3+1]*p[1] + F.Rgw[k*3+2]*p[2] + F.tgw[k];
-               // a field none of the wavefront's spheres is inside of contributes nothing (the reference
-               // skips an out-of-bounds lookup, src/orcdchomp_mod.cpp:1176-1183): no cells, no reads
+               CellDesc & F = fc[i0 + q];
+               real gx[3];
                bool inb = live;
 #pragma unroll
-               for (int k=0; k<3; k++) { const real x = gp[k] * F.inv_length[k]; inb = inb && !(x < (real)0) && !(x > (real)1); }
+               for (int k=0; k<3; k++)
+               {
+                  gx[k] = F.M[k*3+0]*p[0] + F.M[k*3+1]*p[1] + F.M[k*3+2]*p[2] + F.t[k];
+                  inb = inb && !(gx[k] < (real)0) && !(gx[k] > F.fsize[k]);      // the reference's x < 0 || x > 1 (grid.c:196-199)
+               }
+               // a field none of the wavefront's spheres is inside of contributes nothing (the reference
+               // skips an out-of-bounds lookup, src/orcdchomp_mod.cpp:1176-1183): no cells, no reads
                use[q] = (__builtin_amdgcn_ballot_w64(inb) != 0ull);
                if (!use[q]) continue;
-               cells[q] = sdf_cells(F, gp);
-               v0[q] = F.data[ORC_SDF_IDX(cells[q].index)];
+               if (dbg) dbg[5]++;
+               inbq[q] = inb;
+               int off = 0;
 #pragma unroll
-               for (int k=0; k<3; k++) vn[q][k] = F.data[ORC_SDF_IDX(cells[q].nidx[k])];
+               for (int k=0; k<3; k++)
+               {
+                  const real g = inb ? gx[k] : (real)0.25;             // lanes outside read cell 0 (valid memory), results masked
+                  real fl = M<real>::floor_(g);
+                  fl = M<real>::min_(fl, F.fsize_m1[k]);               // g == size: the last cell (grid.c:203)
+                  fr[q][k] = (g - fl) - (real)0.5;                     // offset from the cell centre, in cells
+                  // one-sided difference towards the nearer neighbour, inwards at the faces (grid.c:372-389)
+                  prev[q][k] = (fl == (real)0) ? false : ((fl == F.fsize_m1[k]) ? true : (fr[q][k] < (real)0));
+                  off += (int) fl * ((k == 2) ? (int) sizeof(real) : F.stride_b[k]);
+               }
+               const char * base = (const char *) F.data;
+               v0[q] = *(const real *)(base + off);
+#pragma unroll
+               for (int k=0; k<3; k++)
+               {
+                  const int sb = (k == 2) ? (int) sizeof(real) : F.stride_b[k];
+                  vn[q][k] = *(const real *)(base + (off + (prev[q][k] ? -sb : sb)));
+               }
             }
 #pragma unroll
             for (int q=0; q<4; q++)
             {
                if (i0 + q >= b.n_sdfs || !use[q]) continue;
-               const DevSdf<real> & F = sdfs[i0 + q];
-               real gg[3], val;
-               sdf_combine(F, cells[q], v0[q], vn[q], val, gg);
-               const bool better = cells[q].inb && (val < best);       // strict <: HUGE_VAL never wins
+               CellDesc & F = fc[i0 + q];
+               bool poisoned = (v0[q] == inf);
+               real val = v0[q], df[3];
+#pragma unroll
+               for (int k=2; k>=0; k--)                                 // the reference walks the axes z, y, x
+               {
+                  poisoned = poisoned || (vn[q][k] == inf);
+                  const real dd = vn[q][k] - v0[q];
+                  df[k] = prev[q][k] ? -dd : dd;                        // after - before
+                  val += df[k] * fr[q][k];
+               }
+               val = poisoned ? inf : val;
+               const bool better = inbq[q] && (val < best);            // strict <: HUGE_VAL never wins
                best = better ? val : best;
                has = has || better;
+               // the gradient only counts within epsilon of the surface (scale == 0 beyond it, below): a field
+               // that is the nearest of no sphere of the wavefront inside that range is not rotated back
+               if (__builtin_amdgcn_ballot_w64(better && (val - radius < b.epsilon)) == 0ull) continue;
 #pragma unroll
                for (int k=0; k<3; k++)
                {
-                  const real gw = F.Rwg[k*3+0]*gg[0] + F.Rwg[k*3+1]*gg[1] + F.Rwg[k*3+2]*gg[2];      // grid -> world
+                  const real gw = F.W[k*3+0]*df[0] + F.W[k*3+1]*df[1] + F.W[k*3+2]*df[2];      // grid -> world, per metre
                   bgrad[k] = better ? gw : bgrad[k];
                }
             }
@@ -276,8 +312,10 @@ __device__ __forceinline__ void cost_tile_generic(const BT & b, const ModelView<
       ORC_GMARK(1);
       // (2) the net force of every pair in the set on this lane's sphere
       const int mflag = moving ? 1 : 0;
+      if (dbg) dbg[6]++;
       while (__ballot(near != 0ull) != 0ull)
       {
+         if (dbg) dbg[4]++;
          const bool act = near != 0ull;
          const int o = act ? __builtin_ctzll(near) : ss;                // (lanes that are done look at themselves: valid memory, masked)
          near &= near - 1ull;

@@ -94,6 +94,25 @@ struct DevSdf
    real Rwg[9];            // grid -> world rotation (pose_world_gsdf), for the gradient
 };
 
+// The same field for the many-sphere cost path (cost_generic.h), read with scalar loads: everything is
+// expressed in units of cells, so that a lookup needs no quotient and no product with a cell size.
+//   g = M p + t          grid coordinates of a world point, in cells (0 .. size)
+//   value = v0 + sum_d (after_d - before_d) (g_d - (sub_d + 0.5))
+//   world gradient = W (after - before)
+// (struct cd_grid + run_rsdf of the reference; the formulae are those of src/libcd/grid.c:331-454 with the
+// three quotients per axis folded into M, t and W on the host in double precision)
+template <typename real>
+struct DevSdfCell
+{
+   real M[9];              // diag(size/length) Rgw
+   real t[3];              // diag(size/length) tgw
+   real W[9];              // Rwg diag(size/length)
+   real fsize[3];          // size as reals
+   real fsize_m1[3];       // size - 1
+   int stride_b[2];        // byte strides of the x and y axes (z: sizeof(real))
+   const real * data;      // C order [x][y][z]
+};
+
 // a TSR hard constraint on every moving point (struct run_contsr + struct tsr of the reference,
 // src/orcdchomp_mod.cpp:873-885, src/orcdchomp_mod.h:80-87), folded onto the device's joint order
 template <typename real>
@@ -138,6 +157,7 @@ struct DevBatch
    LdsLayout lay;          // = lds_layout(...) of this launch
    const DevModel<real> * model;
    const DevSdf<real> * sdfs;
+   const DevSdfCell<real> * sdfc;      // [n_sdfs] the same fields in cell units (many-sphere cost path)
    int n_sdfs;
    int n_runs, n_points, m, n;
    int tile_m;             // moving waypoints per tile (the largest tile: what the LDS carve-up holds)

@@ -126,6 +126,31 @@ Module::~Module()
    }
 }
 
+hipEvent_t Module::acquire_event(int dev)
+{
+   {
+      std::lock_guard<std::mutex> lock(timing_mutex_);
+      std::vector<hipEvent_t> & pool = event_pool_[dev];
+      if (!pool.empty()) { hipEvent_t ev = pool.back(); pool.pop_back(); return ev; }
+   }
+   hipEvent_t ev;
+   hip_check(hipEventCreate(&ev), "hipEventCreate");
+   return ev;
+}
+
+void Module::release_event(int dev, hipEvent_t ev)
+{
+   std::lock_guard<std::mutex> lock(timing_mutex_);
+   event_pool_[dev].push_back(ev);
+}
+
+void Module::add_kernel_time(double ms)
+{
+   std::lock_guard<std::mutex> lock(timing_mutex_);
+   kernel_ms_total += ms;
+   kernel_launches++;
+}
+
 // a pool of n streams on every device of the module; live batches hold the streams they were bound
 // to, so the pool only changes while no batch exists
 void Module::set_num_streams(int n)

@@ -11,6 +11,7 @@
 #include <functional>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "dev_types.h"
@@ -160,7 +161,7 @@ private:
    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events_;
    Metric metric_;
    // device buffers (typed by params.precision)
-   void * d_model_ = nullptr; void * d_sdfs_ = nullptr;
+   void * d_model_ = nullptr; void * d_sdfs_ = nullptr; void * d_sdfc_ = nullptr;
    void * d_traj_ = nullptr; void * d_AG_ = nullptr; void * d_G_ = nullptr; void * d_Gcost_ = nullptr;
    double * d_costs_ = nullptr; double * d_trace_ = nullptr; size_t trace_cap_ = 0;
    int * d_status_ = nullptr; int * d_iters_done_ = nullptr; int * d_leap_ = nullptr; long long * d_phase_ = nullptr;
@@ -287,7 +288,11 @@ public:
    void time_collect();
    double kernel_ms_total = 0.0;
    int kernel_launches = 0;
-   std::vector<hipEvent_t> & event_pool(int device) { return event_pool_[device]; }
+   // The pool of timing events and the totals are shared by all shards, and the shards of one batch may
+   // launch from host threads of their own (Batch::for_shards): everything below takes timing_mutex_.
+   hipEvent_t acquire_event(int device);                       // a pooled event of `device`, or a new one (the device must be current)
+   void release_event(int device, hipEvent_t ev);
+   void add_kernel_time(double ms);
    std::string last_error;
    std::string last_reply;
    std::string last_collision_details;   // what the reference logs with RAVELOG_ERROR in gettraj
@@ -305,6 +310,7 @@ private:
    std::map<int, std::unique_ptr<Batch>> batches_;
    int next_batch_id_ = 1;
    std::map<int, std::vector<hipEvent_t>> event_pool_;
+   std::mutex timing_mutex_;
 };
 
 void hip_check(hipError_t e, const char * what);

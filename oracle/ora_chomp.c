@@ -176,6 +176,7 @@ int ora_chomp_alloc_constraints(ora_chomp * c)
 static int dgesv_one(int n, double * A, int * ipiv, double * b)
 {
    int i, j, k, info = 0;
+   /* dgetrf: the factors and the row interchanges only; b is not touched yet */
    for (k=0; k<n; k++)
    {
       int p = k; double big = fabs(A[(size_t) k*n+k]);
@@ -186,17 +187,25 @@ static int dgesv_one(int n, double * A, int * ipiv, double * b)
       {
          double t;
          for (j=0; j<n; j++) { t = A[(size_t) k*n+j]; A[(size_t) k*n+j] = A[(size_t) p*n+j]; A[(size_t) p*n+j] = t; }
-         t = b[k]; b[k] = b[p]; b[p] = t;
       }
       for (i=k+1; i<n; i++)
       {
          const double l = A[(size_t) i*n+k] / A[(size_t) k*n+k];
          A[(size_t) i*n+k] = l;
          for (j=k+1; j<n; j++) A[(size_t) i*n+j] -= l * A[(size_t) k*n+j];
-         b[i] -= l * b[k];
       }
    }
-   if (info) return info;        /* dgesv does not solve a singular system */
+   /* info > 0: dgesv never calls dgetrs, the right-hand side stays as it was (chomp.c:582-586 then
+    * pushes the ORIGINAL h back through A^-1 J^T) */
+   if (info) return info;
+   /* dgetrs: interchanges, forward and back substitution */
+   for (k=0; k<n; k++)                /* dlaswp: all interchanges first (the stored multipliers carry the later ones) */
+   {
+      const int p = ipiv[k];
+      if (p != k) { const double t = b[k]; b[k] = b[p]; b[p] = t; }
+   }
+   for (k=0; k<n; k++)
+      for (i=k+1; i<n; i++) b[i] -= A[(size_t) i*n+k] * b[k];
    for (k=n-1; k>=0; k--)
    {
       double sum = b[k];

@@ -1,0 +1,64 @@
+"""-m gpu: the N > 1 product path (BASELINE configs[2]) rehearsed on ONE card.
+
+`python bench.py --gpus 2` with no WORLD_SIZE in the environment must start its own two ranks (a child
+`torch.distributed.run`, created before the parent touches the GPU); each rank iterates its contiguous
+block of the 65 536-run batch of seed 20250102 (cut to --batch 512 runs per rank here), rank 0 gathers
+the step-0 trajectories on the host (gloo; no data-path collective) and prints the one JSON line.  The
+gathered trajectories must equal, bit for bit, a single-process batch of the same 1024 goals: a run's
+bits do not depend on which rank or which block it is in.  The log of the rehearsal is kept under
+profiles/ (r03_rehearsal_2ranks_gloo.json) when the test runs on the builder's GPU box.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import common
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run_bench(extra, tmp_path, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + extra
+    return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_starts_its_own_two_ranks_and_gathers(tmp_path):
+    dump = str(tmp_path / "gathered.npy")
+    r = _run_bench(["--gpus", "2", "--backend", "gloo", "--batch", "512", "--steps", "2", "--warmup", "1",
+                    "--no-cpu-baseline", "--dump-gather", dump], tmp_path)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 prints the ONE line
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak"
+    assert line["gather"]["runs"] == 1024 and line["runs_total"] == 2 * 2 * 512
+    assert len(line["per_rank"]) == 2 and all(p["value"] > 0 for p in line["per_rank"])
+    assert line["parity_rel_l2_max_vs_oracle"] is not None and line["parity_rel_l2_max_vs_oracle"] <= 1e-6
+    got = np.load(dump)
+    assert got.shape == (1024, 100, 7)
+
+    # the same 1024 runs as ONE batch in this process
+    import or_cdchomp_amd
+    mod = or_cdchomp_amd.Module(0)
+    model = common.setup_product_wam(mod)
+    goals = common.wam_goals(65536, seed=20250102)[:1024]
+    bid = mod.batch_create(model.name, goals, **common.CONFIG2_KW)
+    mod.batch_iterate(bid, 100)
+    single = mod.batch_gettraj(bid)
+    mod.batch_destroy(bid)
+    mod.close()
+    assert np.array_equal(got, single), "gathered trajectories of the two ranks differ from the single-process batch"
+
+    keep = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(keep):
+        with open(os.path.join(keep, "r03_rehearsal_2ranks_gloo.json"), "w") as f:
+            json.dump({"command": "python bench.py --gpus 2 --backend gloo --batch 512 --steps 2 --warmup 1 --no-cpu-baseline",
+                       "line": line, "gathered_equals_single_process_batch": True}, f, indent=1)

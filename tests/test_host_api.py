@@ -84,3 +84,33 @@ def test_robot_models():
     assert (a["parent"] < range(a["n_links"])).all()
     t = robots.tree30()
     assert t.n_dof == 30 and len(t.spheres) == 60
+
+
+def _bench(extra, env_extra=None, timeout=300):
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, cwd=ROOT, env=env, capture_output=True,
+                          text=True, timeout=timeout)
+
+
+def test_bench_refuses_a_world_that_is_not_gpus():
+    """under a launcher (WORLD_SIZE set) --gpus must name that world, in either direction"""
+    r = _bench(["--gpus", "2", "--steps", "1"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE (1) != --gpus (2)" in (r.stdout + r.stderr)
+    r = _bench(["--gpus", "1", "--steps", "1"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE (2) != --gpus (1)" in (r.stdout + r.stderr)
+
+
+def test_bench_gpus_n_starts_its_own_ranks():
+    """`bench.py --gpus 2` with no WORLD_SIZE starts two child ranks itself and exits with their code: without a
+    GPU every rank refuses ("needs an MI355X"), so the command must fail -- through the launcher it started
+    (the launcher ends the other rank as soon as one has failed: at least one of them has said so)"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: tests/test_gpu_multirank.py runs the real thing")
+    r = _bench(["--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0"])
+    assert r.returncode != 0
+    text = r.stdout + r.stderr
+    assert text.count("bench.py needs an MI355X") >= 1 and "torch.distributed" in text, text[-3000:]
