@@ -608,6 +608,46 @@ void BatchShard::build_device(const Robot & robot)
       }
       device_sphere_order.push_back(inact[s].xml);
    }
+   // the FK walk's records (DevFkJoint): fixed transform, axis, control word and the first four spheres of the link
+   for (int k=0; k<nj; k++)
+   {
+      const DevJoint<real> & J = M.joints[k];
+      DevFkJoint<real> & F = M.fkj[k];
+      for (int q=0; q<9; q++) F.Rfix[q] = J.Rfix[q];
+      for (int q=0; q<3; q++) { F.tfix[q] = J.tfix[q]; F.axis[q] = J.axis[q]; }
+      const int count = J.sph_end - J.sph_begin;
+      F.ctl = (count & 255) | ((J.sph_begin & 255) << 8) | (((J.load_slot + 2) & 15) << 16) | (((J.save_slot + 2) & 15) << 20)
+            | ((J.type == 1 ? 1 : 0) << 24) | ((J.col & 127) << 25);
+      for (int u=0; u<4; u++)
+      {
+         const int sidx = (u < count) ? J.sph_begin + u : 0;
+         for (int q=0; q<3; q++) F.sph[u][q] = (u < count) ? M.sph_pos[sidx][q] : (real) 0;
+         F.slot[u] = (u < count) ? M.slot_of[sidx] : 0;
+      }
+   }
+   // A chain that then branches: joints 0 .. c are each other's parents, c has several children and everything after c
+   // hangs below it.  The walk is cut at the child of c that balances [0, cut) against (chain + [cut, nj)).
+   M.fk_split = 0; M.fk_nanc = 0; M.fk_b_begin = nj;
+   if (roots.size() == 1 && nj >= 8 && !getenv("ORC_NO_FK_SPLIT"))
+   {
+      std::vector<int> ppos(nj);                       // parent of the k-th joint of the walk, as a position of the walk
+      for (int k=0; k<nj; k++) ppos[k] = (jparent[order[k]] < 0) ? -1 : pos_in_order[jparent[order[k]]];
+      int c = 0;
+      while (c + 1 < nj && children[order[c]].size() == 1) c++;       // the chain in front of the first branching joint
+      bool chain = true;
+      for (int k=1; k<=c; k++) if (ppos[k] != k - 1) chain = false;
+      if (chain && children[order[c]].size() >= 2)
+      {
+         int best = -1, best_len = nj;
+         for (size_t ci=1; ci<children[order[c]].size(); ci++)
+         {
+            const int cut = pos_in_order[children[order[c]][ci]];
+            const int len = std::max(cut, (c + 1) + (nj - cut));
+            if (len < best_len) { best_len = len; best = cut; }
+         }
+         if (best > 0 && 4 * best_len <= 3 * nj) { M.fk_split = 1; M.fk_nanc = c + 1; M.fk_b_begin = best; }
+      }
+   }
    nj_ = nj; Sa_ = lanes; S_ = lanes + (int) inact.size() - n_static; GS_ = M.GS; tree_ = M.tree | ((M.GS == 16) ? 2 : 0);     // kernel variant bits
    if (M.GS == 16 && !M.tree && M.jt_scan == 1 && M.placed && nj <= 16 && !getenv("ORC_NO_KIND"))
       tree_ |= 16 | (M.floating ? 64 : 0);      // the variants that know all this at compile time (chomp_kernel.hip phase_cost KIND)
@@ -681,6 +721,9 @@ void BatchShard::build_device(const Robot & robot)
    ms_.nj = M.nj; ms_.floating = M.floating; ms_.tree = M.tree; ms_.Sa = M.Sa; ms_.S = M.S; ms_.Sa_real = M.Sa_real; ms_.placed = M.placed;
    ms_.GS = M.GS; ms_.base_sph_begin = M.base_sph_begin; ms_.base_sph_end = M.base_sph_end; ms_.jt_scan = M.jt_scan; ms_.n_static = M.n_static;
    ms_.live_mask = M.live_mask; ms_.static_mask = M.static_mask;
+   ms_.fk_split = M.fk_split; ms_.fk_nanc = M.fk_nanc; ms_.fk_b_begin = M.fk_b_begin; ms_.pad_ = 0;
+   if (getenv("ORC_DEBUG_PLAN") && M.fk_split)
+      fprintf(stderr, "orc fk: the walk is cut in two: joints [0, %d) | chain [0, %d) + joints [%d, %d)\n", M.fk_b_begin, M.fk_nanc, M.fk_b_begin, nj);
    DevModel<real> * dm = dev_alloc<DevModel<real>>(1);
    hip_check(hipMemcpyAsync(dm, &M, sizeof(M), hipMemcpyHostToDevice, st), "model");
    hip_check(hipStreamSynchronize(st), "model sync");

@@ -875,6 +875,7 @@ __device__ __forceinline__ real smooth_grad(const BT & b, const real * T_s, int 
 #endif
 
 #include "cost_gs16.h"
+#include "self_mfma.h"
 #include "cost_generic.h"
 #include "fk.h"
 
@@ -906,7 +907,7 @@ struct Env
    long long * phc_s;                      // [8] per-phase cycle counters (diagnostics), thread 0
    real * T_s, * G_s, * Gc, * W_s, * pos_s, * ax_s, * srad_s, * sinact_s, * jl_s, * r2_s, * pcr_s, * sphpos_s, * base_s;
    int * slink_s, * jtype_s, * jcol_s, * slot_s;
-   int * jctl_s; DevSdf<real> * sdfs_s; unsigned long long * saff_s;
+   int * jctl_s; DevSdf<real> * sdfs_s; unsigned long long * saff_s, * sallow_s;
    real * traj_g, * AG_g, * AG_s;
    const real * pcr_tab;
    int pstr, astr;
@@ -951,17 +952,19 @@ __device__ __forceinline__ Env<real> make_env(const BT & b, unsigned char * smem
    E.jctl_s = (int *)(smem_raw + L.joints_bytes);
    E.sdfs_s = (DevSdf<real> *)(smem_raw + L.sdfs_bytes);
    E.saff_s = (unsigned long long *)(smem_raw + L.saff_bytes);
+   E.sallow_s = (unsigned long long *)(smem_raw + L.sallow_bytes);
    ModelView<real> & mod = E.mod;
    mod.nj = nj; mod.n = n; mod.floating = b.ms.floating; mod.tree = b.ms.tree; mod.Sa = Sa; mod.S = S; mod.GS = b.ms.GS; mod.jt_scan = b.ms.jt_scan;
    mod.Sa_real = b.ms.Sa_real; mod.placed = b.ms.placed; mod.live_mask = b.ms.live_mask; mod.slot_of = E.slot_s;
    mod.base_sph_begin = b.ms.base_sph_begin; mod.base_sph_end = b.ms.base_sph_end;
    mod.base_R = E.base_s; mod.base_t = E.base_s + 9;
-   mod.jctl = E.jctl_s; mod.sph_pos = (const real (*)[3]) E.sphpos_s; mod.sph_affects = E.saff_s;
+   mod.jctl = E.jctl_s; mod.sph_pos = (const real (*)[3]) E.sphpos_s; mod.sph_affects = E.saff_s; mod.sph_allowed = E.sallow_s;
    mod.jpk = (const __attribute__((address_space(4))) int *) b.model->jpacked;
    mod.jpk2 = (const __attribute__((address_space(4))) int *) b.model->jpacked2;
    mod.sph_pos_c = (const __attribute__((address_space(4))) real (*)[3]) b.model->sph_pos;
    mod.joints_c = (const __attribute__((address_space(4))) DevJoint<real> *) b.model->joints;
    mod.slot_c = (const __attribute__((address_space(4))) int *) b.model->slot_of;
+   mod.fkj = (const __attribute__((address_space(4))) DevFkJoint<real> *) b.model->fkj;
    mod.n_static = b.ms.n_static;
    mod.empty_mask = b.ms.placed ? (unsigned int)(~(b.ms.live_mask | b.ms.static_mask) & 0xFFFFull) : 0u;
    mod.static_slot_c = (const __attribute__((address_space(4))) int *) b.model->static_slot;
@@ -1040,6 +1043,15 @@ __device__ __attribute__((noinline)) void phase_setup(const void * kp)
    if (tid < 8) E.phc_s[tid] = 0;
    __syncthreads();
 
+   if (!GS16 && tid < 64)
+   {
+      // the spheres a sphere can collide with: active, on another link (src/orcdchomp_mod.cpp:1255-1256)
+      unsigned long long allow = 0ull;
+      if (tid < Sa)
+         for (int o=0; o<Sa; o++)
+            if (E.slink_s[o] != E.slink_s[tid]) allow |= 1ull << o;
+      E.sallow_s[tid] = allow;
+   }
    if (GS16 && tid < 64)
    {
       // squared range of the pair (lane, lane rotated by K) for the row rotations of the
@@ -1088,16 +1100,23 @@ __device__ __attribute__((noinline)) void phase_fk(const void * kp, int ts_in, i
    const int tid = threadIdx.x, n = b.n;
    const int nfk = te - ts + 2;          // waypoints ts .. te+1 (global index)
    __builtin_amdgcn_s_setprio(ORC_PRIO_FK);          // latency-bound phases go first when they have something to issue
-   // a wavefront walks 20 waypoints: five triads of lanes (x, y, z rows) in each of its four rows of 16
-   const int lane16 = tid & 15, triad = (lane16 * 11) >> 5, wave0 = (tid >> 6) * 20;
-   const int wv = wave0 + ((tid >> 4) & 3) * 5 + triad;
-   for (int w0=0; w0<nfk; w0+=(BLOCK/64)*20)
+   // a wavefront walks 20 waypoints: five triads of lanes (x, y, z rows) in each of its four rows of 16.  A robot whose
+   // joint tree is a chain that then branches (DevModel::fk_split) is walked by PAIRS of wavefronts: one takes the
+   // joints up to fk_b_begin, the other the chain (without storing) and the joints from fk_b_begin on
+   const int lane16 = tid & 15, triad = (lane16 * 11) >> 5, wave = uni(tid >> 6);      // (the compiler must know the walk's joint indices as uniform: scalar loads)
+   const int nseg = (b.ms.fk_split && (BLOCK/64) % 2 == 0) ? 2 : 1;
+   const int seg = (nseg == 2) ? (wave & 1) : 0, group = (nseg == 2) ? (wave >> 1) : wave, groups = (BLOCK/64) / nseg;
+   const int nj = E.mod.nj;
+   const int n_anc = seg ? b.ms.fk_nanc : 0, j_begin = seg ? b.ms.fk_b_begin : 0, j_end = (nseg == 2 && !seg) ? b.ms.fk_b_begin : nj;
+   const int wv = group * 20 + ((tid >> 4) & 3) * 5 + triad;
+   for (int w0=0; w0<nfk; w0+=groups*20)
    {
-      if (w0 + wave0 >= nfk) continue;             // a wavefront without a waypoint in this round (wave-uniform)
+      if (w0 + group * 20 >= nfk) continue;             // a wavefront without a waypoint in this round (wave-uniform)
       const int w = w0 + wv;
       const bool valid = (lane16 < 15) && (w < nfk);
       const int wr = valid ? w : 0;
-      fk_waypoint_triad<real, TREE>(E.mod, E.T_s + (ts + wr)*n, E.mod.nj, (lane16 < 15) ? lane16 - 3*triad : 0, valid, E.pos_s + wr*E.pstr, E.ax_s + wr*E.astr);
+      fk_waypoint_triad<real, TREE>(E.mod, E.T_s + (ts + wr)*n, n_anc, j_begin, j_end, seg == 0, (lane16 < 15) ? lane16 - 3*triad : 0, valid,
+                                    E.pos_s + wr*E.pstr, E.ax_s + wr*E.astr);
    }
    __syncthreads();
    phase_mark<real>(b, E, 0);
@@ -1693,6 +1712,7 @@ void collision_verdict_kernel(DevVerdict<real> v)
    mod.sph_pos_c = (const __attribute__((address_space(4))) real (*)[3]) gmod.sph_pos;
    mod.joints_c = (const __attribute__((address_space(4))) DevJoint<real> *) gmod.joints;
    mod.slot_c = (const __attribute__((address_space(4))) int *) gmod.slot_of;
+   mod.fkj = (const __attribute__((address_space(4))) DevFkJoint<real> *) gmod.fkj;
    __syncthreads();
 
    const real * traj = v.traj + (size_t) run * np * n;
@@ -1725,7 +1745,7 @@ void collision_verdict_kernel(DevVerdict<real> v)
          const int s = (tid >> 6) * 20 + ((tid >> 4) & 3) * 5 + triad;
          const bool valid = (lane16 < 15) && (s < count);
          const int sr = valid ? s : 0;
-         fk_waypoint_triad<real, TREE>(mod, rows_s + sr*n, nj, (lane16 < 15) ? lane16 - 3*triad : 0, valid, pos_s + sr*pstr, ax_s + sr*astr);
+         fk_waypoint_triad<real, TREE>(mod, rows_s + sr*n, 0, 0, nj, true, (lane16 < 15) ? lane16 - 3*triad : 0, valid, pos_s + sr*pstr, ax_s + sr*astr);
       }
       __syncthreads();
       for (int item=tid; item<count*Sa; item+=ORC_BLOCK)

@@ -225,8 +225,20 @@ __device__ __forceinline__ void cost_tile_generic(const BT & b, const ModelView<
       }
       // (1) which active spheres this lane's sphere is in range of: bit o of `near`
       unsigned long long near = 0ull;
+      bool nominated = false;                 // `near` holds candidates: pass (2) repeats the reference's test on them
 #ifndef ORC_ABLATE_PASS1
-      if (GS == 64)
+      if (sizeof(real) == 4 && GS == 64)
+      {
+         // fp32, one waypoint per wavefront: the 64 x 64 range tests by the matrix cores (self_mfma.h).  The result
+         // nominates pairs (all that are in range and a few that are up to ~3e-5 m beyond)
+         if constexpr (sizeof(real) == 4)
+         {
+            near = self_candidates_mfma(p, radius + (real)0.5 * b.epsilon_self) & mod.sph_allowed[ss];
+            near = live ? near : 0ull;
+            nominated = true;
+         }
+      }
+      else if (GS == 64)
       {
          // one waypoint per wavefront: the partner's centre, radius and link come round by the
          // wavefront rotation of the DPP unit (wave_rol:1, lane i takes lane i+1; K applications bring
@@ -316,7 +328,7 @@ __device__ __forceinline__ void cost_tile_generic(const BT & b, const ModelView<
       while (__ballot(near != 0ull) != 0ull)
       {
          if (dbg) dbg[4]++;
-         const bool act = near != 0ull;
+         bool act = near != 0ull;
          const int o = act ? __builtin_ctzll(near) : ss;                // (lanes that are done look at themselves: valid memory, masked)
          near &= near - 1ull;
          const int src = gbase + o;                                     // the partner's lane
@@ -330,6 +342,11 @@ __device__ __forceinline__ void cost_tile_generic(const BT & b, const ModelView<
          const real ro = srad_s[o];
          const real d[3] = { p[0]-po[0], p[1]-po[1], p[2]-po[2] };
          const real d2 = d[0]*d[0] + d[1]*d[1] + d[2]*d[2];
+         {
+            // nominated pairs: "skip spheres far enough away from us" (src/orcdchomp_mod.cpp:1267-1268)
+            const real R = (radius + b.epsilon_self) + ro;
+            act = act && !(nominated && d2 > R*R);
+         }
          real inv_d;
          real dist = sqrt_rsq(act ? d2 : (real)1, &inv_d);
          dist -= radius + ro;

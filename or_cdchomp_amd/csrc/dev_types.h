@@ -42,6 +42,18 @@ struct DevJoint
    int packed2;       // (load_slot + 2) | (save_slot + 2) << 4: the tree's frame traffic, scalar like `packed`
 };
 
+// What the FK walk reads of one joint (fk.h), as one record: a burst of scalar loads per joint (32 words in fp32),
+// the spheres riding on the joint's link included (their table entries used to be loaded one sphere at a time,
+// each load a scalar-cache round trip in the middle of the joint's step)
+template <typename real>
+struct DevFkJoint
+{
+   real Rfix[9], tfix[3], axis[3];
+   int ctl;             // spheres on the link: count (bits 0-7), index of the first in the sorted order (8-15); load_slot + 2 (16-19), save_slot + 2 (20-23); revolute (24); column (25-31)
+   real sph[4][3];      // centres of the first four of them in the link frame (more: DevModel::sph_pos from the fifth on)
+   int slot[4];         // their slots of the position buffer
+};
+
 template <typename real>
 struct DevModel
 {
@@ -76,6 +88,10 @@ struct DevModel
    int static_slot[16];
    real static_pos[16][3];                          // world positions
    unsigned long long static_mask;                  // bit s: lane/slot s holds one of them
+   DevFkJoint<real> fkj[ORC_MAX_JOINTS];            // the FK walk's records, depth-first order like `joints`
+   // A robot that is a chain [0, fk_nanc) which then branches: the branches from joint fk_b_begin on can be walked by
+   // another wavefront (which walks the chain as well, without storing): two walks of about half the length
+   int fk_split, fk_nanc, fk_b_begin;
 };
 
 // a rooted signed distance field (struct run_rsdf + struct cd_grid)
@@ -136,6 +152,7 @@ struct DevTsr
 struct ModelScalars
 {
    int nj, floating, tree, Sa, S, Sa_real, placed, GS, base_sph_begin, base_sph_end, jt_scan, n_static;
+   int fk_split, fk_nanc, fk_b_begin, pad_;
    unsigned long long live_mask, static_mask;
 };
 struct LdsLayout
@@ -147,6 +164,7 @@ struct LdsLayout
    int joints_bytes;       // byte offset of the staged joint control words [nj][2]
    int sdfs_bytes;         // byte offset of the staged DevSdf[n_sdfs]
    int saff_bytes;         // byte offset of the staged affects masks [Sa]
+   int sallow_bytes;       // byte offset of the self-collision partner masks [64] (robots with more than 16 active spheres)
    int total_bytes;
 };
 
@@ -258,11 +276,13 @@ struct ModelView
    const int * jctl;                       // [nj][2] control words of a joint: DevJoint::packed, and aff_begin | aff_end << 8 | type << 16 | col << 24
    const real (* sph_pos)[3];              // [Sa][3]
    const unsigned long long * sph_affects; // [Sa]
+   const unsigned long long * sph_allowed; // [64] bit o of entry s: sphere o is active and rides on another link than sphere s (many-sphere path)
    const __attribute__((address_space(4))) int * jpk;    // [nj] DevModel::jpacked (global memory, scalar loads)
    const __attribute__((address_space(4))) int * jpk2;   // [nj] DevModel::jpacked2
    const __attribute__((address_space(4))) real (* sph_pos_c)[3];   // DevModel::sph_pos (scalar loads: the FK walk's sphere tables)
    const __attribute__((address_space(4))) int * slot_c;            // DevModel::slot_of
    const __attribute__((address_space(4))) DevJoint<real> * joints_c;   // DevModel::joints (scalar loads: the walk's fixed transforms and axes)
+   const __attribute__((address_space(4))) DevFkJoint<real> * fkj;     // DevModel::fkj (scalar loads: one record per joint)
    const __attribute__((address_space(4))) int * static_slot_c;         // DevModel::static_slot / static_pos (FK writes them into every row)
    const __attribute__((address_space(4))) real (* static_pos_c)[3];
 };
@@ -313,6 +333,7 @@ inline LdsLayout lds_layout(int np, int n, int Sa, int S, int nj, int tile_m, in
    L.joints_bytes = bytes; bytes += nj * 8; bytes = (bytes + 15) & ~15;
    L.sdfs_bytes = bytes;   bytes += n_sdfs * sdf_size; bytes = (bytes + 15) & ~15;
    L.saff_bytes = bytes;   bytes += Sa * 8;
+   L.sallow_bytes = bytes; bytes += (Sa > 16) ? 64 * 8 : 0;
    if (alias) L.lim_bytes = ORC_LDS_HEADER + (L.pos + work_reals) * real_size;
    else { L.lim_bytes = bytes; bytes += ORC_LIM_SCRATCH; }
    L.total_bytes = (g_global && !alias) ? (1 << 30) : bytes;      // G in the tile buffers needs tiles that hold it

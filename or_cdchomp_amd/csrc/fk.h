@@ -66,11 +66,15 @@ __device__ __forceinline__ void sincos_joint(float x, float * sn, float * cs)
    *cs = ((q + 1) & 2) ? -ca : ca;
 }
 
+#ifndef ORC_FK_AHEAD
+#define ORC_FK_AHEAD 1
+#endif
+
 // one row of a frame: R[k][0..2] and t[k]
 template <typename real>
 struct FrameRow { real r[3]; real t; };
 
-// apply joint J to row `cur` (in place); emit component k of the world axis / anchor and of the
+// apply the joint of record J to row `cur` (in place); emit component k of the world axis / anchor and of the
 // centres of the spheres riding on the joint's link.  `store` is false on the idle lane.
 // The step is ONE instruction stream for every kind of joint (round 2; the walk used to branch on the
 // joint's type, on coordinate axes and on identity transforms -- a dozen scalar branches per joint, and
@@ -79,76 +83,102 @@ struct FrameRow { real r[3]; real t; };
 //    r  <- r' Rot(a, q) = r' c + (1 - c)(r'.a) a - s (a x r')          (Rodrigues for a row vector)
 //    t  <- tj + qp aw
 // with (s, c, qp) = (sin q, cos q, 0) for a revolute and (0, 1, q) for a prismatic joint, prepared with
-// the sin/cos.  pk = the joint's control word as a scalar: only the sphere range is read from it.
-template <typename real, typename JT>
-__device__ __forceinline__ void fk_joint_row(const ModelView<real> & mod, const JT & J, int pk, FrameRow<real> & cur,
-   real qp, real sn, real cs, bool store, real * axo_k, real * pos_k)
+// the sin/cos.  The record (DevFkJoint) is in scalar registers: fixed transform, axis and the table entries of
+// up to four spheres enter the products as scalar operands.
+template <typename real, bool LAZY, typename JT>
+__device__ __forceinline__ void fk_joint_row(const ModelView<real> & mod, const JT & J, const __attribute__((address_space(4))) DevFkJoint<real> * src,
+   FrameRow<real> & cur, real qp, real sn, real cs, bool store, real * axo_k, real * pos_k)
 {
-   const int s_begin = (pk >> 8) & 255, s_end = (pk >> 16) & 255;
-   real Rf[9], tf[3], ax[3];
-#pragma unroll
-   for (int c=0; c<9; c++) Rf[c] = J.Rfix[c];
-#pragma unroll
-   for (int c=0; c<3; c++) { tf[c] = J.tfix[c]; ax[c] = J.axis[c]; }
    // joint frame in the world: cur o (Rfix, tfix)
-   const real tj = cur.r[0]*tf[0] + cur.r[1]*tf[1] + cur.r[2]*tf[2] + cur.t;
+   const real tj = cur.r[0]*J.tfix[0] + cur.r[1]*J.tfix[1] + cur.r[2]*J.tfix[2] + cur.t;
    real rp[3];
 #pragma unroll
    for (int c=0; c<3; c++)
-      rp[c] = cur.r[0]*Rf[0*3+c] + cur.r[1]*Rf[1*3+c] + cur.r[2]*Rf[2*3+c];
-   const real aw = rp[0]*ax[0] + rp[1]*ax[1] + rp[2]*ax[2];
+      rp[c] = cur.r[0]*J.Rfix[0*3+c] + cur.r[1]*J.Rfix[1*3+c] + cur.r[2]*J.Rfix[2*3+c];
+   const real aw = rp[0]*J.axis[0] + rp[1]*J.axis[1] + rp[2]*J.axis[2];
    if (store) { axo_k[0] = aw; axo_k[3] = tj; }
    const real d = aw * ((real)1 - cs);
-   const real x0 = ax[1]*rp[2] - ax[2]*rp[1], x1 = ax[2]*rp[0] - ax[0]*rp[2], x2 = ax[0]*rp[1] - ax[1]*rp[0];
-   cur.r[0] = (rp[0]*cs + d*ax[0]) - sn*x0;
-   cur.r[1] = (rp[1]*cs + d*ax[1]) - sn*x1;
-   cur.r[2] = (rp[2]*cs + d*ax[2]) - sn*x2;
+   const real x0 = J.axis[1]*rp[2] - J.axis[2]*rp[1], x1 = J.axis[2]*rp[0] - J.axis[0]*rp[2], x2 = J.axis[0]*rp[1] - J.axis[1]*rp[0];
+   cur.r[0] = (rp[0]*cs + d*J.axis[0]) - sn*x0;
+   cur.r[1] = (rp[1]*cs + d*J.axis[1]) - sn*x1;
+   cur.r[2] = (rp[2]*cs + d*J.axis[2]) - sn*x2;
    cur.t = tj + qp*aw;
 #ifndef ORC_ABLATE_FKSPH
-   // The spheres riding on the joint's link.  Their table entries (centre in the link frame, slot of
-   // the position buffer) are the same for every lane: they come by scalar loads from the model in
-   // global memory, four spheres per batch and the rest one at a time, and enter the products as scalar
-   // operands.
    if (store)
    {
-      int s0 = s_begin;
-      for (; s0+4<=s_end; s0+=4)
+      const int count = J.ctl & 255;
+      if (LAZY)
       {
-         real lp[4][3]; int off[4];
-#pragma unroll
-         for (int u=0; u<4; u++)
+         // fp64: the sphere part of the record is fetched here, after the frame (the whole record is 59 words)
+         if (count > 0)
          {
-            lp[u][0] = mod.sph_pos_c[s0 + u][0]; lp[u][1] = mod.sph_pos_c[s0 + u][1]; lp[u][2] = mod.sph_pos_c[s0 + u][2];
-            off[u] = mod.slot_c[s0 + u];
+            real lp[4][3]; int off[4];
+#pragma unroll
+            for (int u=0; u<4; u++) { lp[u][0] = src->sph[u][0]; lp[u][1] = src->sph[u][1]; lp[u][2] = src->sph[u][2]; off[u] = src->slot[u]; }
+#pragma unroll
+            for (int u=0; u<4; u++)
+               if (u < count) pos_k[off[u]*3] = cur.r[0]*lp[u][0] + cur.r[1]*lp[u][1] + cur.r[2]*lp[u][2] + cur.t;
          }
+      }
+      else
+      {
 #pragma unroll
          for (int u=0; u<4; u++)
-            pos_k[off[u]*3] = cur.r[0]*lp[u][0] + cur.r[1]*lp[u][1] + cur.r[2]*lp[u][2] + cur.t;
+            if (u < count)         // (wave-uniform)
+               pos_k[J.slot[u]*3] = cur.r[0]*J.sph[u][0] + cur.r[1]*J.sph[u][1] + cur.r[2]*J.sph[u][2] + cur.t;
       }
-      for (; s0<s_end; s0++)      // what is left of the link's spheres, one at a time
+      if (count > 4)            // a link with more than four spheres: the rest from the model's table, one at a time
       {
-         const real l0 = mod.sph_pos_c[s0][0], l1 = mod.sph_pos_c[s0][1], l2 = mod.sph_pos_c[s0][2];
-         pos_k[mod.slot_c[s0]*3] = cur.r[0]*l0 + cur.r[1]*l1 + cur.r[2]*l2 + cur.t;
+         const int s_first = (J.ctl >> 8) & 255;
+         for (int s0=s_first+4; s0<s_first+count; s0++)
+         {
+            const real l0 = mod.sph_pos_c[s0][0], l1 = mod.sph_pos_c[s0][1], l2 = mod.sph_pos_c[s0][2];
+            pos_k[mod.slot_c[s0]*3] = cur.r[0]*l0 + cur.r[1]*l1 + cur.r[2]*l2 + cur.t;
+         }
       }
    }
 #endif
 }
 
+// a joint's record into (scalar) registers
+template <typename real, bool SPHERES>
+__device__ __forceinline__ DevFkJoint<real> fk_record(const __attribute__((address_space(4))) DevFkJoint<real> * src)
+{
+   DevFkJoint<real> d;
+#pragma unroll
+   for (int q=0; q<9; q++) d.Rfix[q] = src->Rfix[q];
+#pragma unroll
+   for (int q=0; q<3; q++) { d.tfix[q] = src->tfix[q]; d.axis[q] = src->axis[q]; }
+   d.ctl = src->ctl;
+   if (SPHERES)
+#pragma unroll
+   for (int u=0; u<4; u++)
+   {
+#pragma unroll
+      for (int q=0; q<3; q++) d.sph[u][q] = src->sph[u][q];
+      d.slot[u] = src->slot[u];
+   }
+   return d;
+}
+
 // FK of one waypoint by a triad of lanes (k = 0, 1, 2: the x, y, z rows; row = its trajectory row).
 // `valid` is false for lanes without a waypoint (a DPP row of 16 lanes holds five triads, its last lane
 // idles; and lanes past the last waypoint): they compute on a clamped row and store nothing.
-// The sin/cos of a waypoint's joints are shared by its triad: lane k evaluates joints k, k+3, ... and
-// leaves (s, c, qp) in the joint's own slot of ax_wp, which the walk overwrites with the joint's axis
+// The walk covers the joints [0, n_anc) WITHOUT storing anything (the chain in front of the branches another
+// wavefront walks in full, see phase_fk; their sin/cos are evaluated by every lane) and then the joints
+// [j_begin, j_end), whose axes, anchors and sphere centres it stores; `first`: this walk also stores what belongs
+// to no joint (the spheres of a floating base, the row's static and empty slots).  The whole robot: (0, 0, nj, true).
+// The sin/cos of a waypoint's own joints are shared by its triad: lane k evaluates joints j_begin + k, + k + 3, ...
+// and leaves (s, c, qp) in the joint's own slot of ax_wp, which the walk overwrites with the joint's axis
 // and anchor when it gets there (the three lanes sit in one wavefront, whose LDS operations execute in
-// program order: every lane has read the slot before any lane writes it).  (Until round 2 a waypoint
-// took a quad with the fourth lane idle and the sin/cos travelling by quad broadcasts: 16 waypoints per
-// wavefront instead of 20, a quarter more FK instructions per iteration.)
+// program order: every lane has read the slot before any lane writes it).
+// A joint's record is fetched one step ahead of its use (scalar loads; the joint's step itself then waits for
+// nothing but its three staged numbers).
 // TREE = the joint tree branches (saved frames).
 template <typename real, bool TREE>
-__device__ __forceinline__ void fk_waypoint_triad(const ModelView<real> & mod, const real * row, int nj, int k, bool valid,
-   real * pos_wp, real * ax_wp)
+__device__ __forceinline__ void fk_waypoint_triad(const ModelView<real> & mod, const real * row, int n_anc, int j_begin, int j_end, bool first,
+   int k, bool valid, real * pos_wp, real * ax_wp)
 {
-   const bool store = valid;
    const int kk = k;
    real * pos_k = pos_wp + kk;
    FrameRow<real> base, cur, sv0, sv1, sv2, sv3;
@@ -162,12 +192,13 @@ __device__ __forceinline__ void fk_waypoint_triad(const ModelView<real> & mod, c
       else if (kk == 1) { base.r[0] = 2*(xy+zw);     base.r[1] = 1 - 2*(xx+zz); base.r[2] = 2*(yz-xw); }
       else              { base.r[0] = 2*(xz-yw);     base.r[1] = 2*(yz+xw);     base.r[2] = 1 - 2*(xx+yy); }
       base.t = row[kk];
-      for (int s=mod.base_sph_begin; s<mod.base_sph_end; s++)
-      {
-         const real * lp = mod.sph_pos[s];
-         const real o = base.r[0]*lp[0] + base.r[1]*lp[1] + base.r[2]*lp[2] + base.t;
-         if (store) pos_k[mod.slot_of[s]*3] = o;
-      }
+      if (first)
+         for (int s=mod.base_sph_begin; s<mod.base_sph_end; s++)
+         {
+            const real * lp = mod.sph_pos[s];
+            const real o = base.r[0]*lp[0] + base.r[1]*lp[1] + base.r[2]*lp[2] + base.t;
+            if (valid) pos_k[mod.slot_of[s]*3] = o;
+         }
    }
    else
    {
@@ -177,11 +208,11 @@ __device__ __forceinline__ void fk_waypoint_triad(const ModelView<real> & mod, c
    }
    cur = base;
    if (TREE) { sv0 = base; sv1 = base; sv2 = base; sv3 = base; }
-   // the triad's sin/cos: lane k evaluates joints k, k+3, ...
-   for (int j0=0; j0<nj; j0+=3)
+   // the triad's sin/cos of the joints it stores: lane k evaluates joints j_begin + k, + k + 3, ...
+   for (int j0=j_begin; j0<j_end; j0+=3)
    {
       const int j = j0 + kk;
-      const int jm = (j < nj) ? j : nj - 1;
+      const int jm = (j < j_end) ? j : j_end - 1;
       const int pkm = mod.jctl[2*jm];
       real qm = row[(pkm >> 24) & 127];
       real snm, csm;
@@ -193,44 +224,71 @@ __device__ __forceinline__ void fk_waypoint_triad(const ModelView<real> & mod, c
       // a prismatic joint: no rotation, the frame moves q along the axis; a revolute one: no translation
       const bool revolute = ((pkm & 3) == 1);
       snm = revolute ? snm : (real)0; csm = revolute ? csm : (real)1; qm = revolute ? (real)0 : qm;
-      if (store && j < nj) { real * st = ax_wp + jm*6; st[0] = snm; st[1] = csm; st[2] = qm; }
+      if (valid && j < j_end) { real * st = ax_wp + jm*6; st[0] = snm; st[1] = csm; st[2] = qm; }
    }
    __builtin_amdgcn_wave_barrier();
-   for (int j=0; j<nj; j++)
+   const int n_steps = n_anc + (j_end - j_begin);
+   auto joint_of = [&](int idx) { return (idx < n_anc) ? idx : j_begin + (idx - n_anc); };
+   // (fp32: 2 x 32 scalar registers hold this joint's record and the next; an fp64 record is 59 words, and two of
+   // them cost more in scalar spills than the fetch ahead gains: measured on BASELINE configs[1] and [3])
+   constexpr bool AHEAD = ORC_FK_AHEAD && sizeof(real) == 4;
+   DevFkJoint<real> nxt;
+   if (AHEAD) nxt = fk_record<real, true>(mod.fkj + joint_of(0));
+   for (int idx=0; idx<n_steps; idx++)
    {
-      const auto & J = mod.joints_c[j];             // scalar loads: fixed transform and axis enter the products as scalar operands
-      const int pk = mod.jpk[j];
-      const int pk2 = TREE ? mod.jpk2[j] : 0;
-      const real * st = ax_wp + j*6;
-      const real sn = st[0], cs = st[1], qp = st[2];
+      const int j = joint_of(idx);
+      DevFkJoint<real> J;
+      if (AHEAD)
+      {
+         J = nxt;
+         nxt = fk_record<real, true>(mod.fkj + joint_of((idx + 1 < n_steps) ? idx + 1 : idx));      // the next joint's record, a step ahead
+      }
+      else J = fk_record<real, false>(mod.fkj + j);
+      const bool own = (idx >= n_anc);                                    // (wave-uniform)
+      real sn, cs, qp;
+      if (own)
+      {
+         const real * st = ax_wp + j*6;
+         sn = st[0]; cs = st[1]; qp = st[2];
+      }
+      else
+      {
+         const bool revolute = ((J.ctl >> 24) & 1) != 0;
+         const real q = row[(J.ctl >> 25) & 127];
+         sincos_joint(q, &sn, &cs);
+         sn = revolute ? sn : (real)0; cs = revolute ? cs : (real)1; qp = revolute ? (real)0 : q;
+      }
       if (TREE)
       {
          // continue from the previous joint's frame unless the tree branches here
-         const int load_slot = (pk2 & 15) - 2;
+         const int load_slot = ((J.ctl >> 16) & 15) - 2;
          if (load_slot == -2) cur = base;
          else if (load_slot == 0) cur = sv0;
          else if (load_slot == 1) cur = sv1;
          else if (load_slot == 2) cur = sv2;
          else if (load_slot == 3) cur = sv3;
       }
-      fk_joint_row(mod, J, pk, cur, qp, sn, cs, store, ax_wp + j*6 + kk, pos_k);
+      fk_joint_row<real, !AHEAD>(mod, J, mod.fkj + j, cur, qp, sn, cs, valid && own, ax_wp + j*6 + kk, pos_k);
       if (TREE)
       {
-         const int save_slot = ((pk2 >> 4) & 15) - 2;
+         const int save_slot = ((J.ctl >> 20) & 15) - 2;
          if (save_slot == 0) sv0 = cur;
          else if (save_slot == 1) sv1 = cur;
          else if (save_slot == 2) sv2 = cur;
          else if (save_slot == 3) sv3 = cur;
       }
    }
-   // slots of the placed row that hold no sphere stay at zero (the cost phase may then multiply by what it
-   // finds there: cost_gs16.h FULL16)
-   for (unsigned int em=mod.empty_mask; em; em&=em-1u)
-      if (store) pos_k[(__builtin_ctz(em))*3] = (real)0;
-   // inactive spheres carried on free lanes of the row (DevModel::static_*): the same centre in every row
-   for (int q=0; q<mod.n_static; q++)
+   if (first)
    {
-      const real c0 = mod.static_pos_c[q][0], c1 = mod.static_pos_c[q][1], c2 = mod.static_pos_c[q][2];      // scalar loads
-      if (store) pos_k[mod.static_slot_c[q]*3] = (kk == 0) ? c0 : ((kk == 1) ? c1 : c2);
+      // slots of the placed row that hold no sphere stay at zero (the cost phase may then multiply by what it
+      // finds there: cost_gs16.h FULL16)
+      for (unsigned int em=mod.empty_mask; em; em&=em-1u)
+         if (valid) pos_k[(__builtin_ctz(em))*3] = (real)0;
+      // inactive spheres carried on free lanes of the row (DevModel::static_*): the same centre in every row
+      for (int q=0; q<mod.n_static; q++)
+      {
+         const real c0 = mod.static_pos_c[q][0], c1 = mod.static_pos_c[q][1], c2 = mod.static_pos_c[q][2];      // scalar loads
+         if (valid) pos_k[mod.static_slot_c[q]*3] = (kk == 0) ? c0 : ((kk == 1) ? c1 : c2);
+      }
    }
 }
