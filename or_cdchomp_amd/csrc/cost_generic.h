@@ -82,120 +82,99 @@ __device__ __forceinline__ void cost_tile_generic(const BT & b, const ModelView<
       const bool moving = vnorm > (real)0.000001;
       const real wself = vnorm * b.obs_factor_self;
 
-      // ---- obstacle term (src/orcdchomp_mod.cpp:1171-1246) ----
+      // ---- obstacle term (src/orcdchomp_mod.cpp:1171-1246), in two halves: the cell reads of the fields are issued
+      // here and used AFTER the self-collision term, whose range tests (matrix cores) and pair forces do not depend on
+      // them: the reads' round trip through L2 runs under that work instead of in front of an idle wavefront ----
+      real best = inf; bool has = false; real bgrad[3] = {0,0,0};
+      // The fields in cell units (DevSdfCell), their descriptors by scalar loads from global memory: the
+      // constants enter the products as scalar operands (staged in LDS, as the 16-lane path has them, every one
+      // of them was a broadcast read into a vector register: ~50 per field and lane).  The cell reads of up to
+      // four fields are issued before any is used (a field per trip would wait for its four reads, an L2
+      // round trip, before the next field's addresses are formed).
+      typedef const __attribute__((address_space(4))) DevSdfCell<real> CellDesc;
+      CellDesc * fc = (CellDesc *) b.sdfc;
+      real v0[4], vn[4][3], fr[4][3];      // (of the batch of up to four fields in flight)
+      bool prev[4][3], inbq[4];
+      bool use[4] = { false, false, false, false };              // wave-uniform: some sphere of the wavefront is inside the field
+      auto sdf_issue = [&](int i0)
       {
-         real best = inf; bool has = false; real bgrad[3] = {0,0,0};
+#pragma unroll
+         for (int q=0; q<4; q++)
+         {
+            use[q] = false;
+            if (i0 + q >= b.n_sdfs) continue;                       // wave-uniform
+            CellDesc & F = fc[i0 + q];
+            real gx[3];
+            bool inb = live;
+#pragma unroll
+            for (int k=0; k<3; k++)
+            {
+               gx[k] = F.M[k*3+0]*p[0] + F.M[k*3+1]*p[1] + F.M[k*3+2]*p[2] + F.t[k];
+               inb = inb && !(gx[k] < (real)0) && !(gx[k] > F.fsize[k]);      // the reference's x < 0 || x > 1 (grid.c:196-199)
+            }
+            // a field none of the wavefront's spheres is inside of contributes nothing (the reference
+            // skips an out-of-bounds lookup, src/orcdchomp_mod.cpp:1176-1183): no cells, no reads
+            use[q] = (__builtin_amdgcn_ballot_w64(inb) != 0ull);
+            if (!use[q]) continue;
+            if (dbg) dbg[5]++;
+            inbq[q] = inb;
+            int off = 0;
+#pragma unroll
+            for (int k=0; k<3; k++)
+            {
+               const real g = inb ? gx[k] : (real)0.25;             // lanes outside read cell 0 (valid memory), results masked
+               real fl = M<real>::floor_(g);
+               fl = M<real>::min_(fl, F.fsize_m1[k]);               // g == size: the last cell (grid.c:203)
+               fr[q][k] = (g - fl) - (real)0.5;                     // offset from the cell centre, in cells
+               // one-sided difference towards the nearer neighbour, inwards at the faces (grid.c:372-389)
+               prev[q][k] = (fl == (real)0) ? false : ((fl == F.fsize_m1[k]) ? true : (fr[q][k] < (real)0));
+               off += (int) fl * ((k == 2) ? (int) sizeof(real) : F.stride_b[k]);
+            }
+            const char * base = (const char *) F.data;
+            v0[q] = *(const real *)(base + off);
+#pragma unroll
+            for (int k=0; k<3; k++)
+            {
+               const int sb = (k == 2) ? (int) sizeof(real) : F.stride_b[k];
+               vn[q][k] = *(const real *)(base + (off + (prev[q][k] ? -sb : sb)));
+            }
+         }
+      };
+      auto sdf_finish = [&](int i0)
+      {
+#pragma unroll
+         for (int q=0; q<4; q++)
+         {
+            if (i0 + q >= b.n_sdfs || !use[q]) continue;
+            CellDesc & F = fc[i0 + q];
+            bool poisoned = (v0[q] == inf);
+            real val = v0[q], df[3];
+#pragma unroll
+            for (int k=2; k>=0; k--)                                 // the reference walks the axes z, y, x
+            {
+               poisoned = poisoned || (vn[q][k] == inf);
+               const real dd = vn[q][k] - v0[q];
+               df[k] = prev[q][k] ? -dd : dd;                        // after - before
+               val += df[k] * fr[q][k];
+            }
+            val = poisoned ? inf : val;
+            const bool better = inbq[q] && (val < best);            // strict <: HUGE_VAL never wins
+            best = better ? val : best;
+            has = has || better;
+            // the gradient only counts within epsilon of the surface (scale == 0 beyond it, below): a field
+            // that is the nearest of no sphere of the wavefront inside that range is not rotated back
+            if (__builtin_amdgcn_ballot_w64(better && (val - radius < b.epsilon)) == 0ull) continue;
+#pragma unroll
+            for (int k=0; k<3; k++)
+            {
+               const real gw = F.W[k*3+0]*df[0] + F.W[k*3+1]*df[1] + F.W[k*3+2]*df[2];      // grid -> world, per metre
+               bgrad[k] = better ? gw : bgrad[k];
+            }
+         }
+      };
 #ifndef ORC_ABLATE_SDF
-         // The fields in cell units (DevSdfCell), their descriptors by scalar loads from global memory: the
-         // constants enter the products as scalar operands (staged in LDS, as the 16-lane path has them, every one
-         // of them was a broadcast read into a vector register: ~50 per field and lane).  The cell reads of up to
-         // four fields are issued before any is used (a field per trip would wait for its four reads, an L2
-         // round trip, before the next field's addresses are formed).
-         typedef const __attribute__((address_space(4))) DevSdfCell<real> CellDesc;
-         CellDesc * fc = (CellDesc *) b.sdfc;
-         for (int i0=0; i0<b.n_sdfs; i0+=4)
-         {
-            real v0[4], vn[4][3], fr[4][3];
-            bool prev[4][3], inbq[4];
-            bool use[4] = { false, false, false, false };              // wave-uniform: some sphere of the wavefront is inside the field
-#pragma unroll
-            for (int q=0; q<4; q++)
-            {
-               if (i0 + q >= b.n_sdfs) continue;                       // wave-uniform
-               CellDesc & F = fc[i0 + q];
-               real gx[3];
-               bool inb = live;
-#pragma unroll
-               for (int k=0; k<3; k++)
-               {
-                  gx[k] = F.M[k*3+0]*p[0] + F.M[k*3+1]*p[1] + F.M[k*3+2]*p[2] + F.t[k];
-                  inb = inb && !(gx[k] < (real)0) && !(gx[k] > F.fsize[k]);      // the reference's x < 0 || x > 1 (grid.c:196-199)
-               }
-               // a field none of the wavefront's spheres is inside of contributes nothing (the reference
-               // skips an out-of-bounds lookup, src/orcdchomp_mod.cpp:1176-1183): no cells, no reads
-               use[q] = (__builtin_amdgcn_ballot_w64(inb) != 0ull);
-               if (!use[q]) continue;
-               if (dbg) dbg[5]++;
-               inbq[q] = inb;
-               int off = 0;
-#pragma unroll
-               for (int k=0; k<3; k++)
-               {
-                  const real g = inb ? gx[k] : (real)0.25;             // lanes outside read cell 0 (valid memory), results masked
-                  real fl = M<real>::floor_(g);
-                  fl = M<real>::min_(fl, F.fsize_m1[k]);               // g == size: the last cell (grid.c:203)
-                  fr[q][k] = (g - fl) - (real)0.5;                     // offset from the cell centre, in cells
-                  // one-sided difference towards the nearer neighbour, inwards at the faces (grid.c:372-389)
-                  prev[q][k] = (fl == (real)0) ? false : ((fl == F.fsize_m1[k]) ? true : (fr[q][k] < (real)0));
-                  off += (int) fl * ((k == 2) ? (int) sizeof(real) : F.stride_b[k]);
-               }
-               const char * base = (const char *) F.data;
-               v0[q] = *(const real *)(base + off);
-#pragma unroll
-               for (int k=0; k<3; k++)
-               {
-                  const int sb = (k == 2) ? (int) sizeof(real) : F.stride_b[k];
-                  vn[q][k] = *(const real *)(base + (off + (prev[q][k] ? -sb : sb)));
-               }
-            }
-#pragma unroll
-            for (int q=0; q<4; q++)
-            {
-               if (i0 + q >= b.n_sdfs || !use[q]) continue;
-               CellDesc & F = fc[i0 + q];
-               bool poisoned = (v0[q] == inf);
-               real val = v0[q], df[3];
-#pragma unroll
-               for (int k=2; k>=0; k--)                                 // the reference walks the axes z, y, x
-               {
-                  poisoned = poisoned || (vn[q][k] == inf);
-                  const real dd = vn[q][k] - v0[q];
-                  df[k] = prev[q][k] ? -dd : dd;                        // after - before
-                  val += df[k] * fr[q][k];
-               }
-               val = poisoned ? inf : val;
-               const bool better = inbq[q] && (val < best);            // strict <: HUGE_VAL never wins
-               best = better ? val : best;
-               has = has || better;
-               // the gradient only counts within epsilon of the surface (scale == 0 beyond it, below): a field
-               // that is the nearest of no sphere of the wavefront inside that range is not rotated back
-               if (__builtin_amdgcn_ballot_w64(better && (val - radius < b.epsilon)) == 0ull) continue;
-#pragma unroll
-               for (int k=0; k<3; k++)
-               {
-                  const real gw = F.W[k*3+0]*df[0] + F.W[k*3+1]*df[1] + F.W[k*3+2]*df[2];      // grid -> world, per metre
-                  bgrad[k] = better ? gw : bgrad[k];
-               }
-            }
-         }
+      sdf_issue(0);
 #endif
-         const bool on = live && has;
-         const real dist = best - radius;
-         const real de = dist - b.epsilon;
-         real cs = (dist < (real)0) ? ((real)0.5 * b.epsilon - dist)
-                 : ((dist < b.epsilon) ? ((real)0.5 * inv_eps) * de * de : (real)0);
-         cs *= vnorm * b.obs_factor;
-         cs = on ? cs : (real)0;
-         cost_sphere += (double) cs;
-         const real scale = (dist < (real)0) ? (real)(-1) : ((dist < b.epsilon) ? dist * inv_eps - (real)1 : (real)0);
-         const real sc2 = scale * (vnorm * b.obs_factor);
-         real xg[3], xc[3];
-#pragma unroll
-         for (int k=0; k<3; k++) { xg[k] = (scale == (real)0) ? (real)0 : bgrad[k] * sc2; xc[k] = acc[k]; }
-         const real pg = moving ? (xg[0]*vel[0] + xg[1]*vel[1] + xg[2]*vel[2]) * inv_vn2 : (real)0;
-         const real pc2 = moving ? (xc[0]*vel[0] + xc[1]*vel[1] + xc[2]*vel[2]) * inv_vn2 : (real)0;
-         // x_grad -= cost * curvature, curvature = xc/|v|^2; then c_grad += |v| J^T x_grad.  |v| == 0:
-         // the reference's dgemv(alpha=0) leaves c_grad untouched, so the sphere is skipped (SURVEY 8a C2)
-         const real cw = cs * inv_vn2;
-         const bool push = on && do_iteration && (vnorm != (real)0);
-#pragma unroll
-         for (int k=0; k<3; k++)
-         {
-            const real val = vnorm * ((xg[k] - pg * vel[k]) - cw * (xc[k] - pc2 * vel[k]));
-            f[k] = push ? val : (real)0;
-         }
-      }
-
       ORC_GMARK(0);
       // ---- self collision (src/orcdchomp_mod.cpp:1251-1317) ----
       // inactive spheres have no lane: only this lane's side of the pair
@@ -370,6 +349,40 @@ __device__ __forceinline__ void cost_tile_generic(const BT & b, const ModelView<
             }
          }
       }
+      // ---- the obstacle term's second half: values and gradients of the fields, the sphere's cost and force ----
+#ifndef ORC_ABLATE_SDF
+      sdf_finish(0);
+      for (int i0=4; i0<b.n_sdfs; i0+=4) { sdf_issue(i0); sdf_finish(i0); }      // (more than four fields: the rest one batch at a time)
+#endif
+      {
+         const bool on = live && has;
+         const real dist = best - radius;
+         const real de = dist - b.epsilon;
+         real cs = (dist < (real)0) ? ((real)0.5 * b.epsilon - dist)
+                 : ((dist < b.epsilon) ? ((real)0.5 * inv_eps) * de * de : (real)0);
+         cs *= vnorm * b.obs_factor;
+         cs = on ? cs : (real)0;
+         cost_sphere += (double) cs;
+         const real scale = (dist < (real)0) ? (real)(-1) : ((dist < b.epsilon) ? dist * inv_eps - (real)1 : (real)0);
+         const real sc2 = scale * (vnorm * b.obs_factor);
+         real xg[3], xc[3];
+#pragma unroll
+         for (int k=0; k<3; k++) { xg[k] = (scale == (real)0) ? (real)0 : bgrad[k] * sc2; xc[k] = acc[k]; }
+         const real pg = moving ? (xg[0]*vel[0] + xg[1]*vel[1] + xg[2]*vel[2]) * inv_vn2 : (real)0;
+         const real pc2 = moving ? (xc[0]*vel[0] + xc[1]*vel[1] + xc[2]*vel[2]) * inv_vn2 : (real)0;
+         // x_grad -= cost * curvature, curvature = xc/|v|^2; then c_grad += |v| J^T x_grad.  |v| == 0:
+         // the reference's dgemv(alpha=0) leaves c_grad untouched, so the sphere is skipped (SURVEY 8a C2)
+         const real cw = cs * inv_vn2;
+         const bool push = on && do_iteration && (vnorm != (real)0);
+#pragma unroll
+         for (int k=0; k<3; k++)
+         {
+            const real val = vnorm * ((xg[k] - pg * vel[k]) - cw * (xc[k] - pc2 * vel[k]));
+            f[k] += push ? val : (real)0;
+         }
+      }
+
+
       ORC_GMARK(2);
       if (live) cost_lane += cost_sphere;
 

@@ -237,6 +237,18 @@ __device__ __forceinline__ void fk_waypoint_triad(const ModelView<real> & mod, c
    for (int idx=0; idx<n_steps; idx++)
    {
       const int j = joint_of(idx);
+      const bool own = (idx >= n_anc);                                    // (wave-uniform)
+      // the joint's staged numbers first: the wait for them (LDS) then does not also wait for the scalar loads of
+      // the record fetched ahead, which are issued behind it (both count on lgkmcnt, and scalar loads return out of order)
+      real sn = 0, cs = 0, qp = 0;
+      if (own)
+      {
+         const real * st = ax_wp + j*6;
+         sn = st[0]; cs = st[1]; qp = st[2];
+#if ORC_FK_AHEAD > 1
+         __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+      }
       DevFkJoint<real> J;
       if (AHEAD)
       {
@@ -244,14 +256,7 @@ __device__ __forceinline__ void fk_waypoint_triad(const ModelView<real> & mod, c
          nxt = fk_record<real, true>(mod.fkj + joint_of((idx + 1 < n_steps) ? idx + 1 : idx));      // the next joint's record, a step ahead
       }
       else J = fk_record<real, false>(mod.fkj + j);
-      const bool own = (idx >= n_anc);                                    // (wave-uniform)
-      real sn, cs, qp;
-      if (own)
-      {
-         const real * st = ax_wp + j*6;
-         sn = st[0]; cs = st[1]; qp = st[2];
-      }
-      else
+      if (!own)
       {
          const bool revolute = ((J.ctl >> 24) & 1) != 0;
          const real q = row[(J.ctl >> 25) & 127];
