@@ -115,6 +115,10 @@ int orc_set_workgroup_threads(orc_module * mod, int threads);
 int orc_robot_set_link_names(orc_module * mod, const char * name, const char * const * names, int n);
 int orc_robot_add_manipulator(orc_module * mod, const char * name, const char * manip, int ee_link, const double tool_pose[7]);
 int orc_robot_set_active_manipulator(orc_module * mod, const char * name, const char * manip);
+/* Pairs of links the robot description declares adjacent (OpenRAVE robot files: <adjacent>linkA linkB</adjacent>;
+ * KinBody::GetAdjacentLinks): RobotBase::CheckSelfCollision, which the re-check of mod::gettraj calls
+ * (src/orcdchomp_mod.cpp:2998-2999), never tests them.  link_pairs [n_pairs][2] link indices. */
+int orc_robot_set_adjacent_links(orc_module * mod, const char * name, const int * link_pairs, int n_pairs);
 
 /* a kinbody made of oriented boxes (InitFromBoxes-style); box_poses [n_boxes][7]
  * in the kinbody frame, half_extents [n_boxes][3] */
@@ -185,8 +189,11 @@ int orc_batch_gettraj(orc_module * mod, int batch_id, double * traj_out, size_t 
  * a batch at once, on the device: every run's trajectory is retimed at the dof velocity limits and
  * sampled every 0.04 rad of C-space distance like the reference's loop; a sample collides when an
  * active sphere penetrates a field (the optimizer's own model; OpenRAVE's mesh checker is third
- * party).  Per run (any output may be NULL): collides 0/1, time of the first contact, XML index of
- * the sphere, index of the field, penetration depth in metres. */
+ * party) or, the reference's `|| CheckSelfCollision` (src/orcdchomp_mod.cpp:2998-2999), when two spheres on
+ * links that may collide overlap (not the same link, not parent and child, not links whose spheres already
+ * overlap with all dofs at zero: the sphere model's stand-in for OpenRAVE's adjacent links).  Per run (any
+ * output may be NULL): collides 0/1, time of the first contact, XML index of the sphere, index of the field
+ * (a pair of spheres: -2 - the XML index of the other sphere), penetration depth in metres. */
 int orc_batch_collision_verdict(orc_module * mod, int batch_id, int * collides_out, double * time_out,
                                 int * sphere_out, int * field_out, double * depth_out);
 /* optimizer state read-back for tests: which = "G", "AG", "T" ([n_runs][m][n]) */

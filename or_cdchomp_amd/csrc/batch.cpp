@@ -955,6 +955,7 @@ void BatchShard::build_device(const Robot & robot)
 }
 
 void BatchShard::collision_verdict(const std::vector<int> & offs, const std::vector<int> & seg, const std::vector<double> & u,
+   const std::vector<int> & pairs, const std::vector<double> & pair_rsum, const std::vector<double> & inact_pos,
    int * key_out, double * depth_out)
 {
    DeviceGuard guard(device);
@@ -967,24 +968,29 @@ void BatchShard::collision_verdict(const std::vector<int> & offs, const std::vec
    hip_check(hipMemcpyAsync(d_seg, seg.data(), ns*sizeof(int), hipMemcpyHostToDevice, st), "verdict seg");
    hip_check(hipMemcpyAsync(d_xml, slot_xml.data(), slot_xml.size()*sizeof(int), hipMemcpyHostToDevice, st), "verdict xml");
    hip_check(hipMemsetAsync(d_depth, 0, n_runs*sizeof(double), st), "verdict depth");
-   void * d_u = nullptr;
+   const int n_pairs = (int) pair_rsum.size();
+   int * d_pairs = dev_alloc<int>(pairs.size());
+   hip_check(hipMemcpyAsync(d_pairs, pairs.data(), pairs.size()*sizeof(int), hipMemcpyHostToDevice, st), "verdict pairs");
+   void * d_u = nullptr, * d_rsum = nullptr, * d_inact = nullptr;
    hipError_t e;
    if (params.precision == 64)
    {
-      d_u = upload<double>(u, st);
+      d_u = upload<double>(u, st); d_rsum = upload<double>(pair_rsum, st); d_inact = upload<double>(inact_pos, st);
       DevVerdict<double> v;
       v.model = (const DevModel<double> *) d_model_; v.sdfs = (const DevSdf<double> *) d_sdfs_; v.n_sdfs = n_sdfs_;
       v.n_runs = n_runs; v.n_points = n_points; v.n = n; v.traj = (const double *) d_traj_;
       v.offs = d_offs; v.seg = d_seg; v.u = (const double *) d_u; v.slot_xml = d_xml; v.key_out = d_key; v.depth_out = d_depth;
+      v.n_pairs = n_pairs; v.pairs = d_pairs; v.pair_rsum = (const double *) d_rsum; v.inact_pos = (const double *) d_inact;
       e = orc_launch_verdict_f64(v, orc_verdict_lds_bytes(n, Sa_, Sa_real_, nj_, 8), st, tree_ & 1);
    }
    else
    {
-      d_u = upload<float>(u, st);
+      d_u = upload<float>(u, st); d_rsum = upload<float>(pair_rsum, st); d_inact = upload<float>(inact_pos, st);
       DevVerdict<float> v;
       v.model = (const DevModel<float> *) d_model_; v.sdfs = (const DevSdf<float> *) d_sdfs_; v.n_sdfs = n_sdfs_;
       v.n_runs = n_runs; v.n_points = n_points; v.n = n; v.traj = (const float *) d_traj_;
       v.offs = d_offs; v.seg = d_seg; v.u = (const float *) d_u; v.slot_xml = d_xml; v.key_out = d_key; v.depth_out = d_depth;
+      v.n_pairs = n_pairs; v.pairs = d_pairs; v.pair_rsum = (const float *) d_rsum; v.inact_pos = (const float *) d_inact;
       e = orc_launch_verdict_f32(v, orc_verdict_lds_bytes(n, Sa_, Sa_real_, nj_, 4), st, tree_ & 1);
    }
    hip_check(e, "collision_verdict_kernel launch");
@@ -992,6 +998,7 @@ void BatchShard::collision_verdict(const std::vector<int> & offs, const std::vec
    hip_check(hipMemcpyAsync(depth_out, d_depth, n_runs*sizeof(double), hipMemcpyDeviceToHost, st), "verdict depth");
    hip_check(hipStreamSynchronize(st), "verdict sync");
    dev_free(d_offs); dev_free(d_seg); dev_free(d_xml); dev_free(d_key); dev_free(d_depth); dev_free(d_u);
+   dev_free(d_pairs); dev_free(d_rsum); dev_free(d_inact);
 }
 
 // which iterations of this call resample the momentum, and with what noise
@@ -1386,6 +1393,7 @@ void Batch::get_phase_cycles(long long * out)
 }
 
 void Batch::collision_verdict(const std::vector<int> & soffs, const std::vector<int> & seg, const std::vector<double> & u,
+   const std::vector<int> & pairs, const std::vector<double> & pair_rsum, const std::vector<double> & inact_pos,
    int * key_out, double * depth_out)
 {
    for_shards([&](size_t k) {
@@ -1394,7 +1402,7 @@ void Batch::collision_verdict(const std::vector<int> & soffs, const std::vector<
       for (int r=r0; r<=r1; r++) so[r - r0] = soffs[r] - soffs[r0];
       const std::vector<int> sg(seg.begin() + soffs[r0], seg.begin() + soffs[r1]);
       const std::vector<double> su(u.begin() + soffs[r0], u.begin() + soffs[r1]);
-      shards[k]->collision_verdict(so, sg, su, key_out + r0, depth_out + r0);
+      shards[k]->collision_verdict(so, sg, su, pairs, pair_rsum, inact_pos, key_out + r0, depth_out + r0);
    }, true);
 }
 

@@ -193,6 +193,21 @@ int orc_robot_add_manipulator(orc_module * mod, const char * name, const char * 
    });
 }
 
+int orc_robot_set_adjacent_links(orc_module * mod, const char * name, const int * link_pairs, int n_pairs)
+{
+   return guarded(mod, [&] {
+      orc::Robot & r = mod->impl->robot(name);
+      if (n_pairs < 0 || (n_pairs > 0 && !link_pairs)) throw std::runtime_error("bad adjacent link list!");
+      r.adjacent.clear();
+      for (int k=0; k<n_pairs; k++)
+      {
+         const int a = link_pairs[2*k], b = link_pairs[2*k+1];
+         if (a < 0 || a >= r.n_links || b < 0 || b >= r.n_links) throw std::runtime_error("adjacent link out of range!");
+         r.adjacent.push_back(std::make_pair(a, b));
+      }
+   });
+}
+
 int orc_robot_set_active_manipulator(orc_module * mod, const char * name, const char * manip)
 {
    return guarded(mod, [&] {

@@ -1764,10 +1764,27 @@ void collision_verdict_kernel(DevVerdict<real> v)
             if (sdf_lookup(F, gp, val, gg)) continue;                 // outside this field
             if (val - radius < (real)0)
             {
-               const int key = ((base - s0 + s) << 12) | (xml_s[slot] << 4) | i;
+               const int key = ((base - s0 + s) << 16) | (xml_s[slot] << 8) | i;
                if (key < my_key) { my_key = key; my_depth = (double)(radius - val); }
                atomicMin(&key_s[0], key);
             }
+         }
+      }
+      // self collision: a pair of spheres on links that may collide overlaps
+      for (int item=tid; item<count*v.n_pairs; item+=ORC_BLOCK)
+      {
+         const int s = item / v.n_pairs, pi = item - s*v.n_pairs;
+         const int ea = v.pairs[pi*4+0], eb = v.pairs[pi*4+1];
+         const real * pa = (ea >= 0) ? pos_s + s*pstr + ea*3 : v.inact_pos + (-1 - ea)*3;
+         const real * pb = (eb >= 0) ? pos_s + s*pstr + eb*3 : v.inact_pos + (-1 - eb)*3;
+         const real dx = pa[0]-pb[0], dy = pa[1]-pb[1], dz = pa[2]-pb[2];
+         const real dist = M<real>::sqrt_(dx*dx + dy*dy + dz*dz);
+         const real rs = v.pair_rsum[pi];
+         if (dist - rs < (real)0)
+         {
+            const int key = ((base - s0 + s) << 16) | (1 << 15) | (v.pairs[pi*4+2] << 8) | v.pairs[pi*4+3];
+            if (key < my_key) { my_key = key; my_depth = (double)(rs - dist); }
+            atomicMin(&key_s[0], key);
          }
       }
       __syncthreads();

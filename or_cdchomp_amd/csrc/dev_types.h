@@ -254,7 +254,15 @@ struct DevVerdict
    const int * seg;            // [samples] segment of the trajectory the sample lies on
    const real * u;             // [samples] position on the segment, 0..1
    const int * slot_xml;       // [Sa lanes] XML index of the sphere in a slot, -1: empty
-   int * key_out;              // [n_runs] first contact: (sample << 12) | (XML sphere << 4) | field, or INT_MAX
+   // self collision (src/orcdchomp_mod.cpp:2998-2999: `|| CheckSelfCollision`): the pairs of spheres on links that may
+   // collide, XML order (a < b); an end of a pair is a slot of the position row, or -1 - k: inactive sphere k of inact_pos
+   int n_pairs;
+   const int * pairs;          // [n_pairs][4]: end a, end b, XML index of a, XML index of b
+   const real * pair_rsum;     // [n_pairs] r_a + r_b
+   const real * inact_pos;     // [inactive spheres][3] world positions
+   // first contact of a run, or INT_MAX: (sample << 16) | (self << 15) | (XML sphere (a) << 8) | (field, or XML sphere b):
+   // within a sample the fields come first (sphere, field order), then the pairs
+   int * key_out;              // [n_runs]
    double * depth_out;         // [n_runs] penetration depth of that contact
 };
 

@@ -44,6 +44,39 @@ bool Robot::does_affect(int dof, int link) const
    return false;
 }
 
+std::vector<unsigned char> Robot::self_pairs_excluded() const
+{
+   const int nl = n_links;
+   std::vector<unsigned char> excl((size_t) nl * nl, 0);
+   for (int a=0; a<nl; a++)
+   {
+      excl[(size_t) a*nl + a] = 1;
+      if (parent[a] >= 0) { excl[(size_t) a*nl + parent[a]] = 1; excl[(size_t) parent[a]*nl + a] = 1; }
+   }
+   for (const auto & pr : adjacent) { excl[(size_t) pr.first*nl + pr.second] = 1; excl[(size_t) pr.second*nl + pr.first] = 1; }
+   std::vector<Xform> frames;
+   fk(Pose(), std::vector<double>(n_dof > 0 ? n_dof : 1, 0.0), frames);
+   std::vector<double> pw(spheres.size() * 3);
+   for (size_t a=0; a<spheres.size(); a++)
+   {
+      double r[3];
+      mat3_vec(frames[spheres[a].link].R, spheres[a].pos, r);
+      for (int k=0; k<3; k++) pw[a*3+k] = r[k] + frames[spheres[a].link].t[k];
+   }
+   for (size_t a=0; a<spheres.size(); a++)
+      for (size_t b=a+1; b<spheres.size(); b++)
+      {
+         double d2 = 0.0;
+         for (int k=0; k<3; k++) { const double d = pw[a*3+k] - pw[b*3+k]; d2 += d*d; }
+         if (std::sqrt(d2) - (spheres[a].radius + spheres[b].radius) < 0.0)
+         {
+            excl[(size_t) spheres[a].link*nl + spheres[b].link] = 1;
+            excl[(size_t) spheres[b].link*nl + spheres[a].link] = 1;
+         }
+      }
+   return excl;
+}
+
 void Robot::fk(const Pose & base, const std::vector<double> & q, std::vector<Xform> & frames) const
 {
    frames.resize(n_links);
@@ -317,16 +350,33 @@ std::string serialize_traj(const std::string & robot, const std::vector<int> & a
 {
    std::ostringstream o;
    const int nd = n - col0;
-   o << std::setprecision(std::numeric_limits<double>::digits10 + 1);
+   o << std::setprecision(std::numeric_limits<double>::max_digits10);
    o << "<trajectory>\n<configuration>\n<group name=\"joint_values " << robot;
    for (int a : adofs) o << " " << a;
    o << "\" offset=\"0\" dof=\"" << nd << "\" interpolation=\"linear\"/>\n";
    o << "<group name=\"deltatime\" offset=\"" << nd << "\" dof=\"1\" interpolation=\"\"/>\n";
+   if (col0)
+   {
+      // floating base: the second trajectory of src/orcdchomp_mod.cpp:2912-2956 merged in: the base pose of every
+      // waypoint as `affine_transform <robot> <DOF_Transform>` (x y z, then the quaternion in OpenRAVE's order
+      // w x y z) and its finite-difference velocities over the waypoint's deltatime as `affine_velocities`
+      const int dof_transform = 1 | 2 | 4 | 32;      // OpenRAVE::DOF_XYZ | DOF_RotationQuat
+      o << "<group name=\"affine_transform " << robot << " " << dof_transform << "\" offset=\"" << nd + 1 << "\" dof=\"7\" interpolation=\"linear\"/>\n";
+      o << "<group name=\"affine_velocities " << robot << " " << dof_transform << "\" offset=\"" << nd + 8 << "\" dof=\"7\" interpolation=\"next\"/>\n";
+   }
    o << "</configuration>\n<data count=\"" << n_points << "\">\n";
+   static const int order[7] = { 0, 1, 2, 6, 3, 4, 5 };      // libcd x y z qx qy qz qw -> x y z qw qx qy qz
    for (int i=0; i<n_points; i++)
    {
       for (int j=col0; j<n; j++) o << traj[(size_t) i*n+j] << " ";
-      o << deltatime[i] << (i+1 < n_points ? " " : "");
+      o << deltatime[i];
+      if (col0)
+      {
+         for (int k=0; k<7; k++) o << " " << traj[(size_t) i*n + order[k]];
+         for (int k=0; k<7; k++)
+            o << " " << ((i > 0) ? (traj[(size_t) i*n + order[k]] - traj[(size_t)(i-1)*n + order[k]]) / deltatime[i] : 0.0);
+      }
+      if (i+1 < n_points) o << " ";
    }
    o << "\n</data>\n</trajectory>\n";
    return o.str();
@@ -347,29 +397,42 @@ std::vector<double> retime_linear(const double * traj, int n_points, int n, int 
    return dtm;
 }
 
-// reads a document written by serialize_traj: waypoints [count][dof] and their deltatimes
-bool parse_traj(const std::string & text, std::vector<double> & wp, std::vector<double> & dtm, int & count, int & dof)
+// reads a trajectory document: the rows of its <data> block and where its groups sit in a row.  A document without
+// a <configuration> block (the bare form the tests also pass) is joint values followed by one deltatime.
+struct TrajDoc
+{
+   int count = 0, width = 0;
+   std::vector<double> vals;                       // [count][width]
+   int joint_off = 0, joint_dof = 0, dt_off = -1, base_off = -1;
+};
+bool parse_traj(const std::string & text, TrajDoc & doc)
 {
    const size_t c0 = text.find("<data count=\"");
    if (c0 == std::string::npos) return false;
-   count = std::atoi(text.c_str() + c0 + 13);
+   doc.count = std::atoi(text.c_str() + c0 + 13);
    const size_t d0 = text.find('>', c0), d1 = text.find("</data>", c0);
-   if (d0 == std::string::npos || d1 == std::string::npos || count < 1) return false;
-   std::vector<double> vals;
+   if (d0 == std::string::npos || d1 == std::string::npos || doc.count < 1) return false;
    std::istringstream is(text.substr(d0+1, d1-d0-1));
    double v;
-   while (is >> v) vals.push_back(v);
-   if (vals.empty() || vals.size() % (size_t) count) return false;
-   const int width = (int)(vals.size() / count);
-   dof = width - 1;
-   if (dof < 1) return false;
-   wp.resize((size_t) count * dof); dtm.resize(count);
-   for (int i=0; i<count; i++)
+   while (is >> v) doc.vals.push_back(v);
+   if (doc.vals.empty() || doc.vals.size() % (size_t) doc.count) return false;
+   doc.width = (int)(doc.vals.size() / doc.count);
+   bool any_group = false;
+   for (size_t g=text.find("<group name=\""); g!=std::string::npos && g<c0; g=text.find("<group name=\"", g+1))
    {
-      for (int j=0; j<dof; j++) wp[(size_t) i*dof+j] = vals[(size_t) i*width+j];
-      dtm[i] = vals[(size_t) i*width+dof];
+      const size_t n0 = g + 13, n1 = text.find('"', n0);
+      const size_t o0 = text.find("offset=\"", n1), f0 = text.find("dof=\"", n1);
+      if (n1 == std::string::npos || o0 == std::string::npos || f0 == std::string::npos) return false;
+      const std::string name = text.substr(n0, n1 - n0);
+      const int off = std::atoi(text.c_str() + o0 + 8), dof = std::atoi(text.c_str() + f0 + 5);
+      if (off < 0 || dof < 1 || off + dof > doc.width) return false;
+      any_group = true;
+      if (name.compare(0, 12, "joint_values") == 0) { doc.joint_off = off; doc.joint_dof = dof; }
+      else if (name == "deltatime") doc.dt_off = off;
+      else if (name.compare(0, 16, "affine_transform") == 0 && dof == 7) doc.base_off = off;
    }
-   return true;
+   if (!any_group) { doc.joint_off = 0; doc.joint_dof = doc.width - 1; doc.dt_off = doc.width - 1; }
+   return doc.joint_dof >= 1 && doc.dt_off >= 0;
 }
 
 } // namespace
@@ -813,34 +876,45 @@ std::string Module::cmd_create(const std::vector<std::string> & argv, bool batch
    std::vector<double> sampled;
    if (!batchmode && have_starttraj)
    {
-      if (p.floating_base) throw std::runtime_error("starttraj with floating_base is not supported by this build");
-      std::vector<double> wp, dtm; int count = 0, dof = 0;
-      if (!parse_traj(starttraj, wp, dtm, count, dof)) throw std::runtime_error("Cannot parse starttraj!");
+      TrajDoc doc;
+      if (!parse_traj(starttraj, doc)) throw std::runtime_error("Cannot parse starttraj!");
+      const int dof = doc.joint_dof, count = doc.count, c0 = p.floating_base ? 7 : 0, nn = c0 + dof;
       if (dof != (int) r.active_dofs.size()) throw std::runtime_error("size of adofgoal does not match active dofs!");
+      if (p.floating_base && doc.base_off < 0) throw std::runtime_error("starttraj with floating_base needs an affine_transform group!");
       std::vector<double> tcum(count, 0.0);
-      for (int k=1; k<count; k++) tcum[k] = tcum[k-1] + dtm[k];
+      for (int k=1; k<count; k++) tcum[k] = tcum[k-1] + doc.vals[(size_t) k*doc.width + doc.dt_off];
       const double duration = tcum[count-1];
-      sampled.resize((size_t) p.n_points * dof);
+      sampled.resize((size_t) p.n_points * nn);
+      int seg = 0;
       for (int k=0; k<p.n_points; k++)
       {
          // untimed documents (all deltatimes zero) are sampled uniformly over the waypoint index
          const double t = duration > 0.0 ? k * duration / (p.n_points - 1) : (double) k * (count - 1) / (p.n_points - 1);
-         int seg = 0; double u = 0.0;
+         double u = 0.0;
          if (duration > 0.0)
          {
             while (seg < count-2 && tcum[seg+1] < t) seg++;
             const double dt = tcum[seg+1] - tcum[seg];
-            u = dt > 0.0 ? (t - tcum[seg]) / dt : 0.0;
+            u = (count > 1 && dt > 0.0) ? (t - tcum[seg]) / dt : 0.0;
          }
          else { seg = std::min((int) t, count-2); if (seg < 0) seg = 0; u = t - seg; }
          if (count == 1) { seg = 0; u = 0.0; }
-         for (int j=0; j<dof; j++)
+         const double * r0 = &doc.vals[(size_t) seg*doc.width], * r1 = &doc.vals[(size_t) std::min(seg+1, count-1)*doc.width];
+         double * row = &sampled[(size_t) k*nn];
+         if (p.floating_base)
          {
-            const double a0 = wp[(size_t) seg*dof+j], a1 = wp[(size_t) std::min(seg+1, count-1)*dof+j];
-            sampled[(size_t) k*dof+j] = a0 + (a1 - a0) * u;
+            // the base: OpenRAVE's x y z qw qx qy qz, into libcd's order, normalised (mod.cpp:2389-2399)
+            double vec[7];
+            for (int j=0; j<7; j++) vec[j] = r0[doc.base_off+j] + (r1[doc.base_off+j] - r0[doc.base_off+j]) * u;
+            Pose bp;
+            bp.v[0] = vec[0]; bp.v[1] = vec[1]; bp.v[2] = vec[2]; bp.v[3] = vec[4]; bp.v[4] = vec[5]; bp.v[5] = vec[6]; bp.v[6] = vec[3];
+            pose_normalize(bp);
+            for (int j=0; j<7; j++) row[j] = bp.v[j];
          }
+         for (int j=0; j<dof; j++) row[c0+j] = r0[doc.joint_off+j] + (r1[doc.joint_off+j] - r0[doc.joint_off+j]) * u;
       }
       adofgoal.assign(sampled.end() - dof, sampled.end());
+      if (p.floating_base) { basegoal.assign(sampled.end() - nn, sampled.end() - dof); have_basegoal = true; }
    }
    if (!batchmode && adofgoal.size() != r.active_dofs.size())
       throw std::runtime_error("size of adofgoal does not match active dofs!");
@@ -1010,17 +1084,46 @@ void Module::batch_collision_verdict(int id, int * collides, double * time, int 
       const std::vector<double> dtm = retime_linear(tk, b.n_points, b.n, col0, vmax);
       plan_collision_samples(tk, b.n_points, b.n, col0, dtm, seg, u, times);
       offs[k+1] = (int) seg.size();
-      if (offs[k+1] - offs[k] >= (1 << 19)) throw std::runtime_error("trajectory too long for the batched collision verdict!");
+      if (offs[k+1] - offs[k] >= (1 << 15)) throw std::runtime_error("trajectory too long for the batched collision verdict!");
+   }
+   // the pairs of the self-collision leg (`|| CheckSelfCollision`, mod.cpp:2998-2999): spheres on links that may
+   // collide, in XML order; an end is a slot of the device's position row or an inactive sphere's world position
+   std::vector<int> pairs; std::vector<double> rsum, inact_pos;
+   {
+      const std::vector<unsigned char> excl = rob.self_pairs_excluded();
+      const int ns = (int) rob.spheres.size();
+      std::vector<int> end_of(ns, 0);
+      std::vector<Xform> frames;
+      rob.fk(rob.transform, rob.dof_values, frames);
+      for (int si=0; si<ns; si++)
+      {
+         int slot = -1;
+         for (size_t q=0; q<b.slot_xml.size(); q++) if (b.slot_xml[q] == si) slot = (int) q;
+         if (slot >= 0) { end_of[si] = slot; continue; }
+         end_of[si] = -1 - (int)(inact_pos.size() / 3);
+         double r[3];
+         mat3_vec(frames[rob.spheres[si].link].R, rob.spheres[si].pos, r);
+         for (int q=0; q<3; q++) inact_pos.push_back(r[q] + frames[rob.spheres[si].link].t[q]);
+      }
+      for (int a=0; a<ns; a++)
+         for (int c=a+1; c<ns; c++)
+         {
+            if (excl[(size_t) rob.spheres[a].link * rob.n_links + rob.spheres[c].link]) continue;
+            pairs.push_back(end_of[a]); pairs.push_back(end_of[c]); pairs.push_back(a); pairs.push_back(c);
+            rsum.push_back(rob.spheres[a].radius + rob.spheres[c].radius);
+         }
+      if (ns > 128) throw std::runtime_error("too many spheres for the batched collision verdict!");
    }
    std::vector<int> key(b.n_runs); std::vector<double> dep(b.n_runs);
-   b.collision_verdict(offs, seg, u, key.data(), dep.data());
+   b.collision_verdict(offs, seg, u, pairs, rsum, inact_pos, key.data(), dep.data());
    for (int k=0; k<b.n_runs; k++)
    {
       const bool hit = key[k] != 0x7fffffff;
+      const bool self = hit && ((key[k] >> 15) & 1);
       if (collides) collides[k] = hit ? 1 : 0;
-      if (time) time[k] = hit ? times[(size_t) offs[k] + (key[k] >> 12)] : -1.0;
-      if (sphere) sphere[k] = hit ? ((key[k] >> 4) & 255) : -1;
-      if (field) field[k] = hit ? (key[k] & 15) : -1;
+      if (time) time[k] = hit ? times[(size_t) offs[k] + (key[k] >> 16)] : -1.0;
+      if (sphere) sphere[k] = hit ? ((key[k] >> 8) & 127) : -1;
+      if (field) field[k] = hit ? (self ? -2 - (key[k] & 255) : (key[k] & 255)) : -1;      // a pair: -2 - the other sphere
       if (depth) depth[k] = hit ? dep[k] : 0.0;
    }
 }
@@ -1079,6 +1182,7 @@ std::string Module::cmd_gettraj(const std::vector<std::string> & argv, bool batc
       const double step_time = total_dist > 0.0 ? duration * 0.04 / total_dist : duration + 1.0;
       std::vector<Xform> frames;
       std::vector<double> q = rob.dof_values;
+      const std::vector<unsigned char> self_excl = rob.self_pairs_excluded();
       bool collides = false;
       std::ostringstream details;
       int seg = 0; double tseg0 = 0.0;
@@ -1122,6 +1226,25 @@ std::string Module::cmd_gettraj(const std::vector<std::string> & argv, bool batc
                }
             }
          }
+         // ... || CheckSelfCollision (mod.cpp:2998-2999): two spheres on links that may collide overlap
+         for (size_t a=0; a<rob.spheres.size() && !collides; a++)
+            for (size_t c=a+1; c<rob.spheres.size(); c++)
+            {
+               const Robot::Sphere & sa = rob.spheres[a], & sc = rob.spheres[c];
+               if (self_excl[(size_t) sa.link * rob.n_links + sc.link]) continue;
+               double pa[3], pc[3], d2 = 0.0;
+               mat3_vec(frames[sa.link].R, sa.pos, pa);
+               mat3_vec(frames[sc.link].R, sc.pos, pc);
+               for (int k=0; k<3; k++) { const double d = (pa[k] + frames[sa.link].t[k]) - (pc[k] + frames[sc.link].t[k]); d2 += d*d; }
+               const double dist = std::sqrt(d2), rs = sa.radius + sc.radius;
+               if (dist - rs < 0.0)
+               {
+                  collides = true;
+                  details << "Collision at t=" << time << ": spheres " << a << " and " << c << " of " << b.robot_name
+                          << " overlap by " << (rs - dist) << " m\n";
+                  break;
+               }
+            }
       }
       last_collision_details = no_collision_details ? std::string() : details.str();
       if (collides && !no_collision_exception) throw std::runtime_error("Resulting trajectory is in collision!");

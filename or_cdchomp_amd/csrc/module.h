@@ -38,11 +38,16 @@ struct Robot                      // what the path reads from an OpenRAVE::Robot
    struct Manip { std::string name; int link; Pose tool; };   // GetEndEffectorTransform = link transform o tool
    std::vector<Manip> manips;
    int active_manip = 0;                       // GetActiveManipulator
+   std::vector<std::pair<int, int>> adjacent;  // link pairs the robot description declares adjacent (<adjacent> tags)
    // state
    Pose transform;
    std::vector<double> dof_values;
    std::vector<int> active_dofs;
    bool does_affect(int dof, int link) const;
+   // link pairs a self-collision check skips [n_links][n_links]: the same link, parent and child, the pairs the robot
+   // description declares adjacent, and links whose spheres already overlap with all dofs at zero (KinBody computes
+   // its non-adjacent links from the initial configuration the same way)
+   std::vector<unsigned char> self_pairs_excluded() const;
    // world frames of all links for the given state
    void fk(const Pose & base, const std::vector<double> & q, std::vector<Xform> & frames) const;
 };
@@ -135,6 +140,7 @@ public:
    void set_traj(const double * traj);          // [n_runs][n_points][n] host -> device (warm start)
    // first contact of every run's trajectory with a field, on the device (Module::batch_collision_verdict plans the samples)
    void collision_verdict(const std::vector<int> & offs, const std::vector<int> & seg, const std::vector<double> & u,
+                          const std::vector<int> & pairs, const std::vector<double> & pair_rsum, const std::vector<double> & inact_pos,
                           int * key_out, double * depth_out);
    void get_phase_cycles(long long * out);   // [n_runs][8], diagnostics (ORC_PHASE_TIMERS=1)
    // kernel timing: completed event pairs are added to the module's totals (all of them when `wait`)
@@ -215,6 +221,7 @@ public:
    void set_noise(const double * noise, int n_blocks);
    void set_traj(const double * traj);
    void collision_verdict(const std::vector<int> & offs, const std::vector<int> & seg, const std::vector<double> & u,
+                          const std::vector<int> & pairs, const std::vector<double> & pair_rsum, const std::vector<double> & inact_pos,
                           int * key_out, double * depth_out);
    void get_phase_cycles(long long * out);
    // the per-iteration log of create's dat_filename (src/orcdchomp_mod.cpp:2306-2310, 2811-2818)

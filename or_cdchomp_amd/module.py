@@ -92,6 +92,10 @@ class Module:
         self._check(self._lib.orc_robot_set_link_names(self._h, model.name.encode(), names, len(model.link_names)))
         for mname, link, tool in getattr(model, "manipulators", []):
             self.add_manipulator(model.name, mname, model.link_names.index(link), tool)
+        adj = getattr(model, "adjacent", [])
+        if adj:
+            pairs = np.ascontiguousarray([[model.link_names.index(a), model.link_names.index(b)] for a, b in adj], dtype=np.int32)
+            self._check(self._lib.orc_robot_set_adjacent_links(self._h, model.name.encode(), _ip(pairs), len(adj)))
         if transform is not None:
             self.set_robot_transform(model.name, transform)
         if dof_values is not None:

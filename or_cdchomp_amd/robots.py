@@ -41,6 +41,7 @@ class RobotModel:
     def __init__(self, name):
         self.name = name
         self.link_names = []
+        self.adjacent = []          # (link, link): pairs the robot description declares adjacent (<adjacent> tags)
         self.parent = []
         self.pose_parent_joint = []
         self.joint_type = []
@@ -102,6 +103,9 @@ class RobotModel:
             sphere_link=np.asarray([self.link_names.index(s[0]) for s in self.spheres], dtype=np.int32),
             sphere_pos=np.asarray([s[1] for s in self.spheres], dtype=np.float64).reshape(-1, 3),
             sphere_radius=np.asarray([s[2] for s in self.spheres], dtype=np.float64),
+            n_adjacent=len(self.adjacent),
+            adjacent=np.asarray([[self.link_names.index(a), self.link_names.index(b)] for a, b in self.adjacent],
+                                dtype=np.int32).reshape(-1, 2),
         )
 
 
@@ -164,6 +168,13 @@ def wam7():
     r.limit_lower.append(0.0)
     r.limit_upper.append(math.pi)
     r.add_spheres_xml(WAM_SPHERES_XML)
+    # links a self-collision check never tests against each other, as a robot file lists them in <adjacent> tags:
+    # the links either side of the arm's short links (the elbow wam3, the wrist wam5 / wam6) and the hand with the
+    # links next to it (the sphere model is fat around those joints)
+    for a, b in (("wam1", "wam3"), ("wam2", "wam4"), ("wam3", "wam5"), ("wam4", "wam6"), ("wam5", "wam7"), ("wam6", "handbase")):
+        r.adjacent.append((a, b))
+    for k in range(3):
+        r.adjacent += [("wam7", "Finger%d-1" % k), ("wam6", "Finger%d-1" % k), ("handbase", "Finger%d-2" % k), ("wam7", "Finger%d-2" % k)]
     # the arm's manipulator: end effector = the hand's base, tool frame 0.16 m along the arm
     r.manipulators.append(("arm", "handbase", [0.0, 0.0, 0.16, 0.0, 0.0, 0.0, 1.0]))
     return r

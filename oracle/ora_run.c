@@ -830,6 +830,8 @@ void ora_run_set_traj(ora_run * r, const double * traj) { memcpy(r->traj, traj, 
  * Floating base: the base columns are interpolated like the joints and renormalised.
  * Returns the number of samples walked; *collides 0/1 and the contact's time / XML sphere / field /
  * depth (radius - value). */
+void ora_robot_self_pairs(const ora_robot * rob, unsigned char * excl);
+
 int ora_run_collision_recheck(ora_run * r, const double * vmax /* [n_adof] */, int * collides, double * time_out,
    int * sphere_out, int * field_out, double * depth_out)
 {
@@ -837,6 +839,7 @@ int ora_run_collision_recheck(ora_run * r, const double * vmax /* [n_adof] */, i
    double * tcum = (double *) malloc((size_t) np * sizeof(double));
    double * q = (double *) malloc((size_t) r->robot->n_dof * sizeof(double));
    double total_dist = 0.0, duration, step_time, time;
+   unsigned char * excl = 0;
    int i, j, samples = 0, seg = 0;
    *collides = 0; *time_out = -1.0; *sphere_out = -1; *field_out = -1; *depth_out = 0.0;
    tcum[0] = 0.0;
@@ -893,10 +896,71 @@ int ora_run_collision_recheck(ora_run * r, const double * vmax /* [n_adof] */, i
             }
          }
       }
+      /* ... || boostrobot->CheckSelfCollision(report)  (src/orcdchomp_mod.cpp:2998-2999): the sphere model's
+       * stand-in: two spheres on links that may collide (ora_robot_self_pairs) overlap; first pair in XML order */
+      if (!*collides)
+      {
+         int a, b2;
+         if (!excl) { excl = (unsigned char *) malloc((size_t) r->robot->n_links * r->robot->n_links); ora_robot_self_pairs(r->robot, excl); }
+         for (a=0; a<r->robot->n_spheres && !*collides; a++)
+            for (b2=a+1; b2<r->robot->n_spheres; b2++)
+            {
+               const int la = r->robot->sphere_link[a], lb = r->robot->sphere_link[b2];
+               double pa[3], pb[3], d2 = 0.0, rs, dist;
+               if (la == lb || excl[la * r->robot->n_links + lb]) continue;
+               mat3_vec(r->fkR + 9*la, r->robot->sphere_pos + 3*a, pa);
+               mat3_vec(r->fkR + 9*lb, r->robot->sphere_pos + 3*b2, pb);
+               for (k=0; k<3; k++) { const double d = (pa[k] + r->fkt[3*la+k]) - (pb[k] + r->fkt[3*lb+k]); d2 += d*d; }
+               rs = r->robot->sphere_radius[a] + r->robot->sphere_radius[b2];
+               dist = sqrt(d2);
+               if (dist - rs < 0.0)
+               {
+                  *collides = 1; *time_out = time; *sphere_out = a; *field_out = -2 - b2;
+                  *depth_out = rs - dist;
+                  break;
+               }
+            }
+      }
       samples++;
    }
-   free(tcum); free(q);
+   free(tcum); free(q); free(excl);
    return samples;
+}
+
+/* Which pairs of links a self-collision check looks at.  OpenRAVE's CheckSelfCollision (third party) skips
+ * adjacent links: links joined by a joint, and links that already touch in the robot's initial configuration.
+ * The sphere model's restatement: excl[la][lb] = 1 when la == lb, when one is the other's parent, when the robot
+ * description declares the pair adjacent, or when any sphere of la overlaps any sphere of lb with all dofs at zero. */
+void ora_robot_self_pairs(const ora_robot * rob, unsigned char * excl /* [n_links][n_links] */)
+{
+   const int nl = rob->n_links;
+   const double ident[7] = { 0, 0, 0, 0, 0, 0, 1 };
+   double * q = (double *) calloc((size_t)(rob->n_dof > 0 ? rob->n_dof : 1), sizeof(double));
+   double * R = (double *) malloc((size_t) nl * 9 * sizeof(double)), * t = (double *) malloc((size_t) nl * 3 * sizeof(double));
+   int a, b2, k;
+   memset(excl, 0, (size_t) nl * nl);
+   for (a=0; a<nl; a++)
+   {
+      excl[a*nl + a] = 1;
+      if (rob->parent[a] >= 0) { excl[a*nl + rob->parent[a]] = 1; excl[rob->parent[a]*nl + a] = 1; }
+   }
+   for (a=0; a<rob->n_adjacent; a++)
+   {
+      excl[rob->adjacent[2*a]*nl + rob->adjacent[2*a+1]] = 1;
+      excl[rob->adjacent[2*a+1]*nl + rob->adjacent[2*a]] = 1;
+   }
+   ora_robot_fk(rob, ident, q, R, t, 0, 0);
+   for (a=0; a<rob->n_spheres; a++)
+      for (b2=a+1; b2<rob->n_spheres; b2++)
+      {
+         const int la = rob->sphere_link[a], lb = rob->sphere_link[b2];
+         double pa[3], pb[3], d2 = 0.0, rs = rob->sphere_radius[a] + rob->sphere_radius[b2];
+         mat3_vec(R + 9*la, rob->sphere_pos + 3*a, pa);
+         mat3_vec(R + 9*lb, rob->sphere_pos + 3*b2, pb);
+         for (k=0; k<3; k++) { const double d = (pa[k] + t[3*la+k]) - (pb[k] + t[3*lb+k]); d2 += d*d; }
+         if (sqrt(d2) - rs < 0.0) { excl[la*nl + lb] = 1; excl[lb*nl + la] = 1; }
+      }
+   free(q); free(R); free(t);
 }
 
 /* create's starttraj branch, src/orcdchomp_mod.cpp:2375-2416 (fixed base): row i of the run's
@@ -924,6 +988,66 @@ void ora_sample_starttraj(int count, int dof, const double * wp, const double * 
       }
    }
    free(tcum);
+}
+
+/* create's starttraj branch with floating_base, src/orcdchomp_mod.cpp:2378-2404: the base rows are sampled from
+ * the document's `affine_transform` group (OpenRAVE order x y z qw qx qy qz, linear interpolation), reordered to
+ * libcd's x y z qx qy qz qw and normalised (cd_kin_pose_normalize); the arm columns as above.
+ * wp_joint [count][n_adof], wp_base [count][7]; out [n_points][7 + n_adof]. */
+void ora_sample_starttraj_floating(int count, int n_adof, const double * wp_joint, const double * wp_base, const double * deltatime,
+   int n_points, double * out)
+{
+   const int n = 7 + n_adof;
+   double * tcum = (double *) malloc((size_t) count * sizeof(double));
+   double duration;
+   int i, j, seg = 0;
+   tcum[0] = 0.0;
+   for (i=1; i<count; i++) tcum[i] = tcum[i-1] + deltatime[i];
+   duration = tcum[count-1];
+   for (i=0; i<n_points; i++)
+   {
+      const double t = i * duration / (n_points - 1);             /* mod.cpp:2391, 2402 */
+      const int nxt = (count > 1) ? 1 : 0;
+      double u, vec[7];
+      while (seg < count-2 && tcum[seg+1] < t) seg++;
+      u = (count > 1 && tcum[seg+1] > tcum[seg]) ? (t - tcum[seg]) / (tcum[seg+1] - tcum[seg]) : 0.0;
+      for (j=0; j<7; j++) vec[j] = wp_base[seg*7+j] + (wp_base[(seg+nxt)*7+j] - wp_base[seg*7+j]) * u;
+      out[i*n+0] = vec[0]; out[i*n+1] = vec[1]; out[i*n+2] = vec[2];          /* mod.cpp:2392-2398 */
+      out[i*n+3] = vec[4]; out[i*n+4] = vec[5]; out[i*n+5] = vec[6]; out[i*n+6] = vec[3];
+      ora_kin_pose_normalize(&out[i*n]);
+      for (j=0; j<n_adof; j++)
+         out[i*n+7+j] = wp_joint[seg*n_adof+j] + (wp_joint[(seg+nxt)*n_adof+j] - wp_joint[seg*n_adof+j]) * u;
+   }
+   free(tcum);
+}
+
+/* gettraj's second trajectory for a floating base, src/orcdchomp_mod.cpp:2912-2949: per waypoint
+ * [deltatime, affine_transform x y z qw qx qy qz, affine_velocities (the same order)], the velocities being the
+ * differences to the previous waypoint over its deltatime (zero for the first).  traj [n_points][n] (libcd order
+ * x y z qx qy qz qw in columns 0..6); out [n_points][15]. */
+void ora_gettraj_affine_groups(const double * traj, int n_points, int n, const double * deltatime, double * out)
+{
+   int i;
+   for (i=0; i<n_points; i++)
+   {
+      double * vec = out + (size_t) i*15;
+      int k;
+      for (k=0; k<15; k++) vec[k] = 0.0;
+      vec[1+0] = traj[i*n+0]; vec[1+1] = traj[i*n+1]; vec[1+2] = traj[i*n+2];
+      vec[1+4] = traj[i*n+3]; vec[1+5] = traj[i*n+4]; vec[1+6] = traj[i*n+5]; vec[1+3] = traj[i*n+6];
+      if (i > 0)
+      {
+         const double dt = deltatime[i];
+         vec[0] = dt;
+         vec[1+7+0] = (traj[i*n+0] - traj[(i-1)*n+0]) / dt;
+         vec[1+7+1] = (traj[i*n+1] - traj[(i-1)*n+1]) / dt;
+         vec[1+7+2] = (traj[i*n+2] - traj[(i-1)*n+2]) / dt;
+         vec[1+7+4] = (traj[i*n+3] - traj[(i-1)*n+3]) / dt;
+         vec[1+7+5] = (traj[i*n+4] - traj[(i-1)*n+4]) / dt;
+         vec[1+7+6] = (traj[i*n+5] - traj[(i-1)*n+5]) / dt;
+         vec[1+7+3] = (traj[i*n+6] - traj[(i-1)*n+6]) / dt;
+      }
+   }
 }
 
 void ora_run_sphere_order(const ora_run * r, int * idx)

@@ -160,6 +160,8 @@ typedef struct ora_robot
    const int * sphere_link;       /* [n_spheres] */
    const double * sphere_pos;     /* [n_spheres][3] in link frame */
    const double * sphere_radius;  /* [n_spheres] */
+   int n_adjacent;                /* link pairs the robot description declares adjacent (<adjacent> tags) */
+   const int * adjacent;          /* [n_adjacent][2] */
 } ora_robot;
 
 /* FK: world transforms of all links.  R[n_links][9] row-major, t[n_links][3].
@@ -233,6 +235,13 @@ int ora_run_collision_recheck(ora_run * r, const double * vmax, int * collides, 
    int * sphere_out, int * field_out, double * depth_out);
 /* the starttraj sampling of mod::create (src/orcdchomp_mod.cpp:2375-2416), see ora_run.c */
 void ora_sample_starttraj(int count, int dof, const double * wp, const double * deltatime, int n_points, double * out);
+/* ... with floating_base (src/orcdchomp_mod.cpp:2378-2404) and gettraj's affine_transform / affine_velocities groups
+ * (src/orcdchomp_mod.cpp:2912-2949), see ora_run.c */
+void ora_sample_starttraj_floating(int count, int n_adof, const double * wp_joint, const double * wp_base, const double * deltatime,
+   int n_points, double * out);
+void ora_gettraj_affine_groups(const double * traj, int n_points, int n, const double * deltatime, double * out);
+/* link pairs a self-collision check skips (the sphere model's stand-in for OpenRAVE's adjacent links), see ora_run.c */
+void ora_robot_self_pairs(const ora_robot * rob, unsigned char * excl);
 /* one evaluation of sphere_cost_pre + sphere_cost for every moving point on the
  * current trajectory: G[m][n] (unscaled, as the callback leaves it), costs[m],
  * sphere_poss_all[n_points][S_a][3] */

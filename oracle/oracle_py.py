@@ -34,7 +34,7 @@ class Robot(C.Structure):
                 ("joint_type", c_int_p), ("axis", c_double_p), ("dof_index", c_int_p),
                 ("n_dof", C.c_int), ("limit_lower", c_double_p), ("limit_upper", c_double_p),
                 ("n_spheres", C.c_int), ("sphere_link", c_int_p), ("sphere_pos", c_double_p),
-                ("sphere_radius", c_double_p)]
+                ("sphere_radius", c_double_p), ("n_adjacent", C.c_int), ("adjacent", c_int_p)]
 
 
 class RunParams(C.Structure):
@@ -112,6 +112,9 @@ def lib():
         L.ora_run_set_traj.argtypes = [C.c_void_p, c_double_p]
         L.ora_run_collision_recheck.argtypes = [C.c_void_p, c_double_p, c_int_p, c_double_p, c_int_p, c_int_p, c_double_p]
         L.ora_sample_starttraj.argtypes = [C.c_int, C.c_int, c_double_p, c_double_p, C.c_int, c_double_p]
+        L.ora_sample_starttraj_floating.argtypes = [C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, C.c_int, c_double_p]
+        L.ora_gettraj_affine_groups.argtypes = [c_double_p, C.c_int, C.c_int, c_double_p, c_double_p]
+        L.ora_robot_self_pairs.argtypes = [C.POINTER(Robot), C.POINTER(C.c_ubyte)]
         for nm in ("ora_run_n", "ora_run_m", "ora_run_n_points", "ora_run_n_spheres_active",
                    "ora_run_n_spheres", "ora_run_hmc_resample_iter", "ora_run_iter"):
             getattr(L, nm).argtypes = [C.c_void_p]
@@ -219,6 +222,8 @@ class OraRobot:
         r.sphere_link = ip(a["sphere_link"])
         r.sphere_pos = dp(a["sphere_pos"])
         r.sphere_radius = dp(a["sphere_radius"])
+        r.n_adjacent = a["n_adjacent"]
+        r.adjacent = ip(a["adjacent"])
         self.r = r
         self.model = model
 
@@ -356,6 +361,32 @@ def sample_starttraj(wp, deltatime, n_points):
     wp = f64(wp); dtm = f64(deltatime)
     out = np.zeros((n_points, wp.shape[1]))
     lib().ora_sample_starttraj(wp.shape[0], wp.shape[1], dp(wp), dp(dtm), n_points, dp(out))
+    return out
+
+
+def sample_starttraj_floating(wp_joint, wp_base, deltatime, n_points):
+    """create's starttraj sampling with floating_base (reference src/orcdchomp_mod.cpp:2378-2404): wp_base rows in
+    OpenRAVE's order x y z qw qx qy qz; returns [n_points][7 + n_adof] with the base in libcd's order, normalised"""
+    wj = f64(wp_joint); wb = f64(wp_base); dtm = f64(deltatime)
+    out = np.zeros((n_points, 7 + wj.shape[1]))
+    lib().ora_sample_starttraj_floating(wj.shape[0], wj.shape[1], dp(wj), dp(wb), dp(dtm), n_points, dp(out))
+    return out
+
+
+def gettraj_affine_groups(traj, deltatime):
+    """gettraj's affine_transform / affine_velocities rows of a floating-base run (reference
+    src/orcdchomp_mod.cpp:2912-2949): [n_points][15] = deltatime, x y z qw qx qy qz, their velocities"""
+    t = f64(traj); dtm = f64(deltatime)
+    out = np.zeros((t.shape[0], 15))
+    lib().ora_gettraj_affine_groups(dp(t), t.shape[0], t.shape[1], dp(dtm), dp(out))
+    return out
+
+
+def self_pairs_excluded(robot):
+    """[n_links][n_links] 0/1: link pairs the self-collision leg of gettraj's re-check skips"""
+    nl = robot.r.n_links
+    out = np.zeros((nl, nl), dtype=np.uint8)
+    lib().ora_robot_self_pairs(robot.ptr, out.ctypes.data_as(C.POINTER(C.c_ubyte)))
     return out
 
 

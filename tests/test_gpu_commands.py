@@ -291,3 +291,122 @@ def test_starttraj_seeding(oracle):
     b2 = mod.batch_create(model.name, goals, **kw); mod.batch_set_traj(b2, mod.batch_gettraj(b1))
     c1, _ = mod.batch_iterate(b1, 4); c2, _ = mod.batch_iterate(b2, 4)
     assert np.array_equal(c1, c2)
+
+
+def _groups(text):
+    """(rows [count][width], {group name's first word: (offset, dof)}) of a trajectory document"""
+    import re
+    count = int(re.search(r'<data count="(\d+)">', text).group(1))
+    vals = np.array(re.search(r'<data count="\d+">\s*(.*?)\s*</data>', text, re.S).group(1).split(), dtype=float)
+    groups = {m.group(1).split()[0]: (int(m.group(2)), int(m.group(3)), m.group(1))
+              for m in re.finditer(r'<group name="([^"]+)" offset="(\d+)" dof="(\d+)"', text)}
+    return vals.reshape(count, -1), groups
+
+
+def test_floating_base_wire_formats(oracle):
+    """gettraj of a floating-base run carries the base pose as `affine_transform` / `affine_velocities` groups
+    (reference src/orcdchomp_mod.cpp:2912-2956: x y z then the quaternion w x y z, velocities = differences over the
+    waypoint's deltatime), and `create starttraj ... floating_base` samples both groups (src/orcdchomp_mod.cpp:2378-2404);
+    both against the oracle's restatements (oracle/ora_run.c)"""
+    mod = bindings.bind(_mk())
+    model = common.setup_product_wam(mod)
+    _, base, _, _ = common.wam_state()
+    goal = common.wam_goals(1, seed=31)[0]
+    basegoal = np.array(base, dtype=float); basegoal[:3] += [0.2, -0.1, 0.15]
+    kw = dict(n_points=30, lambda_=100.0, obs_factor=500.0)
+    run = mod.create(robot=model.name, adofgoal=list(goal), basegoal=list(basegoal), floating_base=True, **kw)
+    mod.iterate(run=run, n_iter=12)
+    traj = mod.batch_gettraj(int(run))[0]                       # [30][14], base in libcd's order x y z qx qy qz qw
+    text = mod.gettraj(run=run, no_collision_check=True)
+    rows, groups = _groups(text)
+    assert rows.shape == (30, 7 + 1 + 14)
+    assert groups["joint_values"][:2] == (0, 7) and groups["deltatime"][:2] == (7, 1)
+    assert groups["affine_transform"][:2] == (8, 7) and groups["affine_velocities"][:2] == (15, 7)
+    assert groups["affine_transform"][2] == "affine_transform %s 39" % model.name       # DOF_XYZ | DOF_RotationQuat
+    assert np.array_equal(rows[:, :7], traj[:, 7:])                                         # the arm columns, digit for digit
+    want = oracle.gettraj_affine_groups(traj, rows[:, 7])
+    assert np.array_equal(rows[:, 7], want[:, 0]) and np.array_equal(rows[:, 8:15], want[:, 1:8])
+    assert np.allclose(rows[:, 15:22], want[:, 8:15], rtol=1e-15, atol=0)
+    assert np.array_equal(rows[:, 8:11], traj[:, 0:3]) and np.array_equal(rows[:, 11], traj[:, 6])      # x y z, then qw first
+    assert np.all(rows[0, 15:22] == 0.0)
+
+    # back in through starttraj: resampled at i * duration / (n_points - 1) like the reference
+    for npts in (30, 17, 64):
+        run2 = mod.create(robot=model.name, starttraj=text, floating_base=True, n_points=npts)
+        t2 = mod.batch_gettraj(int(run2))[0]
+        want2 = oracle.sample_starttraj_floating(rows[:, :7], rows[:, 8:15], rows[:, 7], npts)
+        assert t2.shape == (npts, 14)
+        assert np.allclose(t2, want2, rtol=1e-14, atol=1e-15), np.abs(t2 - want2).max()
+        assert np.allclose(np.linalg.norm(t2[:, 3:7], axis=1), 1.0, rtol=1e-15)
+        assert np.allclose(t2[0], traj[0], rtol=1e-14, atol=1e-15) and np.allclose(t2[-1], traj[-1], rtol=1e-14, atol=1e-15)
+        # the run is usable: it iterates from there
+        mod.iterate(run=run2, n_iter=3)
+        mod.destroy(run=run2)
+    # a document without the base group is refused
+    with pytest.raises(RuntimeError, match="affine_transform"):
+        mod.create(robot=model.name, starttraj=_doc(rows[:, :7], rows[:, 7]), floating_base=True, n_points=30)
+    mod.destroy(run=run)
+
+
+def test_self_collision_in_the_recheck(oracle):
+    """gettraj's re-check also reports two spheres on links that may collide overlapping (reference
+    `|| boostrobot->CheckSelfCollision(report)`, src/orcdchomp_mod.cpp:2998-2999): host path, batched device verdict
+    and the oracle's restatement agree run by run.  The scene's only field is far away, the arm folds its elbow until
+    the hand reaches the shoulder."""
+    import re
+    from or_cdchomp_amd import robots
+    mod = bindings.bind(_mk())
+    model, base, dofvals, adofs = common.wam_state()
+    mod.add_robot(model, transform=base, dof_values=dofvals, active_dofs=adofs)
+    mod.add_kinbody_boxes("far", [([0, 0, 0, 0, 0, 0, 1], [0.05, 0.05, 0.05])], transform=[5, 5, 5, 0, 0, 0, 1])
+    mod.SendCommand("computedistancefield kinbody far")
+    data, lengths, gpose = mod.get_sdf("far")
+    grid = oracle.OraGrid(data, lengths)
+    wpose = np.array(gpose, dtype=float); wpose[:3] += 5.0
+    rob = oracle.OraRobot(model)
+    excl = oracle.self_pairs_excluded(rob)
+    links = model.arrays()["sphere_link"]
+    # the rule: the same link, parent and child, declared adjacent links (wam2 - wam4) and links touching at zero are
+    # skipped; the hand against the base sphere or the upper arm is not
+    assert excl[links[1], links[2]] == 1 and excl[links[4], links[6]] == 1 and excl[links[0], links[10]] == 0 and excl[links[1], links[9]] == 0
+    vmax = np.ones(model.n_dof)
+    mod.set_velocity_limits(model.name, vmax)
+    n_runs = 24
+    rng = np.random.default_rng(41)
+    goals = np.tile(np.asarray(robots.WAM_START), (n_runs, 1))
+    goals[:, 3] = np.linspace(2.3, 3.05, n_runs)
+    goals[:, 2] += rng.uniform(-0.3, 0.3, n_runs); goals[:, 5] += rng.uniform(-0.5, 0.5, n_runs); goals[:, 4] += rng.uniform(-1, 1, n_runs)
+    kw = dict(n_points=40, lambda_=100.0, obs_factor=0.0, obs_factor_self=0.0)
+    bid = mod.batch_create(model.name, goals, **kw)
+    got = mod.batch_collision_verdict(bid)
+    trajs = mod.batch_gettraj(bid)
+    mod.batch_destroy(bid)
+    n_self = 0
+    for k in range(n_runs):
+        orun = oracle.OraRun(rob, base, dofvals, adofs, goals[k], [grid], [wpose], oracle.default_params(**kw))
+        orun.set_traj(trajs[k])
+        want = orun.collision_recheck(vmax[:7])
+        orun.destroy()
+        assert want["collides"] == got["collides"][k], (k, want, {q: got[q][k] for q in got})
+        if want["collides"]:
+            assert want["field"] <= -2                                     # nothing but the robot itself is near
+            assert want["sphere"] == got["sphere"][k] and want["field"] == got["field"][k], (k, want, got["sphere"][k], got["field"][k])
+            assert np.isclose(want["time"], got["time"][k], rtol=1e-12, atol=1e-15)
+            assert np.isclose(want["depth"], got["depth"][k], rtol=1e-9, atol=1e-12)
+            n_self += 1
+        # the single-run command path (host)
+        run = mod.create(robot=model.name, adofgoal=list(goals[k]), **kw)
+        mod.gettraj(run=run, no_collision_exception=True)
+        details = mod.last_collision_details()
+        if want["collides"]:
+            m = re.match(r"Collision at t=(\S+): spheres (\d+) and (\d+) of \S+ overlap by (\S+) m", details)
+            assert m, (k, details)
+            assert int(m.group(2)) == want["sphere"] and int(m.group(3)) == -2 - want["field"]
+            assert np.isclose(float(m.group(1)), want["time"], rtol=1e-5, atol=1e-9)
+            assert np.isclose(float(m.group(4)), want["depth"], rtol=1e-4, atol=1e-9)
+            with pytest.raises(RuntimeError, match="Resulting trajectory is in collision!"):
+                mod.gettraj(run=run)
+        else:
+            assert details == ""
+        mod.destroy(run=run)
+    assert 3 <= n_self < n_runs, n_self
