@@ -1110,7 +1110,7 @@ void BatchShard::plan_hmc(int iter_begin, int iter_end)
 }
 
 template <typename real>
-void BatchShard::launch(int n_iter, bool final_eval)
+void BatchShard::launch(int n_iter, bool final_eval, bool carry)
 {
    DevBatch<real> b;
    std::memset(&b, 0, sizeof(b));
@@ -1146,7 +1146,7 @@ void BatchShard::launch(int n_iter, bool final_eval)
    b.pcr = (const real *) d_pcr_; b.Ainv = (const real *) d_Ainv_;
    b.jl_lo = (const real *) d_jl_lo_; b.jl_hi = (const real *) d_jl_hi_;
    b.hmc_iters = d_hmc_iters_; b.noise = (const real *) d_noise_; b.max_resamples = max_resamples_;
-   b.n_iter = n_iter; b.final_eval = final_eval ? 1 : 0;
+   b.n_iter = n_iter; b.final_eval = final_eval ? 1 : 0; b.carry_status = carry ? 1 : 0;
    b.phase_cycles = d_phase_;
    b.pcr_in_lds = pcr_in_lds_; b.pcr_sym = pcr_sym_; b.pcr_rows = pcr_rows_; b.ag_in_lds = ag_in_lds_;
    b.stagger_mode = stagger_mode_; b.stagger_sleeps = stagger_sleeps_; b.lim_generic = lim_generic_;
@@ -1185,7 +1185,7 @@ void BatchShard::launch(int n_iter, bool final_eval)
    pending_events_.push_back(std::make_pair(ev[0], ev[1]));
 }
 
-void BatchShard::iterate_async(int n_iter, int iter_begin, bool final_eval)
+void BatchShard::iterate_async(int n_iter, int iter_begin, bool final_eval, bool carry)
 {
    if (n_iter < 0) throw std::runtime_error("n_iter must be >=0!");
    DeviceGuard guard(device);
@@ -1199,7 +1199,7 @@ void BatchShard::iterate_async(int n_iter, int iter_begin, bool final_eval)
    max_resamples_ = 0;
    if (iter_begin == 0) std::fill(ext_noise_used_.begin(), ext_noise_used_.end(), 0);
    if (params.use_hmc && n_iter > 0) plan_hmc(iter_begin, iter_begin + n_iter);
-   if (params.precision == 64) launch<double>(n_iter, final_eval); else launch<float>(n_iter, final_eval);
+   if (params.precision == 64) launch<double>(n_iter, final_eval, carry); else launch<float>(n_iter, final_eval, carry);
 }
 
 void BatchShard::sync_begin(double * costs_out, int * status_out, int * iters_out)
@@ -1346,12 +1346,12 @@ void Batch::for_shards(const std::function<void(size_t)> & body, bool threads)
    for (std::exception_ptr & e : errs) if (e) std::rethrow_exception(e);
 }
 
-void Batch::iterate_async(int n_iter, int iter_begin, bool final_eval)
+void Batch::iterate_async(int n_iter, int iter_begin, bool final_eval, bool carry)
 {
    if (n_iter < 0) throw std::runtime_error("n_iter must be >=0!");
    last_n_iter = n_iter;
    // the hmc plan of a shard waits for its device: those go on one host thread per shard
-   for_shards([&](size_t k) { shards[k]->iterate_async(n_iter, iter_begin, final_eval); }, params.use_hmc != 0);
+   for_shards([&](size_t k) { shards[k]->iterate_async(n_iter, iter_begin, final_eval, carry); }, params.use_hmc != 0);
 }
 
 void Batch::sync(double * costs_out, int * status_out, int * iters_out)
@@ -1408,8 +1408,29 @@ void Batch::collision_verdict(const std::vector<int> & soffs, const std::vector<
 
 // create's dat_filename (src/orcdchomp_mod.cpp:2306-2310): one file per run; a batch of several
 // runs takes a printf pattern with one %d (the run index)
+// conversions of a printf pattern: the number of integer conversions (%d, %i, %u with flags and a width), or -1
+// when the pattern holds any other conversion (a caller's pattern is never handed to printf with one)
+int count_int_conversions(const std::string & pattern)
+{
+   int count = 0;
+   for (size_t k=0; k<pattern.size(); k++)
+   {
+      if (pattern[k] != '%') continue;
+      if (k + 1 < pattern.size() && pattern[k+1] == '%') { k++; continue; }
+      size_t q = k + 1;
+      while (q < pattern.size() && (pattern[q] == '0' || pattern[q] == '-' || pattern[q] == '+' || pattern[q] == ' ')) q++;
+      while (q < pattern.size() && pattern[q] >= '0' && pattern[q] <= '9') q++;
+      if (q >= pattern.size() || (pattern[q] != 'd' && pattern[q] != 'i' && pattern[q] != 'u')) return -1;
+      count++; k = q;
+   }
+   return count;
+}
+
 void Batch::open_dat(const std::string & pattern)
 {
+   // one run: the name as it is (src/orcdchomp_mod.cpp:2306-2310); a batch: a pattern with exactly one integer
+   // conversion, the run index
+   if (n_runs > 1 && count_int_conversions(pattern) != 1) throw std::runtime_error("Bad arguments!");
    for (int k=0; k<n_runs; k++)
    {
       char name[1024];

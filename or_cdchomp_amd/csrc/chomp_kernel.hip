@@ -1534,7 +1534,7 @@ __device__ __attribute__((noinline)) void phase_finish(const void * kp, int stat
          b.costs[(size_t) run*3 + 2] = done_smooth;
       }
       b.status[run] = status;
-      b.iters_done[run] = iters_done;
+      b.iters_done[run] = (b.carry_status ? b.iters_done[run] : 0) + iters_done;
       b.leapfrog_first[run] = leapfrog_first;
    }
    // the iterations an aborted run did not make have no log line in the reference: NaN rows
@@ -1553,6 +1553,10 @@ void chomp_iterate_kernel(const DevBatch<real> b)
    const void * kp = (const void *) __builtin_amdgcn_kernarg_segment_ptr();      // DevBatch b is the kernel's only argument
    const int run = blockIdx.x;
    const int tid = threadIdx.x;
+
+   // a launch that continues an iterate call: the run left its joint limits in an earlier launch of the call, the
+   // reference has thrown out of the call by now (workgroup-uniform)
+   if (b.carry_status && b.status[run] != 0) return;
 
    phase_setup<real, TREE, GS16, BLOCK>(kp);
 

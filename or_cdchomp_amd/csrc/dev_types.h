@@ -213,6 +213,7 @@ struct DevBatch
    int max_resamples;
    int n_iter;
    int final_eval;
+   int carry_status;       // this launch continues an iterate call (one launch per iteration: max_time, trajs_fileformstr): a run that left its joint limits in an earlier launch of the call stays out, iters_done accumulates
    long long * phase_cycles; // [n_runs][8] or null: diagnostics (cycles per phase, wave 0)
    real a_diag, a_off;     // D == 1: A = tridiag(a_off, a_diag, a_off), B couples the end rows with a_off
    int pcr_in_lds;         // the cyclic-reduction tables are staged in LDS

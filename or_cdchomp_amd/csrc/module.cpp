@@ -691,25 +691,22 @@ std::string Module::cmd_removefield(const std::vector<std::string> & argv)
 // by column, then translation) + Twe (the same) + Bw [6][2]; 38 fields
 static bool parse_tsr(const std::string & str, TsrSpec & t)
 {
-   int manipindex; char bodyandlink[32];
-   double AR[3][3], Ad[3], BR[3][3], Bd[3];
-   const int ret = std::sscanf(str.c_str(),
-      "%d %31s"
-      " %lf %lf %lf %lf %lf %lf %lf %lf %lf %lf %lf %lf"
-      " %lf %lf %lf %lf %lf %lf %lf %lf %lf %lf %lf %lf"
-      " %lf %lf %lf %lf %lf %lf %lf %lf %lf %lf %lf %lf",
-      &manipindex, bodyandlink,
-      &AR[0][0], &AR[1][0], &AR[2][0], &AR[0][1], &AR[1][1], &AR[2][1], &AR[0][2], &AR[1][2], &AR[2][2],
-      &Ad[0], &Ad[1], &Ad[2],
-      &BR[0][0], &BR[1][0], &BR[2][0], &BR[0][1], &BR[1][1], &BR[2][1], &BR[0][2], &BR[1][2], &BR[2][2],
-      &Bd[0], &Bd[1], &Bd[2],
-      &t.Bw[0][0], &t.Bw[0][1], &t.Bw[1][0], &t.Bw[1][1], &t.Bw[2][0], &t.Bw[2][1],
-      &t.Bw[3][0], &t.Bw[3][1], &t.Bw[4][0], &t.Bw[4][1], &t.Bw[5][0], &t.Bw[5][1]);
-   if (ret != 38) return false;
-   Mat3 A, B;
-   for (int r=0; r<3; r++) for (int c=0; c<3; c++) { A.m[3*r+c] = AR[r][c]; B.m[3*r+c] = BR[r][c]; }
-   t.T0w = pose_from_dR(Ad, A);
-   t.Twe = pose_from_dR(Bd, B);
+   // the wire format of a TSR (tsr_create_parse, src/orcdchomp_mod.cpp:3068-3111): manipulator index, "body link"
+   // word, then 36 numbers: T0w and Twe as a rotation column by column followed by the translation, Bw row by row
+   std::istringstream in(str);
+   int manipindex; std::string bodyandlink;
+   if (!(in >> manipindex >> bodyandlink) || bodyandlink.size() > 31) return false;
+   double num[36];
+   for (double & v : num) if (!(in >> v)) return false;
+   Pose * frames[2] = { &t.T0w, &t.Twe };
+   for (int f=0; f<2; f++)
+   {
+      const double * block = num + 12*f;
+      Mat3 R;
+      for (int col=0; col<3; col++) for (int row=0; row<3; row++) R.m[3*row+col] = block[3*col+row];
+      *frames[f] = pose_from_dR(block + 9, R);
+   }
+   for (int k=0; k<12; k++) t.Bw[k/2][k%2] = num[24+k];
    return true;
 }
 
@@ -975,6 +972,9 @@ std::string Module::cmd_iterate(const std::vector<std::string> & argv, bool batc
    std::vector<int> status(b.n_runs, 0), iters(b.n_runs, 0);
    if (have_fileform && b.params.floating_base)
       throw std::runtime_error("Error: trajs_fileformstr and floating_base combined is not yet implemented!");
+   // the pattern goes to printf with (iteration) for one run as in the reference (mod.cpp:2783-2784), with
+   // (iteration, run) for a batch: exactly those integer conversions and no other
+   if (have_fileform && count_int_conversions(fileform) != (b.n_runs > 1 ? 2 : 1)) bad_arguments();
    // seconds since the call began, without the time spent writing trajectory dumps (mod.cpp:2748-2750,
    // 2781-2795: the reference stops its clock around the dump)
    auto t_last = std::chrono::steady_clock::now();
@@ -1018,10 +1018,16 @@ std::string Module::cmd_iterate(const std::vector<std::string> & argv, bool batc
             t_last = std::chrono::steady_clock::now();        // the dump is off the clock
          }
          const double t_begin = ticks;
-         b.iterate_async(1, it, false);
-         b.sync(costs.data(), st1.data(), iters.data());
+         const std::vector<int> before = (it > 0) ? iters : std::vector<int>(b.n_runs, 0);
+         b.iterate_async(1, it, false, it > 0);                // (runs that left their limits earlier in the call stay out)
+         b.sync(costs.data(), st1.data(), iters.data());       // iterations made accumulate over the launches of the call
          const double t_end = clock_now();
-         if (b.has_dat()) b.write_dat(it, 1, iters.data(), t_begin, t_end);
+         if (b.has_dat())
+         {
+            std::vector<int> made(b.n_runs);
+            for (int k=0; k<b.n_runs; k++) made[k] = iters[k] - before[k];
+            b.write_dat(it, 1, made.data(), t_begin, t_end);
+         }
          for (int k=0; k<b.n_runs; k++) if (st1[k] != 0) { status[k] = st1[k]; aborted = true; }
          // a single run stops where the reference throws; a batch goes on for its other runs
          if (aborted && b.n_runs == 1) break;
@@ -1029,7 +1035,7 @@ std::string Module::cmd_iterate(const std::vector<std::string> & argv, bool batc
       }
       if (!(aborted && b.n_runs == 1))
       {
-         b.iterate_async(0, 0, true);                          // cd_chomp_iterate(c, 0, ...) (mod.cpp:2830)
+         b.iterate_async(0, 0, true, n_iter > 0);              // cd_chomp_iterate(c, 0, ...) (mod.cpp:2830)
          b.sync(costs.data(), st1.data(), nullptr);
       }
    }

@@ -130,7 +130,8 @@ public:
    BatchShard & operator=(const BatchShard &) = delete;
    // iterations [iter_begin, iter_begin + n_iter) of an iterate call (r->iter restarts at 0 in every
    // call, src/orcdchomp_mod.cpp:2752: the hmc schedule compares against it), then the cost-only pass
-   void iterate_async(int n_iter, int iter_begin = 0, bool final_eval = true);
+   // `carry`: the launch continues an iterate call (runs that left their limits earlier in the call stay out)
+   void iterate_async(int n_iter, int iter_begin = 0, bool final_eval = true, bool carry = false);
    void sync_begin(double * costs_out, int * status_out, int * iters_out);   // enqueue the copies
    void sync_end();                                                          // wait for them
    void gettraj(double * out);
@@ -156,7 +157,7 @@ public:
    std::vector<int> slot_xml;               // XML index of the sphere in lane/slot q of the active block, -1: empty
 private:
    template <typename real> void build_device(const Robot & robot);
-   template <typename real> void launch(int n_iter, bool final_eval);
+   template <typename real> void launch(int n_iter, bool final_eval, bool carry);
    void plan_hmc(int iter_begin, int iter_end);
    void construct(const Robot & robot, const double * starts, const double * goals, const double * basegoals,
       const unsigned int * seeds);
@@ -213,7 +214,7 @@ public:
    Batch(Module * mod, const std::vector<int> & devices, const Robot & robot, const BatchParams & p, int n_runs,
       const double * starts, const double * goals, const double * basegoals, const unsigned int * seeds);
    ~Batch();
-   void iterate_async(int n_iter, int iter_begin = 0, bool final_eval = true);
+   void iterate_async(int n_iter, int iter_begin = 0, bool final_eval = true, bool carry = false);
    void sync(double * costs_out, int * status_out, int * iters_out = nullptr);
    void gettraj(double * out);
    void get_state(const std::string & which, double * out);
@@ -321,5 +322,6 @@ private:
 };
 
 void hip_check(hipError_t e, const char * what);
+int count_int_conversions(const std::string & pattern);   // integer conversions of a printf pattern, -1: it holds another kind
 
 } // namespace orc

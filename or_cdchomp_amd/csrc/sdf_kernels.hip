@@ -262,7 +262,8 @@ hipError_t orc_sdf_build_device(const int sizes[3], const double lengths[3], con
          ORC_TRY(hipMemcpyAsync(h_changed, d_changed, sizeof(int), hipMemcpyDeviceToHost, st));
          ORC_TRY(hipStreamSynchronize(st));
          if (!*h_changed) break;
-         if (round > 4 * (sizes[0] + sizes[1] + sizes[2])) { e = hipErrorUnknown; goto done; }   // cannot happen: every round reaches new cells
+         // (every round reaches at least one new cell, so the loop ends by itself: a maze of obstacles takes about as
+         // many rounds as its free-space path has turns, far more than the grid's perimeter)
       }
       hipLaunchKernelGGL(flood_finish_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, d_free, d_obs, count);
       ORC_TRY(hipGetLastError());

@@ -61,73 +61,86 @@ __device__ __forceinline__ void t_quat_to_R(const real q[4], real R[9])
    R[3] = 2*(xy+zw);     R[4] = 1 - 2*(xx+zz); R[5] = 2*(yz-xw);
    R[6] = 2*(xz-yw);     R[7] = 2*(yz+xw);     R[8] = 1 - 2*(xx+yy);
 }
-// cd_kin_quat_from_R, kin.c:418-459 (R row major)
+// cd_kin_quat_from_R, kin.c:418-459 (R row major): the largest of the four squared components is taken from the
+// diagonal (ties go to the later one, as the reference's cascade of comparisons does), the other three from the
+// sums and differences of the off-diagonal pairs
 template <typename real>
 __device__ __forceinline__ void t_quat_from_R(const real R[9], real quat[4])
 {
-   const real xx4 = 1 + R[0] - R[4] - R[8], yy4 = 1 - R[0] + R[4] - R[8], zz4 = 1 - R[0] - R[4] + R[8], ww4 = 1 + R[0] + R[4] + R[8];
-   if (xx4 > yy4 && xx4 > zz4 && xx4 > ww4)
+   const real d4[4] = { 1 + R[0] - R[4] - R[8], 1 - R[0] + R[4] - R[8], 1 - R[0] - R[4] + R[8], 1 + R[0] + R[4] + R[8] };   // 4 x^2, 4 y^2, 4 z^2, 4 w^2
+   // 4 x y, 4 x z, 4 y z, 4 w x, 4 w y, 4 w z
+   const real pr[6] = { R[3] + R[1], R[2] + R[6], R[7] + R[5], R[7] - R[5], R[2] - R[6], R[3] - R[1] };
+   int big = 0;
+#pragma unroll
+   for (int k=1; k<4; k++) if (d4[k] >= d4[big]) big = k;
+   real dbig = d4[0];
+#pragma unroll
+   for (int k=1; k<4; k++) dbig = (big == k) ? d4[k] : dbig;
+   const real qbig = M<real>::sqrt_((real)0.25 * dbig);
+   const real v4 = (real)0.25 / qbig;
+   // product of components a and b (a < b): index into pr
+#pragma unroll
+   for (int c=0; c<4; c++)
    {
-      quat[0] = M<real>::sqrt_((real)0.25*xx4);
-      const real v4 = (real)0.25 / quat[0];
-      quat[1] = v4 * (R[3] + R[1]); quat[2] = v4 * (R[2] + R[6]); quat[3] = v4 * (R[7] - R[5]);
-   }
-   else if (yy4 > zz4 && yy4 > ww4)
-   {
-      quat[1] = M<real>::sqrt_((real)0.25*yy4);
-      const real v4 = (real)0.25 / quat[1];
-      quat[0] = v4 * (R[3] + R[1]); quat[2] = v4 * (R[7] + R[5]); quat[3] = v4 * (R[2] - R[6]);
-   }
-   else if (zz4 > ww4)
-   {
-      quat[2] = M<real>::sqrt_((real)0.25*zz4);
-      const real v4 = (real)0.25 / quat[2];
-      quat[0] = v4 * (R[2] + R[6]); quat[1] = v4 * (R[7] + R[5]); quat[3] = v4 * (R[3] - R[1]);
-   }
-   else
-   {
-      quat[3] = M<real>::sqrt_((real)0.25*ww4);
-      const real v4 = (real)0.25 / quat[3];
-      quat[0] = v4 * (R[7] - R[5]); quat[1] = v4 * (R[2] - R[6]); quat[2] = v4 * (R[3] - R[1]);
+      // pair (min(big, c), max(big, c)) -> (0,1) 0, (0,2) 1, (1,2) 2, (0,3) 3, (1,3) 4, (2,3) 5
+      real v = 0;
+#pragma unroll
+      for (int o=0; o<4; o++)
+      {
+         if (o == c) continue;
+         const int lo = o < c ? o : c, hi = o < c ? c : o;
+         const int idx = (hi == 3) ? 3 + lo : lo + hi - 1;
+         v = (big == o) ? pr[idx] : v;
+      }
+      quat[c] = (big == c) ? qbig : v4 * v;
    }
 }
-// cd_kin_pose_to_xyzypr, kin.c:615-646
+// cd_kin_pose_to_xyzypr, kin.c:615-646: yaw, pitch, roll of the quaternion; at the poles (|sin pitch| > 0.99998) the yaw
+// takes the whole rotation about the vertical
 template <typename real>
 __device__ __forceinline__ void t_pose_to_xyzypr(const real pose[7], real o[6])
 {
    const real qx = pose[3], qy = pose[4], qz = pose[5], qw = pose[6];
-   const real tau = (real) 6.283185307179586476925286766559;
+   const real quarter_turn = (real) 1.5707963267948966192313216916398;
    o[0] = pose[0]; o[1] = pose[1]; o[2] = pose[2];
-   const real sinp2 = qw*qy-qz*qx;
-   if (sinp2 > (real)0.49999) { o[3] = (real)(-2)*TM<real>::atan2_(qx,qw); o[4] = (real)0.25*tau; o[5] = 0; }
-   else if (sinp2 < (real)(-0.49999)) { o[3] = (real)2*TM<real>::atan2_(qx,qw); o[4] = (real)(-0.25)*tau; o[5] = 0; }
-   else
+   const real half_sinp = qw*qy - qz*qx;
+   if (M<real>::fabs_(half_sinp) > (real)0.49999)
    {
-      o[3] = TM<real>::atan2_(2*(qw*qz+qx*qy), 1 - 2*(qy*qy+qz*qz));
-      o[4] = TM<real>::asin_(2*sinp2);
-      o[5] = TM<real>::atan2_(2*(qw*qx+qy*qz), 1 - 2*(qx*qx+qy*qy));
+      const real sgn = half_sinp > 0 ? (real)1 : (real)(-1);
+      o[3] = (real)(-2) * sgn * TM<real>::atan2_(qx, qw); o[4] = sgn * quarter_turn; o[5] = 0;
+      return;
    }
+   o[3] = TM<real>::atan2_(2*(qw*qz + qx*qy), 1 - 2*(qy*qy + qz*qz));
+   o[4] = TM<real>::asin_(2*half_sinp);
+   o[5] = TM<real>::atan2_(2*(qw*qx + qy*qz), 1 - 2*(qx*qx + qy*qy));
 }
-// cd_kin_pose_to_xyzypr_J, kin.c:682-717
+// cd_kin_pose_to_xyzypr_J, kin.c:682-717: the derivative of the above by the pose.  An angle atan2(s, c) has the
+// gradient (c grad s - s grad c) / (c^2 + s^2); the pitch asin(a) has grad a / sqrt(1 - a^2).
 template <typename real>
 __device__ __forceinline__ void t_xyzypr_J(const real pose[7], real J[6][7])
 {
    const real qx = pose[3], qy = pose[4], qz = pose[5], qw = pose[6];
    for (int i=0; i<6; i++) for (int j=0; j<7; j++) J[i][j] = 0;
    J[0][0] = 1; J[1][1] = 1; J[2][2] = 1;
-   real nu = 2*(qw*qz+qx*qy), de = 1 - 2*(qy*qy+qz*qz);
-   J[3][3] = de/(de*de+nu*nu)*(2*qy);
-   J[3][4] = de/(de*de+nu*nu)*(2*qx) - nu/(de*de+nu*nu)*((real)(-4)*qy);
-   J[3][5] = de/(de*de+nu*nu)*(2*qw) - nu/(de*de+nu*nu)*((real)(-4)*qz);
-   J[3][6] = de/(de*de+nu*nu)*(2*qz);
-   const real as = 2 * (qw*qy-qz*qx);
-   const real ia = (real)1/M<real>::sqrt_(1-as*as);
-   J[4][3] = ia*2*(-qz); J[4][4] = ia*2*qw; J[4][5] = ia*2*(-qx); J[4][6] = ia*2*qy;
-   nu = 2*(qw*qx+qy*qz); de = 1 - 2*(qx*qx+qy*qy);
-   J[5][3] = de/(de*de+nu*nu)*(2*qw) - nu/(de*de+nu*nu)*((real)(-4)*qx);
-   J[5][4] = de/(de*de+nu*nu)*(2*qz) - nu/(de*de+nu*nu)*((real)(-4)*qy);
-   J[5][5] = de/(de*de+nu*nu)*(2*qy);
-   J[5][6] = de/(de*de+nu*nu)*(2*qx);
+   auto angle_row = [](real s, real c, const real gs[4], const real gc[4], real * row) {
+      const real inv = (real)1 / (c*c + s*s);
+      const real wc = c * inv, ws = s * inv;
+#pragma unroll
+      for (int k=0; k<4; k++) row[k] = wc * gs[k] - ws * gc[k];
+   };
+   {  // yaw: s = 2 (qw qz + qx qy), c = 1 - 2 (qy^2 + qz^2); gradients by (qx, qy, qz, qw)
+      const real gs[4] = { 2*qy, 2*qx, 2*qw, 2*qz }, gc[4] = { 0, (real)(-4)*qy, (real)(-4)*qz, 0 };
+      angle_row(2*(qw*qz + qx*qy), 1 - 2*(qy*qy + qz*qz), gs, gc, &J[3][3]);
+   }
+   {  // pitch: asin(a), a = 2 (qw qy - qz qx)
+      const real a = 2 * (qw*qy - qz*qx);
+      const real ia2 = (real)2 / M<real>::sqrt_(1 - a*a);
+      J[4][3] = -ia2*qz; J[4][4] = ia2*qw; J[4][5] = -ia2*qx; J[4][6] = ia2*qy;
+   }
+   {  // roll: s = 2 (qw qx + qy qz), c = 1 - 2 (qx^2 + qy^2)
+      const real gs[4] = { 2*qw, 2*qz, 2*qy, 2*qx }, gc[4] = { (real)(-4)*qx, (real)(-4)*qy, 0, 0 };
+      angle_row(2*(qw*qx + qy*qz), 1 - 2*(qx*qx + qy*qy), gs, gc, &J[5][3]);
+   }
 }
 // cd_spatial_pose_jac_inverse, spatial.c:339-375
 template <typename real>

@@ -215,6 +215,9 @@ static int dgesv_one(int n, double * A, int * ipiv, double * b)
    return 0;
 }
 
+/* (for the tests: the solver above on its own) */
+int ora_dgesv_one(int n, double * A, int * ipiv, double * b) { return dgesv_one(n, A, ipiv, b); }
+
 /* src/libcd/chomp.c:239-340: A = sum_d wds[d]/N_d K_d^T K_d etc. */
 static int add_KEs(ora_chomp * c)
 {

@@ -258,6 +258,10 @@ int ora_batch_run(const ora_robot * rob, const double base_pose[7], const double
    const ora_run_params * params, const unsigned int * seeds, int n_iter,
    double * traj_out, double * costs_out, int * status_out, int max_threads);
 
+/* LAPACKE_dgesv(LAPACK_ROW_MAJOR, n, 1, A, n, ipiv, b, 1) as the constraint step uses it (src/libcd/chomp.c:579-581):
+ * returns info; info > 0 (singular): b is left as it was */
+int ora_dgesv_one(int n, double * A, int * ipiv, double * b);
+
 /* --------------------------------------------------------------- shparse */
 /* src/libcd/util_shparse.c:37-128 */
 int ora_util_shparse(char * in, int * argcp, char *** argvp);

@@ -292,3 +292,50 @@ def test_workgroup_shape_is_a_module_setting(oracle):
     mod.set_workgroup_threads(0)
     assert np.array_equal(sd, sa[:24]) and np.array_equal(td, ta[:24])
     assert np.allclose(cd, ca[:24], rtol=1e-13, atol=0)
+
+
+def test_chunked_iterate_of_a_batch_keeps_aborted_runs_out(oracle, tmp_path):
+    """iterate with max_time / trajs_fileformstr runs one launch per iteration; a run of a BATCH that leaves its joint
+    limits in one of them must stay out for the rest of the call, as it does in the fused path (and as the reference,
+    which has thrown by then, src/orcdchomp_mod.cpp:2799-2803): same final trajectories, status and iterations made"""
+    mod = _mk()
+    model = common.setup_product_wam(mod)
+    goals = common.wam_goals(256, seed=20250101)
+    a = mod.batch_create(model.name, goals, **KW)
+    b = mod.batch_create(model.name, goals, **KW)
+    _, st_a = mod.batch_iterate(a, 60)
+    costs = np.zeros((256, 3)); st_b = np.full(256, 9, dtype=np.int32)
+    mod.SendCommand("iteratebatch run %d n_iter 60 max_time 1e9 costs 0x%x status 0x%x" % (b, costs.ctypes.data, st_b.ctypes.data))
+    assert (st_a != 0).sum() >= 3, "the workload should hold a few runs that leave their joint limits"
+    assert np.array_equal(st_a, st_b)
+    ia, ib = mod.batch_iterations_done(a), mod.batch_iterations_done(b)
+    assert np.array_equal(ia, ib) and ia[st_a != 0].max() < 60 and (ia[st_a == 0] == 60).all()
+    assert np.array_equal(mod.batch_gettraj(a), mod.batch_gettraj(b))
+    mod.batch_destroy(a); mod.batch_destroy(b)
+
+
+def test_file_patterns_are_checked_before_they_reach_printf(tmp_path):
+    """dat_filename of a batch: exactly one integer conversion (the run); trajs_fileformstr: the iteration, and the run
+    for a batch; anything else in the pattern (a %s, a %n, a missing conversion) is "Bad arguments!" """
+    mod = _mk()
+    model = common.setup_product_wam(mod)
+    g = np.ascontiguousarray(common.wam_goals(2, seed=3))
+    create = "createbatch robot %s n_runs 2 adofgoals 0x%x n_points 20 " % (model.name, g.ctypes.data)
+    for bad in ("x.dat", "x_%s.dat", "x_%d_%d.dat", "x_%n.dat", "x_%f.dat"):
+        with pytest.raises(RuntimeError, match="Bad arguments!"):
+            mod.SendCommand(create + "dat_filename '%s'" % str(tmp_path / bad))
+    bid = int(mod.SendCommand(create + "dat_filename '%s'" % str(tmp_path / "ok_%02d_100%%.dat")))
+    mod.SendCommand("iteratebatch run %d n_iter 2" % bid)
+    assert os.path.exists(str(tmp_path / "ok_00_100%.dat")) and os.path.exists(str(tmp_path / "ok_01_100%.dat"))
+    for bad in ("t_%d.xml", "t.xml", "t_%d_%s.xml"):
+        with pytest.raises(RuntimeError, match="Bad arguments!"):
+            mod.SendCommand("iteratebatch run %d n_iter 1 trajs_fileformstr '%s'" % (bid, str(tmp_path / bad)))
+    mod.SendCommand("iteratebatch run %d n_iter 2 trajs_fileformstr '%s'" % (bid, str(tmp_path / "t_%03d_r%d.xml")))
+    assert os.path.exists(str(tmp_path / "t_001_r1.xml"))
+    mod.batch_destroy(bid)
+    run = int(mod.SendCommand("create robot %s adofgoal '%s' n_points 20" % (model.name, " ".join("%r" % v for v in g[0]))))
+    for bad in ("s.xml", "s_%d_%d.xml", "s_%s.xml"):
+        with pytest.raises(RuntimeError, match="Bad arguments!"):
+            mod.SendCommand("iterate run %d n_iter 1 trajs_fileformstr '%s'" % (run, str(tmp_path / bad)))
+    mod.SendCommand("iterate run %d n_iter 1 trajs_fileformstr '%s'" % (run, str(tmp_path / "s_%d.xml")))
+    assert os.path.exists(str(tmp_path / "s_0.xml"))

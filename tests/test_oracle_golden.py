@@ -301,3 +301,28 @@ def test_oracle_tsr_constraint_jacobian_and_effect():
     after = max(np.abs(run.eval_contsr(0, T2[i])[0]).max() for i in range(1, 39))
     assert st == 0 and before > 0.1 and after < 1e-5
     run.destroy()
+
+
+def test_oracle_dgesv_leaves_the_right_hand_side_alone_when_singular(oracle):
+    """LAPACKE_dgesv never calls dgetrs when dgetrf reports a zero pivot: chomp.c:582-599 then pushes the ORIGINAL h
+    back through A^-1 J^T ("constraint inversion error!").  The oracle's LU does the same; a regular system is solved."""
+    import ctypes as C
+    L = oracle.lib()
+    L.ora_dgesv_one.argtypes = [C.c_int, oracle.c_double_p, oracle.c_int_p, oracle.c_double_p]
+    rng = np.random.default_rng(5)
+    for n in (1, 3, 8, 17):
+        A = rng.normal(size=(n, n)); b = rng.normal(size=n)
+        A2, b2 = A.copy(), b.copy(); piv = np.zeros(n, dtype=np.int32)
+        assert L.ora_dgesv_one(n, oracle.dp(A2), oracle.ip(piv), oracle.dp(b2)) == 0
+        assert np.allclose(b2, np.linalg.solve(A, b), rtol=1e-9, atol=1e-12)
+    # a constraint given twice: two identical rows and columns
+    J = rng.normal(size=(3, 7)); J2 = np.vstack([J, J])
+    S = J2 @ J2.T
+    h = rng.normal(size=6); h2 = h.copy(); piv = np.zeros(6, dtype=np.int32)
+    info = L.ora_dgesv_one(6, oracle.dp(np.ascontiguousarray(S)), oracle.ip(piv), oracle.dp(h2))
+    if info > 0:                                       # (an exact zero pivot is a matter of rounding)
+        assert np.array_equal(h2, h)
+    Z = np.zeros((4, 4)); Z[0, 0] = 1.0
+    h = rng.normal(size=4); h2 = h.copy(); piv = np.zeros(4, dtype=np.int32)
+    assert L.ora_dgesv_one(4, oracle.dp(Z), oracle.ip(piv), oracle.dp(h2)) == 2
+    assert np.array_equal(h2, h)
