@@ -1168,7 +1168,7 @@ void BatchShard::launch(int n_iter, bool final_eval, bool carry)
       const int N = n + tsr_kmax_, Wd = N + n + 1;
       const size_t need = (size_t) N * Wd + (size_t) n * (n + 1) + n + (size_t)(tsr_kmax_ + 2) * sizeof(int) / sizeof(real) + 2;
       const size_t have = (size_t)(tile_m_ + 2) * b.lay.astr;
-      if (Wd <= 64 && need <= have) { b.tsr_structured = 1; b.tsr_wcap = N * Wd; }
+      if (Wd <= 64 && need <= have) { b.tsr_structured = 1; b.tsr_wcap = N * Wd; b.tsr_nmax = N; }
    }
    b.tsr_ws = (real *) d_tsr_ws_; b.tsr_ws_stride = tsr_ws_stride_; b.tsr_err = d_tsr_err_;
    b.Gdbg = debug_state_ ? (real *) d_G_ : nullptr;

@@ -232,6 +232,7 @@ struct DevBatch
    int tsr_blocks;            // (constraint, point) blocks of the system
    int tsr_structured;        // the system is solved point by point (block tridiagonal KKT form, tsr.h) instead of by the dense LU
    int tsr_wcap;              // reals of the augmented block [N][N + n + 1] of that solve at its largest
+   int tsr_nmax;              // N = n + (most constrained rows on one point): rows of that block at its largest
    // `start_tsr` (src/orcdchomp_mod.cpp:2316-2323, 2570-2576): the start point is a variable.  The workgroup's
    // copy of the trajectory keeps its layout [fixed row][m moving rows][goal] with an unused row in front
    // (n_points = m + 2 rows); the run's rows in global memory are np_global = m + 1: moving rows, goal.

@@ -447,6 +447,365 @@ __device__ void tsr_block_thomas(const BT & b, const Env<real> & E, const real *
    }
 }
 
+// The same elimination with the augmented block [S | F | r] of a point held in REGISTERS, from BOTH ENDS of the
+// trajectory at once (round 3).  In LDS every pivot step was a chain of round trips (pivot, scaled row, the rank-one
+// update, two wave barriers) by one wavefront that issues an instruction every ~9 cycles when it is alone on its
+// SIMD: ~15 k cycles per point, 1.5 M of the 1.6 M cycles of a constrained WAM iteration.
+// * Registers: a block's rows are padded to WP = 16, 32 or 64 columns; lane = (row % (64 / WP), column), register t
+//   of a lane = row t (64 / WP) + row % (64 / WP): a pivot step reads the pivot through v_readlane, the pivot row and
+//   the lane's own multiplier through one ds_bpermute each (no memory behind them) and updates its registers.  The
+//   previous point's [C' | r'] passes from its registers to the next block's the same way; only the rows of C' the
+//   back pass needs go to memory.
+// * Both ends (the twisted factorization of a block tridiagonal system): wavefront 0 eliminates the points
+//   0 .. mid-1 upwards (z_i = r'_i - C'_i z_{i+1}), wavefront 1 the points m-1 .. mid downwards
+//   (z_i = r"_i - C"_i z_{i-1}); the two meet in (I - C'_{mid-1} C"_mid) delta_{mid-1} = r'_{mid-1} - C'_{mid-1} r"_mid,
+//   and both substitute outwards from there at the same time.
+// DIR +1: the points i_begin, i_begin + 1, ... < i_end; DIR -1: i_begin, i_begin - 1, ... > i_end.
+// value of `v` in the lane whose byte address (lane * 4) is `addr4`: ds_bpermute, no memory behind it
+__device__ __forceinline__ double lane_fetch(double v, int addr4)
+{
+   const int lo = __builtin_amdgcn_ds_bpermute(addr4, __double2loint(v)), hi = __builtin_amdgcn_ds_bpermute(addr4, __double2hiint(v));
+   return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float lane_fetch(float v, int addr4) { return __int_as_float(__builtin_amdgcn_ds_bpermute(addr4, __float_as_int(v))); }
+
+// Gauss-Jordan without pivoting on a block held in registers (lane = (row % (64 / WP), column c), register t = row
+// t (64 / WP) + rsub), pivots 0 .. N-1.  All lane fetches of a step (the pivot row at this lane's column, the lane's
+// multipliers of every register) are issued before any is used: one round trip of the cross-lane unit per step, the
+// reciprocal of the pivot is formed meanwhile.  Returns false at a zero or non-finite pivot.
+template <typename real, int WP, int NREG>
+__device__ __forceinline__ bool gauss_jordan_regs(real (& w)[NREG], int N, int c, int rsub)
+{
+   constexpr int RPR = 64 / WP;
+   const int kfetch4 = rsub * WP * 4;
+   for (int k=0; k<N; k++)
+   {
+      const int tk = k / RPR, kbase = (k % RPR) * WP;           // (wavefront-uniform)
+      real wk = w[0];
+#pragma unroll
+      for (int t=1; t<NREG; t++) wk = (tk == t) ? w[t] : wk;
+      const real p = read_lane(wk, kbase + k);
+      const real ap = M<real>::fabs_(p);
+      if (!(ap > (real)0 && ap < M<real>::inf())) return false;
+      const real praw = lane_fetch(wk, (kbase + c) * 4);         // the pivot row at this lane's column
+      real f[NREG];
+#pragma unroll
+      for (int t=0; t<NREG; t++) f[t] = lane_fetch(w[t], kfetch4 + k * 4);      // W[r][k]
+      const real prow = praw * rcp_fast(p);
+#pragma unroll
+      for (int t=0; t<NREG; t++)
+      {
+         const int r = t*RPR + rsub;
+         w[t] = (r == k) ? prow : w[t] - f[t] * prow;
+      }
+   }
+   return true;
+}
+
+template <typename real, int WP, int NREG, int DIR, typename BT>
+__device__ void tsr_eliminate_regs(const BT & b, const Env<real> & E, const real * hws, const real * Jws, real * Cst, int * flag,
+   int i_begin, int i_end, int * rows2)
+{
+   constexpr int RPR = 64 / WP;               // rows per register slice
+   const int lane = threadIdx.x & 63;
+   const int c = lane & (WP - 1), rsub = lane / WP;
+   const int n = b.n, m = b.m, n1 = n + 1;
+   real w[NREG], jn[NREG];                    // the block; what the NEXT block takes from memory (J and h), fetched a point ahead
+#pragma unroll
+   for (int t=0; t<NREG; t++) { w[t] = 0; jn[t] = 0; }
+   // the rows of the system that belong to point i, and this lane's entries of J and h among them
+   auto point_rows = [&](int i, int * rows) {
+      int ki = 0;
+      for (int cn=0; cn<b.n_tsrs; cn++)
+      {
+         const int npts = b.tsrs[cn].npts, kc = b.tsrs[cn].k;
+         const int local = (npts == 1) ? ((b.tsrs[cn].point == i) ? 0 : -1) : m - 1 - i;
+         if (local < 0) continue;
+         if (lane < kc) rows[ki + lane] = b.tsrs[cn].row_base + local * kc + lane;
+         ki += kc;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      return ki;
+   };
+   auto fetch = [&](const int * rows, int ki) {
+      const int N = n + ki, Wd = N + n1;
+#pragma unroll
+      for (int t=0; t<NREG; t++)
+      {
+         const int r = t*RPR + rsub;
+         real v = 0;
+         if (r < n) { if (c >= n && c < N) v = -Jws[(size_t) rows[c - n] * n + r]; }
+         else if (r < N)
+         {
+            const int rr = rows[r - n];
+            if (c < n) v = Jws[(size_t) rr * n + c];
+            else if (c == Wd - 1) v = hws[rr];
+         }
+         jn[t] = v;
+      }
+   };
+   // The common case -- every constraint holds on every moving point -- needs no list: the rows of point i are
+   // row_base + (m - 1 - i) k + a for each constraint, so a lane knows its entries of J and h from (row0, stride)
+   // computed once, and the metric is the Toeplitz one (two numbers from the kernarg block): no scalar load from
+   // memory is left in the loop over the points
+   bool every_point = true;
+   int k_all = 0;
+   for (int cn=0; cn<b.n_tsrs; cn++) { if (b.tsrs[cn].npts != m) every_point = false; k_all += b.tsrs[cn].k; }
+   const bool toeplitz = (b.D == 1);
+   int jrow0[NREG], jstride[NREG], jcol[NREG];      // this lane's entry of register t: J[row][jcol] (jcol >= 0), h[row] (-1), none (-2)
+   real jsign[NREG];
+   if (every_point)
+   {
+      const int N = n + k_all, Wd = N + n1;
+#pragma unroll
+      for (int t=0; t<NREG; t++)
+      {
+         const int r = t*RPR + rsub;
+         int slot = -1, col = -2; real sg = 1;
+         if (r < n) { if (c >= n && c < N) { slot = c - n; col = r; sg = -1; } }
+         else if (r < N) { slot = r - n; col = (c < n) ? c : ((c == Wd - 1) ? -1 : -2); }
+         jrow0[t] = 0; jstride[t] = 0; jcol[t] = (slot >= 0) ? col : -2; jsign[t] = sg;
+         int acc = 0;
+         for (int cn=0; cn<b.n_tsrs; cn++)
+         {
+            const int kc = b.tsrs[cn].k;
+            if (slot >= acc && slot < acc + kc) { jrow0[t] = b.tsrs[cn].row_base + (slot - acc); jstride[t] = kc; }
+            acc += kc;
+         }
+      }
+   }
+   auto fetch_direct = [&](int i) {
+#pragma unroll
+      for (int t=0; t<NREG; t++)
+      {
+         const int row = jrow0[t] + (m - 1 - i) * jstride[t];
+         real v = 0;
+         if (jcol[t] >= 0) v = jsign[t] * Jws[(size_t) row * n + jcol[t]];
+         else if (jcol[t] == -1) v = hws[row];
+         jn[t] = v;
+      }
+   };
+   int Nprev = n;
+   int ki = k_all;
+   if (every_point) fetch_direct(i_begin);
+   else { ki = point_rows(i_begin, rows2); fetch(rows2, ki); }
+   int par = 0;
+   for (int i=i_begin; i!=i_end; i+=DIR)
+   {
+      const int N = n + ki, Wd = N + n1;
+      real lo, di, up;
+      if (toeplitz) { di = b.a_diag; lo = (i > 0) ? b.a_off : (real)0; up = (i < m-1) ? b.a_off : (real)0; }
+      else { lo = (i > 0) ? b.Aband[i] : (real)0; di = b.Aband[(size_t) m + i]; up = (i < m-1) ? b.Aband[(size_t) 2*m + i] : (real)0; }
+      // the coupling to the point eliminated before this one, and to the one that follows
+      const real back = (i == i_begin) ? (real)0 : ((DIR > 0) ? lo : up), fwd = (DIR > 0) ? up : lo;
+      // the block of this point; what it takes of the previous point's [C | r] comes out of that block's registers
+      const int psrc4 = (rsub * WP + ((c < n) ? Nprev + c : Nprev + n)) * 4;
+#pragma unroll
+      for (int t=0; t<NREG; t++)
+      {
+         const int r = t*RPR + rsub;
+         const real pv = lane_fetch(w[t], psrc4);          // C[r][c] (c < n) or r[r] of the previous point: for the rows r < n
+         real v = jn[t];
+         if (r < n)
+         {
+            if (c < n) v = ((r == c) ? di : (real)0) - back * pv;
+            else if (c >= N && c < N + n) v = (c - N == r) ? fwd : (real)0;
+            else if (c == Wd - 1) v = -back * pv;
+         }
+         w[t] = v;
+      }
+      // the next point's rows, and its entries of J and h on their way while this block is eliminated
+      int ki_next = ki;
+      if (i + DIR != i_end)
+      {
+         if (every_point) fetch_direct(i + DIR);
+         else
+         {
+            par ^= 1;
+            ki_next = point_rows(i + DIR, rows2 + 16 * par);
+            fetch(rows2 + 16 * par, ki_next);
+         }
+      }
+      // Gauss-Jordan in the order delta, x (quasi-definite: no pivoting)
+      if (!gauss_jordan_regs<real, WP, NREG>(w, N, c, rsub)) { if (lane == 0) flag[0] = 1; return; }
+      // the delta rows of [C | r] for the back pass
+#pragma unroll
+      for (int t=0; t<NREG; t++)
+      {
+         const int r = t*RPR + rsub;
+         if (r < n && c >= N && c <= N + n) Cst[(size_t) i*n*n1 + r*n1 + (c - N)] = w[t];
+      }
+      Nprev = N; ki = ki_next;
+   }
+   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+}
+
+// where the two eliminations meet: u = delta_{mid-1}, v = delta_mid from (I - C' C") u = r' - C' r", v = r" - C" u
+// (C', r' of point mid-1, C", r" of point mid; one wavefront).  out [2][n].
+template <typename real, int NREG, typename BT>
+__device__ void tsr_meet_regs(const BT & b, const real * Cst, int mid, real * out, int * flag)
+{
+   constexpr int WP = 16, RPR = 4;            // n <= 15: the block [I - C' C" | r' - C' r"] in rows of 16 lanes
+   const int lane = threadIdx.x & 63;
+   const int c = lane & (WP - 1), rsub = lane / WP;
+   const int n = b.n, n1 = n + 1;
+   const real * Ca = Cst + (size_t)(mid - 1) * n * n1, * Cb = Cst + (size_t) mid * n * n1;
+   real w[NREG];
+#pragma unroll
+   for (int t=0; t<NREG; t++)
+   {
+      const int r = t*RPR + rsub;
+      real v = 0;
+      if (r < n && c <= n)
+      {
+         v = (c < n) ? ((c == r) ? (real)1 : (real)0) : Ca[r*n1 + n];
+         for (int j=0; j<n; j++) v -= Ca[r*n1 + j] * Cb[j*n1 + c];
+      }
+      w[t] = v;
+   }
+   if (!gauss_jordan_regs<real, WP, NREG>(w, n, c, rsub)) { if (lane == 0) flag[0] = 1; return; }
+   // u[r] sits in lane (r, n); v[r] = r"[r] - sum_j C"[r][j] u[j] by the lanes (r, 0)
+#pragma unroll
+   for (int t=0; t<NREG; t++)
+   {
+      const int r = t*RPR + rsub;
+      if (r < n && c == n) out[r] = w[t];
+   }
+   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+   __builtin_amdgcn_wave_barrier();
+   if (lane < n)
+   {
+      real v = Cb[lane*n1 + n];
+      for (int j=0; j<n; j++) v -= Cb[lane*n1 + j] * out[j];
+      out[n + lane] = v;
+   }
+   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+}
+// (more than 15 columns: one lane per row, the row in private memory)
+template <typename real, typename BT>
+__device__ void tsr_meet(const BT & b, const real * Cst, int mid, real * out, int * flag)
+{
+   const int lane = threadIdx.x & 63;
+   const int n = b.n, n1 = n + 1;
+   const real * Ca = Cst + (size_t)(mid - 1) * n * n1, * Cb = Cst + (size_t) mid * n * n1;
+   const int r = (lane < n) ? lane : 0;
+   // row r of [I - C' C" | r' - C' r"], Gauss-Jordan with partial pivoting left out (the matrix is I minus a contraction)
+   real row[ORC_MAX_JOINTS + 8];
+   for (int cc=0; cc<=n; cc++)
+   {
+      real sacc = (cc < n) ? ((cc == r) ? (real)1 : (real)0) : Ca[r*n1 + n];
+      for (int j=0; j<n; j++) sacc -= Ca[r*n1 + j] * Cb[j*n1 + cc];
+      row[cc] = sacc;
+   }
+   bool singular = false;
+   for (int k=0; k<n; k++)
+   {
+      real pk = 0;
+      for (int cc=0; cc<=n; cc++) if (cc == k) pk = row[cc];
+      const real p = read_lane(pk, k);
+      const real ap = M<real>::fabs_(p);
+      if (!(ap > (real)0 && ap < M<real>::inf())) { singular = true; break; }
+      const real inv = (real)1 / p;
+      real mine = 0;
+      for (int cc=0; cc<=n; cc++) if (cc == k) mine = row[cc];
+      for (int cc=0; cc<=n; cc++)
+      {
+         const real prow = read_lane(row[cc], k) * inv;
+         row[cc] = (lane == k) ? prow : row[cc] - mine * prow;
+      }
+   }
+   if (singular) { if (lane == 0) flag[0] = 1; return; }
+   const real u = row[n];
+   real v = Cb[r*n1 + n];
+   for (int j=0; j<n; j++) v -= Cb[r*n1 + j] * read_lane(u, j);
+   if (lane < n) { out[lane] = u; out[n + lane] = v; }
+   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+}
+
+// the substitution outwards: delta_i = r_i - C_i delta_(i - DIR), T_i -= delta_i (chomp.c:592-599), starting next to
+// the point whose delta is `start` (lane j holds component j)
+template <typename real, int DIR, int WPS, int NREGS, typename BT>
+__device__ void tsr_substitute(const BT & b, const Env<real> & E, const real * Cst, const real * start, int i_begin, int i_end)
+{
+   const int lane = threadIdx.x & 63;
+   const int n = b.n, n1 = n + 1;
+   real * Tw = E.T_s;
+   if constexpr (WPS > 0)
+   {
+      // lane = (row % (64 / WPS), column j), register t = row t (64 / WPS) + rsub; n + 1 <= WPS.  A lane multiplies its
+      // element C[r][j] (fetched a point ahead, one coalesced read per register) by delta_(i - DIR)[j], the row sums
+      // run over the WPS lanes of a row by DPP, and every lane of row r ends up with delta_i[r]
+      constexpr int RPRS = 64 / WPS;
+      const int j = lane & (WPS - 1), rsub = lane / WPS;
+      const bool is_c = (j < n), is_r = (j == n);
+      // delta of the point before, for column j: from any lane of row j
+      real dj[NREGS];                          // delta[r] of the previous point in the lanes of row r
+#pragma unroll
+      for (int t=0; t<NREGS; t++) { const int r = t*RPRS + rsub; dj[t] = (r < n) ? start[r] : (real)0; }
+      real cn[NREGS];
+      auto fetch = [&](int i) {
+#pragma unroll
+         for (int t=0; t<NREGS; t++)
+         {
+            const int r = t*RPRS + rsub;
+            cn[t] = (r < n && j <= n) ? Cst[(size_t) i*n*n1 + r*n1 + j] : (real)0;
+         }
+      };
+      if (i_begin != i_end) fetch(i_begin);
+      // the lane of row j's data: row j lives in register j / RPRS of the lanes (j % RPRS) * WPS + anything
+      const int src4 = ((j % RPRS) * WPS) * 4;
+      const int treg = j / RPRS;
+      for (int i=i_begin; i!=i_end; i+=DIR)
+      {
+         real cc[NREGS];
+#pragma unroll
+         for (int t=0; t<NREGS; t++) cc[t] = cn[t];
+         if (i + DIR != i_end) fetch(i + DIR);
+         // delta_(prev)[j] for this lane's column
+         real dsel = dj[0];
+#pragma unroll
+         for (int t=1; t<NREGS; t++) dsel = (treg == t) ? dj[t] : dsel;
+         // (every lane fetches from register treg of the source lane: the source holds all registers, pick there)
+         real dcol = 0;
+#pragma unroll
+         for (int t=0; t<NREGS; t++)
+         {
+            const real got = lane_fetch(dj[t], src4);
+            dcol = (treg == t) ? got : dcol;
+         }
+         (void) dsel;
+#pragma unroll
+         for (int t=0; t<NREGS; t++)
+         {
+            const int r = t*RPRS + rsub;
+            real term = is_c ? -cc[t] * dcol : (is_r ? cc[t] : (real)0);
+            // sum over the WPS lanes of the row
+            if (WPS >= 2)  term += dpp_move<0xB1>(term);
+            if (WPS >= 4)  term += dpp_move<0x4E>(term);
+            if (WPS >= 8)  term += dpp_move<0x141>(term);
+            if (WPS >= 16) term += dpp_move<0x140>(term);
+            dj[t] = term;
+            if (r < n && j == 0) Tw[n + i*n + r] -= term;
+         }
+      }
+   }
+   else
+   {
+      real dl = (lane < n) ? start[lane] : (real)0;
+      const int rl = (lane < n) ? lane : 0;
+      for (int i=i_begin; i!=i_end; i+=DIR)
+      {
+         const real * Cr = Cst + (size_t) i*n*n1 + rl*n1;
+         real d = Cr[n];
+         for (int jj=0; jj<n; jj++) d -= Cr[jj] * read_lane(dl, jj);
+         dl = d;
+         if (lane < n) Tw[n + i*n + lane] -= d;
+      }
+   }
+   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+}
+
 // The constraint step.  AG holds the unconstrained update (chomp.c:525-548), T_s the trajectory before it.
 template <typename real, bool GS16, int BLOCK>
 __device__ __attribute__((noinline)) void phase_tsr(const void * kp)
@@ -466,6 +825,12 @@ __device__ __attribute__((noinline)) void phase_tsr(const void * kp)
    const real * T_s = E.T_s;
    const real inv_lambda = (real)(-1) / b.lambda;
 
+#ifdef ORC_TSR_TIMERS
+   long long tmk[6]; tmk[0] = clock64();
+#define ORC_TMARK(k) do { tmk[k] = clock64(); } while (0)
+#else
+#define ORC_TMARK(k) do { } while (0)
+#endif
    // ---- every point constraint into h and J; h += -1/lambda J AG_i (chomp.c:558-565) ----
    for (int o=tid; o<NB; o+=BLOCK)
    {
@@ -484,18 +849,85 @@ __device__ __attribute__((noinline)) void phase_tsr(const void * kp)
       }
    }
    __syncthreads();
+   ORC_TMARK(1);
 #ifndef ORC_ABLATE_NOTH
    if (b.tsr_structured)
    {
       real * Cst = Mws + (size_t) K * K;        // [m][n][n+1]
       if (tid == 0) E.redi[0] = 0;
       __syncthreads();
-      if (tid < 64) tsr_block_thomas<real>(b, E, hws, Jws, Cst, E.redi);
-      __threadfence_block();
-      __syncthreads();
-      const int failed = E.redi[0];
-      __syncthreads();
-      if (!failed) return;
+      const int Nm = b.tsr_nmax, Wm = Nm + n + 1, wave = tid >> 6;
+      int shape = 0;                             // the register form's padded width, 0: the LDS form (one wavefront)
+#ifndef ORC_TSR_LDS
+      if (BLOCK >= 128 && m >= 4 && n <= 62)
+         shape = (Wm <= 16 && Nm <= 8) ? 16 : ((Wm <= 32 && Nm <= 16) ? 32 : ((Wm <= 64 && Nm <= 20) ? 64 : 0));
+#endif
+      if (!shape)
+      {
+         if (tid < 64) tsr_block_thomas<real>(b, E, hws, Jws, Cst, E.redi);
+         __threadfence_block();
+         __syncthreads();
+         const int failed0 = E.redi[0];
+         __syncthreads();
+         if (!failed0) return;
+      }
+      else
+      {
+         const int mid = m / 2;
+         int * rows = (int *) E.ax_s + 32 * wave;          // (dead tile buffer: a wavefront's lists of rows of the current and the next point)
+         real * meet = (real *)((int *) E.ax_s + 64);      // [2][n]: delta_{mid-1}, delta_mid
+         if (wave == 0)
+         {
+            if (shape == 16) tsr_eliminate_regs<real, 16, 2, +1>(b, E, hws, Jws, Cst, E.redi, 0, mid, rows);
+            else if (shape == 32) tsr_eliminate_regs<real, 32, 8, +1>(b, E, hws, Jws, Cst, E.redi, 0, mid, rows);
+            else tsr_eliminate_regs<real, 64, 20, +1>(b, E, hws, Jws, Cst, E.redi, 0, mid, rows);
+         }
+         else if (wave == 1)
+         {
+            if (shape == 16) tsr_eliminate_regs<real, 16, 2, -1>(b, E, hws, Jws, Cst, E.redi, m - 1, mid - 1, rows);
+            else if (shape == 32) tsr_eliminate_regs<real, 32, 8, -1>(b, E, hws, Jws, Cst, E.redi, m - 1, mid - 1, rows);
+            else tsr_eliminate_regs<real, 64, 20, -1>(b, E, hws, Jws, Cst, E.redi, m - 1, mid - 1, rows);
+         }
+         __threadfence_block();
+         __syncthreads();
+         ORC_TMARK(2);
+         if (wave == 0 && !E.redi[0])
+         {
+            if (n <= 7) tsr_meet_regs<real, 2>(b, Cst, mid, meet, E.redi);
+            else if (n <= 15) tsr_meet_regs<real, 4>(b, Cst, mid, meet, E.redi);
+            else tsr_meet<real>(b, Cst, mid, meet, E.redi);
+         }
+         __threadfence_block();
+         __syncthreads();
+         ORC_TMARK(3);
+         const int failed1 = E.redi[0];
+         if (!failed1)
+         {
+            real * Tw = E.T_s;
+            if (wave == 0)
+            {
+               if (tid < n) Tw[n + (mid - 1)*n + tid] -= meet[tid];
+               if (n <= 7) tsr_substitute<real, -1, 8, 1>(b, E, Cst, meet, mid - 2, -1);
+               else if (n <= 15) tsr_substitute<real, -1, 16, 4>(b, E, Cst, meet, mid - 2, -1);
+               else tsr_substitute<real, -1, 0, 1>(b, E, Cst, meet, mid - 2, -1);
+            }
+            else if (wave == 1)
+            {
+               const int ln = tid & 63;
+               if (ln < n) Tw[n + mid*n + ln] -= meet[n + ln];
+               if (n <= 7) tsr_substitute<real, +1, 8, 1>(b, E, Cst, meet + n, mid + 1, m);
+               else if (n <= 15) tsr_substitute<real, +1, 16, 4>(b, E, Cst, meet + n, mid + 1, m);
+               else tsr_substitute<real, +1, 0, 1>(b, E, Cst, meet + n, mid + 1, m);
+            }
+         }
+         __threadfence_block();
+         __syncthreads();
+#ifdef ORC_TSR_TIMERS
+         ORC_TMARK(4);
+         if (tid == 0 && run == 0) printf("tsr step (cycles): constraints %lld eliminate %lld meet %lld substitute %lld\n", tmk[1]-tmk[0], tmk[2]-tmk[1], tmk[3]-tmk[2], tmk[4]-tmk[3]);
+#endif
+         if (!failed1) return;
+      }
       // a singular block: the dense path below treats the case the way the reference does
    }
 #endif
