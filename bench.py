@@ -112,20 +112,60 @@ class Workload:
             self.kernel = "chomp_iterate_kernel<float, tree, generic cost path>"
             self.label = ("30-DOF tree, 60 spheres, 4 box kinbodies with fields at cube_extent=0.005, n_points=200, "
                           "batch=%d, fp32, n_iter=%d per step (BASELINE configs[4])" % (self.n_runs, N_ITER))
+        elif config in ("tsr1", "tsr3"):
+            # the WAM of config 2 with its end-effector link held on a task space region: the hard-constraint step of
+            # cd_chomp_iterate (src/libcd/chomp.c:550-600) with con_tsr (src/orcdchomp_mod.cpp:1330-1497) on every point
+            self.n_runs = batch or 1024
+            self.goals = None
+            self.rows = 1 if config == "tsr1" else 3
+            self.kw = dict(n_points=100, lambda_=100.0, obs_factor=200.0)
+            self.m, self.n, self.Sa, self.n_sdf, self.w, self.momentum = 98, 7, 15, 1, 8, False
+            self.dtype = "f64"
+            self.kernel = "chomp_iterate_kernel<double, chain, 16-lane rows> with the constraint phase (csrc/tsr.h)"
+            self.label = ("WAM 7-DOF, n_points=100, batch=%d goals within 0.4 rad of the start, con_tsr 'all link wam7' with %d constrained "
+                          "row(s) per moving point, n_iter=%d per step, lambda=100 obs_factor=200" % (self.n_runs, self.rows, N_ITER))
         else:
-            raise SystemExit("--config must be 2, 3, 4 or 5")
+            raise SystemExit("--config must be 2, 3, 4, 5, tsr1 or tsr3")
         self.bytes_iter = algorithmic_bytes_per_iter(self.m, self.n, self.Sa, self.n_sdf, self.w, self.momentum)
+        if config in ("tsr1", "tsr3"):
+            # + the constraint step: h and J written and read (2 K (n + 1) w), the rows of C' and r' of the block
+            # elimination written and read (2 m n (n + 1) w); K = m rows
+            K = self.m * self.rows
+            self.bytes_iter += 2 * K * (self.n + 1) * self.w + 2 * self.m * self.n * (self.n + 1) * self.w
         self.robots = robots
+
+    TSR_BASE = [-1.0, 0.0, 1.0, 0.0, float(np.sqrt(0.5)), 0.0, float(np.sqrt(0.5))]      # (a unit quaternion: the constraint frames are poses)
 
     def setup(self, mod):
         if self.config == 5:
             self.model = self.common.setup_product_tree30(mod)
+        elif self.config in ("tsr1", "tsr3"):
+            from or_cdchomp_amd import scenes
+            model, _, dofvals, adofs = self.common.wam_state()
+            mod.add_robot(model, transform=self.TSR_BASE, dof_values=dofvals, active_dofs=adofs)
+            scenes.add_tabletop(mod)
+            mod.SendCommand("computedistancefield kinbody table")
+            self.model = model
+            self.tsr = None
         else:
             self.model = self.common.setup_product_wam(mod)
+
+    def tsr_spec(self):
+        """the end-effector link's own start frame as the TSR frame: xyz free within +-1 m where Bw says so"""
+        if self.tsr is None:
+            _, _, dofvals, _ = self.common.wam_state()
+            R, t = self.model.link_frames(self.TSR_BASE, dofvals)
+            li = self.model.link_names.index("wam7")
+            Bw = [[-1, 1], [-1, 1], [0, 0], [0, 0] if self.rows > 1 else [-3, 3], [0, 0] if self.rows > 2 else [-3, 3], [-3, 3]]
+            self.tsr = (self.robots.Tsr(T0w_R=R[li], T0w_d=t[li], Bw=Bw), li, R[li], t[li], Bw)
+        return self.tsr
 
     def step_goals(self, step, rank):
         if self.config == 2:
             return self.common.wam_goals(self.n_runs, seed=20250101 + 1000 * rank + step)
+        if self.config in ("tsr1", "tsr3"):
+            rng = np.random.default_rng(20250105 + 1000 * rank + step)
+            return np.ascontiguousarray(np.array(self.robots.WAM_START)[None, :] + 0.4 * rng.uniform(-1, 1, size=(self.n_runs, 7)))
         return self.goals
 
     def create(self, mod, step, rank):
@@ -134,6 +174,11 @@ class Workload:
             return mod.batch_create(self.model.name, g, basegoals=self.basegoals, seeds=self.seeds, **self.kw)
         if self.config == 5:
             return mod.batch_create(self.model.name, g, precision=32, **self.kw)
+        if self.config in ("tsr1", "tsr3"):
+            self._keep = getattr(self, "_keep", []) + [g]
+            return int(mod.SendCommand("createbatch robot %s n_runs %d adofgoals 0x%x n_points %d lambda %r obs_factor %r "
+                                       "con_tsr 'all link wam7' '%s'" % (self.model.name, self.n_runs, g.ctypes.data, self.kw["n_points"],
+                                                                       self.kw["lambda_"], self.kw["obs_factor"], self.tsr_spec()[0].serialize())))
         return mod.batch_create(self.model.name, g, **self.kw)
 
     def oracle_setup(self, O):
@@ -145,11 +190,29 @@ class Workload:
         else:
             prob = c.tabletop_problem(O)
             _, base, dofvals, adofs = c.wam_state()
+            if self.config in ("tsr1", "tsr3"):
+                base = self.TSR_BASE
             self.o_args = (O.OraRobot(self.model), base, dofvals, adofs)
             self.o_fields = ([prob["sdf"]], [prob["pose"]])
 
     def oracle_run(self, O, idx, goals, threads, scale=1.0):
         rob, base, dofvals, adofs = self.o_args
+        if self.config in ("tsr1", "tsr3"):
+            # constrained runs: one oracle run object each (the constraint is added to the run), host threads over runs
+            from concurrent.futures import ThreadPoolExecutor
+            _, li, R, t, Bw = self.tsr_spec()
+
+            def one(k):
+                run = O.OraRun(rob, base, dofvals, adofs, goals[k] * scale, self.o_fields[0], self.o_fields[1], O.default_params(**self.kw))
+                run.add_contsr(li, [0, 0, 0, 0, 0, 0, 1], O.pose_from_dR(t, R), [0, 0, 0, 0, 0, 0, 1], Bw)
+                st, costs = run.iterate(N_ITER)
+                out = (run.traj().copy(), np.asarray(costs, dtype=float), st)
+                run.destroy()
+                return out
+            nt = max(1, int(threads))
+            with ThreadPoolExecutor(max_workers=nt) as ex:
+                res = list(ex.map(one, [int(k) for k in idx]))
+            return (np.array([r[0] for r in res]), np.array([r[1] for r in res]), np.array([r[2] for r in res], dtype=np.int32), min(nt, len(res)))
         kw = {}
         if self.config == 4:
             kw = dict(basegoals=self.basegoals[idx], seeds=self.seeds[idx])
@@ -297,7 +360,7 @@ def run_workload(config, args, rank, world, device, dist, steps, warmup, serial_
         if not args.no_cpu_baseline and world == 1:         # the CPU baseline is reported at N=1 only
             cores = host_cores()
             # ~0.1 s (config 2) to ~2.5 s (config 5) per run of 100 iterations on one core; 10-20 s of wall time
-            per_core = {2: 48, 3: 48, 4: 12, 5: 6}[config]
+            per_core = {2: 48, 3: 48, 4: 12, 5: 6, "tsr1": 24, "tsr3": 4}[config]
             sample = args.cpu_runs or int(min(n_runs, max(8, per_core * cores)))
             sidx = np.arange(min(sample, n_runs))
             c0 = time.perf_counter()
@@ -340,7 +403,7 @@ def run_workload(config, args, rank, world, device, dist, steps, warmup, serial_
         cpath = os.path.join(ROOT, "profiles", "counters_latest.json")
         if os.path.exists(cpath):
             try:
-                cj = json.load(open(cpath)).get("config%d" % (2 if config == 3 else config))
+                cj = json.load(open(cpath)).get("config%s" % (2 if config == 3 else config))
                 if cj and cj.get("batch") == n_runs and cj.get("n_iter") == N_ITER:
                     traffic = cj.get("hbm_bytes_per_launch")
                     ipri = cj.get("valu_insts_per_run_iteration")
@@ -356,7 +419,9 @@ def run_workload(config, args, rank, world, device, dist, steps, warmup, serial_
                 traffic, valu = None, None
         flop = FLOP_PER_ITERATION.get(config)
         out = {
-            "metric": "CHOMP iters/sec, 7-DOF x 100-waypoint" if config in (2, 3) else "CHOMP iters/sec (BASELINE configs[%d])" % (config - 1),
+            "metric": "CHOMP iters/sec, 7-DOF x 100-waypoint" if config in (2, 3) else (
+                "CHOMP iters/sec, 7-DOF x 100-waypoint, TSR-constrained (%s)" % config if isinstance(config, str)
+                else "CHOMP iters/sec (BASELINE configs[%d])" % (config - 1)),
             "value": value,
             "unit": "CHOMP iterations/s",
             "n_gpus": world,
@@ -419,8 +484,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", type=int, default=0, help="BASELINE configuration: 2 (default at --gpus 1), 3 (default at "
-                                                          "--gpus > 1), 4 or 5")
+    ap.add_argument("--config", default="", help="BASELINE configuration: 2 (default at --gpus 1), 3 (default at --gpus > 1), 4 or 5; "
+                                                 "tsr1 / tsr3: config 2's runs held on a TSR by one / three hard-constraint rows "
+                                                 "on every moving point (con_tsr, SURVEY.md 8f rank 4)")
     ap.add_argument("--batch", type=int, default=0, help="runs per GPU (default: the configuration's own size)")
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the steps are issued on round-robin: consecutive steps are independent batches, "
@@ -448,6 +514,8 @@ def main():
     if world != args.gpus:
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
     config = args.config or (2 if world == 1 else 3)
+    if str(config) in ("2", "3", "4", "5"):
+        config = int(config)
 
     import torch
     if not torch.cuda.is_available():

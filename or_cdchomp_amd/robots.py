@@ -87,6 +87,28 @@ class RobotModel:
             self.add_sphere(attrs["link"], [float(v) for v in attrs["pos"].split()],
                             float(attrs["radius"]))
 
+    def link_frames(self, base_pose, dof_values):
+        """world frames (R [n_links][3][3], t [n_links][3]) of all links: link frame = parent link frame o
+        pose_parent_joint o motion(axis, q[dof]); base_pose and pose_parent_joint are x y z qx qy qz qw"""
+        def rot(q):
+            x, y, z, w = q
+            return np.array([[1 - 2*(y*y + z*z), 2*(x*y - z*w), 2*(x*z + y*w)],
+                             [2*(x*y + z*w), 1 - 2*(x*x + z*z), 2*(y*z - x*w)],
+                             [2*(x*z - y*w), 2*(y*z + x*w), 1 - 2*(x*x + y*y)]])
+        Rb, tb = rot(base_pose[3:7]), np.asarray(base_pose[:3], dtype=np.float64)
+        R, t = [], []
+        for li in range(len(self.link_names)):
+            Rp, tp = (Rb, tb) if self.parent[li] < 0 else (R[self.parent[li]], t[self.parent[li]])
+            pj = self.pose_parent_joint[li]
+            Rj, tj = Rp @ rot(pj[3:7]), Rp @ np.asarray(pj[:3]) + tp
+            if self.joint_type[li] == JOINT_REVOLUTE:
+                a = np.asarray(self.axis[li]); q = float(dof_values[self.dof_index[li]])
+                Rj = Rj @ rot(list(a * math.sin(0.5 * q)) + [math.cos(0.5 * q)])
+            elif self.joint_type[li] != JOINT_FIXED:
+                tj = tj + float(dof_values[self.dof_index[li]]) * (Rj @ np.asarray(self.axis[li]))
+            R.append(Rj); t.append(tj)
+        return np.array(R), np.array(t)
+
     # flat arrays for the C structs -------------------------------------------------
     def arrays(self):
         return dict(
