@@ -300,6 +300,8 @@ void BatchShard::release()
                      (void **) &d_hmc_iters_, &d_noise_, (void **) &d_phase_, &d_Gcost_, &d_tsrs_, &d_tsr_ws_, (void **) &d_tsr_err_ };
    for (void ** p : all) { dev_free(*p); *p = nullptr; }
    sdf_refs_.clear();
+   for (int k=0; k<2; k++) if (ev_plan_[k]) { (void) hipEventDestroy(ev_plan_[k]); ev_plan_[k] = nullptr; }
+   if (h_overflow_) { (void) hipHostFree(h_overflow_); h_overflow_ = nullptr; }
    for (auto & ev : pending_events_) { mod_->release_event(device, ev.first); mod_->release_event(device, ev.second); }
    pending_events_.clear();
 }
@@ -1028,6 +1030,37 @@ void BatchShard::plan_hmc(int iter_begin, int iter_end)
    if (hmc_on_device_)
    {
       const size_t rsize = (params.precision == 64) ? 8 : 4;
+      if (!getenv("ORC_HMC_PLAN_SYNC"))
+      {
+         // The plan of the call runs on the device's high-priority plan stream, ordered between the shard's earlier
+         // work and the iterate launch by events: the host does not wait for it (queued on the shard's own stream it
+         // sat behind the other stream's iterate launch for ~14 ms of a config-4 step, and the host with it).
+         // Room for the resamples of a call: Poisson(n_iter lambda) + 12 standard deviations + 10 (beyond 1e-20 per
+         // run); a run that still needs more raises the overflow flag, which the call's sync reports as an error.
+         const double mean = n_iter * params.hmc_resample_lambda;
+         const int cap = (int) std::ceil(mean + 12.0 * std::sqrt(mean) + 10.0);
+         const size_t icount = (size_t) n_runs * cap, ncount = icount * mn;
+         if (icount > hmc_cap_iters_ || ncount * rsize > noise_cap_)
+         {
+            hip_check(hipStreamSynchronize(stream_), "hmc buffers: pending work");      // (an earlier launch may still read them)
+            if (icount > hmc_cap_iters_) { dev_free(d_hmc_iters_); d_hmc_iters_ = dev_alloc<int>(icount); hmc_cap_iters_ = icount; }
+            if (ncount * rsize > noise_cap_) { dev_free(d_noise_); hip_check(hipMalloc(&d_noise_, ncount * rsize), "noise"); noise_cap_ = ncount * rsize; }
+         }
+         hipStream_t ps = mod_->plan_stream(device);
+         for (int k=0; k<2; k++) if (!ev_plan_[k]) hip_check(hipEventCreateWithFlags(&ev_plan_[k], hipEventDisableTiming), "hipEventCreate");
+         if (!h_overflow_) { hip_check(hipHostMalloc((void **) &h_overflow_, sizeof(int)), "hipHostMalloc"); *h_overflow_ = 0; }
+         hip_check(hipEventRecord(ev_plan_[0], stream_), "hipEventRecord");
+         hip_check(hipStreamWaitEvent(ps, ev_plan_[0], 0), "hipStreamWaitEvent");
+         hip_check(hipMemsetAsync(d_overflow_, 0, sizeof(int), ps), "hmc overflow");
+         hipError_t e = (params.precision == 64)
+            ? orc_launch_hmc_plan_f64(d_mt_, d_hmc_next_, n_runs, iter_begin, iter_end, cap, mn, params.hmc_resample_lambda, (double *) d_noise_, d_hmc_iters_, d_overflow_, ps)
+            : orc_launch_hmc_plan_f32(d_mt_, d_hmc_next_, n_runs, iter_begin, iter_end, cap, mn, params.hmc_resample_lambda, (float *) d_noise_, d_hmc_iters_, d_overflow_, ps);
+         hip_check(e, "hmc plan");
+         hip_check(hipEventRecord(ev_plan_[1], ps), "hipEventRecord");
+         hip_check(hipStreamWaitEvent(stream_, ev_plan_[1], 0), "hipStreamWaitEvent");
+         max_resamples_ = cap;
+         return;
+      }
       int cap = 6 + (int) std::ceil(n_iter * params.hmc_resample_lambda * 3.0);
       for (;;)
       {
@@ -1209,6 +1242,7 @@ void BatchShard::sync_begin(double * costs_out, int * status_out, int * iters_ou
    if (costs_out) hip_check(hipMemcpyAsync(costs_out, d_costs_, (size_t) n_runs*3*sizeof(double), hipMemcpyDeviceToHost, st), "costs");
    if (status_out) hip_check(hipMemcpyAsync(status_out, d_status_, n_runs*sizeof(int), hipMemcpyDeviceToHost, st), "status");
    if (iters_out) hip_check(hipMemcpyAsync(iters_out, d_iters_done_, n_runs*sizeof(int), hipMemcpyDeviceToHost, st), "iters_done");
+   if (h_overflow_) hip_check(hipMemcpyAsync(h_overflow_, d_overflow_, sizeof(int), hipMemcpyDeviceToHost, st), "hmc overflow");
 }
 
 void BatchShard::sync_end()
@@ -1216,6 +1250,11 @@ void BatchShard::sync_end()
    DeviceGuard guard(device);
    hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
    harvest_events(false);
+   if (h_overflow_ && *h_overflow_)
+   {
+      *h_overflow_ = 0;
+      throw std::runtime_error("hmc: a run drew more momentum resamples in one iterate call than the plan has room for; iterate with fewer iterations per call!");
+   }
 }
 
 namespace {

@@ -10,6 +10,10 @@
 // SDF lookup src/libcd/grid.c:191-209, 331-454.
 #pragma once
 
+#ifndef ORC_GS16_CELL
+#define ORC_GS16_CELL 1      // 1: the one-field variants look the field up in cell units with the descriptor in scalar registers
+#endif
+
 #ifdef ORC_COST_TIMERS
 __device__ long long orc_cost_dbg[8];   // [0] setup [1] obstacle [2] self collision [3] J^T [4] between rounds (thread 0 of every workgroup adds: use one run)
 #endif
@@ -110,6 +114,51 @@ __device__ __forceinline__ void sdf_combine(const DevSdf<real> & f, const SdfCel
       v += slope * c.off[d];
    }
    value = poisoned ? inf : v;
+}
+
+// The lookup for ONE field whose axes are the world's, in cell units (DevSdfCell), the descriptor in scalar registers:
+// g = sol p + t per axis, value = v0 + sum (after - before) (g - (sub + 0.5)), world gradient = sol (after - before).
+// Returns whether p is inside the field (value / gradient are only meaningful then).
+template <typename real, typename CD>
+__device__ __forceinline__ bool sdf_lookup_cell_aligned(const CD & F, const real p[3], real & value, real gw[3])
+{
+   real fr[3]; bool prev[3];
+   bool inb = true;
+   int off = 0;
+#pragma unroll
+   for (int k=0; k<3; k++)
+   {
+      const real gx = F.M[4*k] * p[k] + F.t[k];
+      inb = inb && !(gx < (real)0) && !(gx > F.fsize[k]);
+      real fl = M<real>::floor_(gx);
+      fl = M<real>::max_(M<real>::min_(fl, F.fsize_m1[k]), (real)0);      // g == size: the last cell (grid.c:203); outside: clamped, masked by inb
+      fr[k] = (gx - fl) - (real)0.5;
+      prev[k] = (fl == (real)0) ? false : ((fl == F.fsize_m1[k]) ? true : (fr[k] < (real)0));
+      off += (int) fl * ((k == 2) ? (int) sizeof(real) : F.stride_b[k]);
+   }
+   const char * base = (const char *) F.data;
+   const real v0 = *(const real *)(base + off);
+   real vn[3];
+#pragma unroll
+   for (int k=0; k<3; k++)
+   {
+      const int sb = (k == 2) ? (int) sizeof(real) : F.stride_b[k];
+      vn[k] = *(const real *)(base + (off + (prev[k] ? -sb : sb)));
+   }
+   const real inf = M<real>::inf();
+   bool poisoned = (v0 == inf);
+   real v = v0;
+#pragma unroll
+   for (int k=2; k>=0; k--)                     // the reference walks the axes z, y, x
+   {
+      poisoned = poisoned || (vn[k] == inf);
+      const real dd = vn[k] - v0;
+      const real df = prev[k] ? -dd : dd;       // after - before
+      gw[k] = F.W[4*k] * df;
+      v += df * fr[k];
+   }
+   value = poisoned ? inf : v;
+   return inb;
 }
 
 // One SYMMETRIC rotation step K (1..8) of the self-collision term (src/orcdchomp_mod.cpp:1251-1317).
@@ -283,6 +332,25 @@ __device__ __forceinline__ void cost_tile_gs16(const BT & b, const ModelView<rea
 #pragma unroll
       for (int u=0; u<U; u++) { best[u] = inf; has[u] = false; bgrad[u][0] = 0; bgrad[u][1] = 0; bgrad[u][2] = 0; }
 #ifndef ORC_ABLATE_SDF
+#if ORC_GS16_CELL
+      if constexpr (ONEF)
+      {
+         typedef const __attribute__((address_space(4))) DevSdfCell<real> CellDesc;
+         CellDesc & F = *((CellDesc *) b.sdfc);
+#pragma unroll
+         for (int u=0; u<U; u++)
+         {
+            real gw[3], val;
+            const bool inb = sdf_lookup_cell_aligned<real>(F, p[u], val, gw);
+            const bool better = inb && (val < best[u]);
+            best[u] = better ? val : best[u];
+            has[u] = has[u] || better;
+#pragma unroll
+            for (int k=0; k<3; k++) bgrad[u][k] = better ? gw[k] : bgrad[u][k];
+         }
+      }
+      else
+#endif
       for (int i=0; i<(ONEF ? 1 : b.n_sdfs); i++)
       {
          const DevSdf<real> & F = sdfs[i];

@@ -157,6 +157,11 @@ Module::~Module()
       DeviceGuard guard(kv.first);
       for (hipStream_t st : kv.second) (void) hipStreamDestroy(st);
    }
+   for (auto & kv : plan_streams_)
+   {
+      DeviceGuard guard(kv.first);
+      (void) hipStreamDestroy(kv.second);
+   }
 }
 
 hipEvent_t Module::acquire_event(int dev)
@@ -226,6 +231,20 @@ hipStream_t Module::pick_stream(int dev, bool distinct)
       }
    }
    return pool[next_pool_stream[dev]++ % pool.size()];
+}
+
+hipStream_t Module::plan_stream(int dev)
+{
+   std::lock_guard<std::mutex> lock(timing_mutex_);
+   auto it = plan_streams_.find(dev);
+   if (it != plan_streams_.end()) return it->second;
+   DeviceGuard guard(dev);
+   int least = 0, greatest = 0;
+   hip_check(hipDeviceGetStreamPriorityRange(&least, &greatest), "hipDeviceGetStreamPriorityRange");
+   hipStream_t st;
+   hip_check(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, greatest), "hipStreamCreateWithPriority");
+   plan_streams_[dev] = st;
+   return st;
 }
 
 void Module::time_collect()

@@ -179,6 +179,8 @@ private:
    int n_tsrs_ = 0, cons_k_ = 0; size_t tsr_ws_stride_ = 0;
    int * d_hmc_iters_ = nullptr; void * d_noise_ = nullptr; size_t hmc_cap_iters_ = 0, noise_cap_ = 0;
    int max_resamples_ = 0;
+   hipEvent_t ev_plan_[2] = { nullptr, nullptr };   // iterate stream -> plan stream -> iterate stream
+   int * h_overflow_ = nullptr;                      // pinned: the plan's overflow flag, read with the results of a call
    bool debug_state_ = false;   // ORC_DEBUG_STATE=1: keep the last gradient readable (get_state "G")
    int n_sdfs_ = 0;
    int n_tiles_ = 1, tile_first_ = 0, tile_rest_ = 0;   // tiles of an iteration: the first of tile_first_ moving waypoints, the others of tile_rest_
@@ -292,6 +294,9 @@ public:
    int workgroup_threads = 0;       // 0: the planner's choice; 192 or 256: the workgroup shape of every batch created from now on
    void set_num_streams(int n);
    hipStream_t pick_stream(int device, bool distinct);
+   // a high-priority stream per device for the hmc plan of a call (hmc_kernels.hip): its wavefronts are dispatched ahead
+   // of the iterate launches queued on the other streams instead of behind them
+   hipStream_t plan_stream(int device);
    // kernel timing (HIP events on the shards' streams), harvested from the shards
    void time_collect();
    double kernel_ms_total = 0.0;
@@ -318,6 +323,7 @@ private:
    std::map<int, std::unique_ptr<Batch>> batches_;
    int next_batch_id_ = 1;
    std::map<int, std::vector<hipEvent_t>> event_pool_;
+   std::map<int, hipStream_t> plan_streams_;
    std::mutex timing_mutex_;
 };
 
