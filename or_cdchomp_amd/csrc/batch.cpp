@@ -735,7 +735,8 @@ void BatchShard::build_device(const Robot & robot)
    n_sdfs_ = (int) mod_->sdfs.size();
    if (n_sdfs_ > ORC_MAX_SDFS) throw std::runtime_error("too many signed distance fields for this build!");
    std::vector<DevSdf<real>> hs(n_sdfs_);
-   std::vector<DevSdfCell<real>> hc(n_sdfs_);
+   std::vector<DevSdfCell<real>> hc((size_t)((n_sdfs_ + 3) / 4) * 4 + 4);      // (padded to whole batches of four: the many-sphere cost path loads a batch unconditionally)
+   std::memset(hc.data(), 0, hc.size() * sizeof(DevSdfCell<real>));
    for (int i=0; i<n_sdfs_; i++)
    {
       Sdf & s = *mod_->sdfs[i];
@@ -798,7 +799,7 @@ void BatchShard::build_device(const Robot & robot)
       hc[i].data = hs[i].data;
       if (nc * sizeof(real) >= (size_t) 1 << 31) throw std::runtime_error("signed distance field too large for this build!");
    }
-   DevSdfCell<real> * dc = dev_alloc<DevSdfCell<real>>(n_sdfs_);
+   DevSdfCell<real> * dc = dev_alloc<DevSdfCell<real>>(hc.size());
    hip_check(hipMemcpy(dc, hc.data(), hc.size()*sizeof(DevSdfCell<real>), hipMemcpyHostToDevice), "sdfs (cell units)");
    d_sdfc_ = dc;
    DevSdf<real> * ds = dev_alloc<DevSdf<real>>(n_sdfs_);

@@ -98,55 +98,66 @@ __device__ __forceinline__ void cost_tile_generic(const BT & b, const ModelView<
       bool use[4] = { false, false, false, false };              // wave-uniform: some sphere of the wavefront is inside the field
       auto sdf_issue = [&](int i0)
       {
+         // The descriptors come by scalar loads in three bursts (the array is padded to whole batches of four, so every
+         // burst is unconditional): grid transforms and sizes of all four fields at once, then -- the fields some sphere
+         // of the wavefront is inside of being known -- strides and cell pointers of all four; the gradients' matrices
+         // in sdf_finish.  A burst per field and stage, as the loop was first written, left the wavefront waiting for
+         // eight scalar-cache round trips in a row in front of every waypoint (5.8 k of its 15.6 k cycles).
+         real gx[4][3];
 #pragma unroll
          for (int q=0; q<4; q++)
          {
-            use[q] = false;
-            if (i0 + q >= b.n_sdfs) continue;                       // wave-uniform
             CellDesc & F = fc[i0 + q];
-            real gx[3];
-            bool inb = live;
+            bool inb = live && (i0 + q < b.n_sdfs);
 #pragma unroll
             for (int k=0; k<3; k++)
             {
-               gx[k] = F.M[k*3+0]*p[0] + F.M[k*3+1]*p[1] + F.M[k*3+2]*p[2] + F.t[k];
-               inb = inb && !(gx[k] < (real)0) && !(gx[k] > F.fsize[k]);      // the reference's x < 0 || x > 1 (grid.c:196-199)
+               gx[q][k] = F.M[k*3+0]*p[0] + F.M[k*3+1]*p[1] + F.M[k*3+2]*p[2] + F.t[k];
+               inb = inb && !(gx[q][k] < (real)0) && !(gx[q][k] > F.fsize[k]);      // the reference's x < 0 || x > 1 (grid.c:196-199)
             }
             // a field none of the wavefront's spheres is inside of contributes nothing (the reference
             // skips an out-of-bounds lookup, src/orcdchomp_mod.cpp:1176-1183): no cells, no reads
+            inbq[q] = inb;
             use[q] = (__builtin_amdgcn_ballot_w64(inb) != 0ull);
+         }
+#pragma unroll
+         for (int q=0; q<4; q++)
+         {
+            CellDesc & F = fc[i0 + q];
+            const real m1[3] = { F.fsize_m1[0], F.fsize_m1[1], F.fsize_m1[2] };
+            const int sb3[3] = { F.stride_b[0], F.stride_b[1], (int) sizeof(real) };
+            const char * base = (const char *) F.data;
             if (!use[q]) continue;
             if (dbg) dbg[5]++;
-            inbq[q] = inb;
             int off = 0;
 #pragma unroll
             for (int k=0; k<3; k++)
             {
-               const real g = inb ? gx[k] : (real)0.25;             // lanes outside read cell 0 (valid memory), results masked
+               const real g = inbq[q] ? gx[q][k] : (real)0.25;      // lanes outside read cell 0 (valid memory), results masked
                real fl = M<real>::floor_(g);
-               fl = M<real>::min_(fl, F.fsize_m1[k]);               // g == size: the last cell (grid.c:203)
+               fl = M<real>::min_(fl, m1[k]);                        // g == size: the last cell (grid.c:203)
                fr[q][k] = (g - fl) - (real)0.5;                     // offset from the cell centre, in cells
                // one-sided difference towards the nearer neighbour, inwards at the faces (grid.c:372-389)
-               prev[q][k] = (fl == (real)0) ? false : ((fl == F.fsize_m1[k]) ? true : (fr[q][k] < (real)0));
-               off += (int) fl * ((k == 2) ? (int) sizeof(real) : F.stride_b[k]);
+               prev[q][k] = (fl == (real)0) ? false : ((fl == m1[k]) ? true : (fr[q][k] < (real)0));
+               off += (int) fl * sb3[k];
             }
-            const char * base = (const char *) F.data;
             v0[q] = *(const real *)(base + off);
 #pragma unroll
             for (int k=0; k<3; k++)
-            {
-               const int sb = (k == 2) ? (int) sizeof(real) : F.stride_b[k];
-               vn[q][k] = *(const real *)(base + (off + (prev[q][k] ? -sb : sb)));
-            }
+               vn[q][k] = *(const real *)(base + (off + (prev[q][k] ? -sb3[k] : sb3[k])));
          }
       };
       auto sdf_finish = [&](int i0)
       {
+         real Wq[4][9];                                              // (one burst of scalar loads, see sdf_issue)
+#pragma unroll
+         for (int q=0; q<4; q++)
+#pragma unroll
+            for (int k=0; k<9; k++) Wq[q][k] = fc[i0 + q].W[k];
 #pragma unroll
          for (int q=0; q<4; q++)
          {
             if (i0 + q >= b.n_sdfs || !use[q]) continue;
-            CellDesc & F = fc[i0 + q];
             bool poisoned = (v0[q] == inf);
             real val = v0[q], df[3];
 #pragma unroll
@@ -167,7 +178,7 @@ __device__ __forceinline__ void cost_tile_generic(const BT & b, const ModelView<
 #pragma unroll
             for (int k=0; k<3; k++)
             {
-               const real gw = F.W[k*3+0]*df[0] + F.W[k*3+1]*df[1] + F.W[k*3+2]*df[2];      // grid -> world, per metre
+               const real gw = Wq[q][k*3+0]*df[0] + Wq[q][k*3+1]*df[1] + Wq[q][k*3+2]*df[2];      // grid -> world, per metre
                bgrad[k] = better ? gw : bgrad[k];
             }
          }
