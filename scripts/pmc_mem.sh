@@ -7,7 +7,7 @@ CFG=$1; RUNS=$2; ITER=$3; V=${4:-product}
 if [ $V != product ]; then export ORC_LIB=$ROOT/or_cdchomp_amd/liborcdchomp_var_$V.so; fi
 OUT=$ROOT/gpurun_out/pmcmem_$V; rm -rf $OUT; mkdir -p $OUT
 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum --output-format csv -d $OUT/a -- python3 scripts/run_cfg.py $CFG $RUNS $ITER > $OUT/a.log 2>&1
-rocprofv3 --pmc TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_FLAT_READ_WAVEFRONTS_sum TCC_REQ_sum TCC_READ_sum GRBM_GUI_ACTIVE --output-format csv -d $OUT/b -- python3 scripts/run_cfg.py $CFG $RUNS $ITER > $OUT/b.log 2>&1
+# (a second group with TA_BUSY_avr / GRBM_GUI_ACTIVE made rocprofv3 abort at start-up on this pool and the run hang: left out)
 tail -n 2 $OUT/a.log
 python3 - "$OUT" "$RUNS" "$ITER" <<'PY'
 import csv, glob, collections, sys
