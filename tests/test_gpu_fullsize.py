@@ -118,6 +118,43 @@ def test_config3_shard_8192_runs():
     print("config 3 block: %d of 8192 runs left their joint limits (status -1)" % int((status != 0).sum()))
 
 
+def test_config3_all_eight_blocks_of_the_65536_run_batch():
+    """BASELINE configs[2] as written -- 65 536 runs in contiguous blocks of 8 192 per GPU -- on the one card of this box:
+    every block r = 0..7 iterated the way rank r would (its own batch), and the whole 65 536-run batch as ONE batch cut
+    over eight in-process shards (`devices '0 0 0 0 0 0 0 0'`, the C ABI's own multi-device path).  A run's bits do not
+    depend on which block or batch it is in: block r alone == rows [8192 r, 8192 (r+1)) of the whole batch; the
+    statuses agree with the oracle sample committed for block 0; every run reports the iterations it made."""
+    mod = _module()
+    model = common.setup_product_wam(mod)
+    all_goals = common.wam_goals(65536, seed=20250102)
+    big = _module([0] * 8)
+    common.setup_product_wam(big)
+    bid = big.batch_create(model.name, all_goals, **common.CONFIG2_KW)
+    cb, sb = big.batch_iterate(bid, N_ITER)
+    tb = big.batch_gettraj(bid)
+    ib = big.batch_iterations_done(bid)
+    big.batch_destroy(bid)
+    assert tb.shape == (65536, 100, 7)
+    bad_total = 0
+    for r in range(8):
+        goals = common.config3_goals(rank=r, world=8)
+        assert np.array_equal(goals, all_goals[8192 * r:8192 * (r + 1)])
+        b = mod.batch_create(model.name, goals, **common.CONFIG2_KW)
+        c, s = mod.batch_iterate(b, N_ITER)
+        t = mod.batch_gettraj(b)
+        it = mod.batch_iterations_done(b)
+        mod.batch_destroy(b)
+        sl = slice(8192 * r, 8192 * (r + 1))
+        assert np.array_equal(s, sb[sl]) and np.array_equal(it, ib[sl]), r
+        assert np.array_equal(t, tb[sl]), r
+        ok = s == 0
+        assert np.array_equal(c[ok], cb[sl][ok]), r
+        assert np.array_equal(it == N_ITER, s == 0) and (it[s != 0] < N_ITER).all()
+        assert float((s != 0).mean()) < 0.10
+        bad_total += int((s != 0).sum())
+    print("config 3, all eight blocks: %d of 65536 runs left their joint limits (status -1)" % bad_total)
+
+
 def test_config4_floating_base_momentum_hmc_4096():
     gold = np.load(os.path.join(GOLDEN, "fullsize_config4.npz"))
     mod = _module()
