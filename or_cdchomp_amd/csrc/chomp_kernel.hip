@@ -1560,7 +1560,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
 
    phase_setup<real, TREE, GS16, BLOCK>(kp);
 
-   int leapfrog_first = b.leapfrog_first[run];
+   int leapfrog_first = uni(b.leapfrog_first[run]);      // (the loop's state is wave-uniform: said so, it lives in scalar registers across the phase calls instead of being spilled around them)
    // every iterate call starts afresh: the reference throws out of the call in which a run leaves
    // its joint limits, the run itself stays usable (src/orcdchomp_mod.cpp:2799-2803)
    int status = 0;
@@ -1620,7 +1620,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
 
       if (do_iteration)
       {
-         const int num_limadjs = phase_update<real, TREE, GS16, BLOCK>(kp, it, leapfrog_first);
+         const int num_limadjs = uni(phase_update<real, TREE, GS16, BLOCK>(kp, it, leapfrog_first));
          if (b.use_momentum) leapfrog_first = 0;
          if (!(num_limadjs < 1000)) status = -1;
       }
@@ -1629,7 +1629,8 @@ void chomp_iterate_kernel(const DevBatch<real> b)
       // the log line; the trajectory keeps what the limit rounds made of it (workgroup-uniform)
       if (status != 0) break;
 
-      const PassCosts pc = phase_costs<real, GS16, BLOCK>(kp, do_iteration ? 1 : 0, cost_lane);
+      PassCosts pc = phase_costs<real, GS16, BLOCK>(kp, do_iteration ? 1 : 0, cost_lane);
+      pc.obs = unir(pc.obs); pc.smooth = unir(pc.smooth);
 
       if (tid == 0 && b.trace && do_iteration)
       {

@@ -202,12 +202,17 @@ __device__ __forceinline__ void self_sym_step16(const real * prow, const real * 
    for (int k=0; k<3; k++) uo[k] = dpp_move<F>(u[k]);
    const real wo = dpp_move<F>(wself);
    // shared part of the pair
+   // (lanes without a pair compute on whatever d2 they have -- zero for a lane facing itself: inf and NaN -- and every use
+   // below takes them out by a select, never by a zero factor; two coinciding centres of a pair: NaN, as in the reference)
    real inv_d;
-   real dist = sqrt_rsq_pos(near ? d2 : (real)1, &inv_d);      // (two coinciding centres: NaN, as in the reference)
+   real dist = sqrt_rsq_pos(d2, &inv_d);
    dist -= radius + ro;
    const real de = dist - eps_self;
    const real cself = (dist < (real)0) ? ((real)0.5 * eps_self - dist) : ((real)0.5 * inv_eps_self) * de * de;
-   const real scale = (dist < (real)0) ? (real)(-1) : ((dist < eps_self) ? dist * inv_eps_self - (real)1 : (real)1);
+   // -1 inside the spheres, dist/eps - 1 up to eps, +1 from eps on (the reference leaves g_grad unscaled there,
+   // src/orcdchomp_mod.cpp:1294-1297): max(dist/eps - 1, -1) is the first two at once
+   const real ramp = M<real>::max_(dist * inv_eps_self - (real)1, (real)(-1));
+   const real scale = (dist < eps_self) ? ramp : (real)1;
    // FULL16 (the placed layout: the row has all 16 slots in memory and FK keeps the empty ones at zero, so every
    // partner's numbers are finite): lanes without a pair are taken out by a zero factor instead of three selects
    const real sdi = FULL16 ? (near ? scale * inv_d : (real)0) : scale * inv_d;
