@@ -109,6 +109,43 @@ def test_tree30_multi_sdf(oracle, precision, tol):
     print("tree30 fp%d worst rel L2 %.3e" % (precision, max(errs)))
 
 
+@pytest.mark.parametrize("precision,tol", [(64, 1e-6), (32, 1e-3)])
+def test_tree30_floating_base_arms_crossing(oracle, precision, tol):
+    """the many-sphere path with a floating base and a strong self-collision term, the two arms folded across each
+    other so that many pairs of the 60 spheres come within range: fp32 nominates the pairs on the matrix cores
+    (csrc/self_mfma.h) and repeats the reference's range test on them, fp64 walks the rotations of the wavefront"""
+    mod = _mk_module()
+    model = robots.tree30()
+    base = [0.1, -0.2, 0.3, 0.0, 0.0, 0.0, 1.0]
+    dofvals = np.zeros(model.n_dof)
+    adofs = list(range(model.n_dof))
+    mod.add_robot(model, transform=base, dof_values=dofvals, active_dofs=adofs)
+    grids, poses = _tree_scene(mod, oracle, 0.02)
+    n_runs, n_points, n_iter = 3, 30, 12
+    rng = np.random.default_rng(7)
+    goals = rng.uniform(-0.4, 0.4, size=(n_runs, model.n_dof))
+    goals[:, 2:5] = [0.9, 1.2, -0.6]; goals[:, 16:19] = [-0.9, 1.2, 0.6]        # both arms swing in front of the torso
+    basegoals = np.tile(np.asarray(base), (n_runs, 1)); basegoals[:, :3] += rng.uniform(-0.2, 0.2, size=(n_runs, 3))
+    kw = dict(n_points=n_points, lambda_=400.0, obs_factor=50.0, obs_factor_self=40.0, epsilon_self=0.08, floating_base=1)
+    bid = mod.batch_create(model.name, goals, basegoals=basegoals, precision=precision, **kw)
+    costs, status = mod.batch_iterate(bid, n_iter)
+    traj = mod.batch_gettraj(bid)
+    mod.batch_destroy(bid)
+    rob = oracle.OraRobot(model)
+    errs = []
+    for k in range(n_runs):
+        run = oracle.OraRun(rob, base, dofvals, adofs, goals[k], grids, poses, oracle.default_params(**kw), basegoal=basegoals[k])
+        assert run.n == 37
+        st, ocosts = run.iterate(n_iter)
+        assert st == 0 and status[k] == 0
+        errs.append(common.rel_l2(traj[k], run.traj()))
+        assert ocosts[1] > 0.0                                  # the obstacle + self-collision cost is really there
+        assert np.allclose(costs[k], ocosts, rtol=max(tol, 1e-6) * (100 if precision == 32 else 1), atol=0), (costs[k], ocosts)
+        run.destroy()
+    assert max(errs) <= tol, errs
+    print("tree30 floating, arms crossing, fp%d worst rel L2 %.3e" % (precision, max(errs)))
+
+
 def test_derivative_2(oracle):
     """D=2: pentadiagonal metric, dense A^-1 fallback on the device"""
     mod = _mk_module()
