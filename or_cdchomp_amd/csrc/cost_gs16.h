@@ -11,7 +11,7 @@
 #pragma once
 
 #ifndef ORC_GS16_CELL
-#define ORC_GS16_CELL 1      // 1: the one-field variants look the field up in cell units with the descriptor in scalar registers
+#define ORC_GS16_CELL 2      // 1: the one-field variants look the field up in cell units with the descriptor in scalar registers; 2: the general 16-lane pass as well (two fields: +3 %)
 #endif
 
 #ifdef ORC_COST_TIMERS
@@ -157,6 +157,50 @@ __device__ __forceinline__ bool sdf_lookup_cell_aligned(const CD & F, const real
       gw[k] = F.W[4*k] * df;
       v += df * fr[k];
    }
+   value = poisoned ? inf : v;
+   return inb;
+}
+
+// ... and for a field in general position (rotated against the world): g = M p + t, world gradient W (after - before)
+template <typename real, typename CD>
+__device__ __forceinline__ bool sdf_lookup_cell(const CD & F, const real p[3], real & value, real gw[3])
+{
+   real fr[3]; bool prev[3];
+   bool inb = true;
+   int off = 0;
+#pragma unroll
+   for (int k=0; k<3; k++)
+   {
+      const real gx = F.M[k*3+0]*p[0] + F.M[k*3+1]*p[1] + F.M[k*3+2]*p[2] + F.t[k];
+      inb = inb && !(gx < (real)0) && !(gx > F.fsize[k]);
+      real fl = M<real>::floor_(gx);
+      fl = M<real>::max_(M<real>::min_(fl, F.fsize_m1[k]), (real)0);
+      fr[k] = (gx - fl) - (real)0.5;
+      prev[k] = (fl == (real)0) ? false : ((fl == F.fsize_m1[k]) ? true : (fr[k] < (real)0));
+      off += (int) fl * ((k == 2) ? (int) sizeof(real) : F.stride_b[k]);
+   }
+   const char * base = (const char *) F.data;
+   const real v0 = *(const real *)(base + off);
+   real vn[3];
+#pragma unroll
+   for (int k=0; k<3; k++)
+   {
+      const int sb = (k == 2) ? (int) sizeof(real) : F.stride_b[k];
+      vn[k] = *(const real *)(base + (off + (prev[k] ? -sb : sb)));
+   }
+   const real inf = M<real>::inf();
+   bool poisoned = (v0 == inf);
+   real v = v0, df[3];
+#pragma unroll
+   for (int k=2; k>=0; k--)                     // the reference walks the axes z, y, x
+   {
+      poisoned = poisoned || (vn[k] == inf);
+      const real dd = vn[k] - v0;
+      df[k] = prev[k] ? -dd : dd;               // after - before
+      v += df[k] * fr[k];
+   }
+#pragma unroll
+   for (int k=0; k<3; k++) gw[k] = F.W[k*3+0]*df[0] + F.W[k*3+1]*df[1] + F.W[k*3+2]*df[2];
    value = poisoned ? inf : v;
    return inb;
 }
@@ -352,6 +396,25 @@ __device__ __forceinline__ void cost_tile_gs16(const BT & b, const ModelView<rea
             has[u] = has[u] || better;
 #pragma unroll
             for (int k=0; k<3; k++) bgrad[u][k] = better ? gw[k] : bgrad[u][k];
+         }
+      }
+      else if (ORC_GS16_CELL > 1)
+      {
+         typedef const __attribute__((address_space(4))) DevSdfCell<real> CellDesc;
+         for (int i=0; i<b.n_sdfs; i++)
+         {
+            CellDesc & F = ((CellDesc *) b.sdfc)[i];
+#pragma unroll
+            for (int u=0; u<U; u++)
+            {
+               real gw[3], val;
+               const bool inb = sdf_lookup_cell<real>(F, p[u], val, gw);
+               const bool better = inb && (val < best[u]);           // strict <: HUGE_VAL never wins
+               best[u] = better ? val : best[u];
+               has[u] = has[u] || better;
+#pragma unroll
+               for (int k=0; k<3; k++) bgrad[u][k] = better ? gw[k] : bgrad[u][k];
+            }
          }
       }
       else

@@ -9,6 +9,8 @@ sizes = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "1024").split(",
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 mod = or_cdchomp_amd.Module(0)
 model = common.setup_product_wam(mod)
+if os.environ.get("FIELDS", "1") == "2":
+    mod.SendCommand("computedistancefield kinbody mug")      # a second field (the reference demo has table and mug)
 mod.set_num_streams(int(os.environ.get('NSTREAMS', '0')))
 kw = dict(n_points=100, lambda_=100.0, obs_factor=float(os.environ.get('OBS_FACTOR', '500.0')))
 tag = " ".join("%s=%s" % (k, v) for k, v in sorted(os.environ.items()) if k.startswith("ORC_") or k == "NSTREAMS")
