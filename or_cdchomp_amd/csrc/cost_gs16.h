@@ -678,26 +678,18 @@ __device__ __forceinline__ void cost_tile_gs16(const BT & b, const ModelView<rea
                   const real * row = T_s + (gi+1)*n;
                   const real x = row[0], y = row[1], z = row[2];
                   const real qx = 2*row[3], qy = 2*row[4], qz = 2*row[5], qw = 2*row[6];
-                  real Jsp[6][7];
-#pragma unroll
-                  for (int a=0; a<6; a++)
-#pragma unroll
-                     for (int c=0; c<7; c++) Jsp[a][c] = 0;
-                  Jsp[3][0] = 1; Jsp[4][1] = 1; Jsp[5][2] = 1;
-                  Jsp[0][3] =  qw; Jsp[0][4] = -qz; Jsp[0][5] =  qy; Jsp[0][6] = -qx;
-                  Jsp[1][3] =  qz; Jsp[1][4] =  qw; Jsp[1][5] = -qx; Jsp[1][6] = -qy;
-                  Jsp[2][3] = -qy; Jsp[2][4] =  qx; Jsp[2][5] =  qw; Jsp[2][6] = -qz;
-                  Jsp[3][3] = -z*qz - y*qy; Jsp[3][4] = -z*qw + y*qx; Jsp[3][5] =  z*qx + y*qw; Jsp[3][6] =  z*qy - y*qz;
-                  Jsp[4][3] =  z*qw + x*qy; Jsp[4][4] = -z*qz - x*qx; Jsp[4][5] =  z*qy - x*qw; Jsp[4][6] = -z*qx + x*qz;
-                  Jsp[5][3] = -y*qw + x*qz; Jsp[5][4] =  y*qz + x*qw; Jsp[5][5] = -y*qy - x*qx; Jsp[5][6] =  y*qx - x*qy;
-#pragma unroll
-                  for (int c=0; c<7; c++)
-                  {
-                     real sum = 0;
-#pragma unroll
-                     for (int a=0; a<6; a++) sum += Jsp[a][c] * wt[a];
-                     G_s[gi*n + c] = (real)0.01 * sum;
-                  }
+                  // 0.01 Jsp^T [tau ; f] without forming Jsp: its linear rows are p x (its angular rows), so column c gives
+                  // e_c . (tau - p x f) with e_x = (qw, qz, -qy), e_y = (-qz, qw, qx), e_z = (qy, -qx, qw), e_w = (-qx, -qy, -qz) (all times 2),
+                  // and the three translation columns give the force
+                  const real tq0 = wt[0] - (y*wt[5] - z*wt[4]);
+                  const real tq1 = wt[1] - (z*wt[3] - x*wt[5]);
+                  const real tq2 = wt[2] - (x*wt[4] - y*wt[3]);
+                  const real hundredth = (real)0.01;
+                  G_s[gi*n + 0] = hundredth * wt[3]; G_s[gi*n + 1] = hundredth * wt[4]; G_s[gi*n + 2] = hundredth * wt[5];
+                  G_s[gi*n + 3] = hundredth * ( qw*tq0 + qz*tq1 - qy*tq2);
+                  G_s[gi*n + 4] = hundredth * (-qz*tq0 + qw*tq1 + qx*tq2);
+                  G_s[gi*n + 5] = hundredth * ( qy*tq0 - qx*tq1 + qw*tq2);
+                  G_s[gi*n + 6] = hundredth * (-qx*tq0 - qy*tq1 - qz*tq2);
                }
             }
          }
