@@ -854,7 +854,8 @@ void BatchShard::build_device(const Robot & robot)
    // the WAM workload, scripts/phase_profile.py).
    const int pcr_rows = pcr_rows_;
    const size_t lds_cu = 160*1024;
-   int force_t = 0, force_pcr = -1, force_ag = -1, max_wgs = ORC_WGS_PER_CU, force_block = 0;
+   int force_t = 0, force_pcr = -1, force_ag = -1, force_block = 0;
+   int max_wgs = (sizeof(real) == 4 && GS_ != 16) ? ORC_WGS_PER_CU_FP32_MANY : ORC_WGS_PER_CU;      // (the kernel variant's register budget)
    if (const char * e = getenv("ORC_TILE_M")) force_t = atoi(e);          // experiments
    if (const char * e = getenv("ORC_PCR_LDS")) force_pcr = atoi(e);
    if (const char * e = getenv("ORC_AG_LDS")) force_ag = atoi(e);

@@ -1546,8 +1546,14 @@ __device__ __attribute__((noinline)) void phase_finish(const void * kp, int stat
 // ---------------------------------------------------------------------------
 // The kernel: one workgroup = one run for all iterations of the launch; the loop below only
 // sequences the phase functions and carries the few scalars that cross iterations.
+// second argument of the launch bounds: wavefronts per SIMD = the register budget (3: 168 VGPRs, 12 wavefronts per CU as 3 x 256 or
+// 4 x 192 threads; 2 for the one-run-per-CU shape of 512).  The fp32 many-sphere kernels are built for FOUR (128 VGPRs, four
+// 256-thread workgroups per CU, smaller tiles): measured on BASELINE configs[4] 1.61 -> 1.74 M it/s; the fp64 16-lane kernels
+// at four gain 3 % with overlapping launches and lose 3 % one launch at a time (config 2), lose 5 % on config 4: left at three
+template <typename real, bool GS16, int BLOCK>
+struct WavesPerSimd { static constexpr int value = (BLOCK == 512) ? 2 : ((sizeof(real) == 4 && !GS16) ? ORC_WGS_PER_CU_FP32_MANY : ORC_WGS_PER_CU); };
 template <typename real, bool TREE, bool GS16, int BLOCK, int KIND = 0>
-__global__ __launch_bounds__(BLOCK, (BLOCK == 512 ? 2 : ORC_WGS_PER_CU))      // second argument: wavefronts per SIMD (3 x 4 SIMDs = 12 per CU, as 3 x 256 or 4 x 192 threads; 2 for the one-run-per-CU shape of 512)
+__global__ __launch_bounds__(BLOCK, (WavesPerSimd<real, GS16, BLOCK>::value))
 void chomp_iterate_kernel(const DevBatch<real> b)
 {
    const void * kp = (const void *) __builtin_amdgcn_kernarg_segment_ptr();      // DevBatch b is the kernel's only argument

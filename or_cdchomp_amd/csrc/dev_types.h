@@ -14,6 +14,9 @@
 #ifndef ORC_WGS_PER_CU
 #define ORC_WGS_PER_CU    3       // resident workgroups per CU the kernels' register budget is sized for (launch bounds)
 #endif
+#ifndef ORC_WGS_PER_CU_FP32_MANY
+#define ORC_WGS_PER_CU_FP32_MANY 4   // ... of the fp32 kernels for more than 16 active spheres (128 VGPRs)
+#endif
 #define ORC_SCAN_RPL      4       // rows per lane of the scan solve: m <= 64*ORC_SCAN_RPL
 #define ORC_LDS_HEADER    256     // bytes in front of the LDS carve-up: reduction scratch [16] doubles, [8] ints, column masks, timer mark, phase counters [8]
 #define ORC_LIM_LIST      64      // violated entries the sparse joint-limit rounds handle
