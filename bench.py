@@ -260,6 +260,9 @@ def run_workload(config, args, rank, world, device, dist, steps, warmup, serial_
         # one launch at a time of 769..1024 runs: all of them resident at once with four 192-thread
         # workgroups per CU (orc_set_workgroup_threads); overlapping launches keep the default shape
         mod.set_workgroup_threads(192 if (streams <= 1 and config in (2, 3) and 768 < n_runs <= 1024) else 0)
+        # overlapping launches (or thousands of runs per launch): four workgroups per CU at 128 registers
+        # (orc_set_workgroups_per_cu; +3 % on the WAM workload, trajectories bit-identical)
+        mod.set_workgroups_per_cu(4 if (config in (2, 3) and (streams > 1 or n_runs > 1024)) else 0)
         warm = [wl.create(mod, 900000 + k, rank) for k in range(warmup)]
         timed = [wl.create(mod, k, rank) for k in range(steps)]
         for bid in warm:

@@ -107,6 +107,12 @@ int orc_robot_set_velocity_limits(orc_module * mod, const char * name, const dou
  * 512 unless a shape is set here.  The shape never depends on the batch itself, so that a run's result
  * does not depend on what shares its batch (trajectories are bit-identical across shapes). */
 int orc_set_workgroup_threads(orc_module * mod, int threads);
+/* Register budget of the batches created from now on: 0 (default) the kernels' own (three 256-thread workgroups per CU
+ * at 168 registers for fp64), 4: four per CU at 128 registers with smaller tiles, where a kernel is built for it (fp64
+ * robots of at most 16 active spheres on a fixed-base chain: the WAM of the BASELINE configurations; others keep
+ * their default).  A caller whose launches overlap (orc_set_num_streams >= 2) or hold thousands of runs gains 3 %,
+ * a caller with one launch of <= 1024 runs at a time loses 3 %.  Trajectories are bit-identical either way. */
+int orc_set_workgroups_per_cu(orc_module * mod, int workgroups);
 
 /* What the TSR constraints of `create` address on the robot (src/orcdchomp_mod.cpp:1957-1976):
  * GetLink(name) for `con_tsr 'all link NAME'`; GetManipulators() / GetActiveManipulator() and their

@@ -48,6 +48,7 @@ SYMBOLS = [
     ("orc_robot_set_active_dofs", C.c_int, [C.c_void_p, C.c_char_p, c_int_p, C.c_int]),
     ("orc_robot_set_velocity_limits", C.c_int, [C.c_void_p, C.c_char_p, c_double_p, C.c_int]),
     ("orc_set_workgroup_threads", C.c_int, [C.c_void_p, C.c_int]),
+    ("orc_set_workgroups_per_cu", C.c_int, [C.c_void_p, C.c_int]),
     ("orc_robot_set_link_names", C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int]),
     ("orc_robot_add_manipulator", C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, c_double_p]),
     ("orc_robot_set_adjacent_links", C.c_int, [C.c_void_p, C.c_char_p, c_int_p, C.c_int]),

@@ -866,6 +866,12 @@ void BatchShard::build_device(const Robot & robot)
    // can ask for the 192-thread shape for the whole module: orc_set_workgroup_threads (measured, one
    // launch of 1024 WAM runs: 9.3 M it/s against 8.4 M; from 4096 runs on the order is reversed).
    force_block = mod_->workgroup_threads ? mod_->workgroup_threads : params.workgroup_threads;
+   // orc_set_workgroups_per_cu(4): the fp64 16-lane kernels of a fixed-base chain also exist at 128 VGPRs, four 256-thread
+   // workgroups per CU (three tiles instead of two for the WAM): +3 % when launches overlap, -3 % one launch at a time
+   const int want_wgs = mod_->workgroups_per_cu ? mod_->workgroups_per_cu : params.workgroups_per_cu;
+   const bool budget4 = (want_wgs == 4) && sizeof(real) == 8 && (tree_ & 16) && (tree_ & 2) && !(tree_ & 64) && (force_block == 0 || force_block == 256)
+                        && !getenv("ORC_BLOCK_THREADS");
+   if (budget4) { max_wgs = 4; force_block = 256; }
    if (const char * e = getenv("ORC_BLOCK_THREADS")) force_block = atoi(e);
    int force_g = -1, force_tl = -1;
    if (const char * e = getenv("ORC_G_LDS")) force_g = atoi(e);
@@ -879,7 +885,7 @@ void BatchShard::build_device(const Robot & robot)
    // less LDS per run, and the 1024 runs of BASELINE configs[1] resident at once on 256 CUs
    struct Shape { int block, wgs; };
    std::vector<Shape> shapes;
-   for (int wgs=max_wgs; wgs>=1; wgs--) shapes.push_back({ 256, wgs });
+   for (int wgs=max_wgs; wgs>=(budget4 ? 4 : 1); wgs--) shapes.push_back({ 256, wgs });
    if (max_wgs >= 3) shapes.push_back({ 192, 4 });
    // a caller that asked for the 192-thread shape gets it for runs that do not fit four to a CU as well
    if (force_block == 192) for (int wgs=3; wgs>=1; wgs--) shapes.push_back({ 192, wgs });
@@ -932,7 +938,10 @@ void BatchShard::build_device(const Robot & robot)
             }
          }
    }
+   if (!tile_m_ && budget4)
+      throw std::runtime_error("run does not fit four workgroups per CU (orc_set_workgroups_per_cu)!");
    if (!tile_m_) throw std::runtime_error("run does not fit the LDS of one CU!");
+   if (budget4) tree_ |= 256;
    // Tile boundaries.  A tile of s moving waypoints costs ceil(s * lanes per waypoint / threads) rounds of
    // the workgroup in the cost phase; equal tiles of the largest size are not always the cheapest cut
    // (98 waypoints in tiles of at most 34 at 16 per round: 33 + 33 + 32 is 3 + 3 + 2 rounds, 34 + 32 + 32

@@ -172,6 +172,14 @@ int orc_set_workgroup_threads(orc_module * mod, int threads)
    });
 }
 
+int orc_set_workgroups_per_cu(orc_module * mod, int workgroups)
+{
+   return guarded(mod, [&] {
+      if (workgroups != 0 && workgroups != 4) throw std::runtime_error("workgroups per CU must be 0 (default) or 4!");
+      mod->impl->workgroups_per_cu = workgroups;
+   });
+}
+
 int orc_robot_set_link_names(orc_module * mod, const char * name, const char * const * names, int n)
 {
    return guarded(mod, [&] {

@@ -995,7 +995,7 @@ __device__ __forceinline__ void phase_mark(const BT & b, const Env<real> & E, in
 }
 
 // ---- staging: the run's trajectory and everything read-only the iteration touches, into LDS ----
-template <typename real, bool TREE, bool GS16, int BLOCK>
+template <typename real, bool TREE, bool GS16, int BLOCK, int WGS = 0>      // (WGS: a copy per register budget of the calling kernels, see WavesPerSimd)
 __device__ __attribute__((noinline)) void phase_setup(const void * kp)
 {
    KArg<real> & b = *uniform_kernarg<real>(kp);
@@ -1078,7 +1078,7 @@ __device__ __attribute__((noinline)) void phase_setup(const void * kp)
 }
 
 // ---- hmc momentum resample (src/orcdchomp_mod.cpp:2755-2768): AG <- the call's noise slot ----
-template <typename real, bool GS16, int BLOCK>
+template <typename real, bool GS16, int BLOCK, int WGS = 0>
 __device__ __attribute__((noinline)) void phase_hmc(const void * kp, int slot_in)
 {
    KArg<real> & b = *uniform_kernarg<real>(kp);
@@ -1091,7 +1091,7 @@ __device__ __attribute__((noinline)) void phase_hmc(const void * kp, int slot_in
 }
 
 // ---- FK phase of one tile: lane = (waypoint, world axis) (sphere_cost_pre, src/orcdchomp_mod.cpp:988-1093) ----
-template <typename real, bool TREE, bool GS16, int BLOCK>
+template <typename real, bool TREE, bool GS16, int BLOCK, int WGS = 0>
 __device__ __attribute__((noinline)) void phase_fk(const void * kp, int ts_in, int te_in)
 {
    KArg<real> & b = *uniform_kernarg<real>(kp);
@@ -1125,7 +1125,7 @@ __device__ __attribute__((noinline)) void phase_fk(const void * kp, int ts_in, i
 // ---- start_tsr: the cost pass of the start point alone (one-sided velocity; cost_gs16.h START), after the
 // regular pass of its tile.  A function of its own: inside phase_cost its registers and code were in the way
 // of the regular pass (1 % of config 2's throughput without ever running) ----
-template <typename real, bool TREE, bool GS16, int BLOCK>
+template <typename real, bool TREE, bool GS16, int BLOCK, int WGS = 0>
 __device__ __attribute__((noinline)) double phase_cost_start(const void * kp, int do_iteration_in, double cost_lane)
 {
    KArg<real> & b = *uniform_kernarg<real>(kp);
@@ -1192,7 +1192,7 @@ __device__ __forceinline__ double phase_cost_body(const void * kp, int ts_in, in
    phase_mark<real>(b, E, 1);
    return cost_lane;
 }
-template <typename real, bool TREE, bool GS16, int BLOCK, int KIND = 0, bool ITER = true>
+template <typename real, bool TREE, bool GS16, int BLOCK, int KIND = 0, bool ITER = true, int WGS = 0>
 __device__ __attribute__((noinline)) double phase_cost(const void * kp, int ts_in, int te_in, double cost_lane)
 {
    return phase_cost_body<real, TREE, GS16, BLOCK, KIND, ITER>(kp, ts_in, te_in, cost_lane);
@@ -1200,7 +1200,7 @@ __device__ __attribute__((noinline)) double phase_cost(const void * kp, int ts_i
 
 // ---- update phase (cd_chomp_iterate, src/libcd/chomp.c:490-655): G/m + A T + B, A^-1 G, the step,
 // the joint-limit rounds.  Returns the number of limit rounds made (1000: "ran too many joint limit fixes").
-template <typename real, bool TREE, bool GS16, int BLOCK>
+template <typename real, bool TREE, bool GS16, int BLOCK, int WGS = 0>
 __device__ __attribute__((noinline)) int phase_update(const void * kp, int it_in, int leapfrog_first_in)
 {
    KArg<real> & b = *uniform_kernarg<real>(kp);
@@ -1247,7 +1247,7 @@ __device__ __attribute__((noinline)) int phase_update(const void * kp, int it_in
       }
       __threadfence_block();
       __syncthreads();
-      phase_tsr<real, GS16, BLOCK>(kp);
+      phase_tsr<real, GS16, BLOCK, WGS>(kp);
       const real * AGc = b.use_momentum ? AG_s : AG_g;
       for (int e=tid; e<mn; e+=BLOCK)
       {
@@ -1309,8 +1309,8 @@ __device__ __attribute__((noinline)) int phase_update(const void * kp, int it_in
          if (tid < 64)
          {
             const real kinv = (real)(-1) / ((real)(m + 1) * b.a_off);      // 1/((m+1) ca), ca = -a_off
-            const LimResult lr = (GS16 || b.t_in_lds) ? limit_rounds_call<real, (BLOCK == 512)>(T_s, G_s, jl_s, m, n, kinv, viol_cols)
-                                                      : limit_rounds_call_global<real, (BLOCK == 512)>(T_s, G_s, jl_s, m, n, kinv, viol_cols);
+            const LimResult lr = (GS16 || b.t_in_lds) ? limit_rounds_call<real, (BLOCK == 512) ? 1 : (WGS ? 2 : 0)>(T_s, G_s, jl_s, m, n, kinv, viol_cols)
+                                                      : limit_rounds_call_global<real, (BLOCK == 512) ? 1 : (WGS ? 2 : 0)>(T_s, G_s, jl_s, m, n, kinv, viol_cols);
             if (b.phase_cycles && tid == 0) E.phc_s[7] += lr.kinds;
             if (tid == 0) redi[0] = lr.rounds;
          }
@@ -1443,7 +1443,7 @@ __device__ __attribute__((noinline)) int phase_update(const void * kp, int it_in
 // quaternion renormalisation of the same iteration, as in the reference (cd_chomp_iterate returns
 // before mod.cpp:2806-2808 runs); then that renormalisation.
 struct PassCosts { double obs, smooth; };
-template <typename real, bool GS16, int BLOCK>
+template <typename real, bool GS16, int BLOCK, int WGS = 0>
 __device__ __attribute__((noinline)) PassCosts phase_costs(const void * kp, int do_iteration_in, double cost_lane)
 {
    KArg<real> & b = *uniform_kernarg<real>(kp);
@@ -1507,7 +1507,7 @@ __device__ __attribute__((noinline)) PassCosts phase_costs(const void * kp, int 
 }
 
 // ---- write back: trajectory, momentum, costs, status ----
-template <typename real, bool GS16, int BLOCK>
+template <typename real, bool GS16, int BLOCK, int WGS = 0>
 __device__ __attribute__((noinline)) void phase_finish(const void * kp, int status_in, int iters_done_in, int leapfrog_first_in, int have_costs_in,
    double done_obs, double done_smooth)
 {
@@ -1552,8 +1552,8 @@ __device__ __attribute__((noinline)) void phase_finish(const void * kp, int stat
 // at four gain 3 % with overlapping launches and lose 3 % one launch at a time (config 2), lose 5 % on config 4: left at three
 template <typename real, bool GS16, int BLOCK>
 struct WavesPerSimd { static constexpr int value = (BLOCK == 512) ? 2 : ((sizeof(real) == 4 && !GS16) ? ORC_WGS_PER_CU_FP32_MANY : ORC_WGS_PER_CU); };
-template <typename real, bool TREE, bool GS16, int BLOCK, int KIND = 0>
-__global__ __launch_bounds__(BLOCK, (WavesPerSimd<real, GS16, BLOCK>::value))
+template <typename real, bool TREE, bool GS16, int BLOCK, int KIND = 0, int WGS = 0>      // WGS: 0 the family's own budget, 4: four workgroups of 256 per CU (128 VGPRs)
+__global__ __launch_bounds__(BLOCK, (WGS ? WGS : WavesPerSimd<real, GS16, BLOCK>::value))
 void chomp_iterate_kernel(const DevBatch<real> b)
 {
    const void * kp = (const void *) __builtin_amdgcn_kernarg_segment_ptr();      // DevBatch b is the kernel's only argument
@@ -1564,7 +1564,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
    // reference has thrown out of the call by now (workgroup-uniform)
    if (b.carry_status && b.status[run] != 0) return;
 
-   phase_setup<real, TREE, GS16, BLOCK>(kp);
+   phase_setup<real, TREE, GS16, BLOCK, WGS>(kp);
 
    int leapfrog_first = uni(b.leapfrog_first[run]);      // (the loop's state is wave-uniform: said so, it lives in scalar registers across the phase calls instead of being spilled around them)
    // every iterate call starts afresh: the reference throws out of the call in which a run leaves
@@ -1594,7 +1594,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
       if (do_iteration && b.use_hmc && b.use_momentum && next_resample < b.max_resamples
           && b.hmc_iters[(size_t) run * b.max_resamples + next_resample] == it)
       {
-         phase_hmc<real, GS16, BLOCK>(kp, next_resample);
+         phase_hmc<real, GS16, BLOCK, WGS>(kp, next_resample);
          leapfrog_first = 1;
          next_resample++;
       }
@@ -1605,9 +1605,9 @@ void chomp_iterate_kernel(const DevBatch<real> b)
          const int ts = (tk == 0) ? 0 : b.tile_first + (tk - 1) * b.tile_rest;
          const int te = (tk == b.n_tiles - 1) ? b.m : b.tile_first + tk * b.tile_rest;
 #ifndef ORC_ABLATE_FK
-         phase_fk<real, TREE, GS16, BLOCK>(kp, ts, te);
+         phase_fk<real, TREE, GS16, BLOCK, WGS>(kp, ts, te);
 #ifdef ORC_ABLATE_FKTWICE      // timing experiments: the FK phase twice (what a 2x slower FK would cost)
-         phase_fk<real, TREE, GS16, BLOCK>(kp, ts, te);
+         phase_fk<real, TREE, GS16, BLOCK, WGS>(kp, ts, te);
 #endif
 #endif
 #ifndef ORC_ABLATE_COST
@@ -1618,15 +1618,15 @@ void chomp_iterate_kernel(const DevBatch<real> b)
          if (do_iteration && (!GS16 || ORC_INLINE_COST > 1)) cost_lane = phase_cost_body<real, TREE, GS16, BLOCK, KIND, true>(kp, ts, te, cost_lane);
          else
 #endif
-         cost_lane = do_iteration ? phase_cost<real, TREE, GS16, BLOCK, KIND, true>(kp, ts, te, cost_lane)
-                                  : phase_cost<real, TREE, GS16, BLOCK, KIND, false>(kp, ts, te, cost_lane);
-         if (tk == 0 && b.free_start) cost_lane = phase_cost_start<real, TREE, GS16, BLOCK>(kp, do_iteration ? 1 : 0, cost_lane);
+         cost_lane = do_iteration ? phase_cost<real, TREE, GS16, BLOCK, KIND, true, WGS>(kp, ts, te, cost_lane)
+                                  : phase_cost<real, TREE, GS16, BLOCK, KIND, false, WGS>(kp, ts, te, cost_lane);
+         if (tk == 0 && b.free_start) cost_lane = phase_cost_start<real, TREE, GS16, BLOCK, WGS>(kp, do_iteration ? 1 : 0, cost_lane);
 #endif
       } // tiles
 
       if (do_iteration)
       {
-         const int num_limadjs = uni(phase_update<real, TREE, GS16, BLOCK>(kp, it, leapfrog_first));
+         const int num_limadjs = uni(phase_update<real, TREE, GS16, BLOCK, WGS>(kp, it, leapfrog_first));
          if (b.use_momentum) leapfrog_first = 0;
          if (!(num_limadjs < 1000)) status = -1;
       }
@@ -1635,7 +1635,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
       // the log line; the trajectory keeps what the limit rounds made of it (workgroup-uniform)
       if (status != 0) break;
 
-      PassCosts pc = phase_costs<real, GS16, BLOCK>(kp, do_iteration ? 1 : 0, cost_lane);
+      PassCosts pc = phase_costs<real, GS16, BLOCK, WGS>(kp, do_iteration ? 1 : 0, cost_lane);
       pc.obs = unir(pc.obs); pc.smooth = unir(pc.smooth);
 
       if (tid == 0 && b.trace && do_iteration)
@@ -1647,7 +1647,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
       if (do_iteration) iters_done++;
    }
 
-   phase_finish<real, GS16, BLOCK>(kp, status, iters_done, leapfrog_first, have_costs, done_obs, done_smooth);
+   phase_finish<real, GS16, BLOCK, WGS>(kp, status, iters_done, leapfrog_first, have_costs, done_obs, done_smooth);
 }
 
 // straight-line seeding of every run (src/orcdchomp_mod.cpp:2417-2464):
@@ -1819,7 +1819,7 @@ size_t orc_chomp_lds_bytes(int n_points, int n, int Sa, int S, int nj, int tile_
    return (size_t) lds_layout(n_points, n, Sa, S, nj, tile_m, pcr_rows, (int) real_size, use_momentum, n_sdfs, ss, flags).total_bytes;
 }
 
-template <typename real, bool TREE, bool GS16, int BLOCK, int KIND = 0>
+template <typename real, bool TREE, bool GS16, int BLOCK, int KIND = 0, int WGS = 0>
 static hipError_t launch_iterate_tt(const DevBatch<real> & b, size_t lds, hipStream_t stream)
 {
    // the attribute is per device (and per kernel instantiation)
@@ -1828,12 +1828,12 @@ static hipError_t launch_iterate_tt(const DevBatch<real> & b, size_t lds, hipStr
    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
    if (!((attr_set.load() >> dev) & 1ull))
    {
-      hipError_t e = hipFuncSetAttribute((const void *) chomp_iterate_kernel<real, TREE, GS16, BLOCK, KIND>,
+      hipError_t e = hipFuncSetAttribute((const void *) chomp_iterate_kernel<real, TREE, GS16, BLOCK, KIND, WGS>,
          hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024 - 256);
       if (e != hipSuccess) return e;
       attr_set.fetch_or(1ull << dev);
    }
-   hipLaunchKernelGGL((chomp_iterate_kernel<real, TREE, GS16, BLOCK, KIND>), dim3(b.n_runs), dim3(BLOCK), lds, stream, b);
+   hipLaunchKernelGGL((chomp_iterate_kernel<real, TREE, GS16, BLOCK, KIND, WGS>), dim3(b.n_runs), dim3(BLOCK), lds, stream, b);
    return hipGetLastError();
 }
 
@@ -1861,6 +1861,15 @@ static hipError_t launch_iterate_t(const DevBatch<real> & b, size_t lds, hipStre
    if (variant & 16)      // phase_cost KIND: a chain with placed spheres (16), one field with the world's axes (32), floating base (64)
    {
       const int kind = 1 | ((variant & 32) ? 2 : 0) | ((variant & 64) ? 4 : 0) | (((variant & 160) == 160) ? 8 : 0);
+      // bit 8: the kernels built for four 256-thread workgroups per CU (orc_set_workgroups_per_cu; fp64 fixed-base chains)
+      if constexpr (sizeof(real) == 8)
+         if ((variant & 256) && !(variant & (4 | 8 | 64)))
+            switch (kind)
+            {
+            case 1: return launch_iterate_tt<real, false, true, 256, 1, 4>(b, lds, stream);
+            case 3: return launch_iterate_tt<real, false, true, 256, 3, 4>(b, lds, stream);
+            case 11: return launch_iterate_tt<real, false, true, 256, 11, 4>(b, lds, stream);
+            }
 #define ORC_KIND_CASE(K) case K: \
          if (variant & 8) return launch_iterate_tt<real, false, true, 512, K>(b, lds, stream); \
          if (variant & 4) return launch_iterate_tt<real, false, true, 192, K>(b, lds, stream); \

@@ -19,6 +19,10 @@
 //       a fixed summation order.
 #pragma once
 
+#ifndef ORC_SDF_DEFER
+#define ORC_SDF_DEFER 1      // the fields' cell reads are used after the self-collision term (0: right after they are issued)
+#endif
+
 // START: the pass of the start point alone when it is a variable (`start_tsr`), see cost_gs16.h
 template <typename real, int BLOCK, typename BT, bool START = false>
 __device__ __forceinline__ void cost_tile_generic(const BT & b, const ModelView<real> & mod,
@@ -185,6 +189,9 @@ __device__ __forceinline__ void cost_tile_generic(const BT & b, const ModelView<
       };
 #ifndef ORC_ABLATE_SDF
       sdf_issue(0);
+#if !ORC_SDF_DEFER
+      sdf_finish(0);
+#endif
 #endif
       ORC_GMARK(0);
       // ---- self collision (src/orcdchomp_mod.cpp:1251-1317) ----
@@ -362,7 +369,9 @@ __device__ __forceinline__ void cost_tile_generic(const BT & b, const ModelView<
       }
       // ---- the obstacle term's second half: values and gradients of the fields, the sphere's cost and force ----
 #ifndef ORC_ABLATE_SDF
+#if ORC_SDF_DEFER
       sdf_finish(0);
+#endif
       for (int i0=4; i0<b.n_sdfs; i0+=4) { sdf_issue(i0); sdf_finish(i0); }      // (more than four fields: the rest one batch at a time)
 #endif
       {

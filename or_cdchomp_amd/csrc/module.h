@@ -114,6 +114,7 @@ struct BatchParams
    double epsilon = 0.1, epsilon_self = 0.04, obs_factor = 200.0, obs_factor_self = 10.0;
    int precision = 64;
    int workgroup_threads = 0;   // 0: the module's setting (orc_set_workgroup_threads); `create` asks for 512 for its single run
+   int workgroups_per_cu = 0;   // 0: the module's setting (orc_set_workgroups_per_cu)
 };
 
 class Module;
@@ -292,6 +293,7 @@ public:
    std::map<int, size_t> next_pool_stream;
    int num_streams = 0;
    int workgroup_threads = 0;       // 0: the planner's choice; 192 or 256: the workgroup shape of every batch created from now on
+   int workgroups_per_cu = 0;       // 0: the kernels' own register budget; 4: four 256-thread workgroups per CU where a kernel is built for it
    void set_num_streams(int n);
    hipStream_t pick_stream(int device, bool distinct);
    // a high-priority stream per device for the hmc plan of a call (hmc_kernels.hip): its wavefronts are dispatched ahead

@@ -807,7 +807,7 @@ __device__ void tsr_substitute(const BT & b, const Env<real> & E, const real * C
 }
 
 // The constraint step.  AG holds the unconstrained update (chomp.c:525-548), T_s the trajectory before it.
-template <typename real, bool GS16, int BLOCK>
+template <typename real, bool GS16, int BLOCK, int WGS = 0>
 __device__ __attribute__((noinline)) void phase_tsr(const void * kp)
 {
    KArg<real> & b = *uniform_kernarg<real>(kp);

@@ -72,6 +72,10 @@ class Module:
         """0 (default plan), 192 or 256 threads per workgroup for the batches created from now on"""
         self._check(self._lib.orc_set_workgroup_threads(self._h, int(threads)))
 
+    def set_workgroups_per_cu(self, workgroups):
+        """0 (default budget) or 4: four 256-thread workgroups per CU at 128 registers where a kernel is built for it"""
+        self._check(self._lib.orc_set_workgroups_per_cu(self._h, int(workgroups)))
+
     def set_num_streams(self, n):
         self._check(self._lib.orc_set_num_streams(self._h, int(n)))
 

@@ -292,6 +292,21 @@ def test_workgroup_shape_is_a_module_setting(oracle):
     mod.set_workgroup_threads(0)
     assert np.array_equal(sd, sa[:24]) and np.array_equal(td, ta[:24])
     assert np.allclose(cd, ca[:24], rtol=1e-13, atol=0)
+    # orc_set_workgroups_per_cu(4): the kernels built for four 256-thread workgroups per CU (128 registers, three tiles
+    # for the WAM instead of two): the same trajectories; a robot the budget is not built for keeps its default
+    mod.set_workgroups_per_cu(4)
+    e = mod.batch_create(model.name, goals, **kw)
+    ce, se = mod.batch_iterate(e, 60)
+    te = mod.batch_gettraj(e)
+    mod.batch_destroy(e)
+    f = mod.batch_create(model.name, goals[:8], floating_base=1, basegoals=np.tile(common.wam_state()[1], (8, 1)), **kw)
+    mod.batch_iterate(f, 3)
+    mod.batch_destroy(f)
+    mod.set_workgroups_per_cu(0)
+    assert np.array_equal(se, sa) and np.array_equal(te, ta)
+    assert np.allclose(ce, ca, rtol=1e-13, atol=0)
+    with pytest.raises(RuntimeError, match="workgroups per CU must be 0"):
+        mod.set_workgroups_per_cu(3)
 
 
 def test_chunked_iterate_of_a_batch_keeps_aborted_runs_out(oracle, tmp_path):
