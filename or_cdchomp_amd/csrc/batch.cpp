@@ -271,6 +271,7 @@ void BatchShard::construct(const Robot & robot, const double * starts, const dou
       hip_check(orc_launch_hmc_seed(d_mt_, d_hmc_next_, d_seeds, n_runs, st), "hmc seed");
       hip_check(hipStreamSynchronize(st), "hmc seed sync");
       dev_free(d_seeds);
+      if (!getenv("ORC_HMC_PLAN_SYNC")) hmc_reserve(hmc_room(100), false);      // (a call of up to 100 iterations allocates nothing)
    }
    else
    {
@@ -301,7 +302,6 @@ void BatchShard::release()
    for (void ** p : all) { dev_free(*p); *p = nullptr; }
    sdf_refs_.clear();
    for (int k=0; k<2; k++) if (ev_plan_[k]) { (void) hipEventDestroy(ev_plan_[k]); ev_plan_[k] = nullptr; }
-   if (h_overflow_) { (void) hipHostFree(h_overflow_); h_overflow_ = nullptr; }
    for (auto & ev : pending_events_) { mod_->release_event(device, ev.first); mod_->release_event(device, ev.second); }
    pending_events_.clear();
 }
@@ -1034,6 +1034,25 @@ static void parallel_for_runs(int count, const std::function<void(int, int)> & b
 
 // Resamples of the iterations [iter_begin, iter_end) of an iterate call; the kernel gets their
 // positions relative to iter_begin, the noise scale uses the call's own counter (mod.cpp:2757).
+// room for the momentum resamples of one iterate call of n_iter iterations: Poisson(n_iter lambda) + 8 standard
+// deviations + 6 (a run draws more than that in a call with probability ~1e-12)
+int BatchShard::hmc_room(int n_iter) const
+{
+   const double mean = n_iter * params.hmc_resample_lambda;
+   return (int) std::ceil(mean + 8.0 * std::sqrt(mean) + 6.0);
+}
+
+// the plan's buffers (resample iterations [n_runs][cap], noise [n_runs][cap][m n]) for `cap` resamples per run
+void BatchShard::hmc_reserve(int cap, bool pending_work)
+{
+   const size_t rsize = (params.precision == 64) ? 8 : 4;
+   const size_t icount = (size_t) n_runs * cap, ncount = icount * m * n;
+   if (icount <= hmc_cap_iters_ && ncount * rsize <= noise_cap_) return;
+   if (pending_work) hip_check(hipStreamSynchronize(stream_), "hmc buffers: pending work");      // (an earlier launch may still read them)
+   if (icount > hmc_cap_iters_) { dev_free(d_hmc_iters_); d_hmc_iters_ = dev_alloc<int>(icount); hmc_cap_iters_ = icount; }
+   if (ncount * rsize > noise_cap_) { dev_free(d_noise_); hip_check(hipMalloc(&d_noise_, ncount * rsize), "noise"); noise_cap_ = ncount * rsize; }
+}
+
 void BatchShard::plan_hmc(int iter_begin, int iter_end)
 {
    const size_t mn = (size_t) m * n;
@@ -1046,20 +1065,13 @@ void BatchShard::plan_hmc(int iter_begin, int iter_end)
          // The plan of the call runs on the device's high-priority plan stream, ordered between the shard's earlier
          // work and the iterate launch by events: the host does not wait for it (queued on the shard's own stream it
          // sat behind the other stream's iterate launch for ~14 ms of a config-4 step, and the host with it).
-         // Room for the resamples of a call: Poisson(n_iter lambda) + 12 standard deviations + 10 (beyond 1e-20 per
-         // run); a run that still needs more raises the overflow flag, which the call's sync reports as an error.
-         const double mean = n_iter * params.hmc_resample_lambda;
-         const int cap = (int) std::ceil(mean + 12.0 * std::sqrt(mean) + 10.0);
-         const size_t icount = (size_t) n_runs * cap, ncount = icount * mn;
-         if (icount > hmc_cap_iters_ || ncount * rsize > noise_cap_)
-         {
-            hip_check(hipStreamSynchronize(stream_), "hmc buffers: pending work");      // (an earlier launch may still read them)
-            if (icount > hmc_cap_iters_) { dev_free(d_hmc_iters_); d_hmc_iters_ = dev_alloc<int>(icount); hmc_cap_iters_ = icount; }
-            if (ncount * rsize > noise_cap_) { dev_free(d_noise_); hip_check(hipMalloc(&d_noise_, ncount * rsize), "noise"); noise_cap_ = ncount * rsize; }
-         }
+         // Room for the resamples of a call: hmc_room(); a run that still needs more raises the overflow flag, which the
+         // call's sync reports as an error.  The buffers of a 100-iteration call exist since `create`.
+         const int cap = hmc_room(n_iter);
+         hmc_reserve(cap, true);
          hipStream_t ps = mod_->plan_stream(device);
          for (int k=0; k<2; k++) if (!ev_plan_[k]) hip_check(hipEventCreateWithFlags(&ev_plan_[k], hipEventDisableTiming), "hipEventCreate");
-         if (!h_overflow_) { hip_check(hipHostMalloc((void **) &h_overflow_, sizeof(int)), "hipHostMalloc"); *h_overflow_ = 0; }
+         overflow_armed_ = true;
          hip_check(hipEventRecord(ev_plan_[0], stream_), "hipEventRecord");
          hip_check(hipStreamWaitEvent(ps, ev_plan_[0], 0), "hipStreamWaitEvent");
          hip_check(hipMemsetAsync(d_overflow_, 0, sizeof(int), ps), "hmc overflow");
@@ -1253,7 +1265,7 @@ void BatchShard::sync_begin(double * costs_out, int * status_out, int * iters_ou
    if (costs_out) hip_check(hipMemcpyAsync(costs_out, d_costs_, (size_t) n_runs*3*sizeof(double), hipMemcpyDeviceToHost, st), "costs");
    if (status_out) hip_check(hipMemcpyAsync(status_out, d_status_, n_runs*sizeof(int), hipMemcpyDeviceToHost, st), "status");
    if (iters_out) hip_check(hipMemcpyAsync(iters_out, d_iters_done_, n_runs*sizeof(int), hipMemcpyDeviceToHost, st), "iters_done");
-   if (h_overflow_) hip_check(hipMemcpyAsync(h_overflow_, d_overflow_, sizeof(int), hipMemcpyDeviceToHost, st), "hmc overflow");
+   if (overflow_armed_) hip_check(hipMemcpyAsync(&overflow_host_, d_overflow_, sizeof(int), hipMemcpyDeviceToHost, st), "hmc overflow");
 }
 
 void BatchShard::sync_end()
@@ -1261,9 +1273,9 @@ void BatchShard::sync_end()
    DeviceGuard guard(device);
    hip_check(hipStreamSynchronize(stream_), "hipStreamSynchronize");
    harvest_events(false);
-   if (h_overflow_ && *h_overflow_)
+   if (overflow_armed_ && overflow_host_)
    {
-      *h_overflow_ = 0;
+      overflow_host_ = 0;
       throw std::runtime_error("hmc: a run drew more momentum resamples in one iterate call than the plan has room for; iterate with fewer iterations per call!");
    }
 }

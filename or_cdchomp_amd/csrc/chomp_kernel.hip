@@ -919,7 +919,7 @@ __device__ __forceinline__ Env<real> make_env(const BT & b, unsigned char * smem
 {
    Env<real> E;
    const int run = blockIdx.x;
-   const int n = b.n, m = b.m, np = b.n_points, mn = m*n;
+   const int n = b.n, m = b.m, mn = m*n;
    const int nj = b.ms.nj, Sa = b.ms.Sa, S = b.ms.S;
    const auto & L = b.lay;          // computed on the host (lds_layout, dev_types.h)
    E.red = (double *) smem_raw;                            // [8] reduction scratch

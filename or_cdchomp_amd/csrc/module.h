@@ -160,6 +160,8 @@ private:
    template <typename real> void build_device(const Robot & robot);
    template <typename real> void launch(int n_iter, bool final_eval, bool carry);
    void plan_hmc(int iter_begin, int iter_end);
+   int hmc_room(int n_iter) const;
+   void hmc_reserve(int cap, bool pending_work);
    void construct(const Robot & robot, const double * starts, const double * goals, const double * basegoals,
       const unsigned int * seeds);
    void release();                  // frees every device buffer (destructor and failed construction)
@@ -181,7 +183,7 @@ private:
    int * d_hmc_iters_ = nullptr; void * d_noise_ = nullptr; size_t hmc_cap_iters_ = 0, noise_cap_ = 0;
    int max_resamples_ = 0;
    hipEvent_t ev_plan_[2] = { nullptr, nullptr };   // iterate stream -> plan stream -> iterate stream
-   int * h_overflow_ = nullptr;                      // pinned: the plan's overflow flag, read with the results of a call
+   int overflow_host_ = 0; bool overflow_armed_ = false;   // the plan's overflow flag, read with the results of a call
    bool debug_state_ = false;   // ORC_DEBUG_STATE=1: keep the last gradient readable (get_state "G")
    int n_sdfs_ = 0;
    int n_tiles_ = 1, tile_first_ = 0, tile_rest_ = 0;   // tiles of an iteration: the first of tile_first_ moving waypoints, the others of tile_rest_

@@ -248,7 +248,7 @@ hipError_t orc_sdf_build_device(const int sizes[3], const double lengths[3], con
       ORC_TRY(hipGetLastError());
       hipLaunchKernelGGL(flood_start_kernel, dim3(1), dim3(1), 0, st, d_free, 0L);
       ORC_TRY(hipGetLastError());
-      for (int round=0; ; round++)
+      for (;;)
       {
          ORC_TRY(hipMemsetAsync(d_changed, 0, sizeof(int), st));
          for (int axis=0; axis<3; axis++)
