@@ -258,11 +258,13 @@ def run_workload(config, args, rank, world, device, dist, steps, warmup, serial_
         """(elapsed seconds max over ranks, iterations made by this rank, batch ids, per-step results)"""
         mod.set_num_streams(streams if streams > 1 else 0)
         # one launch at a time of 769..1024 runs: all of them resident at once with four 192-thread
-        # workgroups per CU (orc_set_workgroup_threads); overlapping launches keep the default shape
-        mod.set_workgroup_threads(192 if (streams <= 1 and config in (2, 3) and 768 < n_runs <= 1024) else 0)
-        # overlapping launches (or thousands of runs per launch): four workgroups per CU at 128 registers
-        # (orc_set_workgroups_per_cu; +3 % on the WAM workload, trajectories bit-identical)
-        mod.set_workgroups_per_cu(4 if (config in (2, 3) and (streams > 1 or n_runs > 1024)) else 0)
+        # workgroups per CU at 168 registers (orc_set_workgroup_threads); overlapping launches, batches of thousands of
+        # runs and the TSR-constrained runs use the kernels built for four 256-thread workgroups per CU at 128 registers
+        # (orc_set_workgroups_per_cu(4): +3-5 % / +50 % on the constrained runs; trajectories bit-identical either way)
+        serial_1024 = (streams <= 1 and config in (2, 3) and 768 < n_runs <= 1024)
+        mod.set_workgroup_threads(192 if serial_1024 else 0)
+        wgs_auto = 4 if ((config in (2, 3) and not serial_1024) or config in ("tsr1", "tsr3")) else 0
+        mod.set_workgroups_per_cu(wgs_auto if args.workgroups_per_cu < 0 else args.workgroups_per_cu)
         warm = [wl.create(mod, 900000 + k, rank) for k in range(warmup)]
         timed = [wl.create(mod, k, rank) for k in range(steps)]
         for bid in warm:
@@ -499,6 +501,8 @@ def main():
     ap.add_argument("--cpu-runs", type=int, default=0, help="override the cpu baseline sample size")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for a "
                                                       "single-GPU rehearsal of the multi-rank path)")
+    ap.add_argument("--workgroups-per-cu", type=int, default=-1, help="register budget of the batches (orc_set_workgroups_per_cu): 0 or 4; "
+                                                                      "default: 4 for the overlapping / large-batch legs of configs 2 and 3")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="default run only (N = 1, config 2): do not append the config 4 and config 5 lines")
     ap.add_argument("--other-steps", type=int, default=5, help="steps of each `other_configs` line")
