@@ -297,7 +297,7 @@ void BatchShard::release()
 {
    void ** all[] = { &d_model_, &d_sdfs_, &d_sdfc_, &d_traj_, &d_AG_, &d_G_, (void **) &d_mt_, (void **) &d_mt_bak_, (void **) &d_hmc_next_,
                      (void **) &d_hmc_next_bak_, (void **) &d_overflow_, (void **) &d_costs_, (void **) &d_trace_, (void **) &d_status_,
-                     (void **) &d_iters_done_, (void **) &d_leap_, &d_Aband_, &d_beta_s_, &d_beta_g_, &d_pcr_, &d_Ainv_, &d_jl_lo_, &d_jl_hi_,
+                     (void **) &d_iters_done_, (void **) &d_leap_, &d_Aband_, &d_beta_s_, &d_beta_g_, &d_metric64_, &d_pcr_, &d_Ainv_, &d_jl_lo_, &d_jl_hi_,
                      (void **) &d_hmc_iters_, &d_noise_, (void **) &d_phase_, &d_Gcost_, &d_tsrs_, &d_tsr_ws_, (void **) &d_tsr_err_ };
    for (void ** p : all) { dev_free(*p); *p = nullptr; }
    sdf_refs_.clear();
@@ -370,21 +370,38 @@ void BatchShard::build_device(const Robot & robot)
    std::vector<int> roots;
    for (int k=0; k<nj; k++) { if (jparent[k] < 0) roots.push_back(k); else children[jparent[k]].push_back(k); }
    std::vector<int> order, load_slot(nj, -1), save_slot(nj, -1);
+   // A branch point's frame is kept in a slot while all of its subtrees but the last are walked; the last takes it out of
+   // the slot.  Walking the subtree that needs the most slots last (a stable sort: robots whose subtrees need the same
+   // keep their order) bounds the slots by the tree's Strahler number, <= log2(joints + 1): four for any tree of 30.
+   std::vector<int> need(nj, 0);
+   {
+      std::function<int(int)> slots_needed = [&](int k) -> int
+      {
+         std::vector<int> & ch = children[k];
+         for (int c : ch) slots_needed(c);
+         std::stable_sort(ch.begin(), ch.end(), [&](int a, int b) { return need[a] < need[b]; });
+         int v = 0;
+         for (size_t c=0; c<ch.size(); c++) v = std::max(v, need[ch[c]] + ((c + 1 < ch.size()) ? 1 : 0));
+         return need[k] = v;
+      };
+      for (int rk : roots) slots_needed(rk);
+   }
    int open_slots = 0;
    std::function<void(int)> visit = [&](int k)
    {
       order.push_back(k);
-      if (children[k].size() > 1)
+      const size_t nc = children[k].size();
+      if (nc > 1)
       {
          if (open_slots >= ORC_MAX_SAVE) throw std::runtime_error("kinematic tree branches too deeply for this build!");
          save_slot[k] = open_slots++;
       }
-      for (size_t c=0; c<children[k].size(); c++)
+      for (size_t c=0; c<nc; c++)
       {
+         if (nc > 1 && c + 1 == nc) open_slots--;
          load_slot[children[k][c]] = (c == 0) ? -1 : save_slot[k];
          visit(children[k][c]);
       }
-      if (children[k].size() > 1) open_slots--;
    };
    for (int rk : roots) { load_slot[rk] = -2; visit(rk); }
    std::vector<int> pos_in_order(nj);
@@ -811,6 +828,13 @@ void BatchShard::build_device(const Robot & robot)
    d_Aband_ = upload<real>(metric_.Aband, st);
    d_beta_s_ = upload<real>(metric_.beta_s, st);
    d_beta_g_ = upload<real>(metric_.beta_g, st);
+   if (sizeof(real) == 4 && params.derivative >= 2)
+   {
+      std::vector<double> all(metric_.Aband);
+      all.insert(all.end(), metric_.beta_s.begin(), metric_.beta_s.end());
+      all.insert(all.end(), metric_.beta_g.begin(), metric_.beta_g.end());
+      d_metric64_ = upload<double>(all, st);
+   }
    // A^-1: closed-form Toeplitz inverse through two wave scans per column when the metric is
    // ca tridiag(-1,2,-1) (derivative 1), else cyclic reduction (tridiagonal) or the dense inverse
    solve_mode_ = (params.derivative == 1) ? 0 : 1;
@@ -1196,6 +1220,7 @@ void BatchShard::launch(int n_iter, bool final_eval, bool carry)
    b.use_momentum = params.use_momentum; b.use_hmc = params.use_hmc && max_resamples_ > 0;
    b.D = (params.derivative == 1 && params.free_start) ? -1 : params.derivative;
    b.Aband = (const real *) d_Aband_; b.beta_s = (const real *) d_beta_s_; b.beta_g = (const real *) d_beta_g_;
+   b.metric64 = (const double *) d_metric64_;
    b.kss = metric_.kss; b.ksg = metric_.ksg; b.kgg = metric_.kgg;
    b.solve_mode = solve_mode_;
    b.pcr_levels = metric_.pcr_levels;

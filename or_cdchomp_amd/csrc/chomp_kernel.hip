@@ -1460,6 +1460,23 @@ __device__ __attribute__((noinline)) PassCosts phase_costs(const void * kp, int 
       for (int e=tid; e<mn; e+=BLOCK)
       {
          const int i = div_n(e, rn_f), c = e - i*n;
+         if (sizeof(real) == 4 && b.metric64)
+         {
+            // fp32 and a higher derivative: the band's entries are ~1/dt^4 and the sum is of order one, so this one sum is
+            // taken in double from the band in double (the trajectory is what it is: its rounding costs ~1e-5 of the sum)
+            const int D = b.D;
+            const double * A64 = b.metric64, * bs64 = A64 + (size_t)(2*D + 1) * m, * bg64 = bs64 + m;
+            const double bt = bs64[i] * (double) T_s[c] + bg64[i] * (double) T_s[(np-1)*n + c];
+            double s = bt;
+            for (int k=-D; k<=D; k++)
+            {
+               const int r = i + k;
+               if (r < 0 || r >= m) continue;
+               s += A64[(size_t)(k+D) * m + i] * (double) T_s[(r+1)*n + c];
+            }
+            acc += (double) T_s[n + e] * (0.5 * (s + bt));
+            continue;
+         }
          const real sg = smooth_grad<real>(b, T_s, i, c);     // (A T + B)
          const real bt = (b.D == 1) ? b.a_off * ((i == 0 ? T_s[c] : (real)0) + (i == m-1 ? T_s[(np-1)*n + c] : (real)0))
                                     : b.beta_s[i] * T_s[c] + b.beta_g[i] * T_s[(np-1)*n + c];
@@ -1671,7 +1688,8 @@ __global__ void seed_traj_kernel(real * traj, const double * starts, const doubl
       }
       if (floating)
       {
-         const double len = ::sqrt(row[3]*row[3] + row[4]*row[4] + row[5]*row[5] + row[6]*row[6]);
+         // the sum of squares as written (no fused multiply-add: the rows of a seed are compared bit for bit)
+         const double len = ::sqrt(__dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(row[3], row[3]), __dmul_rn(row[4], row[4])), __dmul_rn(row[5], row[5])), __dmul_rn(row[6], row[6])));
          const double inv = 1.0 / len;
          row[3] *= inv; row[4] *= inv; row[5] *= inv; row[6] *= inv;
       }

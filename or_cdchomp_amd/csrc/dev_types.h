@@ -202,6 +202,8 @@ struct DevBatch
    const real * Aband;     // [2D+1][m]
    const real * beta_s;    // [m]  B[i] = beta_s[i]*q_start + beta_g[i]*q_goal
    const real * beta_g;    // [m]
+   const double * metric64; // fp32 runs with derivative >= 2: Aband, beta_s, beta_g in double ([2D+1][m], [m], [m]) for the smoothness cost, whose
+                           // terms (~1/dt^4) cancel to a number of order one; null otherwise
    double kss, ksg, kgg;   // trC = 0.5*(kss|s|^2 + 2 ksg s.g + kgg|g|^2)
    // A^-1 application
    int solve_mode;         // 0 cyclic reduction (tridiagonal), 1 dense A^-1, 2 closed-form Toeplitz inverse by wave scans

@@ -175,7 +175,7 @@ private:
    void * d_traj_ = nullptr; void * d_AG_ = nullptr; void * d_G_ = nullptr; void * d_Gcost_ = nullptr;
    double * d_costs_ = nullptr; double * d_trace_ = nullptr; size_t trace_cap_ = 0;
    int * d_status_ = nullptr; int * d_iters_done_ = nullptr; int * d_leap_ = nullptr; long long * d_phase_ = nullptr;
-   void * d_Aband_ = nullptr; void * d_beta_s_ = nullptr; void * d_beta_g_ = nullptr;
+   void * d_Aband_ = nullptr; void * d_beta_s_ = nullptr; void * d_beta_g_ = nullptr; void * d_metric64_ = nullptr;
    void * d_pcr_ = nullptr; void * d_Ainv_ = nullptr; void * d_jl_lo_ = nullptr; void * d_jl_hi_ = nullptr;
    // TSR hard constraints (csrc/tsr.h): the device copies of the constraints, the per-run workspace
    void * d_tsrs_ = nullptr; void * d_tsr_ws_ = nullptr; int * d_tsr_err_ = nullptr;

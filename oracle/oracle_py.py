@@ -242,9 +242,12 @@ def default_params(start_tsr=None, **kw):
     """start_tsr = (ee_link, tool[7], T0w[7], Twe[7], Bw[6][2]): `start_tsr` of create"""
     p = RunParams()
     lib().ora_run_params_default(C.byref(p))
+    known = set(f[0] for f in RunParams._fields_)
     for k, v in kw.items():
         if k == "lambda":
             k = "lambda_"
+        if k not in known:
+            raise TypeError("oracle run parameter %r does not exist" % k)
         setattr(p, k, v)
     if start_tsr is not None:
         ee_link, tool, T0w, Twe, Bw = start_tsr

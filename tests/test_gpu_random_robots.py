@@ -1,0 +1,189 @@
+"""-m gpu: seeded random robots against the oracle.
+
+The kernel is compiled in many shapes (16 / 32 / 64 lanes per waypoint, chains with their J^T suffix scan, trees with
+ranges or masks, the FK walk cut in two, fixed or floating base, spheres placed on the row, inactive spheres, the
+matrix-core nomination of pairs in fp32): which of them a robot gets is decided at `create` from its description.
+The named configurations pin a handful of robots; this test draws robots nobody tuned for -- random topology,
+joint types, axes, fixed transforms, sphere counts, active dofs and run parameters -- and asks the same of each:
+the trajectory and the costs of the reference's arithmetic (oracle/ora_run.c, src/orcdchomp_mod.cpp:968-1327,
+src/libcd/chomp.c:430-683) to 1e-6 (fp64) / 1e-3 (fp32, which the reference does not have)."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+import common
+from or_cdchomp_amd import robots, scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_quat(rng, max_angle):
+    axis = rng.normal(size=3); axis /= np.linalg.norm(axis)
+    return robots.quat_from_axis_angle(tuple(axis), float(rng.uniform(-max_angle, max_angle)))
+
+
+def random_robot(seed):
+    """returns (model, description) -- a robot of 2..26 moving joints"""
+    rng = np.random.default_rng(1000 + seed)
+    kind = ("chain", "fork", "tree")[int(rng.integers(0, 3))]
+    n_joints = int(rng.integers(2, 27 if kind != "chain" else 17))
+    many = bool(rng.uniform() < 0.15)
+    model = robots.RobotModel("rnd%d" % seed)
+    model.add_link("base")
+    names = ["base"]
+    cut = int(rng.integers(1, max(2, n_joints // 2)))               # fork: a chain of `cut` joints, then two branches
+    tips = []
+    for j in range(n_joints):
+        if kind == "chain":
+            parent = names[-1]
+        elif kind == "fork":
+            if j <= cut:
+                parent = names[-1]
+            else:
+                if len(tips) < 2:
+                    tips = [names[cut], names[cut]]
+                b = int(rng.integers(0, 2))
+                parent = tips[b]
+        else:
+            parent = names[int(rng.integers(max(0, len(names) - 4), len(names)))]
+        # now and then a fixed link between two joints
+        if rng.uniform() < 0.12:
+            fx = "f%d" % j
+            model.add_link(fx, parent, tuple(rng.uniform(-0.05, 0.05, size=3)), _random_quat(rng, 0.6), joint=robots.JOINT_FIXED)
+            if rng.uniform() < 0.5:
+                model.add_sphere(fx, tuple(rng.uniform(-0.02, 0.02, size=3)), float(rng.uniform(0.03, 0.05)))
+            parent = fx
+        nm = "j%d" % j
+        prismatic = rng.uniform() < 0.15
+        axis = rng.normal(size=3)
+        if rng.uniform() < 0.5:
+            axis = np.eye(3)[int(rng.integers(0, 3))]
+        limits = (-0.25, 0.25) if prismatic else ((-2.2, 2.2) if rng.uniform() < 0.8 else None)
+        model.add_link(nm, parent, tuple(rng.uniform(-0.04, 0.04, size=2)) + (float(rng.uniform(0.08, 0.2)),),
+                       _random_quat(rng, 0.5) if rng.uniform() < 0.4 else (0, 0, 0, 1),
+                       joint=robots.JOINT_PRISMATIC if prismatic else robots.JOINT_REVOLUTE, axis=tuple(axis), limits=limits)
+        names.append(nm)
+        if kind == "fork" and j > cut:
+            tips[b] = nm
+    # spheres: 0..3 per moving link, at most 60 in all, at least one on the last link
+    budget = 60 - len(model.spheres)
+    for nm in names[1:]:
+        k = int(rng.integers(0, 4)) if n_joints <= 16 else int(rng.integers(0, 3))
+        if many:
+            k = int(rng.integers(2, 4))                                  # more than 32 spheres: a wavefront per waypoint
+        if nm == names[-1]:
+            k = max(k, 1)
+        for _ in range(min(k, budget)):
+            model.add_sphere(nm, tuple(rng.uniform(-0.03, 0.03, size=2)) + (float(rng.uniform(0.0, 0.12)),), float(rng.uniform(0.03, 0.07)))
+            budget -= 1
+    if rng.uniform() < 0.5:
+        model.add_sphere("base", (0.0, 0.0, 0.05), 0.08)               # never moves: an inactive sphere
+    return model, "%s of %d joints, %d spheres" % (kind, n_joints, len(model.spheres))
+
+
+def _scene(mod, oracle, which):
+    if which == "table":
+        scenes.add_tabletop(mod)
+        mod.SendCommand("computedistancefield kinbody table")
+        prob = common.tabletop_problem(oracle)
+        return [prob["sdf"]], [prob["pose"]]
+    rng = np.random.default_rng(20250104)
+    grids, poses = [], []
+    for name, (boxes, pose) in scenes.random_boxes(rng, n_bodies=which).items():
+        mod.add_kinbody_boxes(name, boxes, transform=pose)
+        mod.SendCommand("computedistancefield kinbody %s cube_extent 0.02 aabb_padding 0.15" % name)
+        data, lengths, gpose = mod.get_sdf(name)
+        grids.append(oracle.OraGrid(data, lengths))
+        out = np.zeros(7)
+        oracle.lib().ora_kin_pose_compose(oracle.dp(oracle.f64(pose)), oracle.dp(oracle.f64(gpose)), oracle.dp(out))
+        poses.append(out)
+    return grids, poses
+
+
+SEEDS = list(range(int(os.environ.get("ORC_RANDOM_ROBOTS", "24"))))       # more of them: ORC_RANDOM_ROBOTS=400 pytest ...
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+def test_random_robot_matches_oracle(oracle, seed):
+    import or_cdchomp_amd
+    rng = np.random.default_rng(5000 + seed)
+    model, what = random_robot(seed)
+    n_dof = model.n_dof
+    # active dofs: all, or a subset (the others stay where the robot stands; their links' spheres may be inactive)
+    if rng.uniform() < 0.35 and n_dof > 3:
+        adofs = sorted(rng.choice(n_dof, size=int(rng.integers(2, n_dof)), replace=False).tolist())
+    else:
+        adofs = list(range(n_dof))
+    lo = np.array([max(model.limit_lower[d], -1.5) for d in range(n_dof)])
+    hi = np.array([min(model.limit_upper[d], 1.5) for d in range(n_dof)])
+    dofvals = rng.uniform(0.5 * lo, 0.5 * hi)
+    which = ("table", 2, 4, "table")[int(rng.integers(0, 4))]
+    base = ([-0.55, 0.05, 0.75] if which == "table" else [0.05, -0.1, 0.35]) + list(_random_quat(rng, 0.7))
+    floating = bool(rng.uniform() < 0.25)
+    precision = 32 if rng.uniform() < 0.25 else 64
+    momentum = bool(rng.uniform() < 0.3)
+    second_order = bool(rng.uniform() < 0.12)
+    hmc = momentum and bool(rng.uniform() < 0.4)
+    long_traj = bool(rng.uniform() < 0.1)                 # several tiles of waypoints
+    tol = 1e-3 if precision == 32 else 1e-6
+    n_runs = 3
+    n_points = int(rng.integers(100, 230)) if long_traj else int(rng.integers(5, 72))
+    n_iter = int(rng.integers(6, 16))
+    kw = dict(n_points=n_points, lambda_=float(rng.uniform(120.0, 400.0)), obs_factor=float(rng.uniform(20.0, 200.0)),
+              obs_factor_self=float(rng.uniform(2.0, 20.0)), epsilon=float(rng.uniform(0.06, 0.14)),
+              epsilon_self=float(rng.uniform(0.02, 0.08)))
+    if momentum:
+        kw["use_momentum"] = 1
+    if second_order:
+        kw["derivative"] = 2
+    if hmc:
+        kw["use_hmc"] = 1
+        kw["hmc_resample_lambda"] = float(rng.uniform(0.02, 0.3))
+    seeds = rng.integers(0, 1000, size=n_runs).astype(np.uint32)
+    if floating:
+        kw["floating_base"] = 1
+    mod = or_cdchomp_amd.Module(0)
+    mod.add_robot(model, transform=base, dof_values=dofvals, active_dofs=adofs)
+    grids, poses = _scene(mod, oracle, which)
+    goals = rng.uniform(0.7 * lo[adofs], 0.7 * hi[adofs], size=(n_runs, len(adofs)))
+    basegoals = None
+    if floating:
+        basegoals = np.tile(np.asarray(base), (n_runs, 1)); basegoals[:, :3] += rng.uniform(-0.2, 0.2, size=(n_runs, 3))
+    rob = oracle.OraRobot(model)
+    okw = dict(kw)
+    if "derivative" in okw:
+        okw["D"] = okw.pop("derivative")                  # the oracle's name for it
+    # the reference refuses a robot whose active dofs move no sphere (src/orcdchomp_mod.cpp:2296): so must both sides
+    try:
+        probe = oracle.OraRun(rob, base, dofvals, adofs, goals[0], grids, poses, oracle.default_params(**okw),
+                              basegoal=None if basegoals is None else basegoals[0])
+    except RuntimeError as e:
+        with pytest.raises(RuntimeError) as pe:
+            mod.batch_create(model.name, goals, basegoals=basegoals, seeds=seeds, precision=precision, **kw)
+        assert str(e) in str(pe.value)
+        print("seed %d (%s): both refuse: %s" % (seed, what, e))
+        return
+    probe.destroy()
+    bid = mod.batch_create(model.name, goals, basegoals=basegoals, seeds=seeds, precision=precision, **kw)
+    seeded = mod.batch_gettraj(bid)
+    costs, status = mod.batch_iterate(bid, n_iter)
+    traj = mod.batch_gettraj(bid)
+    mod.batch_destroy(bid)
+    errs = []
+    for k in range(n_runs):
+        run = oracle.OraRun(rob, base, dofvals, adofs, goals[k], grids, poses, oracle.default_params(seed=int(seeds[k]), **okw),
+                            basegoal=None if basegoals is None else basegoals[k])
+        if precision == 64:
+            assert np.array_equal(seeded[k], run.traj())
+        st, ocosts = run.iterate(n_iter)
+        assert st == status[k], (seed, what, k, st, status[k])
+        if st == 0:
+            errs.append(common.rel_l2(traj[k], run.traj()))
+            assert np.allclose(costs[k], ocosts, rtol=tol * (100 if precision == 32 else 1), atol=1e-12), (seed, what, costs[k], ocosts)
+        run.destroy()
+    assert errs and max(errs) <= tol, (seed, what, errs)
+    print("seed %d (%s; %d of %d dofs active, %s, fp%d, %d points, %s%s): worst rel L2 %.2e" % (
+        seed, what, len(adofs), n_dof, "floating" if floating else "fixed", precision, n_points,
+        "%s fields" % which if which != "table" else "table", (", momentum" if momentum else "") + (" + hmc" if hmc else "") + (", derivative 2" if second_order else ""), max(errs)))
