@@ -19,7 +19,7 @@ hipError_t orc_launch_iterate_f64(const DevBatch<double> & b, size_t lds, hipStr
 hipError_t orc_launch_iterate_f32(const DevBatch<float> & b, size_t lds, hipStream_t stream, int tree);
 hipError_t orc_launch_verdict_f64(const DevVerdict<double> & v, size_t lds, hipStream_t stream, int tree);
 hipError_t orc_launch_verdict_f32(const DevVerdict<float> & v, size_t lds, hipStream_t stream, int tree);
-size_t orc_verdict_lds_bytes(int n, int Sa, int Sa_real, int nj, size_t real_size);
+size_t orc_verdict_lds_bytes(int n, int Sa, int Sa_real, int nj, size_t real_size, int chunk);
 hipError_t orc_launch_hmc_seed(uint32_t * state, int * next, const unsigned int * seeds, int n_runs, hipStream_t stream);
 hipError_t orc_launch_hmc_plan_f64(uint32_t * state, int * next, int n_runs, int iter_begin, int iter_end, int cap, size_t mn, double lambda,
    double * noise, int * iters, int * overflow, hipStream_t stream);
@@ -1010,25 +1010,28 @@ void BatchShard::collision_verdict(const std::vector<int> & offs, const std::vec
    hip_check(hipMemcpyAsync(d_pairs, pairs.data(), pairs.size()*sizeof(int), hipMemcpyHostToDevice, st), "verdict pairs");
    void * d_u = nullptr, * d_rsum = nullptr, * d_inact = nullptr;
    hipError_t e;
+   // samples per pass: 64, or what the LDS of a CU holds of this robot's rows, positions and joint frames
+   int chunk = 64;
+   while (chunk > 4 && orc_verdict_lds_bytes(n, Sa_, Sa_real_, nj_, params.precision / 8, chunk) > 160*1024 - 256) chunk -= 4;
    if (params.precision == 64)
    {
       d_u = upload<double>(u, st); d_rsum = upload<double>(pair_rsum, st); d_inact = upload<double>(inact_pos, st);
       DevVerdict<double> v;
       v.model = (const DevModel<double> *) d_model_; v.sdfs = (const DevSdf<double> *) d_sdfs_; v.n_sdfs = n_sdfs_;
-      v.n_runs = n_runs; v.n_points = n_points; v.n = n; v.traj = (const double *) d_traj_;
+      v.n_runs = n_runs; v.n_points = n_points; v.n = n; v.chunk = chunk; v.traj = (const double *) d_traj_;
       v.offs = d_offs; v.seg = d_seg; v.u = (const double *) d_u; v.slot_xml = d_xml; v.key_out = d_key; v.depth_out = d_depth;
       v.n_pairs = n_pairs; v.pairs = d_pairs; v.pair_rsum = (const double *) d_rsum; v.inact_pos = (const double *) d_inact;
-      e = orc_launch_verdict_f64(v, orc_verdict_lds_bytes(n, Sa_, Sa_real_, nj_, 8), st, tree_ & 1);
+      e = orc_launch_verdict_f64(v, orc_verdict_lds_bytes(n, Sa_, Sa_real_, nj_, 8, chunk), st, tree_ & 1);
    }
    else
    {
       d_u = upload<float>(u, st); d_rsum = upload<float>(pair_rsum, st); d_inact = upload<float>(inact_pos, st);
       DevVerdict<float> v;
       v.model = (const DevModel<float> *) d_model_; v.sdfs = (const DevSdf<float> *) d_sdfs_; v.n_sdfs = n_sdfs_;
-      v.n_runs = n_runs; v.n_points = n_points; v.n = n; v.traj = (const float *) d_traj_;
+      v.n_runs = n_runs; v.n_points = n_points; v.n = n; v.chunk = chunk; v.traj = (const float *) d_traj_;
       v.offs = d_offs; v.seg = d_seg; v.u = (const float *) d_u; v.slot_xml = d_xml; v.key_out = d_key; v.depth_out = d_depth;
       v.n_pairs = n_pairs; v.pairs = d_pairs; v.pair_rsum = (const float *) d_rsum; v.inact_pos = (const float *) d_inact;
-      e = orc_launch_verdict_f32(v, orc_verdict_lds_bytes(n, Sa_, Sa_real_, nj_, 4), st, tree_ & 1);
+      e = orc_launch_verdict_f32(v, orc_verdict_lds_bytes(n, Sa_, Sa_real_, nj_, 4, chunk), st, tree_ & 1);
    }
    hip_check(e, "collision_verdict_kernel launch");
    hip_check(hipMemcpyAsync(key_out, d_key, n_runs*sizeof(int), hipMemcpyDeviceToHost, st), "verdict keys");

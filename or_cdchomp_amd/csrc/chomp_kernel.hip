@@ -1700,7 +1700,7 @@ __global__ void seed_traj_kernel(real * traj, const double * starts, const doubl
 // ---------------------------------------------------------------------------
 // Collision verdict of every run's trajectory: one workgroup per run walks the run's samples (planned
 // on the host: every 0.04 rad of C-space distance along the retimed trajectory, as the reference's
-// re-check in gettraj, src/orcdchomp_mod.cpp:2958-3006) 64 at a time: rows interpolated on their
+// re-check in gettraj, src/orcdchomp_mod.cpp:2958-3006) up to 64 at a time (DevVerdict::chunk): rows interpolated on their
 // segments -> FK (fk.h, four lanes per sample) -> every active sphere against every field.  The
 // first contact in (sample, XML sphere, field) order is reported, which is where the reference's
 // loop stops.
@@ -1712,13 +1712,13 @@ void collision_verdict_kernel(DevVerdict<real> v)
    const DevModel<real> & gmod = *v.model;
    const int run = blockIdx.x, tid = threadIdx.x;
    const int n = v.n, np = v.n_points, nj = gmod.nj, Sa = gmod.Sa;
-   const int pstr = (Sa*3) | 1, astr = (nj*6) | 1;
+   const int pstr = (Sa*3) | 1, astr = (nj*6) | 1, chunk = v.chunk;
    int * key_s = (int *) smem_raw;                                   // [4]
    real * lds = (real *)(smem_raw + 16);
-   real * rows_s = lds;                                              // [64][n]
-   real * pos_s = rows_s + ((64*n + 3) & ~3);                        // [64][pstr]
-   real * ax_s = pos_s + ((64*pstr + 3) & ~3);                       // [64][astr]
-   real * sphpos_s = ax_s + ((64*astr + 3) & ~3);                    // [Sa][3]
+   real * rows_s = lds;                                              // [chunk][n]
+   real * pos_s = rows_s + ((chunk*n + 3) & ~3);                        // [chunk][pstr]
+   real * ax_s = pos_s + ((chunk*pstr + 3) & ~3);                       // [chunk][astr]
+   real * sphpos_s = ax_s + ((chunk*astr + 3) & ~3);                    // [Sa][3]
    real * base_s = sphpos_s + ((Sa*3 + 3) & ~3);                     // [12]
    real * srad_s = base_s + 12;                                      // [Sa]
    int * slot_s = (int *)(srad_s + ((Sa + 3) & ~3));                 // [Sa_real]
@@ -1747,9 +1747,9 @@ void collision_verdict_kernel(DevVerdict<real> v)
    const real * traj = v.traj + (size_t) run * np * n;
    const int s0 = v.offs[run], s1 = v.offs[run+1];
    double my_depth = 0.0; int my_key = 0x7fffffff;
-   for (int base=s0; base<s1; base+=64)
+   for (int base=s0; base<s1; base+=chunk)
    {
-      const int count = (s1 - base < 64) ? s1 - base : 64;
+      const int count = (s1 - base < chunk) ? s1 - base : chunk;
       // rows of the samples: a0 + (a1 - a0) u on their segments
       for (int e=tid; e<count*n; e+=ORC_BLOCK)
       {
@@ -1963,11 +1963,11 @@ hipError_t orc_launch_verdict_f64(const DevVerdict<double> & v, size_t lds, hipS
 hipError_t orc_launch_verdict_f32(const DevVerdict<float> & v, size_t lds, hipStream_t stream, int tree) { return launch_verdict_t<float>(v, lds, stream, tree); }
 
 // dynamic LDS of collision_verdict_kernel (the carve-up at its top)
-size_t orc_verdict_lds_bytes(int n, int Sa, int Sa_real, int nj, size_t real_size)
+size_t orc_verdict_lds_bytes(int n, int Sa, int Sa_real, int nj, size_t real_size, int chunk)
 {
    const int pstr = (Sa*3) | 1, astr = (nj*6) | 1;
    auto r4 = [](int x) { return (x + 3) & ~3; };
-   size_t reals = (size_t) r4(64*n) + r4(64*pstr) + r4(64*astr) + r4(Sa*3) + 12 + r4(Sa);
+   size_t reals = (size_t) r4(chunk*n) + r4(chunk*pstr) + r4(chunk*astr) + r4(Sa*3) + 12 + r4(Sa);
    size_t ints = (size_t) r4(Sa_real) + r4(Sa);
    return 16 + reals * real_size + ints * 4 + (size_t) nj * 8 + 64;
 }

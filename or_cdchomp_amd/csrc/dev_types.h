@@ -256,6 +256,7 @@ struct DevVerdict
    const DevSdf<real> * sdfs;
    int n_sdfs;
    int n_runs, n_points, n;
+   int chunk;                  // samples walked at a time (<= 64: as many as the CU's LDS holds of this robot)
    const real * traj;          // [n_runs][n_points][n]
    const int * offs;           // [n_runs+1] first sample of every run
    const int * seg;            // [samples] segment of the trajectory the sample lies on

@@ -187,3 +187,62 @@ def test_random_robot_matches_oracle(oracle, seed):
     print("seed %d (%s; %d of %d dofs active, %s, fp%d, %d points, %s%s): worst rel L2 %.2e" % (
         seed, what, len(adofs), n_dof, "floating" if floating else "fixed", precision, n_points,
         "%s fields" % which if which != "table" else "table", (", momentum" if momentum else "") + (" + hmc" if hmc else "") + (", derivative 2" if second_order else ""), max(errs)))
+
+
+@pytest.mark.parametrize("seed", SEEDS[:16] if len(SEEDS) <= 24 else SEEDS)
+def test_random_robot_collision_verdict_matches_oracle(oracle, seed):
+    """gettraj's re-check on the device (src/orcdchomp_mod.cpp:2958-3006): field contacts and
+    self collisions of robots whose spheres overlap as they come -- which pairs of links count (same link, parent and
+    child, links that touch at the zero configuration) is decided by two independent pieces of code."""
+    import or_cdchomp_amd
+    rng = np.random.default_rng(9000 + seed)
+    model, what = random_robot(seed)
+    n_dof = model.n_dof
+    adofs = list(range(n_dof)) if rng.uniform() < 0.6 or n_dof < 4 else sorted(rng.choice(n_dof, size=int(rng.integers(2, n_dof)), replace=False).tolist())
+    lo = np.array([max(model.limit_lower[d], -1.5) for d in range(n_dof)])
+    hi = np.array([min(model.limit_upper[d], 1.5) for d in range(n_dof)])
+    dofvals = rng.uniform(0.3 * lo, 0.3 * hi)
+    which = ("table", 2)[int(rng.integers(0, 2))]
+    base = ([-0.55, 0.05, 0.75] if which == "table" else [0.05, -0.1, 0.35]) + list(_random_quat(rng, 0.7))
+    floating = bool(rng.uniform() < 0.25)
+    n_runs, n_points = 12, int(rng.integers(6, 50))
+    kw = dict(n_points=n_points, lambda_=200.0, obs_factor=50.0)
+    if floating:
+        kw["floating_base"] = 1
+    mod = or_cdchomp_amd.Module(0)
+    mod.add_robot(model, transform=base, dof_values=dofvals, active_dofs=adofs)
+    vmax = rng.uniform(0.2, 3.0, size=n_dof)
+    mod.set_velocity_limits(model.name, vmax)
+    grids, poses = _scene(mod, oracle, which)
+    goals = rng.uniform(lo[adofs], hi[adofs], size=(n_runs, len(adofs)))
+    basegoals = None
+    if floating:
+        basegoals = np.tile(np.asarray(base), (n_runs, 1)); basegoals[:, :3] += rng.uniform(-0.3, 0.3, size=(n_runs, 3))
+    rob = oracle.OraRobot(model)
+    try:
+        oracle.OraRun(rob, base, dofvals, adofs, goals[0], grids, poses, oracle.default_params(**kw),
+                      basegoal=None if basegoals is None else basegoals[0]).destroy()
+    except RuntimeError:
+        pytest.skip("the active dofs of this draw move no sphere")
+    bid = mod.batch_create(model.name, goals, basegoals=basegoals, **kw)
+    mod.batch_iterate(bid, 2)
+    got = mod.batch_collision_verdict(bid)
+    trajs = mod.batch_gettraj(bid)
+    mod.batch_destroy(bid)
+    kinds = [0, 0, 0]
+    for k in range(n_runs):
+        orun = oracle.OraRun(rob, base, dofvals, adofs, goals[k], grids, poses, oracle.default_params(**kw),
+                             basegoal=None if basegoals is None else basegoals[k])
+        orun.set_traj(trajs[k])
+        want = orun.collision_recheck(vmax[adofs])
+        orun.destroy()
+        mine = {q: got[q][k] for q in got}
+        assert want["collides"] == mine["collides"], (seed, what, k, want, mine)
+        if want["collides"]:
+            assert want["sphere"] == mine["sphere"] and want["field"] == mine["field"], (seed, what, k, want, mine)
+            assert np.isclose(want["time"], mine["time"], rtol=1e-12, atol=1e-15), (seed, what, k, want, mine)
+            assert np.isclose(want["depth"], mine["depth"], rtol=1e-9, atol=1e-12), (seed, what, k, want, mine)
+            kinds[1 if want["field"] >= 0 else 2] += 1
+        else:
+            kinds[0] += 1
+    print("seed %d (%s, %s): %d free, %d in a field, %d self collisions" % (seed, what, "floating" if floating else "fixed", *kinds))
