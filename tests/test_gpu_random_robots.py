@@ -246,3 +246,91 @@ def test_random_robot_collision_verdict_matches_oracle(oracle, seed):
         else:
             kinds[0] += 1
     print("seed %d (%s, %s): %d free, %d in a field, %d self collisions" % (seed, what, "floating" if floating else "fixed", *kinds))
+
+
+@pytest.mark.parametrize("seed", SEEDS[:16] if len(SEEDS) <= 24 else SEEDS)
+def test_random_robot_tsr_constraint_matches_oracle(oracle, seed):
+    """`con_tsr 'all link L'` (src/libcd/chomp.c:553-600, src/orcdchomp_mod.cpp:1330-1497) on random
+    robots: one to three rows of the pose error of the last link held at their start values on every moving point.  The
+    constraint step's elimination runs in registers in one of three shapes chosen from the run's size (csrc/tsr.h)."""
+    import or_cdchomp_amd
+    rng = np.random.default_rng(13000 + seed)
+    model, what = random_robot(seed)
+    n_dof = model.n_dof
+    adofs = list(range(n_dof))
+    lo = np.array([max(model.limit_lower[d], -1.5) for d in range(n_dof)])
+    hi = np.array([min(model.limit_upper[d], 1.5) for d in range(n_dof)])
+    dofvals = rng.uniform(0.5 * lo, 0.5 * hi)
+    # a unit quaternion to the last bit matters to nobody, but the poses are inverted as if it were one
+    base = [-0.55, 0.05, 0.75] + list(_random_quat(rng, 0.7))
+    link = model.link_names[-1]
+    li = len(model.link_names) - 1
+    # joints between the base and that link
+    n_anc, cur = 0, li
+    while cur >= 0:
+        n_anc += model.joint_type[cur] != robots.JOINT_FIXED
+        cur = model.parent[cur]
+    k = int(rng.integers(1, 1 + min(3, max(1, n_anc // 2))))
+    floating = bool(rng.uniform() < 0.2)
+    momentum = bool(rng.uniform() < 0.3)
+    n_runs = 3
+    n_points = int(rng.integers(100, 210)) if rng.uniform() < 0.15 else int(rng.integers(5, 70))
+    n_iter = int(rng.integers(5, 14))
+    lam = float(rng.uniform(120.0, 400.0))
+    mod = or_cdchomp_amd.Module(0)
+    mod.add_robot(model, transform=base, dof_values=dofvals, active_dofs=adofs)
+    grids, poses = _scene(mod, oracle, "table")
+    rob = oracle.OraRobot(model)
+    R, t, _, _ = rob.fk(base, dofvals)
+    goals = dofvals[None, :] + 0.35 * rng.uniform(-1, 1, size=(n_runs, n_dof)) * np.minimum(1.0, hi - lo)
+    goals = np.ascontiguousarray(np.clip(goals, lo, hi))
+    # rows the link's joints can actually move: a row whose Jacobian is rounding noise (the y of a point on its own
+    # joint's axis) makes the step a quotient of two such numbers, in the reference as here
+    for attempt in range(12):
+        rows = sorted(rng.choice(6, size=k, replace=False).tolist())
+        Bw = [[0, 0] if r in rows else ([-1, 1] if r < 3 else [-3, 3]) for r in range(6)]
+        probe = oracle.OraRun(rob, base, dofvals, adofs, goals[0], grids, poses, oracle.default_params(n_points=9))
+        probe.add_contsr(li, [0, 0, 0, 0, 0, 0, 1], oracle.pose_from_dR(t[li], R[li]), [0, 0, 0, 0, 0, 0, 1], Bw)
+        smin = min(np.linalg.svd(probe.eval_contsr(0, probe.traj()[i])[1], compute_uv=False).min() for i in range(1, 8))
+        probe.destroy()
+        if smin > 0.02:
+            break
+    else:
+        pytest.skip("no well-posed rows found for the last link of this draw")
+    tsr = robots.Tsr(T0w_R=R[li], T0w_d=t[li], Bw=Bw)
+    cmd = "createbatch robot %s n_runs %d adofgoals 0x%x n_points %d lambda %.17g obs_factor 100 con_tsr 'all link %s' '%s'" % (
+        model.name, n_runs, goals.ctypes.data, n_points, lam, link, tsr.serialize())
+    basegoals = None
+    if floating:
+        basegoals = np.tile(np.asarray(base), (n_runs, 1)); basegoals[:, :3] += rng.uniform(-0.15, 0.15, size=(n_runs, 3))
+        cmd += " basegoals 0x%x floating_base" % basegoals.ctypes.data
+    if momentum:
+        cmd += " use_momentum"
+    bid = int(mod.SendCommand(cmd))
+    costs, status = mod.batch_iterate(bid, n_iter)
+    traj = mod.batch_gettraj(bid)
+    mod.batch_destroy(bid)
+    okw = dict(n_points=n_points, lambda_=lam, obs_factor=100.0)
+    if floating:
+        okw["floating_base"] = 1
+    if momentum:
+        okw["use_momentum"] = 1
+    errs = []
+    for r in range(n_runs):
+        run = oracle.OraRun(rob, base, dofvals, adofs, goals[r], grids, poses, oracle.default_params(**okw),
+                            basegoal=None if basegoals is None else basegoals[r])
+        assert run.add_contsr(li, [0, 0, 0, 0, 0, 0, 1], oracle.pose_from_dR(t[li], R[li]), [0, 0, 0, 0, 0, 0, 1], Bw) == k
+        st, oc = run.iterate(n_iter)
+        ot = run.traj().copy()
+        run.destroy()
+        if st != 0 or not np.all(np.isfinite(ot)):
+            assert status[r] != 0 or not np.all(np.isfinite(traj[r])), (seed, what, r, st, status[r])
+            continue
+        assert status[r] == 0, (seed, what, r, status[r])
+        errs.append(common.rel_l2(traj[r], ot))
+        assert np.allclose(costs[r], oc, rtol=1e-6, atol=1e-12), (seed, what, r, costs[r], oc)
+    if not errs:
+        pytest.skip("the constraint of this draw is singular for the oracle as well")
+    assert max(errs) <= 1e-6, (seed, what, rows, errs)
+    print("seed %d (%s, %s%s, %d points, rows %s of link %s behind %d joints): worst rel L2 %.2e" % (
+        seed, what, "floating" if floating else "fixed", ", momentum" if momentum else "", n_points, rows, link, n_anc, max(errs)))
