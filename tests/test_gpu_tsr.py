@@ -376,3 +376,43 @@ def test_con_tsr_full_trajectory_length(oracle):
     sub = mod.batch_gettraj(bid)
     mod.batch_destroy(bid)
     assert np.array_equal(sub, traj[8:16])
+
+
+def test_con_tsr_on_a_link_no_active_joint_moves(oracle):
+    """a constraint nothing can satisfy or violate: the rows of a link the active joints do not move have a zero
+    Jacobian, J Ainv J^T is the zero matrix, the reference's dgesv reports it singular ("constraint inversion
+    error!", src/libcd/chomp.c:579-590), leaves h as it is and pushes J^T h = 0 to the trajectory -- the run goes on as
+    if unconstrained.  The structured elimination meets a zero pivot and hands over to the dense path, which does the same."""
+    O = oracle
+    base = _unit_base()
+    mod = or_cdchomp_amd.Module(0)
+    model, dofvals, adofs = _setup(mod, base)
+    Rl, tl, ll = _start_frame(O, model, base, dofvals, "wam0", [0, 0, 0, 0, 0, 0, 1])
+    Bw = [[0, 0], [-1, 1], [0, 0], [-3, 3], [-3, 3], [-3, 3]]
+    tsr = robots.Tsr(T0w_R=Rl, T0w_d=tl + np.array([0.05, 0.0, -0.02]), Bw=Bw)      # and the link is not where the TSR wants it
+    n_runs, n_points, n_iter = 3, 30, 8
+    goals = _near_goals(n_runs, 11)
+    bid = int(mod.SendCommand("createbatch robot %s n_runs %d adofgoals 0x%x n_points %d lambda 100 obs_factor 200 con_tsr 'all link wam0' '%s'"
+                              % (model.name, n_runs, goals.ctypes.data, n_points, tsr.serialize())))
+    costs, status = mod.batch_iterate(bid, n_iter)
+    traj = mod.batch_gettraj(bid)
+    mod.batch_destroy(bid)
+    bid = mod.batch_create(model.name, goals, n_points=n_points, lambda_=100.0, obs_factor=200.0)
+    costs_free, _ = mod.batch_iterate(bid, n_iter)
+    traj_free = mod.batch_gettraj(bid)
+    mod.batch_destroy(bid)
+    prob = common.tabletop_problem(O)
+    rob = O.OraRobot(model)
+    for k in range(n_runs):
+        run = O.OraRun(rob, base, dofvals, adofs, goals[k], [prob["sdf"]], [prob["pose"]],
+                       O.default_params(n_points=n_points, lambda_=100.0, obs_factor=200.0))
+        assert run.add_contsr(ll, [0, 0, 0, 0, 0, 0, 1], O.pose_from_dR(tl + np.array([0.05, 0.0, -0.02]), Rl), [0, 0, 0, 0, 0, 0, 1], Bw) == 2
+        h, J = run.eval_contsr(0, run.traj()[5])
+        assert np.all(J == 0.0) and np.abs(h).max() > 0.01
+        st, oc = run.iterate(n_iter)
+        assert st == 0 and status[k] == 0
+        assert np.all(np.isfinite(traj[k]))
+        assert common.rel_l2(traj[k], run.traj()) <= 1e-6
+        assert np.allclose(costs[k], oc, rtol=1e-6, atol=0)
+        assert common.rel_l2(traj[k], traj_free[k]) <= 1e-9          # and that is the unconstrained run
+        run.destroy()
