@@ -334,3 +334,102 @@ def test_random_robot_tsr_constraint_matches_oracle(oracle, seed):
     assert max(errs) <= 1e-6, (seed, what, rows, errs)
     print("seed %d (%s, %s%s, %d points, rows %s of link %s behind %d joints): worst rel L2 %.2e" % (
         seed, what, "floating" if floating else "fixed", ", momentum" if momentum else "", n_points, rows, link, n_anc, max(errs)))
+
+
+@pytest.mark.parametrize("seed", SEEDS[:12] if len(SEEDS) <= 24 else SEEDS)
+def test_random_robot_through_the_commands(oracle, seed):
+    """the command layer on random robots: `create` / `iterate` / `gettraj` of one run give the
+    bits of the same run inside a batch; the trajectory document names the active dofs and carries the retimed waypoints
+    (src/orcdchomp_mod.cpp:2897-2956) digit for digit; fed back through `create starttraj` (src/orcdchomp_mod.cpp:2375-2416)
+    it seeds what the oracle's sampler reads out of the same document, at this and at another length."""
+    import re
+    import or_cdchomp_amd
+    from or_cdchomp_amd import bindings
+    rng = np.random.default_rng(17000 + seed)
+    model, what = random_robot(seed)
+    n_dof = model.n_dof
+    adofs = list(range(n_dof)) if rng.uniform() < 0.5 or n_dof < 4 else sorted(rng.choice(n_dof, size=int(rng.integers(2, n_dof)), replace=False).tolist())
+    lo = np.array([max(model.limit_lower[d], -1.5) for d in range(n_dof)])
+    hi = np.array([min(model.limit_upper[d], 1.5) for d in range(n_dof)])
+    dofvals = rng.uniform(0.5 * lo, 0.5 * hi)
+    base = [-0.55, 0.05, 0.75] + list(_random_quat(rng, 0.7))
+    floating = bool(rng.uniform() < 0.3)
+    momentum = bool(rng.uniform() < 0.3)
+    n_points, n_iter = int(rng.integers(4, 60)), int(rng.integers(1, 9))
+    lam = round(float(rng.uniform(120.0, 400.0)), 4)           # the python layer writes `lambda %0.04f`
+    mod = bindings.bind(or_cdchomp_amd.Module(0))
+    mod.add_robot(model, transform=base, dof_values=dofvals, active_dofs=adofs)
+    vmax = rng.uniform(0.2, 3.0, size=n_dof)
+    mod.set_velocity_limits(model.name, vmax)
+    _scene(mod, oracle, "table")
+    n_runs, mine = 5, int(rng.integers(0, 5))
+    goals = rng.uniform(0.7 * lo[adofs], 0.7 * hi[adofs], size=(n_runs, len(adofs)))
+    basegoals = None
+    if floating:
+        basegoals = np.tile(np.asarray(base), (n_runs, 1)); basegoals[:, :3] += rng.uniform(-0.2, 0.2, size=(n_runs, 3))
+    kw = dict(n_points=n_points, lambda_=lam, obs_factor=80.0)
+    ckw = dict(kw)
+    if momentum:
+        kw["use_momentum"] = 1; ckw["use_momentum"] = True
+    if floating:
+        kw["floating_base"] = 1
+    try:
+        bid = mod.batch_create(model.name, goals, basegoals=basegoals, **kw)
+    except RuntimeError as e:
+        assert "at least one sphere" in str(e)
+        with pytest.raises(RuntimeError, match="at least one sphere"):
+            mod.create(robot=model.name, adofgoal=[float(v) for v in goals[mine]], **ckw)
+        return
+    bcosts, bstatus = mod.batch_iterate(bid, n_iter)
+    btraj = mod.batch_gettraj(bid)
+    mod.batch_destroy(bid)
+    if floating:
+        run = mod.create(robot=model.name, adofgoal=[float(v) for v in goals[mine]], basegoal=[float(v) for v in basegoals[mine]], floating_base=True, **ckw)
+    else:
+        run = mod.create(robot=model.name, adofgoal=[float(v) for v in goals[mine]], **ckw)
+    if bstatus[mine] != 0:
+        with pytest.raises(RuntimeError, match="Resulting trajectory is outside of joint limits!"):
+            mod.iterate(run=run, n_iter=n_iter)
+        mod.destroy(run=run)
+        return
+    out = [None]
+    mod.iterate(run=run, n_iter=n_iter, cost=out)                  # the python layer's out-parameter (orcdchomp.py:176-185)
+    cost = out[0]
+    traj = mod.batch_gettraj(int(run))[0]
+    assert np.array_equal(traj, btraj[mine])
+    assert np.isclose(cost, bcosts[mine][0], rtol=1e-5, atol=0)      # operator<<(double): six digits
+    text = mod.gettraj(run=run, no_collision_check=True)
+    count = int(re.search(r'<data count="(\d+)">', text).group(1))
+    vals = np.array(re.search(r'<data count="\d+">\s*(.*?)\s*</data>', text, re.S).group(1).split(), dtype=float).reshape(count, -1)
+    groups = {m.group(1).split()[0]: (int(m.group(2)), int(m.group(3)), m.group(1))
+              for m in re.finditer(r'<group name="([^"]+)" offset="(\d+)" dof="(\d+)"', text)}
+    na, c0 = len(adofs), (7 if floating else 0)
+    assert count == n_points and groups["joint_values"][:2] == (0, na) and groups["deltatime"][:2] == (na, 1)
+    assert groups["joint_values"][2] == "joint_values %s %s" % (model.name, " ".join(str(d) for d in adofs))
+    assert np.array_equal(vals[:, :na], traj[:, c0:])
+    dt = vals[:, na]
+    want_dt = np.r_[0.0, (np.abs(np.diff(traj[:, c0:], axis=0)) / vmax[adofs]).max(axis=1)]
+    assert np.allclose(dt, want_dt, rtol=1e-12, atol=0)
+    if floating:
+        assert vals.shape[1] == na + 1 + 14 and groups["affine_transform"][:2] == (na + 1, 7)
+        want = oracle.gettraj_affine_groups(traj, dt)
+        assert np.array_equal(vals[:, na + 1:na + 8], want[:, 1:8]) and np.allclose(vals[:, na + 8:], want[:, 8:15], rtol=1e-15, atol=0)
+    else:
+        assert vals.shape[1] == na + 1
+    # and back in: the same length gives the same waypoints, another length the oracle's samples
+    for npts in (n_points, int(rng.integers(3, 80))):
+        if dt.sum() == 0.0:
+            break
+        run2 = mod.create(robot=model.name, starttraj=text, n_points=npts, **({"floating_base": True} if floating else {}))
+        t2 = mod.batch_gettraj(int(run2))[0]
+        mod.destroy(run=run2)
+        if floating:
+            want2 = oracle.sample_starttraj_floating(vals[:, :na], vals[:, na + 1:na + 8], dt, npts)
+        else:
+            want2 = oracle.sample_starttraj(vals[:, :na], dt, npts)
+        assert t2.shape == want2.shape
+        assert np.allclose(t2, want2, rtol=1e-13, atol=1e-14), (seed, what, npts, np.abs(t2 - want2).max())
+        # (sampled at equal steps of time, not at the document's waypoints: the ends are the ends)
+        assert np.allclose(t2[0], traj[0], rtol=1e-12, atol=1e-14) and np.allclose(t2[-1], traj[-1], rtol=1e-12, atol=1e-14)
+    mod.destroy(run=run)
+    print("seed %d (%s; %d of %d dofs, %s, %d points): commands ok" % (seed, what, na, n_dof, "floating" if floating else "fixed", n_points))
