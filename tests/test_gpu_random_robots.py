@@ -147,6 +147,11 @@ def test_random_robot_matches_oracle(oracle, seed):
     mod = or_cdchomp_amd.Module(0)
     mod.add_robot(model, transform=base, dof_values=dofvals, active_dofs=adofs)
     grids, poses = _scene(mod, oracle, which)
+    # the workgroup shapes a caller can ask for (orc_set_workgroup_threads, orc_set_workgroups_per_cu)
+    threads = (0, 0, 192, 512)[int(rng.integers(0, 4))]
+    per_cu = 4 if rng.uniform() < 0.3 and threads == 0 else 0
+    mod.set_workgroup_threads(threads)
+    mod.set_workgroups_per_cu(per_cu)
     goals = rng.uniform(0.7 * lo[adofs], 0.7 * hi[adofs], size=(n_runs, len(adofs)))
     basegoals = None
     if floating:
@@ -166,7 +171,13 @@ def test_random_robot_matches_oracle(oracle, seed):
         print("seed %d (%s): both refuse: %s" % (seed, what, e))
         return
     probe.destroy()
-    bid = mod.batch_create(model.name, goals, basegoals=basegoals, seeds=seeds, precision=precision, **kw)
+    try:
+        bid = mod.batch_create(model.name, goals, basegoals=basegoals, seeds=seeds, precision=precision, **kw)
+    except RuntimeError as e:
+        assert per_cu == 4 and "does not fit four workgroups per CU" in str(e), e
+        mod.set_workgroups_per_cu(0)
+        per_cu = -4
+        bid = mod.batch_create(model.name, goals, basegoals=basegoals, seeds=seeds, precision=precision, **kw)
     seeded = mod.batch_gettraj(bid)
     costs, status = mod.batch_iterate(bid, n_iter)
     traj = mod.batch_gettraj(bid)
@@ -186,7 +197,8 @@ def test_random_robot_matches_oracle(oracle, seed):
     assert errs and max(errs) <= tol, (seed, what, errs)
     print("seed %d (%s; %d of %d dofs active, %s, fp%d, %d points, %s%s): worst rel L2 %.2e" % (
         seed, what, len(adofs), n_dof, "floating" if floating else "fixed", precision, n_points,
-        "%s fields" % which if which != "table" else "table", (", momentum" if momentum else "") + (" + hmc" if hmc else "") + (", derivative 2" if second_order else ""), max(errs)))
+        "%s fields" % which if which != "table" else "table", (", momentum" if momentum else "") + (" + hmc" if hmc else "") + (", derivative 2" if second_order else "")
+        + (", %d threads" % threads if threads else "") + (", four per CU" if per_cu == 4 else (", four per CU refused" if per_cu else "")), max(errs)))
 
 
 @pytest.mark.parametrize("seed", SEEDS[:16] if len(SEEDS) <= 24 else SEEDS)
