@@ -8,7 +8,11 @@
  * Conventions
  *   - all functions return 0 on success, non-zero on error; the message of the
  *     last error of a module is available through orc_last_error() and uses the
- *     reference's own exception strings.
+ *     reference's own exception strings.  1 = the call failed
+ *     (message set), 2 = no module was passed.  A null pointer where an array, a
+ *     name or a struct is required, an unknown handle, a short buffer or a
+ *     malformed robot description is such an error, not a fault; pointers
+ *     documented as optional may be NULL.
  *   - pose = 7 doubles [x y z qx qy qz qw]           (src/libcd/kin.c:42-52)
  *   - grids are C ordered [x][y][z] doubles            (src/libcd/grid.c:31-32)
  *   - trajectories are run-major: traj[run][waypoint][dof]

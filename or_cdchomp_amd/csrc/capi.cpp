@@ -24,6 +24,13 @@ int guarded(orc_module * mod, F f)
    catch (const std::exception & e) { mod->last_error = e.what(); return 1; }
    catch (...) { mod->last_error = "unknown error"; return 1; }
 }
+
+// a C caller's mistakes come back as error codes, never as a fault inside the library
+void need(const void * p, const char * what)
+{
+   if (!p) throw std::runtime_error(std::string("null argument: ") + what);
+}
+const char * str(const char * s, const char * what) { need(s, what); return s; }
 }
 
 extern "C" {
@@ -101,6 +108,21 @@ int orc_last_reply(const orc_module * mod, char * out, size_t out_cap)
 int orc_env_add_robot(orc_module * mod, const char * name, const orc_robot_desc * d)
 {
    return guarded(mod, [&] {
+      need(name, "name"); need(d, "robot description");
+      if (d->n_links < 1 || d->n_dof < 0 || d->n_spheres < 0) throw std::runtime_error("bad robot description: counts!");
+      need(d->parent, "parent"); need(d->pose_parent_joint, "pose_parent_joint"); need(d->joint_type, "joint_type");
+      need(d->axis, "axis"); need(d->dof_index, "dof_index");
+      if (d->n_dof) { need(d->limit_lower, "limit_lower"); need(d->limit_upper, "limit_upper"); }
+      if (d->n_spheres) { need(d->sphere_link, "sphere_link"); need(d->sphere_pos, "sphere_pos"); need(d->sphere_radius, "sphere_radius"); }
+      for (int i=0; i<d->n_links; i++)
+      {
+         const int jt = d->joint_type[i], dof = d->dof_index[i];
+         if (jt < 0 || jt > 2) throw std::runtime_error("bad robot description: joint type (0 fixed, 1 revolute, 2 prismatic)!");
+         if (jt == 0 ? dof != -1 : (dof < 0 || dof >= d->n_dof)) throw std::runtime_error("bad robot description: dof index of a joint!");
+         const double * a = d->axis + 3*i;
+         const double a2 = a[0]*a[0] + a[1]*a[1] + a[2]*a[2];
+         if (jt != 0 && !(a2 > 0.0 && a2 < 1e300)) throw std::runtime_error("bad robot description: joint axis!");
+      }
       orc::Robot r;
       r.name = name;
       r.n_links = d->n_links;
@@ -123,6 +145,7 @@ int orc_env_add_robot(orc_module * mod, const char * name, const orc_robot_desc 
          if (sp.link < 0 || sp.link >= d->n_links) throw std::runtime_error("link in <orcdchomp> does not exist.");
          for (int k=0; k<3; k++) sp.pos[k] = d->sphere_pos[3*s+k];
          sp.radius = d->sphere_radius[s];
+         if (!(sp.radius > 0.0 && sp.radius < 1e300)) throw std::runtime_error("bad robot description: sphere radius!");
          r.spheres.push_back(sp);
       }
       r.dof_values.assign(d->n_dof, 0.0);
@@ -133,14 +156,15 @@ int orc_env_add_robot(orc_module * mod, const char * name, const orc_robot_desc 
 
 int orc_robot_set_transform(orc_module * mod, const char * name, const double pose[7])
 {
-   return guarded(mod, [&] { mod->impl->robot(name).transform = orc::Pose(pose); });
+   return guarded(mod, [&] { need(pose, "pose"); mod->impl->robot(str(name, "name")).transform = orc::Pose(pose); });
 }
 
 int orc_robot_set_dof_values(orc_module * mod, const char * name, const double * values, int n)
 {
    return guarded(mod, [&] {
-      orc::Robot & r = mod->impl->robot(name);
+      orc::Robot & r = mod->impl->robot(str(name, "name"));
       if (n != r.n_dof) throw std::runtime_error("wrong number of dof values!");
+      if (n) need(values, "values");
       r.dof_values.assign(values, values + n);
    });
 }
@@ -148,7 +172,9 @@ int orc_robot_set_dof_values(orc_module * mod, const char * name, const double *
 int orc_robot_set_active_dofs(orc_module * mod, const char * name, const int * indices, int n)
 {
    return guarded(mod, [&] {
-      orc::Robot & r = mod->impl->robot(name);
+      orc::Robot & r = mod->impl->robot(str(name, "name"));
+      if (n < 0) throw std::runtime_error("bad dof index!");
+      if (n) need(indices, "indices");
       for (int i=0; i<n; i++) if (indices[i] < 0 || indices[i] >= r.n_dof) throw std::runtime_error("bad dof index!");
       r.active_dofs.assign(indices, indices + n);
    });
@@ -157,8 +183,9 @@ int orc_robot_set_active_dofs(orc_module * mod, const char * name, const int * i
 int orc_robot_set_velocity_limits(orc_module * mod, const char * name, const double * limits, int n)
 {
    return guarded(mod, [&] {
-      orc::Robot & r = mod->impl->robot(name);
+      orc::Robot & r = mod->impl->robot(str(name, "name"));
       if (n != r.n_dof) throw std::runtime_error("wrong number of velocity limits!");
+      if (n) need(limits, "limits");
       r.limit_vel.assign(limits, limits + n);
    });
 }
@@ -183,8 +210,10 @@ int orc_set_workgroups_per_cu(orc_module * mod, int workgroups)
 int orc_robot_set_link_names(orc_module * mod, const char * name, const char * const * names, int n)
 {
    return guarded(mod, [&] {
-      orc::Robot & r = mod->impl->robot(name);
+      orc::Robot & r = mod->impl->robot(str(name, "name"));
       if (n != r.n_links) throw std::runtime_error("wrong number of link names!");
+      need(names, "names");
+      for (int i=0; i<n; i++) need(names[i], "a link name");
       r.link_names.assign(names, names + n);
    });
 }
@@ -192,10 +221,10 @@ int orc_robot_set_link_names(orc_module * mod, const char * name, const char * c
 int orc_robot_add_manipulator(orc_module * mod, const char * name, const char * manip, int ee_link, const double tool_pose[7])
 {
    return guarded(mod, [&] {
-      orc::Robot & r = mod->impl->robot(name);
+      orc::Robot & r = mod->impl->robot(str(name, "name"));
       if (ee_link < 0 || ee_link >= r.n_links) throw std::runtime_error("manipulator end-effector link out of range!");
       orc::Robot::Manip m;
-      m.name = manip; m.link = ee_link;
+      m.name = str(manip, "manipulator name"); m.link = ee_link;
       if (tool_pose) m.tool = orc::Pose(tool_pose);
       r.manips.push_back(m);
    });
@@ -204,7 +233,7 @@ int orc_robot_add_manipulator(orc_module * mod, const char * name, const char * 
 int orc_robot_set_adjacent_links(orc_module * mod, const char * name, const int * link_pairs, int n_pairs)
 {
    return guarded(mod, [&] {
-      orc::Robot & r = mod->impl->robot(name);
+      orc::Robot & r = mod->impl->robot(str(name, "name"));
       if (n_pairs < 0 || (n_pairs > 0 && !link_pairs)) throw std::runtime_error("bad adjacent link list!");
       r.adjacent.clear();
       for (int k=0; k<n_pairs; k++)
@@ -219,9 +248,9 @@ int orc_robot_set_adjacent_links(orc_module * mod, const char * name, const int 
 int orc_robot_set_active_manipulator(orc_module * mod, const char * name, const char * manip)
 {
    return guarded(mod, [&] {
-      orc::Robot & r = mod->impl->robot(name);
+      orc::Robot & r = mod->impl->robot(str(name, "name"));
       for (size_t k=0; k<r.manips.size(); k++)
-         if (r.manips[k].name == manip) { r.active_manip = (int) k; return; }
+         if (r.manips[k].name == str(manip, "manipulator name")) { r.active_manip = (int) k; return; }
       throw std::runtime_error("manipulator not found!");
    });
 }
@@ -229,6 +258,9 @@ int orc_robot_set_active_manipulator(orc_module * mod, const char * name, const 
 int orc_env_add_kinbody_boxes(orc_module * mod, const char * name, int n_boxes, const double * box_poses, const double * half_extents)
 {
    return guarded(mod, [&] {
+      need(name, "name");
+      if (n_boxes < 0) throw std::runtime_error("bad number of boxes!");
+      if (n_boxes) { need(box_poses, "box_poses"); need(half_extents, "half_extents"); }
       orc::KinBody k;
       k.name = name;
       for (int i=0; i<n_boxes; i++)
@@ -244,19 +276,21 @@ int orc_env_add_kinbody_boxes(orc_module * mod, const char * name, int n_boxes, 
 
 int orc_kinbody_set_transform(orc_module * mod, const char * name, const double pose[7])
 {
-   return guarded(mod, [&] { mod->impl->kinbody(name).transform = orc::Pose(pose); });
+   return guarded(mod, [&] { need(pose, "pose"); mod->impl->kinbody(str(name, "name")).transform = orc::Pose(pose); });
 }
 
 int orc_kinbody_enable(orc_module * mod, const char * name, int enabled)
 {
-   return guarded(mod, [&] { mod->impl->kinbody(name).enabled = enabled != 0; });
+   return guarded(mod, [&] { mod->impl->kinbody(str(name, "name")).enabled = enabled != 0; });
 }
 
 int orc_scene_add_sdf(orc_module * mod, const char * kinbody, const int sizes[3], const double lengths[3],
    const double pose[7], const double * data)
 {
    return guarded(mod, [&] {
+      need(kinbody, "kinbody"); need(sizes, "sizes"); need(lengths, "lengths"); need(pose, "pose"); need(data, "data");
       if (!mod->impl->has_body(kinbody)) throw std::runtime_error("Could not find kinbody with that name!");
+      for (int i=0; i<3; i++) if (sizes[i] < 2 || !(lengths[i] > 0.0)) throw std::runtime_error("sdf grids need at least 2 cells per dimension and positive lengths!");
       orc::Grid g;
       for (int i=0; i<3; i++) { g.sizes[i] = sizes[i]; g.lengths[i] = lengths[i]; }
       g.data.assign(data, data + g.ncells());
@@ -268,6 +302,7 @@ int orc_scene_get_sdf(orc_module * mod, const char * kinbody, int sizes[3], doub
    double * data, size_t data_cap)
 {
    return guarded(mod, [&] {
+      need(kinbody, "kinbody"); need(sizes, "sizes"); need(lengths, "lengths"); need(pose, "pose");
       orc::Sdf * s = mod->impl->find_sdf(kinbody);
       if (!s) throw std::runtime_error("No sdf for that kinbody!");
       for (int i=0; i<3; i++) { sizes[i] = s->grid.sizes[i]; lengths[i] = s->grid.lengths[i]; }
@@ -282,6 +317,7 @@ int orc_scene_get_sdf(orc_module * mod, const char * kinbody, int sizes[3], doub
 
 void orc_batch_params_default(orc_batch_params * p)
 {
+   if (!p) return;
    orc::BatchParams d;
    p->n_points = d.n_points; p->floating_base = d.floating_base; p->lambda = d.lambda;
    p->derivative = d.derivative; p->use_momentum = d.use_momentum; p->use_hmc = d.use_hmc;
@@ -293,6 +329,7 @@ int orc_batch_create(orc_module * mod, const char * robot, const orc_batch_param
    const double * starts, const double * goals, const double * basegoals, const unsigned int * seeds, int * batch_id)
 {
    return guarded(mod, [&] {
+      need(robot, "robot"); need(p, "params"); need(batch_id, "batch_id");
       orc::BatchParams q;
       q.n_points = p->n_points; q.floating_base = p->floating_base; q.lambda = p->lambda;
       q.derivative = p->derivative; q.use_momentum = p->use_momentum; q.use_hmc = p->use_hmc;
@@ -338,6 +375,7 @@ int orc_batch_get_trace(orc_module * mod, int id, double * out, size_t cap)
 {
    return guarded(mod, [&] {
       orc::Batch & b = mod->impl->batch(id);
+      need(out, "out");
       if (cap < (size_t) b.n_runs * b.last_n_iter * 3) throw std::runtime_error("buffer too small!");
       b.get_trace(out);
    });
@@ -345,13 +383,17 @@ int orc_batch_get_trace(orc_module * mod, int id, double * out, size_t cap)
 
 int orc_batch_set_noise(orc_module * mod, int id, const double * noise, int n_blocks)
 {
-   return guarded(mod, [&] { mod->impl->batch(id).set_noise(noise, n_blocks); });
+   return guarded(mod, [&] {
+      if (n_blocks < 0 || (n_blocks > 0 && !noise)) throw std::runtime_error("bad noise blocks!");
+      mod->impl->batch(id).set_noise(noise, n_blocks);
+   });
 }
 
 int orc_batch_gettraj(orc_module * mod, int id, double * out, size_t cap)
 {
    return guarded(mod, [&] {
       orc::Batch & b = mod->impl->batch(id);
+      need(out, "out");
       if (cap < (size_t) b.n_runs * b.n_points * b.n) throw std::runtime_error("buffer too small!");
       b.gettraj(out);
    });
@@ -360,13 +402,17 @@ int orc_batch_gettraj(orc_module * mod, int id, double * out, size_t cap)
 int orc_batch_collision_verdict(orc_module * mod, int id, int * collides_out, double * time_out, int * sphere_out,
    int * field_out, double * depth_out)
 {
-   return guarded(mod, [&] { mod->impl->batch_collision_verdict(id, collides_out, time_out, sphere_out, field_out, depth_out); });
+   return guarded(mod, [&] {
+      need(collides_out, "collides_out");
+      mod->impl->batch_collision_verdict(id, collides_out, time_out, sphere_out, field_out, depth_out);
+   });
 }
 
 int orc_batch_get_state(orc_module * mod, int id, const char * which, double * out, size_t cap)
 {
    return guarded(mod, [&] {
       orc::Batch & b = mod->impl->batch(id);
+      need(which, "which"); need(out, "out");
       if (std::string(which) == "phase")
       {
          if (cap < (size_t) b.n_runs * 8) throw std::runtime_error("buffer too small!");
@@ -394,6 +440,7 @@ int orc_batch_set_traj(orc_module * mod, int id, const double * traj, size_t cou
 {
    return guarded(mod, [&] {
       orc::Batch & b = mod->impl->batch(id);
+      need(traj, "traj");
       if (count != (size_t) b.n_runs * b.n_points * b.n) throw std::runtime_error("wrong trajectory size!");
       b.set_traj(traj);
    });
