@@ -188,6 +188,8 @@ void BatchShard::construct(const Robot & robot, const double * starts, const dou
    adofindices = robot.active_dofs;
    if (n > ORC_MAX_JOINTS + 7) throw std::runtime_error("too many optimizer dofs for this build!");
    if (m < 1) throw std::runtime_error("n_points must be >=3!");
+   if (m > ORC_MAX_POINTS) throw std::runtime_error("n_points is beyond what this build plans for (at most " + std::to_string(ORC_MAX_POINTS + 2) + ")!");
+   if ((double) n_runs * n_points * n * 8.0 > 64e9) throw std::runtime_error("the batch's trajectories exceed 64 GB!");
 
    // joint limits (mod.cpp:2639-2660)
    jl_lo_.assign(n, -HUGE_VAL); jl_hi_.assign(n, HUGE_VAL);

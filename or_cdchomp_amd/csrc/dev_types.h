@@ -8,6 +8,7 @@
 
 #define ORC_MAX_JOINTS   32      // active (optimized) joints of one robot
 #define ORC_MAX_SPHERES  64      // spheres of one robot (active + inactive)
+#define ORC_MAX_POINTS   4096    // moving waypoints of one run (the dense m x m matrices of the metric are built on the host at create)
 #define ORC_MAX_SAVE     4       // saved frames while walking a kinematic tree
 #define ORC_MAX_SDFS     8
 #define ORC_BLOCK        256     // threads per workgroup: one workgroup per run

@@ -361,6 +361,7 @@ void invert_dense(std::vector<double> & Mx, int n)
 void build_metric(int m, int D, double dt, Metric & out, bool free_start)
 {
    if (D < 1) throw std::runtime_error("derivative must be >=1!");
+   if (D > 16) throw std::runtime_error("derivative is beyond what this build plans for (at most 16)!");
    out.m = m; out.D = D;
    // K_d (N_d x m) and the endpoint coefficient vectors es_d, eg_d (N_d) with
    // E_d = es_d (x) start + eg_d (x) goal
