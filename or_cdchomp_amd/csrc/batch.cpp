@@ -896,7 +896,7 @@ void BatchShard::build_device(const Robot & robot)
    // workgroups per CU (three tiles instead of two for the WAM): +3 % when launches overlap, -3 % one launch at a time
    const int want_wgs = mod_->workgroups_per_cu ? mod_->workgroups_per_cu : params.workgroups_per_cu;
    const bool budget4 = (want_wgs == 4) && sizeof(real) == 8 && (tree_ & 16) && (tree_ & 2) && !(tree_ & 64) && (force_block == 0 || force_block == 256)
-                        && !getenv("ORC_BLOCK_THREADS");
+                        && !getenv("ORC_BLOCK_THREADS") && !getenv("ORC_WGS") && !getenv("ORC_TILE_M");      // (the experiments' switches come first)
    if (budget4) { max_wgs = 4; force_block = 256; }
    if (const char * e = getenv("ORC_BLOCK_THREADS")) force_block = atoi(e);
    int force_g = -1, force_tl = -1;
