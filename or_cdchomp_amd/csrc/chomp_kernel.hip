@@ -840,6 +840,20 @@ __device__ __forceinline__ real smooth_grad(const BT & b, const real * T_s, int 
    if (D == 1)       // tridiagonal Toeplitz: the end rows couple to the fixed endpoints with a_off
       return b.a_diag * T_s[(i+1)*n + c] + b.a_off * (T_s[i*n + c] + T_s[(i+2)*n + c]);
    D = (D < 0) ? -D : D;      // (-1: tridiagonal without a start boundary, DevBatch::D)
+   if (sizeof(real) == 4 && b.metric64)
+   {
+      // fp32 and a higher derivative: the band's entries are ~1/dt^4 (1e7 for 200 waypoints) and the row's sum is of order
+      // one to a hundred: summed in fp32 the rounding alone is of that order.  Taken in double from the band in double.
+      const double * A64 = b.metric64, * bs64 = A64 + (size_t)(2*D + 1) * m, * bg64 = bs64 + m;
+      double s = bs64[i] * (double) T_s[c] + bg64[i] * (double) T_s[(b.n_points-1)*n + c];
+      for (int k=-D; k<=D; k++)
+      {
+         const int r = i + k;
+         if (r < 0 || r >= m) continue;
+         s += A64[(size_t)(k+D) * m + i] * (double) T_s[(r+1)*n + c];
+      }
+      return (real) s;
+   }
    real s = b.beta_s[i] * T_s[c] + b.beta_g[i] * T_s[(b.n_points-1)*n + c];
    for (int k=-D; k<=D; k++)
    {

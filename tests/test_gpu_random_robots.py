@@ -128,7 +128,7 @@ def test_random_robot_matches_oracle(oracle, seed):
     hmc = momentum and bool(rng.uniform() < 0.4)
     long_traj = bool(rng.uniform() < 0.1)                 # several tiles of waypoints
     tol = 1e-3 if precision == 32 else 1e-6
-    n_runs = 3
+    n_runs = (3, 3, 3, 40, 300)[int(rng.integers(0, 5))]           # 256 runs and more: the hmc streams live on the device
     n_points = int(rng.integers(100, 230)) if long_traj else int(rng.integers(5, 72))
     n_iter = int(rng.integers(6, 16))
     kw = dict(n_points=n_points, lambda_=float(rng.uniform(120.0, 400.0)), obs_factor=float(rng.uniform(20.0, 200.0)),
@@ -156,6 +156,8 @@ def test_random_robot_matches_oracle(oracle, seed):
     basegoals = None
     if floating:
         basegoals = np.tile(np.asarray(base), (n_runs, 1)); basegoals[:, :3] += rng.uniform(-0.2, 0.2, size=(n_runs, 3))
+    desc = "%s; %d runs, %d of %d dofs active, %s, fp%d, %s, %d iterations, %d threads, per_cu %d, %s" % (
+        what, n_runs, len(adofs), n_dof, "floating" if floating else "fixed", precision, which, n_iter, threads, per_cu, kw)
     rob = oracle.OraRobot(model)
     okw = dict(kw)
     if "derivative" in okw:
@@ -183,7 +185,7 @@ def test_random_robot_matches_oracle(oracle, seed):
     traj = mod.batch_gettraj(bid)
     mod.batch_destroy(bid)
     errs = []
-    for k in range(n_runs):
+    for k in sorted(set([0, n_runs // 2, n_runs - 1, 1 % n_runs, (n_runs * 3) // 4])):      # (all of three, a sample of a larger batch)
         run = oracle.OraRun(rob, base, dofvals, adofs, goals[k], grids, poses, oracle.default_params(seed=int(seeds[k]), **okw),
                             basegoal=None if basegoals is None else basegoals[k])
         if precision == 64:
@@ -194,9 +196,9 @@ def test_random_robot_matches_oracle(oracle, seed):
             errs.append(common.rel_l2(traj[k], run.traj()))
             assert np.allclose(costs[k], ocosts, rtol=tol * (100 if precision == 32 else 1), atol=1e-12), (seed, what, costs[k], ocosts)
         run.destroy()
-    assert errs and max(errs) <= tol, (seed, what, errs)
-    print("seed %d (%s; %d of %d dofs active, %s, fp%d, %d points, %s%s): worst rel L2 %.2e" % (
-        seed, what, len(adofs), n_dof, "floating" if floating else "fixed", precision, n_points,
+    assert errs and max(errs) <= tol, (seed, desc, errs)
+    print("seed %d (%s; %d runs, %d of %d dofs active, %s, fp%d, %d points, %s%s): worst rel L2 %.2e" % (
+        seed, what, n_runs, len(adofs), n_dof, "floating" if floating else "fixed", precision, n_points,
         "%s fields" % which if which != "table" else "table", (", momentum" if momentum else "") + (" + hmc" if hmc else "") + (", derivative 2" if second_order else "")
         + (", %d threads" % threads if threads else "") + (", four per CU" if per_cu == 4 else (", four per CU refused" if per_cu else "")), max(errs)))
 
