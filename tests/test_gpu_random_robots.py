@@ -151,13 +151,17 @@ def test_random_robot_matches_oracle(oracle, seed):
     threads = (0, 0, 192, 512)[int(rng.integers(0, 4))]
     per_cu = 4 if rng.uniform() < 0.3 and threads == 0 else 0
     mod.set_workgroup_threads(threads)
+    if rng.uniform() < 0.2:
+        mod.set_num_streams(2)                             # launches of one module on two streams: nothing a run can see
     mod.set_workgroups_per_cu(per_cu)
     goals = rng.uniform(0.7 * lo[adofs], 0.7 * hi[adofs], size=(n_runs, len(adofs)))
     basegoals = None
     if floating:
         basegoals = np.tile(np.asarray(base), (n_runs, 1)); basegoals[:, :3] += rng.uniform(-0.2, 0.2, size=(n_runs, 3))
+    # one call, or two (the run's iteration counter restarts, the next resampling iteration is kept: src/orcdchomp_mod.cpp:2752)
+    calls = [n_iter] if rng.uniform() < 0.7 or n_iter < 4 else [n_iter // 2, n_iter - n_iter // 2]
     desc = "%s; %d runs, %d of %d dofs active, %s, fp%d, %s, %d iterations, %d threads, per_cu %d, %s" % (
-        what, n_runs, len(adofs), n_dof, "floating" if floating else "fixed", precision, which, n_iter, threads, per_cu, kw)
+        what, n_runs, len(adofs), n_dof, "floating" if floating else "fixed", precision, which, n_iter, threads, per_cu, dict(kw, calls=calls))
     rob = oracle.OraRobot(model)
     okw = dict(kw)
     if "derivative" in okw:
@@ -181,7 +185,11 @@ def test_random_robot_matches_oracle(oracle, seed):
         per_cu = -4
         bid = mod.batch_create(model.name, goals, basegoals=basegoals, seeds=seeds, precision=precision, **kw)
     seeded = mod.batch_gettraj(bid)
-    costs, status = mod.batch_iterate(bid, n_iter)
+    traces = []
+    for n_call in calls:
+        costs, status = mod.batch_iterate(bid, n_call)
+        traces.append(mod.batch_trace(bid, n_call))
+    trace = np.concatenate(traces, axis=1)
     traj = mod.batch_gettraj(bid)
     mod.batch_destroy(bid)
     errs = []
@@ -190,11 +198,19 @@ def test_random_robot_matches_oracle(oracle, seed):
                             basegoal=None if basegoals is None else basegoals[k])
         if precision == 64:
             assert np.array_equal(seeded[k], run.traj())
-        st, ocosts = run.iterate(n_iter)
-        assert st == status[k], (seed, what, k, st, status[k])
+        otrace = []
+        for n_call in calls:
+            st, ocosts, otr = run.iterate(n_call, trace=True)
+            otrace.append(otr)
+            if st != 0:
+                break
+        otrace = np.concatenate(otrace, axis=0)
+        assert st == status[k], (seed, desc, k, st, status[k])
         if st == 0:
             errs.append(common.rel_l2(traj[k], run.traj()))
-            assert np.allclose(costs[k], ocosts, rtol=tol * (100 if precision == 32 else 1), atol=1e-12), (seed, what, costs[k], ocosts)
+            assert np.allclose(costs[k], ocosts, rtol=tol * (100 if precision == 32 else 1), atol=1e-12), (seed, desc, costs[k], ocosts)
+            # the costs of every iteration (what `dat_filename` logs, src/orcdchomp_mod.cpp:2815-2818)
+            assert np.allclose(trace[k], otrace, rtol=tol * (100 if precision == 32 else 1), atol=1e-12), (seed, desc, k)
         run.destroy()
     assert errs and max(errs) <= tol, (seed, desc, errs)
     print("seed %d (%s; %d runs, %d of %d dofs active, %s, fp%d, %d points, %s%s): worst rel L2 %.2e" % (
