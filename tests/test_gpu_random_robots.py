@@ -144,7 +144,10 @@ def test_random_robot_matches_oracle(oracle, seed):
     seeds = rng.integers(0, 1000, size=n_runs).astype(np.uint32)
     if floating:
         kw["floating_base"] = 1
-    mod = or_cdchomp_amd.Module(0)
+    # now and then the batch is cut over several "devices" inside the process (contiguous blocks, host-side
+    # gather; here the one card two or three times, uneven blocks included)
+    shards = int(rng.integers(2, 4)) if rng.uniform() < 0.15 else 1
+    mod = or_cdchomp_amd.Module([0] * shards if shards > 1 else 0)
     mod.add_robot(model, transform=base, dof_values=dofvals, active_dofs=adofs)
     grids, poses = _scene(mod, oracle, which)
     # the workgroup shapes a caller can ask for (orc_set_workgroup_threads, orc_set_workgroups_per_cu)
@@ -161,7 +164,7 @@ def test_random_robot_matches_oracle(oracle, seed):
     # one call, or two (the run's iteration counter restarts, the next resampling iteration is kept: src/orcdchomp_mod.cpp:2752)
     calls = [n_iter] if rng.uniform() < 0.7 or n_iter < 4 else [n_iter // 2, n_iter - n_iter // 2]
     desc = "%s; %d runs, %d of %d dofs active, %s, fp%d, %s, %d iterations, %d threads, per_cu %d, %s" % (
-        what, n_runs, len(adofs), n_dof, "floating" if floating else "fixed", precision, which, n_iter, threads, per_cu, dict(kw, calls=calls))
+        what, n_runs, len(adofs), n_dof, "floating" if floating else "fixed", precision, which, n_iter, threads, per_cu, dict(kw, calls=calls, shards=shards))
     rob = oracle.OraRobot(model)
     okw = dict(kw)
     if "derivative" in okw:
