@@ -305,6 +305,9 @@ def test_random_robot_tsr_constraint_matches_oracle(oracle, seed):
         cur = model.parent[cur]
     k = int(rng.integers(1, 1 + min(3, max(1, n_anc // 2))))
     floating = bool(rng.uniform() < 0.2)
+    # the constraint on every moving point, the start point itself a variable held on a TSR (`start_tsr`,
+    # src/orcdchomp_mod.cpp:1988-1992, 2316-2323, 2570-2576: not together with a floating base), or both
+    variant = "con" if floating else ("con", "con", "con", "start", "start+con")[int(rng.integers(0, 5))]
     momentum = bool(rng.uniform() < 0.3)
     n_runs = 3
     n_points = int(rng.integers(100, 210)) if rng.uniform() < 0.15 else int(rng.integers(5, 70))
@@ -319,20 +322,41 @@ def test_random_robot_tsr_constraint_matches_oracle(oracle, seed):
     goals = np.ascontiguousarray(np.clip(goals, lo, hi))
     # rows the link's joints can actually move: a row whose Jacobian is rounding noise (the y of a point on its own
     # joint's axis) makes the step a quotient of two such numbers, in the reference as here
-    for attempt in range(12):
-        rows = sorted(rng.choice(6, size=k, replace=False).tolist())
-        Bw = [[0, 0] if r in rows else ([-1, 1] if r < 3 else [-3, 3]) for r in range(6)]
-        probe = oracle.OraRun(rob, base, dofvals, adofs, goals[0], grids, poses, oracle.default_params(n_points=9))
-        probe.add_contsr(li, [0, 0, 0, 0, 0, 0, 1], oracle.pose_from_dR(t[li], R[li]), [0, 0, 0, 0, 0, 0, 1], Bw)
-        smin = min(np.linalg.svd(probe.eval_contsr(0, probe.traj()[i])[1], compute_uv=False).min() for i in range(1, 8))
-        probe.destroy()
-        if smin > 0.02:
-            break
-    else:
+    def bw_of(rows):
+        return [[0, 0] if r in rows else ([-1, 1] if r < 3 else [-3, 3]) for r in range(6)]
+
+    def draw_rows(points, count, among=range(6), together_with=()):
+        """`count` rows out of `among` whose Jacobian, stacked on that of the rows `together_with`, has full rank at `points`"""
+        for attempt in range(12):
+            rows = sorted(rng.choice(list(among), size=count, replace=False).tolist())
+            probe = oracle.OraRun(rob, base, dofvals, adofs, goals[0], grids, poses, oracle.default_params(n_points=9))
+            probe.add_contsr(li, [0, 0, 0, 0, 0, 0, 1], oracle.pose_from_dR(t[li], R[li]), [0, 0, 0, 0, 0, 0, 1], bw_of(sorted(set(rows) | set(together_with))))
+            smin = min(np.linalg.svd(probe.eval_contsr(0, probe.traj()[i])[1], compute_uv=False).min() for i in points)
+            probe.destroy()
+            if smin > 0.02:
+                return rows, bw_of(rows)
         pytest.skip("no well-posed rows found for the last link of this draw")
+    rows, Bw = draw_rows(range(1, 8), k)
+    rows_s, Bw_s = None, None
+    if variant == "start":
+        rows_s, Bw_s = draw_rows([0], k)
+    elif variant == "start+con":
+        # the start point carries both constraints: other rows than the constraint of every point holds, or the reference's
+        # system has the same row twice (singular to rounding: dgesv's answer is noise there, and so is everybody's)
+        if 2 * k > n_anc:
+            k = max(1, n_anc // 2); rows, Bw = draw_rows(range(1, 8), k)
+        free = [r for r in range(6) if r not in rows]
+        ks = int(rng.integers(1, 1 + max(1, min(len(free), n_anc - k, 3))))
+        rows_s, Bw_s = draw_rows([0], ks, among=free, together_with=rows)
     tsr = robots.Tsr(T0w_R=R[li], T0w_d=t[li], Bw=Bw)
-    cmd = "createbatch robot %s n_runs %d adofgoals 0x%x n_points %d lambda %.17g obs_factor 100 con_tsr 'all link %s' '%s'" % (
-        model.name, n_runs, goals.ctypes.data, n_points, lam, link, tsr.serialize())
+    cmd = "createbatch robot %s n_runs %d adofgoals 0x%x n_points %d lambda %.17g obs_factor 100" % (
+        model.name, n_runs, goals.ctypes.data, n_points, lam)
+    if variant != "start":
+        cmd += " con_tsr 'all link %s' '%s'" % (link, tsr.serialize())
+    if variant != "con":
+        # `start_tsr` speaks of the active manipulator's end effector: the last link, no tool offset
+        mod.add_manipulator(model.name, "tip", li)
+        cmd += " start_tsr '%s'" % robots.Tsr(T0w_R=R[li], T0w_d=t[li], Bw=Bw_s).serialize()
     basegoals = None
     if floating:
         basegoals = np.tile(np.asarray(base), (n_runs, 1)); basegoals[:, :3] += rng.uniform(-0.15, 0.15, size=(n_runs, 3))
@@ -340,7 +364,9 @@ def test_random_robot_tsr_constraint_matches_oracle(oracle, seed):
     if momentum:
         cmd += " use_momentum"
     bid = int(mod.SendCommand(cmd))
+    seeded = mod.batch_gettraj(bid)
     costs, status = mod.batch_iterate(bid, n_iter)
+    ptrace = mod.batch_trace(bid, n_iter)
     traj = mod.batch_gettraj(bid)
     mod.batch_destroy(bid)
     okw = dict(n_points=n_points, lambda_=lam, obs_factor=100.0)
@@ -350,23 +376,31 @@ def test_random_robot_tsr_constraint_matches_oracle(oracle, seed):
         okw["use_momentum"] = 1
     errs = []
     for r in range(n_runs):
-        run = oracle.OraRun(rob, base, dofvals, adofs, goals[r], grids, poses, oracle.default_params(**okw),
+        st_arg = None if variant == "con" else (li, [0, 0, 0, 0, 0, 0, 1], oracle.pose_from_dR(t[li], R[li]), [0, 0, 0, 0, 0, 0, 1], Bw_s)
+        run = oracle.OraRun(rob, base, dofvals, adofs, goals[r], grids, poses, oracle.default_params(start_tsr=st_arg, **okw),
                             basegoal=None if basegoals is None else basegoals[r])
-        assert run.add_contsr(li, [0, 0, 0, 0, 0, 0, 1], oracle.pose_from_dR(t[li], R[li]), [0, 0, 0, 0, 0, 0, 1], Bw) == k
-        st, oc = run.iterate(n_iter)
+        if variant != "start":
+            assert run.add_contsr(li, [0, 0, 0, 0, 0, 0, 1], oracle.pose_from_dR(t[li], R[li]), [0, 0, 0, 0, 0, 0, 1], Bw) == k
+        assert np.array_equal(seeded[r], run.traj()), (seed, what, variant)
+        st, oc, otr = run.iterate(n_iter, trace=True)
         ot = run.traj().copy()
         run.destroy()
+        # where the two part company, if they do: at once is a mistake, late and growing is the run's own conditioning
+        rel = np.abs(ptrace[r] - otr).max(axis=1) / np.maximum(np.abs(otr).max(axis=1), 1e-300)
+        part = "first iteration with costs apart by 1e-9: %s of %d; rel per iteration %s" % (
+            (np.where(rel > 1e-9)[0][:1].tolist() or ["none"])[0], n_iter, np.array2string(rel, precision=1))
         if st != 0 or not np.all(np.isfinite(ot)):
-            assert status[r] != 0 or not np.all(np.isfinite(traj[r])), (seed, what, r, st, status[r])
+            assert status[r] != 0 or not np.all(np.isfinite(traj[r])), (seed, what, variant, r, st, status[r], part)
             continue
-        assert status[r] == 0, (seed, what, r, status[r])
+        assert status[r] == 0, (seed, what, variant, r, status[r], part)
         errs.append(common.rel_l2(traj[r], ot))
-        assert np.allclose(costs[r], oc, rtol=1e-6, atol=1e-12), (seed, what, r, costs[r], oc)
+        assert np.allclose(costs[r], oc, rtol=1e-6, atol=1e-12), (seed, what, variant, rows, rows_s, r, costs[r], oc, part)
     if not errs:
         pytest.skip("the constraint of this draw is singular for the oracle as well")
     assert max(errs) <= 1e-6, (seed, what, rows, errs)
-    print("seed %d (%s, %s%s, %d points, rows %s of link %s behind %d joints): worst rel L2 %.2e" % (
-        seed, what, "floating" if floating else "fixed", ", momentum" if momentum else "", n_points, rows, link, n_anc, max(errs)))
+    print("seed %d (%s, %s%s, %d points, %s, rows %s%s of link %s behind %d joints): worst rel L2 %.2e" % (
+        seed, what, "floating" if floating else "fixed", ", momentum" if momentum else "", n_points, variant, rows if variant != "start" else "",
+        " start rows %s" % rows_s if rows_s else "", link, n_anc, max(errs)))
 
 
 @pytest.mark.parametrize("seed", SEEDS[:12] if len(SEEDS) <= 24 else SEEDS)
