@@ -416,3 +416,39 @@ def test_con_tsr_on_a_link_no_active_joint_moves(oracle):
         assert np.allclose(costs[k], oc, rtol=1e-6, atol=0)
         assert common.rel_l2(traj[k], traj_free[k]) <= 1e-9          # and that is the unconstrained run
         run.destroy()
+
+
+def test_the_same_con_tsr_twice(oracle):
+    """the same constraint passed twice: J Ainv J^T has every row twice, the elimination meets an exactly zero pivot, the
+    reference's dgesv reports "constraint inversion error!" and leaves h as it is (src/libcd/chomp.c:579-590; dgetrs is
+    never called), and h -- the constraint values, not multipliers -- goes through J^T and Ainv to the trajectory.
+    Deterministic nonsense, and the same nonsense here: the structured elimination hands over to the dense path."""
+    O = oracle
+    base = _unit_base()
+    mod = or_cdchomp_amd.Module(0)
+    model, dofvals, adofs = _setup(mod, base)
+    Ree, tee, li = _start_frame(O, model, base, dofvals, "wam7", [0, 0, 0, 0, 0, 0, 1])
+    Bw = [[-1, 1], [-1, 1], [0, 0], [-3, 3], [-3, 3], [-3, 3]]
+    tsr = robots.Tsr(T0w_R=Ree, T0w_d=tee, Bw=Bw)
+    n_runs, n_points, n_iter = 3, 24, 4
+    goals = _near_goals(n_runs, 5, spread=0.2)
+    bid = int(mod.SendCommand("createbatch robot %s n_runs %d adofgoals 0x%x n_points %d lambda 100 obs_factor 200 "
+                              "con_tsr 'all link wam7' '%s' con_tsr 'all link wam7' '%s'"
+                              % (model.name, n_runs, goals.ctypes.data, n_points, tsr.serialize(), tsr.serialize())))
+    costs, status = mod.batch_iterate(bid, n_iter)
+    traj = mod.batch_gettraj(bid)
+    mod.batch_destroy(bid)
+    prob = common.tabletop_problem(O)
+    rob = O.OraRobot(model)
+    T0w = O.pose_from_dR(tee, Ree)
+    for k in range(n_runs):
+        run = O.OraRun(rob, base, dofvals, adofs, goals[k], [prob["sdf"]], [prob["pose"]],
+                       O.default_params(n_points=n_points, lambda_=100.0, obs_factor=200.0))
+        run.add_contsr(li, [0, 0, 0, 0, 0, 0, 1], T0w, [0, 0, 0, 0, 0, 0, 1], Bw)
+        run.add_contsr(li, [0, 0, 0, 0, 0, 0, 1], T0w, [0, 0, 0, 0, 0, 0, 1], Bw)
+        st, oc = run.iterate(n_iter)
+        assert st == status[k]
+        assert np.all(np.isfinite(traj[k])) and np.all(np.isfinite(run.traj()))
+        assert common.rel_l2(traj[k], run.traj()) <= 1e-6, common.rel_l2(traj[k], run.traj())
+        assert np.allclose(costs[k], oc, rtol=1e-6, atol=0)
+        run.destroy()
