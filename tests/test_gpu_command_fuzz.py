@@ -90,6 +90,8 @@ def test_random_command_text_never_faults(tmp_path):
             replies += 1
             if toks[0] == "create" and out.strip().isdigit():
                 runs.append(out.strip())
+                while len(runs) > 48:                      # (live runs hold device memory: a bounded number of them)
+                    mod.SendCommand("destroy run %s" % runs.pop(0))
             if toks[0] == "destroy" and toks[2] in runs:
                 runs.remove(toks[2])
         except RuntimeError as e:
