@@ -113,8 +113,8 @@ int orc_robot_set_velocity_limits(orc_module * mod, const char * name, const dou
 int orc_set_workgroup_threads(orc_module * mod, int threads);
 /* Register budget of the batches created from now on: 0 (default) the kernels' own (three 256-thread workgroups per CU
  * at 168 registers for fp64), 4: four per CU at 128 registers with smaller tiles, where a kernel is built for it (fp64
- * robots of at most 16 active spheres on a fixed-base chain: the WAM of the BASELINE configurations; others keep
- * their default).  A caller whose launches overlap (orc_set_num_streams >= 2) or hold thousands of runs gains 3 %,
+ * robots of at most 16 active spheres on a fixed-base chain: the WAM of the BASELINE configurations; others, and runs
+ * too long for the smaller share of the LDS, keep their default).  A caller whose launches overlap (orc_set_num_streams >= 2) or hold thousands of runs gains 3 %,
  * a caller with one launch of <= 1024 runs at a time loses 3 %.  Trajectories are bit-identical either way. */
 int orc_set_workgroups_per_cu(orc_module * mod, int workgroups);
 

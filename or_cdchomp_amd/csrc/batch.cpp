@@ -895,14 +895,21 @@ void BatchShard::build_device(const Robot & robot)
    // orc_set_workgroups_per_cu(4): the fp64 16-lane kernels of a fixed-base chain also exist at 128 VGPRs, four 256-thread
    // workgroups per CU (three tiles instead of two for the WAM): +3 % when launches overlap, -3 % one launch at a time
    const int want_wgs = mod_->workgroups_per_cu ? mod_->workgroups_per_cu : params.workgroups_per_cu;
-   const bool budget4 = (want_wgs == 4) && sizeof(real) == 8 && (tree_ & 16) && (tree_ & 2) && !(tree_ & 64) && (force_block == 0 || force_block == 256)
+   const int max_wgs_default = max_wgs, force_block_asked = force_block;
+   bool budget4 = false;
+   const int lanes_per_wp = (GS_ == 16) ? 16 : GS_;
+   tile_m_ = 0;
+   // (a run the four-per-CU budget has no room for -- a long trajectory -- is planned with the default budget instead)
+   for (int pass=0; pass<2 && !tile_m_; pass++)
+   {
+   max_wgs = max_wgs_default; force_block = force_block_asked;
+   budget4 = (pass == 0) && (want_wgs == 4) && sizeof(real) == 8 && (tree_ & 16) && (tree_ & 2) && !(tree_ & 64) && (force_block == 0 || force_block == 256)
                         && !getenv("ORC_BLOCK_THREADS") && !getenv("ORC_WGS") && !getenv("ORC_TILE_M");      // (the experiments' switches come first)
    if (budget4) { max_wgs = 4; force_block = 256; }
    if (const char * e = getenv("ORC_BLOCK_THREADS")) force_block = atoi(e);
    int force_g = -1, force_tl = -1;
    if (const char * e = getenv("ORC_G_LDS")) force_g = atoi(e);
    if (const char * e = getenv("ORC_T_LDS")) force_tl = atoi(e);
-   const int lanes_per_wp = (GS_ == 16) ? 16 : GS_;
    tile_m_ = 0;
    block_ = 256;
    double best_score = -1.0;
@@ -964,8 +971,7 @@ void BatchShard::build_device(const Robot & robot)
             }
          }
    }
-   if (!tile_m_ && budget4)
-      throw std::runtime_error("run does not fit four workgroups per CU (orc_set_workgroups_per_cu)!");
+   }
    if (!tile_m_) throw std::runtime_error("run does not fit the LDS of one CU!");
    if (budget4) tree_ |= 256;
    // Tile boundaries.  A tile of s moving waypoints costs ceil(s * lanes per waypoint / threads) rounds of

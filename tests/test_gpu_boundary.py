@@ -302,7 +302,17 @@ def test_workgroup_shape_is_a_module_setting(oracle):
     f = mod.batch_create(model.name, goals[:8], floating_base=1, basegoals=np.tile(common.wam_state()[1], (8, 1)), **kw)
     mod.batch_iterate(f, 3)
     mod.batch_destroy(f)
+    # ... and so does a run the budget has no room for (800 waypoints: the trajectory alone is 45 KB, a workgroup's share 40 KB)
+    long_kw = dict(kw, n_points=800)
+    g4 = mod.batch_create(model.name, goals[:4], **long_kw)
+    cg4, sg4 = mod.batch_iterate(g4, 5)
+    tg4 = mod.batch_gettraj(g4)
+    mod.batch_destroy(g4)
     mod.set_workgroups_per_cu(0)
+    g0 = mod.batch_create(model.name, goals[:4], **long_kw)
+    cg0, sg0 = mod.batch_iterate(g0, 5)
+    assert np.array_equal(tg4, mod.batch_gettraj(g0)) and np.array_equal(cg4, cg0) and np.array_equal(sg4, sg0)
+    mod.batch_destroy(g0)
     assert np.array_equal(se, sa) and np.array_equal(te, ta)
     assert np.allclose(ce, ca, rtol=1e-13, atol=0)
     with pytest.raises(RuntimeError, match="workgroups per CU must be 0"):

@@ -180,13 +180,8 @@ def test_random_robot_matches_oracle(oracle, seed):
         print("seed %d (%s): both refuse: %s" % (seed, what, e))
         return
     probe.destroy()
-    try:
-        bid = mod.batch_create(model.name, goals, basegoals=basegoals, seeds=seeds, precision=precision, **kw)
-    except RuntimeError as e:
-        assert per_cu == 4 and "does not fit four workgroups per CU" in str(e), e
-        mod.set_workgroups_per_cu(0)
-        per_cu = -4
-        bid = mod.batch_create(model.name, goals, basegoals=basegoals, seeds=seeds, precision=precision, **kw)
+    # (a run the four-per-CU budget is not built for, or has no room for, keeps the default budget)
+    bid = mod.batch_create(model.name, goals, basegoals=basegoals, seeds=seeds, precision=precision, **kw)
     seeded = mod.batch_gettraj(bid)
     traces = []
     for n_call in calls:
@@ -219,7 +214,7 @@ def test_random_robot_matches_oracle(oracle, seed):
     print("seed %d (%s; %d runs, %d of %d dofs active, %s, fp%d, %d points, %s%s): worst rel L2 %.2e" % (
         seed, what, n_runs, len(adofs), n_dof, "floating" if floating else "fixed", precision, n_points,
         "%s fields" % which if which != "table" else "table", (", momentum" if momentum else "") + (" + hmc" if hmc else "") + (", derivative 2" if second_order else "")
-        + (", %d threads" % threads if threads else "") + (", four per CU" if per_cu == 4 else (", four per CU refused" if per_cu else "")), max(errs)))
+        + (", %d threads" % threads if threads else "") + (", four per CU asked" if per_cu == 4 else ""), max(errs)))
 
 
 @pytest.mark.parametrize("seed", SEEDS[:16] if len(SEEDS) <= 24 else SEEDS)
