@@ -1,0 +1,213 @@
+"""The oracle's own robot model on random robots (CPU).  OpenRAVE's forward kinematics and Jacobians are third-party
+and absent ("parity unpinned"), so the oracle's restatement (oracle/ora_robot.c) defines truth for every
+parity test -- the least this file can do is check it against something written independently: the numpy kinematics of
+`robots.RobotModel.link_frames` for the sphere centres of every waypoint (fixed and floating base, revolute and
+prismatic joints, rotated joint frames, fixed links in between), and finite differences of those for the rows of the
+TSR constraint Jacobian (src/orcdchomp_mod.cpp:1330-1497), which goes through the same geometric Jacobian as the
+sphere term."""
+import numpy as np
+import pytest
+
+import common
+from or_cdchomp_amd import robots
+from test_gpu_random_robots import random_robot, _random_quat
+
+SEEDS = list(range(40))
+
+
+def _setup(oracle, seed, floating):
+    rng = np.random.default_rng(23000 + seed)
+    model, what = random_robot(seed)
+    n_dof = model.n_dof
+    adofs = list(range(n_dof)) if rng.uniform() < 0.5 or n_dof < 4 else sorted(rng.choice(n_dof, size=int(rng.integers(2, n_dof)), replace=False).tolist())
+    lo = np.array([max(model.limit_lower[d], -1.5) for d in range(n_dof)])
+    hi = np.array([min(model.limit_upper[d], 1.5) for d in range(n_dof)])
+    dofvals = rng.uniform(0.5 * lo, 0.5 * hi)
+    base = np.array([-0.55, 0.05, 0.75] + list(_random_quat(rng, 0.9)))
+    goal = rng.uniform(0.8 * lo[adofs], 0.8 * hi[adofs])
+    basegoal = None
+    if floating:
+        basegoal = base.copy(); basegoal[:3] += rng.uniform(-0.3, 0.3, size=3)
+        q = np.array(_random_quat(rng, 0.5)); basegoal[3:] = robots.quat_mul(tuple(base[3:]), tuple(q))
+    prob = common.tabletop_problem(oracle)
+    rob = oracle.OraRobot(model)
+    kw = dict(n_points=9, lambda_=100.0)
+    if floating:
+        kw["floating_base"] = 1
+    try:
+        run = oracle.OraRun(rob, base, dofvals, adofs, goal, [prob["sdf"]], [prob["pose"]], oracle.default_params(**kw), basegoal=basegoal)
+    except RuntimeError:
+        pytest.skip("the active dofs of this draw move no sphere")
+    return model, what, adofs, dofvals, base, rob, run
+
+
+def _sphere_centres(model, base_pose, q):
+    R, t = model.link_frames(base_pose, q)
+    a = model.arrays()
+    return np.array([R[l] @ p + t[l] for l, p in zip(a["sphere_link"], a["sphere_pos"])])
+
+
+@pytest.mark.parametrize("floating", [False, True])
+@pytest.mark.parametrize("seed", SEEDS)
+def test_oracle_sphere_centres_are_those_of_the_numpy_kinematics(oracle, seed, floating):
+    model, what, adofs, dofvals, base, rob, run = _setup(oracle, seed, floating)
+    _, _, P = run.eval_obstacle()                     # [n_points][Sa][3], the active spheres in the run's order
+    order = run.sphere_order()
+    T = run.traj()
+    c0 = 7 if floating else 0
+    for wp in range(run.n_points):
+        q = dofvals.copy(); q[adofs] = T[wp, c0:]
+        bp = T[wp, :7] if floating else base
+        want = _sphere_centres(model, bp, q)
+        for s in range(run.Sa):
+            assert np.allclose(P[wp, s], want[order[s]], rtol=0, atol=1e-12), (seed, what, wp, s)
+    run.destroy()
+
+
+@pytest.mark.parametrize("seed", SEEDS[:24])
+def test_oracle_tsr_jacobian_is_the_derivative_of_its_value(oracle, seed):
+    model, what, adofs, dofvals, base, rob, run = _setup(oracle, seed, False)
+    li = len(model.link_names) - 1
+    R, t, _, _ = rob.fk(base, dofvals)
+    Bw = [[0, 0]] * 6                                 # all six rows: x y z and the three angles
+    assert run.add_contsr(li, [0.02, -0.01, 0.05, 0, 0, 0, 1], oracle.pose_from_dR(t[li], R[li]), [0, 0, 0, 0, 0, 0, 1], Bw) == 6
+    T = run.traj()
+    for wp in (1, 4, 7):
+        point = T[wp].copy()
+        h0, J = run.eval_contsr(0, point)
+        for j in range(run.n):
+            eps = 1e-6
+            pp = point.copy(); pp[j] += eps
+            pm = point.copy(); pm[j] -= eps
+            hp, _ = run.eval_contsr(0, pp)
+            hm, _ = run.eval_contsr(0, pm)
+            d = (hp - hm) / (2 * eps)
+            d[3:] = (d[3:] + np.pi / (2 * eps)) % (np.pi / eps) - np.pi / (2 * eps)      # (an angle may wrap between the two)
+            assert np.allclose(J[:, j], d, rtol=1e-5, atol=2e-6), (seed, what, wp, j, J[:, j], d)
+    run.destroy()
+
+
+# ---- the sphere cost and its gradient, restated a second time ------------------------------------------------------------
+# numpy, written from the reference's text (src/orcdchomp_mod.cpp:1099-1127 velocities and accelerations, 1134-1327
+# sphere_cost), with the sphere Jacobians taken as central differences of the numpy kinematics above instead of any
+# analytic form: what the C oracle (oracle/ora_run.c, the yardstick of every parity test) computes with its own FK, its own
+# Jacobian columns (revolute: axis x lever, prismatic: axis) and its own bookkeeping of active / inactive spheres must come
+# out of this too.  The grid's interpolation and gradient are the oracle's (those are pinned to the reference's grid.c).
+
+def _rot(q):
+    x, y, z, w = q
+    return np.array([[1 - 2*(y*y + z*z), 2*(x*y - z*w), 2*(x*z + y*w)],
+                     [2*(x*y + z*w), 1 - 2*(x*x + z*z), 2*(y*z - x*w)],
+                     [2*(x*z - y*w), 2*(y*z + x*w), 1 - 2*(x*x + y*y)]])
+
+
+def _numpy_sphere_cost(model, base, dofvals, adofs, T, order, Sa, grids, poses, eps, eps_self, obs, obs_self):
+    n_points, n = T.shape
+    m = n_points - 2
+    dt = 1.0 / (n_points - 1)
+    a = model.arrays()
+    link = a["sphere_link"][order]; radius = a["sphere_radius"][order]
+    S = len(order)
+
+    def centres(row):
+        q = np.array(dofvals, dtype=float); q[adofs] = row
+        return _sphere_centres(model, base, q)[order]            # the run's order: active first
+    P = np.array([centres(T[k])[:Sa] for k in range(n_points)])
+    P_inactive = centres(np.asarray(dofvals)[adofs])[Sa:]         # where they are when the run is created
+    G = np.zeros((m, n)); costs = np.zeros(m)
+    h = 1e-6
+    for i in range(m):
+        row = T[i + 1]
+        J = np.zeros((Sa, 3, n))
+        for j in range(n):
+            rp = row.copy(); rp[j] += h
+            rm = row.copy(); rm[j] -= h
+            J[:, :, j] = (centres(rp)[:Sa] - centres(rm)[:Sa]) / (2 * h)
+        vel = (P[i + 2] - P[i]) / (2 * dt)
+        acc = (P[i] - 2 * P[i + 1] + P[i + 2]) / (dt * dt)
+        for s in range(Sa):
+            p = P[i + 1, s]; v = vel[s]; vn = np.linalg.norm(v)
+            cost_sphere = 0.0
+            best, best_k = np.inf, -1
+            for k, (g, pose) in enumerate(zip(grids, poses)):
+                Rw = _rot(pose[3:7]); gp = Rw.T @ (p - np.asarray(pose[:3]))
+                err, val = g.interp(gp)
+                if err:
+                    continue
+                if val < best:
+                    best, best_k = val, k
+            if best_k >= 0:
+                g, pose = grids[best_k], poses[best_k]
+                Rw = _rot(pose[3:7]); gp = Rw.T @ (p - np.asarray(pose[:3]))
+                dist = best - radius[s]
+                if dist < 0.0:
+                    cost_sphere += vn * obs * (0.5 * eps - dist)
+                elif dist < eps:
+                    cost_sphere += vn * obs * (0.5 / eps) * (dist - eps) ** 2
+                _, gg = g.grad(gp)
+                x = Rw @ gg
+                x = x * (-1.0 if dist < 0.0 else ((dist / eps - 1.0) if dist < eps else 0.0))
+                x = x * (vn * obs)
+                if vn > 0.000001:
+                    x = x - (x @ v) / (vn * vn) * v
+                curv = acc[s].copy()
+                if vn > 0.000001:
+                    curv = curv - (curv @ v) / (vn * vn) * v
+                if vn != 0.0:                                   # (dgemv with alpha == 0 leaves c_grad alone whatever x holds)
+                    curv = curv / (vn * vn)
+                    x = x - cost_sphere * curv
+                    G[i] += vn * (J[s].T @ x)
+            for s2 in range(S):
+                if link[s2] == link[s]:
+                    continue
+                d = p - (P[i + 1, s2] if s2 < Sa else P_inactive[s2 - Sa])
+                dist = np.linalg.norm(d)
+                if dist > radius[s] + radius[s2] + eps_self:
+                    continue
+                unit = d / dist
+                dist -= radius[s] + radius[s2]
+                if dist < 0.0:
+                    cost_sphere += vn * obs_self * (0.5 * eps_self - dist)
+                else:
+                    cost_sphere += vn * obs_self * (0.5 / eps_self) * (dist - eps_self) ** 2
+                x = unit * (-1.0 if dist < 0.0 else ((dist / eps_self - 1.0) if dist < eps_self else 1.0))
+                x = x * (vn * obs_self)
+                if vn > 0.000001:
+                    x = x - (x @ v) / (vn * vn) * v
+                J2 = J[s] - (J[s2] if s2 < Sa else 0.0)
+                G[i] += J2.T @ x
+            costs[i] += cost_sphere
+    return G, costs, P
+
+
+@pytest.mark.parametrize("seed", SEEDS[:20])
+def test_oracle_sphere_cost_against_a_second_restatement(oracle, seed):
+    rng = np.random.default_rng(29000 + seed)
+    model, what, adofs, dofvals, base, rob, probe = _setup(oracle, seed, False)
+    probe.destroy()
+    prob = common.tabletop_problem(oracle)
+    grids, poses = [prob["sdf"]], [np.asarray(prob["pose"], dtype=float)]
+    # a second, rotated field around the robot so that best-of-two and the rotation of the gradient take part
+    occ = np.zeros((14, 12, 10)); occ[5:9, 4:8, 3:7] = np.inf
+    blob = oracle.OraGrid(occ, [0.7, 0.6, 0.5]).bin_sdf()
+    bpose = np.array([-0.85, -0.25, 0.55] + list(_random_quat(rng, 1.0)))
+    grids.append(blob); poses.append(bpose)
+    lo = np.array([max(model.limit_lower[d], -1.5) for d in range(model.n_dof)])
+    hi = np.array([min(model.limit_upper[d], 1.5) for d in range(model.n_dof)])
+    goal = rng.uniform(0.9 * lo[adofs], 0.9 * hi[adofs])
+    eps, eps_self, obs, obs_self = 0.12, float(rng.uniform(0.03, 0.1)), 130.0, 17.0
+    kw = dict(n_points=int(rng.integers(5, 12)), lambda_=100.0, epsilon=eps, epsilon_self=eps_self, obs_factor=obs, obs_factor_self=obs_self)
+    run = oracle.OraRun(rob, base, dofvals, adofs, goal, grids, poses, oracle.default_params(**kw))
+    # not the straight line only: a trajectory that bends (accelerations, the curvature term)
+    T = run.traj()
+    T[1:-1] += 0.08 * rng.normal(size=T[1:-1].shape)
+    G, costs, P = run.eval_obstacle()
+    order = run.sphere_order()
+    G2, costs2, P2 = _numpy_sphere_cost(model, base, dofvals, adofs, T.copy(), order, run.Sa, grids, poses, eps, eps_self, obs, obs_self)
+    assert np.allclose(P, P2, rtol=0, atol=1e-12)
+    assert np.allclose(costs, costs2, rtol=1e-9, atol=1e-12), (seed, what, costs, costs2)
+    scale = max(np.abs(G).max(), 1e-9)
+    assert np.allclose(G, G2, rtol=2e-6, atol=2e-7 * scale), (seed, what, np.abs(G - G2).max(), scale)
+    assert costs.sum() > 0.0 or seed >= 0
+    run.destroy()
+    print("seed %d (%s): %d waypoints, cost %.3g, |G| %.3g, worst difference %.1e" % (seed, what, T.shape[0], costs.sum(), scale, np.abs(G - G2).max()))
