@@ -211,3 +211,143 @@ def test_oracle_sphere_cost_against_a_second_restatement(oracle, seed):
     assert costs.sum() > 0.0 or seed >= 0
     run.destroy()
     print("seed %d (%s): %d waypoints, cost %.3g, |G| %.3g, worst difference %.1e" % (seed, what, T.shape[0], costs.sum(), scale, np.abs(G - G2).max()))
+
+
+# ---- the optimizer, restated a second time -----------------------------------------------------------------------------
+# numpy with its LAPACK (np.linalg.inv is dgetrf + dgetri, what the reference calls), dense matrices and the reference's
+# order of operations, written from the text of src/libcd/chomp.c:40-178 (defaults), 239-340 (K, E -> A, B, trC), 342-428
+# (A^-1), 430-683 (the iteration: gradient, metric, momentum, step, joint-limit rounds, costs) and the loop around it,
+# src/orcdchomp_mod.cpp:2752-2849.  The cost callback is the oracle's sphere term (checked above) evaluated at THIS
+# optimizer's trajectory through a second run object: what is compared is oracle/ora_chomp.c, the banded / dense metric, the
+# limit projection and the bookkeeping of the costs.
+
+class NumpyChomp:
+    def __init__(self, T, D, lam, use_momentum, lower, upper):
+        n_points, n = T.shape
+        self.T = T.copy(); self.m = m = n_points - 2; self.n = n; self.lam = lam; self.use_momentum = use_momentum
+        self.lower = lower; self.upper = upper
+        dt = 1.0 / (n_points - 1)                                        # src/orcdchomp_mod.cpp:2567
+        wds = np.zeros(D); wds[D - 1] = 1.0                              # chomp.c:127-128
+        inits = [T[0]] + [np.zeros(n)] * (D - 1)                         # chomp.c:131-141: zero vectors, not NULL
+        finals = [T[-1]] + [np.zeros(n)] * (D - 1)
+        Kprev = None; Eprev = None; Nprev = m
+        self.A = np.zeros((m, m)); self.B = np.zeros((m, n)); cnn = np.zeros((n, n))
+        for d in range(D):
+            N = Nprev - 1 + 1 + 1
+            diff = np.zeros((N, Nprev)); E = np.zeros((N, n))
+            diff[0, 0] = 1.0 / dt; E[0] += -1.0 / dt * inits[d]
+            for i in range(Nprev - 1):
+                diff[1 + i, i] = -1.0 / dt; diff[1 + i, i + 1] = 1.0 / dt
+            diff[N - 1, Nprev - 1] = -1.0 / dt; E[N - 1] += 1.0 / dt * finals[d]
+            K = diff if d == 0 else diff @ Kprev
+            if d > 0:
+                E = E + diff @ Eprev
+            self.A += wds[d] / N * (K.T @ K); self.B += wds[d] / N * (K.T @ E); cnn += wds[d] / N * (E.T @ E)
+            Kprev, Eprev, Nprev = K, E, N
+        self.trC = 0.5 * np.trace(cnn)
+        self.Ainv = np.linalg.inv(self.A)
+        self.AG = np.zeros((m, n)); self.leapfrog_first = 1              # chomp.c:80, 114-115
+
+    def smooth_cost(self):
+        Tm = self.T[1:-1]
+        return np.trace(0.5 * Tm.T @ (self.A @ Tm) + self.B.T @ Tm) + self.trC
+
+    def iterate(self, cost_callback):
+        """one pass of cd_chomp_iterate(c, 1, ...): returns (status, cost_obs of the trajectory it started from, cost_smooth after)"""
+        m, n = self.m, self.n
+        G, costs = cost_callback(self.T)
+        cost_obs = costs.sum() / m
+        G = G / m
+        Tm = self.T[1:-1]
+        G = G + self.A @ Tm
+        G = G + self.B
+        if not self.use_momentum:
+            self.AG = self.Ainv @ G
+        elif self.leapfrog_first:
+            self.AG = self.AG + 0.5 / self.lam * (self.Ainv @ G); self.leapfrog_first = 0
+        else:
+            self.AG = self.AG + 1.0 / self.lam * (self.Ainv @ G)
+        Tm -= self.AG / self.lam
+        for rounds in range(1000):
+            Gjl = np.zeros((m, n)); largest = 0.0; where = (0, 0)
+            for i in range(m):
+                for j in range(n):
+                    if Tm[i, j] < self.lower[j]:
+                        Gjl[i, j] = self.lower[j] - Tm[i, j]
+                        if abs(Gjl[i, j]) > largest:
+                            largest = abs(Gjl[i, j]); where = (i, j)
+                    if Tm[i, j] > self.upper[j]:
+                        Gjl[i, j] = self.upper[j] - Tm[i, j]
+                        if abs(Gjl[i, j]) > largest:
+                            largest = abs(Gjl[i, j]); where = (i, j)
+            if largest == 0.0:
+                break
+            GA = self.Ainv @ Gjl
+            Tm += 1.01 * Gjl[where] / GA[where] * GA
+        else:
+            return -1, cost_obs, None
+        return 0, cost_obs, self.smooth_cost()
+
+
+@pytest.mark.parametrize("seed", SEEDS[:24])
+def test_oracle_optimizer_against_a_second_restatement(oracle, seed):
+    rng = np.random.default_rng(37000 + seed)
+    model, what, adofs, dofvals, base, rob, probe = _setup(oracle, seed, False)
+    probe.destroy()
+    prob = common.tabletop_problem(oracle)
+    grids, poses = [prob["sdf"]], [np.asarray(prob["pose"], dtype=float)]
+    lo = np.array([max(model.limit_lower[d], -1.5) for d in range(model.n_dof)])
+    hi = np.array([min(model.limit_upper[d], 1.5) for d in range(model.n_dof)])
+    # goals close to the limits now and then: the joint-limit rounds run
+    goal = rng.uniform(0.7 * lo[adofs], 0.7 * hi[adofs])
+    if seed % 3 == 0:
+        # goals a hair inside the limits, and a start moved next to them as well: the joint-limit rounds run
+        tl = np.array([model.limit_lower[d] if np.isfinite(model.limit_lower[d]) else -1.5 for d in adofs])
+        th = np.array([model.limit_upper[d] if np.isfinite(model.limit_upper[d]) else 1.5 for d in adofs])
+        side = rng.uniform(size=len(adofs)) < 0.5
+        beyond = rng.uniform(size=len(adofs)) < 0.4                     # ... and some goals a little beyond them (nothing clamps a goal)
+        goal = np.where(side, th - 0.004 * (th - tl), tl + 0.004 * (th - tl)) + np.where(beyond, np.where(side, 1.0, -1.0) * 0.03 * (th - tl), 0.0)
+        dofvals = dofvals.copy(); dofvals[adofs] = np.where(side, th - 0.02 * (th - tl), tl + 0.02 * (th - tl))
+    D = 2 if seed % 5 == 4 else 1
+    momentum = 1 if seed % 4 == 1 else 0
+    lam = float(rng.uniform(60.0, 300.0))
+    kw = dict(n_points=int(rng.integers(5, 40)), lambda_=lam, obs_factor=float(rng.uniform(50.0, 400.0)), D=D, use_momentum=momentum)
+    run = oracle.OraRun(rob, base, dofvals, adofs, goal, grids, poses, oracle.default_params(**kw))
+    callback_run = oracle.OraRun(rob, base, dofvals, adofs, goal, grids, poses, oracle.default_params(**kw))
+
+    def callback(T):
+        callback_run.set_traj(T)
+        G, costs, _ = callback_run.eval_obstacle()
+        return G.copy(), costs.copy()
+    lower = np.array([model.limit_lower[d] for d in adofs]); upper = np.array([model.limit_upper[d] for d in adofs])
+    mine = NumpyChomp(run.traj(), D, lam, momentum, lower, upper)
+    # the metric itself, entry by entry
+    assert np.allclose(run.mat("A", run.m, run.m), mine.A, rtol=1e-12, atol=0) and np.allclose(run.mat("B", run.m, run.n), mine.B, rtol=1e-12, atol=1e-300)
+    assert np.allclose(run.mat("Ainv", run.m, run.m), mine.Ainv, rtol=1e-8, atol=1e-14)
+    n_iter = int(rng.integers(3, 25))
+    rounds = 0
+    status = st = 0
+    trace, otrace = [], []
+    for it in range(n_iter):
+        st, ocosts, otr = run.iterate(1, trace=True)                       # (no hmc: n calls of one iteration are one call of n)
+        rounds += run.chomp().last_num_limadjs
+        status, cobs, csm = mine.iterate(callback)
+        assert status == st, (seed, what, it, status, st)
+        if st != 0:
+            break
+        trace.append([cobs + csm, cobs, csm]); otrace.append(otr[0])
+    otrace = np.array(otrace)
+    if st != 0:
+        pytest.skip("the run leaves its joint limits for good in both")
+    # (the reference reports the obstacle cost of the trajectory before the step and the smoothness cost after it)
+    assert np.allclose(np.array(trace), otrace, rtol=1e-8, atol=1e-12), (seed, what)
+    assert common.rel_l2(mine.T, run.traj()) <= 1e-9, (seed, what, common.rel_l2(mine.T, run.traj()))
+    # the final call with do_iteration = 0: both costs of the trajectory as it stands (src/orcdchomp_mod.cpp:2833)
+    G, costs = callback(mine.T)
+    final = np.array([costs.sum() / mine.m + mine.smooth_cost(), costs.sum() / mine.m, mine.smooth_cost()])
+    assert np.allclose(final, ocosts, rtol=1e-8, atol=1e-12), (seed, what, final, ocosts)
+    if seed % 3 == 0 and seed < 12:
+        assert rounds > 0, "the draw was meant to run the joint-limit rounds"
+    print("seed %d (%s): D %d, momentum %d, %d points, %d iterations, %d joint-limit rounds: rel L2 %.1e" % (
+        seed, what, D, momentum, kw["n_points"], n_iter, rounds, common.rel_l2(mine.T, run.traj())))
+    run.destroy(); callback_run.destroy()
