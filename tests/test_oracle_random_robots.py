@@ -252,8 +252,9 @@ class NumpyChomp:
         Tm = self.T[1:-1]
         return np.trace(0.5 * Tm.T @ (self.A @ Tm) + self.B.T @ Tm) + self.trC
 
-    def iterate(self, cost_callback):
-        """one pass of cd_chomp_iterate(c, 1, ...): returns (status, cost_obs of the trajectory it started from, cost_smooth after)"""
+    def iterate(self, cost_callback, con_eval=None):
+        """one pass of cd_chomp_iterate(c, 1, ...): returns (status, cost_obs of the trajectory it started from, cost_smooth after);
+        con_eval(point) -> (h [k], J [k][n]): a hard constraint on every moving point (chomp.c:553-600)"""
         m, n = self.m, self.n
         G, costs = cost_callback(self.T)
         cost_obs = costs.sum() / m
@@ -267,6 +268,18 @@ class NumpyChomp:
             self.AG = self.AG + 0.5 / self.lam * (self.Ainv @ G); self.leapfrog_first = 0
         else:
             self.AG = self.AG + 1.0 / self.lam * (self.Ainv @ G)
+        if con_eval is not None:
+            # h_i + (-1/lambda) J_i AG_i; the system J Ainv J^T x = h over all points at once; LAPACK's dgesv; delta = Ainv J^T x
+            hs, Js = zip(*[con_eval(Tm[i].copy()) for i in range(m)])
+            k = len(hs[0])
+            h = np.concatenate([hs[i] - (1.0 / self.lam) * (Js[i] @ self.AG[i]) for i in range(m)])
+            JAJT = np.zeros((m * k, m * k))
+            for i1 in range(m):
+                for i2 in range(m):
+                    JAJT[i1*k:(i1+1)*k, i2*k:(i2+1)*k] = self.Ainv[i1, i2] * (Js[i1] @ Js[i2].T)
+            x = np.linalg.solve(JAJT, h)
+            for i in range(m):
+                Tm -= np.outer(self.Ainv[:, i], Js[i].T @ x[i*k:(i+1)*k])
         Tm -= self.AG / self.lam
         for rounds in range(1000):
             Gjl = np.zeros((m, n)); largest = 0.0; where = (0, 0)
@@ -350,4 +363,68 @@ def test_oracle_optimizer_against_a_second_restatement(oracle, seed):
         assert rounds > 0, "the draw was meant to run the joint-limit rounds"
     print("seed %d (%s): D %d, momentum %d, %d points, %d iterations, %d joint-limit rounds: rel L2 %.1e" % (
         seed, what, D, momentum, kw["n_points"], n_iter, rounds, common.rel_l2(mine.T, run.traj())))
+    run.destroy(); callback_run.destroy()
+
+
+@pytest.mark.parametrize("seed", SEEDS[:16])
+def test_oracle_constraint_step_against_a_second_restatement(oracle, seed):
+    """the TSR hard constraint on every moving point (src/libcd/chomp.c:553-600): the oracle factors the system with its
+    own LU with partial pivoting, the restatement hands the same dense system to LAPACK's dgesv (numpy.linalg.solve) -- the
+    reference's own call.  Constraint values and Jacobians are the oracle's (checked by finite differences above)."""
+    rng = np.random.default_rng(41000 + seed)
+    model, what, adofs, dofvals, base, rob, probe = _setup(oracle, seed, False)
+    probe.destroy()
+    adofs = list(range(model.n_dof))
+    prob = common.tabletop_problem(oracle)
+    grids, poses = [prob["sdf"]], [np.asarray(prob["pose"], dtype=float)]
+    lo = np.array([max(model.limit_lower[d], -1.5) for d in range(model.n_dof)])
+    hi = np.array([min(model.limit_upper[d], 1.5) for d in range(model.n_dof)])
+    goal = np.clip(dofvals + 0.3 * rng.uniform(-1, 1, size=model.n_dof) * np.minimum(1.0, hi - lo), lo, hi)
+    li = len(model.link_names) - 1
+    R, t, _, _ = rob.fk(base, dofvals)
+    momentum = 1 if seed % 3 == 1 else 0
+    lam = float(rng.uniform(100.0, 300.0))
+    kw = dict(n_points=int(rng.integers(5, 30)), lambda_=lam, obs_factor=100.0, use_momentum=momentum)
+    T0w = oracle.pose_from_dR(t[li], R[li])
+    ident = [0, 0, 0, 0, 0, 0, 1]
+    rows = None
+    for attempt in range(12):
+        cand = sorted(rng.choice(6, size=int(rng.integers(1, 3)), replace=False).tolist())
+        Bw = [[0, 0] if r in cand else ([-1, 1] if r < 3 else [-3, 3]) for r in range(6)]
+        pr = oracle.OraRun(rob, base, dofvals, adofs, goal, grids, poses, oracle.default_params(n_points=9))
+        pr.add_contsr(li, ident, T0w, ident, Bw)
+        smin = min(np.linalg.svd(pr.eval_contsr(0, pr.traj()[i])[1], compute_uv=False).min() for i in range(1, 8))
+        pr.destroy()
+        if smin > 0.05:
+            rows = cand
+            break
+    if rows is None:
+        pytest.skip("no well-posed rows for the last link of this draw")
+    run = oracle.OraRun(rob, base, dofvals, adofs, goal, grids, poses, oracle.default_params(**kw))
+    assert run.add_contsr(li, ident, T0w, ident, Bw) == len(rows)
+    callback_run = oracle.OraRun(rob, base, dofvals, adofs, goal, grids, poses, oracle.default_params(**kw))
+    callback_run.add_contsr(li, ident, T0w, ident, Bw)
+
+    def callback(T):
+        callback_run.set_traj(T)
+        G, costs, _ = callback_run.eval_obstacle()
+        return G.copy(), costs.copy()
+
+    def con_eval(point):
+        h, J = callback_run.eval_contsr(0, point)
+        return h.copy(), J.copy()
+    lower = np.array([model.limit_lower[d] for d in adofs]); upper = np.array([model.limit_upper[d] for d in adofs])
+    mine = NumpyChomp(run.traj(), 1, lam, momentum, lower, upper)
+    n_iter = int(rng.integers(3, 12))
+    worst = 0.0
+    for it in range(n_iter):
+        st, ocosts, otr = run.iterate(1, trace=True)
+        status, cobs, csm = mine.iterate(callback, con_eval)
+        assert status == st == 0, (seed, what, it, status, st)
+        assert np.allclose([cobs + csm, cobs, csm], otr[0], rtol=1e-7, atol=1e-12), (seed, what, it)
+        worst = max(worst, common.rel_l2(mine.T, run.traj()))
+    assert worst <= 1e-8, (seed, what, rows, worst)
+    after = max(np.abs(con_eval(mine.T[i])[0]).max() for i in range(1, mine.T.shape[0] - 1))
+    print("seed %d (%s): rows %s, momentum %d, %d points, %d iterations: worst rel L2 %.1e, constraint left at %.1e" % (
+        seed, what, rows, momentum, kw["n_points"], n_iter, worst, after))
     run.destroy(); callback_run.destroy()
