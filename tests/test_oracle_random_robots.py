@@ -428,3 +428,78 @@ def test_oracle_constraint_step_against_a_second_restatement(oracle, seed):
     print("seed %d (%s): rows %s, momentum %d, %d points, %d iterations: worst rel L2 %.1e, constraint left at %.1e" % (
         seed, what, rows, momentum, kw["n_points"], n_iter, worst, after))
     run.destroy(); callback_run.destroy()
+
+
+class GslStream:
+    """gsl_rng_mt19937 seeded the way gsl_rng_set does it (0 -> 4357; numpy's legacy seeding is the same init_genrand),
+    gsl_rng_uniform = the 32-bit output / 2^32, gsl_ran_gaussian = the polar Box-Muller of GSL's randist/gauss.c"""
+    def __init__(self, seed, count=200000):
+        self.raw = np.random.RandomState(seed if seed else 4357).randint(0, 2 ** 32, size=count, dtype=np.uint64)
+        self.k = 0
+
+    def uniform(self):
+        v = float(self.raw[self.k]) / 4294967296.0
+        self.k += 1
+        return v
+
+    def uniform_pos(self):
+        while True:
+            v = self.uniform()
+            if v != 0.0:
+                return v
+
+    def gaussian(self, sigma):
+        while True:
+            x = -1 + 2 * self.uniform_pos(); y = -1 + 2 * self.uniform_pos()
+            r2 = x * x + y * y
+            if not (r2 > 1.0 or r2 == 0):
+                return sigma * y * np.sqrt(-2.0 * np.log(r2) / r2)
+
+
+@pytest.mark.parametrize("seed", SEEDS[:12])
+def test_oracle_hmc_loop_against_a_second_restatement(oracle, seed):
+    """`use_hmc` (src/orcdchomp_mod.cpp:2752-2768): at its resampling iterations the momentum is redrawn from the run's
+    GSL stream, row-major, sigma = 1/sqrt(100 e^(0.02 iter)), the next resampling iteration moves on by 1 + (int)(-ln u /
+    lambda_hmc), the leapfrog starts over; `iter` restarts with every `iterate` call while the resampling iteration is
+    kept.  The stream itself is GSL's published algorithm in both writings (numpy's mt19937 here)."""
+    import math
+    rng = np.random.default_rng(43000 + seed)
+    model, what, adofs, dofvals, base, rob, probe = _setup(oracle, seed, False)
+    probe.destroy()
+    prob = common.tabletop_problem(oracle)
+    grids, poses = [prob["sdf"]], [np.asarray(prob["pose"], dtype=float)]
+    lo = np.array([max(model.limit_lower[d], -1.5) for d in range(model.n_dof)])
+    hi = np.array([min(model.limit_upper[d], 1.5) for d in range(model.n_dof)])
+    goal = rng.uniform(0.6 * lo[adofs], 0.6 * hi[adofs])
+    lam = float(rng.uniform(100.0, 300.0)); hl = float(rng.uniform(0.05, 0.5)); gsl_seed = int(rng.integers(0, 50))
+    kw = dict(n_points=int(rng.integers(5, 24)), lambda_=lam, obs_factor=100.0, use_momentum=1, use_hmc=1, hmc_resample_lambda=hl, seed=gsl_seed)
+    run = oracle.OraRun(rob, base, dofvals, adofs, goal, grids, poses, oracle.default_params(**kw))
+    callback_run = oracle.OraRun(rob, base, dofvals, adofs, goal, grids, poses, oracle.default_params(**kw))
+
+    def callback(T):
+        callback_run.set_traj(T)
+        G, costs, _ = callback_run.eval_obstacle()
+        return G.copy(), costs.copy()
+    lower = np.array([model.limit_lower[d] for d in adofs]); upper = np.array([model.limit_upper[d] for d in adofs])
+    mine = NumpyChomp(run.traj(), 1, lam, 1, lower, upper)
+    stream = GslStream(gsl_seed)
+    resample_iter, resamples = 0, 0
+    for n_call in (int(rng.integers(4, 15)), int(rng.integers(4, 15))):           # two calls: iter restarts, the schedule does not
+        st, ocosts, otr = run.iterate(n_call, trace=True)
+        assert st == 0
+        for it in range(n_call):
+            if it == resample_iter:
+                alpha = 100.0 * math.exp(0.02 * it)
+                for i in range(mine.m):
+                    for j in range(mine.n):
+                        mine.AG[i, j] = stream.gaussian(1.0 / math.sqrt(alpha))
+                mine.leapfrog_first = 1
+                resample_iter += 1 + int(-math.log(stream.uniform()) / hl)
+                resamples += 1
+            status, cobs, csm = mine.iterate(callback)
+            assert status == 0
+            assert np.allclose([cobs + csm, cobs, csm], otr[it], rtol=1e-8, atol=1e-12), (seed, what, it)
+        assert common.rel_l2(mine.T, run.traj()) <= 1e-10, (seed, what, common.rel_l2(mine.T, run.traj()))
+    assert resamples >= 1
+    print("seed %d (%s): gsl seed %d, lambda_hmc %.2f, %d resamplings: rel L2 %.1e" % (seed, what, gsl_seed, hl, resamples, common.rel_l2(mine.T, run.traj())))
+    run.destroy(); callback_run.destroy()
