@@ -101,7 +101,7 @@ def _rot(q):
                      [2*(x*z - y*w), 2*(y*z + x*w), 1 - 2*(x*x + y*y)]])
 
 
-def _numpy_sphere_cost(model, base, dofvals, adofs, T, order, Sa, grids, poses, eps, eps_self, obs, obs_self):
+def _numpy_sphere_cost(model, base, dofvals, adofs, T, order, Sa, grids, poses, eps, eps_self, obs, obs_self, floating=False):
     n_points, n = T.shape
     m = n_points - 2
     dt = 1.0 / (n_points - 1)
@@ -110,10 +110,16 @@ def _numpy_sphere_cost(model, base, dofvals, adofs, T, order, Sa, grids, poses, 
     S = len(order)
 
     def centres(row):
-        q = np.array(dofvals, dtype=float); q[adofs] = row
+        q = np.array(dofvals, dtype=float)
+        if floating:
+            # the base pose is part of the row; a rotation is what its quaternion is after normalisation
+            q[adofs] = row[7:]
+            bp = np.array(row[:7], dtype=float); bp[3:] = bp[3:] / np.linalg.norm(bp[3:])
+            return _sphere_centres(model, bp, q)[order]
+        q[adofs] = row
         return _sphere_centres(model, base, q)[order]            # the run's order: active first
     P = np.array([centres(T[k])[:Sa] for k in range(n_points)])
-    P_inactive = centres(np.asarray(dofvals)[adofs])[Sa:]         # where they are when the run is created
+    P_inactive = None if floating else centres(np.asarray(dofvals)[adofs])[Sa:]         # where they are when the run is created
     G = np.zeros((m, n)); costs = np.zeros(m)
     h = 1e-6
     for i in range(m):
@@ -123,6 +129,8 @@ def _numpy_sphere_cost(model, base, dofvals, adofs, T, order, Sa, grids, poses, 
             rp = row.copy(); rp[j] += h
             rm = row.copy(); rm[j] -= h
             J[:, :, j] = (centres(rp)[:Sa] - centres(rm)[:Sa]) / (2 * h)
+        if floating:
+            J[:, :, :7] *= 0.01            # src/orcdchomp_mod.cpp:1075-1080 (under a comment that says "overwrite with zeros")
         vel = (P[i + 2] - P[i]) / (2 * dt)
         acc = (P[i] - 2 * P[i + 1] + P[i + 2]) / (dt * dt)
         for s in range(Sa):
@@ -503,3 +511,32 @@ def test_oracle_hmc_loop_against_a_second_restatement(oracle, seed):
     assert resamples >= 1
     print("seed %d (%s): gsl seed %d, lambda_hmc %.2f, %d resamplings: rel L2 %.1e" % (seed, what, gsl_seed, hl, resamples, common.rel_l2(mine.T, run.traj())))
     run.destroy(); callback_run.destroy()
+
+
+@pytest.mark.parametrize("seed", SEEDS[:16])
+def test_oracle_sphere_cost_floating_base_against_a_second_restatement(oracle, seed):
+    """floating base (src/orcdchomp_mod.cpp:1008-1016, 1050-1085; src/libcd/spatial.c:71-102, 295-337): the reference
+    forms the base columns of a sphere's Jacobian as X(-p) . Jsp(pose) times 0.01.  Without the 0.01 that is the derivative
+    of the sphere's centre with respect to the seven pose numbers, the quaternion taken as the rotation it normalises to --
+    so the second restatement takes exactly that derivative by central differences and scales it."""
+    rng = np.random.default_rng(47000 + seed)
+    model, what, adofs, dofvals, base, rob, run = _setup(oracle, seed, True)
+    prob = common.tabletop_problem(oracle)
+    grids, poses = [prob["sdf"]], [np.asarray(prob["pose"], dtype=float)]
+    T = run.traj()
+    T[1:-1, :3] += 0.03 * rng.normal(size=T[1:-1, :3].shape)
+    T[1:-1, 7:] += 0.08 * rng.normal(size=T[1:-1, 7:].shape)
+    q = T[1:-1, 3:7] + 0.05 * rng.normal(size=T[1:-1, 3:7].shape)
+    T[1:-1, 3:7] = q / np.linalg.norm(q, axis=1)[:, None]
+    G, costs, P = run.eval_obstacle()
+    assert run.Sa == run.S                                      # with a floating base every sphere is active (mod.cpp:2273)
+    p = run.chomp()
+    G2, costs2, P2 = _numpy_sphere_cost(model, base, dofvals, adofs, T.copy(), run.sphere_order(), run.Sa, grids, poses,
+                                        0.1, 0.04, 200.0, 10.0, floating=True)      # the reference's defaults (mod.cpp:1845-1848)
+    assert np.allclose(P, P2, rtol=0, atol=1e-12)
+    assert np.allclose(costs, costs2, rtol=1e-9, atol=1e-12), (seed, what)
+    scale = max(np.abs(G).max(), 1e-9)
+    assert np.allclose(G, G2, rtol=2e-6, atol=2e-7 * scale), (seed, what, np.abs(G - G2).max(), scale)
+    assert np.abs(G[:, :7]).max() > 0.0
+    print("seed %d (%s): |G| %.3g, base columns up to %.3g, worst difference %.1e" % (seed, what, scale, np.abs(G[:, :7]).max(), np.abs(G - G2).max()))
+    run.destroy()
