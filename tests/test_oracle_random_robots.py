@@ -540,3 +540,39 @@ def test_oracle_sphere_cost_floating_base_against_a_second_restatement(oracle, s
     assert np.abs(G[:, :7]).max() > 0.0
     print("seed %d (%s): |G| %.3g, base columns up to %.3g, worst difference %.1e" % (seed, what, scale, np.abs(G[:, :7]).max(), np.abs(G - G2).max()))
     run.destroy()
+
+
+def _hom(R, t):
+    M = np.eye(4); M[:3, :3] = R; M[:3, 3] = t
+    return M
+
+
+@pytest.mark.parametrize("floating", [False, True])
+@pytest.mark.parametrize("seed", SEEDS[:16])
+def test_oracle_tsr_value_against_a_second_restatement(oracle, seed, floating):
+    """the value of a TSR constraint (src/orcdchomp_mod.cpp:1330-1415: T0w^-1 . T_ee . Twe^-1 as x y z and the ZYX
+    angles of src/libcd/kin.c:615-646, Bw's rows in the order x y z roll pitch yaw), with quaternion products in the
+    oracle, with 4 x 4 matrices and the angles read off the rotation matrix here; T0w, Twe and the tool offset at random."""
+    rng = np.random.default_rng(53000 + seed)
+    model, what, adofs, dofvals, base, rob, run = _setup(oracle, seed, floating)
+    li = int(rng.integers(1, len(model.link_names)))
+    tool = np.array(list(rng.uniform(-0.1, 0.1, size=3)) + list(_random_quat(rng, 1.0)))
+    T0w = np.array(list(rng.uniform(-0.5, 0.5, size=3)) + list(_random_quat(rng, 2.0)))
+    Twe = np.array(list(rng.uniform(-0.2, 0.2, size=3)) + list(_random_quat(rng, 2.0)))
+    assert run.add_contsr(li, tool, T0w, Twe, [[0, 0]] * 6) == 6
+    T = run.traj()
+    c0 = 7 if floating else 0
+    for wp in range(run.n_points):
+        point = T[wp].copy()
+        point[c0:] += 0.2 * rng.normal(size=run.n - c0)
+        h, _ = run.eval_contsr(0, point)
+        q = dofvals.copy(); q[adofs] = point[c0:]
+        bp = point[:7] if floating else base
+        R, t = model.link_frames(bp, q)
+        M = np.linalg.inv(_hom(_rot(T0w[3:]), T0w[:3])) @ _hom(R[li], t[li]) @ _hom(_rot(tool[3:]), tool[:3]) @ np.linalg.inv(_hom(_rot(Twe[3:]), Twe[:3]))
+        yaw = np.arctan2(M[1, 0], M[0, 0]); pitch = np.arcsin(-M[2, 0]); roll = np.arctan2(M[2, 1], M[2, 2])
+        want = np.array([M[0, 3], M[1, 3], M[2, 3], roll, pitch, yaw])
+        if abs(pitch) > 1.5:
+            continue                                  # next to the gimbal lock the reference switches formula
+        assert np.allclose(h, want, rtol=0, atol=1e-10), (seed, what, wp, h, want)
+    run.destroy()
