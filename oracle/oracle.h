@@ -21,7 +21,12 @@
  *   which exist in this image, so the reference cannot be run):
  *     chomp.c iterate as a whole, kin.c/spatial.c, sphere_cost*, FK/Jacobians
  *     (OpenRAVE), the GSL noise stream.  These follow the reference text line by
- *     line with the file:line cited at every function.
+ *     line with the file:line cited at every function.  They are checked against a
+ *     SECOND restatement written independently in numpy from the same text (dense
+ *     matrices and LAPACK for the optimizer and the constraint step, finite
+ *     differences of a numpy kinematics for every Jacobian, numpy's mt19937 for
+ *     the noise): tests/test_oracle_random_robots.py.  That is two readings of
+ *     the reference agreeing, not the reference run: "parity unpinned" stands.
  */
 #ifndef ORACLE_H
 #define ORACLE_H
