@@ -915,7 +915,10 @@ std::string Module::cmd_create(const std::vector<std::string> & argv, bool batch
          }
          else { seg = std::min((int) t, count-2); if (seg < 0) seg = 0; u = t - seg; }
          if (count == 1) { seg = 0; u = 0.0; }
-         const double * r0 = &doc.vals[(size_t) seg*doc.width], * r1 = &doc.vals[(size_t) std::min(seg+1, count-1)*doc.width];
+         int s0 = seg, s1 = std::min(seg+1, count-1);
+         // at (and past) the end a trajectory is its last waypoint (OpenRAVE's Sample), also when the last segments take no time
+         if (duration > 0.0 && (k == p.n_points-1 || t >= duration)) { s0 = s1 = count-1; u = 0.0; }
+         const double * r0 = &doc.vals[(size_t) s0*doc.width], * r1 = &doc.vals[(size_t) s1*doc.width];
          double * row = &sampled[(size_t) k*nn];
          if (p.floating_base)
          {

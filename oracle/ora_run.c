@@ -979,11 +979,15 @@ void ora_sample_starttraj(int count, int dof, const double * wp, const double * 
    {
       const double t = i * duration / (n_points - 1);             /* mod.cpp:2412 */
       double u;
+      int s0, s1;
       while (seg < count-2 && tcum[seg+1] < t) seg++;
       u = (count > 1 && tcum[seg+1] > tcum[seg]) ? (t - tcum[seg]) / (tcum[seg+1] - tcum[seg]) : 0.0;
+      s0 = seg; s1 = (count > 1) ? seg+1 : seg;
+      /* at (and past) the end a trajectory is its last waypoint (OpenRAVE's Sample), also when its last segments take no time */
+      if (duration > 0.0 && (i == n_points-1 || t >= duration)) { s0 = s1 = count-1; u = 0.0; }
       for (j=0; j<dof; j++)
       {
-         const double a0 = wp[seg*dof+j], a1 = wp[(count > 1 ? seg+1 : seg)*dof+j];
+         const double a0 = wp[s0*dof+j], a1 = wp[s1*dof+j];
          out[i*dof+j] = a0 + (a1 - a0) * u;
       }
    }
@@ -1007,16 +1011,18 @@ void ora_sample_starttraj_floating(int count, int n_adof, const double * wp_join
    for (i=0; i<n_points; i++)
    {
       const double t = i * duration / (n_points - 1);             /* mod.cpp:2391, 2402 */
-      const int nxt = (count > 1) ? 1 : 0;
       double u, vec[7];
+      int s0, s1;
       while (seg < count-2 && tcum[seg+1] < t) seg++;
       u = (count > 1 && tcum[seg+1] > tcum[seg]) ? (t - tcum[seg]) / (tcum[seg+1] - tcum[seg]) : 0.0;
-      for (j=0; j<7; j++) vec[j] = wp_base[seg*7+j] + (wp_base[(seg+nxt)*7+j] - wp_base[seg*7+j]) * u;
+      s0 = seg; s1 = (count > 1) ? seg+1 : seg;
+      if (duration > 0.0 && (i == n_points-1 || t >= duration)) { s0 = s1 = count-1; u = 0.0; }      /* the end: the last waypoint */
+      for (j=0; j<7; j++) vec[j] = wp_base[s0*7+j] + (wp_base[s1*7+j] - wp_base[s0*7+j]) * u;
       out[i*n+0] = vec[0]; out[i*n+1] = vec[1]; out[i*n+2] = vec[2];          /* mod.cpp:2392-2398 */
       out[i*n+3] = vec[4]; out[i*n+4] = vec[5]; out[i*n+5] = vec[6]; out[i*n+6] = vec[3];
       ora_kin_pose_normalize(&out[i*n]);
       for (j=0; j<n_adof; j++)
-         out[i*n+7+j] = wp_joint[seg*n_adof+j] + (wp_joint[(seg+nxt)*n_adof+j] - wp_joint[seg*n_adof+j]) * u;
+         out[i*n+7+j] = wp_joint[s0*n_adof+j] + (wp_joint[s1*n_adof+j] - wp_joint[s0*n_adof+j]) * u;
    }
    free(tcum);
 }

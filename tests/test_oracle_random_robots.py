@@ -576,3 +576,40 @@ def test_oracle_tsr_value_against_a_second_restatement(oracle, seed, floating):
             continue                                  # next to the gimbal lock the reference switches formula
         assert np.allclose(h, want, rtol=0, atol=1e-10), (seed, what, wp, h, want)
     run.destroy()
+
+
+@pytest.mark.parametrize("seed", SEEDS[:12])
+def test_oracle_starttraj_sampling_is_linear_interpolation_in_time(oracle, seed):
+    """`create starttraj` (src/orcdchomp_mod.cpp:2375-2416): waypoint i of the run is the passed trajectory sampled at
+    i * duration / (n_points - 1); for the linearly interpolated, linearly retimed documents `gettraj` writes that is
+    numpy.interp over the cumulated deltatimes, column by column (base position included; the base quaternion is
+    interpolated component-wise and normalised, src/orcdchomp_mod.cpp:2391-2402)."""
+    rng = np.random.default_rng(59000 + seed)
+    k, n = int(rng.integers(2, 40)), int(rng.integers(1, 20))
+    wp = rng.normal(size=(k, n))
+    dt = np.r_[0.0, rng.uniform(0.0, 1.0, size=k - 1)]
+    dt[rng.uniform(size=k) < 0.1] = 0.0                         # waypoints that take no time
+    dt[0] = 0.0
+    if dt.sum() == 0.0:
+        dt[-1] = 0.5
+    tc = np.cumsum(dt)
+    for npts in (3, int(rng.integers(4, 90))):
+        got = oracle.sample_starttraj(wp, dt, npts)
+        ts = np.arange(npts) * tc[-1] / (npts - 1)
+        want = np.column_stack([np.interp(ts, tc, wp[:, j]) for j in range(n)])
+        # (where two waypoints share a time, both writings must pick the same side: compare away from those instants)
+        ok = np.array([np.min(np.abs(t - tc[np.r_[False, dt[1:] == 0.0]])) > 1e-9 if np.any(dt[1:] == 0.0) else True for t in ts])
+        assert np.allclose(got[ok], want[ok], rtol=1e-12, atol=1e-13), (seed, npts)
+        assert np.allclose(got[0], wp[0], atol=1e-13) and np.allclose(got[-1], wp[-1], atol=1e-12)
+    # floating base: position like a joint, quaternion component-wise then normalised, reordered to libcd's x y z w
+    wb = rng.normal(size=(k, 7)); wb[:, 3:] /= np.linalg.norm(wb[:, 3:], axis=1)[:, None]
+    npts = int(rng.integers(3, 50))
+    got = oracle.sample_starttraj_floating(wp, wb, dt, npts)
+    ts = np.arange(npts) * tc[-1] / (npts - 1)
+    pos = np.column_stack([np.interp(ts, tc, wb[:, j]) for j in range(3)])
+    qw_first = np.column_stack([np.interp(ts, tc, wb[:, 3 + j]) for j in range(4)])          # OpenRAVE's order: w x y z
+    q = np.column_stack([qw_first[:, 1], qw_first[:, 2], qw_first[:, 3], qw_first[:, 0]])
+    q = q / np.linalg.norm(q, axis=1)[:, None]
+    arm = np.column_stack([np.interp(ts, tc, wp[:, j]) for j in range(n)])
+    ok = np.array([np.min(np.abs(t - tc[np.r_[False, dt[1:] == 0.0]])) > 1e-9 if np.any(dt[1:] == 0.0) else True for t in ts])
+    assert np.allclose(got[ok], np.column_stack([pos, q, arm])[ok], rtol=1e-12, atol=1e-13), seed
