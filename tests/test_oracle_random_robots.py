@@ -101,9 +101,10 @@ def _rot(q):
                      [2*(x*z - y*w), 2*(y*z + x*w), 1 - 2*(x*x + y*y)]])
 
 
-def _numpy_sphere_cost(model, base, dofvals, adofs, T, order, Sa, grids, poses, eps, eps_self, obs, obs_self, floating=False):
+def _numpy_sphere_cost(model, base, dofvals, adofs, T, order, Sa, grids, poses, eps, eps_self, obs, obs_self, floating=False, free_start=False):
     n_points, n = T.shape
-    m = n_points - 2
+    m = n_points - 2 + (1 if free_start else 0)                  # `start_tsr`: the start point moves too (mod.cpp:2315-2316)
+    first = 0 if free_start else 1                               # trajectory row of moving point 0
     dt = 1.0 / (n_points - 1)
     a = model.arrays()
     link = a["sphere_link"][order]; radius = a["sphere_radius"][order]
@@ -123,7 +124,8 @@ def _numpy_sphere_cost(model, base, dofvals, adofs, T, order, Sa, grids, poses, 
     G = np.zeros((m, n)); costs = np.zeros(m)
     h = 1e-6
     for i in range(m):
-        row = T[i + 1]
+        r0 = i + first
+        row = T[r0]
         J = np.zeros((Sa, 3, n))
         for j in range(n):
             rp = row.copy(); rp[j] += h
@@ -131,10 +133,15 @@ def _numpy_sphere_cost(model, base, dofvals, adofs, T, order, Sa, grids, poses, 
             J[:, :, j] = (centres(rp)[:Sa] - centres(rm)[:Sa]) / (2 * h)
         if floating:
             J[:, :, :7] *= 0.01            # src/orcdchomp_mod.cpp:1075-1080 (under a comment that says "overwrite with zeros")
-        vel = (P[i + 2] - P[i]) / (2 * dt)
-        acc = (P[i] - 2 * P[i + 1] + P[i + 2]) / (dt * dt)
+        if r0 == 0:
+            # the start point: one-sided velocity, the acceleration of the point after it (mod.cpp:1107-1112, 1125-1126)
+            vel = (P[1] - P[0]) / dt
+            acc = (P[0] - 2 * P[1] + P[2]) / (dt * dt)
+        else:
+            vel = (P[r0 + 1] - P[r0 - 1]) / (2 * dt)
+            acc = (P[r0 - 1] - 2 * P[r0] + P[r0 + 1]) / (dt * dt)
         for s in range(Sa):
-            p = P[i + 1, s]; v = vel[s]; vn = np.linalg.norm(v)
+            p = P[r0, s]; v = vel[s]; vn = np.linalg.norm(v)
             cost_sphere = 0.0
             best, best_k = np.inf, -1
             for k, (g, pose) in enumerate(zip(grids, poses)):
@@ -168,7 +175,7 @@ def _numpy_sphere_cost(model, base, dofvals, adofs, T, order, Sa, grids, poses, 
             for s2 in range(S):
                 if link[s2] == link[s]:
                     continue
-                d = p - (P[i + 1, s2] if s2 < Sa else P_inactive[s2 - Sa])
+                d = p - (P[r0, s2] if s2 < Sa else P_inactive[s2 - Sa])
                 dist = np.linalg.norm(d)
                 if dist > radius[s] + radius[s2] + eps_self:
                     continue
@@ -230,22 +237,25 @@ def test_oracle_sphere_cost_against_a_second_restatement(oracle, seed):
 # limit projection and the bookkeeping of the costs.
 
 class NumpyChomp:
-    def __init__(self, T, D, lam, use_momentum, lower, upper):
+    def __init__(self, T, D, lam, use_momentum, lower, upper, free_start=False):
         n_points, n = T.shape
-        self.T = T.copy(); self.m = m = n_points - 2; self.n = n; self.lam = lam; self.use_momentum = use_momentum
+        self.free_start = free_start
+        self.T = T.copy(); self.m = m = n_points - 2 + (1 if free_start else 0); self.n = n; self.lam = lam; self.use_momentum = use_momentum
         self.lower = lower; self.upper = upper
         dt = 1.0 / (n_points - 1)                                        # src/orcdchomp_mod.cpp:2567
         wds = np.zeros(D); wds[D - 1] = 1.0                              # chomp.c:127-128
-        inits = [T[0]] + [np.zeros(n)] * (D - 1)                         # chomp.c:131-141: zero vectors, not NULL
+        inits = [None if free_start else T[0]] + [np.zeros(n)] * (D - 1)  # chomp.c:131-141: zero vectors, not NULL; `start_tsr`: inits[0] = NULL (mod.cpp:2572)
         finals = [T[-1]] + [np.zeros(n)] * (D - 1)
         Kprev = None; Eprev = None; Nprev = m
         self.A = np.zeros((m, m)); self.B = np.zeros((m, n)); cnn = np.zeros((n, n))
         for d in range(D):
-            N = Nprev - 1 + 1 + 1
+            hi = 0 if inits[d] is None else 1
+            N = Nprev - 1 + hi + 1
             diff = np.zeros((N, Nprev)); E = np.zeros((N, n))
-            diff[0, 0] = 1.0 / dt; E[0] += -1.0 / dt * inits[d]
+            if hi:
+                diff[0, 0] = 1.0 / dt; E[0] += -1.0 / dt * inits[d]
             for i in range(Nprev - 1):
-                diff[1 + i, i] = -1.0 / dt; diff[1 + i, i + 1] = 1.0 / dt
+                diff[hi + i, i] = -1.0 / dt; diff[hi + i, i + 1] = 1.0 / dt
             diff[N - 1, Nprev - 1] = -1.0 / dt; E[N - 1] += 1.0 / dt * finals[d]
             K = diff if d == 0 else diff @ Kprev
             if d > 0:
@@ -256,8 +266,11 @@ class NumpyChomp:
         self.Ainv = np.linalg.inv(self.A)
         self.AG = np.zeros((m, n)); self.leapfrog_first = 1              # chomp.c:80, 114-115
 
+    def moving(self):
+        return self.T[0:-1] if self.free_start else self.T[1:-1]
+
     def smooth_cost(self):
-        Tm = self.T[1:-1]
+        Tm = self.moving()
         return np.trace(0.5 * Tm.T @ (self.A @ Tm) + self.B.T @ Tm) + self.trC
 
     def iterate(self, cost_callback, con_eval=None):
@@ -267,7 +280,7 @@ class NumpyChomp:
         G, costs = cost_callback(self.T)
         cost_obs = costs.sum() / m
         G = G / m
-        Tm = self.T[1:-1]
+        Tm = self.moving()
         G = G + self.A @ Tm
         G = G + self.B
         if not self.use_momentum:
@@ -277,17 +290,19 @@ class NumpyChomp:
         else:
             self.AG = self.AG + 1.0 / self.lam * (self.Ainv @ G)
         if con_eval is not None:
-            # h_i + (-1/lambda) J_i AG_i; the system J Ainv J^T x = h over all points at once; LAPACK's dgesv; delta = Ainv J^T x
-            hs, Js = zip(*[con_eval(Tm[i].copy()) for i in range(m)])
-            k = len(hs[0])
-            h = np.concatenate([hs[i] - (1.0 / self.lam) * (Js[i] @ self.AG[i]) for i in range(m)])
-            JAJT = np.zeros((m * k, m * k))
-            for i1 in range(m):
-                for i2 in range(m):
-                    JAJT[i1*k:(i1+1)*k, i2*k:(i2+1)*k] = self.Ainv[i1, i2] * (Js[i1] @ Js[i2].T)
-            x = np.linalg.solve(JAJT, h)
-            for i in range(m):
-                Tm -= np.outer(self.Ainv[:, i], Js[i].T @ x[i*k:(i+1)*k])
+            # h_i + (-1/lambda) J_i AG_i; the system J Ainv J^T x = h over all constrained points at once; LAPACK's dgesv;
+            # delta = Ainv J^T x.  con_eval: one function for every moving point, or a list of (point index, function)
+            cons = [(i, con_eval) for i in range(m)] if callable(con_eval) else list(con_eval)
+            ev = [(i, *f(Tm[i].copy())) for i, f in cons]
+            hs = [hh - (1.0 / self.lam) * (JJ @ self.AG[i]) for i, hh, JJ in ev]
+            off = np.cumsum([0] + [len(hh) for hh in hs])
+            JAJT = np.zeros((off[-1], off[-1]))
+            for a, (i1, _, J1) in enumerate(ev):
+                for b2, (i2, _, J2) in enumerate(ev):
+                    JAJT[off[a]:off[a+1], off[b2]:off[b2+1]] = self.Ainv[i1, i2] * (J1 @ J2.T)
+            x = np.linalg.solve(JAJT, np.concatenate(hs))
+            for a, (i, _, JJ) in enumerate(ev):
+                Tm -= np.outer(self.Ainv[:, i], JJ.T @ x[off[a]:off[a+1]])
         Tm -= self.AG / self.lam
         for rounds in range(1000):
             Gjl = np.zeros((m, n)); largest = 0.0; where = (0, 0)
@@ -613,3 +628,101 @@ def test_oracle_starttraj_sampling_is_linear_interpolation_in_time(oracle, seed)
     arm = np.column_stack([np.interp(ts, tc, wp[:, j]) for j in range(n)])
     ok = np.array([np.min(np.abs(t - tc[np.r_[False, dt[1:] == 0.0]])) > 1e-9 if np.any(dt[1:] == 0.0) else True for t in ts])
     assert np.allclose(got[ok], np.column_stack([pos, q, arm])[ok], rtol=1e-12, atol=1e-13), seed
+
+
+@pytest.mark.parametrize("seed", SEEDS[:16])
+def test_oracle_free_start_against_a_second_restatement(oracle, seed):
+    """`start_tsr` (src/orcdchomp_mod.cpp:1988-1992, 2316-2323, 2570-2576): the start point is a variable -- one more
+    moving point, no init row in the first difference operator, a one-sided sphere velocity and a borrowed acceleration
+    for it (1107-1112, 1125-1126) -- held on a TSR by a constraint on that one point; now and then a `con_tsr` on
+    every point on other rows as well."""
+    rng = np.random.default_rng(67000 + seed)
+    model, what, adofs, dofvals, base, rob, probe = _setup(oracle, seed, False)
+    probe.destroy()
+    adofs = list(range(model.n_dof))
+    prob = common.tabletop_problem(oracle)
+    grids, poses = [prob["sdf"]], [np.asarray(prob["pose"], dtype=float)]
+    lo = np.array([max(model.limit_lower[d], -1.5) for d in range(model.n_dof)])
+    hi = np.array([min(model.limit_upper[d], 1.5) for d in range(model.n_dof)])
+    goal = np.clip(dofvals + 0.3 * rng.uniform(-1, 1, size=model.n_dof) * np.minimum(1.0, hi - lo), lo, hi)
+    li = len(model.link_names) - 1
+    R, t, _, _ = rob.fk(base, dofvals)
+    T0w = oracle.pose_from_dR(t[li], R[li]); ident = [0, 0, 0, 0, 0, 0, 1]
+    n_anc, cur = 0, li
+    while cur >= 0:
+        n_anc += model.joint_type[cur] != robots.JOINT_FIXED
+        cur = model.parent[cur]
+
+    def rows_ok(rows, points):
+        Bw = [[0, 0] if r in rows else ([-1, 1] if r < 3 else [-3, 3]) for r in range(6)]
+        pr = oracle.OraRun(rob, base, dofvals, adofs, goal, grids, poses, oracle.default_params(n_points=9))
+        pr.add_contsr(li, ident, T0w, ident, Bw)
+        smin = min(np.linalg.svd(pr.eval_contsr(0, pr.traj()[i])[1], compute_uv=False).min() for i in points)
+        pr.destroy()
+        return Bw if smin > 0.05 else None
+    rows_s = Bw_s = rows_c = Bw_c = None
+    with_con = seed % 3 == 0 and n_anc >= 2
+    for attempt in range(20):
+        rows_s = sorted(rng.choice(6, size=1, replace=False).tolist())
+        rows_c = sorted(rng.choice([r for r in range(6) if r not in rows_s], size=1, replace=False).tolist()) if with_con else []
+        Bw_s = rows_ok(sorted(rows_s + rows_c), [0]) and rows_ok(rows_s, [0])
+        Bw_c = rows_ok(rows_c, range(0, 8)) if with_con else None
+        if Bw_s and (Bw_c or not with_con):
+            break
+    else:
+        pytest.skip("no well-posed rows for the last link of this draw")
+    momentum = 1 if seed % 4 == 2 else 0
+    lam = float(rng.uniform(100.0, 300.0))
+    kw = dict(n_points=int(rng.integers(5, 30)), lambda_=lam, obs_factor=100.0, use_momentum=momentum)
+    st_arg = (li, ident, T0w, ident, Bw_s)
+    run = oracle.OraRun(rob, base, dofvals, adofs, goal, grids, poses, oracle.default_params(start_tsr=st_arg, **kw))
+    cb = oracle.OraRun(rob, base, dofvals, adofs, goal, grids, poses, oracle.default_params(start_tsr=st_arg, **kw))
+    # a plain run whose first constraint is the start TSR's rows / the con_tsr's rows: evaluates them at any point
+    ev_s = oracle.OraRun(rob, base, dofvals, adofs, goal, grids, poses, oracle.default_params(**kw)); ev_s.add_contsr(li, ident, T0w, ident, Bw_s)
+    ev_c = None
+    if with_con:
+        run.add_contsr(li, ident, T0w, ident, Bw_c); cb.add_contsr(li, ident, T0w, ident, Bw_c)
+        ev_c = oracle.OraRun(rob, base, dofvals, adofs, goal, grids, poses, oracle.default_params(**kw)); ev_c.add_contsr(li, ident, T0w, ident, Bw_c)
+    assert run.m == run.n_points - 1
+    # the sphere term with the start point moving: the oracle's against the numpy restatement
+    T = run.traj().copy()
+    T[0:-1] += 0.05 * rng.normal(size=T[0:-1].shape)
+    cb.set_traj(T)
+    G, costs, P = cb.eval_obstacle()
+    G2, costs2, P2 = _numpy_sphere_cost(model, base, dofvals, adofs, T.copy(), cb.sphere_order(), cb.Sa, grids, poses,
+                                        0.1, 0.04, 100.0, 10.0, free_start=True)
+    scale = max(np.abs(G).max(), 1e-9)
+    assert G.shape[0] == run.n_points - 1 and np.allclose(costs, costs2, rtol=1e-9, atol=1e-12)
+    assert np.allclose(G, G2, rtol=2e-6, atol=2e-7 * scale), (seed, what, np.abs(G - G2).max(), scale)
+
+    def callback(Tq):
+        cb.set_traj(Tq)
+        Gq, cq, _ = cb.eval_obstacle()
+        return Gq.copy(), cq.copy()
+
+    def con_start(point):
+        h, J = ev_s.eval_contsr(0, point)
+        return h.copy(), J.copy()
+
+    def con_all(point):
+        h, J = ev_c.eval_contsr(0, point)
+        return h.copy(), J.copy()
+    lower = np.array([model.limit_lower[d] for d in adofs]); upper = np.array([model.limit_upper[d] for d in adofs])
+    mine = NumpyChomp(run.traj(), 1, lam, momentum, lower, upper, free_start=True)
+    assert np.allclose(run.mat("A", run.m, run.m), mine.A, rtol=1e-12, atol=0) and np.allclose(run.mat("B", run.m, run.n), mine.B, rtol=1e-12, atol=1e-300)
+    # the reference's list of constraints: the start TSR on point 0, then the con_tsr on every point (any order solves the same system)
+    cons = [(0, con_start)] + ([(i, con_all) for i in range(mine.m)] if with_con else [])
+    n_iter = int(rng.integers(3, 10))
+    worst = 0.0
+    for it in range(n_iter):
+        st, ocosts, otr = run.iterate(1, trace=True)
+        status, cobs, csm = mine.iterate(callback, cons)
+        assert status == st == 0, (seed, what, it, status, st)
+        assert np.allclose([cobs + csm, cobs, csm], otr[0], rtol=1e-7, atol=1e-12), (seed, what, it, [cobs + csm, cobs, csm], otr[0])
+        worst = max(worst, common.rel_l2(mine.T, run.traj()))
+    assert worst <= 1e-8, (seed, what, worst)
+    print("seed %d (%s): start rows %s%s, momentum %d, %d points, %d iterations: worst rel L2 %.1e" % (
+        seed, what, rows_s, " + rows %s on every point" % rows_c if with_con else "", momentum, kw["n_points"], n_iter, worst))
+    for r_ in (run, cb, ev_s, ev_c):
+        if r_ is not None:
+            r_.destroy()
