@@ -264,7 +264,10 @@ def run_workload(config, args, rank, world, device, dist, steps, warmup, serial_
         serial_1024 = (streams <= 1 and config in (2, 3) and 768 < n_runs <= 1024)
         mod.set_workgroup_threads(192 if serial_1024 else 0)
         wgs_auto = 4 if ((config in (2, 3) and not serial_1024) or config in ("tsr1", "tsr3")) else 0
-        mod.set_workgroups_per_cu(wgs_auto if args.workgroups_per_cu < 0 else args.workgroups_per_cu)
+        wgs = wgs_auto if args.workgroups_per_cu < 0 else args.workgroups_per_cu
+        mod.set_workgroups_per_cu(wgs)
+        knobs = {"orc_set_num_streams": streams if streams > 1 else 0, "orc_set_workgroup_threads": 192 if serial_1024 else 0,
+                 "orc_set_workgroups_per_cu": wgs}
         warm = [wl.create(mod, 900000 + k, rank) for k in range(warmup)]
         timed = [wl.create(mod, k, rank) for k in range(steps)]
         for bid in warm:
@@ -284,7 +287,8 @@ def run_workload(config, args, rank, world, device, dist, steps, warmup, serial_
         elapsed = sharding.max_over_ranks(t1 - t0, dist)
         iters = [mod.batch_iterations_done(bid) for bid in timed]
         kernel_ms, launches = mod.kernel_time()
-        return dict(elapsed=elapsed, own_elapsed=t1 - t0, iters=iters, ids=timed, results=results, kernel_ms=kernel_ms, launches=launches)
+        return dict(elapsed=elapsed, own_elapsed=t1 - t0, iters=iters, ids=timed, results=results, kernel_ms=kernel_ms, launches=launches,
+                    knobs=knobs)
 
     # ---- strictly serial launches on one stream (reported beside the headline) --------------------
     serial = None
@@ -346,20 +350,25 @@ def run_workload(config, args, rank, world, device, dist, steps, warmup, serial_
         otraj, ocosts, ost, _ = wl.oracle_run(O, idx, goals0, k_check)
         # Some runs of these workloads are chaotic in the reference algorithm itself (CHOMP bouncing off
         # joint limits amplifies rounding x4 per projection): the oracle run again
-        # with the goals moved by ONE ulp shows which, and how far such a run may legitimately drift.
+        # with the goals moved by ONE ulp (up, down) shows which, and how far such a run may legitimately drift
+        # (tests/common.py CHAOS_FACTOR, profiles/r04_chaos_ratio.txt).
         # Parity is quoted over the well-conditioned runs; the others are listed with both figures.
-        ptraj, _, pst, _ = wl.oracle_run(O, idx, goals0, k_check, scale=1.0 + 2.0 ** -52)
         errs = [wl.common.rel_l2(traj0[k], otraj[j]) for j, k in enumerate(idx)]
-        self_amp = [wl.common.rel_l2(ptraj[j], otraj[j]) for j in range(k_check)]
+        self_amp = [0.0] * k_check
+        pst = np.zeros(k_check, dtype=np.int64)
+        for f in wl.common.ULPS:
+            ptraj, _, ps, _ = wl.oracle_run(O, idx, goals0, k_check, scale=f)
+            self_amp = [max(self_amp[j], wl.common.rel_l2(ptraj[j], otraj[j])) for j in range(k_check)]
+            pst |= (np.asarray(ps) != 0)
         well = [j for j in range(k_check) if self_amp[j] < 1e-9 and ost[j] == 0 and pst[j] == 0 and st0[idx[j]] == 0]
         parity = max(errs[j] for j in well) if well else None
-        parity_ill = [{"run": int(idx[j]), "hip_vs_oracle": errs[j], "oracle_vs_oracle_goal_plus_one_ulp": self_amp[j],
+        parity_ill = [{"run": int(idx[j]), "hip_vs_oracle": errs[j], "oracle_vs_oracle_goal_plus_minus_one_ulp": self_amp[j],
                        "status_hip": int(st0[idx[j]]), "status_oracle": int(ost[j])}
                       for j in range(k_check) if j not in well]
         if parity is None or parity > parity_bound:
             rc = 3
         for j in range(k_check):
-            if j not in well and ost[j] == 0 and st0[idx[j]] == 0 and errs[j] > max(parity_bound, 5000.0 * self_amp[j]):
+            if j not in well and ost[j] == 0 and st0[idx[j]] == 0 and errs[j] > max(parity_bound, wl.common.CHAOS_FACTOR * self_amp[j]):
                 rc = 3
 
         if not args.no_cpu_baseline and world == 1:         # the CPU baseline is reported at N=1 only
@@ -405,11 +414,20 @@ def run_workload(config, args, rank, world, device, dist, steps, warmup, serial_
         # counters of profiles/ (rocprofv3 --pmc passes of this command, scripts/pmc_counters.sh)
         traffic = None
         valu = None
+        counters_note = "no counters under profiles/ for this workload"
         cpath = os.path.join(ROOT, "profiles", "counters_latest.json")
         if os.path.exists(cpath):
             try:
+                from or_cdchomp_amd import _capi
                 cj = json.load(open(cpath)).get("config%s" % (2 if config == 3 else config))
+                if cj and cj.get("csrc_hash") != _capi.csrc_hash():
+                    # counters of another build say nothing about this one
+                    counters_note = ("profiles/counters_latest.json was taken from build %s, this is build %s: traffic and valu_issue "
+                                     "are not quoted (scripts/profile_round.sh + scripts/summarize_profile.py renew them)"
+                                     % (cj.get("csrc_hash"), _capi.csrc_hash()))
+                    cj = None
                 if cj and cj.get("batch") == n_runs and cj.get("n_iter") == N_ITER:
+                    counters_note = "rocprofv3 --pmc passes of this build (%s), %s" % (cj.get("csrc_hash"), cj.get("source"))
                     traffic = cj.get("hbm_bytes_per_launch")
                     ipri = cj.get("valu_insts_per_run_iteration")
                     if ipri:
@@ -439,7 +457,12 @@ def run_workload(config, args, rank, world, device, dist, steps, warmup, serial_
             "dtype": wl.dtype,
             "data": "synthetic",
             "config": {"workload": wl.label, "runs_per_gpu": n_runs, "n_iter": N_ITER, "n_points": wl.m + 2, "dof": wl.n,
-                       "parallelism": "runs sharded over %d GPU(s) in contiguous blocks, no collective" % world},
+                       "parallelism": "runs sharded over %d GPU(s) in contiguous blocks, no collective" % world,
+                       # the module settings of each leg (include/orcdchomp_amd.h); a caller with the defaults (all 0) gets the
+                       # planner's own shape: trajectories are bit-identical, throughput a few per cent lower
+                       "knobs": {"value": main_leg["knobs"], "value_serial": None if serial is None else serial["knobs"]}},
+            "backend": None if dist is None else dist.get_backend(),
+            "dist_world_size": 1 if dist is None else dist.get_world_size(),
             "iterations_made": made, "iterations_nominal": nominal,
             "runs_outside_joint_limits": int((whole["status"] != 0).sum()),
             "runs_total": int(whole["status"].size),
@@ -468,7 +491,7 @@ def run_workload(config, args, rank, world, device, dist, steps, warmup, serial_
                          "algorithmic_bytes_per_launch": bytes_launch_nominal,
                          "algorithmic_bytes_launch_0_as_made": bytes_launch,
                          "algorithmic_bytes_per_iteration_per_run": bytes_iter,
-                         "valu_issue": valu},
+                         "valu_issue": valu, "counters": counters_note},
             "cpu_baseline": cpu,
             "parity_rel_l2_max_vs_oracle": parity, "parity_bound": parity_bound,
             "parity_runs_checked": k_check, "parity_ill_conditioned_runs": parity_ill,
@@ -482,6 +505,104 @@ def run_workload(config, args, rank, world, device, dist, steps, warmup, serial_
         mod.batch_destroy(bid)
     mod.close()
     return out, rc
+
+
+def batch_sweep(device, batches):
+    """BASELINE.json quotes the metric "batch swept": config 2's runs at other batch sizes, one launch at a time on one
+    stream (a launch ends with its slowest run).  Batches of at most 256 runs also with the latency shape
+    (orc_set_workgroup_threads(512): eight wavefronts on a run, one run per CU), which is what the single-run `create`
+    command uses by itself."""
+    import torch
+    import common
+    import or_cdchomp_amd
+    mod = or_cdchomp_amd.Module(device)
+    model = common.setup_product_wam(mod)
+    lines = []
+    for b in batches:
+        launches = 10 if b <= 64 else (3 if b <= 4096 else (2 if b <= 16384 else 1))
+        entry = {"batch": int(b), "launches": launches, "n_iter": N_ITER}
+        for name, threads in (("value", 0), ("value_latency_shape", 512)):
+            if threads and b > 256:
+                continue
+            wgs = 4 if b > 1024 else 0
+            mod.set_workgroup_threads(threads)
+            mod.set_workgroups_per_cu(wgs)
+            warm = mod.batch_create(model.name, common.wam_goals(b, seed=20250301 + b), **common.CONFIG2_KW)
+            mod.batch_iterate(warm, N_ITER)
+            mod.batch_destroy(warm)
+            ids = [mod.batch_create(model.name, common.wam_goals(b, seed=20250401 + 17 * b + k), **common.CONFIG2_KW) for k in range(launches)]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for bid in ids:
+                mod.batch_iterate_async(bid, N_ITER)
+            for bid in ids:
+                mod.batch_sync(bid)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            made = float(sum(mod.batch_iterations_done(bid).sum() for bid in ids))
+            for bid in ids:
+                mod.batch_destroy(bid)
+            entry[name] = made / (t1 - t0)
+            if not threads:
+                entry["ms_per_launch"] = (t1 - t0) / launches * 1e3
+                entry["iterations_made"] = made
+                entry["knobs"] = {"orc_set_num_streams": 0, "orc_set_workgroup_threads": 0, "orc_set_workgroups_per_cu": wgs}
+        lines.append(entry)
+    mod.close()
+    return {"workload": "config 2's runs (WAM 7-DOF, n_points=100, n_iter=100 per launch, costs every iteration) at other batch sizes, "
+                        "serial launches on one stream, wall clock around the launches incl. the copy-back of costs and status",
+            "unit": "CHOMP iterations/s", "sweep": lines}
+
+
+def stage_breakdown(device):
+    """The reference's own time breakdown (compile-time DEBUG_TIMING, src/orcdchomp_mod.cpp:2835-2847, src/libcd/chomp.c:446-456,
+    662-676) for config 2's batch, from the kernel's per-phase cycle counters (ORC_PHASE_TIMERS=1: s_memtime around the
+    phases of every iteration, one workgroup = one run).  The timers cost a few per cent, so this is a step of its own."""
+    import ctypes as C
+    import common
+    import or_cdchomp_amd
+    os.environ["ORC_PHASE_TIMERS"] = "1"
+    try:
+        mod = or_cdchomp_amd.Module(device)
+        model = common.setup_product_wam(mod)
+        n_runs = 1024
+        bid = mod.batch_create(model.name, common.wam_goals(n_runs, seed=20250101), **common.CONFIG2_KW)
+        mod.batch_iterate(bid, N_ITER)
+        ph = np.zeros((n_runs, 8))
+        mod._check(mod._lib.orc_batch_get_state(mod._h, bid, b"phase", ph.ctypes.data_as(C.POINTER(C.c_double)), ph.size))
+        it = mod.batch_iterations_done(bid).astype(np.float64) + 1.0          # + the final cost-only pass
+        mod.batch_destroy(bid)
+        mod.close()
+    finally:
+        os.environ.pop("ORC_PHASE_TIMERS", None)
+    cyc = ph[:, :6].sum(axis=0) / it.sum()                                    # cycles per run-iteration: FK, cost, obs-reduce, smooth+solve+step, limits, smooth cost
+    total = float(cyc.sum())
+    sec = lambda c: float(c) / CLOCK_HZ * N_ITER                              # seconds of 100 iterations of one run's workgroup
+    return {
+        "unit": "seconds one run's workgroup spends per 100 iterations (cycles / 2.4 GHz), mean over the 1024 runs of config 2; "
+                "three to four workgroups share a CU, so the shares, not the sums, compare with wall time",
+        "cycles_per_iteration": total,
+        "ticks_vels": 0.0,
+        "ticks_callback_pre": sec(cyc[0]),
+        "ticks_fk": sec(cyc[0]), "ticks_jacobians": 0.0, "ticks_pre_velsaccs": 0.0,
+        "ticks_callbacks": sec(cyc[1] + cyc[2]),
+        "ticks_selfcol": None,
+        "ticks_smoothgrad": sec(cyc[3]),
+        "ticks_joint_limits": sec(cyc[4]),
+        "ticks_smoothcost": sec(cyc[5]),
+        "share": {"ticks_callback_pre": float(cyc[0]) / total, "ticks_callbacks": float(cyc[1] + cyc[2]) / total,
+                  "ticks_smoothgrad": float(cyc[3]) / total, "ticks_joint_limits": float(cyc[4]) / total,
+                  "ticks_smoothcost": float(cyc[5]) / total},
+        "mapping": "ticks_vels: the dense velocity product (chomp.c:449-451) is dead work on this path and not made (SURVEY.md 8a M1). "
+                   "ticks_callback_pre = ticks_fk: the FK phase (sphere centres, joint axes and anchors of every waypoint); "
+                   "ticks_jacobians 0: the 3 x n sphere Jacobians are never formed (J^T is a wrench sum inside the cost pass); "
+                   "ticks_pre_velsaccs 0: the central differences are taken inside the cost pass from the positions in LDS. "
+                   "ticks_callbacks: the cost pass (field lookups, obstacle and self-collision forces, J^T) and its reduction; "
+                   "ticks_selfcol is inside it and has no timer of its own in the product build (-DORC_COST_TIMERS builds have: "
+                   "DESIGN.md section 3). ticks_smoothgrad: G += A T + B TOGETHER WITH what the reference leaves untimed: A^-1 G, "
+                   "the step (chomp.c:525-605); ticks_joint_limits: the projection rounds (chomp.c:608-655, untimed in the reference); "
+                   "ticks_smoothcost: chomp.c:660-677",
+    }
 
 
 def main():
@@ -499,13 +620,16 @@ def main():
     ap.add_argument("--serial-steps", type=int, default=-1, help="steps of the strictly serial leg (value_serial); default min(steps, 10)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-runs", type=int, default=0, help="override the cpu baseline sample size")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo for a "
-                                                      "single-GPU rehearsal of the multi-rank path)")
+    ap.add_argument("--backend", default="gloo", help="torch.distributed backend for N>1.  The path has no data-path collective "
+                                                      "(north_star: host-side gather only): a barrier, one max-reduce of the elapsed "
+                                                      "time and the gather of results, all on the host (gloo).  nccl (= RCCL) is optional")
     ap.add_argument("--workgroups-per-cu", type=int, default=-1, help="register budget of the batches (orc_set_workgroups_per_cu): 0 or 4; "
                                                                       "default: 4 for the overlapping / large-batch legs of configs 2 and 3")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="default run only (N = 1, config 2): do not append the config 4 and config 5 lines")
     ap.add_argument("--other-steps", type=int, default=5, help="steps of each `other_configs` line")
+    ap.add_argument("--no-sweep", action="store_true", help="default run only: do not append `batch_sweep`, `tsr1` and `stages`")
+    ap.add_argument("--sweep-batches", default="1,64,4096,16384,65536", help="batch sizes of `batch_sweep`")
     ap.add_argument("--dump-gather", default="", help="N > 1: rank 0 saves the gathered step-0 trajectories here (.npy)")
     args = ap.parse_args()
     if args.gpus < 1:
@@ -548,6 +672,13 @@ def main():
             others.append(line)
             rc = rc or rc_c
         out["other_configs"] = others
+        # the rest of the metric under the same clock: the batch sweep, the TSR-constrained line, the reference's stage names
+        if not args.no_sweep:
+            out["batch_sweep"] = batch_sweep(device, [int(b) for b in args.sweep_batches.split(",")])
+            line, rc_c = run_workload("tsr1", args, rank, world, device, dist, args.other_steps, 1, min(args.other_steps, 3))
+            out["tsr1"] = line
+            rc = rc or rc_c
+            out["stages"] = stage_breakdown(device)
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

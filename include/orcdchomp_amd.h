@@ -136,6 +136,31 @@ int orc_env_add_kinbody_boxes(orc_module * mod, const char * name, int n_boxes,
    const double * box_poses, const double * half_extents);
 int orc_kinbody_set_transform(orc_module * mod, const char * name, const double pose[7]);
 int orc_kinbody_enable(orc_module * mod, const char * name, int enabled);
+/* KinBody::GetTransform of a robot or kinbody; a kinbody the robot holds is where its link carries it now */
+int orc_body_get_transform(orc_module * mod, const char * name, double pose_out[7]);
+
+/* ---- grabbed bodies ----------------------------------------------------------
+ * mod::create collects the spheres of the robot AND of every kinbody the robot is grabbing
+ * (src/orcdchomp_mod.cpp:2168-2300: r->robot->GetGrabbed(), the body's <orcdchomp> kdata, the link
+ * r->robot->IsGrabbing(k)); carrying an object is the planner's normal use.  The stand-ins for what the
+ * reference asks OpenRAVE: */
+/* the <orcdchomp><spheres> data of a kinbody (src/orcdchomp_kdata.cpp:79-94; the stand-in's kinbodies have one
+ * link, so the sphere's link attribute is that link): sphere_pos [n_spheres][3] in the kinbody frame */
+int orc_kinbody_set_spheres(orc_module * mod, const char * name, int n_spheres, const double * sphere_pos,
+   const double * sphere_radius);
+/* RobotBase::Grab(body, link): from now on the kinbody is rigid with robot link `link` at its current relative
+ * transform (orc_robot_set_dof_values / orc_robot_set_transform carry it along) and a `create` for this robot
+ * adds the body's spheres to the run: each rides on `link` at T_w_rlink^-1 o T_w_klink o pos
+ * (src/orcdchomp_mod.cpp:2200-2208), active when an active dof moves `link` (2265-2291); the run's sphere list is the
+ * last grabbed body's spheres first and the robot's last, as the head insertion of 2273-2290 leaves it.  XML
+ * sphere indices reported by the collision verdict count through the robot's spheres, then the held bodies' in the
+ * order they were grabbed.  A held body (or the robot) without spheres makes `create` fail with the reference's
+ * "no spheres! kinbody does not have a <orcdchomp> tag defined?" (2262-2263).  The re-check of gettraj includes the
+ * spheres a run was created with (the reference's note at 2992-2996).  A run keeps the spheres it was created with. */
+int orc_robot_grab(orc_module * mod, const char * robot, const char * kinbody, int link);
+/* RobotBase::Release(body) / ReleaseAllGrabbed(): the body stays where the link left it */
+int orc_robot_release(orc_module * mod, const char * robot, const char * kinbody);
+int orc_robot_release_all(orc_module * mod, const char * robot);
 
 /* ---- SDF access --------------------------------------------------------------
  * the module's field list (struct sdf, src/orcdchomp_mod.cpp:148-153) */

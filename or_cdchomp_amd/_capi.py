@@ -56,6 +56,11 @@ SYMBOLS = [
     ("orc_env_add_kinbody_boxes", C.c_int, [C.c_void_p, C.c_char_p, C.c_int, c_double_p, c_double_p]),
     ("orc_kinbody_set_transform", C.c_int, [C.c_void_p, C.c_char_p, c_double_p]),
     ("orc_kinbody_enable", C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    ("orc_body_get_transform", C.c_int, [C.c_void_p, C.c_char_p, c_double_p]),
+    ("orc_kinbody_set_spheres", C.c_int, [C.c_void_p, C.c_char_p, C.c_int, c_double_p, c_double_p]),
+    ("orc_robot_grab", C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int]),
+    ("orc_robot_release", C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),
+    ("orc_robot_release_all", C.c_int, [C.c_void_p, C.c_char_p]),
     ("orc_scene_add_sdf", C.c_int, [C.c_void_p, C.c_char_p, c_int_p, c_double_p, c_double_p, c_double_p]),
     ("orc_scene_get_sdf", C.c_int, [C.c_void_p, C.c_char_p, c_int_p, c_double_p, c_double_p, c_double_p, C.c_size_t]),
     ("orc_batch_params_default", None, [C.POINTER(BatchParams)]),
@@ -88,6 +93,20 @@ SYMBOLS = [
 ]
 
 _LIB = None
+
+
+def csrc_hash():
+    """fingerprint of the kernel and host sources the library is built from (csrc/*, the header): profiles carry it so that
+    counters taken from another build are not quoted for this one (bench.py, scripts/summarize_profile.py)"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h")) +
+                   glob.glob(os.path.join(_HERE, "csrc", "*.cpp")) + [os.path.join(_HERE, "csrc", "Makefile")])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def build():

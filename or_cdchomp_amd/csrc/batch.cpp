@@ -581,6 +581,14 @@ void BatchShard::build_device(const Robot & robot)
          std::memcpy(&bits, &v, sizeof(bits));
          key += std::to_string(bits) + ",";
       }
+      {
+         // ... and the spheres themselves: the same robot holding a body is another row of spheres
+         unsigned long long h = 1469598103934665603ull;
+         auto mix = [&h](const void * p, size_t nb) { const unsigned char * c = (const unsigned char *) p; for (size_t i=0; i<nb; i++) { h ^= c[i]; h *= 1099511628211ull; } };
+         for (const Robot::Sphere & sp : robot.spheres) { mix(&sp.link, sizeof(sp.link)); mix(sp.pos, sizeof(sp.pos)); mix(&sp.radius, sizeof(sp.radius)); }
+         key += "|h" + std::to_string(h);
+      }
+      std::lock_guard<std::recursive_mutex> env_lock(mod_->env_mutex);
       auto hit = mod_->placement_cache.find(key);
       if (hit == mod_->placement_cache.end() || (int) hit->second.size() != Sa + n_static)
          hit = mod_->placement_cache.insert_or_assign(key, place_spheres_on_row(robot, params.epsilon_self, xml_of)).first;
@@ -760,6 +768,7 @@ void BatchShard::build_device(const Robot & robot)
    {
       Sdf & s = *mod_->sdfs[i];
       const size_t nc = s.grid.ncells();
+      std::lock_guard<std::recursive_mutex> env_lock(mod_->env_mutex);      // (the device copies are shared by the shards)
       if (sizeof(real) == 8)
       {
          std::shared_ptr<void> & buf = s.dev64[device];
@@ -1412,15 +1421,22 @@ Batch::Batch(Module * mod, const std::vector<int> & devices, const Robot & robot
       const int base = n_runs / world, extra = n_runs % world;
       offs[r+1] = offs[r] + base + (r < extra ? 1 : 0);
    }
+   std::vector<hipStream_t> streams(world);
    for (int r=0; r<world; r++)
    {
-      const size_t lo = (size_t) offs[r];
       bool repeated = false;                      // a device listed twice: its shards get streams of their own
       for (int q=0; q<world; q++) if (q != r && devices[q] == devices[r]) repeated = true;
-      shards.emplace_back(new BatchShard(mod, devices[r], mod->pick_stream(devices[r], repeated), robot, p, offs[r+1] - offs[r],
+      streams[r] = mod->pick_stream(devices[r], repeated);
+   }
+   // one host thread per shard builds it on its device (model fold, uploads, seed kernel); what the shards share in the
+   // module (the placement cache, the fields' device copies, the event pool) is behind its mutexes
+   shards.resize(world);
+   for_shards([&](size_t r) {
+      const size_t lo = (size_t) offs[r];
+      shards[r].reset(new BatchShard(mod, devices[r], streams[r], robot, p, offs[r+1] - offs[r],
          starts ? starts + lo * n_adof : nullptr, goals + lo * n_adof, basegoals ? basegoals + lo * 7 : nullptr,
          seeds ? seeds + lo : nullptr));
-   }
+   }, true);
    const BatchShard & s0 = *shards[0];
    n_points = s0.n_points; n = s0.n; m = s0.m;
    robot_name = s0.robot_name; adofindices = s0.adofindices;
@@ -1448,16 +1464,18 @@ void Batch::iterate_async(int n_iter, int iter_begin, bool final_eval, bool carr
 {
    if (n_iter < 0) throw std::runtime_error("n_iter must be >=0!");
    last_n_iter = n_iter;
-   // the hmc plan of a shard waits for its device: those go on one host thread per shard
-   for_shards([&](size_t k) { shards[k]->iterate_async(n_iter, iter_begin, final_eval, carry); }, params.use_hmc != 0);
+   // one host thread per shard: each asserts its device and launches there (the hmc plan of a shard may wait for its device)
+   for_shards([&](size_t k) { shards[k]->iterate_async(n_iter, iter_begin, final_eval, carry); }, true);
 }
 
 void Batch::sync(double * costs_out, int * status_out, int * iters_out)
 {
-   for (size_t k=0; k<shards.size(); k++)
+   // the host-side gather: every shard copies its block straight into the caller's arrays
+   for_shards([&](size_t k) {
       shards[k]->sync_begin(costs_out ? costs_out + (size_t) offs[k]*3 : nullptr, status_out ? status_out + offs[k] : nullptr,
                             iters_out ? iters_out + offs[k] : nullptr);
-   for (size_t k=0; k<shards.size(); k++) shards[k]->sync_end();
+      shards[k]->sync_end();
+   }, true);
 }
 
 void Batch::gettraj(double * out)

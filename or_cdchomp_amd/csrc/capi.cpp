@@ -279,6 +279,48 @@ int orc_kinbody_set_transform(orc_module * mod, const char * name, const double 
    return guarded(mod, [&] { need(pose, "pose"); mod->impl->kinbody(str(name, "name")).transform = orc::Pose(pose); });
 }
 
+int orc_kinbody_set_spheres(orc_module * mod, const char * name, int n_spheres, const double * sphere_pos, const double * sphere_radius)
+{
+   return guarded(mod, [&] {
+      orc::KinBody & k = mod->impl->kinbody(str(name, "name"));
+      if (n_spheres < 0) throw std::runtime_error("bad number of spheres!");
+      if (n_spheres) { need(sphere_pos, "sphere_pos"); need(sphere_radius, "sphere_radius"); }
+      k.spheres.clear();
+      for (int i=0; i<n_spheres; i++)
+      {
+         orc::Robot::Sphere sp;
+         sp.link = 0; sp.radius = sphere_radius[i];
+         for (int q=0; q<3; q++) sp.pos[q] = sphere_pos[3*i+q];
+         k.spheres.push_back(sp);
+      }
+   });
+}
+
+int orc_robot_grab(orc_module * mod, const char * robot, const char * kinbody, int link)
+{
+   return guarded(mod, [&] { mod->impl->grab(str(robot, "robot"), str(kinbody, "kinbody"), link); });
+}
+
+int orc_robot_release(orc_module * mod, const char * robot, const char * kinbody)
+{
+   return guarded(mod, [&] { mod->impl->release(str(robot, "robot"), str(kinbody, "kinbody")); });
+}
+
+int orc_robot_release_all(orc_module * mod, const char * robot)
+{
+   return guarded(mod, [&] { mod->impl->release_all(str(robot, "robot")); });
+}
+
+int orc_body_get_transform(orc_module * mod, const char * name, double pose_out[7])
+{
+   return guarded(mod, [&] {
+      need(pose_out, "pose_out");
+      if (!mod->impl->has_body(str(name, "name"))) throw std::runtime_error("Could not find kinbody with that name!");
+      const orc::Pose p = mod->impl->body_transform(name);
+      for (int i=0; i<7; i++) pose_out[i] = p.v[i];
+   });
+}
+
 int orc_kinbody_enable(orc_module * mod, const char * name, int enabled)
 {
    return guarded(mod, [&] { mod->impl->kinbody(str(name, "name")).enabled = enabled != 0; });

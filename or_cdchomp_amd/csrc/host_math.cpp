@@ -103,6 +103,34 @@ Xform xform_mul(const Xform & a, const Xform & b)
    return c;
 }
 
+Xform xform_inverse(const Xform & a)
+{
+   // solve [R | t] by elimination with partial pivoting on the augmented rows [R | I]
+   double w[3][6];
+   for (int i=0; i<3; i++)
+      for (int j=0; j<3; j++) { w[i][j] = a.R.m[3*i+j]; w[i][3+j] = (i == j) ? 1.0 : 0.0; }
+   for (int c=0; c<3; c++)
+   {
+      int piv = c;
+      for (int i=c+1; i<3; i++) if (std::fabs(w[i][c]) > std::fabs(w[piv][c])) piv = i;
+      if (piv != c) for (int j=0; j<6; j++) std::swap(w[c][j], w[piv][j]);
+      const double d = w[c][c];
+      for (int j=0; j<6; j++) w[c][j] /= d;
+      for (int i=0; i<3; i++)
+      {
+         if (i == c) continue;
+         const double f = w[i][c];
+         for (int j=0; j<6; j++) w[i][j] -= f * w[c][j];
+      }
+   }
+   Xform inv;
+   for (int i=0; i<3; i++) for (int j=0; j<3; j++) inv.R.m[3*i+j] = w[i][3+j];
+   double r[3];
+   mat3_vec(inv.R, a.t, r);
+   for (int i=0; i<3; i++) inv.t[i] = -r[i];
+   return inv;
+}
+
 Mat3 axis_angle(const double a[3], double q)
 {
    const double c = std::cos(q), s = std::sin(q), v = 1.0 - c;

@@ -33,6 +33,8 @@ void pose_normalize(Pose & p);                            // src/libcd/kin.c:64-
 void pose_apply(const Pose & ab, const double in[3], double out[3]); // kin.c:180-212
 Xform xform_from_pose(const Pose & p);                    // via quat_to_R
 Xform xform_mul(const Xform & a, const Xform & b);
+// inverse of a frame whose 3x3 part need not be orthonormal (a base quaternion that is not of unit length scales it)
+Xform xform_inverse(const Xform & a);
 Mat3 mat3_mul(const Mat3 & a, const Mat3 & b);
 void mat3_vec(const Mat3 & a, const double v[3], double out[3]);
 Mat3 axis_angle(const double axis[3], double q);

@@ -289,8 +289,79 @@ Pose Module::body_transform(const std::string & name) const
    auto r = robots_.find(name);
    if (r != robots_.end()) return r->second.transform;
    auto k = kinbodies_.find(name);
-   if (k != kinbodies_.end()) return k->second.transform;
+   if (k != kinbodies_.end())
+   {
+      // a held body moves with the link that holds it (OpenRAVE updates grabbed bodies with the robot's state)
+      for (const auto & kv : robots_)
+         for (const Robot::Grab & g : kv.second.grabbed)
+            if (g.body == name)
+            {
+               std::vector<Xform> frames;
+               kv.second.fk(kv.second.transform, kv.second.dof_values, frames);
+               const Xform now = xform_mul(frames[g.link], g.rel);
+               return pose_from_dR(now.t, now.R);
+            }
+      return k->second.transform;
+   }
    throw std::runtime_error("KinBody " + name + " referenced by active signed distance field does not exist!\n");
+}
+
+void Module::grab(const std::string & rname, const std::string & body, int link)
+{
+   Robot & r = robot(rname);
+   KinBody & k = kinbody(body);
+   if (link < 0 || link >= r.n_links) throw std::runtime_error("grabbing link out of range!");
+   for (const auto & kv : robots_)
+      for (const Robot::Grab & g : kv.second.grabbed)
+         if (g.body == body) throw std::runtime_error("that kinbody is already grabbed!");
+   std::vector<Xform> frames;
+   r.fk(r.transform, r.dof_values, frames);
+   Robot::Grab g;
+   g.body = body; g.link = link;
+   g.rel = xform_mul(xform_inverse(frames[link]), xform_from_pose(k.transform));
+   r.grabbed.push_back(g);
+}
+
+void Module::release(const std::string & rname, const std::string & body)
+{
+   Robot & r = robot(rname);
+   for (size_t i=0; i<r.grabbed.size(); i++)
+      if (r.grabbed[i].body == body)
+      {
+         kinbody(body).transform = body_transform(body);      // the body stays where the link left it
+         r.grabbed.erase(r.grabbed.begin() + i);
+         return;
+      }
+   throw std::runtime_error("the robot is not grabbing that kinbody!");
+}
+
+void Module::release_all(const std::string & rname)
+{
+   Robot & r = robot(rname);
+   while (!r.grabbed.empty()) release(rname, r.grabbed.back().body);
+}
+
+Robot Module::robot_for_run(const std::string & rname)
+{
+   Robot eff = robot(rname);
+   // a body without spheres, the robot itself included (src/orcdchomp_mod.cpp:2262-2263)
+   if (eff.spheres.empty()) throw std::runtime_error("no spheres! kinbody does not have a <orcdchomp> tag defined?");
+   for (const Robot::Grab & g : eff.grabbed)
+   {
+      const KinBody & k = kinbody(g.body);
+      if (k.spheres.empty()) throw std::runtime_error("no spheres! kinbody does not have a <orcdchomp> tag defined?");
+      for (const Robot::Sphere & ks : k.spheres)
+      {
+         // T_w_rlink^-1 o T_w_klink o pos (mod.cpp:2200-2208); the held body is rigid with its link, so the product of
+         // the first two is what the grab recorded
+         Robot::Sphere sp;
+         sp.link = g.link; sp.radius = ks.radius;
+         mat3_vec(g.rel.R, ks.pos, sp.pos);
+         for (int q=0; q<3; q++) sp.pos[q] += g.rel.t[q];
+         eff.spheres.push_back(sp);
+      }
+   }
+   return eff;
 }
 
 Sdf * Module::find_sdf(const std::string & kinbody)
@@ -315,7 +386,7 @@ int Module::create_batch(const std::string & rname, const BatchParams & p, int n
    const double * starts, const double * goals, const double * basegoals, const unsigned int * seeds,
    const std::vector<int> * devices_override)
 {
-   Robot & r = robot(rname);
+   const Robot r = robot_for_run(rname);
    if (devices_override)
    {
       int count = 0;
@@ -323,6 +394,7 @@ int Module::create_batch(const std::string & rname, const BatchParams & p, int n
       for (int d : *devices_override) if (d < 0 || d >= count) throw std::runtime_error("orcdchomp_amd: bad device ordinal");
    }
    std::unique_ptr<Batch> b(new Batch(this, devices_override ? *devices_override : devices, r, p, n_runs, starts, goals, basegoals, seeds));
+   b->run_spheres = r.spheres;
    const int id = next_batch_id_++;
    batches_[id] = std::move(b);
    return id;
@@ -1099,7 +1171,8 @@ void Module::batch_collision_verdict(int id, int * collides, double * time, int 
 {
    Batch & b = batch(id);
    const int col0 = b.params.floating_base ? 7 : 0;
-   Robot & rob = robot(b.robot_name);
+   Robot rob = robot(b.robot_name);
+   rob.spheres = b.run_spheres;         // the robot's and those of the bodies it held at create (mod.cpp:2992-2996)
    std::vector<double> vmax;
    for (int a : b.adofindices) vmax.push_back(a < (int) rob.limit_vel.size() ? rob.limit_vel[a] : 1.0);
    std::vector<double> traj((size_t) b.n_runs * b.n_points * b.n);
@@ -1188,7 +1261,8 @@ std::string Module::cmd_gettraj(const std::vector<std::string> & argv, bool batc
       return "";
    }
    const int col0 = b.params.floating_base ? 7 : 0;
-   Robot & rob = robot(b.robot_name);
+   Robot rob = robot(b.robot_name);
+   rob.spheres = b.run_spheres;
    std::vector<double> vmax;
    for (int a : b.adofindices) vmax.push_back(a < (int) rob.limit_vel.size() ? rob.limit_vel[a] : 1.0);
    // timing (mod.cpp:2905-2911)

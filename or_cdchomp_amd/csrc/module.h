@@ -39,6 +39,10 @@ struct Robot                      // what the path reads from an OpenRAVE::Robot
    std::vector<Manip> manips;
    int active_manip = 0;                       // GetActiveManipulator
    std::vector<std::pair<int, int>> adjacent;  // link pairs the robot description declares adjacent (<adjacent> tags)
+   // kinbodies the robot holds, in the order they were grabbed (RobotBase::Grab / GetGrabbed, src/orcdchomp_mod.cpp:2168-2171):
+   // the body is rigid with `link` from the moment of the grab, `rel` = T_w_link^-1 o T_w_body at that moment
+   struct Grab { std::string body; int link; Xform rel; };
+   std::vector<Grab> grabbed;
    // state
    Pose transform;
    std::vector<double> dof_values;
@@ -59,6 +63,9 @@ struct KinBody                    // box-only kinbody (InitFromBoxes style)
    bool enabled = true;
    struct B { Pose pose; double half[3]; };
    std::vector<B> boxes;
+   // <orcdchomp><spheres> of the kinbody (src/orcdchomp_kdata.cpp:79-94), in its own frame (one link): what create
+   // reads from a body the robot holds (src/orcdchomp_mod.cpp:2173-2211); `link` is unused
+   std::vector<Robot::Sphere> spheres;
 };
 
 // makes `device` the calling thread's current HIP device for the lifetime of the object
@@ -241,6 +248,7 @@ public:
    std::vector<int> adofindices;
    std::vector<int> device_sphere_order;
    std::vector<int> slot_xml;
+   std::vector<Robot::Sphere> run_spheres;   // the spheres create collected (robot + held bodies): what the XML indices count through
    std::vector<std::unique_ptr<BatchShard>> shards;
    std::vector<int> offs;            // first run of every shard, then n_runs
    bool has_dat() const { return !dat_.empty(); }
@@ -265,7 +273,14 @@ public:
    void add_kinbody(const KinBody & k);
    KinBody & kinbody(const std::string & name);
    bool has_body(const std::string & name) const;
-   Pose body_transform(const std::string & name) const;   // robot or kinbody
+   Pose body_transform(const std::string & name) const;   // robot or kinbody (a held kinbody: where its link carries it now)
+   // RobotBase::Grab(body, link) / Release(body) / ReleaseAllGrabbed()
+   void grab(const std::string & robot, const std::string & body, int link);
+   void release(const std::string & robot, const std::string & body);
+   void release_all(const std::string & robot);
+   // the robot as create collects its spheres (src/orcdchomp_mod.cpp:2148-2300): its own in XML order, then those of
+   // every held body in GetGrabbed() order, each on the link that holds the body at T_w_rlink^-1 o T_w_klink o pos
+   Robot robot_for_run(const std::string & name);
 
    // fields
    void add_sdf(const std::string & kinbody, const Grid & sdf, const Pose & pose_kinbody_gsdf);
@@ -275,6 +290,9 @@ public:
    // lane placement of a robot's active spheres (place_spheres_on_row): a pure function of the robot
    // (geometry, limits, frozen dof values), the active dofs, floating base and epsilon_self
    std::map<std::string, std::vector<int>> placement_cache;
+   // the shards of a batch are built on host threads of their own (Batch::Batch): the placement cache and the fields'
+   // device copies (Sdf::dev64 / dev32) are taken under this
+   std::recursive_mutex env_mutex;
 
    // batches
    int create_batch(const std::string & robot, const BatchParams & p, int n_runs,

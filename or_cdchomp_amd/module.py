@@ -148,6 +148,29 @@ class Module:
     def set_kinbody_transform(self, name, pose):
         self._check(self._lib.orc_kinbody_set_transform(self._h, name.encode(), _dp(_f64(pose))))
 
+    def body_transform(self, name):
+        """GetTransform of a robot or kinbody (a held kinbody: where its link carries it now)"""
+        pose = np.zeros(7)
+        self._check(self._lib.orc_body_get_transform(self._h, name.encode(), _dp(pose)))
+        return pose
+
+    def set_kinbody_spheres(self, name, pos, radius):
+        """the <orcdchomp><spheres> data of a kinbody: what `create` reads from a body the robot holds"""
+        pos = _f64(pos).reshape(-1, 3); radius = _f64(radius).reshape(-1)
+        assert len(pos) == len(radius)
+        self._check(self._lib.orc_kinbody_set_spheres(self._h, name.encode(), len(radius), _dp(pos), _dp(radius)))
+
+    def grab(self, robot, kinbody, link):
+        """RobotBase::Grab(body, link): link = robot link index"""
+        self._check(self._lib.orc_robot_grab(self._h, robot.encode(), kinbody.encode(), int(link)))
+
+    def release(self, robot, kinbody=None):
+        """RobotBase::Release(body), or ReleaseAllGrabbed() without a body"""
+        if kinbody is None:
+            self._check(self._lib.orc_robot_release_all(self._h, robot.encode()))
+        else:
+            self._check(self._lib.orc_robot_release(self._h, robot.encode(), kinbody.encode()))
+
     def enable_kinbody(self, name, enabled=True):
         self._check(self._lib.orc_kinbody_enable(self._h, name.encode(), 1 if enabled else 0))
 

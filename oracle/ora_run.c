@@ -115,6 +115,9 @@ struct ora_run              /* src/orcdchomp_mod.cpp:887-966 */
    double epsilon, epsilon_self, obs_factor, obs_factor_self;
    run_sphere * spheres;    /* array, first n_spheres_active are active */
    int n_spheres, n_spheres_active;
+   /* the spheres create collected, robot first, then the grabbed bodies in GetGrabbed() order, each in XML order
+    * (xml_index counts through this list); a grabbed body's spheres sit on the grabbing link */
+   int * eff_link; double * eff_pos; double * eff_radius;
    double * sphere_poss_inactive;
    double * sphere_poss_all;
    double * sphere_poss;
@@ -419,6 +422,7 @@ static void run_free(ora_run * r)
 {
    if (!r) return;
    free(r->traj); free(r->dofvals); free(r->adofindices); free(r->spheres);
+   free(r->eff_link); free(r->eff_pos); free(r->eff_radius);
    free(r->sphere_poss_inactive); free(r->sphere_poss_all); free(r->sphere_vels);
    free(r->sphere_accs); free(r->sphere_jacs); free(r->J2); free(r->rsdfs);
    free(r->fkR); free(r->fkt); free(r->fkaxis); free(r->fkanchor);
@@ -619,37 +623,96 @@ ora_run * ora_run_create(const ora_robot * rob, const double base_pose[7], const
    memcpy(r->adofindices, adofindices, n_adof * sizeof(int));
    n = (r->floating_base ? 7 : 0) + n_adof;                       /* mod.cpp:2104-2105 */
 
-   /* spheres: active ones first, in XML order; inactive appended */
-   is_active = (int *) malloc((rob->n_spheres ? rob->n_spheres : 1) * sizeof(int));
-   n_act = 0;
-   for (si=0; si<rob->n_spheres; si++)
+   /* spheres of the robot and of every grabbed body (mod.cpp:2148-2300).  Body i = 0 is the robot, the others
+    * follow in GetGrabbed() order (2168-2171).  A body without spheres is an error (2262-2263), also the robot. */
    {
-      int act = r->floating_base ? 1 : 0;
-      for (j=0; j<n_adof && !act; j++)
-         if (ora_robot_does_affect(rob, adofindices[j], rob->sphere_link[si])) act = 1;
-      is_active[si] = act;
-      n_act += act;
-   }
-   n_inact = rob->n_spheres - n_act;
-   if (!n_act) { free(is_active); run_free(r); *errmsg = "robot active dofs must have at least one sphere!"; return 0; }
-   r->n_spheres = rob->n_spheres;
-   r->n_spheres_active = n_act;
-   r->spheres = (run_sphere *) calloc(rob->n_spheres, sizeof(run_sphere));
-   {
-      int ia = 0, ii = n_act;
-      /* the kdata list reverses XML order and the head insertion in create reverses it
-       * again for active spheres (XML order); inactive ones are head-inserted once more
-       * on an (uninitialised, treated as NULL) list, i.e. reversed kdata order = XML order */
+      int n_eff = rob->n_spheres, gi, k, * eff_body;
+      for (gi=0; gi<rob->n_grabbed; gi++) n_eff += rob->grabbed[gi].n_spheres;
+      if (!rob->n_spheres) { run_free(r); *errmsg = "no spheres! kinbody does not have a <orcdchomp> tag defined?"; return 0; }
+      for (gi=0; gi<rob->n_grabbed; gi++)
+         if (!rob->grabbed[gi].n_spheres) { run_free(r); *errmsg = "no spheres! kinbody does not have a <orcdchomp> tag defined?"; return 0; }
+      r->eff_link = (int *) malloc((size_t) n_eff * sizeof(int));
+      r->eff_pos = (double *) malloc((size_t) n_eff * 3 * sizeof(double));
+      r->eff_radius = (double *) malloc((size_t) n_eff * sizeof(double));
+      eff_body = (int *) malloc((size_t) n_eff * sizeof(int));
       for (si=0; si<rob->n_spheres; si++)
       {
-         run_sphere * s = is_active[si] ? &r->spheres[ia++] : &r->spheres[ii++];
-         s->radius = rob->sphere_radius[si];
-         s->robot_linkindex = rob->sphere_link[si];
-         memcpy(s->pos_wrt_link, rob->sphere_pos + 3*si, 3*sizeof(double));
-         s->xml_index = si;
+         r->eff_link[si] = rob->sphere_link[si];
+         memcpy(r->eff_pos + 3*si, rob->sphere_pos + 3*si, 3*sizeof(double));
+         r->eff_radius[si] = rob->sphere_radius[si];
+         eff_body[si] = 0;
       }
+      if (rob->n_grabbed)
+      {
+         /* T_w_rlink.inverse() * T_w_klink * pos with the transforms of the moment of create (2200-2208).  The link
+          * frames of this model are 3x4 matrices (a base quaternion that is not of unit length scales them, as in
+          * kin.c's expanded form), so the inverse is the matrix inverse */
+         double * R = (double *) malloc((size_t) rob->n_links * 9 * sizeof(double));
+         double * t = (double *) malloc((size_t) rob->n_links * 3 * sizeof(double));
+         ora_robot_fk(rob, base_pose, dofvals, R, t, 0, 0);
+         for (gi=0; gi<rob->n_grabbed; gi++)
+         {
+            const ora_grabbed * g = &rob->grabbed[gi];
+            const double * A = R + 9*g->robot_link;
+            double inv[9], det, Rk[3][3];
+            inv[0] = A[4]*A[8] - A[5]*A[7]; inv[1] = A[2]*A[7] - A[1]*A[8]; inv[2] = A[1]*A[5] - A[2]*A[4];
+            inv[3] = A[5]*A[6] - A[3]*A[8]; inv[4] = A[0]*A[8] - A[2]*A[6]; inv[5] = A[2]*A[3] - A[0]*A[5];
+            inv[6] = A[3]*A[7] - A[4]*A[6]; inv[7] = A[1]*A[6] - A[0]*A[7]; inv[8] = A[0]*A[4] - A[1]*A[3];
+            det = A[0]*inv[0] + A[1]*inv[3] + A[2]*inv[6];
+            for (k=0; k<9; k++) inv[k] /= det;
+            /* OpenRAVE's Transform * Vector rotates with the unit-quaternion matrix (geometry.h), the form this model's
+             * link frames are made of (ora_robot_fk), not libcd's expanded one */
+            ora_kin_quat_to_R(g->pose_world_klink + 3, Rk);
+            for (k=0; k<g->n_spheres; k++, si++)
+            {
+               double pw[3], d[3];
+               mat3_vec(&Rk[0][0], g->sphere_pos + 3*k, pw);
+               for (j=0; j<3; j++) d[j] = pw[j] + g->pose_world_klink[j] - t[3*g->robot_link + j];
+               mat3_vec(inv, d, r->eff_pos + 3*si);
+               r->eff_link[si] = g->robot_link;
+               r->eff_radius[si] = g->sphere_radius[k];
+               eff_body[si] = 1 + gi;
+            }
+         }
+         free(R); free(t);
+      }
+
+      /* active / inactive (2265-2291): is the sphere's robot link moved by an active dof */
+      is_active = (int *) malloc((size_t) n_eff * sizeof(int));
+      n_act = 0;
+      for (si=0; si<n_eff; si++)
+      {
+         int act = r->floating_base ? 1 : 0;
+         for (j=0; j<n_adof && !act; j++)
+            if (ora_robot_does_affect(rob, adofindices[j], r->eff_link[si])) act = 1;
+         is_active[si] = act;
+         n_act += act;
+      }
+      n_inact = n_eff - n_act;
+      if (!n_act) { free(is_active); free(eff_body); run_free(r); *errmsg = "robot active dofs must have at least one sphere!"; return 0; }
+      r->n_spheres = n_eff;
+      r->n_spheres_active = n_act;
+      r->spheres = (run_sphere *) calloc((size_t) n_eff, sizeof(run_sphere));
+      {
+         int ia = 0, ii = n_act, body;
+         /* The kdata list reverses a body's XML order and the head insertion in create reverses it again: a body's
+          * spheres end in XML order.  Bodies are walked robot first and each body's spheres go to the HEAD of the
+          * list, active and inactive alike (2273-2290; s_inactive_head is uninitialised there, treated as NULL):
+          * the last grabbed body comes first, the robot last */
+         for (body=rob->n_grabbed; body>=0; body--)
+            for (si=0; si<n_eff; si++)
+            {
+               run_sphere * s;
+               if (eff_body[si] != body) continue;
+               s = is_active[si] ? &r->spheres[ia++] : &r->spheres[ii++];
+               s->radius = r->eff_radius[si];
+               s->robot_linkindex = r->eff_link[si];
+               memcpy(s->pos_wrt_link, r->eff_pos + 3*si, 3*sizeof(double));
+               s->xml_index = si;
+            }
+      }
+      free(is_active); free(eff_body);
    }
-   free(is_active);
 
    ora_rng_set(&r->rng, params->seed);                            /* mod.cpp:2303-2304 */
 
@@ -831,6 +894,7 @@ void ora_run_set_traj(ora_run * r, const double * traj) { memcpy(r->traj, traj, 
  * Returns the number of samples walked; *collides 0/1 and the contact's time / XML sphere / field /
  * depth (radius - value). */
 void ora_robot_self_pairs(const ora_robot * rob, unsigned char * excl);
+static void self_pairs(const ora_robot * rob, int ns, const int * link, const double * pos, const double * radius, unsigned char * excl);
 
 int ora_run_collision_recheck(ora_run * r, const double * vmax /* [n_adof] */, int * collides, double * time_out,
    int * sphere_out, int * field_out, double * depth_out)
@@ -874,24 +938,25 @@ int ora_run_collision_recheck(ora_run * r, const double * vmax /* [n_adof] */, i
       for (j=0; j<r->n_adof; j++)
          q[r->adofindices[j]] = r->traj[seg*n+col0+j] + (r->traj[(seg+1)*n+col0+j] - r->traj[seg*n+col0+j]) * u;
       ora_robot_fk(r->robot, base, q, r->fkR, r->fkt, 0, 0);
-      /* spheres in XML order */
-      for (si=0; si<r->robot->n_spheres && !*collides; si++)
+      /* spheres in XML order: the robot's, then those of the bodies it held at create (the reference's note at
+       * 2992-2996: CheckCollision and RobotBase::CheckSelfCollision include the grabbed bodies) */
+      for (si=0; si<r->n_spheres && !*collides; si++)
       {
          double pw[3];
-         int li = r->robot->sphere_link[si], active = r->floating_base;
+         int li = r->eff_link[si], active = r->floating_base;
          for (j=0; j<r->n_adof && !active; j++) active = ora_robot_does_affect(r->robot, r->adofindices[j], li);
          if (!active) continue;
-         mat3_vec(r->fkR + 9*li, r->robot->sphere_pos + 3*si, pw);
+         mat3_vec(r->fkR + 9*li, r->eff_pos + 3*si, pw);
          for (k=0; k<3; k++) pw[k] += r->fkt[3*li+k];
          for (fi=0; fi<r->n_rsdfs; fi++)
          {
             double pg[3], val;
             ora_kin_pose_compos(r->rsdfs[fi].pose_gsdf_world, pw, pg);
             if (ora_grid_double_interp(r->rsdfs[fi].grid, pg, &val)) continue;
-            if (val - r->robot->sphere_radius[si] < 0.0)
+            if (val - r->eff_radius[si] < 0.0)
             {
                *collides = 1; *time_out = time; *sphere_out = si; *field_out = fi;
-               *depth_out = r->robot->sphere_radius[si] - val;
+               *depth_out = r->eff_radius[si] - val;
                break;
             }
          }
@@ -901,17 +966,17 @@ int ora_run_collision_recheck(ora_run * r, const double * vmax /* [n_adof] */, i
       if (!*collides)
       {
          int a, b2;
-         if (!excl) { excl = (unsigned char *) malloc((size_t) r->robot->n_links * r->robot->n_links); ora_robot_self_pairs(r->robot, excl); }
-         for (a=0; a<r->robot->n_spheres && !*collides; a++)
-            for (b2=a+1; b2<r->robot->n_spheres; b2++)
+         if (!excl) { excl = (unsigned char *) malloc((size_t) r->robot->n_links * r->robot->n_links); self_pairs(r->robot, r->n_spheres, r->eff_link, r->eff_pos, r->eff_radius, excl); }
+         for (a=0; a<r->n_spheres && !*collides; a++)
+            for (b2=a+1; b2<r->n_spheres; b2++)
             {
-               const int la = r->robot->sphere_link[a], lb = r->robot->sphere_link[b2];
+               const int la = r->eff_link[a], lb = r->eff_link[b2];
                double pa[3], pb[3], d2 = 0.0, rs, dist;
                if (la == lb || excl[la * r->robot->n_links + lb]) continue;
-               mat3_vec(r->fkR + 9*la, r->robot->sphere_pos + 3*a, pa);
-               mat3_vec(r->fkR + 9*lb, r->robot->sphere_pos + 3*b2, pb);
+               mat3_vec(r->fkR + 9*la, r->eff_pos + 3*a, pa);
+               mat3_vec(r->fkR + 9*lb, r->eff_pos + 3*b2, pb);
                for (k=0; k<3; k++) { const double d = (pa[k] + r->fkt[3*la+k]) - (pb[k] + r->fkt[3*lb+k]); d2 += d*d; }
-               rs = r->robot->sphere_radius[a] + r->robot->sphere_radius[b2];
+               rs = r->eff_radius[a] + r->eff_radius[b2];
                dist = sqrt(d2);
                if (dist - rs < 0.0)
                {
@@ -931,7 +996,8 @@ int ora_run_collision_recheck(ora_run * r, const double * vmax /* [n_adof] */, i
  * adjacent links: links joined by a joint, and links that already touch in the robot's initial configuration.
  * The sphere model's restatement: excl[la][lb] = 1 when la == lb, when one is the other's parent, when the robot
  * description declares the pair adjacent, or when any sphere of la overlaps any sphere of lb with all dofs at zero. */
-void ora_robot_self_pairs(const ora_robot * rob, unsigned char * excl /* [n_links][n_links] */)
+static void self_pairs(const ora_robot * rob, int ns, const int * link, const double * pos, const double * radius,
+   unsigned char * excl /* [n_links][n_links] */)
 {
    const int nl = rob->n_links;
    const double ident[7] = { 0, 0, 0, 0, 0, 0, 1 };
@@ -950,17 +1016,22 @@ void ora_robot_self_pairs(const ora_robot * rob, unsigned char * excl /* [n_link
       excl[rob->adjacent[2*a+1]*nl + rob->adjacent[2*a]] = 1;
    }
    ora_robot_fk(rob, ident, q, R, t, 0, 0);
-   for (a=0; a<rob->n_spheres; a++)
-      for (b2=a+1; b2<rob->n_spheres; b2++)
+   for (a=0; a<ns; a++)
+      for (b2=a+1; b2<ns; b2++)
       {
-         const int la = rob->sphere_link[a], lb = rob->sphere_link[b2];
-         double pa[3], pb[3], d2 = 0.0, rs = rob->sphere_radius[a] + rob->sphere_radius[b2];
-         mat3_vec(R + 9*la, rob->sphere_pos + 3*a, pa);
-         mat3_vec(R + 9*lb, rob->sphere_pos + 3*b2, pb);
+         const int la = link[a], lb = link[b2];
+         double pa[3], pb[3], d2 = 0.0, rs = radius[a] + radius[b2];
+         mat3_vec(R + 9*la, pos + 3*a, pa);
+         mat3_vec(R + 9*lb, pos + 3*b2, pb);
          for (k=0; k<3; k++) { const double d = (pa[k] + t[3*la+k]) - (pb[k] + t[3*lb+k]); d2 += d*d; }
          if (sqrt(d2) - rs < 0.0) { excl[la*nl + lb] = 1; excl[lb*nl + la] = 1; }
       }
    free(q); free(R); free(t);
+}
+
+void ora_robot_self_pairs(const ora_robot * rob, unsigned char * excl /* [n_links][n_links] */)
+{
+   self_pairs(rob, rob->n_spheres, rob->sphere_link, rob->sphere_pos, rob->sphere_radius, excl);
 }
 
 /* create's starttraj branch, src/orcdchomp_mod.cpp:2375-2416 (fixed base): row i of the run's

@@ -149,6 +149,7 @@ int ora_chomp_iterate(ora_chomp * c, int do_iteration, double * costp_total, dou
  * Links are in topological order (parent index < own index, root parent -1).
  * link frame = parent link frame o pose_parent_joint o motion(axis, q[dof]).
  * joint_type: 0 fixed, 1 revolute, 2 prismatic. */
+struct ora_grabbed;
 typedef struct ora_robot
 {
    int n_links;
@@ -167,7 +168,23 @@ typedef struct ora_robot
    const double * sphere_radius;  /* [n_spheres] */
    int n_adjacent;                /* link pairs the robot description declares adjacent (<adjacent> tags) */
    const int * adjacent;          /* [n_adjacent][2] */
+   /* kinbodies the robot is grabbing, in GetGrabbed() order (src/orcdchomp_mod.cpp:2168-2171); 0 / NULL: none */
+   int n_grabbed;
+   const struct ora_grabbed * grabbed;
 } ora_robot;
+
+/* A grabbed kinbody as create sees it (src/orcdchomp_mod.cpp:2173-2210): its <orcdchomp> spheres, the robot link
+ * that holds it (RobotBase::IsGrabbing(k)) and the world transform of the kinbody's link at create
+ * (k->GetLink(linkname)->GetTransform(); the stand-in environment's kinbodies have one link).  A sphere rides on
+ * the grabbing link at T_w_rlink^-1 * T_w_klink * pos (2200-2208). */
+typedef struct ora_grabbed
+{
+   int robot_link;
+   double pose_world_klink[7];
+   int n_spheres;
+   const double * sphere_pos;     /* [n_spheres][3] in the kinbody link's frame */
+   const double * sphere_radius;  /* [n_spheres] */
+} ora_grabbed;
 
 /* FK: world transforms of all links.  R[n_links][9] row-major, t[n_links][3].
  * Also world joint axis / anchor per link (axis_w zero for fixed joints). */

@@ -29,12 +29,18 @@ class Grid(C.Structure):
                 ("lengths", C.c_double * 3), ("data", c_double_p)]
 
 
+class Grabbed(C.Structure):
+    _fields_ = [("robot_link", C.c_int), ("pose_world_klink", C.c_double * 7), ("n_spheres", C.c_int),
+                ("sphere_pos", c_double_p), ("sphere_radius", c_double_p)]
+
+
 class Robot(C.Structure):
     _fields_ = [("n_links", C.c_int), ("parent", c_int_p), ("pose_parent_joint", c_double_p),
                 ("joint_type", c_int_p), ("axis", c_double_p), ("dof_index", c_int_p),
                 ("n_dof", C.c_int), ("limit_lower", c_double_p), ("limit_upper", c_double_p),
                 ("n_spheres", C.c_int), ("sphere_link", c_int_p), ("sphere_pos", c_double_p),
-                ("sphere_radius", c_double_p), ("n_adjacent", C.c_int), ("adjacent", c_int_p)]
+                ("sphere_radius", c_double_p), ("n_adjacent", C.c_int), ("adjacent", c_int_p),
+                ("n_grabbed", C.c_int), ("grabbed", C.POINTER(Grabbed))]
 
 
 class RunParams(C.Structure):
@@ -205,9 +211,23 @@ class OraGrid:
 
 # ------------------------------------------------------------------ robot helpers
 class OraRobot:
-    def __init__(self, model):
+    def __init__(self, model, grabbed=()):
+        """grabbed: the kinbodies the robot holds, in GetGrabbed() order (reference src/orcdchomp_mod.cpp:2168-2171):
+        tuples (robot link index, pose_world_klink[7], sphere_pos[k][3], sphere_radius[k])"""
         a = model.arrays()
         self._keep = a
+        self._grab_keep = []
+        self._grabbed = (Grabbed * max(len(grabbed), 1))()
+        for gi, (link, pose, pos, rad) in enumerate(grabbed):
+            pos = f64(pos).reshape(-1, 3); rad = f64(rad).reshape(-1)
+            assert len(pos) == len(rad)
+            self._grab_keep.append((pos, rad))
+            g = self._grabbed[gi]
+            g.robot_link = int(link)
+            for i in range(7):
+                g.pose_world_klink[i] = float(pose[i])
+            g.n_spheres = len(rad)
+            g.sphere_pos = dp(pos); g.sphere_radius = dp(rad)
         r = Robot()
         r.n_links = a["n_links"]
         r.parent = ip(a["parent"])
@@ -224,6 +244,8 @@ class OraRobot:
         r.sphere_radius = dp(a["sphere_radius"])
         r.n_adjacent = a["n_adjacent"]
         r.adjacent = ip(a["adjacent"])
+        r.n_grabbed = len(grabbed)
+        r.grabbed = C.cast(self._grabbed, C.POINTER(Grabbed))
         self.r = r
         self.model = model
 

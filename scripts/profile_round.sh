@@ -9,6 +9,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
 cd $ROOT
+python3 -c "from or_cdchomp_amd import _capi; print(_capi.csrc_hash())" > $OUT/csrc_hash.txt
 B="bench.py --config $CFG --no-cpu-baseline --serial-steps 0 $@"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $B --steps 20 --warmup 3 > $OUT/bench_trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $B --steps 2 --warmup 1 > $OUT/bench_pmc_fetch.log 2>&1

@@ -55,7 +55,13 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
         summary["counters"][k] = {"mean_per_launch": sum(v) / len(v), "launches": len(v)}
     summary["dispatch"] = meta
 c = summary["counters"]
-entry = {"batch": batch, "n_iter": n_iter, "from": name, "source": "profiles/%s_summary.json" % name}
+sys.path.insert(0, root)
+from or_cdchomp_amd import _capi
+# the build the counters belong to: bench.py quotes them only while csrc/ still hashes to this
+hfile = os.path.join(src, "csrc_hash.txt")      # written on the GPU box by scripts/profile_round.sh beside the counters
+build_hash = open(hfile).read().strip() if os.path.exists(hfile) else _capi.csrc_hash()
+entry = {"batch": batch, "n_iter": n_iter, "from": name, "source": "profiles/%s_summary.json" % name, "csrc_hash": build_hash}
+summary["csrc_hash"] = entry["csrc_hash"]
 if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
     # MI355X_MICROARCH.md "HBM": FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half
     # of a wide coalesced read -> doubled (our gathers are narrow, so this is an upper estimate)

@@ -75,6 +75,29 @@ def setup_product_wam(mod, name="BarrettWAM"):
     return model
 
 
+# A run whose oracle result moves by `amp` (relative L2) when its goal moves by one ulp is "ill-conditioned": CHOMP
+# bouncing off a joint limit amplifies a rounding-level difference ~4x per projection, and a rounding difference of
+# the HIP path is amplified like any other.  Such a run is held to CHAOS_FACTOR x amp instead of the 1e-6 bar, with amp
+# the larger of the two movements under goal x (1 +- 2^-52).  Measured (scripts/chaos_ratio.py, profiles/r04_chaos_ratio.txt:
+# 2048 runs of config 2 and 512 of config 4, 180 of them ill-conditioned): err / amp has median 0.95, p90 3.9, p99 31,
+# maximum 132 -- the ratio of two random projections on the run's unstable direction, heavy-tailed; with one
+# perturbation instead of two the maximum is 240.  300 leaves a factor of two over the largest ratio seen (5000 until round 3).
+CHAOS_FACTOR = 300.0
+ULPS = (1.0 + 2.0 ** -52, 1.0 - 2.0 ** -52)
+
+
+def amplification(run, goals, base):
+    """how far each oracle run moves under one-ulp changes of its goal: `run(goals)` -> (traj, costs, status, ...), `base` its
+    result on the goals themselves.  Returns (amp [n_runs], stable [n_runs]: the status is the same in all three)"""
+    amp = np.zeros(len(goals))
+    stable = np.ones(len(goals), dtype=bool)
+    for f in ULPS:
+        res = run(np.asarray(goals) * f)
+        amp = np.maximum(amp, [rel_l2(res[0][k], base[0][k]) for k in range(len(goals))])
+        stable &= (np.asarray(res[2]) == np.asarray(base[2]))
+    return amp, stable
+
+
 def rel_l2(a, b):
     a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))

@@ -6,8 +6,9 @@ the HIP path to the oracle at full size without a long oracle run on the GPU box
 
 Per configuration: the sample's run indices inside the full batch, the oracle's trajectories, costs
 and status after n_iter iterations, and `self_amp`: the relative L2 distance between that trajectory
-and the oracle's own trajectory when the goal is moved by ONE ulp -- the conditioning of the run
-(chaotic runs of the reference algorithm are held to their measured amplification).
+and the oracle's own trajectory when the goal is moved by ONE ulp, up or down, whichever moves it more -- the
+conditioning of the run (chaotic runs of the reference algorithm are held to common.CHAOS_FACTOR times their measured
+amplification; profiles/r04_chaos_ratio.txt is the distribution that factor comes from).
 The inputs are not stored: tests/common.py rebuilds them from the seeds (config 5's occupancy comes
 from the product's host voxelizer, the stand-in for OpenRAVE's collision checker; the fields
 themselves are the oracle's flood fill + distance transform of it, stored here bit-packed so that
@@ -29,6 +30,7 @@ from or_cdchomp_amd import robots                # noqa: E402
 
 N_ITER = 100
 ULP = 1.0 + 2.0 ** -52
+ULP_DOWN = 1.0 - 2.0 ** -52
 
 
 def sample_indices(n_runs, count):
@@ -41,17 +43,17 @@ def run_wam(goals, kw, basegoals=None, seeds=None):
     rob = O.OraRobot(model)
     p = O.default_params(**kw)
     out = []
-    for g in (goals, goals * ULP):
+    for g in (goals, goals * ULP, goals * ULP_DOWN):
         out.append(O.batch_run(rob, base, dofvals, adofs, g, [prob["sdf"]], [prob["pose"]], p, N_ITER,
                                basegoals=basegoals, seeds=seeds))
     return out
 
 
 def pack(name, idx, res, extra=None):
-    (traj, costs, status, _), (ptraj, _, pstatus, _) = res
-    amp = np.array([common.rel_l2(ptraj[k], traj[k]) for k in range(len(idx))])
+    (traj, costs, status, _), (ptraj, _, pstatus, _), (mtraj, _, mstatus, _) = res
+    amp = np.array([max(common.rel_l2(ptraj[k], traj[k]), common.rel_l2(mtraj[k], traj[k])) for k in range(len(idx))])
     d = dict(index=idx, traj=traj, costs=costs, status=status, self_amp=amp, status_goal_plus_one_ulp=pstatus,
-             n_iter=np.int64(N_ITER))
+             status_goal_minus_one_ulp=mstatus, n_iter=np.int64(N_ITER))
     if extra:
         d.update(extra)
     path = os.path.join(HERE, name)
@@ -82,7 +84,7 @@ def main():
     goals = common.config5_goals(4096)
     idx = sample_indices(4096, 8)
     p = O.default_params(**common.CONFIG5_KW)
-    res = [O.batch_run(rob, base, dofvals, adofs, g, grids, poses, p, N_ITER) for g in (goals[idx], goals[idx] * ULP)]
+    res = [O.batch_run(rob, base, dofvals, adofs, g, grids, poses, p, N_ITER) for g in (goals[idx], goals[idx] * ULP, goals[idx] * ULP_DOWN)]
     extra = {}
     for k, (name, occ, lengths, gpose, bpose) in enumerate(common.config5_occupancy()):
         extra["occ_bits_%d" % k] = np.packbits(np.isinf(occ).ravel())

@@ -200,19 +200,20 @@ def test_results_do_not_depend_on_batch_composition(oracle, monkeypatch):
     plain = mod.batch_gettraj(bid)
     prob = common.tabletop_problem(oracle)
     _, base, dofvals, adofs = common.wam_state()
-    otraj, _, ost, _ = oracle.batch_run(oracle.OraRobot(model), base, dofvals, adofs, goals, [prob["sdf"]], [prob["pose"]],
-                                        oracle.default_params(**KW), 100)
-    ptraj, _, _, _ = oracle.batch_run(oracle.OraRobot(model), base, dofvals, adofs, goals * (1.0 + 2.0 ** -52), [prob["sdf"]],
-                                      [prob["pose"]], oracle.default_params(**KW), 100)
+    ora = lambda g: oracle.batch_run(oracle.OraRobot(model), base, dofvals, adofs, g, [prob["sdf"]], [prob["pose"]],
+                                     oracle.default_params(**KW), 100)
+    ores = ora(goals)
+    otraj, ost = ores[0], ores[2]
+    amps, _ = common.amplification(ora, goals, ores)
     errs = []
     for k in range(64):
         if st[k] != 0 or ost[k] != 0:
             continue
-        amp = common.rel_l2(ptraj[k], otraj[k])
+        amp = amps[k]
         e = common.rel_l2(plain[k], trajs[0][k])
         errs.append(e)
-        assert e <= max(1e-9, 5000.0 * amp), (k, e, amp)
-        assert common.rel_l2(plain[k], otraj[k]) <= max(1e-6, 5000.0 * amp)
+        assert e <= max(1e-9, common.CHAOS_FACTOR * amp), (k, e, amp)
+        assert common.rel_l2(plain[k], otraj[k]) <= max(1e-6, common.CHAOS_FACTOR * amp)
     assert np.median(errs) <= 1e-12
 
 

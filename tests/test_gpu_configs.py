@@ -179,26 +179,32 @@ def test_joint_limit_status(oracle):
     bid = mod.batch_create(model.name, goals, **kw)
     costs, status = mod.batch_iterate(bid, 100)
     traj = mod.batch_gettraj(bid)
-    otraj, ocosts, ostatus, _ = oracle.batch_run(oracle.OraRobot(model), base, dofvals, adofs, goals,
-                                                 [prob["sdf"]], [prob["pose"]], oracle.default_params(**kw), 100)
+    ora = lambda g: oracle.batch_run(oracle.OraRobot(model), base, dofvals, adofs, g, [prob["sdf"]], [prob["pose"]],
+                                     oracle.default_params(**kw), 100)
+    ores = ora(goals)
+    otraj, ocosts, ostatus = ores[:3]
     assert (ostatus == -1).sum() > 0, "the workload is expected to contain diverging runs"
-    # a diverging run is chaotic shortly before it fails, so the verdict may flip for a few
+    # A diverging run is chaotic shortly before it fails, so the verdict may flip for a few.  What the oracle says about
+    # itself (scripts/chaos_ratio.py, profiles/r04_chaos_ratio.txt): its own status agrees with its status under a one-ulp
+    # change of the goal for 99.4-99.6 % of config 2's runs, and so does the HIP path's (99.4 % of 2048 runs; 97 % was the
+    # bar until round 3).  Every run whose status differs must be one the oracle itself cannot reproduce.
+    amp, stable = common.amplification(ora, goals, ores)
     agree = (status == ostatus)
-    assert agree.mean() >= 0.97, agree.mean()
+    assert agree.mean() >= 0.98, agree.mean()
+    for k in np.flatnonzero(~agree):
+        assert amp[k] >= 1e-9 or not stable[k], (k, status[k], ostatus[k], amp[k])
     ok = (status == 0) & (ostatus == 0)
-    errs = np.array([common.rel_l2(traj[k], otraj[k]) for k in np.where(ok)[0]])
-    assert np.median(errs) <= 1e-9
-    assert (errs <= 1e-6).mean() >= 0.9, np.sort(errs)[-8:]
-    # the runs above 1e-6 are the ones about to diverge (cost exploding, limits hit every
-    # iteration): they are chaotic in the reference algorithm itself.  Show that with the
-    # oracle alone (one-ulp change of the goal) and hold the HIP path to that conditioning.
-    bad = np.where(ok)[0][errs > 1e-6]
-    pgoals = goals[bad] * (1.0 + 2.0 ** -52)
-    ptraj, _, pstatus, _ = oracle.batch_run(oracle.OraRobot(model), base, dofvals, adofs, pgoals,
-                                            [prob["sdf"]], [prob["pose"]], oracle.default_params(**kw), 100)
-    for j, k in enumerate(bad):
-        amp = common.rel_l2(ptraj[j], otraj[k]) / 2.0 ** -52
-        assert pstatus[j] != 0 or common.rel_l2(traj[k], otraj[k]) <= max(1e-6, 10.0 * amp * 1e-13), (k, amp)
+    errs = np.array([common.rel_l2(traj[k], otraj[k]) for k in range(len(goals))])
+    assert np.median(errs[ok]) <= 1e-9
+    well = ok & (amp < 1e-9) & stable
+    assert well.sum() >= 0.8 * ok.sum()
+    assert errs[well].max() <= 1e-6, np.sort(errs[well])[-8:]
+    # the others are the runs about to diverge (cost exploding, limits hit every iteration): chaotic in the reference
+    # algorithm itself, shown by the oracle alone (one-ulp changes of the goal); the HIP path is held to that conditioning
+    ill = ok & ~well
+    assert (errs[ill] <= np.maximum(1e-6, common.CHAOS_FACTOR * amp[ill])).all(), (errs[ill], amp[ill])
+    print("joint-limit workload: status agreement %.4f, %d well-conditioned runs worst %.2e, %d ill-conditioned worst ratio %.1f"
+          % (agree.mean(), well.sum(), errs[well].max(), ill.sum(), (errs[ill] / np.maximum(amp[ill], 1e-300)).max() if ill.any() else 0.0))
     from or_cdchomp_amd import bindings
     k = int(np.where(status == -1)[0][0])
     with pytest.raises(RuntimeError, match="Resulting trajectory is outside of joint limits!"):

@@ -1,0 +1,319 @@
+"""-m gpu: runs of a robot that HOLDS something (reference src/orcdchomp_mod.cpp:2168-2300).
+
+`create` collects the spheres of the robot and of every kinbody the robot is grabbing; a held body's spheres ride
+on the grabbing link at T_w_rlink^-1 o T_w_klink o pos.  The product gets the bodies through the C ABI
+(orc_kinbody_set_spheres, orc_robot_grab / _release), the oracle through ora_robot.grabbed; both see the same
+numbers.  Bars: trajectories within 1e-6 relative L2, costs within 1e-6 (north_star)."""
+import numpy as np
+import pytest
+
+import common
+import or_cdchomp_amd
+from or_cdchomp_amd import bindings, robots
+
+pytestmark = pytest.mark.gpu
+
+TRAJ_TOL = 1e-6
+COST_TOL = 1e-6
+KW = dict(n_points=60, lambda_=100.0, obs_factor=500.0)
+
+# spheres of the held bodies, in their own frames
+MUG_POS = [[0.0, 0.0, 0.03]]
+MUG_RAD = [0.05]
+BOX_POS = [[0.0, 0.0, 0.0], [0.09, 0.0, 0.0], [0.0, 0.09, 0.02], [0.09, 0.09, 0.02]]
+BOX_RAD = [0.05, 0.045, 0.04, 0.05]
+
+
+def _hand_pose(model, base, dofvals, offset):
+    """a pose near the hand: the handbase frame's origin moved by `offset` along its axes, a fixed tilt"""
+    R, t = model.link_frames(base, dofvals)
+    li = model.link_names.index("handbase")
+    p = t[li] + R[li] @ np.asarray(offset)
+    q = robots.quat_from_axis_angle((0.3, -0.5, 0.8), 0.7)
+    return list(p) + list(q)
+
+
+@pytest.fixture()
+def scene(oracle):
+    mod = or_cdchomp_amd.Module(0)
+    model = common.setup_product_wam(mod)
+    _, base, dofvals, adofs = common.wam_state()
+    prob = common.tabletop_problem(oracle)
+    mug_pose = _hand_pose(model, base, dofvals, (0.0, 0.0, 0.17))
+    box_pose = _hand_pose(model, base, dofvals, (-0.04, -0.05, 0.15))
+    mod.add_kinbody_boxes("cup", [([0, 0, 0.03, 0, 0, 0, 1], [0.03, 0.03, 0.05])], transform=mug_pose)
+    mod.set_kinbody_spheres("cup", MUG_POS, MUG_RAD)
+    mod.add_kinbody_boxes("box", [([0.045, 0.045, 0.01, 0, 0, 0, 1], [0.08, 0.08, 0.04])], transform=box_pose)
+    mod.set_kinbody_spheres("box", BOX_POS, BOX_RAD)
+    mod.add_kinbody_boxes("bare", [([0, 0, 0, 0, 0, 0, 1], [0.02, 0.02, 0.02])], transform=mug_pose)
+    yield dict(mod=mod, model=model, base=base, dofvals=dofvals, adofs=adofs, prob=prob, mug_pose=mug_pose, box_pose=box_pose,
+               hand=model.link_names.index("handbase"))
+    mod.close()
+
+
+def _oracle_batch(oracle, s, grabbed, goals, n_iter, basegoals=None, **kw):
+    """(traj, costs, status, amplification): the oracle's runs, and how far each moves when its goal moves by one ulp
+    (a run that bounces off joint limits or sits deep in a self collision amplifies rounding)"""
+    rob = oracle.OraRobot(s["model"], grabbed=grabbed)
+    args = (rob, s["base"], s["dofvals"], s["adofs"])
+    rest = ([s["prob"]["sdf"]], [s["prob"]["pose"]], oracle.default_params(**kw), n_iter)
+    bg = {} if basegoals is None else dict(basegoals=basegoals)
+    ora = lambda g: oracle.batch_run(*args, g, *rest, **bg)
+    res = ora(np.asarray(goals))
+    amp, _ = common.amplification(ora, goals, res)
+    return res[0], res[1], res[2], amp
+
+
+def _compare(mod, bid, n_iter, otraj, ocosts, ost, amp):
+    costs, status = mod.batch_iterate(bid, n_iter)
+    traj = mod.batch_gettraj(bid)
+    assert np.array_equal(status, ost), (status, ost)
+    ok = status == 0
+    assert ok.sum() >= len(ok) // 2
+    err = np.array([common.rel_l2(traj[k], otraj[k]) for k in range(len(ost))])
+    well = ok & (amp < 1e-9)
+    assert well.sum() >= len(ok) // 2, amp
+    assert err[well].max() <= TRAJ_TOL, err
+    assert np.allclose(costs[well], ocosts[well], rtol=COST_TOL, atol=0), np.abs(costs[well] / ocosts[well] - 1).max()
+    # a run the oracle itself moves under a one-ulp change of its goal is held to that amplification
+    ill = ok & ~well
+    assert (err[ill] <= np.maximum(TRAJ_TOL, common.CHAOS_FACTOR * amp[ill])).all(), (err[ill], amp[ill])
+    return traj, err[well].max()
+
+
+def test_wam_holding_a_one_sphere_body(scene, oracle):
+    """15 + 1 active spheres: the 16-lane kernel family with a full row (the WAM's inactive shoulder sphere goes back to the
+    loop over inactive spheres)"""
+    s = scene; mod = s["mod"]
+    mod.grab(s["model"].name, "cup", s["hand"])
+    goals = common.wam_goals(12, seed=41)
+    bid = mod.batch_create(s["model"].name, goals, **KW)
+    otraj, ocosts, ost, amp = _oracle_batch(oracle, s, [(s["hand"], s["mug_pose"], MUG_POS, MUG_RAD)], goals, 60, **KW)
+    _, worst = _compare(mod, bid, 60, otraj, ocosts, ost, amp)
+    mod.batch_destroy(bid)
+    # the held sphere changes the answer: the same goals without the body differ
+    ntraj, _, nst, _ = _oracle_batch(oracle, s, [], goals, 60, **KW)
+    assert max(common.rel_l2(ntraj[k], otraj[k]) for k in range(len(goals)) if ost[k] == 0 and nst[k] == 0) > 1e-4
+    print("one held sphere: worst rel L2 %.2e" % worst)
+
+
+def test_wam_holding_a_four_sphere_body(scene, oracle):
+    """15 + 4 = 19 active spheres: past the 16-lane row, the 32-lane groups of the many-sphere kernel family"""
+    s = scene; mod = s["mod"]
+    mod.grab(s["model"].name, "box", s["hand"])
+    goals = common.wam_goals(12, seed=42)
+    bid = mod.batch_create(s["model"].name, goals, **KW)
+    otraj, ocosts, ost, amp = _oracle_batch(oracle, s, [(s["hand"], s["box_pose"], BOX_POS, BOX_RAD)], goals, 60, **KW)
+    _, worst = _compare(mod, bid, 60, otraj, ocosts, ost, amp)
+    mod.batch_destroy(bid)
+    print("four held spheres: worst rel L2 %.2e" % worst)
+
+
+def test_two_bodies_on_different_links_momentum(scene, oracle):
+    """two held bodies, one on the hand and one on the forearm (wam4), with momentum: the order of the grabs is the order
+    of GetGrabbed()"""
+    s = scene; mod = s["mod"]
+    fore = s["model"].link_names.index("wam4")
+    mod.grab(s["model"].name, "box", s["hand"])
+    mod.grab(s["model"].name, "cup", fore)
+    goals = common.wam_goals(8, seed=43)
+    kw = dict(KW, use_momentum=1)
+    bid = mod.batch_create(s["model"].name, goals, **kw)
+    grabbed = [(s["hand"], s["box_pose"], BOX_POS, BOX_RAD), (fore, s["mug_pose"], MUG_POS, MUG_RAD)]
+    otraj, ocosts, ost, amp = _oracle_batch(oracle, s, grabbed, goals, 40, **kw)
+    _compare(mod, bid, 40, otraj, ocosts, ost, amp)
+    mod.batch_destroy(bid)
+
+
+def test_body_on_a_link_no_active_dof_moves(scene, oracle):
+    """a body held by the base link: its spheres are INACTIVE (mod.cpp:2265-2291), partners of the self-collision term only"""
+    s = scene; mod = s["mod"]
+    base_link = s["model"].link_names.index("wam0")
+    # somewhere the arm sweeps through
+    R, t = s["model"].link_frames(s["base"], s["dofvals"])
+    pose = list(t[s["model"].link_names.index("wam4")] + np.array([0.05, 0.1, 0.0])) + [0, 0, 0, 1]
+    mod.set_kinbody_transform("box", pose)
+    mod.grab(s["model"].name, "box", base_link)
+    goals = common.wam_goals(8, seed=44)
+    kw = dict(KW, obs_factor_self=40.0)
+    bid = mod.batch_create(s["model"].name, goals, **kw)
+    otraj, ocosts, ost, amp = _oracle_batch(oracle, s, [(base_link, pose, BOX_POS, BOX_RAD)], goals, 40, **kw)
+    _compare(mod, bid, 40, otraj, ocosts, ost, amp)
+    mod.batch_destroy(bid)
+    ntraj, _, _, _ = _oracle_batch(oracle, s, [], goals, 40, **kw)
+    assert max(common.rel_l2(ntraj[k], otraj[k]) for k in range(len(goals))) > 1e-6      # they do act
+
+
+def test_floating_base_holding_a_body(scene, oracle):
+    """floating base: every sphere is active (mod.cpp:2273), 16 + 1 of them"""
+    s = scene; mod = s["mod"]
+    mod.grab(s["model"].name, "cup", s["hand"])
+    goals = common.wam_goals(6, seed=45)
+    basegoals = np.tile(np.asarray(s["base"], dtype=np.float64), (6, 1))
+    basegoals[:, :3] += np.random.default_rng(45).uniform(-0.2, 0.2, size=(6, 3))
+    kw = dict(n_points=40, lambda_=100.0, obs_factor=500.0, floating_base=1)
+    bid = mod.batch_create(s["model"].name, goals, basegoals=basegoals, **kw)
+    otraj, ocosts, ost, amp = _oracle_batch(oracle, s, [(s["hand"], s["mug_pose"], MUG_POS, MUG_RAD)], goals, 30, basegoals=basegoals, **kw)
+    _compare(mod, bid, 30, otraj, ocosts, ost, amp)
+    mod.batch_destroy(bid)
+
+
+def test_grab_release_is_never_grabbed(scene):
+    """grab -> release -> create gives the bits of a robot that never held anything; a run keeps the spheres it was created with"""
+    s = scene; mod = s["mod"]
+    goals = common.wam_goals(6, seed=46)
+    b0 = mod.batch_create(s["model"].name, goals, **KW)
+    mod.grab(s["model"].name, "box", s["hand"])
+    b1 = mod.batch_create(s["model"].name, goals, **KW)
+    mod.release(s["model"].name, "box")
+    assert np.allclose(mod.body_transform("box"), s["box_pose"], rtol=0, atol=1e-5)      # left where the hand was (the demo's base quaternion is not of unit length: 1e-5)
+    b2 = mod.batch_create(s["model"].name, goals, **KW)
+    mod.grab(s["model"].name, "cup", s["hand"]); mod.grab(s["model"].name, "box", s["hand"])
+    mod.release(s["model"].name)                                                            # ReleaseAllGrabbed
+    b3 = mod.batch_create(s["model"].name, goals, **KW)
+    out = []
+    for b in (b0, b1, b2, b3):
+        c, st = mod.batch_iterate(b, 30)
+        out.append((mod.batch_gettraj(b), c, st))
+        mod.batch_destroy(b)
+    for k in (2, 3):
+        assert np.array_equal(out[0][0], out[k][0]) and np.array_equal(out[0][1], out[k][1])
+    assert not np.array_equal(out[0][0], out[1][0])
+    with pytest.raises(RuntimeError, match="not grabbing"):
+        mod.release(s["model"].name, "box")
+
+
+def test_single_run_is_its_run_in_a_batch(scene):
+    """the `create` command of the reference for a robot that holds something == the same goal inside a batch, bit for bit"""
+    s = scene
+    mod = bindings.bind(s["mod"])
+    mod.grab(s["model"].name, "box", s["hand"])
+    goals = common.wam_goals(5, seed=47)
+    bid = mod.batch_create(s["model"].name, goals, **KW)
+    mod.batch_iterate(bid, 25)
+    traj = mod.batch_gettraj(bid)
+    mod.batch_destroy(bid)
+    import re
+    for k in (0, 3):
+        run = mod.create(robot=s["model"].name, adofgoal=list(goals[k]), **KW)
+        mod.iterate(run=run, n_iter=25)
+        text = mod.gettraj(run=run, no_collision_check=True)
+        mod.destroy(run=run)
+        vals = np.array(re.search(r'<data count="60">\s*(.*?)\s*</data>', text, re.S).group(1).split(), dtype=float).reshape(60, 8)
+        assert np.array_equal(vals[:, :7], traj[k])
+
+
+def test_no_spheres_is_the_references_error(scene):
+    """a held body without <orcdchomp> data stops create (mod.cpp:2262-2263), and so does a robot without any"""
+    s = scene; mod = s["mod"]
+    mod.grab(s["model"].name, "bare", s["hand"])
+    with pytest.raises(RuntimeError, match="no spheres! kinbody does not have a <orcdchomp> tag defined\\?"):
+        mod.batch_create(s["model"].name, common.wam_goals(2), **KW)
+    with pytest.raises(RuntimeError, match="no spheres!"):
+        mod.SendCommand("create robot %s adofgoal '0 0 0 0 0 0 0'" % s["model"].name)
+    mod.release(s["model"].name, "bare")
+    with pytest.raises(RuntimeError, match="already grabbed"):
+        mod.grab(s["model"].name, "cup", s["hand"]); mod.grab(s["model"].name, "cup", s["hand"])
+    with pytest.raises(RuntimeError, match="out of range"):
+        mod.grab(s["model"].name, "box", 99)
+    with pytest.raises(RuntimeError, match="Could not find kinbody"):
+        mod.grab(s["model"].name, "nothing", 0)
+    naked = robots.wam7(); naked.name = "naked"; naked.spheres = []
+    mod.add_robot(naked, transform=s["base"], dof_values=s["dofvals"], active_dofs=s["adofs"])
+    with pytest.raises(RuntimeError, match="no spheres!"):
+        mod.batch_create("naked", common.wam_goals(2), **KW)
+
+
+def test_held_body_moves_with_its_link(oracle):
+    """Grab, then move the robot: the body goes along (OpenRAVE updates grabbed bodies with the robot's state) and `create`
+    evaluates T_w_rlink^-1 o T_w_klink o pos with the transforms of the moment of create (mod.cpp:2200-2208)"""
+    mod = or_cdchomp_amd.Module(0)
+    model = robots.wam7()
+    base = [-1.0, 0.0, 1.0, 0.0, np.sqrt(0.5), 0.0, np.sqrt(0.5)]          # the demo's pose with a unit quaternion
+    q0 = np.zeros(model.n_dof); q0[:7] = [0.3, -0.4, 0.2, 1.0, 0.1, -0.3, 0.2]
+    q1 = np.zeros(model.n_dof); q1[:7] = robots.WAM_START
+    mod.add_robot(model, transform=base, dof_values=q0, active_dofs=list(range(7)))
+    from or_cdchomp_amd import scenes
+    scenes.add_tabletop(mod)
+    mod.SendCommand("computedistancefield kinbody table")
+    hand = model.link_names.index("handbase")
+    pose0 = _hand_pose(model, base, q0, (0.0, 0.02, 0.17))
+    mod.add_kinbody_boxes("cup", [([0, 0, 0.03, 0, 0, 0, 1], [0.03, 0.03, 0.05])], transform=pose0)
+    mod.set_kinbody_spheres("cup", MUG_POS, MUG_RAD)
+    mod.grab(model.name, "cup", hand)
+    mod.set_dof_values(model.name, q1)
+    # where the body is now: F_link(q1) o F_link(q0)^-1 o T_body(q0), by the Python model
+    R0, t0 = model.link_frames(base, q0); R1, t1 = model.link_frames(base, q1)
+    def rot(q):
+        x, y, z, w = q
+        return np.array([[1 - 2*(y*y + z*z), 2*(x*y - z*w), 2*(x*z + y*w)], [2*(x*y + z*w), 1 - 2*(x*x + z*z), 2*(y*z - x*w)],
+                         [2*(x*z - y*w), 2*(y*z + x*w), 1 - 2*(x*x + y*y)]])
+    Rrel = R0[hand].T @ rot(pose0[3:7]); trel = R0[hand].T @ (np.asarray(pose0[:3]) - t0[hand])
+    Rnow, tnow = R1[hand] @ Rrel, R1[hand] @ trel + t1[hand]
+    pose1 = oracle.pose_from_dR(tnow, Rnow)
+    got = mod.body_transform("cup")
+    assert np.allclose(got[:3], pose1[:3], rtol=0, atol=1e-12)
+    assert min(np.abs(got[3:] - pose1[3:]).max(), np.abs(got[3:] + pose1[3:]).max()) < 1e-12
+    goals = common.wam_goals(6, seed=48)
+    bid = mod.batch_create(model.name, goals, **KW)
+    prob = common.tabletop_problem(oracle)
+    sc = dict(model=model, base=base, dofvals=q1, adofs=list(range(7)), prob=prob)
+    otraj, ocosts, ost, amp = _oracle_batch(oracle, sc, [(hand, pose1, MUG_POS, MUG_RAD)], goals, 40, **KW)
+    _compare(mod, bid, 40, otraj, ocosts, ost, amp)
+    mod.batch_destroy(bid)
+    mod.close()
+
+
+def test_recheck_includes_the_held_spheres(scene, oracle):
+    """the re-check of gettraj looks at the held bodies too (mod.cpp:2992-2996): a body that hangs below the hand meets the
+    table where the bare arm does not; device verdict, host re-check and the oracle's agree run by run"""
+    s = scene
+    mod = bindings.bind(s["mod"])
+    model = s["model"]
+    vmax = np.ones(model.n_dof)
+    # a long rod of spheres below the hand
+    rod_pos = [[0.0, 0.0, 0.05 + 0.09 * i] for i in range(4)]
+    rod_rad = [0.05] * 4
+    rod_pose = _hand_pose(model, s["base"], s["dofvals"], (0.0, 0.0, 0.15))
+    rod_pose[3:] = [0, 0, 0, 1]
+    R, t = model.link_frames(s["base"], s["dofvals"])
+    # the rod's axis along the hand's z
+    rod_pose = list(oracle.pose_from_dR(t[s["hand"]] + R[s["hand"]] @ np.array([0, 0, 0.15]), R[s["hand"]]))
+    mod.add_kinbody_boxes("rod", [([0, 0, 0.2, 0, 0, 0, 1], [0.02, 0.02, 0.2])], transform=rod_pose)
+    mod.set_kinbody_spheres("rod", rod_pos, rod_rad)
+    n_runs = 32
+    goals = common.wam_goals(n_runs, seed=49)
+    kw = dict(n_points=40, lambda_=100.0, obs_factor=500.0)
+    b_bare = mod.batch_create(model.name, goals, **kw)
+    mod.grab(model.name, "rod", s["hand"])
+    bid = mod.batch_create(model.name, goals, **kw)
+    mod.batch_iterate(bid, 30); mod.batch_iterate(b_bare, 30)
+    got = mod.batch_collision_verdict(bid)
+    bare = mod.batch_collision_verdict(b_bare)
+    traj = mod.batch_gettraj(bid)
+    assert (got["sphere"] >= 16).any(), got["sphere"]                  # contacts of the held spheres (XML indices after the robot's 16)
+    print("re-check: %d of %d runs collide holding the rod (%d through a held sphere first), %d bare" % (
+        got["collides"].sum(), n_runs, (got["sphere"] >= 16).sum(), bare["collides"].sum()))
+    rob = oracle.OraRobot(model, grabbed=[(s["hand"], rod_pose, rod_pos, rod_rad)])
+    for k in range(n_runs):
+        orun = oracle.OraRun(rob, s["base"], s["dofvals"], s["adofs"], goals[k], [s["prob"]["sdf"]], [s["prob"]["pose"]],
+                             oracle.default_params(**kw))
+        assert orun.S == 20 and orun.Sa == 19
+        orun.set_traj(traj[k])
+        want = orun.collision_recheck(vmax[:7])
+        orun.destroy()
+        assert want["collides"] == got["collides"][k], (k, want)
+        if want["collides"]:
+            assert want["sphere"] == got["sphere"][k] and want["field"] == got["field"][k], (k, want, got["sphere"][k], got["field"][k])
+            assert np.isclose(want["time"], got["time"][k], rtol=1e-12, atol=1e-15)
+            assert np.isclose(want["depth"], got["depth"][k], rtol=1e-9, atol=1e-12)
+    # the host re-check of the single-run command says the same as the device's
+    k = int(np.flatnonzero(got["sphere"] >= 16)[0])
+    run = mod.create(robot=model.name, adofgoal=list(goals[k]), **kw)
+    mod.iterate(run=run, n_iter=30)
+    with pytest.raises(RuntimeError, match="Resulting trajectory is in collision!"):
+        mod.gettraj(run=run)
+    mod.gettraj(run=run, no_collision_exception=True)
+    assert ("sphere %d " % got["sphere"][k]) in mod.last_collision_details() or ("spheres %d and" % got["sphere"][k]) in mod.last_collision_details()
+    mod.destroy(run=run)
+    mod.batch_destroy(bid); mod.batch_destroy(b_bare)
