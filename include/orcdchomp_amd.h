@@ -129,6 +129,12 @@ int orc_robot_set_active_manipulator(orc_module * mod, const char * name, const 
  * KinBody::GetAdjacentLinks): RobotBase::CheckSelfCollision, which the re-check of mod::gettraj calls
  * (src/orcdchomp_mod.cpp:2998-2999), never tests them.  link_pairs [n_pairs][2] link indices. */
 int orc_robot_set_adjacent_links(orc_module * mod, const char * name, const int * link_pairs, int n_pairs);
+/* The self-collision leg of the re-check is a stand-in: OpenRAVE tests the links' meshes, this library the bounding
+ * spheres of the optimizer's model, which are fatter (a trajectory whose meshes clear each other by less than the spheres'
+ * slack is "in collision" here and returned by the reference), and "adjacent in the initial configuration" is taken with
+ * all dofs at zero.  enabled = 0 leaves that leg out for this robot (gettraj, gettrajbatch ... verdict,
+ * orc_batch_collision_verdict); `gettraj ... no_self_collision_check` does the same for one call.  Default 1. */
+int orc_robot_set_self_check(orc_module * mod, const char * name, int enabled);
 
 /* a kinbody made of oriented boxes (InitFromBoxes-style); box_poses [n_boxes][7]
  * in the kinbody frame, half_extents [n_boxes][3] */

@@ -53,6 +53,7 @@ SYMBOLS = [
     ("orc_robot_add_manipulator", C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, c_double_p]),
     ("orc_robot_set_adjacent_links", C.c_int, [C.c_void_p, C.c_char_p, c_int_p, C.c_int]),
     ("orc_robot_set_active_manipulator", C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),
+    ("orc_robot_set_self_check", C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     ("orc_env_add_kinbody_boxes", C.c_int, [C.c_void_p, C.c_char_p, C.c_int, c_double_p, c_double_p]),
     ("orc_kinbody_set_transform", C.c_int, [C.c_void_p, C.c_char_p, c_double_p]),
     ("orc_kinbody_enable", C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),

@@ -610,6 +610,12 @@ void BatchShard::build_device(const Robot & robot)
       }
    }
    if (!is_placed) n_static = 0;
+   if (is_placed)
+   {
+      // entries past the active spheres: the slots without an active sphere, in order (static or empty: their wrench is zero)
+      int next = Sa;
+      for (int q=0; q<16 && next<16; q++) if (!((M.live_mask >> q) & 1ull)) M.slot_of[next++] = q;
+   }
    M.n_static = n_static; M.static_mask = 0ull;
    M.Sa_real = Sa; M.Sa = lanes; M.S = lanes + (int) inact.size() - n_static;
    slot_xml.assign(lanes, -1);
@@ -824,6 +830,7 @@ void BatchShard::build_device(const Robot & robot)
       }
       hc[i].stride_b[0] = s.grid.sizes[1] * s.grid.sizes[2] * (int) sizeof(real);
       hc[i].stride_b[1] = s.grid.sizes[2] * (int) sizeof(real);
+      hc[i].stride_r[0] = (real) hc[i].stride_b[0]; hc[i].stride_r[1] = (real) hc[i].stride_b[1]; hc[i].stride_r[2] = (real) sizeof(real);
       hc[i].data = hs[i].data;
       if (nc * sizeof(real) >= (size_t) 1 << 31) throw std::runtime_error("signed distance field too large for this build!");
    }
@@ -1010,14 +1017,14 @@ void BatchShard::build_device(const Robot & robot)
 
 void BatchShard::collision_verdict(const std::vector<int> & offs, const std::vector<int> & seg, const std::vector<double> & u,
    const std::vector<int> & pairs, const std::vector<double> & pair_rsum, const std::vector<double> & inact_pos,
-   int * key_out, double * depth_out)
+   unsigned long long * key_out, double * depth_out)
 {
    DeviceGuard guard(device);
    hipStream_t st = stream_;
    hip_check(hipStreamSynchronize(st), "verdict: pending work");
    const size_t ns = seg.size();
    int * d_offs = dev_alloc<int>(offs.size()); int * d_seg = dev_alloc<int>(ns); int * d_xml = dev_alloc<int>(slot_xml.size());
-   int * d_key = dev_alloc<int>(n_runs); double * d_depth = dev_alloc<double>(n_runs);
+   unsigned long long * d_key = dev_alloc<unsigned long long>(n_runs); double * d_depth = dev_alloc<double>(n_runs);
    hip_check(hipMemcpyAsync(d_offs, offs.data(), offs.size()*sizeof(int), hipMemcpyHostToDevice, st), "verdict offs");
    hip_check(hipMemcpyAsync(d_seg, seg.data(), ns*sizeof(int), hipMemcpyHostToDevice, st), "verdict seg");
    hip_check(hipMemcpyAsync(d_xml, slot_xml.data(), slot_xml.size()*sizeof(int), hipMemcpyHostToDevice, st), "verdict xml");
@@ -1051,7 +1058,7 @@ void BatchShard::collision_verdict(const std::vector<int> & offs, const std::vec
       e = orc_launch_verdict_f32(v, orc_verdict_lds_bytes(n, Sa_, Sa_real_, nj_, 4, chunk), st, tree_ & 1);
    }
    hip_check(e, "collision_verdict_kernel launch");
-   hip_check(hipMemcpyAsync(key_out, d_key, n_runs*sizeof(int), hipMemcpyDeviceToHost, st), "verdict keys");
+   hip_check(hipMemcpyAsync(key_out, d_key, n_runs*sizeof(unsigned long long), hipMemcpyDeviceToHost, st), "verdict keys");
    hip_check(hipMemcpyAsync(depth_out, d_depth, n_runs*sizeof(double), hipMemcpyDeviceToHost, st), "verdict depth");
    hip_check(hipStreamSynchronize(st), "verdict sync");
    dev_free(d_offs); dev_free(d_seg); dev_free(d_xml); dev_free(d_key); dev_free(d_depth); dev_free(d_u);
@@ -1510,7 +1517,7 @@ void Batch::get_phase_cycles(long long * out)
 
 void Batch::collision_verdict(const std::vector<int> & soffs, const std::vector<int> & seg, const std::vector<double> & u,
    const std::vector<int> & pairs, const std::vector<double> & pair_rsum, const std::vector<double> & inact_pos,
-   int * key_out, double * depth_out)
+   unsigned long long * key_out, double * depth_out)
 {
    for_shards([&](size_t k) {
       const int r0 = offs[k], r1 = offs[k+1];

@@ -245,6 +245,11 @@ int orc_robot_set_adjacent_links(orc_module * mod, const char * name, const int 
    });
 }
 
+int orc_robot_set_self_check(orc_module * mod, const char * name, int enabled)
+{
+   return guarded(mod, [&] { mod->impl->robot(str(name, "name")).self_check = enabled != 0; });
+}
+
 int orc_robot_set_active_manipulator(orc_module * mod, const char * name, const char * manip)
 {
    return guarded(mod, [&] {

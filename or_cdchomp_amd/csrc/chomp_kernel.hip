@@ -1037,7 +1037,7 @@ __device__ __attribute__((noinline)) void phase_setup(const void * kp)
       E.jctl_s[2*e+1] = (J.aff_begin & 255) | ((J.aff_end & 255) << 8) | ((J.type & 255) << 16) | ((J.col & 255) << 24);
    }
    for (int e=tid; e<Sa*3; e+=BLOCK) E.sphpos_s[e] = gmod.sph_pos[e/3][e%3];
-   for (int e=tid; e<E.mod.Sa_real; e+=BLOCK) E.slot_s[e] = gmod.slot_of[e];
+   for (int e=tid; e<(E.mod.placed ? E.mod.Sa : E.mod.Sa_real); e+=BLOCK) E.slot_s[e] = gmod.slot_of[e];      // (placed: all 16 entries, see DevModel::slot_of)
    for (int e=tid; e<Sa; e+=BLOCK) E.saff_s[e] = gmod.sph_affects[e];
    for (int e=tid; e<12; e+=BLOCK) E.base_s[e] = (e < 9) ? gmod.base_R[e] : gmod.base_t[e-9];
    {
@@ -1105,8 +1105,11 @@ __device__ __attribute__((noinline)) void phase_hmc(const void * kp, int slot_in
 }
 
 // ---- FK phase of one tile: lane = (waypoint, world axis) (sphere_cost_pre, src/orcdchomp_mod.cpp:988-1093) ----
+#ifndef ORC_INLINE_FK
+#define ORC_INLINE_FK 0      // 1: the FK phase of the fp64 16-lane kernels inside the kernel function (no callee-saved registers to preserve, 37 scalar registers through v_writelane and back per call otherwise) -- but the loop invariants it hoists across the other phases' calls are spilled to scratch and reloaded inside the joint loop: measured slower, kept for A/B
+#endif
 template <typename real, bool TREE, bool GS16, int BLOCK, int WGS = 0>
-__device__ __attribute__((noinline)) void phase_fk(const void * kp, int ts_in, int te_in)
+__device__ __forceinline__ void phase_fk_body(const void * kp, int ts_in, int te_in)
 {
    KArg<real> & b = *uniform_kernarg<real>(kp);
    const int ts = uni(ts_in), te = uni(te_in);
@@ -1134,6 +1137,11 @@ __device__ __attribute__((noinline)) void phase_fk(const void * kp, int ts_in, i
    }
    __syncthreads();
    phase_mark<real>(b, E, 0);
+}
+template <typename real, bool TREE, bool GS16, int BLOCK, int WGS = 0>
+__device__ __attribute__((noinline)) void phase_fk(const void * kp, int ts_in, int te_in)
+{
+   phase_fk_body<real, TREE, GS16, BLOCK, WGS>(kp, ts_in, te_in);
 }
 
 // ---- start_tsr: the cost pass of the start point alone (one-sided velocity; cost_gs16.h START), after the
@@ -1636,7 +1644,8 @@ void chomp_iterate_kernel(const DevBatch<real> b)
          const int ts = (tk == 0) ? 0 : b.tile_first + (tk - 1) * b.tile_rest;
          const int te = (tk == b.n_tiles - 1) ? b.m : b.tile_first + tk * b.tile_rest;
 #ifndef ORC_ABLATE_FK
-         phase_fk<real, TREE, GS16, BLOCK, WGS>(kp, ts, te);
+         if constexpr (ORC_INLINE_FK && GS16 && sizeof(real) == 8) phase_fk_body<real, TREE, GS16, BLOCK, WGS>(kp, ts, te);
+         else phase_fk<real, TREE, GS16, BLOCK, WGS>(kp, ts, te);
 #ifdef ORC_ABLATE_FKTWICE      // timing experiments: the FK phase twice (what a 2x slower FK would cost)
          phase_fk<real, TREE, GS16, BLOCK, WGS>(kp, ts, te);
 #endif
@@ -1727,7 +1736,7 @@ void collision_verdict_kernel(DevVerdict<real> v)
    const int run = blockIdx.x, tid = threadIdx.x;
    const int n = v.n, np = v.n_points, nj = gmod.nj, Sa = gmod.Sa;
    const int pstr = (Sa*3) | 1, astr = (nj*6) | 1, chunk = v.chunk;
-   int * key_s = (int *) smem_raw;                                   // [4]
+   unsigned long long * key_s = (unsigned long long *) smem_raw;     // [2]: the first contact's key (sample << 32 | pair bit << 31 | sphere << 16 | field or partner)
    real * lds = (real *)(smem_raw + 16);
    real * rows_s = lds;                                              // [chunk][n]
    real * pos_s = rows_s + ((chunk*n + 3) & ~3);                        // [chunk][pstr]
@@ -1743,7 +1752,7 @@ void collision_verdict_kernel(DevVerdict<real> v)
    for (int e=tid; e<Sa; e+=ORC_BLOCK) { srad_s[e] = gmod.sph_radius[e]; xml_s[e] = v.slot_xml[e]; }
    for (int e=tid; e<gmod.Sa_real; e+=ORC_BLOCK) slot_s[e] = gmod.slot_of[e];
    for (int e=tid; e<nj; e+=ORC_BLOCK) { jctl_s[2*e] = gmod.joints[e].packed; jctl_s[2*e+1] = 0; }
-   if (tid == 0) key_s[0] = 0x7fffffff;
+   if (tid == 0) key_s[0] = ORC_VERDICT_NONE;
    ModelView<real> mod;
    mod.nj = nj; mod.n = n; mod.floating = gmod.floating; mod.tree = gmod.tree; mod.Sa = Sa; mod.S = gmod.S; mod.GS = gmod.GS;
    mod.base_sph_begin = gmod.base_sph_begin; mod.base_sph_end = gmod.base_sph_end; mod.jt_scan = 0;
@@ -1760,7 +1769,7 @@ void collision_verdict_kernel(DevVerdict<real> v)
 
    const real * traj = v.traj + (size_t) run * np * n;
    const int s0 = v.offs[run], s1 = v.offs[run+1];
-   double my_depth = 0.0; int my_key = 0x7fffffff;
+   double my_depth = 0.0; unsigned long long my_key = ORC_VERDICT_NONE;
    for (int base=s0; base<s1; base+=chunk)
    {
       const int count = (s1 - base < chunk) ? s1 - base : chunk;
@@ -1807,7 +1816,7 @@ void collision_verdict_kernel(DevVerdict<real> v)
             if (sdf_lookup(F, gp, val, gg)) continue;                 // outside this field
             if (val - radius < (real)0)
             {
-               const int key = ((base - s0 + s) << 16) | (xml_s[slot] << 8) | i;
+               const unsigned long long key = ((unsigned long long)(base - s0 + s) << 32) | ((unsigned long long) xml_s[slot] << 16) | (unsigned long long) i;
                if (key < my_key) { my_key = key; my_depth = (double)(radius - val); }
                atomicMin(&key_s[0], key);
             }
@@ -1825,19 +1834,19 @@ void collision_verdict_kernel(DevVerdict<real> v)
          const real rs = v.pair_rsum[pi];
          if (dist - rs < (real)0)
          {
-            const int key = ((base - s0 + s) << 16) | (1 << 15) | (v.pairs[pi*4+2] << 8) | v.pairs[pi*4+3];
+            const unsigned long long key = ((unsigned long long)(base - s0 + s) << 32) | (1ull << 31) | ((unsigned long long) v.pairs[pi*4+2] << 16) | (unsigned long long) v.pairs[pi*4+3];
             if (key < my_key) { my_key = key; my_depth = (double)(rs - dist); }
             atomicMin(&key_s[0], key);
          }
       }
       __syncthreads();
-      if (key_s[0] != 0x7fffffff) break;          // a contact in this chunk: later samples cannot come first
+      if (key_s[0] != ORC_VERDICT_NONE) break;          // a contact in this chunk: later samples cannot come first
       __syncthreads();
    }
    __syncthreads();
-   const int first = key_s[0];
+   const unsigned long long first = key_s[0];
    if (tid == 0) v.key_out[run] = first;
-   if (first != 0x7fffffff && my_key == first) v.depth_out[run] = my_depth;
+   if (first != ORC_VERDICT_NONE && my_key == first) v.depth_out[run] = my_depth;
 }
 
 } // namespace
@@ -1878,6 +1887,20 @@ static hipError_t launch_iterate_tt(const DevBatch<real> & b, size_t lds, hipStr
 template <typename real>
 static hipError_t launch_iterate_t(const DevBatch<real> & b, size_t lds, hipStream_t stream, int variant)
 {
+#ifdef ORC_FAST_BUILD
+   // experiment builds (make var DEFS=-DORC_FAST_BUILD): only the kernels of the config-2 bench legs are compiled (the fp64
+   // fixed-base chain with placed spheres, one aligned field, no inactive sphere left: KIND 11), half a minute instead of three
+   if constexpr (sizeof(real) == 8)
+   {
+      if ((variant & (16 | 2 | 1)) == (16 | 2) && (((variant & 32) ? 2 : 0) | 1 | (((variant & 160) == 160) ? 8 : 0)) == 11 && !(variant & 64))
+      {
+         if ((variant & 256) && !(variant & (4 | 8))) return launch_iterate_tt<real, false, true, 256, 11, 4>(b, lds, stream);
+         if (variant & 4) return launch_iterate_tt<real, false, true, 192, 11>(b, lds, stream);
+         if (!(variant & 8)) return launch_iterate_tt<real, false, true, 256, 11>(b, lds, stream);
+      }
+   }
+   return hipErrorInvalidValue;
+#else
    if ((variant & 16) && !(variant & 2))      // the many-sphere path with its J^T form known (phase_cost KIND 1)
    {
       if (variant & 1)
@@ -1931,6 +1954,7 @@ static hipError_t launch_iterate_t(const DevBatch<real> & b, size_t lds, hipStre
    case 6: return launch_iterate_tt<real, false, true, 192>(b, lds, stream);
    default: return launch_iterate_tt<real, true, true, 192>(b, lds, stream);
    }
+#endif
 }
 
 hipError_t orc_launch_iterate_f64(const DevBatch<double> & b, size_t lds, hipStream_t stream, int variant)

@@ -14,6 +14,10 @@
 #define ORC_GS16_CELL 2      // 1: the one-field variants look the field up in cell units with the descriptor in scalar registers; 2: the general 16-lane pass as well (two fields: +3 %)
 #endif
 
+#ifndef ORC_LEAN
+#define ORC_LEAN 1           // round 4: the pass with fewer issue slots (0: the round-3 forms, for A/B builds)
+#endif
+
 #ifdef ORC_COST_TIMERS
 __device__ long long orc_cost_dbg[8];   // [0] setup [1] obstacle [2] self collision [3] J^T [4] between rounds (thread 0 of every workgroup adds: use one run)
 #endif
@@ -161,6 +165,52 @@ __device__ __forceinline__ bool sdf_lookup_cell_aligned(const CD & F, const real
    return inb;
 }
 
+// The same lookup in fp64 with fewer issue slots (ORC_LEAN): which side the one-sided difference looks at is a SIGN (+-1.0: one
+// select of a high word) instead of a flag, so the neighbour's offset is one fused multiply-add, `after - before` one product
+// (exact: the factor is +-1), and the cell offset is formed in fp64 (exact below 2^53) and converted once: no quarter-rate
+// integer multiply, no 64-bit address arithmetic (unsigned 32-bit offsets against the field's base in scalar registers).
+// Bit-identical to sdf_lookup_cell_aligned.
+template <typename CD>
+__device__ __forceinline__ bool sdf_lookup_cell_aligned_lean(const CD & F, const double p[3], double & value, double gw[3])
+{
+   double fr[3], sgn[3], fl[3];
+   bool inb = true;
+#pragma unroll
+   for (int k=0; k<3; k++)
+   {
+      const double gx = F.M[4*k] * p[k] + F.t[k];
+      inb = inb && !(gx < 0.0) && !(gx > F.fsize[k]);
+      double f0 = M<double>::floor_(gx);
+      f0 = M<double>::max_(M<double>::min_(f0, F.fsize_m1[k]), 0.0);
+      fl[k] = f0;
+      fr[k] = (gx - f0) - 0.5;
+      // -1: the cell before (previous) is the other end of the difference; +1: the cell after
+      const int hi_mid = (fr[k] < 0.0) ? (int) 0xBFF00000 : 0x3FF00000;
+      const int hi_end = (f0 == F.fsize_m1[k]) ? (int) 0xBFF00000 : hi_mid;
+      sgn[k] = __hiloint2double((f0 == 0.0) ? 0x3FF00000 : hi_end, 0);
+   }
+   const double offr = fma(fl[0], F.stride_r[0], fma(fl[1], F.stride_r[1], fl[2] * F.stride_r[2]));
+   const char * base = (const char *) F.data;
+   const double v0 = *(const double *)(base + (unsigned int) (int) offr);
+   double vn[3];
+#pragma unroll
+   for (int k=0; k<3; k++)
+      vn[k] = *(const double *)(base + (unsigned int) (int) fma(sgn[k], F.stride_r[k], offr));
+   const double inf = M<double>::inf();
+   bool poisoned = (v0 == inf);
+   double v = v0;
+#pragma unroll
+   for (int k=2; k>=0; k--)                     // the reference walks the axes z, y, x
+   {
+      poisoned = poisoned || (vn[k] == inf);
+      const double df = sgn[k] * (vn[k] - v0);  // after - before
+      gw[k] = F.W[4*k] * df;
+      v += df * fr[k];
+   }
+   value = poisoned ? inf : v;
+   return inb;
+}
+
 // ... and for a field in general position (rotated against the world): g = M p + t, world gradient W (after - before)
 template <typename real, typename CD>
 __device__ __forceinline__ bool sdf_lookup_cell(const CD & F, const real p[3], real & value, real gw[3])
@@ -222,18 +272,31 @@ __device__ __forceinline__ bool sdf_lookup_cell(const CD & F, const real p[3], r
 // flags: bit 0 live, bit 1 moving.  The obstacle cost of both sides is summed where it is
 // computed (the per-run cost is a sum over all lanes anyway).
 template <typename real, int K, bool FULL16 = false>
-__device__ __forceinline__ void self_sym_step16(const real * prow, const real * r2row, int srow, unsigned long long live_lanes, const real p[3],
-   real radius, const real u[3], real wself, real eps_self, real inv_eps_self, bool do_iteration,
+__device__ __forceinline__ void self_sym_step16(const real * prow, const real * r2row, const real * srad, int srow, unsigned long long live_lanes, bool live_lane,
+   const real p[3], real radius, const real u[3], real wself, real eps_self, real inv_eps_self, bool do_iteration,
    real f[3], double & cost_sphere)
 {
    constexpr int F = 0x120 + K, B = 0x120 + (16 - K);     // row_ror:K and its inverse
    const int sp = dpp_move<F>(srow);
+#if ORC_LEAN
+   // (LDS addresses are 32 bits: as a generic pointer the partner's address is a 64-bit multiply-add, a quarter-rate instruction)
+   typedef const __attribute__((address_space(3))) real * lds_real_p;
+   lds_real_p pp = (lds_real_p)((unsigned int)(unsigned long long) prow + __umul24((unsigned int) sp, (unsigned int)(3 * sizeof(real))));
+#else
    const real * pp = prow + sp*3;
+#endif
    real d[3];
 #pragma unroll
    for (int k=0; k<3; k++) d[k] = p[k] - pp[k];
    const real d2 = d[0]*d[0] + d[1]*d[1] + d[2]*d[2];
    const real R2 = r2row[(K-1)*16 + srow];
+#if ORC_LEAN
+   // the lane's own bit of the ballot IS the comparison's lane mask: no shift-and-test of the 64-bit mask per lane
+   const bool near = (d2 <= R2) && live_lane;
+   const unsigned long long near_lanes = __builtin_amdgcn_ballot_w64(d2 <= R2) & live_lanes;      // wave-uniform (scalar: and, compare, branch)
+   if (near_lanes == 0ull) return;
+   const real ro = srad[sp];                                // the partner's radius from the table in LDS (two DPP moves otherwise)
+#else
    const unsigned long long near_lanes = __builtin_amdgcn_ballot_w64(d2 <= R2) & live_lanes;      // wave-uniform
    if (near_lanes == 0ull) return;
 #ifdef ORC_ABLATE_ROTF
@@ -241,6 +304,7 @@ __device__ __forceinline__ void self_sym_step16(const real * prow, const real * 
 #endif
    const bool near = (near_lanes >> (threadIdx.x & 63)) & 1ull;
    const real ro = dpp_move<F>(radius);
+#endif
    real uo[3];
 #pragma unroll
    for (int k=0; k<3; k++) uo[k] = dpp_move<F>(u[k]);
@@ -390,7 +454,12 @@ __device__ __forceinline__ void cost_tile_gs16(const BT & b, const ModelView<rea
          for (int u=0; u<U; u++)
          {
             real gw[3], val;
-            const bool inb = sdf_lookup_cell_aligned<real>(F, p[u], val, gw);
+            bool inb;
+#if ORC_LEAN
+            if constexpr (sizeof(real) == 8) inb = sdf_lookup_cell_aligned_lean(F, p[u], val, gw);
+            else
+#endif
+            inb = sdf_lookup_cell_aligned<real>(F, p[u], val, gw);
             const bool better = inb && (val < best[u]);
             best[u] = better ? val : best[u];
             has[u] = has[u] || better;
@@ -469,9 +538,18 @@ __device__ __forceinline__ void cost_tile_gs16(const BT & b, const ModelView<rea
          const real sc2 = scale * (vnorm[u] * b.obs_factor);
          real xg[3], xc[3];
 #pragma unroll
+#if ORC_LEAN
+         // (the best field's gradient is finite -- a poisoned value never wins -- and zero without a field, so scale == 0 gives
+         // an exact zero without a select; the guard of the two projections is one select of their common factor)
+         for (int k=0; k<3; k++) { xg[k] = bgrad[u][k] * sc2; xc[k] = acc[u][k]; }
+         const real ivm = moving[u] ? inv_vn2[u] : (real)0;
+         const real pg = (xg[0]*vel[u][0] + xg[1]*vel[u][1] + xg[2]*vel[u][2]) * ivm;
+         const real pc2 = (xc[0]*vel[u][0] + xc[1]*vel[u][1] + xc[2]*vel[u][2]) * ivm;
+#else
          for (int k=0; k<3; k++) { xg[k] = (scale == (real)0) ? (real)0 : bgrad[u][k] * sc2; xc[k] = acc[u][k]; }
          const real pg = moving[u] ? (xg[0]*vel[u][0] + xg[1]*vel[u][1] + xg[2]*vel[u][2]) * inv_vn2[u] : (real)0;
          const real pc2 = moving[u] ? (xc[0]*vel[u][0] + xc[1]*vel[u][1] + xc[2]*vel[u][2]) * inv_vn2[u] : (real)0;
+#endif
          // x_grad -= cost * curvature, curvature = xc/|v|^2; then c_grad += |v| J^T x_grad.  |v| == 0:
          // the reference's dgemv(alpha=0) leaves c_grad untouched, so the sphere is skipped
          const real cw = cs * inv_vn2[u];
@@ -530,7 +608,7 @@ __device__ __forceinline__ void cost_tile_gs16(const BT & b, const ModelView<rea
       {
          const unsigned long long live_lanes = __builtin_amdgcn_ballot_w64(live[u]);
          const real * prow = pos_s + l[u]*pstr;
-#define ORC_STEP(K) self_sym_step16<real, K, NJ16>(prow, r2_s, s, live_lanes, p[u], radius, uvec[u], wself[u], \
+#define ORC_STEP(K) self_sym_step16<real, K, NJ16>(prow, r2_s, srad_s, s, live_lanes, live[u], p[u], radius, uvec[u], wself[u], \
                        b.epsilon_self, inv_eps_self, do_iteration, f[u], cost_sphere[u])
          ORC_STEP(1); ORC_STEP(2); ORC_STEP(3); ORC_STEP(4); ORC_STEP(5); ORC_STEP(6); ORC_STEP(7); ORC_STEP(8);
 #undef ORC_STEP
@@ -538,7 +616,11 @@ __device__ __forceinline__ void cost_tile_gs16(const BT & b, const ModelView<rea
 #endif
 
 #pragma unroll
+#if ORC_LEAN
+      for (int u=0; u<U; u++) cost_lane += cost_sphere[u];      // (every term of it was masked where it was added)
+#else
       for (int u=0; u<U; u++) cost_lane += live[u] ? cost_sphere[u] : 0.0;
+#endif
 
       ORC_CMARK(2);
       // ---- J^T contraction and reduction over the 16 spheres of a waypoint ----
@@ -558,6 +640,16 @@ __device__ __forceinline__ void cost_tile_gs16(const BT & b, const ModelView<rea
          //                      G_j = axis_j . sum f                          (prismatic)
          // which is sum_s axis_j . ((p_s - anchor_j) x f_s) of src/orcdchomp_mod.cpp:1040-1048,1323.
          real w6[U][6];
+#if ORC_LEAN
+         if (mod.n_static)
+         {
+            const bool stat = ((b.ms.static_mask >> s) & 1ull) != 0;
+#pragma unroll
+            for (int u=0; u<U; u++)
+#pragma unroll
+               for (int k=0; k<3; k++) f[u][k] = stat ? (real)0 : f[u][k];
+         }
+#endif
          if (mod.jt_scan || mod.floating)
          {
 #pragma unroll
@@ -567,8 +659,14 @@ __device__ __forceinline__ void cost_tile_gs16(const BT & b, const ModelView<rea
                w6[u][1] = p[u][2]*f[u][0] - p[u][0]*f[u][2];
                w6[u][2] = p[u][0]*f[u][1] - p[u][1]*f[u][0];
                w6[u][3] = f[u][0]; w6[u][4] = f[u][1]; w6[u][5] = f[u][2];
+#if !ORC_LEAN
 #pragma unroll
                for (int k=0; k<6; k++) w6[u][k] = live[u] ? w6[u][k] : (real)0;
+#endif
+               // (ORC_LEAN: a lane that is not live holds f = 0 -- every addition to f is masked by the lane's own liveness or by a
+               // pair's range entry, -1 for lanes without a sphere -- and a finite position: its wrench is an exact zero already.
+               // The one exception, a static lane (an inactive sphere riding on a free lane receives its pairs' reactions), is
+               // taken out where the forces are final, below.)
             }
          }
          if (mod.jt_scan)
@@ -578,14 +676,22 @@ __device__ __forceinline__ void cost_tile_gs16(const BT & b, const ModelView<rea
                // the scan runs over the spheres sorted by joint: lane i takes the wrench of the i-th of them
                int sl = s;
                __asm__ volatile("" : "+v"(sl));      // keeps the table read inside the pass (hoisted, it is spilled to scratch)
+#if ORC_LEAN
+               const int src = mod.slot_of[sl];      // slot_of[i >= Sa_real]: a slot without an active sphere (batch.cpp), whose wrench is zero
+#else
                const int src = (sl < mod.Sa_real) ? mod.slot_of[sl] : sl;
+#endif
 #pragma unroll
                for (int u=0; u<U; u++)
 #pragma unroll
                   for (int k=0; k<6; k++)
                   {
                      const real v = __shfl(w6[u][k], src, 16);
+#if ORC_LEAN
+                     w6[u][k] = v;      // (lanes past the active spheres fetch a lane whose wrench is zero: `src` below)
+#else
                      w6[u][k] = (s < mod.Sa_real) ? v : (real)0;
+#endif
                   }
             }
 #pragma unroll
@@ -616,7 +722,11 @@ __device__ __forceinline__ void cost_tile_gs16(const BT & b, const ModelView<rea
                   for (int k=0; k<6; k++)
                   {
                      const real hi = __shfl(w6[u][k], ab & 15, 16);
+#if ORC_LEAN
+                     W[k] = hi;         // (a joint that moves no sphere: the result is selected to zero below, once)
+#else
                      W[k] = (ab < 16) ? hi : (real)0;
+#endif
                   }
                   if (mod.jt_scan == 2)
                   {
@@ -633,7 +743,19 @@ __device__ __forceinline__ void cost_tile_gs16(const BT & b, const ModelView<rea
                   const real c2 = W[2] - (ax[3]*W[4] - ax[4]*W[3]);
                   const real crev = ax[0]*c0 + ax[1]*c1 + ax[2]*c2;
                   const real cpri = ax[0]*W[3] + ax[1]*W[4] + ax[2]*W[5];
+#if ORC_LEAN
+                  const real gj = (ab < 16) ? (rev ? crev : cpri) : (real)0;      // (ab == 16: the joint moves no sphere)
+                  if (jok && (item < items) && (wl[u] < nw))
+                  {
+                     // (the gradient rows are in LDS for most layouts: an LDS store with a 32-bit address instead of a flat one)
+                     typedef __attribute__((address_space(3))) real * lds_real_w;
+                     const unsigned int gi = (unsigned int)((ts + wl[u])*n + col);
+                     if (b.g_in_lds) ((lds_real_w)(unsigned int)(unsigned long long) G_s)[gi] = gj;
+                     else G_s[gi] = gj;
+                  }
+#else
                   if (jok && (item < items) && (wl[u] < nw)) G_s[(ts + wl[u])*n + col] = rev ? crev : cpri;
+#endif
                }
             }
          }

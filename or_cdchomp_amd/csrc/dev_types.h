@@ -19,6 +19,7 @@
 #define ORC_WGS_PER_CU_FP32_MANY 4   // ... of the fp32 kernels for more than 16 active spheres (128 VGPRs)
 #endif
 #define ORC_SCAN_RPL      4       // rows per lane of the scan solve: m <= 64*ORC_SCAN_RPL
+#define ORC_VERDICT_NONE  0x7fffffffffffffffull      // key of a run without a contact (collision_verdict_kernel)
 #define ORC_LDS_HEADER    256     // bytes in front of the LDS carve-up: reduction scratch [16] doubles, [8] ints, column masks, timer mark, phase counters [8]
 #define ORC_LIM_LIST      64      // violated entries the sparse joint-limit rounds handle
 #define ORC_LIM_SCRATCH  (256 + ORC_LIM_LIST*16)   // bytes: 4 wave records + header, entry list
@@ -70,7 +71,7 @@ struct DevModel
    int Sa_real;            // active spheres (sorted by the joint they ride on: the order of sph_pos, J^T ranges, slot_of)
    int placed;             // slot_of is not the identity
    unsigned long long live_mask;   // bit s: lane/slot s of the active block holds a sphere
-   int slot_of[ORC_MAX_SPHERES];   // sorted index -> slot (lane of the DPP row / index of pos, sph_radius, sph_link, sph_affects)
+   int slot_of[ORC_MAX_SPHERES];   // sorted index -> slot (lane of the DPP row / index of pos, sph_radius, sph_link, sph_affects); placed rows: entries Sa_real .. 15 name slots WITHOUT an active sphere (the J^T scan fetches an exact zero through them)
    int GS;                 // lanes per waypoint in the cost phase (power of two >= Sa)
    int base_sph_begin;     // active spheres fixed to the base frame (floating base only)
    int base_sph_end;
@@ -131,6 +132,8 @@ struct DevSdfCell
    real fsize_m1[3];       // size - 1
    int stride_b[2];        // byte strides of the x and y axes (z: sizeof(real))
    const real * data;      // C order [x][y][z]
+   real stride_r[3];       // the byte strides of the three axes as reals (fp64: cell offsets are formed by fused multiply-adds, exactly)
+   real pad_;
 };
 
 // a TSR hard constraint on every moving point (struct run_contsr + struct tsr of the reference,
@@ -271,7 +274,7 @@ struct DevVerdict
    const real * inact_pos;     // [inactive spheres][3] world positions
    // first contact of a run, or INT_MAX: (sample << 16) | (self << 15) | (XML sphere (a) << 8) | (field, or XML sphere b):
    // within a sample the fields come first (sphere, field order), then the pairs
-   int * key_out;              // [n_runs]
+   unsigned long long * key_out;   // [n_runs]: ORC_VERDICT_NONE, or sample << 32 | pair bit << 31 | XML sphere << 16 | field or partner sphere
    double * depth_out;         // [n_runs] penetration depth of that contact
 };
 

@@ -1067,8 +1067,13 @@ std::string Module::cmd_iterate(const std::vector<std::string> & argv, bool batc
    if (have_fileform && b.params.floating_base)
       throw std::runtime_error("Error: trajs_fileformstr and floating_base combined is not yet implemented!");
    // the pattern goes to printf with (iteration) for one run as in the reference (mod.cpp:2783-2784), with
-   // (iteration, run) for a batch: exactly those integer conversions and no other
-   if (have_fileform && count_int_conversions(fileform) != (b.n_runs > 1 ? 2 : 1)) bad_arguments();
+   // (iteration, run) for a batch: those integer conversions and no other.  One run may also pass a constant name (no
+   // conversion: every iteration overwrites the file, which is what the reference's sprintf makes of it)
+   if (have_fileform)
+   {
+      const int nconv = count_int_conversions(fileform);
+      if (b.n_runs > 1 ? nconv != 2 : (nconv != 0 && nconv != 1)) bad_arguments();
+   }
    // seconds since the call began, without the time spent writing trajectory dumps (mod.cpp:2748-2750,
    // 2781-2795: the reference stops its clock around the dump)
    auto t_last = std::chrono::steady_clock::now();
@@ -1167,7 +1172,7 @@ static void plan_collision_samples(const double * traj, int n_points, int n, int
    }
 }
 
-void Module::batch_collision_verdict(int id, int * collides, double * time, int * sphere, int * field, double * depth)
+void Module::batch_collision_verdict(int id, int * collides, double * time, int * sphere, int * field, double * depth, bool self_check)
 {
    Batch & b = batch(id);
    const int col0 = b.params.floating_base ? 7 : 0;
@@ -1185,11 +1190,13 @@ void Module::batch_collision_verdict(int id, int * collides, double * time, int 
       const std::vector<double> dtm = retime_linear(tk, b.n_points, b.n, col0, vmax);
       plan_collision_samples(tk, b.n_points, b.n, col0, dtm, seg, u, times);
       offs[k+1] = (int) seg.size();
-      if (offs[k+1] - offs[k] >= (1 << 15)) throw std::runtime_error("trajectory too long for the batched collision verdict!");
+      if (offs[k+1] - offs[k] >= (1 << 30)) throw std::runtime_error("trajectory too long for the batched collision verdict!");
    }
    // the pairs of the self-collision leg (`|| CheckSelfCollision`, mod.cpp:2998-2999): spheres on links that may
    // collide, in XML order; an end is a slot of the device's position row or an inactive sphere's world position
    std::vector<int> pairs; std::vector<double> rsum, inact_pos;
+   if ((int) rob.spheres.size() > 128) throw std::runtime_error("too many spheres for the batched collision verdict!");
+   if (self_check && rob.self_check)
    {
       const std::vector<unsigned char> excl = rob.self_pairs_excluded();
       const int ns = (int) rob.spheres.size();
@@ -1213,18 +1220,20 @@ void Module::batch_collision_verdict(int id, int * collides, double * time, int 
             pairs.push_back(end_of[a]); pairs.push_back(end_of[c]); pairs.push_back(a); pairs.push_back(c);
             rsum.push_back(rob.spheres[a].radius + rob.spheres[c].radius);
          }
-      if (ns > 128) throw std::runtime_error("too many spheres for the batched collision verdict!");
    }
-   std::vector<int> key(b.n_runs); std::vector<double> dep(b.n_runs);
+   std::vector<unsigned long long> key(b.n_runs); std::vector<double> dep(b.n_runs);
    b.collision_verdict(offs, seg, u, pairs, rsum, inact_pos, key.data(), dep.data());
+   if (getenv("ORC_DEBUG_VERDICT"))
+      for (int k=0; k<b.n_runs; k++) fprintf(stderr, "verdict run %d key %016llx samples %d\n", k, key[k], offs[k+1] - offs[k]);
    for (int k=0; k<b.n_runs; k++)
    {
-      const bool hit = key[k] != 0x7fffffff;
-      const bool self = hit && ((key[k] >> 15) & 1);
+      // key: sample << 32 | pair bit << 31 | XML sphere << 16 | field (or, for a pair, the other sphere)
+      const bool hit = key[k] != ORC_VERDICT_NONE;
+      const bool self = hit && ((key[k] >> 31) & 1ull);
       if (collides) collides[k] = hit ? 1 : 0;
-      if (time) time[k] = hit ? times[(size_t) offs[k] + (key[k] >> 16)] : -1.0;
-      if (sphere) sphere[k] = hit ? ((key[k] >> 8) & 127) : -1;
-      if (field) field[k] = hit ? (self ? -2 - (key[k] & 255) : (key[k] & 255)) : -1;      // a pair: -2 - the other sphere
+      if (time) time[k] = hit ? times[(size_t) offs[k] + (size_t)(key[k] >> 32)] : -1.0;
+      if (sphere) sphere[k] = hit ? (int)((key[k] >> 16) & 0x7fffull) : -1;
+      if (field) field[k] = hit ? (self ? -2 - (int)(key[k] & 0xffffull) : (int)(key[k] & 0xffffull)) : -1;      // a pair: -2 - the other sphere
       if (depth) depth[k] = hit ? dep[k] : 0.0;
    }
 }
@@ -1233,7 +1242,7 @@ void Module::batch_collision_verdict(int id, int * collides, double * time, int 
 std::string Module::cmd_gettraj(const std::vector<std::string> & argv, bool batchmode)
 {
    int run = 0;
-   bool no_collision_check = false, no_collision_exception = false, no_collision_details = false;
+   bool no_collision_check = false, no_collision_exception = false, no_collision_details = false, no_self_check = false;
    double * out_ptr = nullptr;
    int * verdict_ptr = nullptr;
    const int argc = (int) argv.size();
@@ -1244,6 +1253,7 @@ std::string Module::cmd_gettraj(const std::vector<std::string> & argv, bool batc
       else if (argv[i] == "no_collision_check") no_collision_check = true;
       else if (argv[i] == "no_collision_exception") no_collision_exception = true;
       else if (argv[i] == "no_collision_details") no_collision_details = true;
+      else if (argv[i] == "no_self_collision_check") no_self_check = true;      // additive: the field leg of the re-check alone
       else if (batchmode && argv[i] == "out" && i+1 < argc) out_ptr = (double *) parse_pointer(argv[++i]);
       else if (batchmode && argv[i] == "verdict" && i+1 < argc) verdict_ptr = (int *) parse_pointer(argv[++i]);
       else break;
@@ -1257,7 +1267,7 @@ std::string Module::cmd_gettraj(const std::vector<std::string> & argv, bool batc
    {
       if (!out_ptr) throw std::runtime_error("gettrajbatch needs out %p!");
       std::memcpy(out_ptr, traj.data(), traj.size() * sizeof(double));
-      if (verdict_ptr) batch_collision_verdict(run, verdict_ptr, nullptr, nullptr, nullptr, nullptr);
+      if (verdict_ptr) batch_collision_verdict(run, verdict_ptr, nullptr, nullptr, nullptr, nullptr, !no_self_check);
       return "";
    }
    const int col0 = b.params.floating_base ? 7 : 0;
@@ -1329,7 +1339,7 @@ std::string Module::cmd_gettraj(const std::vector<std::string> & argv, bool batc
             }
          }
          // ... || CheckSelfCollision (mod.cpp:2998-2999): two spheres on links that may collide overlap
-         for (size_t a=0; a<rob.spheres.size() && !collides; a++)
+         for (size_t a=0; a<rob.spheres.size() && !collides && !no_self_check && rob.self_check; a++)
             for (size_t c=a+1; c<rob.spheres.size(); c++)
             {
                const Robot::Sphere & sa = rob.spheres[a], & sc = rob.spheres[c];

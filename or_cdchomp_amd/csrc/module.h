@@ -39,6 +39,7 @@ struct Robot                      // what the path reads from an OpenRAVE::Robot
    std::vector<Manip> manips;
    int active_manip = 0;                       // GetActiveManipulator
    std::vector<std::pair<int, int>> adjacent;  // link pairs the robot description declares adjacent (<adjacent> tags)
+   bool self_check = true;                     // the sphere-pair stand-in for CheckSelfCollision in gettraj's re-check (orc_robot_set_self_check)
    // kinbodies the robot holds, in the order they were grabbed (RobotBase::Grab / GetGrabbed, src/orcdchomp_mod.cpp:2168-2171):
    // the body is rigid with `link` from the moment of the grab, `rel` = T_w_link^-1 o T_w_body at that moment
    struct Grab { std::string body; int link; Xform rel; };
@@ -150,7 +151,7 @@ public:
    // first contact of every run's trajectory with a field, on the device (Module::batch_collision_verdict plans the samples)
    void collision_verdict(const std::vector<int> & offs, const std::vector<int> & seg, const std::vector<double> & u,
                           const std::vector<int> & pairs, const std::vector<double> & pair_rsum, const std::vector<double> & inact_pos,
-                          int * key_out, double * depth_out);
+                          unsigned long long * key_out, double * depth_out);
    void get_phase_cycles(long long * out);   // [n_runs][8], diagnostics (ORC_PHASE_TIMERS=1)
    // kernel timing: completed event pairs are added to the module's totals (all of them when `wait`)
    void harvest_events(bool wait);
@@ -235,7 +236,7 @@ public:
    void set_traj(const double * traj);
    void collision_verdict(const std::vector<int> & offs, const std::vector<int> & seg, const std::vector<double> & u,
                           const std::vector<int> & pairs, const std::vector<double> & pair_rsum, const std::vector<double> & inact_pos,
-                          int * key_out, double * depth_out);
+                          unsigned long long * key_out, double * depth_out);
    void get_phase_cycles(long long * out);
    // the per-iteration log of create's dat_filename (src/orcdchomp_mod.cpp:2306-2310, 2811-2818)
    void open_dat(const std::string & pattern);
@@ -302,7 +303,7 @@ public:
    void destroy_batch(int id);
    // collision verdict of all runs of a batch (gettraj's re-check, batched on the device): per run
    // collides (0/1), time of the first contact on the retimed trajectory, XML sphere, field, depth
-   void batch_collision_verdict(int id, int * collides, double * time, int * sphere, int * field, double * depth);
+   void batch_collision_verdict(int id, int * collides, double * time, int * sphere, int * field, double * depth, bool self_check = true);
 
    hipStream_t stream = nullptr;     // orc_set_stream: the stream of the first device's work (NULL: its default stream)
    int device;                       // first entry of `devices`

@@ -861,6 +861,7 @@ __device__ __attribute__((noinline)) void phase_tsr(const void * kp)
 #ifndef ORC_TSR_LDS
       if (BLOCK >= 128 && m >= 4 && n <= 62)
          shape = (Wm <= 16 && Nm <= 8) ? 16 : ((Wm <= 32 && Nm <= 16) ? 32 : ((Wm <= 64 && Nm <= 20) ? 64 : 0));
+         if (Nm - n > 16) shape = 0;      // (the row lists of a point hold 16 entries: more constrained rows on one point take the dense path)
 #endif
       if (!shape)
       {

@@ -115,6 +115,10 @@ class Module:
     def set_active_manipulator(self, robot, name):
         self._check(self._lib.orc_robot_set_active_manipulator(self._h, robot.encode(), name.encode()))
 
+    def set_self_check(self, robot, enabled=True):
+        """the sphere-pair stand-in for CheckSelfCollision in gettraj's re-check, per robot (default on)"""
+        self._check(self._lib.orc_robot_set_self_check(self._h, robot.encode(), 1 if enabled else 0))
+
     def set_robot_transform(self, name, pose):
         self._check(self._lib.orc_robot_set_transform(self._h, name.encode(), _dp(_f64(pose))))
 

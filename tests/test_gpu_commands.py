@@ -406,7 +406,23 @@ def test_self_collision_in_the_recheck(oracle):
             assert np.isclose(float(m.group(4)), want["depth"], rtol=1e-4, atol=1e-9)
             with pytest.raises(RuntimeError, match="Resulting trajectory is in collision!"):
                 mod.gettraj(run=run)
+            # the stand-in can be left out: for one call (an additive flag of gettraj) ...
+            mod.SendCommand("gettraj run %s no_self_collision_check" % run)
+            assert mod.last_collision_details() == ""
         else:
             assert details == ""
         mod.destroy(run=run)
     assert 3 <= n_self < n_runs, n_self
+    # ... or for the robot (orc_robot_set_self_check): the field leg of the re-check alone is left, and nothing is near the field
+    mod.set_self_check(model.name, False)
+    bid = mod.batch_create(model.name, goals, **kw)
+    assert mod.batch_collision_verdict(bid)["collides"].sum() == 0
+    run = mod.create(robot=model.name, adofgoal=list(goals[-1]), **kw)
+    mod.gettraj(run=run)
+    mod.destroy(run=run)
+    mod.set_self_check(model.name, True)
+    assert mod.batch_collision_verdict(bid)["collides"].sum() == n_self
+    ver = np.full(n_runs, -7, dtype=np.int32); out = np.zeros((n_runs, 40, 7))
+    mod.SendCommand("gettrajbatch run %d out 0x%x verdict 0x%x no_self_collision_check" % (bid, out.ctypes.data, ver.ctypes.data))
+    assert ver.sum() == 0
+    mod.batch_destroy(bid)
