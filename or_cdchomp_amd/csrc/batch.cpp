@@ -919,7 +919,7 @@ void BatchShard::build_device(const Robot & robot)
    for (int pass=0; pass<2 && !tile_m_; pass++)
    {
    max_wgs = max_wgs_default; force_block = force_block_asked;
-   budget4 = (pass == 0) && (want_wgs == 4) && sizeof(real) == 8 && (tree_ & 16) && (tree_ & 2) && !(tree_ & 64) && (force_block == 0 || force_block == 256)
+   budget4 = (pass == 0) && (want_wgs == 4) && sizeof(real) == 8 && (tree_ & 16) && (tree_ & 2) && (!(tree_ & 64) || (tree_ & 160) == 160) && (force_block == 0 || force_block == 256)
                         && !getenv("ORC_BLOCK_THREADS") && !getenv("ORC_WGS") && !getenv("ORC_TILE_M");      // (the experiments' switches come first)
    if (budget4) { max_wgs = 4; force_block = 256; }
    if (const char * e = getenv("ORC_BLOCK_THREADS")) force_block = atoi(e);
@@ -953,10 +953,15 @@ void BatchShard::build_device(const Robot & robot)
          for (int t_lds=1; t_lds>=0; t_lds--)
          {
             if (force_g >= 0 && g_lds != force_g) continue;
-            if (!t_lds && (GS_ == 16 || g_lds)) continue;      // the trajectory in global memory: generic cost path, after G went there
+            if (!t_lds && g_lds) continue;                      // the trajectory in global memory: after G went there
             if (!t_lds && params.free_start) continue;         // start_tsr: the workgroup's copy has a row the global rows do not
-            if (force_tl >= 0 && t_lds != force_tl && GS_ != 16 && !g_lds) continue;
-            const int flags = (solve_mode_ == 2 ? ORC_LDS_SMALL_WORK : 0) | (g_lds ? 0 : ORC_LDS_G_GLOBAL) | (t_lds ? 0 : ORC_LDS_T_GLOBAL);
+            if (force_tl >= 0 && t_lds != force_tl && !g_lds) continue;
+            if (!t_lds && GS_ == 16 && n_tsrs_ > 0) continue;   // (the constraint phase of the 16-lane kernels reads the LDS copy)
+            // T in global memory: the update phase and the cost sums work on a copy staged in the dead tile buffers (round 4)
+            // unless the run has constraints (their phase reads the trajectory where FK does) or ORC_T_STAGED=0
+            const bool want_staged = !t_lds && n_tsrs_ == 0 && !(getenv("ORC_T_STAGED") && atoi(getenv("ORC_T_STAGED")) == 0);
+            int flags = (solve_mode_ == 2 ? ORC_LDS_SMALL_WORK : 0) | (g_lds ? 0 : ORC_LDS_G_GLOBAL) | (t_lds ? 0 : ORC_LDS_T_GLOBAL)
+                      | (want_staged ? ORC_LDS_T_STAGED : 0);
             if (with_pcr && !pcr_rows) continue;
             if (force_pcr >= 0 && with_pcr != force_pcr && pcr_rows) continue;
             if (!ag_lds && !params.use_momentum) continue;
@@ -964,17 +969,25 @@ void BatchShard::build_device(const Robot & robot)
             for (int t=(m < 254 ? m : 254); t>=1; t--)
             {
                if (force_t > 0 && t != (force_t < m ? force_t : m)) continue;
-               const size_t need = orc_chomp_lds_bytes(m + 2, n, Sa_, S_, nj, t, with_pcr ? pcr_rows : 0, sizeof(real),
-                                                       params.use_momentum && ag_lds, n_sdfs_, flags);
+               size_t need = orc_chomp_lds_bytes(m + 2, n, Sa_, S_, nj, t, with_pcr ? pcr_rows : 0, sizeof(real),
+                                                 params.use_momentum && ag_lds, n_sdfs_, flags);
+               if (need > budget && (flags & ORC_LDS_T_STAGED))
+               {
+                  // (tiles too small to hold the copy: the trajectory is iterated in place through L2)
+                  const size_t plain = orc_chomp_lds_bytes(m + 2, n, Sa_, S_, nj, t, with_pcr ? pcr_rows : 0, sizeof(real),
+                                                           params.use_momentum && ag_lds, n_sdfs_, flags & ~ORC_LDS_T_STAGED);
+                  if (plain <= budget) { need = plain; flags &= ~ORC_LDS_T_STAGED; }
+               }
                if (need > budget) continue;
                const int tiles = (m + t - 1) / t;
-               const double fk_passes = tiles * std::ceil((t + 2) / (block / 4.0));
+               // an FK pass of the workgroup covers 20 waypoints per wavefront (fk.h: triads of lanes)
+               const double fk_passes = tiles * std::ceil((t + 2) / (block / 64 * 20.0));
                const double rounds = tiles * std::ceil(t * (double) lanes_per_wp / block);
                // measured: an FK pass costs ~1.7k cycles per joint, a round of the 16-lane cost phase ~11k,
                // of the generic one ~350 per active sphere (WAM / 30-dof tree, scripts/phase_profile*.py)
                const double fk_pass = 1.7e3 * nj, round_cycles = (GS_ == 16) ? 11e3 : 350.0 * Sa_;
                const double cycles = fk_pass * fk_passes + round_cycles * rounds + 30e3 * (256.0 / block) + (with_pcr ? 0.0 : 1e3) + (ag_lds ? 0.0 : 2e3)
-                                   + (g_lds ? 0.0 : 2e3) + (t_lds ? 0.0 : 6e3);
+                                   + (g_lds ? 0.0 : 2e3) + (t_lds ? 0.0 : ((flags & ORC_LDS_T_STAGED) ? 4e3 : 12e3));
                const double waves_per_simd = wgs * block / 256.0;
                // (four workgroups of three wavefronts measured 7-10 % below three of four at equal wavefronts per SIMD)
                const double score = wgs * (1.0 - 0.05 * (waves_per_simd - 1.0)) * (block == 192 ? 0.90 : 1.0) / cycles;
@@ -1231,7 +1244,7 @@ void BatchShard::launch(int n_iter, bool final_eval, bool carry)
    b.tile_m = tile_m_;
    b.n_tiles = n_tiles_; b.tile_first = tile_first_; b.tile_rest = tile_rest_;
    b.traj = (real *) d_traj_; b.AG = (real *) d_AG_; b.Gdbg = (real *) d_G_; b.Gcost = (real *) d_Gcost_;
-   b.g_in_lds = g_in_lds_; b.lds_flags = lds_flags_; b.t_in_lds = t_in_lds_;
+   b.g_in_lds = g_in_lds_; b.lds_flags = lds_flags_; b.t_in_lds = t_in_lds_; b.t_staged = (lds_flags_ & ORC_LDS_T_STAGED) ? 1 : 0;
    b.ms = ms_;
    b.lay = lds_layout(m + 2, n, Sa_, S_, nj_, tile_m_, pcr_in_lds_ ? pcr_rows_ : 0, (int) sizeof(real),
                       params.use_momentum && ag_in_lds_, n_sdfs_, (int) sizeof(DevSdf<real>), lds_flags_);

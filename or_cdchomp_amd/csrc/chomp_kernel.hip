@@ -920,6 +920,7 @@ struct Env
    double * red; int * redi; unsigned int * colmask_s;
    long long * phc_s;                      // [8] per-phase cycle counters (diagnostics), thread 0
    real * T_s, * G_s, * Gc, * W_s, * pos_s, * ax_s, * srad_s, * sinact_s, * jl_s, * r2_s, * pcr_s, * sphpos_s, * base_s;
+   real * T_u;                             // the trajectory as the update phase and the cost sums see it: T_s, or its staged copy (DevBatch::t_staged)
    int * slink_s, * jtype_s, * jcol_s, * slot_s;
    int * jctl_s; DevSdf<real> * sdfs_s; unsigned long long * saff_s, * sallow_s;
    real * traj_g, * AG_g, * AG_s;
@@ -945,7 +946,8 @@ __device__ __forceinline__ Env<real> make_env(const BT & b, unsigned char * smem
    // [np][n]; the kernels of the generic cost path may leave it in global memory (large robots: the
    // LDS then holds tiles only and a third workgroup fits the CU); __syncthreads orders the accesses
    // of a workgroup's wavefronts to it
-   E.T_s  = (!GS16 && !b.t_in_lds) ? E.traj_g : lds + L.T;
+   E.T_s  = !b.t_in_lds ? E.traj_g : lds + L.T;      // (the 16-lane kernels too, since round 4: long runs trade the LDS copy for larger tiles)
+   E.T_u  = (!b.t_in_lds && b.t_staged) ? lds + L.Tu : E.T_s;
    E.G_s  = lds + L.G;                                     // [m][n] (inside the tile buffers when !g_in_lds: update phase only)
    E.Gc = b.g_in_lds ? E.G_s : b.Gcost + (size_t) run * mn;   // where the cost phase puts its gradient rows
    E.W_s  = lds + L.W;                                     // [m][n] work
@@ -1018,7 +1020,7 @@ __device__ __attribute__((noinline)) void phase_setup(const void * kp)
    const int tid = threadIdx.x;
    const int n = b.n, m = b.m, np = b.n_points, mn = m*n;
    const int nj = E.mod.nj, Sa = E.mod.Sa, S = E.mod.S;
-   if (GS16 || b.t_in_lds)
+   if (b.t_in_lds)
    {
       // start_tsr: the start point is the first moving row.  The row in front of it is not a trajectory
       // point (no start boundary in the metric); it holds a copy of the point AFTER the start point, so that
@@ -1102,6 +1104,24 @@ __device__ __attribute__((noinline)) void phase_hmc(const void * kp, int slot_in
    const real * nz = b.noise + ((size_t) blockIdx.x * b.max_resamples + slot) * mn;
    for (int e=threadIdx.x; e<mn; e+=BLOCK) E.AG_s[e] = nz[e];
    __syncthreads();
+}
+
+// copy `count` reals between global memory and LDS with eight loads in flight per thread (a plain loop waits for every
+// load before it issues the next: a round trip through L2 or the Infinity Cache per 2 KB)
+template <typename real, int BLOCK>
+__device__ __forceinline__ void copy_batched(real * dst, const real * src, int count)
+{
+   const int tid = threadIdx.x;
+   int e = tid;
+   for (; e + 7*BLOCK < count; e += 8*BLOCK)
+   {
+      real v[8];
+#pragma unroll
+      for (int q=0; q<8; q++) v[q] = src[e + q*BLOCK];
+#pragma unroll
+      for (int q=0; q<8; q++) dst[e + q*BLOCK] = v[q];
+   }
+   for (; e < count; e += BLOCK) dst[e] = src[e];
 }
 
 // ---- FK phase of one tile: lane = (waypoint, world axis) (sphere_cost_pre, src/orcdchomp_mod.cpp:988-1093) ----
@@ -1232,8 +1252,17 @@ __device__ __attribute__((noinline)) int phase_update(const void * kp, int it_in
    const int n = b.n, m = b.m, mn = m*n;
    const float rn_f = 1.0f / (float) n;        // for div_n
    double * red = E.red; int * redi = E.redi; unsigned int * colmask_s = E.colmask_s;
-   real * T_s = E.T_s, * G_s = E.G_s, * Gc = E.Gc, * W_s = E.W_s, * jl_s = E.jl_s, * AG_g = E.AG_g, * AG_s = E.AG_s;
+   real * T_s = E.T_u, * G_s = E.G_s, * Gc = E.Gc, * W_s = E.W_s, * jl_s = E.jl_s, * AG_g = E.AG_g, * AG_s = E.AG_s;
    const real * pcr_tab = E.pcr_tab;
+   const bool staged = !b.t_in_lds && b.t_staged;
+   if (staged)
+   {
+      // the trajectory lives in global memory (FK reads it there, larger tiles in exchange); this phase works on a copy in the
+      // tile buffers, which are dead by now: one coalesced read here and one write at the end instead of stencils and
+      // column scans through L2 (the preceding cost pass ended with a barrier)
+      copy_batched<real, BLOCK>(T_s, E.traj_g, b.n_points*n);
+      __syncthreads();
+   }
 
    __builtin_amdgcn_s_setprio(ORC_PRIO_UPDATE);
    if (tid < 2) colmask_s[tid] = 0u;       // read last after the previous step's barrier, set again after the next one
@@ -1331,7 +1360,7 @@ __device__ __attribute__((noinline)) int phase_update(const void * kp, int it_in
          if (tid < 64)
          {
             const real kinv = (real)(-1) / ((real)(m + 1) * b.a_off);      // 1/((m+1) ca), ca = -a_off
-            const LimResult lr = (GS16 || b.t_in_lds) ? limit_rounds_call<real, (BLOCK == 512) ? 1 : (WGS ? 2 : 0)>(T_s, G_s, jl_s, m, n, kinv, viol_cols)
+            const LimResult lr = (b.t_in_lds || staged) ? limit_rounds_call<real, (BLOCK == 512) ? 1 : (WGS ? 2 : 0)>(T_s, G_s, jl_s, m, n, kinv, viol_cols)
                                                       : limit_rounds_call_global<real, (BLOCK == 512) ? 1 : (WGS ? 2 : 0)>(T_s, G_s, jl_s, m, n, kinv, viol_cols);
             if (b.phase_cycles && tid == 0) E.phc_s[7] += lr.kinds;
             if (tid == 0) redi[0] = lr.rounds;
@@ -1454,6 +1483,12 @@ __device__ __attribute__((noinline)) int phase_update(const void * kp, int it_in
          __syncthreads();
       }
    }
+   if (staged)
+   {
+      // the moving rows back to global memory (the end points do not move); every path above ended with a barrier
+      copy_batched<real, BLOCK>(E.traj_g + n, T_s + n, mn);
+      __syncthreads();
+   }
    phase_mark<real>(b, E, 4);
    if (b.phase_cycles && tid == 0) E.phc_s[6] += num_limadjs;   // rounds (phc[7]: kinds of rounds, see LimResult)
    return num_limadjs;
@@ -1474,7 +1509,14 @@ __device__ __attribute__((noinline)) PassCosts phase_costs(const void * kp, int 
    const int tid = threadIdx.x;
    const int n = b.n, m = b.m, np = b.n_points, mn = m*n;
    const float rn_f = 1.0f / (float) n;
-   const real * T_s = E.T_s;
+   const real * T_s = E.T_u;
+   const bool staged = !b.t_in_lds && b.t_staged;
+   if (staged && !do_iteration)
+   {
+      // the cost-only pass that ends a call: no update phase has staged the trajectory
+      copy_batched<real, BLOCK>(E.T_u, E.traj_g, np*n);
+      __syncthreads();
+   }
    PassCosts pc;
    __builtin_amdgcn_s_setprio(ORC_PRIO_UPDATE);
    {
@@ -1532,13 +1574,14 @@ __device__ __attribute__((noinline)) PassCosts phase_costs(const void * kp, int 
    // floating base: renormalise the quaternion of every row (mod.cpp:2806-2808)
    if (do_iteration && E.mod.floating)
    {
-      real * Tw = E.T_s;
+      real * Tw = E.T_u;
       for (int w=tid; w<np; w+=BLOCK)
       {
          real * row = Tw + w*n;
          const real len = M<real>::sqrt_(row[3]*row[3] + row[4]*row[4] + row[5]*row[5] + row[6]*row[6]);
          const real inv = (real)1 / len;
          row[3] *= inv; row[4] *= inv; row[5] *= inv; row[6] *= inv;
+         if (staged) { real * g = E.traj_g + w*n; g[3] = row[3]; g[4] = row[4]; g[5] = row[5]; g[6] = row[6]; }      // (the copy's rows go back where FK reads them)
       }
       __syncthreads();
    }
@@ -1556,7 +1599,7 @@ __device__ __attribute__((noinline)) void phase_finish(const void * kp, int stat
    const int run = blockIdx.x, tid = threadIdx.x;
    const int n = b.n, m = b.m, np = b.n_points, mn = m*n;
    __syncthreads();
-   if (GS16 || b.t_in_lds)
+   if (b.t_in_lds)
    {
       const int skip = b.free_start ? n : 0;
       for (int e=skip+tid; e<np*n; e+=BLOCK) E.traj_g[e - skip] = E.T_s[e];
@@ -1888,15 +1931,21 @@ template <typename real>
 static hipError_t launch_iterate_t(const DevBatch<real> & b, size_t lds, hipStream_t stream, int variant)
 {
 #ifdef ORC_FAST_BUILD
-   // experiment builds (make var DEFS=-DORC_FAST_BUILD): only the kernels of the config-2 bench legs are compiled (the fp64
+   // experiment builds (make var DEFS=-DORC_FAST_BUILD=2): only the kernels of the config-2 bench legs are compiled (the fp64
    // fixed-base chain with placed spheres, one aligned field, no inactive sphere left: KIND 11), half a minute instead of three
    if constexpr (sizeof(real) == 8)
    {
-      if ((variant & (16 | 2 | 1)) == (16 | 2) && (((variant & 32) ? 2 : 0) | 1 | (((variant & 160) == 160) ? 8 : 0)) == 11 && !(variant & 64))
+      const int kind = 1 | ((variant & 32) ? 2 : 0) | ((variant & 64) ? 4 : 0) | (((variant & 160) == 160) ? 8 : 0);
+      if ((variant & (16 | 2 | 1)) == (16 | 2))
       {
-         if ((variant & 256) && !(variant & (4 | 8))) return launch_iterate_tt<real, false, true, 256, 11, 4>(b, lds, stream);
-         if (variant & 4) return launch_iterate_tt<real, false, true, 192, 11>(b, lds, stream);
-         if (!(variant & 8)) return launch_iterate_tt<real, false, true, 256, 11>(b, lds, stream);
+#if ORC_FAST_BUILD == 4      // -DORC_FAST_BUILD=4: BASELINE configs[3] (floating base, KIND 15) at the default shape and at four workgroups per CU
+         if (kind == 15 && (variant & 256) && !(variant & (4 | 8))) return launch_iterate_tt<real, false, true, 256, 15, 4>(b, lds, stream);
+         if (kind == 15 && !(variant & (4 | 8))) return launch_iterate_tt<real, false, true, 256, 15>(b, lds, stream);
+#else
+         if (kind == 11 && (variant & 256) && !(variant & (4 | 8))) return launch_iterate_tt<real, false, true, 256, 11, 4>(b, lds, stream);
+         if (kind == 11 && (variant & 4)) return launch_iterate_tt<real, false, true, 192, 11>(b, lds, stream);
+         if (kind == 11 && !(variant & 8)) return launch_iterate_tt<real, false, true, 256, 11>(b, lds, stream);
+#endif
       }
    }
    return hipErrorInvalidValue;
@@ -1918,12 +1967,13 @@ static hipError_t launch_iterate_t(const DevBatch<real> & b, size_t lds, hipStre
       const int kind = 1 | ((variant & 32) ? 2 : 0) | ((variant & 64) ? 4 : 0) | (((variant & 160) == 160) ? 8 : 0);
       // bit 8: the kernels built for four 256-thread workgroups per CU (orc_set_workgroups_per_cu; fp64 fixed-base chains)
       if constexpr (sizeof(real) == 8)
-         if ((variant & 256) && !(variant & (4 | 8 | 64)))
+         if ((variant & 256) && !(variant & (4 | 8)))
             switch (kind)
             {
             case 1: return launch_iterate_tt<real, false, true, 256, 1, 4>(b, lds, stream);
             case 3: return launch_iterate_tt<real, false, true, 256, 3, 4>(b, lds, stream);
             case 11: return launch_iterate_tt<real, false, true, 256, 11, 4>(b, lds, stream);
+            case 15: return launch_iterate_tt<real, false, true, 256, 15, 4>(b, lds, stream);      // (floating base, one aligned field: BASELINE configs[3])
             }
 #define ORC_KIND_CASE(K) case K: \
          if (variant & 8) return launch_iterate_tt<real, false, true, 512, K>(b, lds, stream); \

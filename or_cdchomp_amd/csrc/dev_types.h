@@ -165,6 +165,7 @@ struct ModelScalars
 struct LdsLayout
 {
    int T, G, W, AG, pos, ax, srad, sinact, jl, pcr, r2, end_reals;
+   int Tu;                 // ORC_LDS_T_STAGED: where the update and cost-summing phases keep their copy of the trajectory (inside the tile buffers, dead by then)
    int lim_bytes;          // byte offset of the joint-limit scratch (ORC_LIM_SCRATCH bytes)
    int pstr, astr;         // waypoint strides of pos / ax: odd, so that lane = waypoint accesses (FK) hit distinct LDS banks
    int ints_bytes;         // byte offset of the int tables (slink, jtype, jcol)
@@ -227,6 +228,7 @@ struct DevBatch
    real a_diag, a_off;     // D == 1: A = tridiag(a_off, a_diag, a_off), B couples the end rows with a_off
    int pcr_in_lds;         // the cyclic-reduction tables are staged in LDS
    int t_in_lds;           // the trajectory lives in LDS for the launch (else it is iterated in place in global memory)
+   int t_staged;           // !t_in_lds: the update phase and the cost sums work on a copy in the dead tile buffers (LdsLayout::Tu)
    int g_in_lds;           // the cost phase writes its gradient rows to LDS (else to Gcost; the update phase stages them)
    int lds_flags;          // ORC_LDS_* flags of the layout
    int ag_in_lds;          // the momentum AG lives in LDS for the launch (else it is updated in place in global memory)
@@ -314,7 +316,8 @@ __host__ __device__
 // global memory and the update phase keeps G in the (then dead) tile buffers
 #define ORC_LDS_SMALL_WORK 1
 #define ORC_LDS_G_GLOBAL   2
-#define ORC_LDS_T_GLOBAL   4      // the trajectory stays in global memory (updated in place through L2): generic cost path only
+#define ORC_LDS_T_GLOBAL   4      // the trajectory stays in global memory between the phases (FK reads it there): the LDS then holds larger tiles
+#define ORC_LDS_T_STAGED   8      // (with T_GLOBAL) the update phase and the cost sums work on a copy staged in the then dead tile buffers and write it back
 inline LdsLayout lds_layout(int np, int n, int Sa, int S, int nj, int tile_m, int pcr_rows, int real_size,
    int use_ag, int n_sdfs, int sdf_size, int flags)
 {
@@ -331,7 +334,8 @@ inline LdsLayout lds_layout(int np, int n, int Sa, int S, int nj, int tile_m, in
    const int work_reals = ((((flags & ORC_LDS_SMALL_WORK) || mn <= work_min) ? work_min : mn) + 3) & ~3;
    const int tile_reals = (((tile_m+2)*L.pstr + 3) & ~3) + (((tile_m+2)*L.astr + 3) & ~3);
    const bool g_global = (flags & ORC_LDS_G_GLOBAL) != 0;
-   const bool alias = tile_reals >= work_reals + lim_reals + (g_global ? ((mn + 3) & ~3) : 0);
+   const bool t_staged = (flags & ORC_LDS_T_GLOBAL) && (flags & ORC_LDS_T_STAGED);
+   const bool alias = tile_reals >= work_reals + lim_reals + (g_global ? ((mn + 3) & ~3) : 0) + (t_staged ? ((np*n + 3) & ~3) : 0);
    L.T = (flags & ORC_LDS_T_GLOBAL) ? 0 : take(np*n);
    L.G = g_global ? 0 : take(mn);
    L.W = alias ? 0 : take(work_reals);
@@ -340,6 +344,7 @@ inline LdsLayout lds_layout(int np, int n, int Sa, int S, int nj, int tile_m, in
    L.ax = take((tile_m+2)*L.astr);
    if (alias) L.W = L.pos;
    if (g_global) L.G = L.pos + work_reals + lim_reals;      // (only valid when alias: checked below)
+   L.Tu = t_staged ? L.pos + work_reals + lim_reals + (g_global ? ((mn + 3) & ~3) : 0) : -1;
    L.srad = take(S);
    L.sinact = take((S-Sa)*3 + 1);
    L.jl = take(2*n);
@@ -356,6 +361,6 @@ inline LdsLayout lds_layout(int np, int n, int Sa, int S, int nj, int tile_m, in
    L.sallow_bytes = bytes; bytes += (Sa > 16) ? 64 * 8 : 0;
    if (alias) L.lim_bytes = ORC_LDS_HEADER + (L.pos + work_reals) * real_size;
    else { L.lim_bytes = bytes; bytes += ORC_LIM_SCRATCH; }
-   L.total_bytes = (g_global && !alias) ? (1 << 30) : bytes;      // G in the tile buffers needs tiles that hold it
+   L.total_bytes = ((g_global || t_staged) && !alias) ? (1 << 30) : bytes;      // G (and the staged trajectory) in the tile buffers need tiles that hold them
    return L;
 }

@@ -8,6 +8,8 @@ import numpy as np, time, ctypes as C
 import common, or_cdchomp_amd
 which = int(sys.argv[1]); n_runs = int(sys.argv[2]) if len(sys.argv) > 2 else 4096; n_iter = int(sys.argv[3]) if len(sys.argv) > 3 else 100
 mod = or_cdchomp_amd.Module(0)
+mod.set_workgroups_per_cu(int(os.environ.get('WGS_PER_CU', '0')))
+mod.set_workgroup_threads(int(os.environ.get('WG_THREADS', '0')))
 if which == 4:
     model = common.setup_product_wam(mod)
     goals, basegoals, seeds, kw = common.config4_problem(n_runs)
