@@ -1688,7 +1688,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
          const int te = (tk == b.n_tiles - 1) ? b.m : b.tile_first + tk * b.tile_rest;
 #ifndef ORC_ABLATE_FK
          if constexpr (ORC_INLINE_FK && GS16 && sizeof(real) == 8) phase_fk_body<real, TREE, GS16, BLOCK, WGS>(kp, ts, te);
-         else phase_fk<real, TREE, GS16, BLOCK, WGS>(kp, ts, te);
+         else phase_fk<real, TREE, GS16, BLOCK, WGS>(kp, ts, te);      // (skipping the call for the wavefronts without a waypoint in the tile -- their share of the callee-saved registers -- measured nothing: profiles/r04_ab_experiments.txt)
 #ifdef ORC_ABLATE_FKTWICE      // timing experiments: the FK phase twice (what a 2x slower FK would cost)
          phase_fk<real, TREE, GS16, BLOCK, WGS>(kp, ts, te);
 #endif
