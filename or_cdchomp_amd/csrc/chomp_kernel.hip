@@ -1656,7 +1656,7 @@ void chomp_iterate_kernel(const DevBatch<real> b)
 
    // co-resident workgroups that start in lockstep stay in lockstep (all in the one-wave FK phase
    // together, then all in the cost phase): delaying every other one interleaves their phases
-   if (b.stagger_mode)
+   if (b.stagger_mode && b.stagger_mode != 9)
    {
       const bool late = (b.stagger_mode == 1) ? (blockIdx.x & 1) : ((blockIdx.x >> 8) & 1);
       if (late) for (int k=0; k<b.stagger_sleeps; k++) __builtin_amdgcn_s_sleep(127);
@@ -1686,6 +1686,10 @@ void chomp_iterate_kernel(const DevBatch<real> b)
       {
          const int ts = (tk == 0) ? 0 : b.tile_first + (tk - 1) * b.tile_rest;
          const int te = (tk == b.n_tiles - 1) ? b.m : b.tile_first + tk * b.tile_rest;
+         // ORC_STAGGER_MODE=9 (a timing experiment, wrong results): only the first tile is walked and a pause stands in for a
+         // barrier across workgroups -- what an iteration of ONE run would take with its tiles on as many CUs
+         // (scripts/single_run_latency.py, profiles/r04_single_run_ceiling.txt)
+         if (b.stagger_mode == 9 && tk > 0) { if (tk == 1) for (int k=0; k<b.stagger_sleeps; k++) __builtin_amdgcn_s_sleep(10); continue; }
 #ifndef ORC_ABLATE_FK
          if constexpr (ORC_INLINE_FK && GS16 && sizeof(real) == 8) phase_fk_body<real, TREE, GS16, BLOCK, WGS>(kp, ts, te);
          else phase_fk<real, TREE, GS16, BLOCK, WGS>(kp, ts, te);      // (skipping the call for the wavefronts without a waypoint in the tile -- their share of the callee-saved registers -- measured nothing: profiles/r04_ab_experiments.txt)
@@ -1933,12 +1937,17 @@ static hipError_t launch_iterate_t(const DevBatch<real> & b, size_t lds, hipStre
 #ifdef ORC_FAST_BUILD
    // experiment builds (make var DEFS=-DORC_FAST_BUILD=2): only the kernels of the config-2 bench legs are compiled (the fp64
    // fixed-base chain with placed spheres, one aligned field, no inactive sphere left: KIND 11), half a minute instead of three
+#if ORC_FAST_BUILD == 5      // -DORC_FAST_BUILD=5: BASELINE configs[4] (fp32, the many-sphere pass of a tree with its J^T form known)
+   if constexpr (sizeof(real) == 4)
+      if ((variant & 16) && !(variant & 2) && (variant & 1) && !(variant & (4 | 8))) return launch_iterate_tt<real, true, false, 256, 1>(b, lds, stream);
+#endif
    if constexpr (sizeof(real) == 8)
    {
       const int kind = 1 | ((variant & 32) ? 2 : 0) | ((variant & 64) ? 4 : 0) | (((variant & 160) == 160) ? 8 : 0);
       if ((variant & (16 | 2 | 1)) == (16 | 2))
       {
-#if ORC_FAST_BUILD == 4      // -DORC_FAST_BUILD=4: BASELINE configs[3] (floating base, KIND 15) at the default shape and at four workgroups per CU
+#if ORC_FAST_BUILD == 5
+#elif ORC_FAST_BUILD == 4      // -DORC_FAST_BUILD=4: BASELINE configs[3] (floating base, KIND 15) at the default shape and at four workgroups per CU
          if (kind == 15 && (variant & 256) && !(variant & (4 | 8))) return launch_iterate_tt<real, false, true, 256, 15, 4>(b, lds, stream);
          if (kind == 15 && !(variant & (4 | 8))) return launch_iterate_tt<real, false, true, 256, 15>(b, lds, stream);
 #else

@@ -143,12 +143,24 @@ __device__ __forceinline__ void cost_tile_generic(const BT & b, const ModelView<
                fr[q][k] = (g - fl) - (real)0.5;                     // offset from the cell centre, in cells
                // one-sided difference towards the nearer neighbour, inwards at the faces (grid.c:372-389)
                prev[q][k] = (fl == (real)0) ? false : ((fl == m1[k]) ? true : (fr[q][k] < (real)0));
+#if ORC_LEAN
+               off += __mul24((int) fl, sb3[k]);                     // (cell index and byte stride are below 2^24: a full-rate multiply)
+#else
                off += (int) fl * sb3[k];
+#endif
             }
+#if ORC_LEAN
+            // (unsigned 32-bit offsets against the field's base in scalar registers: no sign extension, no 64-bit address add)
+            v0[q] = *(const real *)(base + (unsigned int) off);
+#pragma unroll
+            for (int k=0; k<3; k++)
+               vn[q][k] = *(const real *)(base + (unsigned int)(off + (prev[q][k] ? -sb3[k] : sb3[k])));
+#else
             v0[q] = *(const real *)(base + off);
 #pragma unroll
             for (int k=0; k<3; k++)
                vn[q][k] = *(const real *)(base + (off + (prev[q][k] ? -sb3[k] : sb3[k])));
+#endif
          }
       };
       auto sdf_finish = [&](int i0)

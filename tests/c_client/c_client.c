@@ -122,6 +122,36 @@ int main(void)
                            reply, sizeof reply) == 0 || strcmp(orc_last_error(m), "con_tsr link not found!") != 0) bad++;
    }
 
+   /* the arm picks something up (RobotBase::Grab): a kinbody with <orcdchomp> spheres held by the hand link; create then
+    * collects its spheres with the robot's (src/orcdchomp_mod.cpp:2168-2300), and released the robot plans as before */
+   {
+      const double part_pose[7] = { 0.5, 0.0, 1.4, 0,0,0,1 }, origin[7] = { 0,0,0, 0,0,0,1 }, part_half[3] = { 0.03, 0.03, 0.03 };
+      const double part_sph[2][3] = { {0,0,0}, {0.07,0,0} }, part_rad[2] = { 0.04, 0.03 };
+      double costs_held[NR][3], costs_free[NR][3], where[7];
+      int bid_held = 0, bid_free = 0;
+      CHECK(orc_env_add_kinbody_boxes(m, "part", 1, origin, part_half));
+      CHECK(orc_kinbody_set_transform(m, "part", part_pose));                   /* next to the hand at q0 */
+      CHECK(orc_kinbody_set_spheres(m, "part", 2, &part_sph[0][0], part_rad));
+      CHECK(orc_robot_grab(m, "arm3", "part", 3));
+      CHECK(orc_batch_create(m, "arm3", &p, NR, NULL, &goals[0][0], NULL, NULL, &bid_held));
+      CHECK(orc_batch_iterate(m, bid_held, 60, &costs_held[0][0], status));
+      CHECK(orc_body_get_transform(m, "part", where));
+      CHECK(orc_robot_release(m, "arm3", "part"));
+      CHECK(orc_batch_create(m, "arm3", &p, NR, NULL, &goals[0][0], NULL, NULL, &bid_free));
+      CHECK(orc_batch_iterate(m, bid_free, 60, &costs_free[0][0], status));
+      int differ = 0;
+      for (int k=0; k<NR; k++)
+      {
+         if (costs_free[k][0] != costs[k][0]) bad++;                          /* released: the bits of the robot that never held anything */
+         if (costs_held[k][0] != costs[k][0]) differ++;
+      }
+      if (!differ || fabs(where[0] - 0.5) > 1e-12) bad++;
+      printf("holding 'part' (2 spheres on the hand): cost of run 0 %.6f against %.6f without; the part sits at x = %.3f\n", costs_held[0][0], costs[0][0], where[0]);
+      CHECK(orc_batch_destroy(m, bid_held));
+      CHECK(orc_batch_destroy(m, bid_free));
+      if (orc_robot_release(m, "arm3", "part") == 0 || !strstr(orc_last_error(m), "not grabbing")) bad++;
+   }
+
    int collides[NR];
    CHECK(orc_batch_collision_verdict(m, bid, collides, NULL, NULL, NULL, NULL));
    int nc = 0; for (int k=0; k<NR; k++) nc += collides[k];

@@ -81,6 +81,25 @@ def test_null_pointers_and_bad_handles_are_error_codes():
     assert L.orc_env_add_kinbody_boxes(h, b"box", 2, None, None) == 1 and "null argument" in _err(mod)
     assert L.orc_env_add_kinbody_boxes(h, b"box", -1, None, None) == 1
     scenes.add_tabletop(mod)
+    # bodies the robot holds (orc_kinbody_set_spheres, orc_robot_grab / _release, orc_body_get_transform, orc_robot_set_self_check)
+    one = (C.c_double * 3)(0, 0, 0); rad = (C.c_double * 1)(0.05)
+    assert L.orc_kinbody_set_spheres(h, None, 1, one, rad) == 1 and L.orc_kinbody_set_spheres(h, b"ghost", 1, one, rad) == 1
+    assert "Could not find kinbody" in _err(mod)
+    assert L.orc_kinbody_set_spheres(h, b"mug", 1, None, rad) == 1 and L.orc_kinbody_set_spheres(h, b"mug", 1, one, None) == 1
+    assert L.orc_kinbody_set_spheres(h, b"mug", -1, one, rad) == 1 and "bad number of spheres" in _err(mod)
+    assert L.orc_kinbody_set_spheres(h, b"mug", 0, None, None) == 0 and L.orc_kinbody_set_spheres(h, b"mug", 1, one, rad) == 0
+    assert L.orc_robot_grab(h, None, b"mug", 1) == 1 and L.orc_robot_grab(h, b"arm", None, 1) == 1
+    assert L.orc_robot_grab(h, b"nobody", b"mug", 1) == 1 and "Could not find robot" in _err(mod)
+    assert L.orc_robot_grab(h, b"arm", b"ghost", 1) == 1 and "Could not find kinbody" in _err(mod)
+    assert L.orc_robot_grab(h, b"arm", b"mug", -1) == 1 and L.orc_robot_grab(h, b"arm", b"mug", 999) == 1 and "out of range" in _err(mod)
+    assert L.orc_robot_release(h, b"arm", b"mug") == 1 and "not grabbing" in _err(mod)
+    assert L.orc_robot_grab(h, b"arm", b"mug", 3) == 0 and L.orc_robot_grab(h, b"arm", b"mug", 3) == 1 and "already grabbed" in _err(mod)
+    got = (C.c_double * 7)()
+    assert L.orc_body_get_transform(h, b"mug", None) == 1 and L.orc_body_get_transform(h, b"ghost", got) == 1 and L.orc_body_get_transform(h, None, got) == 1
+    assert L.orc_body_get_transform(h, b"mug", got) == 0 and L.orc_body_get_transform(h, b"arm", got) == 0
+    assert L.orc_robot_release(h, b"arm", None) == 1 and L.orc_robot_release(h, b"arm", b"mug") == 0
+    assert L.orc_robot_release_all(h, None) == 1 and L.orc_robot_release_all(h, b"nobody") == 1 and L.orc_robot_release_all(h, b"arm") == 0
+    assert L.orc_robot_set_self_check(h, None, 0) == 1 and L.orc_robot_set_self_check(h, b"nobody", 0) == 1 and L.orc_robot_set_self_check(h, b"arm", 1) == 0
     sizes = (C.c_int * 3)(4, 4, 1); lengths = (C.c_double * 3)(0.1, 0.1, 0.1)
     data = (C.c_double * 64)()
     assert L.orc_scene_add_sdf(h, b"table", sizes, lengths, pose, data) == 1 and "at least 2 cells" in _err(mod)
