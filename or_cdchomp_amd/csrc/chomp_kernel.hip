@@ -1298,7 +1298,9 @@ __device__ __attribute__((noinline)) int phase_update(const void * kp, int it_in
       }
       __threadfence_block();
       __syncthreads();
+      phase_mark<real>(b, E, 3);
       phase_tsr<real, GS16, BLOCK, WGS>(kp);
+      phase_mark<real>(b, E, 2);      // (slot 2: the constraint step)
       const real * AGc = b.use_momentum ? AG_s : AG_g;
       for (int e=tid; e<mn; e+=BLOCK)
       {

@@ -295,6 +295,9 @@ __device__ __forceinline__ void self_sym_step16(const real * prow, const real * 
    const bool near = (d2 <= R2) && live_lane;
    const unsigned long long near_lanes = __builtin_amdgcn_ballot_w64(d2 <= R2) & live_lanes;      // wave-uniform (scalar: and, compare, branch)
    if (near_lanes == 0ull) return;
+#ifdef ORC_ABLATE_ROTF
+   { __asm__ volatile("" :: "s"(near_lanes)); return; }      // timing experiments: range tests only
+#endif
    const real ro = srad[sp];                                // the partner's radius from the table in LDS (two DPP moves otherwise)
 #else
    const unsigned long long near_lanes = __builtin_amdgcn_ballot_w64(d2 <= R2) & live_lanes;      // wave-uniform

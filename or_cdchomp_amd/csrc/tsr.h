@@ -14,6 +14,7 @@
 // the slow path of a rarely used feature: it is written for equality with the reference's
 // arithmetic, not for speed.
 #pragma once
+#include <utility>
 
 template <typename real> struct TM;
 template <> struct TM<double>
@@ -473,11 +474,48 @@ __device__ __forceinline__ float lane_fetch(float v, int addr4) { return __int_a
 // t (64 / WP) + rsub), pivots 0 .. N-1.  All lane fetches of a step (the pivot row at this lane's column, the lane's
 // multipliers of every register) are issued before any is used: one round trip of the cross-lane unit per step, the
 // reciprocal of the pivot is formed meanwhile.  Returns false at a zero or non-finite pivot.
+template <int K> struct PivotIndex { static constexpr int value = K; };
+template <int... Ks, typename F>
+__device__ __forceinline__ void for_each_pivot(std::integer_sequence<int, Ks...>, F && f) { (f(PivotIndex<Ks>{}), ...); }
+
 template <typename real, int WP, int NREG>
 __device__ __forceinline__ bool gauss_jordan_regs(real (& w)[NREG], int N, int c, int rsub)
 {
    constexpr int RPR = 64 / WP;
    const int kfetch4 = rsub * WP * 4;
+   bool ok = true;      // (checked once per block: a branch on the pivot would sit in the dependent chain of every step; past a zero
+                        // pivot the block fills with inf and NaN, which nothing reads -- the caller takes the dense path)
+   if constexpr (WP <= 32)
+   {
+      // Every step written out: the pivot's register and the rows that hold it are known at compile time, so no step selects its
+      // pivot row among the registers or compares row numbers, and with 16-lane rows the lane's multipliers W[r][k] are a DPP
+      // broadcast inside its row (row_newbcast: no trip through the cross-lane unit).  Steps k >= N are skipped (wave-uniform).
+      for_each_pivot(std::make_integer_sequence<int, NREG * RPR>{}, [&](auto kc) {
+         constexpr int k = decltype(kc)::value, tk = k / RPR, j = k % RPR;
+         if (k < N)
+         {
+            const real p = read_lane(w[tk], j * WP + k);
+            const real ap = M<real>::fabs_(p);
+            ok = ok && (ap > (real)0 && ap < M<real>::inf());
+            const real praw = lane_fetch(w[tk], (j * WP + c) * 4);      // the pivot row at this lane's column
+            real f[NREG];
+#pragma unroll
+            for (int t=0; t<NREG; t++)
+            {
+               if constexpr (WP == 16) f[t] = dpp_move<0x150 + (k & 15)>(w[t]);      // W[r][k]: lane k of the lane's own row
+               else f[t] = lane_fetch(w[t], kfetch4 + k * 4);
+            }
+            const real prow = praw * rcp_fast(p);
+#pragma unroll
+            for (int t=0; t<NREG; t++)
+            {
+               const real upd = w[t] - f[t] * prow;
+               w[t] = (t == tk) ? ((rsub == j) ? prow : upd) : upd;
+            }
+         }
+      });
+      return ok;
+   }
    for (int k=0; k<N; k++)
    {
       const int tk = k / RPR, kbase = (k % RPR) * WP;           // (wavefront-uniform)
@@ -486,7 +524,7 @@ __device__ __forceinline__ bool gauss_jordan_regs(real (& w)[NREG], int N, int c
       for (int t=1; t<NREG; t++) wk = (tk == t) ? w[t] : wk;
       const real p = read_lane(wk, kbase + k);
       const real ap = M<real>::fabs_(p);
-      if (!(ap > (real)0 && ap < M<real>::inf())) return false;
+      ok = ok && (ap > (real)0 && ap < M<real>::inf());
       const real praw = lane_fetch(wk, (kbase + c) * 4);         // the pivot row at this lane's column
       real f[NREG];
 #pragma unroll
@@ -499,7 +537,7 @@ __device__ __forceinline__ bool gauss_jordan_regs(real (& w)[NREG], int N, int c
          w[t] = (r == k) ? prow : w[t] - f[t] * prow;
       }
    }
-   return true;
+   return ok;
 }
 
 template <typename real, int WP, int NREG, int DIR, typename BT>
@@ -555,6 +593,8 @@ __device__ void tsr_eliminate_regs(const BT & b, const Env<real> & E, const real
    const bool toeplitz = (b.D == 1);
    int jrow0[NREG], jstride[NREG], jcol[NREG];      // this lane's entry of register t: J[row][jcol] (jcol >= 0), h[row] (-1), none (-2)
    real jsign[NREG];
+#pragma unroll
+   for (int t=0; t<NREG; t++) { jrow0[t] = 0; jstride[t] = 0; jcol[t] = -2; jsign[t] = 1; }
    if (every_point)
    {
       const int N = n + k_all, Wd = N + n1;
@@ -575,16 +615,24 @@ __device__ void tsr_eliminate_regs(const BT & b, const Env<real> & E, const real
          }
       }
    }
+   // (the reads are unconditional -- a lane without an entry reads h[row_base] -- and nothing is computed from them here: the
+   // wait for them then sits where the next block is put together, a whole elimination later, instead of behind each load)
+   real jraw[NREG];
+   const real * jsrc[NREG]; int jstep[NREG];
+#pragma unroll
+   for (int t=0; t<NREG; t++)
+   {
+      jsrc[t] = (jcol[t] >= 0) ? Jws + (size_t) jrow0[t] * n + jcol[t] : hws + jrow0[t];
+      jstep[t] = (jcol[t] >= 0) ? jstride[t] * n : jstride[t];
+      jraw[t] = 0;
+   }
    auto fetch_direct = [&](int i) {
 #pragma unroll
-      for (int t=0; t<NREG; t++)
-      {
-         const int row = jrow0[t] + (m - 1 - i) * jstride[t];
-         real v = 0;
-         if (jcol[t] >= 0) v = jsign[t] * Jws[(size_t) row * n + jcol[t]];
-         else if (jcol[t] == -1) v = hws[row];
-         jn[t] = v;
-      }
+      for (int t=0; t<NREG; t++) jraw[t] = jsrc[t][(m - 1 - i) * jstep[t]];
+   };
+   auto use_direct = [&]() {
+#pragma unroll
+      for (int t=0; t<NREG; t++) jn[t] = (jcol[t] == -2) ? (real)0 : ((jcol[t] >= 0) ? jsign[t] * jraw[t] : jraw[t]);
    };
    int Nprev = n;
    int ki = k_all;
@@ -600,6 +648,7 @@ __device__ void tsr_eliminate_regs(const BT & b, const Env<real> & E, const real
       // the coupling to the point eliminated before this one, and to the one that follows
       const real back = (i == i_begin) ? (real)0 : ((DIR > 0) ? lo : up), fwd = (DIR > 0) ? up : lo;
       // the block of this point; what it takes of the previous point's [C | r] comes out of that block's registers
+      if (every_point) use_direct();
       const int psrc4 = (rsub * WP + ((c < n) ? Nprev + c : Nprev + n)) * 4;
 #pragma unroll
       for (int t=0; t<NREG; t++)
@@ -880,12 +929,16 @@ __device__ __attribute__((noinline)) void phase_tsr(const void * kp)
          if (wave == 0)
          {
             if (shape == 16) tsr_eliminate_regs<real, 16, 2, +1>(b, E, hws, Jws, Cst, E.redi, 0, mid, rows);
+            else if (shape == 32 && Nm <= 10) tsr_eliminate_regs<real, 32, 5, +1>(b, E, hws, Jws, Cst, E.redi, 0, mid, rows);      // (two rows per register: a WAM point with up to three constrained rows)
+            else if (shape == 32 && Nm <= 12) tsr_eliminate_regs<real, 32, 6, +1>(b, E, hws, Jws, Cst, E.redi, 0, mid, rows);
             else if (shape == 32) tsr_eliminate_regs<real, 32, 8, +1>(b, E, hws, Jws, Cst, E.redi, 0, mid, rows);
             else tsr_eliminate_regs<real, 64, 20, +1>(b, E, hws, Jws, Cst, E.redi, 0, mid, rows);
          }
          else if (wave == 1)
          {
             if (shape == 16) tsr_eliminate_regs<real, 16, 2, -1>(b, E, hws, Jws, Cst, E.redi, m - 1, mid - 1, rows);
+            else if (shape == 32 && Nm <= 10) tsr_eliminate_regs<real, 32, 5, -1>(b, E, hws, Jws, Cst, E.redi, m - 1, mid - 1, rows);
+            else if (shape == 32 && Nm <= 12) tsr_eliminate_regs<real, 32, 6, -1>(b, E, hws, Jws, Cst, E.redi, m - 1, mid - 1, rows);
             else if (shape == 32) tsr_eliminate_regs<real, 32, 8, -1>(b, E, hws, Jws, Cst, E.redi, m - 1, mid - 1, rows);
             else tsr_eliminate_regs<real, 64, 20, -1>(b, E, hws, Jws, Cst, E.redi, m - 1, mid - 1, rows);
          }
