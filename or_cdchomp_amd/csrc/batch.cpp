@@ -273,7 +273,10 @@ void BatchShard::construct(const Robot & robot, const double * starts, const dou
       hip_check(orc_launch_hmc_seed(d_mt_, d_hmc_next_, d_seeds, n_runs, st), "hmc seed");
       hip_check(hipStreamSynchronize(st), "hmc seed sync");
       dev_free(d_seeds);
-      if (!getenv("ORC_HMC_PLAN_SYNC")) hmc_reserve(hmc_room(100), false);      // (a call of up to 100 iterations allocates nothing)
+      hip_check(hipMemsetAsync(d_overflow_, 0, sizeof(int), st), "hmc overflow");
+      hip_check(hipStreamSynchronize(st), "hmc overflow");
+      // (the plan's buffers -- [n_runs][cap][m n] of noise: 1.8 GB for BASELINE config 4 -- are the first iterate call's to
+      // allocate: a caller that creates many batches ahead of time holds none of them until a batch runs)
    }
    else
    {
@@ -297,6 +300,7 @@ BatchShard::~BatchShard()
 
 void BatchShard::release()
 {
+   if (plan_shared_) { d_hmc_iters_ = nullptr; d_noise_ = nullptr; hmc_cap_iters_ = 0; noise_cap_ = 0; }      // (the module's, not this shard's)
    void ** all[] = { &d_model_, &d_sdfs_, &d_sdfc_, &d_traj_, &d_AG_, &d_G_, (void **) &d_mt_, (void **) &d_mt_bak_, (void **) &d_hmc_next_,
                      (void **) &d_hmc_next_bak_, (void **) &d_overflow_, (void **) &d_costs_, (void **) &d_trace_, (void **) &d_status_,
                      (void **) &d_iters_done_, (void **) &d_leap_, &d_Aband_, &d_beta_s_, &d_beta_g_, &d_metric64_, &d_pcr_, &d_Ainv_, &d_jl_lo_, &d_jl_hi_,
@@ -1102,6 +1106,7 @@ static void parallel_for_runs(int count, const std::function<void(int, int)> & b
 // deviations + 6 (a run draws more than that in a call with probability ~1e-12)
 int BatchShard::hmc_room(int n_iter) const
 {
+   if (const char * e = getenv("ORC_HMC_ROOM")) return atoi(e);      // tests: too little room on purpose
    const double mean = n_iter * params.hmc_resample_lambda;
    return (int) std::ceil(mean + 8.0 * std::sqrt(mean) + 6.0);
 }
@@ -1111,10 +1116,17 @@ void BatchShard::hmc_reserve(int cap, bool pending_work)
 {
    const size_t rsize = (params.precision == 64) ? 8 : 4;
    const size_t icount = (size_t) n_runs * cap, ncount = icount * m * n;
-   if (icount <= hmc_cap_iters_ && ncount * rsize <= noise_cap_) return;
-   if (pending_work) hip_check(hipStreamSynchronize(stream_), "hmc buffers: pending work");      // (an earlier launch may still read them)
-   if (icount > hmc_cap_iters_) { dev_free(d_hmc_iters_); d_hmc_iters_ = dev_alloc<int>(icount); hmc_cap_iters_ = icount; }
-   if (ncount * rsize > noise_cap_) { dev_free(d_noise_); hip_check(hipMalloc(&d_noise_, ncount * rsize), "noise"); noise_cap_ = ncount * rsize; }
+   // the buffers of this shard's stream, shared by every batch that runs on it (Module::plan_buffers)
+   Module::PlanBuffers & pb = mod_->plan_buffers(device, stream_);
+   if (icount > pb.iters_count || ncount * rsize > pb.noise_bytes)
+   {
+      if (pending_work) hip_check(hipStreamSynchronize(stream_), "hmc buffers: pending work");      // (an earlier launch may still read them)
+      if (icount > pb.iters_count) { dev_free(pb.iters); pb.iters = nullptr; pb.iters_count = 0; pb.iters = dev_alloc<int>(icount); pb.iters_count = icount; }
+      if (ncount * rsize > pb.noise_bytes) { dev_free(pb.noise); pb.noise = nullptr; pb.noise_bytes = 0; hip_check(hipMalloc(&pb.noise, ncount * rsize), "noise"); pb.noise_bytes = ncount * rsize; }
+   }
+   plan_shared_ = true;
+   d_hmc_iters_ = pb.iters; hmc_cap_iters_ = pb.iters_count;
+   d_noise_ = pb.noise; noise_cap_ = pb.noise_bytes;
 }
 
 void BatchShard::plan_hmc(int iter_begin, int iter_end)
@@ -1138,7 +1150,7 @@ void BatchShard::plan_hmc(int iter_begin, int iter_end)
          overflow_armed_ = true;
          hip_check(hipEventRecord(ev_plan_[0], stream_), "hipEventRecord");
          hip_check(hipStreamWaitEvent(ps, ev_plan_[0], 0), "hipStreamWaitEvent");
-         hip_check(hipMemsetAsync(d_overflow_, 0, sizeof(int), ps), "hmc overflow");
+         // (the flag is cleared where it is read, sync_begin: calls queued without a sync in between add to it)
          hipError_t e = (params.precision == 64)
             ? orc_launch_hmc_plan_f64(d_mt_, d_hmc_next_, n_runs, iter_begin, iter_end, cap, mn, params.hmc_resample_lambda, (double *) d_noise_, d_hmc_iters_, d_overflow_, ps)
             : orc_launch_hmc_plan_f32(d_mt_, d_hmc_next_, n_runs, iter_begin, iter_end, cap, mn, params.hmc_resample_lambda, (float *) d_noise_, d_hmc_iters_, d_overflow_, ps);
@@ -1309,6 +1321,7 @@ void BatchShard::launch(int n_iter, bool final_eval, bool carry)
 void BatchShard::iterate_async(int n_iter, int iter_begin, bool final_eval, bool carry)
 {
    if (n_iter < 0) throw std::runtime_error("n_iter must be >=0!");
+   if (unusable_) throw std::runtime_error("hmc: an earlier iterate call of this batch ran out of room for its momentum resamples; destroy the batch and create it again!");
    DeviceGuard guard(device);
    last_n_iter = n_iter;
    const size_t tneed = (size_t) n_runs * (n_iter ? n_iter : 1) * 3;
@@ -1319,6 +1332,10 @@ void BatchShard::iterate_async(int n_iter, int iter_begin, bool final_eval, bool
    }
    max_resamples_ = 0;
    if (iter_begin == 0) std::fill(ext_noise_used_.begin(), ext_noise_used_.end(), 0);
+   // The plan's buffers belong to the stream (Module::plan_buffers): the plan and the launch that reads it go into the stream
+   // as one piece -- another shard on the same stream, launched from another host thread, must not get its plan in between.
+   std::unique_lock<std::mutex> plan_lock;
+   if (params.use_hmc && n_iter > 0 && hmc_on_device_) plan_lock = std::unique_lock<std::mutex>(mod_->plan_buffers(device, stream_).enqueue);
    if (params.use_hmc && n_iter > 0) plan_hmc(iter_begin, iter_begin + n_iter);
    if (params.precision == 64) launch<double>(n_iter, final_eval, carry); else launch<float>(n_iter, final_eval, carry);
 }
@@ -1330,7 +1347,11 @@ void BatchShard::sync_begin(double * costs_out, int * status_out, int * iters_ou
    if (costs_out) hip_check(hipMemcpyAsync(costs_out, d_costs_, (size_t) n_runs*3*sizeof(double), hipMemcpyDeviceToHost, st), "costs");
    if (status_out) hip_check(hipMemcpyAsync(status_out, d_status_, n_runs*sizeof(int), hipMemcpyDeviceToHost, st), "status");
    if (iters_out) hip_check(hipMemcpyAsync(iters_out, d_iters_done_, n_runs*sizeof(int), hipMemcpyDeviceToHost, st), "iters_done");
-   if (overflow_armed_) hip_check(hipMemcpyAsync(&overflow_host_, d_overflow_, sizeof(int), hipMemcpyDeviceToHost, st), "hmc overflow");
+   if (overflow_armed_)
+   {
+      hip_check(hipMemcpyAsync(&overflow_host_, d_overflow_, sizeof(int), hipMemcpyDeviceToHost, st), "hmc overflow");
+      hip_check(hipMemsetAsync(d_overflow_, 0, sizeof(int), st), "hmc overflow");
+   }
 }
 
 void BatchShard::sync_end()
@@ -1340,8 +1361,11 @@ void BatchShard::sync_end()
    harvest_events(false);
    if (overflow_armed_ && overflow_host_)
    {
+      // the iterate kernel has run with a cut schedule and the generators have moved on: nothing to go back to
       overflow_host_ = 0;
-      throw std::runtime_error("hmc: a run drew more momentum resamples in one iterate call than the plan has room for; iterate with fewer iterations per call!");
+      unusable_ = true;
+      throw std::runtime_error("hmc: a run drew more momentum resamples in one iterate call than the plan has room for (probability ~1e-12 per run and call); "
+                               "the batch is not usable any more: destroy it, create it again and iterate with fewer iterations per call!");
    }
 }
 

@@ -162,6 +162,11 @@ Module::~Module()
       DeviceGuard guard(kv.first);
       (void) hipStreamDestroy(kv.second);
    }
+   for (auto & kv : plan_buffers_)
+   {
+      DeviceGuard guard(kv.first.first);
+      (void) hipFree(kv.second.noise); (void) hipFree(kv.second.iters);
+   }
 }
 
 hipEvent_t Module::acquire_event(int dev)
@@ -245,6 +250,12 @@ hipStream_t Module::plan_stream(int dev)
    hip_check(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, greatest), "hipStreamCreateWithPriority");
    plan_streams_[dev] = st;
    return st;
+}
+
+Module::PlanBuffers & Module::plan_buffers(int dev, hipStream_t stream)
+{
+   std::lock_guard<std::mutex> lock(timing_mutex_);
+   return plan_buffers_[std::make_pair(dev, stream)];      // (references to a map's elements stay valid)
 }
 
 void Module::time_collect()

@@ -191,7 +191,9 @@ private:
    int * d_hmc_iters_ = nullptr; void * d_noise_ = nullptr; size_t hmc_cap_iters_ = 0, noise_cap_ = 0;
    int max_resamples_ = 0;
    hipEvent_t ev_plan_[2] = { nullptr, nullptr };   // iterate stream -> plan stream -> iterate stream
-   int overflow_host_ = 0; bool overflow_armed_ = false;   // the plan's overflow flag, read with the results of a call
+   int overflow_host_ = 0; bool overflow_armed_ = false;   // the plan's overflow flag, read (and cleared) with the results of a call
+   bool plan_shared_ = false;                               // d_noise_ / d_hmc_iters_ are the module's buffers of this shard's stream
+   bool unusable_ = false;                                  // set by an overflow: the runs' schedules were cut short, the batch has to be created again
    bool debug_state_ = false;   // ORC_DEBUG_STATE=1: keep the last gradient readable (get_state "G")
    int n_sdfs_ = 0;
    int n_tiles_ = 1, tile_first_ = 0, tile_rest_ = 0;   // tiles of an iteration: the first of tile_first_ moving waypoints, the others of tile_rest_
@@ -320,6 +322,11 @@ public:
    // a high-priority stream per device for the hmc plan of a call (hmc_kernels.hip): its wavefronts are dispatched ahead
    // of the iterate launches queued on the other streams instead of behind them
    hipStream_t plan_stream(int device);
+   // The momentum-resampling plan of an iterate call (noise [n_runs][cap][m n], resample iterations [n_runs][cap]) is written and
+   // read inside that one call, so the batches that run on one stream share one pair of buffers: the stream orders their
+   // calls.  (A buffer per batch held 1.8 GB for every config-4 batch a caller had created ahead of time.)
+   struct PlanBuffers { void * noise = nullptr; size_t noise_bytes = 0; int * iters = nullptr; size_t iters_count = 0; std::mutex enqueue; };
+   PlanBuffers & plan_buffers(int device, hipStream_t stream);
    // kernel timing (HIP events on the shards' streams), harvested from the shards
    void time_collect();
    double kernel_ms_total = 0.0;
@@ -347,6 +354,7 @@ private:
    int next_batch_id_ = 1;
    std::map<int, std::vector<hipEvent_t>> event_pool_;
    std::map<int, hipStream_t> plan_streams_;
+   std::map<std::pair<int, hipStream_t>, PlanBuffers> plan_buffers_;
    std::mutex timing_mutex_;
 };
 

@@ -62,6 +62,59 @@ def test_floating_base_momentum_hmc(oracle, monkeypatch, device_streams):
     print("floating/hmc worst rel L2 %.3e" % max(errs))
 
 
+def _hmc_batch(mod, model, n_runs, seed0, n_points=40):
+    _, base, _, _ = common.wam_state()
+    goals = common.wam_goals(n_runs, seed=20250103 + seed0)
+    basegoals = np.tile(np.asarray(base), (n_runs, 1))
+    seeds = np.arange(n_runs, dtype=np.uint32) + seed0
+    kw = dict(n_points=n_points, lambda_=100.0, obs_factor=500.0, floating_base=1, use_momentum=1, use_hmc=1, hmc_resample_lambda=0.05)
+    return mod.batch_create(model.name, goals, basegoals=basegoals, seeds=seeds, **kw)
+
+
+def test_hmc_plan_out_of_room_leaves_the_batch_unusable(monkeypatch):
+    """a run that draws more momentum resamples in one call than the plan has room for: the call reports it, and the
+    batch -- whose kernel ran with a cut schedule -- refuses further calls instead of going on from an inconsistent state
+    (ORC_HMC_ROOM: room for one resample per run and call, where 60 iterations at lambda 0.05 draw three on average)"""
+    monkeypatch.setenv("ORC_HMC_DEVICE", "1")
+    mod = _mk_module()
+    model = common.setup_product_wam(mod)
+    good = _hmc_batch(mod, model, 8, 0)
+    bad = _hmc_batch(mod, model, 8, 100)
+    monkeypatch.setenv("ORC_HMC_ROOM", "1")
+    with pytest.raises(RuntimeError, match="not usable any more"):
+        mod.batch_iterate(bad, 60)
+    monkeypatch.delenv("ORC_HMC_ROOM")
+    with pytest.raises(RuntimeError, match="create it again"):
+        mod.batch_iterate(bad, 5)
+    mod.batch_destroy(bad)
+    costs, status = mod.batch_iterate(good, 60)          # the flag was the other batch's: this one runs
+    assert np.all(np.isfinite(costs))
+    mod.batch_destroy(good)
+
+
+def test_hmc_batches_of_one_stream_share_the_plan_buffers(monkeypatch):
+    """the noise of an iterate call is written and read inside the call, so the batches of a stream share one buffer
+    (Module::plan_buffers): calls of two batches queued back to back without a sync give what each gives alone"""
+    monkeypatch.setenv("ORC_HMC_DEVICE", "1")
+    alone = []
+    for seed0, n_runs in ((0, 8), (100, 12)):
+        mod = _mk_module()
+        model = common.setup_product_wam(mod)
+        bid = _hmc_batch(mod, model, n_runs, seed0)
+        mod.batch_iterate(bid, 30)
+        alone.append(mod.batch_gettraj(bid))
+    mod = _mk_module()
+    mod.set_num_streams(1)
+    model = common.setup_product_wam(mod)
+    a = _hmc_batch(mod, model, 8, 0)
+    b = _hmc_batch(mod, model, 12, 100)
+    mod.batch_iterate_async(a, 30)
+    mod.batch_iterate_async(b, 30)
+    mod.batch_sync(a); mod.batch_sync(b)
+    assert np.array_equal(mod.batch_gettraj(a), alone[0])
+    assert np.array_equal(mod.batch_gettraj(b), alone[1])
+
+
 def _tree_scene(mod, oracle, cube_extent):
     """four box kinbodies with their own fields (config 5), returned for the oracle as well"""
     rng = np.random.default_rng(20250104)
