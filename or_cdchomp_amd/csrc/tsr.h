@@ -121,7 +121,10 @@ template <typename real>
 __device__ __forceinline__ void t_xyzypr_J(const real pose[7], real J[6][7])
 {
    const real qx = pose[3], qy = pose[4], qz = pose[5], qw = pose[6];
-   for (int i=0; i<6; i++) for (int j=0; j<7; j++) J[i][j] = 0;
+#pragma unroll
+   for (int i=0; i<6; i++)
+#pragma unroll
+      for (int j=0; j<7; j++) J[i][j] = 0;
    J[0][0] = 1; J[1][1] = 1; J[2][2] = 1;
    auto angle_row = [](real s, real c, const real gs[4], const real gc[4], real * row) {
       const real inv = (real)1 / (c*c + s*s);
@@ -143,53 +146,30 @@ __device__ __forceinline__ void t_xyzypr_J(const real pose[7], real J[6][7])
       angle_row(2*(qw*qx + qy*qz), 1 - 2*(qx*qx + qy*qy), gs, gc, &J[5][3]);
    }
 }
-// cd_spatial_pose_jac_inverse, spatial.c:339-375
-template <typename real>
-__device__ __forceinline__ void t_jac_inverse(const real pose[7], real Ji[7][6])
-{
-   const real x = pose[0], y = pose[1], z = pose[2];
-   const real qxd2 = (real)0.5*pose[3], qyd2 = (real)0.5*pose[4], qzd2 = (real)0.5*pose[5], qwd2 = (real)0.5*pose[6];
-   for (int i=0; i<7; i++) for (int j=0; j<6; j++) Ji[i][j] = 0;
-   Ji[0][1] =  z; Ji[0][2] = -y; Ji[1][0] = -z; Ji[1][2] =  x; Ji[2][0] =  y; Ji[2][1] = -x;
-   Ji[0][3] = 1; Ji[1][4] = 1; Ji[2][5] = 1;
-   Ji[3][0] =  qwd2; Ji[3][1] =  qzd2; Ji[3][2] = -qyd2;
-   Ji[4][0] = -qzd2; Ji[4][1] =  qwd2; Ji[4][2] =  qxd2;
-   Ji[5][0] =  qyd2; Ji[5][1] = -qxd2; Ji[5][2] =  qwd2;
-   Ji[6][0] = -qxd2; Ji[6][1] = -qyd2; Ji[6][2] = -qzd2;
-}
-// cd_spatial_xm_from_pose, spatial.c:71-102: [R 0; [r]x R  R]
-template <typename real>
-__device__ __forceinline__ void t_xm_from_pose(real xm[6][6], const real pose[7])
-{
-   real R[9];
-   t_quat_to_R(pose+3, R);
-   for (int i=0; i<6; i++) for (int j=0; j<6; j++) xm[i][j] = 0;
-   for (int i=0; i<3; i++) for (int j=0; j<3; j++) { xm[i][j] = R[3*i+j]; xm[3+i][3+j] = R[3*i+j]; }
-   const real rx[3][3] = { { 0, -pose[2], pose[1] }, { pose[2], 0, -pose[0] }, { -pose[1], pose[0], 0 } };
-   for (int i=0; i<3; i++) for (int j=0; j<3; j++)
-   {
-      real s = 0;
-      for (int k=0; k<3; k++) s += rx[i][k] * R[3*k+j];
-      xm[3+i][j] = s;
-   }
-}
-
 // a frame walking the joints of the end effector's chain (the build's own kinematic model, the one
 // fk.h walks for the spheres): cur <- cur o (Rfix, tfix); world axis and anchor; cur <- cur o motion(q)
 template <typename real>
 struct TFrame { real R[9], t[3]; };
-template <typename real>
-__device__ __forceinline__ void t_apply_joint(const DevJoint<real> & J, real q, TFrame<real> & cur, real axis_w[3], real anchor[3])
+template <typename real, typename JT>
+__device__ __forceinline__ void t_apply_joint(const JT & J, real q, TFrame<real> & cur, real axis_w[3], real anchor[3])
 {
    real Rj[9], tj[3];
+   real Rf[9], tf[3], ax[3];
+#pragma unroll
+   for (int e=0; e<9; e++) Rf[e] = J.Rfix[e];
+#pragma unroll
+   for (int e=0; e<3; e++) { tf[e] = J.tfix[e]; ax[e] = J.axis[e]; }
+#pragma unroll
    for (int r=0; r<3; r++)
    {
-      for (int c=0; c<3; c++) Rj[3*r+c] = cur.R[3*r+0]*J.Rfix[0*3+c] + cur.R[3*r+1]*J.Rfix[1*3+c] + cur.R[3*r+2]*J.Rfix[2*3+c];
-      tj[r] = cur.R[3*r+0]*J.tfix[0] + cur.R[3*r+1]*J.tfix[1] + cur.R[3*r+2]*J.tfix[2] + cur.t[r];
+#pragma unroll
+      for (int c=0; c<3; c++) Rj[3*r+c] = cur.R[3*r+0]*Rf[0*3+c] + cur.R[3*r+1]*Rf[1*3+c] + cur.R[3*r+2]*Rf[2*3+c];
+      tj[r] = cur.R[3*r+0]*tf[0] + cur.R[3*r+1]*tf[1] + cur.R[3*r+2]*tf[2] + cur.t[r];
    }
+#pragma unroll
    for (int r=0; r<3; r++)
    {
-      axis_w[r] = Rj[3*r+0]*J.axis[0] + Rj[3*r+1]*J.axis[1] + Rj[3*r+2]*J.axis[2];
+      axis_w[r] = Rj[3*r+0]*ax[0] + Rj[3*r+1]*ax[1] + Rj[3*r+2]*ax[2];
       anchor[r] = tj[r];
    }
    if (J.type == 1)
@@ -197,101 +177,174 @@ __device__ __forceinline__ void t_apply_joint(const DevJoint<real> & J, real q, 
       real sn, cs;
       M<real>::sincos_(q, &sn, &cs);
       const real v = (real)1 - cs;
-      const real a0 = J.axis[0], a1 = J.axis[1], a2 = J.axis[2];
+      const real a0 = ax[0], a1 = ax[1], a2 = ax[2];
       real Rm[9];
       Rm[0] = cs + a0*a0*v;    Rm[1] = a0*a1*v - a2*sn; Rm[2] = a0*a2*v + a1*sn;
       Rm[3] = a1*a0*v + a2*sn; Rm[4] = cs + a1*a1*v;    Rm[5] = a1*a2*v - a0*sn;
       Rm[6] = a2*a0*v - a1*sn; Rm[7] = a2*a1*v + a0*sn; Rm[8] = cs + a2*a2*v;
+#pragma unroll
       for (int r=0; r<3; r++)
+#pragma unroll
          for (int c=0; c<3; c++) cur.R[3*r+c] = Rj[3*r+0]*Rm[0*3+c] + Rj[3*r+1]*Rm[1*3+c] + Rj[3*r+2]*Rm[2*3+c];
+#pragma unroll
       for (int r=0; r<3; r++) cur.t[r] = tj[r];
    }
    else
    {
+#pragma unroll
       for (int e=0; e<9; e++) cur.R[e] = Rj[e];
+#pragma unroll
       for (int r=0; r<3; r++) cur.t[r] = tj[r] + q*axis_w[r];
    }
 }
 
-// con_tsr (src/orcdchomp_mod.cpp:1330-1497) at one trajectory row: h[k] and J[k][n] of the enabled rows
-template <typename real>
-__device__ void tsr_eval_point(const DevModel<real> & gm, const DevTsr<real> & ts, const real * point, int n, real * hrow, real * Jrows)
+// con_tsr (src/orcdchomp_mod.cpp:1330-1497) at one trajectory row: h[k] and J[k][n] of the enabled rows.
+// One lane = one point.  Everything a lane keeps is indexed at compile time (registers: a table indexed by a loop counter is
+// a table in scratch memory, 2.4 KB of it per lane until round 4), the joints' constants come by scalar loads, and only the
+// enabled rows of the chain of Jacobians are formed -- row `row` of
+//    B = (xyzypr-Jacobian . pose-Jacobian-inverse)(pose) . spatial transform(table_world)        (mod.cpp:1466-1480)
+// with the sums in the order the full 6 x 7 . 7 x 6 . 6 x 6 products take them (their other terms are exact zeros).
+// KMAX: the most rows a lane holds (3 or 6: six rows of B next to the walk's frames do not fit the register budget).
+template <typename real, int KMAX>
+__device__ __forceinline__ void tsr_eval_point_k(const DevModel<real> & gm, const DevTsr<real> & ts, const real * point, int n, real * hrow, real * Jrows)
 {
+   typedef const __attribute__((address_space(4))) DevJoint<real> JointC;
+   JointC * joints = (JointC *) gm.joints;
+   const int nj = __builtin_amdgcn_readfirstlane(gm.nj);
    TFrame<real> base, cur;
    if (gm.floating)
    {
-      t_quat_to_R(point+3, base.R);
+      const real q[4] = { point[3], point[4], point[5], point[6] };
+      t_quat_to_R(q, base.R);
       base.t[0] = point[0]; base.t[1] = point[1]; base.t[2] = point[2];
    }
    else
    {
+#pragma unroll
       for (int e=0; e<9; e++) base.R[e] = gm.base_R[e];
+#pragma unroll
       for (int e=0; e<3; e++) base.t[e] = gm.base_t[e];
    }
    // the end-effector link's frame: walk its chain, then the fixed transform to the link
    cur = base;
    real aw[3], an[3];
-   for (int j=0; j<gm.nj; j++)
-      if ((ts.chain_mask >> j) & 1u) t_apply_joint(gm.joints[j], point[gm.joints[j].col], cur, aw, an);
+   for (int j=0; j<nj; j++)
+      if ((ts.chain_mask >> j) & 1u) t_apply_joint<real>(joints[j], point[joints[j].col], cur, aw, an);
    real Rl[9], tl[3];
+#pragma unroll
    for (int r=0; r<3; r++)
    {
+#pragma unroll
       for (int c=0; c<3; c++) Rl[3*r+c] = cur.R[3*r+0]*ts.Xl_R[0*3+c] + cur.R[3*r+1]*ts.Xl_R[1*3+c] + cur.R[3*r+2]*ts.Xl_R[2*3+c];
       tl[r] = cur.R[3*r+0]*ts.Xl_t[0] + cur.R[3*r+1]*ts.Xl_t[1] + cur.R[3*r+2]*ts.Xl_t[2] + cur.t[r];
    }
-   real pose_link[7], pose_ee[7], pose_obj[7], pose_table_obj[7], xyzypr[6];
+   real pose_link[7], pose_ee[7], pose_obj[7], P[7], xyzypr[6], tool[7], ee_obj[7], tw[7];
+#pragma unroll
+   for (int e=0; e<7; e++) { tool[e] = ts.tool[e]; ee_obj[e] = ts.ee_obj[e]; tw[e] = ts.table_world[e]; }
    pose_link[0] = tl[0]; pose_link[1] = tl[1]; pose_link[2] = tl[2];
    t_quat_from_R(Rl, pose_link+3);
-   t_pose_compose(pose_link, ts.tool, pose_ee);                 // GetEndEffectorTransform (mod.cpp:1382-1394)
-   t_pose_compose(pose_ee, ts.ee_obj, pose_obj);                // mod.cpp:1396-1398
-   t_pose_compose(ts.table_world, pose_obj, pose_table_obj);    // mod.cpp:1400-1404
-   t_pose_to_xyzypr(pose_table_obj, xyzypr);
+   t_pose_compose(pose_link, tool, pose_ee);                 // GetEndEffectorTransform (mod.cpp:1382-1394)
+   t_pose_compose(pose_ee, ee_obj, pose_obj);                // mod.cpp:1396-1398
+   t_pose_compose(tw, pose_obj, P);                          // mod.cpp:1400-1404: the object in the TSR's frame
+   t_pose_to_xyzypr(P, xyzypr);
+   // the enabled rows, three bits each (xyzypr order: x y z yaw pitch roll <- Bw rows x y z roll pitch yaw)
+   unsigned int rowpack = 0; int k = 0;
+#pragma unroll
+   for (int tsri=0; tsri<6; tsri++) if (ts.enabled[tsri]) { rowpack |= (unsigned int)(tsri<3?tsri:8-tsri) << (3*k); k++; }
+   // what the rows of B are made of
+   real R[9], rxR[9];                           // spatial transform of table_world: [R 0; [r]x R  R]   (spatial.c:71-102)
+   t_quat_to_R(tw+3, R);
    {
-      int ki = 0;
-      for (int tsri=0; tsri<6; tsri++) if (ts.enabled[tsri]) hrow[ki++] = xyzypr[tsri<3?tsri:8-tsri];
+      const real rx[9] = { 0, -tw[2], tw[1],  tw[2], 0, -tw[0],  -tw[1], tw[0], 0 };
+#pragma unroll
+      for (int i=0; i<3; i++)
+#pragma unroll
+         for (int j=0; j<3; j++) { real s = 0; for (int q=0; q<3; q++) s += rx[3*i+q] * R[3*q+j]; rxR[3*i+j] = s; }
    }
-   // xyzypr-Jacobian . pose-Jacobian-inverse . spatial transform (mod.cpp:1466-1480)
-   real xm[6][6], Ji[7][6], Jx[6][7], A6[6][6], B6[6][6];
-   t_xm_from_pose(xm, ts.table_world);
-   t_jac_inverse(pose_table_obj, Ji);
-   t_xyzypr_J(pose_table_obj, Jx);
-   for (int i=0; i<6; i++) for (int j=0; j<6; j++) { real s = 0; for (int k=0; k<7; k++) s += Jx[i][k] * Ji[k][j]; A6[i][j] = s; }
-   for (int i=0; i<6; i++) for (int j=0; j<6; j++) { real s = 0; for (int k=0; k<6; k++) s += A6[i][k] * xm[k][j]; B6[i][j] = s; }
-   for (int e=0; e<ts.k*n; e++) Jrows[e] = 0;
+   real Jx[6][7];
+   t_xyzypr_J(P, Jx);                           // rows 3..5, columns 3..6 are what is not 0 or 1 (kin.c:682-717)
+   const real x = P[0], y = P[1], z = P[2];
+   const real qxd2 = (real)0.5*P[3], qyd2 = (real)0.5*P[4], qzd2 = (real)0.5*P[5], qwd2 = (real)0.5*P[6];
+   // pose-Jacobian-inverse (spatial.c:339-375): rows 0..2 = [[r]x | I], rows 3..6 = the quaternion part, columns 0..2
+   const real Jiq[4][3] = { { qwd2, qzd2, -qyd2 }, { -qzd2, qwd2, qxd2 }, { qyd2, -qxd2, qwd2 }, { -qxd2, -qyd2, -qzd2 } };
+   real B[KMAX][6];
+#pragma unroll
+   for (int ki=0; ki<KMAX; ki++)
+   {
+#pragma unroll
+      for (int j=0; j<6; j++) B[ki][j] = 0;
+      if (ki < k)
+      {
+         const int row = (rowpack >> (3*ki)) & 7u;
+         real hv = xyzypr[0];
+#pragma unroll
+         for (int e=1; e<6; e++) hv = (row == e) ? xyzypr[e] : hv;
+         hrow[ki] = hv;
+         real a[6];
+         if (row < 3)
+         {
+            a[0] = (row == 0) ? (real)0 : ((row == 1) ? -z : y);
+            a[1] = (row == 0) ? z : ((row == 1) ? (real)0 : -x);
+            a[2] = (row == 0) ? -y : ((row == 1) ? x : (real)0);
+            a[3] = (row == 0) ? (real)1 : (real)0; a[4] = (row == 1) ? (real)1 : (real)0; a[5] = (row == 2) ? (real)1 : (real)0;
+         }
+         else
+         {
+            real g[4];
+#pragma unroll
+            for (int q=0; q<4; q++) g[q] = (row == 3) ? Jx[3][3+q] : ((row == 4) ? Jx[4][3+q] : Jx[5][3+q]);
+#pragma unroll
+            for (int c=0; c<3; c++) { real s = 0; for (int q=0; q<4; q++) s += g[q] * Jiq[q][c]; a[c] = s; }
+            a[3] = 0; a[4] = 0; a[5] = 0;
+         }
+#pragma unroll
+         for (int j=0; j<3; j++)
+         {
+            real s = 0;
+#pragma unroll
+            for (int i=0; i<3; i++) s += a[i] * R[3*i+j];
+#pragma unroll
+            for (int i=0; i<3; i++) s += a[3+i] * rxR[3*i+j];
+            B[ki][j] = s;
+            real u = 0;
+#pragma unroll
+            for (int i=0; i<3; i++) u += a[3+i] * R[3*i+j];
+            B[ki][3+j] = u;
+         }
+      }
+   }
+   for (int e=0; e<k*n; e++) Jrows[e] = 0;
    // . spatial Jacobian, column by column (mod.cpp:1432-1464, 1481-1491)
    if (gm.floating)
    {
       // cd_spatial_pose_jac(point), spatial.c:295-337: the first seven columns
-      const real x = point[0], y = point[1], z = point[2];
+      const real px = point[0], py = point[1], pz = point[2];
       const real qx = 2*point[3], qy = 2*point[4], qz = 2*point[5], qw = 2*point[6];
-      real Jsp[6][7];
-      for (int a=0; a<6; a++) for (int c=0; c<7; c++) Jsp[a][c] = 0;
-      Jsp[3][0] = 1; Jsp[4][1] = 1; Jsp[5][2] = 1;
-      Jsp[0][3] =  qw; Jsp[0][4] = -qz; Jsp[0][5] =  qy; Jsp[0][6] = -qx;
-      Jsp[1][3] =  qz; Jsp[1][4] =  qw; Jsp[1][5] = -qx; Jsp[1][6] = -qy;
-      Jsp[2][3] = -qy; Jsp[2][4] =  qx; Jsp[2][5] =  qw; Jsp[2][6] = -qz;
-      Jsp[3][3] = -z*qz - y*qy; Jsp[3][4] = -z*qw + y*qx; Jsp[3][5] =  z*qx + y*qw; Jsp[3][6] =  z*qy - y*qz;
-      Jsp[4][3] =  z*qw + x*qy; Jsp[4][4] = -z*qz - x*qx; Jsp[4][5] =  z*qy - x*qw; Jsp[4][6] = -z*qx + x*qz;
-      Jsp[5][3] = -y*qw + x*qz; Jsp[5][4] =  y*qz + x*qw; Jsp[5][5] = -y*qy - x*qx; Jsp[5][6] =  y*qx - x*qy;
+      const real Jsp[6][7] = {
+         { 0, 0, 0,  qw, -qz,  qy, -qx },
+         { 0, 0, 0,  qz,  qw, -qx, -qy },
+         { 0, 0, 0, -qy,  qx,  qw, -qz },
+         { 1, 0, 0, -pz*qz - py*qy, -pz*qw + py*qx,  pz*qx + py*qw,  pz*qy - py*qz },
+         { 0, 1, 0,  pz*qw + px*qy, -pz*qz - px*qx,  pz*qy - px*qw, -pz*qx + px*qz },
+         { 0, 0, 1, -py*qw + px*qz,  py*qz + px*qw, -py*qy - px*qx,  py*qx - px*qy } };
+#pragma unroll
       for (int c=0; c<7; c++)
-      {
-         int ki = 0;
-         for (int tsri=0; tsri<6; tsri++) if (ts.enabled[tsri])
+#pragma unroll
+         for (int ki=0; ki<KMAX; ki++) if (ki < k)
          {
-            const int row = tsri<3?tsri:8-tsri;
             real s = 0;
-            for (int k=0; k<6; k++) s += B6[row][k] * Jsp[k][c];
+#pragma unroll
+            for (int q=0; q<6; q++) s += B[ki][q] * Jsp[q][c];
             Jrows[ki*n + c] = s;
-            ki++;
          }
-      }
    }
    cur = base;
-   for (int j=0; j<gm.nj; j++)
+   for (int j=0; j<nj; j++)
       if ((ts.chain_mask >> j) & 1u)
       {
-         const DevJoint<real> & J = gm.joints[j];
-         t_apply_joint(J, point[J.col], cur, aw, an);
+         JointC & J = joints[j];
+         const int col = J.col;
+         t_apply_joint<real>(J, point[col], cur, aw, an);
          real col6[6];
          if (J.type == 1)
          {
@@ -302,16 +355,21 @@ __device__ void tsr_eval_point(const DevModel<real> & gm, const DevTsr<real> & t
             col6[5] = aw[0]*(-an[1]) - aw[1]*(-an[0]);
          }
          else { col6[0] = 0; col6[1] = 0; col6[2] = 0; col6[3] = aw[0]; col6[4] = aw[1]; col6[5] = aw[2]; }
-         int ki = 0;
-         for (int tsri=0; tsri<6; tsri++) if (ts.enabled[tsri])
+#pragma unroll
+         for (int ki=0; ki<KMAX; ki++) if (ki < k)
          {
-            const int row = tsri<3?tsri:8-tsri;
             real s = 0;
-            for (int k=0; k<6; k++) s += B6[row][k] * col6[k];
-            Jrows[ki*n + J.col] = s;
-            ki++;
+#pragma unroll
+            for (int q=0; q<6; q++) s += B[ki][q] * col6[q];
+            Jrows[ki*n + col] = s;
          }
       }
+}
+template <typename real>
+__device__ void tsr_eval_point(const DevModel<real> & gm, const DevTsr<real> & ts, const real * point, int n, real * hrow, real * Jrows)
+{
+   if (ts.k <= 3) tsr_eval_point_k<real, 3>(gm, ts, point, n, hrow, Jrows);
+   else tsr_eval_point_k<real, 6>(gm, ts, point, n, hrow, Jrows);
 }
 
 // (constraint, point) of block o in the reference's list order (the list grows at its head,
@@ -474,6 +532,17 @@ __device__ __forceinline__ float lane_fetch(float v, int addr4) { return __int_a
 // t (64 / WP) + rsub), pivots 0 .. N-1.  All lane fetches of a step (the pivot row at this lane's column, the lane's
 // multipliers of every register) are issued before any is used: one round trip of the cross-lane unit per step, the
 // reciprocal of the pivot is formed meanwhile.  Returns false at a zero or non-finite pivot.
+// A function that is called (not inlined) receives its arguments in vector registers: loop bounds, base addresses and the
+// kernarg block then count as "divergent", loops over them are run by lane masks and their address arithmetic by the vector
+// pipe.  These put a wave-uniform value back into scalar registers.
+template <typename T>
+__device__ __forceinline__ T * uniform_ptr(T * p)
+{
+   const unsigned long long v = (unsigned long long) p;
+   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned) v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+   return (T *)(((unsigned long long) hi << 32) | lo);
+}
+
 template <int K> struct PivotIndex { static constexpr int value = K; };
 template <int... Ks, typename F>
 __device__ __forceinline__ void for_each_pivot(std::integer_sequence<int, Ks...>, F && f) { (f(PivotIndex<Ks>{}), ...); }
@@ -483,8 +552,9 @@ __device__ __forceinline__ bool gauss_jordan_regs(real (& w)[NREG], int N, int c
 {
    constexpr int RPR = 64 / WP;
    const int kfetch4 = rsub * WP * 4;
-   bool ok = true;      // (checked once per block: a branch on the pivot would sit in the dependent chain of every step; past a zero
-                        // pivot the block fills with inf and NaN, which nothing reads -- the caller takes the dense path)
+   // (a zero or non-finite pivot is looked for once per block, in its result: a test in every step sat in the steps' dependent
+   // chain; past such a pivot the block fills with NaN, which nothing reads -- the caller takes the dense path)
+   bool ok = true;
    if constexpr (WP <= 32)
    {
       // Every step written out: the pivot's register and the rows that hold it are known at compile time, so no step selects its
@@ -495,8 +565,6 @@ __device__ __forceinline__ bool gauss_jordan_regs(real (& w)[NREG], int N, int c
          if (k < N)
          {
             const real p = read_lane(w[tk], j * WP + k);
-            const real ap = M<real>::fabs_(p);
-            ok = ok && (ap > (real)0 && ap < M<real>::inf());
             const real praw = lane_fetch(w[tk], (j * WP + c) * 4);      // the pivot row at this lane's column
             real f[NREG];
 #pragma unroll
@@ -514,7 +582,11 @@ __device__ __forceinline__ bool gauss_jordan_regs(real (& w)[NREG], int N, int c
             }
          }
       });
-      return ok;
+      // a zero or non-finite pivot: its reciprocal's Newton step is 0 x inf, and the NaN is in every entry one step later
+      bool finite = true;
+#pragma unroll
+      for (int t=0; t<NREG; t++) finite = finite && (M<real>::fabs_(w[t]) < M<real>::inf());
+      return __builtin_amdgcn_ballot_w64(!finite) == 0ull;
    }
    for (int k=0; k<N; k++)
    {
@@ -541,9 +613,14 @@ __device__ __forceinline__ bool gauss_jordan_regs(real (& w)[NREG], int N, int c
 }
 
 template <typename real, int WP, int NREG, int DIR, typename BT>
-__device__ void tsr_eliminate_regs(const BT & b, const Env<real> & E, const real * hws, const real * Jws, real * Cst, int * flag,
-   int i_begin, int i_end, int * rows2)
+__device__ void tsr_eliminate_regs(const BT & b_, const Env<real> & E, const real * hws_, const real * Jws_, real * Cst_, int * flag_,
+   int i_begin_, int i_end_, int * rows2_)
 {
+   const BT & b = *uniform_ptr(&b_);
+   const real * hws = uniform_ptr(hws_), * Jws = uniform_ptr(Jws_);
+   real * Cst = uniform_ptr(Cst_);
+   int * flag = uniform_ptr(flag_), * rows2 = uniform_ptr(rows2_);
+   const int i_begin = __builtin_amdgcn_readfirstlane(i_begin_), i_end = __builtin_amdgcn_readfirstlane(i_end_);
    constexpr int RPR = 64 / WP;               // rows per register slice
    const int lane = threadIdx.x & 63;
    const int c = lane & (WP - 1), rsub = lane / WP;
@@ -618,11 +695,15 @@ __device__ void tsr_eliminate_regs(const BT & b, const Env<real> & E, const real
    // (the reads are unconditional -- a lane without an entry reads h[row_base] -- and nothing is computed from them here: the
    // wait for them then sits where the next block is put together, a whole elimination later, instead of behind each load)
    real jraw[NREG];
-   const real * jsrc[NREG]; int jstep[NREG];
+   // (pointers into GLOBAL memory, said so: a read through a generic pointer is a FLAT instruction, which counts on the LDS
+   // counter as well -- the wait for a step's cross-lane fetches then also waited for the next point's J and h)
+   typedef const __attribute__((address_space(1))) real * GlobalIn;
+   typedef __attribute__((address_space(1))) real * GlobalOut;
+   GlobalIn jsrc[NREG]; int jstep[NREG];
 #pragma unroll
    for (int t=0; t<NREG; t++)
    {
-      jsrc[t] = (jcol[t] >= 0) ? Jws + (size_t) jrow0[t] * n + jcol[t] : hws + jrow0[t];
+      jsrc[t] = (GlobalIn)((jcol[t] >= 0) ? Jws + (size_t) jrow0[t] * n + jcol[t] : hws + jrow0[t]);
       jstep[t] = (jcol[t] >= 0) ? jstride[t] * n : jstride[t];
       jraw[t] = 0;
    }
@@ -630,14 +711,60 @@ __device__ void tsr_eliminate_regs(const BT & b, const Env<real> & E, const real
 #pragma unroll
       for (int t=0; t<NREG; t++) jraw[t] = jsrc[t][(m - 1 - i) * jstep[t]];
    };
-   auto use_direct = [&]() {
+   if (every_point)
+   {
+      // The loop of the common case: every block has the same shape, so what a lane's entries ARE (metric diagonal, coupling
+      // to the next point, a row of C' or r' of the previous point, an entry of J or h) is decided once, and a block is
+      // put together by selects on lane masks -- written with the conditions inside the loop it was 440 of the 600
+      // instructions of a point, most of them branches around two or three instructions.
+      const int N = __builtin_amdgcn_readfirstlane(n + k_all), Wd = N + n1;      // (uniform: the steps k >= N are skipped by scalar branches)
+      // entry = c_diag a_ii + c_fwd a_i,i+1 + c_prev (-a_i,i-1 x the previous point's entry) + c_j (J or h from memory), the
+      // coefficients 0, 1 or -1 and at most two terms not zero: exact, and three multiply-adds instead of a dozen selects
+      real c_diag[NREG], c_fwd[NREG], c_prev[NREG], c_j[NREG];
+      bool st_ok[NREG];
+      int st_off[NREG];
 #pragma unroll
-      for (int t=0; t<NREG; t++) jn[t] = (jcol[t] == -2) ? (real)0 : ((jcol[t] >= 0) ? jsign[t] * jraw[t] : jraw[t]);
-   };
+      for (int t=0; t<NREG; t++)
+      {
+         const int r = t*RPR + rsub;
+         const bool is_sd = (r < n) && (c < n);
+         c_diag[t] = (is_sd && r == c) ? (real)1 : (real)0;
+         c_fwd[t] = ((r < n) && (c >= N) && (c < N + n) && (c - N == r)) ? (real)1 : (real)0;
+         c_prev[t] = (is_sd || ((r < n) && (c == Wd - 1))) ? (real)1 : (real)0;
+         c_j[t] = (jcol[t] == -2) ? (real)0 : ((jcol[t] >= 0) ? jsign[t] : (real)1);
+         st_ok[t] = (r < n) && (c >= N) && (c <= N + n);
+         st_off[t] = st_ok[t] ? r*n1 + (c - N) : 0;
+      }
+      const int psrc4 = (rsub * WP + ((c < n) ? N + c : N + n)) * 4;
+      const real a_diag = b.a_diag, a_off = b.a_off;      // (read here: the stores of the loop could alias them)
+      fetch_direct(i_begin);
+      for (int i=i_begin; i!=i_end; i+=DIR)
+      {
+         real lo, di, up;
+         if (toeplitz) { di = a_diag; lo = (i > 0) ? a_off : (real)0; up = (i < m-1) ? a_off : (real)0; }
+         else { lo = (i > 0) ? b.Aband[i] : (real)0; di = b.Aband[(size_t) m + i]; up = (i < m-1) ? b.Aband[(size_t) 2*m + i] : (real)0; }
+         const real back = (i == i_begin) ? (real)0 : ((DIR > 0) ? lo : up), fwd = (DIR > 0) ? up : lo;
+#pragma unroll
+         for (int t=0; t<NREG; t++)
+         {
+            const real pv = lane_fetch(w[t], psrc4);          // C[r][c] (c < n) or r[r] of the previous point (zero in front of the first)
+            real v = c_j[t] * jraw[t];
+            v = fma(c_diag[t], di, v);
+            v = fma(c_fwd[t], fwd, v);
+            w[t] = fma(c_prev[t] * pv, -back, v);
+         }
+         if (i + DIR != i_end) fetch_direct(i + DIR);
+         if (!gauss_jordan_regs<real, WP, NREG>(w, N, c, rsub)) { if (lane == 0) flag[0] = 1; return; }
+         GlobalOut Ci = (GlobalOut)(Cst + (size_t) i*n*n1);
+#pragma unroll
+         for (int t=0; t<NREG; t++) if (st_ok[t]) Ci[st_off[t]] = w[t];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      return;
+   }
    int Nprev = n;
    int ki = k_all;
-   if (every_point) fetch_direct(i_begin);
-   else { ki = point_rows(i_begin, rows2); fetch(rows2, ki); }
+   ki = point_rows(i_begin, rows2); fetch(rows2, ki);
    int par = 0;
    for (int i=i_begin; i!=i_end; i+=DIR)
    {
@@ -648,7 +775,6 @@ __device__ void tsr_eliminate_regs(const BT & b, const Env<real> & E, const real
       // the coupling to the point eliminated before this one, and to the one that follows
       const real back = (i == i_begin) ? (real)0 : ((DIR > 0) ? lo : up), fwd = (DIR > 0) ? up : lo;
       // the block of this point; what it takes of the previous point's [C | r] comes out of that block's registers
-      if (every_point) use_direct();
       const int psrc4 = (rsub * WP + ((c < n) ? Nprev + c : Nprev + n)) * 4;
 #pragma unroll
       for (int t=0; t<NREG; t++)
@@ -668,13 +794,9 @@ __device__ void tsr_eliminate_regs(const BT & b, const Env<real> & E, const real
       int ki_next = ki;
       if (i + DIR != i_end)
       {
-         if (every_point) fetch_direct(i + DIR);
-         else
-         {
-            par ^= 1;
-            ki_next = point_rows(i + DIR, rows2 + 16 * par);
-            fetch(rows2 + 16 * par, ki_next);
-         }
+         par ^= 1;
+         ki_next = point_rows(i + DIR, rows2 + 16 * par);
+         fetch(rows2 + 16 * par, ki_next);
       }
       // Gauss-Jordan in the order delta, x (quasi-definite: no pivoting)
       if (!gauss_jordan_regs<real, WP, NREG>(w, N, c, rsub)) { if (lane == 0) flag[0] = 1; return; }
@@ -693,8 +815,13 @@ __device__ void tsr_eliminate_regs(const BT & b, const Env<real> & E, const real
 // where the two eliminations meet: u = delta_{mid-1}, v = delta_mid from (I - C' C") u = r' - C' r", v = r" - C" u
 // (C', r' of point mid-1, C", r" of point mid; one wavefront).  out [2][n].
 template <typename real, int NREG, typename BT>
-__device__ void tsr_meet_regs(const BT & b, const real * Cst, int mid, real * out, int * flag)
+__device__ void tsr_meet_regs(const BT & b_, const real * Cst_, int mid_, real * out_, int * flag_)
 {
+   const BT & b = *uniform_ptr(&b_);
+   const real * Cst = uniform_ptr(Cst_);
+   real * out = uniform_ptr(out_);
+   int * flag = uniform_ptr(flag_);
+   const int mid = __builtin_amdgcn_readfirstlane(mid_);
    constexpr int WP = 16, RPR = 4;            // n <= 15: the block [I - C' C" | r' - C' r"] in rows of 16 lanes
    const int lane = threadIdx.x & 63;
    const int c = lane & (WP - 1), rsub = lane / WP;
@@ -775,11 +902,14 @@ __device__ void tsr_meet(const BT & b, const real * Cst, int mid, real * out, in
 // the substitution outwards: delta_i = r_i - C_i delta_(i - DIR), T_i -= delta_i (chomp.c:592-599), starting next to
 // the point whose delta is `start` (lane j holds component j)
 template <typename real, int DIR, int WPS, int NREGS, typename BT>
-__device__ void tsr_substitute(const BT & b, const Env<real> & E, const real * Cst, const real * start, int i_begin, int i_end)
+__device__ void tsr_substitute(const BT & b_, const Env<real> & E, const real * Cst_, const real * start_, int i_begin_, int i_end_)
 {
+   const BT & b = *uniform_ptr(&b_);
+   const real * Cst = uniform_ptr(Cst_), * start = uniform_ptr(start_);
+   const int i_begin = __builtin_amdgcn_readfirstlane(i_begin_), i_end = __builtin_amdgcn_readfirstlane(i_end_);
    const int lane = threadIdx.x & 63;
    const int n = b.n, n1 = n + 1;
-   real * Tw = E.T_s;
+   real * Tw = uniform_ptr(E.T_s);
    if constexpr (WPS > 0)
    {
       // lane = (row % (64 / WPS), column j), register t = row t (64 / WPS) + rsub; n + 1 <= WPS.  A lane multiplies its
@@ -792,14 +922,20 @@ __device__ void tsr_substitute(const BT & b, const Env<real> & E, const real * C
       real dj[NREGS];                          // delta[r] of the previous point in the lanes of row r
 #pragma unroll
       for (int t=0; t<NREGS; t++) { const int r = t*RPRS + rsub; dj[t] = (r < n) ? start[r] : (real)0; }
+      // (reads of global memory and updates of LDS, both said so: through generic pointers they are FLAT instructions, which
+      // count on both memory counters -- the wait for a cross-lane fetch then waits for the rows of C' fetched ahead too; and
+      // unconditional, every lane from an address of its own or the block's first entry)
+      typedef const __attribute__((address_space(1))) real * GlobalIn;
+      typedef __attribute__((address_space(3))) real * LdsOut;
+      GlobalIn Cg = (GlobalIn) Cst;
+      LdsOut Tl = (LdsOut)(unsigned int)(unsigned long long) Tw;
+      bool cok[NREGS]; int coff[NREGS];
+#pragma unroll
+      for (int t=0; t<NREGS; t++) { const int r = t*RPRS + rsub; cok[t] = (r < n) && (j <= n); coff[t] = cok[t] ? r*n1 + j : 0; }
       real cn[NREGS];
       auto fetch = [&](int i) {
 #pragma unroll
-         for (int t=0; t<NREGS; t++)
-         {
-            const int r = t*RPRS + rsub;
-            cn[t] = (r < n && j <= n) ? Cst[(size_t) i*n*n1 + r*n1 + j] : (real)0;
-         }
+         for (int t=0; t<NREGS; t++) cn[t] = Cg[(size_t) i*n*n1 + coff[t]];
       };
       if (i_begin != i_end) fetch(i_begin);
       // the lane of row j's data: row j lives in register j / RPRS of the lanes (j % RPRS) * WPS + anything
@@ -809,7 +945,7 @@ __device__ void tsr_substitute(const BT & b, const Env<real> & E, const real * C
       {
          real cc[NREGS];
 #pragma unroll
-         for (int t=0; t<NREGS; t++) cc[t] = cn[t];
+         for (int t=0; t<NREGS; t++) cc[t] = cok[t] ? cn[t] : (real)0;
          if (i + DIR != i_end) fetch(i + DIR);
          // delta_(prev)[j] for this lane's column
          real dsel = dj[0];
@@ -835,7 +971,7 @@ __device__ void tsr_substitute(const BT & b, const Env<real> & E, const real * C
             if (WPS >= 8)  term += dpp_move<0x141>(term);
             if (WPS >= 16) term += dpp_move<0x140>(term);
             dj[t] = term;
-            if (r < n && j == 0) Tw[n + i*n + r] -= term;
+            if (r < n && j == 0) Tl[n + i*n + r] -= term;
          }
       }
    }
@@ -886,9 +1022,7 @@ __device__ __attribute__((noinline)) void phase_tsr(const void * kp)
       int c, i, row0;
       tsr_block<real>(b, o, c, i, row0);
       const DevTsr<real> & ts = b.tsrs[c];
-      real point[ORC_MAX_JOINTS + 7];
-      for (int q=0; q<n; q++) point[q] = T_s[(i+1)*n + q];
-      tsr_eval_point<real>(gm, ts, point, n, hws + row0, Jws + (size_t) row0 * n);
+      tsr_eval_point<real>(gm, ts, T_s + (i+1)*n, n, hws + row0, Jws + (size_t) row0 * n);
       for (int a=0; a<ts.k; a++)
       {
          real s = 0;
@@ -910,7 +1044,7 @@ __device__ __attribute__((noinline)) void phase_tsr(const void * kp)
 #ifndef ORC_TSR_LDS
       if (BLOCK >= 128 && m >= 4 && n <= 62)
          shape = (Wm <= 16 && Nm <= 8) ? 16 : ((Wm <= 32 && Nm <= 16) ? 32 : ((Wm <= 64 && Nm <= 20) ? 64 : 0));
-         if (Nm - n > 16) shape = 0;      // (the row lists of a point hold 16 entries: more constrained rows on one point take the dense path)
+      if (Nm - n > 16) shape = 0;      // (the row lists of a point hold 16 entries: more constrained rows on one point take the dense path)
 #endif
       if (!shape)
       {

@@ -14,8 +14,8 @@ import shutil
 import sys
 
 tag, name = sys.argv[1], sys.argv[2]          # e.g.  a  r02_config2
-config = int(sys.argv[3]) if len(sys.argv) > 3 else 2
-batch = int(sys.argv[4]) if len(sys.argv) > 4 else {2: 1024, 4: 4096, 5: 4096}[config]
+config = (int(sys.argv[3]) if sys.argv[3].isdigit() else sys.argv[3]) if len(sys.argv) > 3 else 2      # 2, 4, 5, tsr1, tsr3
+batch = int(sys.argv[4]) if len(sys.argv) > 4 else {2: 1024, 4: 4096, 5: 4096, "tsr1": 1024, "tsr3": 1024}[config]
 n_iter = int(sys.argv[5]) if len(sys.argv) > 5 else 100
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
@@ -25,7 +25,7 @@ os.makedirs(dst, exist_ok=True)
 newest = lambda pattern: max(glob.glob(pattern), key=os.path.getmtime)
 stats = newest(os.path.join(src, "trace", "*", "*kernel_stats.csv"))
 shutil.copy(stats, os.path.join(dst, name + "_kernel_stats.csv"))
-summary = {"source": "rocprofv3 on `python3 bench.py --config %d --no-cpu-baseline --serial-steps 0 --steps N --warmup W` "
+summary = {"source": "rocprofv3 on `python3 bench.py --config %s --no-cpu-baseline --serial-steps 0 --steps N --warmup W` "
                      "(scripts/profile_round.sh): --kernel-trace --stats with 20 steps; one --pmc pass per counter group with 2 steps" % config,
            "config": config, "batch": batch, "n_iter": n_iter, "counters": {}}
 for row in csv.DictReader(open(stats)):
@@ -75,7 +75,7 @@ if "SQ_INSTS_VALU" in c:
     summary["valu_insts_per_run_iteration"] = entry["valu_insts_per_run_iteration"]
 path = os.path.join(dst, "counters_latest.json")
 allc = json.load(open(path)) if os.path.exists(path) else {}
-allc["config%d" % config] = entry
+allc["config%s" % config] = entry
 json.dump(allc, open(path, "w"), indent=1)
 json.dump(summary, open(os.path.join(dst, name + "_summary.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in summary.items() if k != "bench_line_of_the_traced_run"}, indent=1))
