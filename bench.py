@@ -627,8 +627,8 @@ def main():
                                                                       "default: 4 for the overlapping / large-batch legs of configs 2 and 3")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="default run only (N = 1, config 2): do not append the config 4 and config 5 lines")
-    ap.add_argument("--other-steps", type=int, default=5, help="steps of each `other_configs` line")
-    ap.add_argument("--no-sweep", action="store_true", help="default run only: do not append `batch_sweep`, `tsr1` and `stages`")
+    ap.add_argument("--other-steps", type=int, default=8, help="steps of each `other_configs` line (even: the steps alternate between two streams)")
+    ap.add_argument("--no-sweep", action="store_true", help="default run only: do not append `batch_sweep`, `tsr1`, `tsr3` and `stages`")
     ap.add_argument("--sweep-batches", default="1,64,4096,16384,65536", help="batch sizes of `batch_sweep`")
     ap.add_argument("--dump-gather", default="", help="N > 1: rank 0 saves the gathered step-0 trajectories here (.npy)")
     args = ap.parse_args()
@@ -668,16 +668,17 @@ def main():
         # the other two single-GPU configurations under the same clock (a few steps each)
         others = []
         for c in (4, 5):
-            line, rc_c = run_workload(c, args, rank, world, device, dist, args.other_steps, 1, min(args.other_steps, 3))
+            line, rc_c = run_workload(c, args, rank, world, device, dist, args.other_steps, 2, min(args.other_steps, 3))
             others.append(line)
             rc = rc or rc_c
         out["other_configs"] = others
         # the rest of the metric under the same clock: the batch sweep, the TSR-constrained line, the reference's stage names
         if not args.no_sweep:
             out["batch_sweep"] = batch_sweep(device, [int(b) for b in args.sweep_batches.split(",")])
-            line, rc_c = run_workload("tsr1", args, rank, world, device, dist, args.other_steps, 1, min(args.other_steps, 3))
-            out["tsr1"] = line
-            rc = rc or rc_c
+            for c in ("tsr1", "tsr3"):
+                line, rc_c = run_workload(c, args, rank, world, device, dist, args.other_steps, 2, min(args.other_steps, 3))
+                out[c] = line
+                rc = rc or rc_c
             out["stages"] = stage_breakdown(device)
     if rank == 0:
         print(json.dumps(out))
