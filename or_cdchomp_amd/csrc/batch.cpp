@@ -902,6 +902,7 @@ void BatchShard::build_device(const Robot & robot)
    const size_t lds_cu = 160*1024;
    int force_t = 0, force_pcr = -1, force_ag = -1, force_block = 0;
    int max_wgs = (sizeof(real) == 4 && GS_ != 16) ? ORC_WGS_PER_CU_FP32_MANY : ORC_WGS_PER_CU;      // (the kernel variant's register budget)
+   const int max_wgs_budget = max_wgs;
    if (const char * e = getenv("ORC_TILE_M")) force_t = atoi(e);          // experiments
    if (const char * e = getenv("ORC_PCR_LDS")) force_pcr = atoi(e);
    if (const char * e = getenv("ORC_AG_LDS")) force_ag = atoi(e);
@@ -919,17 +920,21 @@ void BatchShard::build_device(const Robot & robot)
    bool budget4 = false;
    const int lanes_per_wp = (GS_ == 16) ? 16 : GS_;
    tile_m_ = 0;
-   // (a run the four-per-CU budget has no room for -- a long trajectory -- is planned with the default budget instead)
-   for (int pass=0; pass<2 && !tile_m_; pass++)
+   // (a run the four-per-CU budget has no room for -- a long trajectory -- is planned with the default budget instead; a run
+   // that has no plan under the experiments' switches -- a forced tile of 33 waypoints at four workgroups per CU, the gradient
+   // rows forced out of LDS for a trajectory of three points -- is planned without them: the switches are preferences)
+   for (int pass=0; pass<3 && !tile_m_; pass++)
    {
-   max_wgs = max_wgs_default; force_block = force_block_asked;
+   const bool relax = (pass == 2);
+   max_wgs = relax ? max_wgs_budget : max_wgs_default; force_block = force_block_asked;
+   if (relax) { force_t = 0; force_pcr = -1; force_ag = -1; }
    budget4 = (pass == 0) && (want_wgs == 4) && sizeof(real) == 8 && (tree_ & 16) && (tree_ & 2) && (!(tree_ & 64) || (tree_ & 160) == 160) && (force_block == 0 || force_block == 256)
                         && !getenv("ORC_BLOCK_THREADS") && !getenv("ORC_WGS") && !getenv("ORC_TILE_M");      // (the experiments' switches come first)
    if (budget4) { max_wgs = 4; force_block = 256; }
-   if (const char * e = getenv("ORC_BLOCK_THREADS")) force_block = atoi(e);
+   if (const char * e = getenv("ORC_BLOCK_THREADS")) if (!relax) force_block = atoi(e);
    int force_g = -1, force_tl = -1;
-   if (const char * e = getenv("ORC_G_LDS")) force_g = atoi(e);
-   if (const char * e = getenv("ORC_T_LDS")) force_tl = atoi(e);
+   if (const char * e = getenv("ORC_G_LDS")) if (!relax) force_g = atoi(e);
+   if (const char * e = getenv("ORC_T_LDS")) if (!relax) force_tl = atoi(e);
    tile_m_ = 0;
    block_ = 256;
    double best_score = -1.0;

@@ -928,7 +928,8 @@ __device__ void tsr_substitute(const BT & b_, const Env<real> & E, const real * 
       typedef const __attribute__((address_space(1))) real * GlobalIn;
       typedef __attribute__((address_space(3))) real * LdsOut;
       GlobalIn Cg = (GlobalIn) Cst;
-      LdsOut Tl = (LdsOut)(unsigned int)(unsigned long long) Tw;
+      LdsOut Tl = (LdsOut)(unsigned int)(unsigned long long) Tw;      // (when the trajectory lives in LDS: many-sphere robots may iterate it in global memory)
+      const bool t_lds = b.t_in_lds != 0;
       bool cok[NREGS]; int coff[NREGS];
 #pragma unroll
       for (int t=0; t<NREGS; t++) { const int r = t*RPRS + rsub; cok[t] = (r < n) && (j <= n); coff[t] = cok[t] ? r*n1 + j : 0; }
@@ -971,7 +972,7 @@ __device__ void tsr_substitute(const BT & b_, const Env<real> & E, const real * 
             if (WPS >= 8)  term += dpp_move<0x141>(term);
             if (WPS >= 16) term += dpp_move<0x140>(term);
             dj[t] = term;
-            if (r < n && j == 0) Tl[n + i*n + r] -= term;
+            if (r < n && j == 0) { if (t_lds) Tl[n + i*n + r] -= term; else Tw[n + i*n + r] -= term; }
          }
       }
    }

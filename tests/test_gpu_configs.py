@@ -75,6 +75,9 @@ def test_hmc_plan_out_of_room_leaves_the_batch_unusable(monkeypatch):
     """a run that draws more momentum resamples in one call than the plan has room for: the call reports it, and the
     batch -- whose kernel ran with a cut schedule -- refuses further calls instead of going on from an inconsistent state
     (ORC_HMC_ROOM: room for one resample per run and call, where 60 iterations at lambda 0.05 draw three on average)"""
+    import os
+    if os.environ.get("ORC_HMC_PLAN_SYNC"):
+        pytest.skip("the synchronous plan (round 2's way, scripts/test_toggles.sh) retries with more room instead")
     monkeypatch.setenv("ORC_HMC_DEVICE", "1")
     mod = _mk_module()
     model = common.setup_product_wam(mod)

@@ -238,6 +238,57 @@ def test_start_tsr_many_sphere_robot(oracle):
         run.destroy()
 
 
+@pytest.mark.parametrize("where", ["lds", "global"])
+def test_con_tsr_many_sphere_robot_trajectory_in_global_memory(oracle, monkeypatch, where):
+    """`con_tsr` on a robot with more than 16 spheres, whose kernels may iterate the trajectory in global memory (a long
+    trajectory of many dofs does not fit the LDS beside its tiles): the constraint step reads and moves it where it lives.
+    ORC_T_LDS=0 / ORC_G_LDS=0 ask the planner for that layout on a run short enough for the oracle."""
+    O = oracle
+    if where == "global":
+        monkeypatch.setenv("ORC_T_LDS", "0")
+        monkeypatch.setenv("ORC_G_LDS", "0")
+    mod = or_cdchomp_amd.Module(0)
+    model = robots.tree30()
+    base = [0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 1.0]
+    rng = np.random.default_rng(5)
+    dofvals = rng.uniform(-0.3, 0.3, size=model.n_dof)
+    adofs = list(range(model.n_dof))
+    mod.add_robot(model, transform=base, dof_values=dofvals, active_dofs=adofs)
+    li = model.link_names.index("L13")
+    tool = [0, 0, 0.15, 0, 0, 0, 1]
+    mod.add_manipulator(model.name, "left", li, tool)
+    from or_cdchomp_amd import scenes
+    grids, poses = [], []
+    for name, (boxes, pose) in scenes.random_boxes(np.random.default_rng(20250104)).items():
+        mod.add_kinbody_boxes(name, boxes, transform=pose)
+        mod.SendCommand("computedistancefield kinbody %s cube_extent 0.02 aabb_padding 0.15" % name)
+        data, lengths, gpose = mod.get_sdf(name)
+        grids.append(O.OraGrid(data, lengths))
+        out = np.zeros(7)
+        O.lib().ora_kin_pose_compose(O.dp(O.f64(pose)), O.dp(O.f64(gpose)), O.dp(out))
+        poses.append(out)
+    rob = O.OraRobot(model)
+    R, t, _, _ = rob.fk(base, dofvals)
+    tee = t[li] + R[li] @ np.array(tool[:3])
+    Bw = [[-1, 1], [-1, 1], [0, 0], [-3, 3], [-3, 3], [-3, 3]]          # the tool keeps its height in its own start frame
+    tsr = robots.Tsr(T0w_R=R[li], T0w_d=tee, Bw=Bw)
+    n_runs, n_points, n_iter = 3, 30, 12
+    goals = dofvals[None, :] + rng.uniform(-0.3, 0.3, size=(n_runs, model.n_dof))
+    bid = int(mod.SendCommand("createbatch robot %s n_runs %d adofgoals 0x%x n_points %d lambda 200 obs_factor 100 "
+                              "con_tsr 'all manipee left' '%s'" % (model.name, n_runs, goals.ctypes.data, n_points, tsr.serialize())))
+    costs, status = mod.batch_iterate(bid, n_iter)
+    traj = mod.batch_gettraj(bid)
+    mod.batch_destroy(bid)
+    for k in range(n_runs):
+        run = O.OraRun(rob, base, dofvals, adofs, goals[k], grids, poses, O.default_params(n_points=n_points, lambda_=200.0, obs_factor=100.0))
+        assert run.add_contsr(li, tool, O.pose_from_dR(tee, R[li]), [0, 0, 0, 0, 0, 0, 1], Bw) == 1
+        st, oc = run.iterate(n_iter)
+        assert st == 0 and status[k] == 0
+        assert common.rel_l2(traj[k], run.traj()) <= 1e-6, common.rel_l2(traj[k], run.traj())
+        assert np.allclose(costs[k], oc, rtol=1e-6, atol=0)
+        run.destroy()
+
+
 def test_start_tsr_argument_errors():
     mod = or_cdchomp_amd.Module(0)
     model, dofvals, adofs = _setup(mod, _unit_base())
