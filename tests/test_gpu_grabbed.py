@@ -109,6 +109,25 @@ def test_wam_holding_a_four_sphere_body(scene, oracle):
     print("four held spheres: worst rel L2 %.2e" % worst)
 
 
+def test_wam_holding_a_four_sphere_body_fp32(scene, oracle):
+    """the same 19 active spheres in single precision: the fp32 many-sphere kernels (the family of BASELINE config 5, with
+    the self-collision range tests on the matrix cores), held to north_star's fp32 bar of 1e-3"""
+    s = scene; mod = s["mod"]
+    mod.grab(s["model"].name, "box", s["hand"])
+    goals = common.wam_goals(12, seed=42)
+    bid = mod.batch_create(s["model"].name, goals, precision=32, **KW)
+    otraj, ocosts, ost, amp = _oracle_batch(oracle, s, [(s["hand"], s["box_pose"], BOX_POS, BOX_RAD)], goals, 60, **KW)
+    costs, status = mod.batch_iterate(bid, 60)
+    traj = mod.batch_gettraj(bid)
+    mod.batch_destroy(bid)
+    well = (ost == 0) & (status == 0) & (amp < 1e-9)
+    assert well.sum() >= len(goals) // 2, (ost, status, amp)
+    err = np.array([common.rel_l2(traj[k], otraj[k]) for k in range(len(goals))])
+    assert err[well].max() <= 1e-3, err
+    assert np.allclose(costs[well], ocosts[well], rtol=1e-3, atol=0)
+    print("four held spheres, fp32: worst rel L2 %.2e" % err[well].max())
+
+
 def test_two_bodies_on_different_links_momentum(scene, oracle):
     """two held bodies, one on the hand and one on the forearm (wam4), with momentum: the order of the grabs is the order
     of GetGrabbed()"""
