@@ -627,7 +627,8 @@ def main():
                                                                       "default: 4 for the overlapping / large-batch legs of configs 2 and 3")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="default run only (N = 1, config 2): do not append the config 4 and config 5 lines")
-    ap.add_argument("--other-steps", type=int, default=8, help="steps of each `other_configs` line (even: the steps alternate between two streams)")
+    ap.add_argument("--other-steps", type=int, default=16, help="steps of each `other_configs` line (even: the steps alternate between two streams; "
+                                                               "the first and the last step of a stream overlap with nothing: 16 steps are within 2 %% of 40)")
     ap.add_argument("--no-sweep", action="store_true", help="default run only: do not append `batch_sweep`, `tsr1`, `tsr3` and `stages`")
     ap.add_argument("--sweep-batches", default="1,64,4096,16384,65536", help="batch sizes of `batch_sweep`")
     ap.add_argument("--dump-gather", default="", help="N > 1: rank 0 saves the gathered step-0 trajectories here (.npy)")
