@@ -175,7 +175,7 @@ __device__ __forceinline__ void t_apply_joint(const JT & J, real q, TFrame<real>
    if (J.type == 1)
    {
       real sn, cs;
-      M<real>::sincos_(q, &sn, &cs);
+      sincos_joint(q, &sn, &cs);      // (fk.h: the short kernel the FK phase uses, ~1 ulp: the library call carries a large-argument path several times its length)
       const real v = (real)1 - cs;
       const real a0 = ax[0], a1 = ax[1], a2 = ax[2];
       real Rm[9];
