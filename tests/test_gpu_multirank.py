@@ -6,7 +6,7 @@ block of the 65 536-run batch of seed 20250102 (cut to --batch 512 runs per rank
 the step-0 trajectories on the host (gloo; no data-path collective) and prints the one JSON line.  The
 gathered trajectories must equal, bit for bit, a single-process batch of the same 1024 goals: a run's
 bits do not depend on which rank or which block it is in.  The log of the rehearsal is kept under
-profiles/ (r03_rehearsal_2ranks_gloo.json) when the test runs on the builder's GPU box.
+profiles/ (r04_rehearsal_2ranks_gloo.json) when the test runs on the builder's GPU box.
 """
 import json
 import os
@@ -59,6 +59,6 @@ def test_bench_starts_its_own_two_ranks_and_gathers(tmp_path):
 
     keep = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(keep):
-        with open(os.path.join(keep, "r03_rehearsal_2ranks_gloo.json"), "w") as f:
+        with open(os.path.join(keep, "r04_rehearsal_2ranks_gloo.json"), "w") as f:
             json.dump({"command": "python bench.py --gpus 2 --backend gloo --batch 512 --steps 2 --warmup 1 --no-cpu-baseline",
                        "line": line, "gathered_equals_single_process_batch": True}, f, indent=1)
