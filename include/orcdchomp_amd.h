@@ -140,6 +140,8 @@ int orc_robot_set_self_check(orc_module * mod, const char * name, int enabled);
  * in the kinbody frame, half_extents [n_boxes][3] */
 int orc_env_add_kinbody_boxes(orc_module * mod, const char * name, int n_boxes,
    const double * box_poses, const double * half_extents);
+/* KinBody::SetTransform.  A kinbody the robot holds is moved there and rides with its link from there on (the grab's
+ * relative transform is taken anew; passing the pose orc_body_get_transform returns changes nothing) */
 int orc_kinbody_set_transform(orc_module * mod, const char * name, const double pose[7]);
 int orc_kinbody_enable(orc_module * mod, const char * name, int enabled);
 /* KinBody::GetTransform of a robot or kinbody; a kinbody the robot holds is where its link carries it now */

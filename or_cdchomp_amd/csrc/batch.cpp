@@ -837,6 +837,9 @@ void BatchShard::build_device(const Robot & robot)
       hc[i].stride_r[0] = (real) hc[i].stride_b[0]; hc[i].stride_r[1] = (real) hc[i].stride_b[1]; hc[i].stride_r[2] = (real) sizeof(real);
       hc[i].data = hs[i].data;
       if (nc * sizeof(real) >= (size_t) 1 << 31) throw std::runtime_error("signed distance field too large for this build!");
+      // the many-sphere pass forms its cell offsets with 24-bit multiplies (cost_generic.h: signed, both operands below 2^23)
+      if (GS_ != 16 && (hc[i].stride_b[0] >= (1 << 23) || std::max(s.grid.sizes[0], std::max(s.grid.sizes[1], s.grid.sizes[2])) >= (1 << 23)))
+         throw std::runtime_error("signed distance field too large for this build (a y-z plane of 8 MB or more with a robot of more than 16 active spheres)!");
    }
    DevSdfCell<real> * dc = dev_alloc<DevSdfCell<real>>(hc.size());
    hip_check(hipMemcpy(dc, hc.data(), hc.size()*sizeof(DevSdfCell<real>), hipMemcpyHostToDevice), "sdfs (cell units)");
@@ -1166,6 +1169,8 @@ void BatchShard::plan_hmc(int iter_begin, int iter_end)
          return;
       }
       int cap = 6 + (int) std::ceil(n_iter * params.hmc_resample_lambda * 3.0);
+      // (this path keeps buffers of its own: an earlier call without the switch may have left the stream's shared ones here)
+      if (plan_shared_) { d_hmc_iters_ = nullptr; d_noise_ = nullptr; hmc_cap_iters_ = 0; noise_cap_ = 0; plan_shared_ = false; }
       for (;;)
       {
          const size_t icount = (size_t) n_runs * cap, ncount = icount * mn;

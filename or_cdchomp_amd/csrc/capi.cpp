@@ -281,7 +281,7 @@ int orc_env_add_kinbody_boxes(orc_module * mod, const char * name, int n_boxes, 
 
 int orc_kinbody_set_transform(orc_module * mod, const char * name, const double pose[7])
 {
-   return guarded(mod, [&] { need(pose, "pose"); mod->impl->kinbody(str(name, "name")).transform = orc::Pose(pose); });
+   return guarded(mod, [&] { need(pose, "pose"); mod->impl->set_kinbody_transform(str(name, "name"), orc::Pose(pose)); });
 }
 
 int orc_kinbody_set_spheres(orc_module * mod, const char * name, int n_spheres, const double * sphere_pos, const double * sphere_radius)

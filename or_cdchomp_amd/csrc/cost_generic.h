@@ -144,7 +144,7 @@ __device__ __forceinline__ void cost_tile_generic(const BT & b, const ModelView<
                // one-sided difference towards the nearer neighbour, inwards at the faces (grid.c:372-389)
                prev[q][k] = (fl == (real)0) ? false : ((fl == m1[k]) ? true : (fr[q][k] < (real)0));
 #if ORC_LEAN
-               off += __mul24((int) fl, sb3[k]);                     // (cell index and byte stride are below 2^24: a full-rate multiply)
+               off += __mul24((int) fl, sb3[k]);                     // (a full-rate SIGNED 24-bit multiply: cell index and byte stride are below 2^23, checked at create: batch.cpp build_device)
 #else
                off += (int) fl * sb3[k];
 #endif

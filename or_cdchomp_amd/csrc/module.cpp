@@ -333,6 +333,23 @@ void Module::grab(const std::string & rname, const std::string & body, int link)
    r.grabbed.push_back(g);
 }
 
+// SetTransform of a kinbody.  A body the robot holds is moved where the caller says and rides with its link from THERE
+// (the grab's relative transform is taken anew): a binding that copies every body's pose before a command passes a held
+// body's current pose, which changes nothing.
+void Module::set_kinbody_transform(const std::string & body, const Pose & pose)
+{
+   KinBody & k = kinbody(body);
+   k.transform = pose;
+   for (auto & kv : robots_)
+      for (Robot::Grab & g : kv.second.grabbed)
+         if (g.body == body)
+         {
+            std::vector<Xform> frames;
+            kv.second.fk(kv.second.transform, kv.second.dof_values, frames);
+            g.rel = xform_mul(xform_inverse(frames[g.link]), xform_from_pose(pose));
+         }
+}
+
 void Module::release(const std::string & rname, const std::string & body)
 {
    Robot & r = robot(rname);
@@ -655,7 +672,7 @@ std::string Module::cmd_computedistancefield(const std::vector<std::string> & ar
       {
          const KinBody & k = kv.second;
          if (!k.enabled) continue;
-         const Xform xk = xform_from_pose(k.transform);
+         const Xform xk = xform_from_pose(body_transform(kv.first));      // (a held body is where its link is NOW)
          for (const KinBody::B & bx : k.boxes)
          {
             Box b;
@@ -1200,6 +1217,7 @@ void Module::batch_collision_verdict(int id, int * collides, double * time, int 
       const double * tk = &traj[(size_t) k * b.n_points * b.n];
       const std::vector<double> dtm = retime_linear(tk, b.n_points, b.n, col0, vmax);
       plan_collision_samples(tk, b.n_points, b.n, col0, dtm, seg, u, times);
+      if (seg.size() >= ((size_t) 1 << 31) - 1) throw std::runtime_error("trajectory too long for the batched collision verdict!");      // (the running total is an int on both sides)
       offs[k+1] = (int) seg.size();
       if (offs[k+1] - offs[k] >= (1 << 30)) throw std::runtime_error("trajectory too long for the batched collision verdict!");
    }

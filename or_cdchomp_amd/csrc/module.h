@@ -280,6 +280,7 @@ public:
    // RobotBase::Grab(body, link) / Release(body) / ReleaseAllGrabbed()
    void grab(const std::string & robot, const std::string & body, int link);
    void release(const std::string & robot, const std::string & body);
+   void set_kinbody_transform(const std::string & body, const Pose & pose);      // (a held body is re-anchored to its link)
    void release_all(const std::string & robot);
    // the robot as create collects its spheres (src/orcdchomp_mod.cpp:2148-2300): its own in XML order, then those of
    // every held body in GetGrabbed() order, each on the link that holds the body at T_w_rlink^-1 o T_w_klink o pos

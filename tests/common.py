@@ -220,3 +220,29 @@ def setup_product_tree30(mod, cube_extent=CONFIG5_CUBE, padding=CONFIG5_PADDING)
     for name in config5_bodies():
         mod.SendCommand("computedistancefield kinbody %s cube_extent %f aabb_padding %f" % (name, cube_extent, padding))
     return model
+
+
+# ---- the WAM of config 2 holding a four-sphere box (reference src/orcdchomp_mod.cpp:2168-2300; bench.py `held4`,
+# tests/test_gpu_grabbed.py): 15 + 4 = 19 active spheres, the 32-lane kernel family in fp64 ----
+HELD4_POS = [[0.0, 0.0, 0.0], [0.09, 0.0, 0.0], [0.0, 0.09, 0.02], [0.09, 0.09, 0.02]]
+HELD4_RAD = [0.05, 0.045, 0.04, 0.05]
+HELD4_OFFSET = (-0.04, -0.05, 0.15)      # of the box's frame from the handbase frame's origin, along its axes
+
+
+def held4_pose(model):
+    from or_cdchomp_amd import robots
+    _, base, dofvals, _ = wam_state()
+    R, t = model.link_frames(base, dofvals)
+    li = model.link_names.index("handbase")
+    return list(t[li] + R[li] @ np.asarray(HELD4_OFFSET)) + list(robots.quat_from_axis_angle((0.3, -0.5, 0.8), 0.7))
+
+
+def setup_product_wam_held4(mod):
+    """the config-2 scene with the box in the WAM's hand; returns (model, hand link index, box pose)"""
+    model = setup_product_wam(mod)
+    pose = held4_pose(model)
+    hand = model.link_names.index("handbase")
+    mod.add_kinbody_boxes("held4", [([0.045, 0.045, 0.01, 0, 0, 0, 1], [0.08, 0.08, 0.04])], transform=pose)
+    mod.set_kinbody_spheres("held4", HELD4_POS, HELD4_RAD)
+    mod.grab(model.name, "held4", hand)
+    return model, hand, pose

@@ -338,3 +338,58 @@ def test_recheck_includes_the_held_spheres(scene, oracle):
     assert ("sphere %d " % got["sphere"][k]) in mod.last_collision_details() or ("spheres %d and" % got["sphere"][k]) in mod.last_collision_details()
     mod.destroy(run=run)
     mod.batch_destroy(bid); mod.batch_destroy(b_bare)
+
+
+def test_computedistancefield_sees_a_held_body_where_its_link_is():
+    """Grab, move the robot, then computedistancefield: the collision queries of the voxelization (mod.cpp:462-531,
+    CheckCollision(cube)) see a grabbed body at its CURRENT pose, in its own field and in every other body's.  The same
+    scene built with the body put down at that pose gives the same cells bit for bit; set_kinbody_transform on a held body
+    re-anchors it to its link."""
+    from or_cdchomp_amd import scenes
+    model = robots.wam7()
+    base = [-1.0, 0.0, 1.0, 0.0, np.sqrt(0.5), 0.0, np.sqrt(0.5)]
+    q0 = np.zeros(model.n_dof); q0[:7] = [0.3, -0.4, 0.2, 1.0, 0.1, -0.3, 0.2]
+    q1 = np.zeros(model.n_dof); q1[:7] = robots.WAM_START
+    hand = model.link_names.index("handbase")
+    pose0 = _hand_pose(model, base, q0, (0.0, 0.02, 0.17))
+    cup = [([0, 0, 0.03, 0, 0, 0, 1], [0.03, 0.03, 0.05])]
+
+    held = or_cdchomp_amd.Module(0)
+    held.add_robot(model, transform=base, dof_values=q0, active_dofs=list(range(7)))
+    scenes.add_tabletop(held)
+    held.add_kinbody_boxes("cup", cup, transform=pose0)
+    held.grab(model.name, "cup", hand)
+    held.set_dof_values(model.name, q1)
+    pose1 = held.body_transform("cup")
+    assert np.abs(np.asarray(pose1[:3]) - np.asarray(pose0[:3])).max() > 0.05      # the hand went somewhere else
+    held.SendCommand("computedistancefield kinbody cup aabb_padding 0.1")
+    held.SendCommand("computedistancefield kinbody table")
+
+    put = or_cdchomp_amd.Module(0)
+    put.add_robot(model, transform=base, dof_values=q1, active_dofs=list(range(7)))
+    scenes.add_tabletop(put)
+    put.add_kinbody_boxes("cup", cup, transform=pose1)
+    put.SendCommand("computedistancefield kinbody cup aabb_padding 0.1")
+    put.SendCommand("computedistancefield kinbody table")
+    stale = or_cdchomp_amd.Module(0)                                                # ... and the body left at its grab-time pose differs
+    stale.add_robot(model, transform=base, dof_values=q1, active_dofs=list(range(7)))
+    scenes.add_tabletop(stale)
+    stale.add_kinbody_boxes("cup", cup, transform=pose0)
+    stale.SendCommand("computedistancefield kinbody table")
+    for name in ("cup", "table"):
+        a, la, pa = held.get_sdf(name); b, lb, pb = put.get_sdf(name)
+        assert np.array_equal(a, b) and np.array_equal(la, lb) and np.array_equal(pa, pb), name
+    assert not np.array_equal(held.get_sdf("table")[0], stale.get_sdf("table")[0])
+
+    # SetTransform of a held body: it rides with the link from where it was put
+    def same_pose(a, b):
+        a = np.asarray(a); b = np.asarray(b)
+        return np.abs(a[:3] - b[:3]).max() < 1e-12 and min(np.abs(a[3:] - b[3:]).max(), np.abs(a[3:] + b[3:]).max()) < 1e-12
+    held.set_kinbody_transform("cup", pose0)
+    assert same_pose(held.body_transform("cup"), pose0)
+    held.set_dof_values(model.name, q0)
+    moved = held.body_transform("cup")
+    assert np.abs(np.asarray(moved[:3]) - np.asarray(pose0[:3])).max() > 0.05
+    held.release(model.name, "cup")
+    assert same_pose(held.body_transform("cup"), moved)
+    for m in (held, put, stale): m.close()
