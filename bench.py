@@ -99,7 +99,7 @@ class Workload:
             self.goals, self.basegoals, self.seeds, self.kw = common.config4_problem(self.n_runs)
             self.m, self.n, self.Sa, self.n_sdf, self.w, self.momentum = 198, 14, 16, 1, 8, True
             self.dtype = "f64"
-            self.kernel = "chomp_iterate_kernel<double, tree, 16-lane rows>"
+            self.kernel = "chomp_iterate_kernel<double, chain with a floating base, 16-lane rows>"
             self.label = ("floating base + WAM arm (n=14), n_points=200, use_momentum use_hmc hmc_resample_lambda=0.02 "
                           "seed=run index, batch=%d, n_iter=%d per step (BASELINE configs[3])" % (self.n_runs, N_ITER))
         elif config == 5:
@@ -124,8 +124,19 @@ class Workload:
             self.kernel = "chomp_iterate_kernel<double, chain, 16-lane rows> with the constraint phase (csrc/tsr.h)"
             self.label = ("WAM 7-DOF, n_points=100, batch=%d goals within 0.4 rad of the start, con_tsr 'all link wam7' with %d constrained "
                           "row(s) per moving point, n_iter=%d per step, lambda=100 obs_factor=200" % (self.n_runs, self.rows, N_ITER))
+        elif config == "held4":
+            # config 2's WAM HOLDING a four-sphere box (RobotBase::Grab; src/orcdchomp_mod.cpp:2168-2300: the held body's spheres
+            # join the run's list): 15 + 4 = 19 active spheres, the 32-lane kernel family with the dense pair list (csrc/cost_pairs.h)
+            self.n_runs = batch or 1024
+            self.goals = None
+            self.kw = dict(common.CONFIG2_KW)
+            self.m, self.n, self.Sa, self.n_sdf, self.w, self.momentum = 98, 7, 19, 1, 8, False
+            self.dtype = "f64"
+            self.kernel = "chomp_iterate_kernel<double, chain, 32-lane groups, dense self-collision pair list>"
+            self.label = ("WAM 7-DOF holding a four-sphere box in its hand (19 active spheres), n_points=100, batch=%d random adofgoal, "
+                          "n_iter=%d per step, lambda=100 obs_factor=500, tabletop SDF 40x31x12" % (self.n_runs, N_ITER))
         else:
-            raise SystemExit("--config must be 2, 3, 4, 5, tsr1 or tsr3")
+            raise SystemExit("--config must be 2, 3, 4, 5, tsr1, tsr3 or held4")
         self.bytes_iter = algorithmic_bytes_per_iter(self.m, self.n, self.Sa, self.n_sdf, self.w, self.momentum)
         if config in ("tsr1", "tsr3"):
             # + the constraint step: h and J written and read (2 K (n + 1) w), the rows of C' and r' of the block
@@ -147,6 +158,8 @@ class Workload:
             mod.SendCommand("computedistancefield kinbody table")
             self.model = model
             self.tsr = None
+        elif self.config == "held4":
+            self.model, self.hand, self.held_pose = self.common.setup_product_wam_held4(mod)
         else:
             self.model = self.common.setup_product_wam(mod)
 
@@ -161,7 +174,7 @@ class Workload:
         return self.tsr
 
     def step_goals(self, step, rank):
-        if self.config == 2:
+        if self.config in (2, "held4"):
             return self.common.wam_goals(self.n_runs, seed=20250101 + 1000 * rank + step)
         if self.config in ("tsr1", "tsr3"):
             rng = np.random.default_rng(20250105 + 1000 * rank + step)
@@ -192,7 +205,8 @@ class Workload:
             _, base, dofvals, adofs = c.wam_state()
             if self.config in ("tsr1", "tsr3"):
                 base = self.TSR_BASE
-            self.o_args = (O.OraRobot(self.model), base, dofvals, adofs)
+            grabbed = [(self.hand, self.held_pose, c.HELD4_POS, c.HELD4_RAD)] if self.config == "held4" else []
+            self.o_args = (O.OraRobot(self.model, grabbed=grabbed), base, dofvals, adofs)
             self.o_fields = ([prob["sdf"]], [prob["pose"]])
 
     def oracle_run(self, O, idx, goals, threads, scale=1.0):
@@ -263,7 +277,7 @@ def run_workload(config, args, rank, world, device, dist, steps, warmup, serial_
         # (orc_set_workgroups_per_cu(4): +3-5 % / +50 % on the constrained runs; trajectories bit-identical either way)
         serial_1024 = (streams <= 1 and config in (2, 3) and 768 < n_runs <= 1024)
         mod.set_workgroup_threads(192 if serial_1024 else 0)
-        wgs_auto = 4 if ((config in (2, 3) and not serial_1024) or config in ("tsr1", "tsr3")) else 0
+        wgs_auto = 4 if ((config in (2, 3) and not serial_1024) or config in ("tsr1", "tsr3", "held4")) else 0
         wgs = wgs_auto if args.workgroups_per_cu < 0 else args.workgroups_per_cu
         mod.set_workgroups_per_cu(wgs)
         knobs = {"orc_set_num_streams": streams if streams > 1 else 0, "orc_set_workgroup_threads": 192 if serial_1024 else 0,
@@ -374,7 +388,7 @@ def run_workload(config, args, rank, world, device, dist, steps, warmup, serial_
         if not args.no_cpu_baseline and world == 1:         # the CPU baseline is reported at N=1 only
             cores = host_cores()
             # ~0.1 s (config 2) to ~2.5 s (config 5) per run of 100 iterations on one core; 10-20 s of wall time
-            per_core = {2: 48, 3: 48, 4: 12, 5: 6, "tsr1": 24, "tsr3": 4}[config]
+            per_core = {2: 48, 3: 48, 4: 12, 5: 6, "tsr1": 24, "tsr3": 4, "held4": 32}[config]
             sample = args.cpu_runs or int(min(n_runs, max(8, per_core * cores)))
             sidx = np.arange(min(sample, n_runs))
             c0 = time.perf_counter()
@@ -414,12 +428,15 @@ def run_workload(config, args, rank, world, device, dist, steps, warmup, serial_
         # counters of profiles/ (rocprofv3 --pmc passes of this command, scripts/pmc_counters.sh)
         traffic = None
         valu = None
+        scratch_note = None
         counters_note = "no counters under profiles/ for this workload"
         cpath = os.path.join(ROOT, "profiles", "counters_latest.json")
         if os.path.exists(cpath):
             try:
                 from or_cdchomp_amd import _capi
                 cj = json.load(open(cpath)).get("config%s" % (2 if config == 3 else config))
+                if cj:
+                    scratch_note = cj.get("traffic_note")
                 if cj and cj.get("csrc_hash") != _capi.csrc_hash():
                     # counters of another build say nothing about this one
                     counters_note = ("profiles/counters_latest.json was taken from build %s, this is build %s: traffic and valu_issue "
@@ -439,10 +456,13 @@ def run_workload(config, args, rank, world, device, dist, steps, warmup, serial_
                                 "note": "SQ_INSTS_VALU per launch / (runs x iterations) x 4 cycles x iterations/s "
                                         "/ (1024 SIMDs x clock): the share of vector issue slots the kernel fills"}
             except Exception:
-                traffic, valu = None, None
+                traffic, valu, scratch_note = None, None, None
+        if traffic is None:
+            scratch_note = None
         flop = FLOP_PER_ITERATION.get(config)
         out = {
             "metric": "CHOMP iters/sec, 7-DOF x 100-waypoint" if config in (2, 3) else (
+                "CHOMP iters/sec, 7-DOF x 100-waypoint, the robot holds a four-sphere body" if config == "held4" else
                 "CHOMP iters/sec, 7-DOF x 100-waypoint, TSR-constrained (%s)" % config if isinstance(config, str)
                 else "CHOMP iters/sec (BASELINE configs[%d])" % (config - 1)),
             "value": value,
@@ -477,6 +497,9 @@ def run_workload(config, args, rank, world, device, dist, steps, warmup, serial_
                                       "(the contract's figure); `bound` names what the counters say binds the kernel",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         # what `traffic` is made of: the run's state lives in LDS and the field in L2, so nearly all of it is the
+                         # callee-saved registers of the phase calls going to scratch and back (writes - results), not state
+                         "traffic_note": scratch_note,
                          # what the memory system really moved: counter bytes per launch / launch duration vs the peak
                          # (well above `frac`: the kernel re-reads or spills; below: the state stays on chip)
                          "hbm_measured_frac": None if not (traffic and avg_ms > 0) else traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
@@ -612,7 +635,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="", help="BASELINE configuration: 2 (default at --gpus 1), 3 (default at --gpus > 1), 4 or 5; "
                                                  "tsr1 / tsr3: config 2's runs held on a TSR by one / three hard-constraint rows "
-                                                 "on every moving point (con_tsr, SURVEY.md 8f rank 4)")
+                                                 "on every moving point (con_tsr, SURVEY.md 8f rank 4); held4: config 2's WAM holding a four-sphere box")
     ap.add_argument("--batch", type=int, default=0, help="runs per GPU (default: the configuration's own size)")
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the steps are issued on round-robin: consecutive steps are independent batches, "
@@ -676,11 +699,29 @@ def main():
         # the rest of the metric under the same clock: the batch sweep, the TSR-constrained line, the reference's stage names
         if not args.no_sweep:
             out["batch_sweep"] = batch_sweep(device, [int(b) for b in args.sweep_batches.split(",")])
-            for c in ("tsr1", "tsr3"):
+            for c in ("tsr1", "tsr3", "held4"):
                 line, rc_c = run_workload(c, args, rank, world, device, dist, args.other_steps, 2, min(args.other_steps, 3))
                 out[c] = line
                 rc = rc or rc_c
             out["stages"] = stage_breakdown(device)
+    if rank == 0 and world == 1 and out is not None:
+        # every headline number once more, compact, as the LAST key of the line (a record that keeps only the tail of the line keeps this)
+        from or_cdchomp_amd import _capi
+        r3 = lambda v: None if v is None else float("%.4g" % v)
+        summ = {"unit": "M it/s", "build": _capi.csrc_hash()}
+        key = {2: "c2", 3: "c3", 4: "c4", 5: "c5"}.get(config, str(config))
+        lines = [(key, out)] + [({4: "c4", 5: "c5"}[4 + i], l) for i, l in enumerate(out.get("other_configs") or [])]
+        lines += [(c, out[c]) for c in ("tsr1", "tsr3", "held4") if out.get(c)]
+        for k, l in lines:
+            summ[k] = r3(l["value"] / 1e6)
+            summ[k + "_serial"] = r3(None if l.get("value_serial") is None else l["value_serial"] / 1e6)
+            summ[k + "_frac"] = r3(l["roofline"]["frac"])
+            summ[k + "_parity"] = r3(l.get("parity_rel_l2_max_vs_oracle"))
+            if l.get("cpu_baseline"):
+                summ[k + "_cpu"] = r3(l["cpu_baseline"]["value"] / 1e6)
+        if out.get("batch_sweep"):
+            summ["sweep"] = {str(e["batch"]): r3(e["value"] / 1e6) for e in out["batch_sweep"]["sweep"]}
+        out["summary"] = summ
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

@@ -14,7 +14,7 @@
 
 // launch wrappers implemented in chomp_kernel.hip
 size_t orc_chomp_lds_bytes(int n_points, int n, int Sa, int S, int nj, int tile_m, int pcr_rows, size_t real_size,
-   int use_momentum, int n_sdfs, int flags);
+   int use_momentum, int n_sdfs, int flags, int pair_entries);
 hipError_t orc_launch_iterate_f64(const DevBatch<double> & b, size_t lds, hipStream_t stream, int tree);
 hipError_t orc_launch_iterate_f32(const DevBatch<float> & b, size_t lds, hipStream_t stream, int tree);
 hipError_t orc_launch_verdict_f64(const DevVerdict<double> & v, size_t lds, hipStream_t stream, int tree);
@@ -54,29 +54,16 @@ real * upload(const std::vector<double> & v, hipStream_t s)
 
 void dev_free(void * p) { if (p) (void) hipFree(p); }
 
-// Placement of the active spheres (given by XML index, sorted by joint) on the 16 lanes of a DPP
-// row.  Rotation K of the self-collision term costs its force evaluation whenever some pair of
-// spheres K lanes apart is within range in any of the four waypoints of a wavefront; pairs are
-// within range mostly for structural reasons (neighbouring links, a hand's fingers), so their
-// frequencies are estimated from fixed-seed configurations of the active dofs inside their limits
-// (the other dofs frozen where the robot has them) and a seeded annealing run looks for the
-// placement with the fewest expected evaluations.  Returns slot[k] for the k-th sphere; the
-// identity when nothing better than the sorted order is found.  The placement fixes the order in
-// which a sphere's pair forces are added up, so it must not depend on what shares the batch: it is a
-// pure function of the robot (geometry, limits, frozen dof values), the active dofs and eps_self.
-// Every pair is visited exactly once whatever the placement.
-std::vector<int> place_spheres_on_row(const Robot & robot, double eps_self, const std::vector<int> & xml)
+// how often a pair of the given spheres (XML indices) is within self-collision range: fixed-seed configurations of the active
+// dofs inside their limits, the other dofs frozen where the robot has them.  freq[a*Sa + b] for a < b; pairs of one link: 0.
+// (`next`: the caller's generator; the placement search goes on with it)
+template <typename Rng>
+void pair_range_frequencies(const Robot & robot, double eps_self, const std::vector<int> & xml, Rng & next, std::vector<double> & freq)
 {
    const int Sa = (int) xml.size();
-   std::vector<int> ident(Sa);
-   for (int s=0; s<Sa; s++) ident[s] = s;
-   if (Sa > 16) return ident;
-   unsigned long long rng = 0x9E3779B97F4A7C15ull;
-   auto next = [&rng]() { rng = rng * 6364136223846793005ull + 1442695040888963407ull; return (double)(rng >> 11) * (1.0 / 9007199254740992.0); };
-   // frequencies of "within range" per pair
    const int n_adof = (int) robot.active_dofs.size();
    const int n_samples = 384;
-   std::vector<double> freq((size_t) Sa * Sa, 0.0);
+   freq.assign((size_t) Sa * Sa, 0.0);
    std::vector<double> q = robot.dof_values;
    std::vector<Xform> frames;
    std::vector<double> pw((size_t) Sa * 3);
@@ -109,6 +96,107 @@ std::vector<int> place_spheres_on_row(const Robot & robot, double eps_self, cons
          if (d2 <= R*R) freq[(size_t) a*Sa+b] += 1.0 / n_samples;
       }
    }
+}
+
+// The dense self-collision pair list of the 32-lane kernel family (cost_pairs.h, DevModel::pr_*).  `xml`: the spheres on the
+// lanes of a waypoint's group, the n_active active ones first, then inactive ones carried on free lanes.  Every pair that can
+// count (different links, not both inactive) gets one entry; entries are handed out in the order of how often the pair is within
+// range, each to the earliest round that has a lane left (the last lane of a round never holds a pair: its force is an
+// exact zero, which the unused gather entries of a sphere point at) and in which both of its spheres still have a gather
+// entry free on the side the pair gives them (ORC_PAIR_DEG adding, ORC_PAIR_DEG subtracting): the pair is turned round
+// when that helps.  A pure function of the robot, the active dofs and eps_self (like the placement of the 16-lane rows):
+// the order in which a sphere's pair forces are added up must not depend on what shares the batch.
+// Returns the rounds in use, 0 when the list does not fit ORC_PAIR_ROUNDS.
+struct PairTable { int rounds = 0; std::vector<int> ab, gat; std::vector<double> rsum; unsigned long long deg = 0ull; int n_pairs = 0; double expected_rounds = 0.0; };
+PairTable build_pair_table(const Robot & robot, double eps_self, const std::vector<int> & xml, int n_active, int GS)
+{
+   PairTable T;
+   const int L = (int) xml.size();
+   unsigned long long rng = 0x9E3779B97F4A7C15ull;
+   auto next = [&rng]() { rng = rng * 6364136223846793005ull + 1442695040888963407ull; return (double)(rng >> 11) * (1.0 / 9007199254740992.0); };
+   std::vector<double> freq;
+   pair_range_frequencies(robot, eps_self, xml, next, freq);
+   struct Cand { int a, b; double f; };
+   std::vector<Cand> cand;
+   for (int a=0; a<L; a++) for (int b=a+1; b<L; b++)
+   {
+      if (robot.spheres[xml[a]].link == robot.spheres[xml[b]].link) continue;      // src/orcdchomp_mod.cpp:1255-1256
+      if (a >= n_active && b >= n_active) continue;                                 // two spheres that stand still
+      cand.push_back({ a, b, freq[(size_t) a*L + b] });
+   }
+   std::stable_sort(cand.begin(), cand.end(), [](const Cand & x, const Cand & y) { return x.f > y.f; });
+   const int per_round = GS - 1;
+   std::vector<int> used(ORC_PAIR_ROUNDS, 0);
+   std::vector<int> plus((size_t) ORC_PAIR_ROUNDS * GS, 0), minus((size_t) ORC_PAIR_ROUNDS * GS, 0);
+   T.ab.assign((size_t) ORC_PAIR_ROUNDS * 32, 0); T.gat.assign((size_t) ORC_PAIR_ROUNDS * 32, 0); T.rsum.assign((size_t) ORC_PAIR_ROUNDS * 32, 0.0);
+   // gather entries: bytes 0,1 adding, bytes 2,3 subtracting; all of them start at the round's last lane
+   for (size_t e=0; e<T.gat.size(); e++) { const int z = (GS - 1) * 4; T.gat[e] = z | (z << 8) | (z << 16) | (z << 24); }
+   std::vector<double> none(ORC_PAIR_ROUNDS, 1.0);      // probability that no pair of the round is within range (two waypoints per wavefront: squared below)
+   for (const Cand & c : cand)
+   {
+      int r = 0, first = c.a, second = c.b;
+      for (; r<ORC_PAIR_ROUNDS; r++)
+      {
+         if (used[r] >= per_round) continue;
+         const bool fwd = plus[(size_t) r*GS + c.a] < ORC_PAIR_DEG && minus[(size_t) r*GS + c.b] < ORC_PAIR_DEG;
+         const bool rev = plus[(size_t) r*GS + c.b] < ORC_PAIR_DEG && minus[(size_t) r*GS + c.a] < ORC_PAIR_DEG;
+         if (!fwd && !rev) continue;
+         // the orientation that leaves the spheres' sides more evenly used
+         const int load_f = plus[(size_t) r*GS + c.a] + minus[(size_t) r*GS + c.b], load_r = plus[(size_t) r*GS + c.b] + minus[(size_t) r*GS + c.a];
+         if (!fwd || (rev && load_r < load_f)) { first = c.b; second = c.a; }
+         break;
+      }
+      if (r == ORC_PAIR_ROUNDS) return PairTable();
+      const int k = used[r]++;
+      const size_t e = (size_t) r*32 + k;
+      T.ab[e] = first | (second << 8);
+      T.rsum[e] = robot.spheres[xml[first]].radius + robot.spheres[xml[second]].radius;
+      int & gp = T.gat[(size_t) r*32 + first];  const int np_ = plus[(size_t) r*GS + first]++;
+      gp = (gp & ~(0xff << (8*np_))) | ((k*4) << (8*np_));
+      int & gm = T.gat[(size_t) r*32 + second]; const int nm_ = minus[(size_t) r*GS + second]++;
+      gm = (gm & ~(0xff << (8*(2 + nm_)))) | ((k*4) << (8*(2 + nm_)));
+      none[r] *= (1.0 - c.f);
+      if (r + 1 > T.rounds) T.rounds = r + 1;
+      T.n_pairs++;
+   }
+   for (int r=0; r<T.rounds; r++)
+   {
+      int dp = 0, dm = 0;
+      for (int q=0; q<GS; q++) { dp = std::max(dp, plus[(size_t) r*GS + q]); dm = std::max(dm, minus[(size_t) r*GS + q]); }
+      T.deg |= (unsigned long long)(dp | (dm << 2)) << (4*r);
+      T.expected_rounds += 1.0 - std::pow(none[r], 64 / GS);
+   }
+   if (getenv("ORC_DEBUG_PLAN"))
+   {
+      fprintf(stderr, "orc pair list: %d pairs of %d lanes in %d rounds of %d; expected force evaluations per wavefront pass %.2f; pairs per round", T.n_pairs, L, T.rounds, per_round, T.expected_rounds);
+      for (int r=0; r<T.rounds; r++) fprintf(stderr, " %d", used[r]);
+      fprintf(stderr, "\n");
+   }
+   return T;
+}
+
+// Placement of the active spheres (given by XML index, sorted by joint) on the 16 lanes of a DPP
+// row.  Rotation K of the self-collision term costs its force evaluation whenever some pair of
+// spheres K lanes apart is within range in any of the four waypoints of a wavefront; pairs are
+// within range mostly for structural reasons (neighbouring links, a hand's fingers), so their
+// frequencies are estimated from fixed-seed configurations of the active dofs inside their limits
+// (the other dofs frozen where the robot has them) and a seeded annealing run looks for the
+// placement with the fewest expected evaluations.  Returns slot[k] for the k-th sphere; the
+// identity when nothing better than the sorted order is found.  The placement fixes the order in
+// which a sphere's pair forces are added up, so it must not depend on what shares the batch: it is a
+// pure function of the robot (geometry, limits, frozen dof values), the active dofs and eps_self.
+// Every pair is visited exactly once whatever the placement.
+std::vector<int> place_spheres_on_row(const Robot & robot, double eps_self, const std::vector<int> & xml)
+{
+   const int Sa = (int) xml.size();
+   std::vector<int> ident(Sa);
+   for (int s=0; s<Sa; s++) ident[s] = s;
+   if (Sa > 16) return ident;
+   unsigned long long rng = 0x9E3779B97F4A7C15ull;
+   auto next = [&rng]() { rng = rng * 6364136223846793005ull + 1442695040888963407ull; return (double)(rng >> 11) * (1.0 / 9007199254740992.0); };
+   // frequencies of "within range" per pair
+   std::vector<double> freq;
+   pair_range_frequencies(robot, eps_self, xml, next, freq);
    struct Pair { int a, b; double keep; };      // keep = probability that none of 4 waypoints has the pair in range
    std::vector<Pair> pairs;
    for (int a=0; a<Sa; a++) for (int b=a+1; b<Sa; b++)
@@ -564,6 +652,21 @@ void BatchShard::build_device(const Robot & robot)
    int n_static = 0;
    if (M.GS == 16 && Sa >= 4 && M.jt_scan != 0 && !getenv("ORC_NO_PLACEMENT") && !getenv("ORC_NO_STATIC_LANES"))
       n_static = std::min((int) inact.size(), 16 - Sa);
+   // 17 .. 32 active spheres on a chain, fp64 (the robot that holds something): the 32-lane family with the dense
+   // self-collision pair list (cost_pairs.h).  The spheres keep their sorted order; inactive ones ride on the free lanes.
+   bool pairs = false;
+   PairTable ptab;
+   const int asked_block = mod_->workgroup_threads ? mod_->workgroup_threads : params.workgroup_threads;
+   if (sizeof(real) == 8 && M.GS == 32 && !M.tree && M.jt_scan == 1 && !params.free_start && (asked_block == 0 || asked_block == 256 || asked_block == 512)
+       && !getenv("ORC_NO_PAIRS") && !getenv("ORC_NO_KIND") && !getenv("ORC_BLOCK_THREADS"))
+   {
+      const int ns = getenv("ORC_NO_STATIC_LANES") ? 0 : std::min((int) inact.size(), M.GS - Sa);
+      std::vector<int> xml_of(Sa + ns);
+      for (int s=0; s<Sa; s++) xml_of[s] = act[s].xml;
+      for (int s=0; s<ns; s++) xml_of[Sa + s] = inact[s].xml;
+      ptab = build_pair_table(robot, params.epsilon_self, xml_of, Sa, M.GS);
+      if (ptab.rounds > 0) { pairs = true; n_static = ns; }
+   }
    std::vector<int> slot_of(Sa + n_static);
    for (int s=0; s<Sa+n_static; s++) slot_of[s] = s;
    int lanes = Sa;
@@ -613,7 +716,8 @@ void BatchShard::build_device(const Robot & robot)
          M.live_mask |= (1ull << q);
       }
    }
-   if (!is_placed) n_static = 0;
+   if (pairs) lanes = Sa + n_static;
+   if (!is_placed && !pairs) n_static = 0;
    if (is_placed)
    {
       // entries past the active spheres: the slots without an active sphere, in order (static or empty: their wrench is zero)
@@ -647,6 +751,9 @@ void BatchShard::build_device(const Robot & robot)
       }
       device_sphere_order.push_back(inact[s].xml);
    }
+   M.pr_rounds = pairs ? ptab.rounds : 0;
+   if (pairs)
+      for (size_t e=0; e<(size_t) ORC_PAIR_ROUNDS * 32; e++) { M.pr_ab[e] = ptab.ab[e]; M.pr_gat[e] = ptab.gat[e]; M.pr_rsum[e] = (real) ptab.rsum[e]; }
    // the FK walk's records (DevFkJoint): fixed transform, axis, control word and the first four spheres of the link
    for (int k=0; k<nj; k++)
    {
@@ -690,8 +797,10 @@ void BatchShard::build_device(const Robot & robot)
    nj_ = nj; Sa_ = lanes; S_ = lanes + (int) inact.size() - n_static; GS_ = M.GS; tree_ = M.tree | ((M.GS == 16) ? 2 : 0);     // kernel variant bits
    if (M.GS == 16 && !M.tree && M.jt_scan == 1 && M.placed && nj <= 16 && !getenv("ORC_NO_KIND"))
       tree_ |= 16 | (M.floating ? 64 : 0);      // the variants that know all this at compile time (chomp_kernel.hip phase_cost KIND)
-   if (M.GS != 16 && !M.floating && M.jt_scan == (M.tree ? 2 : 1) && !getenv("ORC_NO_KIND"))
+   if (M.GS != 16 && !M.floating && M.jt_scan == (M.tree ? 2 : 1) && !getenv("ORC_NO_KIND") && !pairs)
       tree_ |= 16;                              // many-sphere path: the J^T form is known
+   if (pairs) tree_ |= 512 | (M.floating ? 64 : 0);      // the 32-lane family with the dense pair list
+   pair_entries_ = pairs ? ptab.rounds * 32 : 0;
 
    hipStream_t st = stream_;
    // TSR hard constraints, folded onto the device's joint order (csrc/tsr.h)
@@ -760,7 +869,7 @@ void BatchShard::build_device(const Robot & robot)
    ms_.nj = M.nj; ms_.floating = M.floating; ms_.tree = M.tree; ms_.Sa = M.Sa; ms_.S = M.S; ms_.Sa_real = M.Sa_real; ms_.placed = M.placed;
    ms_.GS = M.GS; ms_.base_sph_begin = M.base_sph_begin; ms_.base_sph_end = M.base_sph_end; ms_.jt_scan = M.jt_scan; ms_.n_static = M.n_static;
    ms_.live_mask = M.live_mask; ms_.static_mask = M.static_mask;
-   ms_.fk_split = M.fk_split; ms_.fk_nanc = M.fk_nanc; ms_.fk_b_begin = M.fk_b_begin; ms_.pad_ = 0;
+   ms_.fk_split = M.fk_split; ms_.fk_nanc = M.fk_nanc; ms_.fk_b_begin = M.fk_b_begin; ms_.pr_rounds = M.pr_rounds; ms_.pr_deg = pairs ? ptab.deg : 0ull;
    if (getenv("ORC_DEBUG_PLAN") && M.fk_split)
       fprintf(stderr, "orc fk: the walk is cut in two: joints [0, %d) | chain [0, %d) + joints [%d, %d)\n", M.fk_b_begin, M.fk_nanc, M.fk_b_begin, nj);
    DevModel<real> * dm = dev_alloc<DevModel<real>>(1);
@@ -838,7 +947,7 @@ void BatchShard::build_device(const Robot & robot)
       hc[i].data = hs[i].data;
       if (nc * sizeof(real) >= (size_t) 1 << 31) throw std::runtime_error("signed distance field too large for this build!");
       // the many-sphere pass forms its cell offsets with 24-bit multiplies (cost_generic.h: signed, both operands below 2^23)
-      if (GS_ != 16 && (hc[i].stride_b[0] >= (1 << 23) || std::max(s.grid.sizes[0], std::max(s.grid.sizes[1], s.grid.sizes[2])) >= (1 << 23)))
+      if (GS_ != 16 && !(tree_ & 512) && (hc[i].stride_b[0] >= (1 << 23) || std::max(s.grid.sizes[0], std::max(s.grid.sizes[1], s.grid.sizes[2])) >= (1 << 23)))
          throw std::runtime_error("signed distance field too large for this build (a y-z plane of 8 MB or more with a robot of more than 16 active spheres)!");
    }
    DevSdfCell<real> * dc = dev_alloc<DevSdfCell<real>>(hc.size());
@@ -847,7 +956,7 @@ void BatchShard::build_device(const Robot & robot)
    DevSdf<real> * ds = dev_alloc<DevSdf<real>>(n_sdfs_);
    hip_check(hipMemcpy(ds, hs.data(), hs.size()*sizeof(DevSdf<real>), hipMemcpyHostToDevice), "sdfs");
    d_sdfs_ = ds;
-   if ((tree_ & 16) && n_sdfs_ == 1 && hs[0].rot_identity) tree_ |= 32 | ((S_ == Sa_) ? 128 : 0);      // one field with the world's axes: known at compile time (phase_cost KIND)
+   if ((tree_ & (16 | 512)) && n_sdfs_ == 1 && hs[0].rot_identity) tree_ |= 32 | ((S_ == Sa_) ? 128 : 0);      // one field with the world's axes: known at compile time (phase_cost KIND)
 
    // metric tables
    d_Aband_ = upload<real>(metric_.Aband, st);
@@ -931,7 +1040,7 @@ void BatchShard::build_device(const Robot & robot)
    const bool relax = (pass == 2);
    max_wgs = relax ? max_wgs_budget : max_wgs_default; force_block = force_block_asked;
    if (relax) { force_t = 0; force_pcr = -1; force_ag = -1; }
-   budget4 = (pass == 0) && (want_wgs == 4) && sizeof(real) == 8 && (tree_ & 16) && (tree_ & 2) && (!(tree_ & 64) || (tree_ & 160) == 160) && (force_block == 0 || force_block == 256)
+   budget4 = (pass == 0) && (want_wgs == 4) && sizeof(real) == 8 && (((tree_ & 16) && (tree_ & 2) && (!(tree_ & 64) || (tree_ & 160) == 160)) || (tree_ & 512)) && (force_block == 0 || force_block == 256)
                         && !getenv("ORC_BLOCK_THREADS") && !getenv("ORC_WGS") && !getenv("ORC_TILE_M");      // (the experiments' switches come first)
    if (budget4) { max_wgs = 4; force_block = 256; }
    if (const char * e = getenv("ORC_BLOCK_THREADS")) if (!relax) force_block = atoi(e);
@@ -947,7 +1056,7 @@ void BatchShard::build_device(const Robot & robot)
    struct Shape { int block, wgs; };
    std::vector<Shape> shapes;
    for (int wgs=max_wgs; wgs>=(budget4 ? 4 : 1); wgs--) shapes.push_back({ 256, wgs });
-   if (max_wgs >= 3) shapes.push_back({ 192, 4 });
+   if (max_wgs >= 3 && !(tree_ & 512)) shapes.push_back({ 192, 4 });      // (the pair-list family is built for 256-thread workgroups)
    // a caller that asked for the 192-thread shape gets it for runs that do not fit four to a CU as well
    if (force_block == 192) for (int wgs=3; wgs>=1; wgs--) shapes.push_back({ 192, wgs });
    // the latency shape: eight wavefronts on one run, one run per CU (a lone wavefront issues a vector
@@ -982,12 +1091,12 @@ void BatchShard::build_device(const Robot & robot)
             {
                if (force_t > 0 && t != (force_t < m ? force_t : m)) continue;
                size_t need = orc_chomp_lds_bytes(m + 2, n, Sa_, S_, nj, t, with_pcr ? pcr_rows : 0, sizeof(real),
-                                                 params.use_momentum && ag_lds, n_sdfs_, flags);
+                                                 params.use_momentum && ag_lds, n_sdfs_, flags, pair_entries_);
                if (need > budget && (flags & ORC_LDS_T_STAGED))
                {
                   // (tiles too small to hold the copy: the trajectory is iterated in place through L2)
                   const size_t plain = orc_chomp_lds_bytes(m + 2, n, Sa_, S_, nj, t, with_pcr ? pcr_rows : 0, sizeof(real),
-                                                           params.use_momentum && ag_lds, n_sdfs_, flags & ~ORC_LDS_T_STAGED);
+                                                           params.use_momentum && ag_lds, n_sdfs_, flags & ~ORC_LDS_T_STAGED, pair_entries_);
                   if (plain <= budget) { need = plain; flags &= ~ORC_LDS_T_STAGED; }
                }
                if (need > budget) continue;
@@ -997,7 +1106,7 @@ void BatchShard::build_device(const Robot & robot)
                const double rounds = tiles * std::ceil(t * (double) lanes_per_wp / block);
                // measured: an FK pass costs ~1.7k cycles per joint, a round of the 16-lane cost phase ~11k,
                // of the generic one ~350 per active sphere (WAM / 30-dof tree, scripts/phase_profile*.py)
-               const double fk_pass = 1.7e3 * nj, round_cycles = (GS_ == 16) ? 11e3 : 350.0 * Sa_;
+               const double fk_pass = 1.7e3 * nj, round_cycles = (GS_ == 16) ? 11e3 : ((tree_ & 512) ? 9e3 : 350.0 * Sa_);
                const double cycles = fk_pass * fk_passes + round_cycles * rounds + 30e3 * (256.0 / block) + (with_pcr ? 0.0 : 1e3) + (ag_lds ? 0.0 : 2e3)
                                    + (g_lds ? 0.0 : 2e3) + (t_lds ? 0.0 : ((flags & ORC_LDS_T_STAGED) ? 4e3 : 12e3));
                const double waves_per_simd = wgs * block / 256.0;
@@ -1269,7 +1378,7 @@ void BatchShard::launch(int n_iter, bool final_eval, bool carry)
    b.g_in_lds = g_in_lds_; b.lds_flags = lds_flags_; b.t_in_lds = t_in_lds_; b.t_staged = (lds_flags_ & ORC_LDS_T_STAGED) ? 1 : 0;
    b.ms = ms_;
    b.lay = lds_layout(m + 2, n, Sa_, S_, nj_, tile_m_, pcr_in_lds_ ? pcr_rows_ : 0, (int) sizeof(real),
-                      params.use_momentum && ag_in_lds_, n_sdfs_, (int) sizeof(DevSdf<real>), lds_flags_);
+                      params.use_momentum && ag_in_lds_, n_sdfs_, (int) sizeof(DevSdf<real>), lds_flags_, pair_entries_);
    b.costs = d_costs_; b.trace = d_trace_; b.status = d_status_; b.iters_done = d_iters_done_; b.leapfrog_first = d_leap_;
    const double dt = 1.0/(n_points-1);
    b.dt = (real) dt;

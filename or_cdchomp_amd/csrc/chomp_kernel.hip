@@ -889,6 +889,7 @@ __device__ __forceinline__ real smooth_grad(const BT & b, const real * T_s, int 
 #endif
 
 #include "cost_gs16.h"
+#include "cost_pairs.h"
 #include "self_mfma.h"
 #include "cost_generic.h"
 #include "fk.h"
@@ -923,6 +924,7 @@ struct Env
    real * T_u;                             // the trajectory as the update phase and the cost sums see it: T_s, or its staged copy (DevBatch::t_staged)
    int * slink_s, * jtype_s, * jcol_s, * slot_s;
    int * jctl_s; DevSdf<real> * sdfs_s; unsigned long long * saff_s, * sallow_s;
+   real * prs_s; int * pab_s, * pgat_s;    // the staged self-collision pair list (cost_pairs.h): rsum, first | second << 8, gather entries; [pr_rounds][32]
    real * traj_g, * AG_g, * AG_s;
    const real * pcr_tab;
    int pstr, astr;
@@ -969,6 +971,9 @@ __device__ __forceinline__ Env<real> make_env(const BT & b, unsigned char * smem
    E.sdfs_s = (DevSdf<real> *)(smem_raw + L.sdfs_bytes);
    E.saff_s = (unsigned long long *)(smem_raw + L.saff_bytes);
    E.sallow_s = (unsigned long long *)(smem_raw + L.sallow_bytes);
+   E.prs_s = (real *)(smem_raw + L.ptab_bytes);
+   E.pab_s = (int *)(E.prs_s + b.ms.pr_rounds * 32);
+   E.pgat_s = E.pab_s + b.ms.pr_rounds * 32;
    ModelView<real> & mod = E.mod;
    mod.nj = nj; mod.n = n; mod.floating = b.ms.floating; mod.tree = b.ms.tree; mod.Sa = Sa; mod.S = S; mod.GS = b.ms.GS; mod.jt_scan = b.ms.jt_scan;
    mod.Sa_real = b.ms.Sa_real; mod.placed = b.ms.placed; mod.live_mask = b.ms.live_mask; mod.slot_of = E.slot_s;
@@ -1052,6 +1057,8 @@ __device__ __attribute__((noinline)) void phase_setup(const void * kp)
    if (tid < b.n_sdfs) E.sdfs_s[tid].data = E.pos_s;
 #endif
    for (int e=tid; e<n; e+=BLOCK) { E.jl_s[e] = b.jl_lo[e]; E.jl_s[n+e] = b.jl_hi[e]; }
+   if (!GS16)
+      for (int e=tid; e<b.ms.pr_rounds*32; e+=BLOCK) { E.prs_s[e] = gmod.pr_rsum[e]; E.pab_s[e] = gmod.pr_ab[e]; E.pgat_s[e] = gmod.pr_gat[e]; }
    if (b.pcr_in_lds)
       for (int e=tid; e<b.pcr_rows*m; e+=BLOCK) E.pcr_s[e] = b.pcr[e];
    if (b.use_momentum && b.ag_in_lds) for (int e=tid; e<mn; e+=BLOCK) E.AG_s[e] = E.AG_g[e];
@@ -1212,6 +1219,14 @@ __device__ __forceinline__ double phase_cost_body(const void * kp, int ts_in, in
    if constexpr (GS16)
       cost_tile_gs16<real, ORC_U, BLOCK, KArg<real>, false, (KIND & 2) != 0, (KIND & 1) != 0, (KIND & 8) != 0>(b, E.mod, E.sdfs_s, ts, te, do_iteration, E.T_s, E.Gc, E.pos_s, E.ax_s, E.srad_s, E.sinact_s, E.r2_s,
                                          E.slink_s, E.jtype_s, E.jcol_s, inv_eps, inv_eps_self, cost_lane);
+   else if constexpr ((KIND & 16) != 0)
+   {
+      // 17 .. 32 active spheres on a chain: the dense pair list (KIND 16; 16 | 2 | 8: one field with the world's axes, a fixed
+      // base, no inactive sphere left for the loop over them)
+      if constexpr ((KIND & 2) != 0) E.mod.floating = 0;
+      cost_tile_pairs<real, BLOCK, KArg<real>, (KIND & 2) != 0, (KIND & 8) != 0>(b, E.mod, ts, te, do_iteration, E.T_s, E.Gc, E.pos_s, E.ax_s, E.srad_s, E.sinact_s,
+                                         E.slink_s, E.prs_s, E.pab_s, E.pgat_s, inv_eps, inv_eps_self, cost_lane);
+   }
    else
    {
 #ifdef ORC_COST_TIMERS
@@ -1224,9 +1239,12 @@ __device__ __forceinline__ double phase_cost_body(const void * kp, int ts_in, in
    }
    __syncthreads();
 #ifdef ORC_COST_TIMERS
-   if constexpr (!GS16) if (threadIdx.x == 0 && blockIdx.x == 0 && ts > 0 && !do_iteration && te == b.m)
+   if constexpr (!GS16 && (KIND & 16) == 0) if (threadIdx.x == 0 && blockIdx.x == 0 && ts > 0 && !do_iteration && te == b.m)
       printf("generic cost sections (cycles of wavefront 0 of run 0, whole launch): obstacle %lld inactive+pass1 %lld pass2 %lld jt %lld | pass-2 trips %lld fields used %lld wave passes %lld\n",
              orc_cost_dbg[0], orc_cost_dbg[1], orc_cost_dbg[2], orc_cost_dbg[3], orc_cost_dbg[4], orc_cost_dbg[5], orc_cost_dbg[6]);
+   if constexpr (!GS16 && (KIND & 16) != 0) if (threadIdx.x == 0 && blockIdx.x == 0 && ts > 0 && !do_iteration && te == b.m)
+      printf("pair-list cost sections (cycles of wavefront 0 of run 0, whole launch): setup %lld obstacle %lld self %lld jt %lld between %lld\n",
+             orc_cost_dbg[0], orc_cost_dbg[1], orc_cost_dbg[2], orc_cost_dbg[3], orc_cost_dbg[4]);
    if constexpr (GS16) if (threadIdx.x == 0 && blockIdx.x == 0 && ts > 0 && !do_iteration)
       printf("cost sections (cycles of wavefront 0, whole launch): setup %lld obstacle %lld self %lld jt %lld between %lld\n",
              orc_cost_dbg[0], orc_cost_dbg[1], orc_cost_dbg[2], orc_cost_dbg[3], orc_cost_dbg[4]);
@@ -1903,10 +1921,10 @@ void collision_verdict_kernel(DevVerdict<real> v)
 // ---------------------------------------------------------------------------
 // host-side launch wrappers (called from module.cpp)
 size_t orc_chomp_lds_bytes(int n_points, int n, int Sa, int S, int nj, int tile_m, int pcr_rows, size_t real_size,
-   int use_momentum, int n_sdfs, int flags)
+   int use_momentum, int n_sdfs, int flags, int pair_entries)
 {
    const int ss = real_size == 8 ? (int) sizeof(DevSdf<double>) : (int) sizeof(DevSdf<float>);
-   return (size_t) lds_layout(n_points, n, Sa, S, nj, tile_m, pcr_rows, (int) real_size, use_momentum, n_sdfs, ss, flags).total_bytes;
+   return (size_t) lds_layout(n_points, n, Sa, S, nj, tile_m, pcr_rows, (int) real_size, use_momentum, n_sdfs, ss, flags, pair_entries).total_bytes;
 }
 
 template <typename real, bool TREE, bool GS16, int BLOCK, int KIND = 0, int WGS = 0>
@@ -1945,10 +1963,14 @@ static hipError_t launch_iterate_t(const DevBatch<real> & b, size_t lds, hipStre
 #endif
    if constexpr (sizeof(real) == 8)
    {
+#if ORC_FAST_BUILD == 6      // -DORC_FAST_BUILD=6: the WAM that holds a box (the dense pair list, one aligned field) at both budgets
+      if ((variant & 512) && (variant & 32) && (variant & 128) && !(variant & 64))
+         return (variant & 256) ? launch_iterate_tt<real, false, false, 256, 26, 4>(b, lds, stream) : launch_iterate_tt<real, false, false, 256, 26>(b, lds, stream);
+#endif
       const int kind = 1 | ((variant & 32) ? 2 : 0) | ((variant & 64) ? 4 : 0) | (((variant & 160) == 160) ? 8 : 0);
       if ((variant & (16 | 2 | 1)) == (16 | 2))
       {
-#if ORC_FAST_BUILD == 5
+#if ORC_FAST_BUILD == 5 || ORC_FAST_BUILD == 6
 #elif ORC_FAST_BUILD == 4      // -DORC_FAST_BUILD=4: BASELINE configs[3] (floating base, KIND 15) at the default shape and at four workgroups per CU
          if (kind == 15 && (variant & 256) && !(variant & (4 | 8))) return launch_iterate_tt<real, false, true, 256, 15, 4>(b, lds, stream);
          if (kind == 15 && !(variant & (4 | 8))) return launch_iterate_tt<real, false, true, 256, 15>(b, lds, stream);
@@ -1961,6 +1983,18 @@ static hipError_t launch_iterate_t(const DevBatch<real> & b, size_t lds, hipStre
    }
    return hipErrorInvalidValue;
 #else
+   if (variant & 512)      // 17 .. 32 active spheres on a chain, fp64: the dense pair list (cost_pairs.h; phase_cost KIND 16)
+   {
+      if constexpr (sizeof(real) == 8)
+      {
+         const bool lean = (variant & 32) && (variant & 128) && !(variant & 64);      // one aligned field, no inactive sphere left, fixed base
+         if (variant & 4) return hipErrorInvalidValue;      // (no 192-thread shape: batch.cpp keeps such a module on the many-sphere family)
+         if (variant & 8) return lean ? launch_iterate_tt<real, false, false, 512, 26>(b, lds, stream) : launch_iterate_tt<real, false, false, 512, 16>(b, lds, stream);
+         if (variant & 256) return lean ? launch_iterate_tt<real, false, false, 256, 26, 4>(b, lds, stream) : launch_iterate_tt<real, false, false, 256, 16, 4>(b, lds, stream);
+         return lean ? launch_iterate_tt<real, false, false, 256, 26>(b, lds, stream) : launch_iterate_tt<real, false, false, 256, 16>(b, lds, stream);
+      }
+      return hipErrorInvalidValue;
+   }
    if ((variant & 16) && !(variant & 2))      // the many-sphere path with its J^T form known (phase_cost KIND 1)
    {
       if (variant & 1)

@@ -23,6 +23,8 @@
 #define ORC_LDS_HEADER    256     // bytes in front of the LDS carve-up: reduction scratch [16] doubles, [8] ints, column masks, timer mark, phase counters [8]
 #define ORC_LIM_LIST      64      // violated entries the sparse joint-limit rounds handle
 #define ORC_LIM_SCRATCH  (256 + ORC_LIM_LIST*16)   // bytes: 4 wave records + header, entry list
+#define ORC_PAIR_ROUNDS   16      // rounds of the dense self-collision pair list at most (cost_pairs.h): 16 x 32 lanes hold every pair of 32 spheres
+#define ORC_PAIR_DEG      2       // pairs of one round that add to (and that subtract from) one sphere at most
 
 // one optimized joint, in topological order.  Non-optimized joints are folded
 // into the fixed transforms on the host when the batch is created.
@@ -97,6 +99,15 @@ struct DevModel
    // A robot that is a chain [0, fk_nanc) which then branches: the branches from joint fk_b_begin on can be walked by
    // another wavefront (which walks the chain as well, without storing): two walks of about half the length
    int fk_split, fk_nanc, fk_b_begin;
+   // The dense self-collision pair list of the 32-lane family (cost_pairs.h; built at create: batch.cpp build_pair_table).
+   // Every pair of lanes that can ever count (spheres on different links, at least one of them active) has ONE entry;
+   // round r, lane k of a waypoint's lane group evaluates entry r*GS + k for that waypoint: the net force of the pair
+   // on its FIRST sphere (the second receives the opposite).  Entries are in the order of how often the pair is within
+   // range (fixed-seed configurations of the robot), so the rounds that are nearly always needed come first and are full.
+   int pr_rounds;                                   // rounds in use (0: the robot does not use the list)
+   int pr_ab[ORC_PAIR_ROUNDS*32];                   // first lane | second lane << 8; first == second: no pair
+   int pr_gat[ORC_PAIR_ROUNDS*32];                  // for lane s as a SPHERE in round r: the pair lanes (x4: ds_bpermute addresses within the group) whose force it adds (bytes 0, 1) and subtracts (bytes 2, 3); unused: the round's last lane, which never holds a pair
+   real pr_rsum[ORC_PAIR_ROUNDS*32];                // r_first + r_second
 };
 
 // a rooted signed distance field (struct run_rsdf + struct cd_grid)
@@ -159,8 +170,9 @@ struct DevTsr
 struct ModelScalars
 {
    int nj, floating, tree, Sa, S, Sa_real, placed, GS, base_sph_begin, base_sph_end, jt_scan, n_static;
-   int fk_split, fk_nanc, fk_b_begin, pad_;
+   int fk_split, fk_nanc, fk_b_begin, pr_rounds;
    unsigned long long live_mask, static_mask;
+   unsigned long long pr_deg;     // 4 bits per round of the pair list: gather entries in use on the adding side (bits 0-1) and on the subtracting side (bits 2-3)
 };
 struct LdsLayout
 {
@@ -173,6 +185,7 @@ struct LdsLayout
    int sdfs_bytes;         // byte offset of the staged DevSdf[n_sdfs]
    int saff_bytes;         // byte offset of the staged affects masks [Sa]
    int sallow_bytes;       // byte offset of the self-collision partner masks [64] (robots with more than 16 active spheres)
+   int ptab_bytes;         // byte offset of the staged pair list: rsum [entries] reals, then ab [entries], gat [entries] ints (cost_pairs.h)
    int total_bytes;
 };
 
@@ -319,7 +332,7 @@ __host__ __device__
 #define ORC_LDS_T_GLOBAL   4      // the trajectory stays in global memory between the phases (FK reads it there): the LDS then holds larger tiles
 #define ORC_LDS_T_STAGED   8      // (with T_GLOBAL) the update phase and the cost sums work on a copy staged in the then dead tile buffers and write it back
 inline LdsLayout lds_layout(int np, int n, int Sa, int S, int nj, int tile_m, int pcr_rows, int real_size,
-   int use_ag, int n_sdfs, int sdf_size, int flags)
+   int use_ag, int n_sdfs, int sdf_size, int flags, int pair_entries = 0)
 {
    const int m = np - 2, mn = m*n;
    LdsLayout L;
@@ -359,6 +372,8 @@ inline LdsLayout lds_layout(int np, int n, int Sa, int S, int nj, int tile_m, in
    L.sdfs_bytes = bytes;   bytes += n_sdfs * sdf_size; bytes = (bytes + 15) & ~15;
    L.saff_bytes = bytes;   bytes += Sa * 8;
    L.sallow_bytes = bytes; bytes += (Sa > 16) ? 64 * 8 : 0;
+   bytes = (bytes + 15) & ~15;
+   L.ptab_bytes = bytes;   bytes += pair_entries * (real_size + 8);
    if (alias) L.lim_bytes = ORC_LDS_HEADER + (L.pos + work_reals) * real_size;
    else { L.lim_bytes = bytes; bytes += ORC_LIM_SCRATCH; }
    L.total_bytes = ((g_global || t_staged) && !alias) ? (1 << 30) : bytes;      // G (and the staged trajectory) in the tile buffers need tiles that hold them

@@ -206,6 +206,7 @@ private:
    int block_ = 256;                  // threads per workgroup of the iterate kernel (256 or 192)
    int pcr_in_lds_ = 0;
    int tree_ = 0;
+   int pair_entries_ = 0;             // entries of the staged self-collision pair list (rounds x 32; 0: the kernel family does not use one)
    int pcr_rows_ = 0, pcr_sym_ = 0, solve_mode_ = 0, ag_in_lds_ = 1, g_in_lds_ = 1, t_in_lds_ = 1, lds_flags_ = 0, GS_ = 0;
    size_t lds_bytes_ = 0;
    std::vector<double> jl_lo_, jl_hi_;

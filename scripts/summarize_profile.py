@@ -15,7 +15,7 @@ import sys
 
 tag, name = sys.argv[1], sys.argv[2]          # e.g.  a  r02_config2
 config = (int(sys.argv[3]) if sys.argv[3].isdigit() else sys.argv[3]) if len(sys.argv) > 3 else 2      # 2, 4, 5, tsr1, tsr3
-batch = int(sys.argv[4]) if len(sys.argv) > 4 else {2: 1024, 4: 4096, 5: 4096, "tsr1": 1024, "tsr3": 1024}[config]
+batch = int(sys.argv[4]) if len(sys.argv) > 4 else {2: 1024, 4: 4096, 5: 4096, "tsr1": 1024, "tsr3": 1024, "held4": 1024}[config]
 n_iter = int(sys.argv[5]) if len(sys.argv) > 5 else 100
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
@@ -69,6 +69,14 @@ if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
     write = c["WRITE_SIZE"]["mean_per_launch"] * 1024
     summary["hbm_bytes_per_launch"] = fetch + write
     entry.update(hbm_bytes_per_launch=fetch + write, fetch_bytes_corrected=fetch, write_bytes=write)
+    # what the bytes are: the results of a launch (trajectories, momentum, costs, trace) are a few MB; everything a launch WRITES
+    # beyond them is register state going to scratch around the phase calls (callee-saved registers, spills), and most of what it
+    # reads is the same bytes coming back
+    results = {2: 8.0 * 1024 * (100 * 7 + 98 * 7 + 3 * 100 + 8), "held4": 8.0 * 1024 * (100 * 7 + 98 * 7 + 3 * 100 + 8)}.get(config)
+    entry["traffic_note"] = ("of the %.2f GB per launch %.2f GB are writes against ~%s of results: scratch traffic of the phase calls' callee-saved "
+                             "registers and spills (and its way back), not the run's state, which stays in LDS; the field sits in L2"
+                             % ((fetch + write) / 1e9, write / 1e9, ("%.0f MB" % (results / 1e6)) if results else "a few MB to tens of MB"))
+    summary["traffic_note"] = entry["traffic_note"]
 if "SQ_INSTS_VALU" in c:
     # the final cost-only pass of a launch is charged to its n_iter iterations
     entry["valu_insts_per_run_iteration"] = c["SQ_INSTS_VALU"]["mean_per_launch"] / (batch * n_iter)

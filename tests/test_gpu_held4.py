@@ -1,0 +1,161 @@
+"""-m gpu: the WAM of BASELINE configs[1] HOLDING a four-sphere box, at the configuration's full size (1024 runs, 100 waypoints,
+100 iterations): the 32-lane kernel family with the dense self-collision pair list (csrc/cost_pairs.h; reference
+src/orcdchomp_mod.cpp:2168-2300 for the held body's spheres, 1134-1327 for the cost).
+
+At this size the oracle runs a sample (16 runs: 1e-6 relative L2, north_star) and the rest are properties the domain offers: a run
+does not depend on what shares its batch, two calls are one, the costs are the costs of the returned trajectory, the register
+budgets and workgroup shapes the family is built for give the same trajectories bit for bit."""
+import numpy as np
+import pytest
+
+import common
+import or_cdchomp_amd
+
+pytestmark = pytest.mark.gpu
+
+KW = dict(common.CONFIG2_KW)
+N_RUNS = 1024
+
+
+@pytest.fixture(scope="module")
+def held():
+    mod = or_cdchomp_amd.Module(0)
+    model, hand, pose = common.setup_product_wam_held4(mod)
+    goals = common.wam_goals(N_RUNS, seed=20250101)
+    bid = mod.batch_create(model.name, goals, **KW)
+    costs, status = mod.batch_iterate(bid, 100)
+    traj = mod.batch_gettraj(bid)
+    dims = mod.batch_dims(bid)
+    mod.batch_destroy(bid)
+    yield dict(mod=mod, model=model, hand=hand, pose=pose, goals=goals, costs=costs, status=status, traj=traj, dims=dims)
+    mod.close()
+
+
+def test_sample_matches_the_oracle(held, oracle):
+    """16 of the 1024 runs against the oracle (the held body through ora_robot.grabbed), the chaotic ones held to their measured
+    amplification (tests/common.py)"""
+    h = held
+    idx = np.unique(np.linspace(0, N_RUNS - 1, 16).astype(int))
+    _, base, dofvals, adofs = common.wam_state()
+    prob = common.tabletop_problem(oracle)
+    rob = oracle.OraRobot(h["model"], grabbed=[(h["hand"], h["pose"], common.HELD4_POS, common.HELD4_RAD)])
+    ora = lambda g: oracle.batch_run(rob, base, dofvals, adofs, g, [prob["sdf"]], [prob["pose"]], oracle.default_params(**KW), 100)
+    res = ora(h["goals"][idx])
+    amp, stable = common.amplification(ora, h["goals"][idx], res)
+    moved = ~stable
+    otraj, ocosts, ost = res[0], res[1], res[2]
+    st = h["status"][idx]
+    err = np.array([common.rel_l2(h["traj"][k], otraj[j]) for j, k in enumerate(idx)])
+    well = (ost == 0) & (st == 0) & (amp < 1e-9) & ~moved
+    assert well.sum() >= 10, (amp, ost, st)
+    assert err[well].max() <= 1e-6, err
+    assert np.allclose(h["costs"][idx][well], ocosts[well], rtol=1e-6, atol=0)
+    ill = (ost == 0) & (st == 0) & ~well
+    assert (err[ill] <= np.maximum(1e-6, common.CHAOS_FACTOR * amp[ill])).all(), (err[ill], amp[ill])
+    # a status that differs belongs to a run the oracle itself moves under a one-ulp change of its goal
+    assert all(amp[j] >= 1e-9 or moved[j] for j in np.flatnonzero(ost != st)), (ost, st, amp)
+    print("held4, 16 of 1024 runs vs the oracle: worst rel L2 %.2e over %d well-conditioned runs; %d of 1024 runs outside their limits"
+          % (err[well].max(), well.sum(), (h["status"] != 0).sum()))
+
+
+def test_runs_are_independent_of_batch_and_position(held):
+    """a permuted subset, launched on its own, reproduces the full batch bit for bit (the pair list and its summation order are a
+    function of the robot, not of the batch)"""
+    h = held; mod = h["mod"]
+    pick = np.random.default_rng(5).permutation(N_RUNS)[:160]
+    bid = mod.batch_create(h["model"].name, h["goals"][pick], **KW)
+    costs, status = mod.batch_iterate(bid, 100)
+    traj = mod.batch_gettraj(bid)
+    mod.batch_destroy(bid)
+    assert np.array_equal(status, h["status"][pick])
+    assert np.array_equal(traj, h["traj"][pick])
+    assert np.array_equal(costs, h["costs"][pick])
+    # ... and once more in the same order: the launch is deterministic
+    bid = mod.batch_create(h["model"].name, h["goals"], **KW)
+    c2, s2 = mod.batch_iterate(bid, 100)
+    t2 = mod.batch_gettraj(bid)
+    mod.batch_destroy(bid)
+    assert np.array_equal(t2, h["traj"]) and np.array_equal(c2, h["costs"]) and np.array_equal(s2, h["status"])
+
+
+@pytest.mark.parametrize("momentum", [0, 1])
+def test_two_calls_are_one(held, momentum):
+    h = held; mod = h["mod"]
+    goals = h["goals"][:384]
+    kw = dict(KW, use_momentum=momentum)
+    a = mod.batch_create(h["model"].name, goals, **kw)
+    ca, sa = mod.batch_iterate(a, 100)
+    ta = mod.batch_gettraj(a)
+    b = mod.batch_create(h["model"].name, goals, **kw)
+    _, sb1 = mod.batch_iterate(b, 41)
+    cb, sb2 = mod.batch_iterate(b, 59)
+    tb = mod.batch_gettraj(b)
+    mod.batch_destroy(a); mod.batch_destroy(b)
+    sb = np.minimum(sb1, sb2)
+    ok = (sa == 0) & (sb == 0)
+    assert np.array_equal(sa, sb)
+    assert np.array_equal(ta[ok], tb[ok])
+    assert np.array_equal(ca[ok], cb[ok])
+
+
+def test_costs_are_the_costs_of_the_returned_trajectory(held):
+    h = held; mod = h["mod"]
+    goals = h["goals"][:256]
+    bid = mod.batch_create(h["model"].name, goals, **KW)
+    c1, s1 = mod.batch_iterate(bid, 100)
+    t1 = mod.batch_gettraj(bid)
+    c2, s2 = mod.batch_iterate(bid, 0)
+    t2 = mod.batch_gettraj(bid)
+    mod.batch_destroy(bid)
+    ok = s1 == 0
+    assert np.array_equal(t1, t2)
+    assert np.array_equal(c1[ok], c2[ok])
+    assert np.allclose(c1[ok, 0], c1[ok, 1] + c1[ok, 2], rtol=1e-15, atol=0)
+    lo = np.asarray(h["model"].limit_lower[:7]); hi = np.asarray(h["model"].limit_upper[:7])
+    assert ((t1[ok] >= lo - 1e-12) & (t1[ok] <= hi + 1e-12)).all()
+
+
+def test_budgets_and_shapes_give_the_same_trajectories(held):
+    """the kernels built for four workgroups per CU (orc_set_workgroups_per_cu(4)) and the latency shape (512 threads, one run per
+    CU: what the single-run `create` command uses) walk the same pair list in the same order: the same bits"""
+    h = held
+    goals = h["goals"][:96]
+    mod = or_cdchomp_amd.Module(0)
+    model, _, _ = common.setup_product_wam_held4(mod)
+    out = {}
+    for name, wgs, threads in (("default", 0, 0), ("four per CU", 4, 0), ("latency shape", 0, 512)):
+        mod.set_workgroups_per_cu(wgs); mod.set_workgroup_threads(threads)
+        bid = mod.batch_create(model.name, goals, **KW)
+        c, s = mod.batch_iterate(bid, 100)
+        out[name] = (mod.batch_gettraj(bid), c, s)
+        mod.batch_destroy(bid)
+    mod.close()
+    assert np.array_equal(out["default"][0], h["traj"][:96]) and np.array_equal(out["default"][2], h["status"][:96])
+    for name in ("four per CU", "latency shape"):
+        assert np.array_equal(out[name][2], out["default"][2]), name
+        assert np.array_equal(out[name][0], out["default"][0]), name
+        assert np.allclose(out[name][1], out["default"][1], rtol=1e-13, atol=0), name      # (the cost sums are grouped by wavefront)
+
+
+def test_the_held_body_changes_the_answer_and_release_restores_it(held):
+    """grab -> release gives back the robot that never held anything, bit for bit; holding changes the trajectories"""
+    h = held
+    goals = h["goals"][:64]
+    mod = or_cdchomp_amd.Module(0)
+    model = common.setup_product_wam(mod)
+    bid = mod.batch_create(model.name, goals, **KW)
+    mod.batch_iterate(bid, 100)
+    bare = mod.batch_gettraj(bid)
+    mod.batch_destroy(bid)
+    mod.add_kinbody_boxes("held4", [([0.045, 0.045, 0.01, 0, 0, 0, 1], [0.08, 0.08, 0.04])], transform=h["pose"])
+    mod.set_kinbody_spheres("held4", common.HELD4_POS, common.HELD4_RAD)
+    mod.grab(model.name, "held4", h["hand"])
+    mod.release(model.name, "held4")
+    bid = mod.batch_create(model.name, goals, **KW)
+    mod.batch_iterate(bid, 100)
+    again = mod.batch_gettraj(bid)
+    mod.batch_destroy(bid)
+    mod.close()
+    assert np.array_equal(bare, again)
+    ok = h["status"][:64] == 0
+    assert max(common.rel_l2(bare[k], h["traj"][k]) for k in np.flatnonzero(ok)) > 1e-4
