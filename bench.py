@@ -271,16 +271,17 @@ def run_workload(config, args, rank, world, device, dist, steps, warmup, serial_
     def timed_leg(steps, warmup, streams):
         """(elapsed seconds max over ranks, iterations made by this rank, batch ids, per-step results)"""
         mod.set_num_streams(streams if streams > 1 else 0)
-        # one launch at a time of 769..1024 runs: all of them resident at once with four 192-thread
-        # workgroups per CU at 168 registers (orc_set_workgroup_threads); overlapping launches, batches of thousands of
-        # runs and the TSR-constrained runs use the kernels built for four 256-thread workgroups per CU at 128 registers
-        # (orc_set_workgroups_per_cu(4): +3-5 % / +50 % on the constrained runs; trajectories bit-identical either way)
+        # The overlapping leg sets no knob: the planner chooses from the module's stream count, the robot and the run
+        # parameters (four workgroups per CU for fixed-base chains, the 128-thread shape for TSR-constrained runs; batch.cpp).
+        # One launch at a time of 769..1024 runs is the one case a caller has to SAY, because it is a property of the batch:
+        # all of them resident at once with four 192-thread workgroups per CU at 168 registers (orc_set_workgroup_threads)
         serial_1024 = (streams <= 1 and config in (2, 3) and 768 < n_runs <= 1024)
-        mod.set_workgroup_threads(192 if serial_1024 else 0)
-        wgs_auto = 4 if ((config in (2, 3) and not serial_1024) or config in ("tsr1", "tsr3", "held4")) else 0
+        threads = (192 if serial_1024 else 0) if args.workgroup_threads < 0 else args.workgroup_threads
+        mod.set_workgroup_threads(threads)
+        wgs_auto = 4 if (config in (2, 3) and streams <= 1 and n_runs > 1024) else 0      # (serial launches of thousands of runs: also the batch's property)
         wgs = wgs_auto if args.workgroups_per_cu < 0 else args.workgroups_per_cu
         mod.set_workgroups_per_cu(wgs)
-        knobs = {"orc_set_num_streams": streams if streams > 1 else 0, "orc_set_workgroup_threads": 192 if serial_1024 else 0,
+        knobs = {"orc_set_num_streams": streams if streams > 1 else 0, "orc_set_workgroup_threads": threads,
                  "orc_set_workgroups_per_cu": wgs}
         warm = [wl.create(mod, 900000 + k, rank) for k in range(warmup)]
         timed = [wl.create(mod, k, rank) for k in range(steps)]
@@ -646,8 +647,10 @@ def main():
     ap.add_argument("--backend", default="gloo", help="torch.distributed backend for N>1.  The path has no data-path collective "
                                                       "(north_star: host-side gather only): a barrier, one max-reduce of the elapsed "
                                                       "time and the gather of results, all on the host (gloo).  nccl (= RCCL) is optional")
-    ap.add_argument("--workgroups-per-cu", type=int, default=-1, help="register budget of the batches (orc_set_workgroups_per_cu): 0 or 4; "
-                                                                      "default: 4 for the overlapping / large-batch legs of configs 2 and 3")
+    ap.add_argument("--workgroups-per-cu", type=int, default=-1, help="register budget of the batches (orc_set_workgroups_per_cu): 0 (the planner's choice), 3 or 4; "
+                                                                      "default: 0, and 4 for serial launches of more than 1024 runs of configs 2 and 3")
+    ap.add_argument("--workgroup-threads", type=int, default=-1, help="workgroup shape of the batches (orc_set_workgroup_threads): 0, 128, 192, 256 or 512; "
+                                                                      "default: the leg's own choice")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="default run only (N = 1, config 2): do not append the config 4 and config 5 lines")
     ap.add_argument("--other-steps", type=int, default=16, help="steps of each `other_configs` line (even: the steps alternate between two streams; "

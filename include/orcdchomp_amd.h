@@ -108,14 +108,20 @@ int orc_robot_set_velocity_limits(orc_module * mod, const char * name, const dou
  * or overlapping batches are ~5 % slower with it; 512 = eight wavefronts on one run, one run per CU, the
  * whole trajectory in one tile: the latency shape for batches smaller than the chip (one run: 34 k
  * instead of 22 k iterations/s, 256 runs: 5.4 M instead of 4.2 M).  The single-run `create` command uses
- * 512 unless a shape is set here.  The shape never depends on the batch itself, so that a run's result
- * does not depend on what shares its batch (trajectories are bit-identical across shapes). */
+ * 512 unless a shape is set here.  128 = two wavefronts on a run, up to eight runs per CU (fp64 fixed-base chains with at
+ * most 16 active spheres): what the planner gives runs with TSR constraints -- whose elimination is the work of two
+ * wavefronts -- when the module's launches overlap (orc_set_num_streams >= 2): +18 %.  The shape never depends on the batch
+ * itself, so that a run's result does not depend on what shares its batch (trajectories are bit-identical across shapes;
+ * robots with 17 .. 32 active spheres have the 256- and 512-thread shapes and fall back to the many-sphere kernels at 192). */
 int orc_set_workgroup_threads(orc_module * mod, int threads);
-/* Register budget of the batches created from now on: 0 (default) the kernels' own (three 256-thread workgroups per CU
- * at 168 registers for fp64), 4: four per CU at 128 registers with smaller tiles, where a kernel is built for it (fp64
- * robots of at most 16 active spheres on a fixed-base chain: the WAM of the BASELINE configurations; others, and runs
- * too long for the smaller share of the LDS, keep their default).  A caller whose launches overlap (orc_set_num_streams >= 2) or hold thousands of runs gains 3 %,
- * a caller with one launch of <= 1024 runs at a time loses 3 %.  Trajectories are bit-identical either way. */
+/* Register budget of the batches created from now on: 0 (default) the planner's choice, 3 the kernels' own (three 256-thread
+ * workgroups per CU at 168 registers for fp64), 4: four per CU at 128 registers with smaller tiles, where a kernel is built
+ * for it (fp64 robots on a fixed-base chain with at most 16 active spheres -- the WAM of the BASELINE configurations -- or
+ * with 17 .. 32: the robot that holds something; others, and runs too long for the smaller share of the LDS, keep their
+ * default).  The planner's choice is a function of the robot, the run parameters and this module's settings, never of the
+ * batch: four per CU for runs with TSR constraints and for the 17 .. 32-sphere family (faster whatever the launch pattern)
+ * and, when the module's launches overlap (orc_set_num_streams >= 2), for every fixed-base chain (+3-5 %; one launch of
+ * <= 1024 runs at a time is 3 % faster at three).  Trajectories are bit-identical either way. */
 int orc_set_workgroups_per_cu(orc_module * mod, int workgroups);
 
 /* What the TSR constraints of `create` address on the robot (src/orcdchomp_mod.cpp:1957-1976):

@@ -107,7 +107,7 @@ void pair_range_frequencies(const Robot & robot, double eps_self, const std::vec
 // when that helps.  A pure function of the robot, the active dofs and eps_self (like the placement of the 16-lane rows):
 // the order in which a sphere's pair forces are added up must not depend on what shares the batch.
 // Returns the rounds in use, 0 when the list does not fit ORC_PAIR_ROUNDS.
-struct PairTable { int rounds = 0; std::vector<int> ab, gat; std::vector<double> rsum; unsigned long long deg = 0ull; int n_pairs = 0; double expected_rounds = 0.0; };
+struct PairTable { int rounds = 0, hot = 0; std::vector<int> ab, gat; std::vector<double> rsum; unsigned long long deg[2] = { 0ull, 0ull }; int n_pairs = 0; double expected_rounds = 0.0; };
 PairTable build_pair_table(const Robot & robot, double eps_self, const std::vector<int> & xml, int n_active, int GS)
 {
    PairTable T;
@@ -128,8 +128,8 @@ PairTable build_pair_table(const Robot & robot, double eps_self, const std::vect
    const int per_round = GS - 1;
    std::vector<int> used(ORC_PAIR_ROUNDS, 0);
    std::vector<int> plus((size_t) ORC_PAIR_ROUNDS * GS, 0), minus((size_t) ORC_PAIR_ROUNDS * GS, 0);
-   T.ab.assign((size_t) ORC_PAIR_ROUNDS * 32, 0); T.gat.assign((size_t) ORC_PAIR_ROUNDS * 32, 0); T.rsum.assign((size_t) ORC_PAIR_ROUNDS * 32, 0.0);
-   // gather entries: bytes 0,1 adding, bytes 2,3 subtracting; all of them start at the round's last lane
+   T.ab.assign((size_t) ORC_PAIR_ROUNDS * 32, 0); T.gat.assign((size_t) ORC_PAIR_ROUNDS * 32 * 2, 0); T.rsum.assign((size_t) ORC_PAIR_ROUNDS * 32, 0.0);
+   // gather entries: word 0 adding, word 1 subtracting, a byte each; all of them start at the round's last lane
    for (size_t e=0; e<T.gat.size(); e++) { const int z = (GS - 1) * 4; T.gat[e] = z | (z << 8) | (z << 16) | (z << 24); }
    std::vector<double> none(ORC_PAIR_ROUNDS, 1.0);      // probability that no pair of the round is within range (two waypoints per wavefront: squared below)
    for (const Cand & c : cand)
@@ -151,11 +151,12 @@ PairTable build_pair_table(const Robot & robot, double eps_self, const std::vect
       const size_t e = (size_t) r*32 + k;
       T.ab[e] = first | (second << 8);
       T.rsum[e] = robot.spheres[xml[first]].radius + robot.spheres[xml[second]].radius;
-      int & gp = T.gat[(size_t) r*32 + first];  const int np_ = plus[(size_t) r*GS + first]++;
-      gp = (gp & ~(0xff << (8*np_))) | ((k*4) << (8*np_));
-      int & gm = T.gat[(size_t) r*32 + second]; const int nm_ = minus[(size_t) r*GS + second]++;
-      gm = (gm & ~(0xff << (8*(2 + nm_)))) | ((k*4) << (8*(2 + nm_)));
+      int & gp = T.gat[((size_t) r*32 + first)*2 + 0];  const int np_ = plus[(size_t) r*GS + first]++;
+      gp = (int)(((unsigned int) gp & ~(0xffu << (8*np_))) | ((unsigned int)(k*4) << (8*np_)));
+      int & gm = T.gat[((size_t) r*32 + second)*2 + 1]; const int nm_ = minus[(size_t) r*GS + second]++;
+      gm = (int)(((unsigned int) gm & ~(0xffu << (8*nm_))) | ((unsigned int)(k*4) << (8*nm_)));
       none[r] *= (1.0 - c.f);
+      if (c.f > 0.95 && r + 1 > T.hot) T.hot = r + 1;
       if (r + 1 > T.rounds) T.rounds = r + 1;
       T.n_pairs++;
    }
@@ -163,12 +164,12 @@ PairTable build_pair_table(const Robot & robot, double eps_self, const std::vect
    {
       int dp = 0, dm = 0;
       for (int q=0; q<GS; q++) { dp = std::max(dp, plus[(size_t) r*GS + q]); dm = std::max(dm, minus[(size_t) r*GS + q]); }
-      T.deg |= (unsigned long long)(dp | (dm << 2)) << (4*r);
+      T.deg[r >> 3] |= (unsigned long long)(dp | (dm << 4)) << (8*(r & 7));
       T.expected_rounds += 1.0 - std::pow(none[r], 64 / GS);
    }
    if (getenv("ORC_DEBUG_PLAN"))
    {
-      fprintf(stderr, "orc pair list: %d pairs of %d lanes in %d rounds of %d; expected force evaluations per wavefront pass %.2f; pairs per round", T.n_pairs, L, T.rounds, per_round, T.expected_rounds);
+      fprintf(stderr, "orc pair list: %d pairs of %d lanes in %d rounds of %d, %d of them always evaluated; expected force evaluations per wavefront pass %.2f; pairs per round", T.n_pairs, L, T.rounds, per_round, T.hot, T.expected_rounds);
       for (int r=0; r<T.rounds; r++) fprintf(stderr, " %d", used[r]);
       fprintf(stderr, "\n");
    }
@@ -752,8 +753,10 @@ void BatchShard::build_device(const Robot & robot)
       device_sphere_order.push_back(inact[s].xml);
    }
    M.pr_rounds = pairs ? ptab.rounds : 0;
+   M.pr_hot = pairs ? ptab.hot : 0;
    if (pairs)
-      for (size_t e=0; e<(size_t) ORC_PAIR_ROUNDS * 32; e++) { M.pr_ab[e] = ptab.ab[e]; M.pr_gat[e] = ptab.gat[e]; M.pr_rsum[e] = (real) ptab.rsum[e]; }
+      for (size_t e=0; e<(size_t) ORC_PAIR_ROUNDS * 32; e++)
+      { M.pr_ab[e] = ptab.ab[e]; M.pr_gat[2*e] = ptab.gat[2*e]; M.pr_gat[2*e+1] = ptab.gat[2*e+1]; M.pr_rsum[e] = (real) ptab.rsum[e]; }
    // the FK walk's records (DevFkJoint): fixed transform, axis, control word and the first four spheres of the link
    for (int k=0; k<nj; k++)
    {
@@ -869,7 +872,7 @@ void BatchShard::build_device(const Robot & robot)
    ms_.nj = M.nj; ms_.floating = M.floating; ms_.tree = M.tree; ms_.Sa = M.Sa; ms_.S = M.S; ms_.Sa_real = M.Sa_real; ms_.placed = M.placed;
    ms_.GS = M.GS; ms_.base_sph_begin = M.base_sph_begin; ms_.base_sph_end = M.base_sph_end; ms_.jt_scan = M.jt_scan; ms_.n_static = M.n_static;
    ms_.live_mask = M.live_mask; ms_.static_mask = M.static_mask;
-   ms_.fk_split = M.fk_split; ms_.fk_nanc = M.fk_nanc; ms_.fk_b_begin = M.fk_b_begin; ms_.pr_rounds = M.pr_rounds; ms_.pr_deg = pairs ? ptab.deg : 0ull;
+   ms_.fk_split = M.fk_split; ms_.fk_nanc = M.fk_nanc; ms_.fk_b_begin = M.fk_b_begin; ms_.pr_rounds = M.pr_rounds; ms_.pr_deg[0] = pairs ? ptab.deg[0] : 0ull; ms_.pr_deg[1] = pairs ? ptab.deg[1] : 0ull; ms_.pr_hot = M.pr_hot; ms_.pad2_ = 0;
    if (getenv("ORC_DEBUG_PLAN") && M.fk_split)
       fprintf(stderr, "orc fk: the walk is cut in two: joints [0, %d) | chain [0, %d) + joints [%d, %d)\n", M.fk_b_begin, M.fk_nanc, M.fk_b_begin, nj);
    DevModel<real> * dm = dev_alloc<DevModel<real>>(1);
@@ -1027,7 +1030,18 @@ void BatchShard::build_device(const Robot & robot)
    force_block = mod_->workgroup_threads ? mod_->workgroup_threads : params.workgroup_threads;
    // orc_set_workgroups_per_cu(4): the fp64 16-lane kernels of a fixed-base chain also exist at 128 VGPRs, four 256-thread
    // workgroups per CU (three tiles instead of two for the WAM): +3 % when launches overlap, -3 % one launch at a time
-   const int want_wgs = mod_->workgroups_per_cu ? mod_->workgroups_per_cu : params.workgroups_per_cu;
+   int want_wgs = mod_->workgroups_per_cu ? mod_->workgroups_per_cu : params.workgroups_per_cu;
+   // What the caller did not say, the planner chooses -- from the robot, the run parameters and the MODULE's settings, never from
+   // the batch (a run's bits must not depend on what shares its batch).  Runs with TSR constraints and the pair-list family are
+   // faster at four workgroups per CU whatever the launch pattern (the constraint step +50 %, held4 +20 %); a module whose
+   // launches overlap (orc_set_num_streams >= 2) also takes the four-per-CU kernels of a fixed-base chain (+3-5 %) and, for
+   // constrained runs, the 128-thread shape (eight runs per CU: +18 %).  One launch of <= 1024 unconstrained runs at a time
+   // is 3 % faster with the kernels' own budget, which is the default there.  3 = "the kernels' own budget", said explicitly.
+   const bool overlapping = mod_->num_streams >= 2;
+   const bool can128 = sizeof(real) == 8 && (tree_ & 16) && (tree_ & 2) && !(tree_ & (1 | 64));
+   if (want_wgs == 0 && ((n_tsrs_ > 0 && !(tree_ & 64)) || (tree_ & 512) || (overlapping && !(tree_ & 64)))) want_wgs = 4;
+   if (want_wgs == 3) want_wgs = 0;
+   if (force_block == 0 && overlapping && n_tsrs_ > 0 && can128 && !params.free_start && !getenv("ORC_BLOCK_THREADS")) force_block = 128;
    const int max_wgs_default = max_wgs, force_block_asked = force_block;
    bool budget4 = false;
    const int lanes_per_wp = (GS_ == 16) ? 16 : GS_;
@@ -1062,6 +1076,11 @@ void BatchShard::build_device(const Robot & robot)
    // the latency shape: eight wavefronts on one run, one run per CU (a lone wavefront issues a vector
    // instruction every ~9 cycles: two per SIMD halve the time of an iteration; for batches smaller than the chip)
    if (force_block == 512) shapes.push_back({ 512, 1 });
+   // two wavefronts on a run, up to eight runs per CU (the kernels exist for the fp64 16-lane family of a fixed-base chain at
+   // 128 registers): runs with TSR constraints, whose elimination is the work of two wavefronts (csrc/tsr.h), keep all
+   // sixteen wavefronts of a CU at it instead of eight
+   if (force_block == 128 && can128) for (int wgs=(getenv("ORC_WGS128") ? atoi(getenv("ORC_WGS128")) : 8); wgs>=4; wgs--) shapes.push_back({ 128, wgs });
+   if (force_block == 128 && !can128) force_block = 0;      // (a robot the shape is not built for keeps its default)
    for (const Shape & sh : shapes)
    {
       const int wgs = sh.wgs, block = sh.block;
@@ -1431,7 +1450,7 @@ void BatchShard::launch(int n_iter, bool final_eval, bool carry)
    }
    hipEvent_t ev[2] = { mod_->acquire_event(device), mod_->acquire_event(device) };
    hip_check(hipEventRecord(ev[0], stream_), "hipEventRecord");
-   hipError_t e = launch_typed(b, lds_bytes_, stream_, tree_ | (block_ == 192 ? 4 : 0) | (block_ == 512 ? 8 : 0));
+   hipError_t e = launch_typed(b, lds_bytes_, stream_, tree_ | (block_ == 192 ? 4 : 0) | (block_ == 512 ? 8 : 0) | (block_ == 128 ? 1024 : 0));
    hip_check(e, "chomp_iterate_kernel launch");
    hip_check(hipEventRecord(ev[1], stream_), "hipEventRecord");
    pending_events_.push_back(std::make_pair(ev[0], ev[1]));

@@ -193,8 +193,8 @@ int orc_robot_set_velocity_limits(orc_module * mod, const char * name, const dou
 int orc_set_workgroup_threads(orc_module * mod, int threads)
 {
    return guarded(mod, [&] {
-      if (threads != 0 && threads != 192 && threads != 256 && threads != 512)
-         throw std::runtime_error("workgroup threads must be 0 (default), 192, 256 or 512!");
+      if (threads != 0 && threads != 128 && threads != 192 && threads != 256 && threads != 512)
+         throw std::runtime_error("workgroup threads must be 0 (default), 128, 192, 256 or 512!");
       mod->impl->workgroup_threads = threads;
    });
 }
@@ -202,7 +202,7 @@ int orc_set_workgroup_threads(orc_module * mod, int threads)
 int orc_set_workgroups_per_cu(orc_module * mod, int workgroups)
 {
    return guarded(mod, [&] {
-      if (workgroups != 0 && workgroups != 4) throw std::runtime_error("workgroups per CU must be 0 (default) or 4!");
+      if (workgroups != 0 && workgroups != 3 && workgroups != 4) throw std::runtime_error("workgroups per CU must be 0 (the planner's choice), 3 or 4!");
       mod->impl->workgroups_per_cu = workgroups;
    });
 }

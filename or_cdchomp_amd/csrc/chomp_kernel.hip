@@ -205,6 +205,7 @@ __device__ __forceinline__ void wave_argmax(real & best, int & best_e);
 template <int BLOCK>
 __device__ __forceinline__ double sum_partials(const double * r)
 {
+   if (BLOCK == 128) return r[0] + r[1];
    if (BLOCK == 192) return (r[0] + r[1]) + r[2];
    if (BLOCK == 256) return (r[0] + r[1]) + (r[2] + r[3]);
    return ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));      // 512 threads
@@ -565,25 +566,35 @@ __device__ __forceinline__ int limit_rounds_regs(PT T_s, PJ jl_s, int m, int n, 
 #pragma unroll
       for (int ci=0; ci<NC; ci++) T[ci][r] = valid[r] ? T_s[n + row*n + col[ci]] : (real)0;
    }
+   // violations, and which lanes hold one (per register slot: scalar masks), kept ACROSS the rounds: a round only changes the
+   // columns it applies A^-1 Gjlimit to, so only those are looked at again (round 5: every round looked at all NC x RPL entries,
+   // a third of a round's instructions for the three to five columns a 200-waypoint momentum run has outside its limits)
+   real g[NC][RPL];
+   unsigned long long mk[NC][RPL];
+   int pc[NC];
+   auto refresh = [&](int ci)
+   {
+      int cnt = 0;
+#pragma unroll
+      for (int r=0; r<RPL; r++)
+      {
+         const real t = T[ci][r];
+         real v = M<real>::max_(lo[ci] - t, (real)0) + M<real>::min_(hi[ci] - t, (real)0);
+         v = valid[r] ? v : (real)0;
+         g[ci][r] = v;
+         mk[ci][r] = __ballot(v != (real)0);
+         cnt += __popcll(mk[ci][r]);
+      }
+      pc[ci] = cnt;
+   };
+#pragma unroll
+   for (int ci=0; ci<NC; ci++) refresh(ci);
    int rounds;
    for (rounds=0; rounds<1000; rounds++)
    {
-      real g[NC][RPL];
-      // violations, and which lanes hold one (per register slot: scalar masks)
-      unsigned long long mk[NC][RPL];
       int total = 0;
 #pragma unroll
-      for (int r=0; r<RPL; r++)
-#pragma unroll
-         for (int ci=0; ci<NC; ci++)
-         {
-            const real t = T[ci][r];
-            real v = M<real>::max_(lo[ci] - t, (real)0) + M<real>::min_(hi[ci] - t, (real)0);
-            v = valid[r] ? v : (real)0;
-            g[ci][r] = v;
-            mk[ci][r] = __ballot(v != (real)0);
-            total += __popcll(mk[ci][r]);
-         }
+      for (int ci=0; ci<NC; ci++) total += pc[ci];
       if (total == 0) break;                          // nothing violated
       if (dbg) *dbg += (total <= 2) ? 1LL : (1LL << 20);       // diagnostics: closed-form rounds | scan rounds << 20 | general-loop rounds << 40
       if (total <= 2)
@@ -624,7 +635,6 @@ __device__ __forceinline__ int limit_rounds_regs(PT T_s, PJ jl_s, int m, int n, 
          // the largest violation; ties to the first row-major index (chomp.c:621-638)
          const real a0 = M<real>::fabs_(gk[0]), a1 = M<real>::fabs_(gk[1]);
          const bool second = (total == 2) && (a1 > a0 || (a1 == a0 && ek[1] < ek[0]));
-         const int w = second ? 1 : 0;
          const real gl = second ? gk[1] : gk[0];
          const int roww = second ? rowk[1] : rowk[0];
          const int ciw = second ? e_ci[1] : e_ci[0];
@@ -638,7 +648,6 @@ __device__ __forceinline__ int limit_rounds_regs(PT T_s, PJ jl_s, int m, int n, 
          }
          const real ga = kinv * ((real)(m - roww) * Pw + (real)(roww + 1) * Qw);
          const real sc = ((real)1.01 * gl) * rcp_fast(ga);
-         (void) w;
 #pragma unroll
          for (int ci=0; ci<NC; ci++)
          {
@@ -654,6 +663,7 @@ __device__ __forceinline__ int limit_rounds_regs(PT T_s, PJ jl_s, int m, int n, 
                const real x = kinv * (wq[r] * P + wp[r] * Q);
                T[ci][r] += sc * x;
             }
+            refresh(ci);
          }
          continue;
       }
@@ -677,7 +687,7 @@ __device__ __forceinline__ int limit_rounds_regs(PT T_s, PJ jl_s, int m, int n, 
       const real gl = read_lane(best_g, owner);
       // GA = A^-1 Gjlimit by one prefix and one suffix wave scan per column.  The winner's column comes
       // first: its entry at the winner is the scale of the round; then every column with a violated entry
-      // is solved and applied at once (nothing of GA is kept: registers for up to 8 columns x 4 rows)
+      // is solved and applied at once (nothing of GA is kept but the winner's column: registers for up to 8 columns x 4 rows)
       auto scan_column = [&](const real (& gc_)[RPL], real (& xo)[RPL])
       {
          real sp = 0, sq = 0;
@@ -697,11 +707,13 @@ __device__ __forceinline__ int limit_rounds_regs(PT T_s, PJ jl_s, int m, int n, 
          }
       };
       real ga_mine = 0;
+      real xw[RPL];
+#pragma unroll
+      for (int r=0; r<RPL; r++) xw[r] = 0;
 #pragma unroll
       for (int ci=0; ci<NC; ci++)
       {
          if (col[ci] != gc) continue;                  // wave-uniform
-         real xw[RPL];
          scan_column(g[ci], xw);
 #pragma unroll
          for (int r=0; r<RPL; r++) ga_mine = (lane*RPL + r == gi) ? xw[r] : ga_mine;
@@ -712,14 +724,21 @@ __device__ __forceinline__ int limit_rounds_regs(PT T_s, PJ jl_s, int m, int n, 
       for (int ci=0; ci<NC; ci++)
       {
          // a column without a violated entry in this round: A^-1 Gjlimit is zero there (wave-uniform)
-         unsigned long long anyc = 0ull;
+         if (pc[ci] == 0) continue;
+         if (col[ci] == gc)
+         {
+            // (the winner's column was solved for the scale already)
 #pragma unroll
-         for (int r=0; r<RPL; r++) anyc |= mk[ci][r];
-         if (anyc == 0ull) continue;
-         real xc[RPL];
-         scan_column(g[ci], xc);
+            for (int r=0; r<RPL; r++) T[ci][r] += sc * xw[r];
+         }
+         else
+         {
+            real xc[RPL];
+            scan_column(g[ci], xc);
 #pragma unroll
-         for (int r=0; r<RPL; r++) T[ci][r] += sc * xc[r];
+            for (int r=0; r<RPL; r++) T[ci][r] += sc * xc[r];
+         }
+         refresh(ci);
       }
    }
 #pragma unroll
@@ -924,7 +943,7 @@ struct Env
    real * T_u;                             // the trajectory as the update phase and the cost sums see it: T_s, or its staged copy (DevBatch::t_staged)
    int * slink_s, * jtype_s, * jcol_s, * slot_s;
    int * jctl_s; DevSdf<real> * sdfs_s; unsigned long long * saff_s, * sallow_s;
-   real * prs_s; int * pab_s, * pgat_s;    // the staged self-collision pair list (cost_pairs.h): rsum, first | second << 8, gather entries; [pr_rounds][32]
+   real * pent_s; int * pgat_s;            // the staged self-collision pair list (cost_pairs.h): entries { rsum, first | second << 8 } [pr_rounds][32][2 reals], gather words [pr_rounds][32][2]
    real * traj_g, * AG_g, * AG_s;
    const real * pcr_tab;
    int pstr, astr;
@@ -971,9 +990,8 @@ __device__ __forceinline__ Env<real> make_env(const BT & b, unsigned char * smem
    E.sdfs_s = (DevSdf<real> *)(smem_raw + L.sdfs_bytes);
    E.saff_s = (unsigned long long *)(smem_raw + L.saff_bytes);
    E.sallow_s = (unsigned long long *)(smem_raw + L.sallow_bytes);
-   E.prs_s = (real *)(smem_raw + L.ptab_bytes);
-   E.pab_s = (int *)(E.prs_s + b.ms.pr_rounds * 32);
-   E.pgat_s = E.pab_s + b.ms.pr_rounds * 32;
+   E.pent_s = (real *)(smem_raw + L.ptab_bytes);
+   E.pgat_s = (int *)(E.pent_s + b.ms.pr_rounds * 32 * 2);
    ModelView<real> & mod = E.mod;
    mod.nj = nj; mod.n = n; mod.floating = b.ms.floating; mod.tree = b.ms.tree; mod.Sa = Sa; mod.S = S; mod.GS = b.ms.GS; mod.jt_scan = b.ms.jt_scan;
    mod.Sa_real = b.ms.Sa_real; mod.placed = b.ms.placed; mod.live_mask = b.ms.live_mask; mod.slot_of = E.slot_s;
@@ -1058,7 +1076,11 @@ __device__ __attribute__((noinline)) void phase_setup(const void * kp)
 #endif
    for (int e=tid; e<n; e+=BLOCK) { E.jl_s[e] = b.jl_lo[e]; E.jl_s[n+e] = b.jl_hi[e]; }
    if (!GS16)
-      for (int e=tid; e<b.ms.pr_rounds*32; e+=BLOCK) { E.prs_s[e] = gmod.pr_rsum[e]; E.pab_s[e] = gmod.pr_ab[e]; E.pgat_s[e] = gmod.pr_gat[e]; }
+      for (int e=tid; e<b.ms.pr_rounds*32; e+=BLOCK)
+      {
+         E.pent_s[2*e] = gmod.pr_rsum[e]; *(int *)(E.pent_s + 2*e + 1) = gmod.pr_ab[e];
+         E.pgat_s[2*e] = gmod.pr_gat[2*e]; E.pgat_s[2*e+1] = gmod.pr_gat[2*e+1];
+      }
    if (b.pcr_in_lds)
       for (int e=tid; e<b.pcr_rows*m; e+=BLOCK) E.pcr_s[e] = b.pcr[e];
    if (b.use_momentum && b.ag_in_lds) for (int e=tid; e<mn; e+=BLOCK) E.AG_s[e] = E.AG_g[e];
@@ -1225,7 +1247,7 @@ __device__ __forceinline__ double phase_cost_body(const void * kp, int ts_in, in
       // base, no inactive sphere left for the loop over them)
       if constexpr ((KIND & 2) != 0) E.mod.floating = 0;
       cost_tile_pairs<real, BLOCK, KArg<real>, (KIND & 2) != 0, (KIND & 8) != 0>(b, E.mod, ts, te, do_iteration, E.T_s, E.Gc, E.pos_s, E.ax_s, E.srad_s, E.sinact_s,
-                                         E.slink_s, E.prs_s, E.pab_s, E.pgat_s, inv_eps, inv_eps_self, cost_lane);
+                                         E.slink_s, E.pent_s, E.pgat_s, inv_eps, inv_eps_self, cost_lane);
    }
    else
    {
@@ -1963,6 +1985,15 @@ static hipError_t launch_iterate_t(const DevBatch<real> & b, size_t lds, hipStre
 #endif
    if constexpr (sizeof(real) == 8)
    {
+#if ORC_FAST_BUILD == 7      // -DORC_FAST_BUILD=7: the TSR-constrained WAM (KIND 11) at four 256-thread and eight 128-thread workgroups per CU
+      if ((variant & (16 | 2 | 1 | 64)) == (16 | 2) && (variant & 160) == 160)
+      {
+         if (variant & 1024) return launch_iterate_tt<real, false, true, 128, 11, 4>(b, lds, stream);
+         if ((variant & 256) && !(variant & (4 | 8))) return launch_iterate_tt<real, false, true, 256, 11, 4>(b, lds, stream);
+         if (!(variant & (4 | 8))) return launch_iterate_tt<real, false, true, 256, 11>(b, lds, stream);
+      }
+      return hipErrorInvalidValue;
+#endif
 #if ORC_FAST_BUILD == 6      // -DORC_FAST_BUILD=6: the WAM that holds a box (the dense pair list, one aligned field) at both budgets
       if ((variant & 512) && (variant & 32) && (variant & 128) && !(variant & 64))
          return (variant & 256) ? launch_iterate_tt<real, false, false, 256, 26, 4>(b, lds, stream) : launch_iterate_tt<real, false, false, 256, 26>(b, lds, stream);
@@ -1983,6 +2014,18 @@ static hipError_t launch_iterate_t(const DevBatch<real> & b, size_t lds, hipStre
    }
    return hipErrorInvalidValue;
 #else
+   if (variant & 1024)     // 128-thread workgroups, eight per CU at 128 registers: the fp64 16-lane family of a fixed-base chain (orc_set_workgroup_threads(128))
+   {
+      if constexpr (sizeof(real) == 8)
+         if ((variant & (16 | 2 | 1 | 64)) == (16 | 2))
+            switch (1 | ((variant & 32) ? 2 : 0) | (((variant & 160) == 160) ? 8 : 0))
+            {
+            case 1: return launch_iterate_tt<real, false, true, 128, 1, 4>(b, lds, stream);
+            case 3: return launch_iterate_tt<real, false, true, 128, 3, 4>(b, lds, stream);
+            case 11: return launch_iterate_tt<real, false, true, 128, 11, 4>(b, lds, stream);
+            }
+      return hipErrorInvalidValue;
+   }
    if (variant & 512)      // 17 .. 32 active spheres on a chain, fp64: the dense pair list (cost_pairs.h; phase_cost KIND 16)
    {
       if constexpr (sizeof(real) == 8)

@@ -12,7 +12,7 @@
 //       some lane of the wavefront has its pair within range, both spheres' velocity terms through ds_bpermute and the net
 //       force of the pair on its first sphere, x_ab - x_ba = s/|d| ((w_a + w_b) d - (d.u_a) u_a - (d.u_b) u_b) (cost_gs16.h
 //       has the derivation; a sphere that stands still has w = 0, u = 0: exactly the other side's visit of the pair);
-//   then lane = sphere again GATHERS: every sphere knows the (at most 2 + 2) pair lanes of the round that add to it and
+//   then lane = sphere again GATHERS: every sphere knows the (at most 4 + 4) pair lanes of the round that add to it and
 //   that subtract from it (DevModel::pr_gat) and fetches their forces in that fixed order.  No scatter, no atomics.
 // The list is ordered by how often a pair is within range, so the pairs that are always within range (neighbouring links,
 // the fingers of a hand, the held body against the hand) fill the first rounds -- with every lane of the wavefront at
@@ -22,6 +22,13 @@
 // J^T as in cost_gs16.h: one suffix scan of the wrench over the waypoint's lanes, lane r finishes joint r.
 #pragma once
 
+#ifndef ORC_PAIR_HOT_EARLY
+#define ORC_PAIR_HOT_EARLY 0      // 1: the always-evaluated rounds fetch their spheres' velocity terms with the centres (more registers in flight)
+#endif
+#ifndef ORC_PAIR_GATHER_GROUP
+#define ORC_PAIR_GATHER_GROUP 2   // gather entries whose fetches are in flight together (1, 2 or 4: 6 registers each)
+#endif
+
 __device__ __forceinline__ double bperm(int addr4, double v)
 {
    const int lo = __builtin_amdgcn_ds_bpermute(addr4, __double2loint(v)), hi = __builtin_amdgcn_ds_bpermute(addr4, __double2hiint(v));
@@ -29,12 +36,29 @@ __device__ __forceinline__ double bperm(int addr4, double v)
 }
 __device__ __forceinline__ float bperm(int addr4, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(addr4, __float_as_int(v))); }
 
+// an entry of the staged pair list { rsum, first | second << 8, pad }: one LDS read (16 bytes in fp64, 8 in fp32)
+template <typename real> struct PairEnt { real rsum; int ab; };
+typedef int orc_v2i __attribute__((ext_vector_type(2)));
+typedef int orc_v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ PairEnt<double> pair_entry(const __attribute__((address_space(3))) double * tab, int e)
+{
+   const orc_v4i w = ((const __attribute__((address_space(3))) orc_v4i *) tab)[e];
+   PairEnt<double> t; t.rsum = __hiloint2double(w.y, w.x); t.ab = w.z;
+   return t;
+}
+__device__ __forceinline__ PairEnt<float> pair_entry(const __attribute__((address_space(3))) float * tab, int e)
+{
+   const orc_v2i w = ((const __attribute__((address_space(3))) orc_v2i *) tab)[e];
+   PairEnt<float> t; t.rsum = __int_as_float(w.x); t.ab = w.y;
+   return t;
+}
+
 // ONEF: there is one field and its axes are the world's, known at compile time.  NOINACT: no inactive sphere is left for
 // the loop over them (none, or all on free lanes of the group).
 template <typename real, int BLOCK, typename BT, bool ONEF = false, bool NOINACT = false>
 __device__ __forceinline__ void cost_tile_pairs(const BT & b, const ModelView<real> & mod, int ts, int te, bool do_iteration,
    const real * T_s, real * G_s, const real * pos_s, const real * ax_s, const real * srad_s, const real * sinact_s, const int * slink_s,
-   const real * prs_gen, const int * pab_gen, const int * pgat_gen, real inv_eps, real inv_eps_self, double & cost_lane)
+   const real * pent_gen, const int * pgat_gen, real inv_eps, real inv_eps_self, double & cost_lane)
 {
    constexpr int GSL = 32;
    typedef const __attribute__((address_space(3))) real * lds_real_p;
@@ -45,10 +69,12 @@ __device__ __forceinline__ void cost_tile_pairs(const BT & b, const ModelView<re
    const int nw = te - ts;                      // moving waypoints of this tile
    const int items = nw * GSL;
    const real inf = M<real>::inf();
-   const int rounds = b.ms.pr_rounds;
+   const int rounds = b.ms.pr_rounds, n_hot = b.ms.pr_hot;
+   const unsigned long long deg0 = b.ms.pr_deg[0], deg1 = b.ms.pr_deg[1];
    const unsigned long long active_mask = b.ms.live_mask, static_mask = b.ms.static_mask;
-   lds_real_p prs = (lds_real_p)(unsigned int)(unsigned long long) prs_gen;
-   lds_int_p pab = (lds_int_p)(unsigned int)(unsigned long long) pab_gen, pgat = (lds_int_p)(unsigned int)(unsigned long long) pgat_gen;
+   typedef const __attribute__((address_space(3))) orc_v2i * lds_int2_p;
+   lds_real_p pent = (lds_real_p)(unsigned int)(unsigned long long) pent_gen;
+   lds_int2_p pgat = (lds_int2_p)(unsigned int)(unsigned long long) pgat_gen;
 
 #ifdef ORC_COST_TIMERS
    long long ctm_ = clock64();
@@ -195,7 +221,8 @@ __device__ __forceinline__ void cost_tile_pairs(const BT & b, const ModelView<re
 #ifndef ORC_ABLATE_ROT
       // the rounds of the pair list: lane = pair.  The loop is written two rounds deep: round r + 2's entry and round r + 1's
       // centres are read while round r is tested and evaluated (one round at a time a round was two dependent LDS round trips --
-      // entry, then centres -- in front of every range test)
+      // entry, then centres -- in front of every range test).  The first rounds hold the pairs that are always within range
+      // (DevModel::pr_hot): they are evaluated without asking, their spheres' velocity terms fetched with the centres.
       {
          const unsigned int prow32 = (unsigned int)(unsigned long long) prow;      // (LDS addresses are 32 bits)
          auto centres = [&](int ab_, real (& d_)[3])
@@ -207,35 +234,40 @@ __device__ __forceinline__ void cost_tile_pairs(const BT & b, const ModelView<re
             for (int k=0; k<3; k++) d_[k] = pa[k] - pb[k];
          };
          const int last = rounds - 1;
-         int ab = pab[s], gat = pgat[s]; real rsum = prs[s];
-         const int e1 = ((1 < last) ? 1 : last)*GSL + s;
-         int ab_n = pab[e1], gat_n = pgat[e1]; real rsum_n = prs[e1];
+         PairEnt<real> ent = pair_entry(pent, s);
+         PairEnt<real> ent_n = pair_entry(pent, ((1 < last) ? 1 : last)*GSL + s);
          real d[3];
-         centres(ab, d);
+         centres(ent.ab, d);
          for (int r=0; r<rounds; r++)
          {
+            const bool hot = (r < n_hot);                                   // wave-uniform
+            const int a = ent.ab & 255, bb = (ent.ab >> 8) & 255;
+            const int la4 = gbase4 + (a << 2), lb4 = gbase4 + (bb << 2);
+            real ua[3], ub[3], wa = 0, wb = 0;
+            auto operands = [&]()
+            {
+#pragma unroll
+               for (int k=0; k<3; k++) { ua[k] = bperm(la4, uvec[k]); ub[k] = bperm(lb4, uvec[k]); }
+               wa = bperm(la4, wself); wb = bperm(lb4, wself);
+            };
+            orc_v2i gat = { 0, 0 };
+            if (ORC_PAIR_HOT_EARLY && hot) { operands(); gat = pgat[r*GSL + s]; }
             // a round ahead: the centres; two rounds ahead: the entry (past the last round: the last round's again, unused)
             real d_n[3];
-            centres(ab_n, d_n);
-            const int e2 = ((r + 2 < last) ? r + 2 : last)*GSL + s;
-            const int ab_nn = pab[e2], gat_nn = pgat[e2]; const real rsum_nn = prs[e2];
-            const int a = ab & 255, bb = (ab >> 8) & 255;
+            centres(ent_n.ab, d_n);
+            const PairEnt<real> ent_nn = pair_entry(pent, ((r + 2 < last) ? r + 2 : last)*GSL + s);
+            const real rsum = ent.rsum;
             const real d2 = d[0]*d[0] + d[1]*d[1] + d[2]*d[2];
             const real R = rsum + b.epsilon_self;
             const bool near = wp_ok && (a != bb) && !(d2 > R*R);       // "skip spheres far enough away from us" (mod.cpp:1267-1268)
 #ifdef ORC_ABLATE_ROTF
             const bool evaluate = false;
 #else
-            const bool evaluate = __builtin_amdgcn_ballot_w64(near) != 0ull;      // wave-uniform
+            const bool evaluate = hot || (__builtin_amdgcn_ballot_w64(near) != 0ull);      // wave-uniform
 #endif
             if (evaluate)
             {
-               // both spheres' velocity terms from their lanes
-               const int la4 = gbase4 + (a << 2), lb4 = gbase4 + (bb << 2);
-               real ua[3], ub[3];
-#pragma unroll
-               for (int k=0; k<3; k++) { ua[k] = bperm(la4, uvec[k]); ub[k] = bperm(lb4, uvec[k]); }
-               const real wa = bperm(la4, wself), wb = bperm(lb4, wself);
+               if (!(ORC_PAIR_HOT_EARLY && hot)) { operands(); gat = pgat[r*GSL + s]; }
                real inv_d;
                real dist = sqrt_rsq_pos(near ? d2 : (real)1, &inv_d);
                dist -= rsum;
@@ -256,22 +288,48 @@ __device__ __forceinline__ void cost_tile_pairs(const BT & b, const ModelView<re
                   real inc[3];
 #pragma unroll
                   for (int k=0; k<3; k++) inc[k] = sdi * fma(d[k], wboth, -fma(qa, ua[k], qb * ub[k]));
-                  // lane = sphere: the two pair lanes of this round that add to it and the two that subtract from it (an entry not in
-                  // use names the round's last lane, whose force is an exact zero); all fetches in flight together
-                  real gv[4][3];
+                  // lane = sphere: the pair lanes of this round that add to it, then those that subtract from it, in list order (an
+                  // entry not in use names the round's last lane, whose force is an exact zero); a side's fetches in flight together
+                  const int dg = (int)(((r < 8) ? deg0 : deg1) >> (8*(r & 7))) & 255;      // entries in use over the round: adding | subtracting << 4 (wave-uniform)
+                  const int dp = dg & 15, dm = dg >> 4;
+                  constexpr int GG = ORC_PAIR_GATHER_GROUP;
 #pragma unroll
-                  for (int q=0; q<4; q++)
+                  for (int q0=0; q0<4; q0+=GG)
                   {
-                     const int src = gbase4 + ((gat >> (8*q)) & 255);
+                     if (q0 >= dp) break;
+                     real gv[GG][3];
 #pragma unroll
-                     for (int k=0; k<3; k++) gv[q][k] = bperm(src, inc[k]);
+                     for (int q=0; q<GG; q++)
+                     {
+                        const int src = gbase4 + ((gat.x >> (8*(q0 + q))) & 255);
+#pragma unroll
+                        for (int k=0; k<3; k++) gv[q][k] = bperm(src, inc[k]);
+                     }
+#pragma unroll
+                     for (int q=0; q<GG; q++)
+#pragma unroll
+                        for (int k=0; k<3; k++) f[k] += gv[q][k];
                   }
 #pragma unroll
-                  for (int k=0; k<3; k++) f[k] = (((f[k] + gv[0][k]) + gv[1][k]) - gv[2][k]) - gv[3][k];
+                  for (int q0=0; q0<4; q0+=GG)
+                  {
+                     if (q0 >= dm) break;
+                     real gv[GG][3];
+#pragma unroll
+                     for (int q=0; q<GG; q++)
+                     {
+                        const int src = gbase4 + ((gat.y >> (8*(q0 + q))) & 255);
+#pragma unroll
+                        for (int k=0; k<3; k++) gv[q][k] = bperm(src, inc[k]);
+                     }
+#pragma unroll
+                     for (int q=0; q<GG; q++)
+#pragma unroll
+                        for (int k=0; k<3; k++) f[k] -= gv[q][k];
+                  }
                }
             }
-            ab = ab_n; gat = gat_n; rsum = rsum_n;
-            ab_n = ab_nn; gat_n = gat_nn; rsum_n = rsum_nn;
+            ent = ent_n; ent_n = ent_nn;
 #pragma unroll
             for (int k=0; k<3; k++) d[k] = d_n[k];
          }

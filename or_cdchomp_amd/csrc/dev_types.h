@@ -24,7 +24,7 @@
 #define ORC_LIM_LIST      64      // violated entries the sparse joint-limit rounds handle
 #define ORC_LIM_SCRATCH  (256 + ORC_LIM_LIST*16)   // bytes: 4 wave records + header, entry list
 #define ORC_PAIR_ROUNDS   16      // rounds of the dense self-collision pair list at most (cost_pairs.h): 16 x 32 lanes hold every pair of 32 spheres
-#define ORC_PAIR_DEG      2       // pairs of one round that add to (and that subtract from) one sphere at most
+#define ORC_PAIR_DEG      4       // pairs of one round that add to (and that subtract from) one sphere at most
 
 // one optimized joint, in topological order.  Non-optimized joints are folded
 // into the fixed transforms on the host when the batch is created.
@@ -106,7 +106,8 @@ struct DevModel
    // range (fixed-seed configurations of the robot), so the rounds that are nearly always needed come first and are full.
    int pr_rounds;                                   // rounds in use (0: the robot does not use the list)
    int pr_ab[ORC_PAIR_ROUNDS*32];                   // first lane | second lane << 8; first == second: no pair
-   int pr_gat[ORC_PAIR_ROUNDS*32];                  // for lane s as a SPHERE in round r: the pair lanes (x4: ds_bpermute addresses within the group) whose force it adds (bytes 0, 1) and subtracts (bytes 2, 3); unused: the round's last lane, which never holds a pair
+   int pr_gat[ORC_PAIR_ROUNDS*32*2];                // for lane s as a SPHERE in round r: the pair lanes (x4: ds_bpermute addresses within the group) whose force it adds (the four bytes of word 0) and subtracts (word 1); unused: the round's last lane, which never holds a pair
+   int pr_hot;                                      // the first pr_hot rounds hold a pair that is (nearly) always within range: they are evaluated without asking
    real pr_rsum[ORC_PAIR_ROUNDS*32];                // r_first + r_second
 };
 
@@ -172,7 +173,8 @@ struct ModelScalars
    int nj, floating, tree, Sa, S, Sa_real, placed, GS, base_sph_begin, base_sph_end, jt_scan, n_static;
    int fk_split, fk_nanc, fk_b_begin, pr_rounds;
    unsigned long long live_mask, static_mask;
-   unsigned long long pr_deg;     // 4 bits per round of the pair list: gather entries in use on the adding side (bits 0-1) and on the subtracting side (bits 2-3)
+   unsigned long long pr_deg[2];  // a byte per round of the pair list: gather entries in use on the adding side (low nibble) and on the subtracting side (high nibble)
+   int pr_hot, pad2_;
 };
 struct LdsLayout
 {
@@ -185,7 +187,7 @@ struct LdsLayout
    int sdfs_bytes;         // byte offset of the staged DevSdf[n_sdfs]
    int saff_bytes;         // byte offset of the staged affects masks [Sa]
    int sallow_bytes;       // byte offset of the self-collision partner masks [64] (robots with more than 16 active spheres)
-   int ptab_bytes;         // byte offset of the staged pair list: rsum [entries] reals, then ab [entries], gat [entries] ints (cost_pairs.h)
+   int ptab_bytes;         // byte offset of the staged pair list (cost_pairs.h): entries of { rsum, first | second << 8, pad } (16 bytes in fp64, 8 in fp32), then the gather words [entries][2]
    int total_bytes;
 };
 
@@ -373,7 +375,7 @@ inline LdsLayout lds_layout(int np, int n, int Sa, int S, int nj, int tile_m, in
    L.saff_bytes = bytes;   bytes += Sa * 8;
    L.sallow_bytes = bytes; bytes += (Sa > 16) ? 64 * 8 : 0;
    bytes = (bytes + 15) & ~15;
-   L.ptab_bytes = bytes;   bytes += pair_entries * (real_size + 8);
+   L.ptab_bytes = bytes;   bytes += pair_entries * (2 * real_size + 8);
    if (alias) L.lim_bytes = ORC_LDS_HEADER + (L.pos + work_reals) * real_size;
    else { L.lim_bytes = bytes; bytes += ORC_LIM_SCRATCH; }
    L.total_bytes = ((g_global || t_staged) && !alias) ? (1 << 30) : bytes;      // G (and the staged trajectory) in the tile buffers need tiles that hold them

@@ -283,7 +283,17 @@ def test_workgroup_shape_is_a_module_setting(oracle):
     assert np.allclose(ca, cb, rtol=1e-13, atol=0)
     assert np.array_equal(tc, tb[10:30]) and np.array_equal(cc, cb[10:30]) and np.array_equal(sc, sb[10:30])
     with pytest.raises(RuntimeError, match="workgroup threads must be 0"):
-        mod.set_workgroup_threads(128)
+        mod.set_workgroup_threads(160)
+    # 128 threads: two wavefronts on a run, eight runs per CU (the shape the planner gives TSR-constrained runs of a module whose
+    # launches overlap): the same trajectories
+    mod.set_workgroup_threads(128)
+    h = mod.batch_create(model.name, goals[:40], **kw)
+    ch, sh = mod.batch_iterate(h, 60)
+    th = mod.batch_gettraj(h)
+    mod.batch_destroy(h)
+    mod.set_workgroup_threads(0)
+    assert np.array_equal(sh, sa[:40]) and np.array_equal(th, ta[:40])
+    assert np.allclose(ch, ca[:40], rtol=1e-13, atol=0)
     # the latency shape (eight wavefronts on one run, the whole trajectory in one tile): the same trajectories
     mod.set_workgroup_threads(512)
     d = mod.batch_create(model.name, goals[:24], **kw)
@@ -317,7 +327,20 @@ def test_workgroup_shape_is_a_module_setting(oracle):
     assert np.array_equal(se, sa) and np.array_equal(te, ta)
     assert np.allclose(ce, ca, rtol=1e-13, atol=0)
     with pytest.raises(RuntimeError, match="workgroups per CU must be 0"):
-        mod.set_workgroups_per_cu(3)
+        mod.set_workgroups_per_cu(5)
+    # what the caller does not say the planner chooses from the MODULE's settings: overlapping launches (orc_set_num_streams >= 2)
+    # take the four-per-CU kernels; 3 says "the kernels' own budget" explicitly.  The trajectories do not notice.
+    mod2 = or_cdchomp_amd.Module(0)
+    common.setup_product_wam(mod2)
+    mod2.set_num_streams(2)
+    for budget in (0, 3, 4):
+        mod2.set_workgroups_per_cu(budget)
+        i = mod2.batch_create(model.name, goals[:32], **kw)
+        ci, si = mod2.batch_iterate(i, 60)
+        assert np.array_equal(si, sa[:32]) and np.array_equal(mod2.batch_gettraj(i), ta[:32]), budget
+        assert np.allclose(ci, ca[:32], rtol=1e-13, atol=0)
+        mod2.batch_destroy(i)
+    mod2.close()
 
 
 def test_chunked_iterate_of_a_batch_keeps_aborted_runs_out(oracle, tmp_path):

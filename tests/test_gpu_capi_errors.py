@@ -75,7 +75,7 @@ def test_null_pointers_and_bad_handles_are_error_codes():
     assert L.orc_robot_add_manipulator(h, b"arm", b"m", 999, None) == 1 and "out of range" in _err(mod)
     assert L.orc_robot_set_active_manipulator(h, b"arm", None) == 1
     assert L.orc_robot_set_adjacent_links(h, b"arm", None, 2) == 1
-    assert L.orc_set_workgroup_threads(h, 100) == 1 and L.orc_set_workgroups_per_cu(h, 3) == 1
+    assert L.orc_set_workgroup_threads(h, 100) == 1 and L.orc_set_workgroups_per_cu(h, 5) == 1
     # scene
     assert L.orc_env_add_kinbody_boxes(h, None, 0, None, None) == 1
     assert L.orc_env_add_kinbody_boxes(h, b"box", 2, None, None) == 1 and "null argument" in _err(mod)
