@@ -533,6 +533,9 @@ __device__ __forceinline__ int limit_rounds_wave(PT T_s, PG G_s, PJ jl_s, int m,
 }
 
 
+#ifndef ORC_LIM_SPARSE
+#define ORC_LIM_SPARSE 0       // violated entries up to which a round takes the entry-by-entry form; 0 (default): one or two by the round-2 closed form, more by wave scans.  Measured at 12 on BASELINE configs[3]: +1 % (profiles/r05_ab_experiments.txt), different last bits: not taken
+#endif
 // The joint-limit rounds with the violated columns held in REGISTERS.  A round only changes the
 // columns that have a violated entry (Gjlimit, and with it A^-1 Gjlimit, is zero in every other
 // column), so no column can join the set found after the step, and the rounds need nothing but
@@ -566,38 +569,143 @@ __device__ __forceinline__ int limit_rounds_regs(PT T_s, PJ jl_s, int m, int n, 
 #pragma unroll
       for (int ci=0; ci<NC; ci++) T[ci][r] = valid[r] ? T_s[n + row*n + col[ci]] : (real)0;
    }
-   // violations, and which lanes hold one (per register slot: scalar masks), kept ACROSS the rounds: a round only changes the
-   // columns it applies A^-1 Gjlimit to, so only those are looked at again (round 5: every round looked at all NC x RPL entries,
-   // a third of a round's instructions for the three to five columns a 200-waypoint momentum run has outside its limits)
-   real g[NC][RPL];
-   unsigned long long mk[NC][RPL];
-   int pc[NC];
-   auto refresh = [&](int ci)
-   {
-      int cnt = 0;
-#pragma unroll
-      for (int r=0; r<RPL; r++)
-      {
-         const real t = T[ci][r];
-         real v = M<real>::max_(lo[ci] - t, (real)0) + M<real>::min_(hi[ci] - t, (real)0);
-         v = valid[r] ? v : (real)0;
-         g[ci][r] = v;
-         mk[ci][r] = __ballot(v != (real)0);
-         cnt += __popcll(mk[ci][r]);
-      }
-      pc[ci] = cnt;
-   };
-#pragma unroll
-   for (int ci=0; ci<NC; ci++) refresh(ci);
+   // A round only changes the columns it applies A^-1 Gjlimit to -- those with a violated entry --, so a column that is back
+   // inside its limits stays there for the rest of the call: it is not looked at again (bit c of `open`, wave-uniform)
+   unsigned int open = (1u << NC) - 1u;
    int rounds;
    for (rounds=0; rounds<1000; rounds++)
    {
+      real g[NC][RPL];
+      // violations, and which lanes hold one (per register slot: scalar masks)
+      unsigned long long mk[NC][RPL];
       int total = 0;
 #pragma unroll
-      for (int ci=0; ci<NC; ci++) total += pc[ci];
+      for (int ci=0; ci<NC; ci++)
+      {
+         if (!((open >> ci) & 1u))
+         {
+#pragma unroll
+            for (int r=0; r<RPL; r++) { g[ci][r] = 0; mk[ci][r] = 0ull; }
+            continue;
+         }
+         int cnt = 0;
+#pragma unroll
+         for (int r=0; r<RPL; r++)
+         {
+            const real t = T[ci][r];
+            real v = M<real>::max_(lo[ci] - t, (real)0) + M<real>::min_(hi[ci] - t, (real)0);
+            v = valid[r] ? v : (real)0;
+            g[ci][r] = v;
+            mk[ci][r] = __ballot(v != (real)0);
+            cnt += __popcll(mk[ci][r]);
+         }
+         if (cnt == 0) open &= ~(1u << ci);
+         total += cnt;
+      }
       if (total == 0) break;                          // nothing violated
+#if ORC_LIM_SPARSE
+      if (dbg) *dbg += (total <= ORC_LIM_SPARSE) ? 1LL : (1LL << 20);       // diagnostics: sparse rounds | scan rounds << 20 | general-loop rounds << 40
+      if (total <= ORC_LIM_SPARSE)
+      {
+         // A few violated entries (nearly every round: a run of neighbouring waypoints of one or two columns): A^-1 Gjlimit from
+         // the closed form of the inverse's columns, x_i = kinv (wq_i P_i + wp_i Q_i) with P_i / Q_i the sums of g wp / g wq over
+         // the violated rows at or before / after row i -- what the wave scans compute, entry by entry instead: the entries are
+         // read out of their lanes (the masks are scalar, the register slot of an entry a compile-time index) and every lane adds
+         // each of them to its rows' sums.  A third of the instructions of a scan round for five entries in two columns.
+         // pass 1: the largest violation; ties to the first row-major index (chomp.c:621-638)
+         real best = 0, best_g = 0; int best_e = 0x7fffffff;
+#pragma unroll
+         for (int ci=0; ci<NC; ci++)
+         {
+            if (!((open >> ci) & 1u)) continue;
+#pragma unroll
+            for (int r=0; r<RPL; r++)
+            {
+               unsigned long long mm = mk[ci][r];
+               while (mm)
+               {
+                  const int ln = __builtin_ctzll(mm); mm &= mm - 1;
+                  const real gk = read_lane(g[ci][r], ln);
+                  const real a = M<real>::fabs_(gk);
+                  const int e = (ln*RPL + r)*n + col[ci];
+                  const bool better = (a > best) || (a == best && e < best_e);
+                  best = better ? a : best; best_g = better ? gk : best_g; best_e = better ? e : best_e;
+               }
+            }
+         }
+         const int ge = __builtin_amdgcn_readfirstlane(best_e);
+         const int gi = ge / n, gc = ge - gi*n;
+         const int owner = gi / RPL, gr = gi - owner*RPL;
+         const real gl = read_lane(best_g, 0);            // (the same in every lane)
+         auto sparse_column = [&](const real (& gc_)[RPL], const unsigned long long (& mc_)[RPL], real (& xo)[RPL])
+         {
+            real P[RPL], Q[RPL];
+#pragma unroll
+            for (int rr=0; rr<RPL; rr++) { P[rr] = 0; Q[rr] = 0; }
+#pragma unroll
+            for (int r=0; r<RPL; r++)
+            {
+               unsigned long long mm = mc_[r];
+               while (mm)
+               {
+                  const int ln = __builtin_ctzll(mm); mm &= mm - 1;
+                  const real gk = read_lane(gc_[r], ln);
+                  const int rowk = ln*RPL + r;
+                  const real gp = gk * (real)(rowk + 1), gq = gk * (real)(m - rowk);
+#pragma unroll
+                  for (int rr=0; rr<RPL; rr++)
+                  {
+                     const bool before = rowk <= lane*RPL + rr;
+                     P[rr] += before ? gp : (real)0;
+                     Q[rr] += before ? (real)0 : gq;
+                  }
+               }
+            }
+#pragma unroll
+            for (int rr=0; rr<RPL; rr++) xo[rr] = kinv * (wq[rr] * P[rr] + wp[rr] * Q[rr]);
+         };
+         // the winner's column first: its entry at the winner is the scale of the round
+         real xw[RPL];
+#pragma unroll
+         for (int rr=0; rr<RPL; rr++) xw[rr] = 0;
+#pragma unroll
+         for (int ci=0; ci<NC; ci++)
+         {
+            if (col[ci] != gc) continue;                  // wave-uniform
+            sparse_column(g[ci], mk[ci], xw);
+         }
+         real ga_sel = 0;
+#pragma unroll
+         for (int rr=0; rr<RPL; rr++) ga_sel = (rr == gr) ? xw[rr] : ga_sel;
+         const real ga = read_lane(ga_sel, owner);
+         const real sc = ((real)1.01 * gl) * rcp_fast(ga);
+#pragma unroll
+         for (int ci=0; ci<NC; ci++)
+         {
+            if (!((open >> ci) & 1u)) continue;           // (a column without a violated entry: A^-1 Gjlimit is zero there)
+            unsigned long long anyc = 0ull;
+#pragma unroll
+            for (int r=0; r<RPL; r++) anyc |= mk[ci][r];
+            if (anyc == 0ull) continue;
+            if (col[ci] == gc)
+            {
+#pragma unroll
+               for (int r=0; r<RPL; r++) T[ci][r] += sc * xw[r];
+            }
+            else
+            {
+               real xc[RPL];
+               sparse_column(g[ci], mk[ci], xc);
+#pragma unroll
+               for (int r=0; r<RPL; r++) T[ci][r] += sc * xc[r];
+            }
+         }
+         continue;
+      }
+#else
       if (dbg) *dbg += (total <= 2) ? 1LL : (1LL << 20);       // diagnostics: closed-form rounds | scan rounds << 20 | general-loop rounds << 40
-      if (total <= 2)
+#endif
+      if (!ORC_LIM_SPARSE && total <= 2)
       {
          // One or two violated entries (nearly every round): A^-1 Gjlimit from the closed form of the
          // inverse's columns, x_i = kinv (wq_i P_i + wp_i Q_i) with P_i / Q_i the sums of g wp / g wq over
@@ -635,6 +743,7 @@ __device__ __forceinline__ int limit_rounds_regs(PT T_s, PJ jl_s, int m, int n, 
          // the largest violation; ties to the first row-major index (chomp.c:621-638)
          const real a0 = M<real>::fabs_(gk[0]), a1 = M<real>::fabs_(gk[1]);
          const bool second = (total == 2) && (a1 > a0 || (a1 == a0 && ek[1] < ek[0]));
+         const int w = second ? 1 : 0;
          const real gl = second ? gk[1] : gk[0];
          const int roww = second ? rowk[1] : rowk[0];
          const int ciw = second ? e_ci[1] : e_ci[0];
@@ -648,6 +757,7 @@ __device__ __forceinline__ int limit_rounds_regs(PT T_s, PJ jl_s, int m, int n, 
          }
          const real ga = kinv * ((real)(m - roww) * Pw + (real)(roww + 1) * Qw);
          const real sc = ((real)1.01 * gl) * rcp_fast(ga);
+         (void) w;
 #pragma unroll
          for (int ci=0; ci<NC; ci++)
          {
@@ -663,7 +773,6 @@ __device__ __forceinline__ int limit_rounds_regs(PT T_s, PJ jl_s, int m, int n, 
                const real x = kinv * (wq[r] * P + wp[r] * Q);
                T[ci][r] += sc * x;
             }
-            refresh(ci);
          }
          continue;
       }
@@ -687,7 +796,7 @@ __device__ __forceinline__ int limit_rounds_regs(PT T_s, PJ jl_s, int m, int n, 
       const real gl = read_lane(best_g, owner);
       // GA = A^-1 Gjlimit by one prefix and one suffix wave scan per column.  The winner's column comes
       // first: its entry at the winner is the scale of the round; then every column with a violated entry
-      // is solved and applied at once (nothing of GA is kept but the winner's column: registers for up to 8 columns x 4 rows)
+      // is solved and applied at once (nothing of GA is kept: registers for up to 8 columns x 4 rows)
       auto scan_column = [&](const real (& gc_)[RPL], real (& xo)[RPL])
       {
          real sp = 0, sq = 0;
@@ -707,13 +816,11 @@ __device__ __forceinline__ int limit_rounds_regs(PT T_s, PJ jl_s, int m, int n, 
          }
       };
       real ga_mine = 0;
-      real xw[RPL];
-#pragma unroll
-      for (int r=0; r<RPL; r++) xw[r] = 0;
 #pragma unroll
       for (int ci=0; ci<NC; ci++)
       {
          if (col[ci] != gc) continue;                  // wave-uniform
+         real xw[RPL];
          scan_column(g[ci], xw);
 #pragma unroll
          for (int r=0; r<RPL; r++) ga_mine = (lane*RPL + r == gi) ? xw[r] : ga_mine;
@@ -724,21 +831,14 @@ __device__ __forceinline__ int limit_rounds_regs(PT T_s, PJ jl_s, int m, int n, 
       for (int ci=0; ci<NC; ci++)
       {
          // a column without a violated entry in this round: A^-1 Gjlimit is zero there (wave-uniform)
-         if (pc[ci] == 0) continue;
-         if (col[ci] == gc)
-         {
-            // (the winner's column was solved for the scale already)
+         unsigned long long anyc = 0ull;
 #pragma unroll
-            for (int r=0; r<RPL; r++) T[ci][r] += sc * xw[r];
-         }
-         else
-         {
-            real xc[RPL];
-            scan_column(g[ci], xc);
+         for (int r=0; r<RPL; r++) anyc |= mk[ci][r];
+         if (anyc == 0ull) continue;
+         real xc[RPL];
+         scan_column(g[ci], xc);
 #pragma unroll
-            for (int r=0; r<RPL; r++) T[ci][r] += sc * xc[r];
-         }
-         refresh(ci);
+         for (int r=0; r<RPL; r++) T[ci][r] += sc * xc[r];
       }
    }
 #pragma unroll
