@@ -146,6 +146,12 @@ int orc_robot_set_self_check(orc_module * mod, const char * name, int enabled);
  * in the kinbody frame, half_extents [n_boxes][3] */
 int orc_env_add_kinbody_boxes(orc_module * mod, const char * name, int n_boxes,
    const double * box_poses, const double * half_extents);
+/* a kinbody given as a triangle mesh (KinBody::InitFromTrimesh; the reference's own scene is meshes, scripts/test_wam7.py:23-28):
+ * vertices [n_tri][3][3] in the kinbody frame.  computedistancefield sweeps its cube against the triangles (the collision
+ * query of src/orcdchomp_mod.cpp:462-531; a mesh is a surface, the flood fill of 540-548 closes its inside; touching counts as
+ * a collision so that a closed mesh gives a closed shell of cells).  Called for an existing kinbody of boxes the triangles are
+ * added to it. */
+int orc_env_add_kinbody_trimesh(orc_module * mod, const char * name, int n_tri, const double * vertices);
 /* KinBody::SetTransform.  A kinbody the robot holds is moved there and rides with its link from there on (the grab's
  * relative transform is taken anew; passing the pose orc_body_get_transform returns changes nothing) */
 int orc_kinbody_set_transform(orc_module * mod, const char * name, const double pose[7]);
@@ -275,6 +281,9 @@ int orc_host_flood_fill(const int sizes[3], double * cells, size_t start);
  * stand-in for OpenRAVE's CheckCollision): occupancy_out gets HUGE_VAL where it touches, 1.0 elsewhere */
 int orc_host_voxelize_boxes(const int sizes[3], const double lengths[3], const double pose_world_gsdf[7], double cube_extent,
    int n_boxes, const double * box_world_poses, const double * half_extents, double * occupancy_out);
+/* ... and of a triangle mesh (world_vertices [n_tri][3][3]): HUGE_VAL where the cube touches a triangle */
+int orc_host_voxelize_trimesh(const int sizes[3], const double lengths[3], const double pose_world_gsdf[7], double cube_extent,
+   int n_tri, const double * world_vertices, double * occupancy_out);
 /* tokenizer of the command grammar: replaces cd_util_shparse (src/libcd/util_shparse.c:37-128).
  * tokens are written NUL-separated into out; returns the token count or -1 if out is too small */
 int orc_host_shparse(const char * in, char * out, size_t out_cap);

@@ -55,6 +55,7 @@ SYMBOLS = [
     ("orc_robot_set_active_manipulator", C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),
     ("orc_robot_set_self_check", C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     ("orc_env_add_kinbody_boxes", C.c_int, [C.c_void_p, C.c_char_p, C.c_int, c_double_p, c_double_p]),
+    ("orc_env_add_kinbody_trimesh", C.c_int, [C.c_void_p, C.c_char_p, C.c_int, c_double_p]),
     ("orc_kinbody_set_transform", C.c_int, [C.c_void_p, C.c_char_p, c_double_p]),
     ("orc_kinbody_enable", C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     ("orc_body_get_transform", C.c_int, [C.c_void_p, C.c_char_p, c_double_p]),
@@ -85,6 +86,7 @@ SYMBOLS = [
     ("orc_host_flood_fill", C.c_int, [c_int_p, c_double_p, C.c_size_t]),
     ("orc_host_voxelize_boxes", C.c_int, [c_int_p, c_double_p, c_double_p, C.c_double, C.c_int, c_double_p, c_double_p,
                                           c_double_p]),
+    ("orc_host_voxelize_trimesh", C.c_int, [c_int_p, c_double_p, c_double_p, C.c_double, C.c_int, c_double_p, c_double_p]),
     ("orc_host_shparse", C.c_int, [C.c_char_p, C.c_char_p, C.c_size_t]),
     ("orc_host_metric", C.c_int, [C.c_int, C.c_int, C.c_double, c_double_p, c_double_p, c_double_p, c_double_p,
                                   c_double_p, C.c_int, c_double_p]),

@@ -279,6 +279,27 @@ int orc_env_add_kinbody_boxes(orc_module * mod, const char * name, int n_boxes, 
    });
 }
 
+int orc_env_add_kinbody_trimesh(orc_module * mod, const char * name, int n_tri, const double * vertices)
+{
+   return guarded(mod, [&] {
+      if (n_tri < 1) throw std::runtime_error("a mesh needs at least one triangle!");
+      need(vertices, "vertices");
+      for (int i=0; i<9*n_tri; i++) if (!std::isfinite(vertices[i])) throw std::runtime_error("mesh vertices must be finite numbers!");
+      const std::string nm = str(name, "name");
+      if (mod->impl->has_body(nm))
+      {
+         // a kinbody of boxes gets its mesh geometry added (a body may have both kinds); a robot of that name is an error
+         orc::KinBody & k = mod->impl->kinbody(nm);
+         k.tris.insert(k.tris.end(), vertices, vertices + 9*(size_t) n_tri);
+         return;
+      }
+      orc::KinBody k;
+      k.name = nm;
+      k.tris.assign(vertices, vertices + 9*(size_t) n_tri);
+      mod->impl->add_kinbody(k);
+   });
+}
+
 int orc_kinbody_set_transform(orc_module * mod, const char * name, const double pose[7])
 {
    return guarded(mod, [&] { need(pose, "pose"); mod->impl->set_kinbody_transform(str(name, "name"), orc::Pose(pose)); });
@@ -555,6 +576,21 @@ int orc_host_voxelize_boxes(const int sizes[3], const double lengths[3], const d
          for (int q=0; q<3; q++) boxes[k].half[q] = half_extents[3*k+q];
       }
       orc::voxelize_boxes(g, orc::Pose(pose_world_gsdf), cube_extent, boxes);
+      std::memcpy(occupancy_out, g.data.data(), g.ncells() * sizeof(double));
+      return 0;
+   }
+   catch (...) { return 1; }
+}
+
+int orc_host_voxelize_trimesh(const int sizes[3], const double lengths[3], const double pose_world_gsdf[7], double cube_extent,
+   int n_tri, const double * world_vertices, double * occupancy_out)
+{
+   try
+   {
+      orc::Grid g;
+      for (int i=0; i<3; i++) { g.sizes[i] = sizes[i]; g.lengths[i] = lengths[i]; }
+      const std::vector<double> tris(world_vertices, world_vertices + 9*(size_t)(n_tri > 0 ? n_tri : 0));
+      orc::voxelize_boxes(g, orc::Pose(pose_world_gsdf), cube_extent, std::vector<orc::Box>(), tris);
       std::memcpy(occupancy_out, g.data.data(), g.ncells() * sizeof(double));
       return 0;
    }

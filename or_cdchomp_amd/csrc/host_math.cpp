@@ -1,5 +1,6 @@
 // host_math.cpp -- see host_math.h
 #include "host_math.h"
+#include "vox_tri.h"
 #include <algorithm>
 #include <cctype>
 #include <cstring>
@@ -323,10 +324,12 @@ bool obb_overlap(const Xform & a, const double ha[3], const Xform & b, const dou
    return true;
 }
 
-void voxelize_boxes(Grid & g, const Pose & pose_world_gsdf, double cube_extent, const std::vector<Box> & obstacles)
+void voxelize_boxes(Grid & g, const Pose & pose_world_gsdf, double cube_extent, const std::vector<Box> & obstacles,
+   const std::vector<double> & tris)
 {
    const double hc[3] = { cube_extent, cube_extent, cube_extent };
    const size_t nc = g.ncells();
+   const size_t n_tris = tris.size() / 9;
    g.data.assign(nc, 1.0);
    for (size_t idx=0; idx<nc; idx++)
    {
@@ -334,8 +337,12 @@ void voxelize_boxes(Grid & g, const Pose & pose_world_gsdf, double cube_extent, 
       g.center(idx, pc.v);
       const Pose pw = pose_compose(pose_world_gsdf, pc);
       const Xform xc = xform_from_pose(pw);
+      bool hit = false;
       for (const Box & b : obstacles)
-         if (obb_overlap(xc, hc, b.world, b.half, 1e-9)) { g.data[idx] = HUGE_VAL; break; }
+         if (obb_overlap(xc, hc, b.world, b.half, 1e-9)) { hit = true; break; }
+      for (size_t k=0; k<n_tris && !hit; k++)
+         if (orc_cube_tri_touch(xc.R.m, xc.t, cube_extent, &tris[9*k], 1e-9)) hit = true;
+      if (hit) g.data[idx] = HUGE_VAL;
    }
 }
 

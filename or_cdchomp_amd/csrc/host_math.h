@@ -72,7 +72,9 @@ bool obb_overlap(const Xform & a, const double ha[3], const Xform & b, const dou
 // occupancy of a grid rooted at pose_world_gsdf: a cube of half-extent cube_extent is swept over the
 // cell centres (src/orcdchomp_mod.cpp:462-531, OpenRAVE's CheckCollision replaced by the box-box
 // test above): HUGE_VAL where it touches a box, 1.0 elsewhere.  g.data is overwritten.
-void voxelize_boxes(Grid & g, const Pose & pose_world_gsdf, double cube_extent, const std::vector<Box> & obstacles);
+// ... and where it touches a triangle (vox_tri.h: a mesh is a surface; touching counts); tris: 9 doubles each, world coordinates
+void voxelize_boxes(Grid & g, const Pose & pose_world_gsdf, double cube_extent, const std::vector<Box> & obstacles,
+   const std::vector<double> & tris = std::vector<double>());
 
 // --------------------------------------------------------------- metric ---
 // Band form of the smoothness metric of cd_chomp_add_KEs / cd_chomp_init

@@ -15,7 +15,7 @@
 hipError_t orc_sdf_from_occupancy_device(const double * occ, double * sdf_out, const int sizes[3], const double lengths[3],
    hipStream_t st);
 hipError_t orc_sdf_build_device(const int sizes[3], const double lengths[3], const double grid_xform[12], const double grid_pose[7],
-   double cube_extent, int n_boxes, const double * boxes, double * sdf_out, hipStream_t st);
+   double cube_extent, int n_boxes, const double * boxes, int n_tris, const double * tris, double * sdf_out, hipStream_t st);
 
 namespace orc {
 
@@ -610,6 +610,14 @@ std::string Module::cmd_computedistancefield(const std::vector<std::string> & ar
    if (kinbodies_.count(kb))
    {
       const KinBody & k = kinbodies_[kb];
+      if (k.enabled) for (size_t v=0; v<k.tris.size()/3; v++)      // (a mesh: the box around its vertices)
+         for (int r=0; r<3; r++)
+         {
+            const double c = k.tris[3*v + r];
+            if (!init) { amin[r] = c; amax[r] = c; }
+            else { if (amin[r] > c) amin[r] = c; if (amax[r] < c) amax[r] = c; }
+            if (r == 2) init = true;
+         }
       if (k.enabled) for (const KinBody::B & bx : k.boxes)
       {
          const Xform x = xform_from_pose(bx.pose);
@@ -668,11 +676,18 @@ std::string Module::cmd_computedistancefield(const std::vector<std::string> & ar
       // (mod.cpp:462-531; OpenRAVE's CheckCollision replaced by a box-box test)
       const Pose pose_world_gsdf = pose_compose(body_transform(kb), pose_gsdf);
       std::vector<Box> obstacles;
+      std::vector<double> tris;                                            // 9 doubles per triangle, world coordinates
       for (auto & kv : kinbodies_)
       {
          const KinBody & k = kv.second;
          if (!k.enabled) continue;
          const Xform xk = xform_from_pose(body_transform(kv.first));      // (a held body is where its link is NOW)
+         for (size_t v=0; v<k.tris.size()/3; v++)
+         {
+            double w[3];
+            mat3_vec(xk.R, &k.tris[3*v], w);
+            for (int r=0; r<3; r++) tris.push_back(w[r] + xk.t[r]);
+         }
          for (const KinBody::B & bx : k.boxes)
          {
             Box b;
@@ -700,12 +715,12 @@ std::string Module::cmd_computedistancefield(const std::vector<std::string> & ar
          double gx[12];
          for (int q=0; q<9; q++) gx[q] = xg.R.m[q];
          for (int q=0; q<3; q++) gx[9+q] = xg.t[q];
-         hip_check(orc_sdf_build_device(g.sizes, g.lengths, gx, pose_world_gsdf.v, cube_extent, (int) obstacles.size(), bx.data(),
+         hip_check(orc_sdf_build_device(g.sizes, g.lengths, gx, pose_world_gsdf.v, cube_extent, (int) obstacles.size(), bx.data(), (int)(tris.size() / 9), tris.data(),
                                         g.data.data(), stream), "sdf build");
       }
       else
       {
-         voxelize_boxes(g, pose_world_gsdf, cube_extent, obstacles);
+         voxelize_boxes(g, pose_world_gsdf, cube_extent, obstacles, tris);
          grid_flood_1_to_0(g, 0);                                                   // mod.cpp:540-548
          const size_t nc = g.ncells();
          for (size_t idx=0; idx<nc; idx++) if (g.data[idx] == 1.0) g.data[idx] = HUGE_VAL;

@@ -57,13 +57,14 @@ struct Robot                      // what the path reads from an OpenRAVE::Robot
    void fk(const Pose & base, const std::vector<double> & q, std::vector<Xform> & frames) const;
 };
 
-struct KinBody                    // box-only kinbody (InitFromBoxes style)
+struct KinBody                    // a kinbody of oriented boxes (InitFromBoxes style) and / or triangles (a mesh: KinBody::InitFromTrimesh, the .iv files of the reference's scene)
 {
    std::string name;
    Pose transform;
    bool enabled = true;
    struct B { Pose pose; double half[3]; };
    std::vector<B> boxes;
+   std::vector<double> tris;      // 9 doubles per triangle, in the kinbody frame
    // <orcdchomp><spheres> of the kinbody (src/orcdchomp_kdata.cpp:79-94), in its own frame (one link): what create
    // reads from a body the robot holds (src/orcdchomp_mod.cpp:2173-2211); `link` is unused
    std::vector<Robot::Sphere> spheres;

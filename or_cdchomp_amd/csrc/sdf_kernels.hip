@@ -12,6 +12,8 @@
 
 #pragma clang fp contract(off)
 
+#include "vox_tri.h"
+
 namespace {
 
 __global__ void edt_lines_kernel(double * data, int n, long stride, long n_outer, long n_inner, double res2,
@@ -117,7 +119,7 @@ struct VoxGrid
    double cube;
 };
 
-__global__ void voxelize_kernel(double * cells, VoxGrid g, const VoxBox * boxes, int n_boxes)
+__global__ void voxelize_kernel(double * cells, VoxGrid g, const VoxBox * boxes, int n_boxes, const double * tris, int n_tris)
 {
    const long count = (long) g.size[0] * g.size[1] * g.size[2];
    const long idx = blockIdx.x * (long) blockDim.x + threadIdx.x;
@@ -136,6 +138,9 @@ __global__ void voxelize_kernel(double * cells, VoxGrid g, const VoxBox * boxes,
    double v = 1.0;
    for (int k=0; k<n_boxes; k++)
       if (obb_overlap_dev(g.R, at, hc, boxes[k], 1e-9)) { v = HUGE_VAL; break; }
+   // ... and against every triangle of the kinbodies given as meshes (vox_tri.h: the host path's own function)
+   for (int k=0; k<n_tris && v == 1.0; k++)
+      if (orc_cube_tri_touch(g.R, at, g.cube, tris + 9*(long) k, 1e-9)) v = HUGE_VAL;
    cells[idx] = v;
 }
 
@@ -206,7 +211,7 @@ hipError_t sq_edt_device(double * d, const int sizes[3], const double lengths[3]
 // boxes -> occupancy -> flood fill -> signed distance field, all on the device; the field comes back
 // to host memory (the module keeps fields on the host: cache file, orc_scene_get_sdf)
 hipError_t orc_sdf_build_device(const int sizes[3], const double lengths[3], const double grid_xform[12], const double grid_pose[7],
-   double cube_extent, int n_boxes, const double * boxes, double * sdf_out, hipStream_t st)
+   double cube_extent, int n_boxes, const double * boxes, int n_tris, const double * tris, double * sdf_out, hipStream_t st)
 {
    const long count = (long) sizes[0] * sizes[1] * sizes[2];
    int maxn = sizes[0]; if (sizes[1] > maxn) maxn = sizes[1]; if (sizes[2] > maxn) maxn = sizes[2];
@@ -230,21 +235,24 @@ hipError_t orc_sdf_build_device(const int sizes[3], const double lengths[3], con
    const size_t z_b = (size_t) maxlines * (maxn + 1) * sizeof(double);
    const size_t f_b = (size_t) maxlines * maxn * sizeof(double);
    const size_t box_b = (size_t)(n_boxes > 0 ? n_boxes : 1) * sizeof(VoxBox);
+   const size_t tri_b = (size_t)(n_tris > 0 ? n_tris : 1) * 9 * sizeof(double);
    char * blob = nullptr;
    int * h_changed = nullptr;
    hipError_t e;
 #define ORC_TRY(x) do { e = (x); if (e != hipSuccess) goto done; } while (0)
-   ORC_TRY(hipMalloc((void **) &blob, 2*cells_b + v_b + z_b + f_b + box_b + 64));
+   ORC_TRY(hipMalloc((void **) &blob, 2*cells_b + v_b + z_b + f_b + box_b + tri_b + 64));
    ORC_TRY(hipHostMalloc((void **) &h_changed, sizeof(int), hipHostMallocDefault));
    {
       double * d_free = (double *) blob; double * d_obs = (double *)(blob + cells_b);
       int * vbuf = (int *)(blob + 2*cells_b); double * zbuf = (double *)(blob + 2*cells_b + v_b);
       double * fbuf = (double *)(blob + 2*cells_b + v_b + z_b);
       VoxBox * d_boxes = (VoxBox *)(blob + 2*cells_b + v_b + z_b + f_b);
-      int * d_changed = (int *)(blob + 2*cells_b + v_b + z_b + f_b + box_b);
+      double * d_tris = (double *)(blob + 2*cells_b + v_b + z_b + f_b + box_b);
+      int * d_changed = (int *)(blob + 2*cells_b + v_b + z_b + f_b + box_b + tri_b);
       static_assert(sizeof(VoxBox) == 15 * sizeof(double), "VoxBox is 15 packed doubles");
       if (n_boxes > 0) ORC_TRY(hipMemcpyAsync(d_boxes, boxes, (size_t) n_boxes * sizeof(VoxBox), hipMemcpyHostToDevice, st));
-      hipLaunchKernelGGL(voxelize_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, d_free, g, d_boxes, n_boxes);
+      if (n_tris > 0) ORC_TRY(hipMemcpyAsync(d_tris, tris, (size_t) n_tris * 9 * sizeof(double), hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(voxelize_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, d_free, g, d_boxes, n_boxes, d_tris, n_tris);
       ORC_TRY(hipGetLastError());
       hipLaunchKernelGGL(flood_start_kernel, dim3(1), dim3(1), 0, st, d_free, 0L);
       ORC_TRY(hipGetLastError());

@@ -149,6 +149,13 @@ class Module:
         if transform is not None:
             self.set_kinbody_transform(name, transform)
 
+    def add_kinbody_trimesh(self, name, triangles, transform=None):
+        """triangles: [n][3][3] vertices in the kinbody frame (KinBody::InitFromTrimesh); added to a kinbody of that name if there is one"""
+        tri = _f64(triangles).reshape(-1, 9)
+        self._check(self._lib.orc_env_add_kinbody_trimesh(self._h, name.encode(), len(tri), _dp(tri)))
+        if transform is not None:
+            self.set_kinbody_transform(name, transform)
+
     def set_kinbody_transform(self, name, pose):
         self._check(self._lib.orc_kinbody_set_transform(self._h, name.encode(), _dp(_f64(pose))))
 
