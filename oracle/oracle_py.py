@@ -434,3 +434,32 @@ def batch_run(robot, base_pose, dofvals, adofindices, adofgoals, grids, poses_wo
                                   dp(goals), bg, len(grids), gp, dp(poses), C.byref(params), sd, n_iter,
                                   dp(traj), dp(costs), ip(status), max_threads)
     return traj, costs, status, threads
+
+
+def reference_sphere_list(bodies):
+    """TEST INFRASTRUCTURE: the order of a run's sphere list as mod::create builds it (src/orcdchomp_mod.cpp:2168-2300), restated
+    literally with Python lists.  bodies: the robot first, then the grabbed kinbodies in GetGrabbed() order; each a dict with
+      xml     the <orcdchomp> spheres' ids in the order of the XML file,
+      group   the ids of the "spheres" geometry-group spheres in (link index, geometry index) order (OpenRAVE >= 0.9, :2214-2259),
+      active  the set of ids on links an active dof moves (:2266-2271).
+    Returns (ids of the list from its head: active ones, then the inactive ones appended, :2299)."""
+    run_list = []            # r->spheres, head first
+    inactive = []            # s_inactive_head, head first
+    for body in bodies:
+        # the kdata list was built by head insertion while the XML was parsed (src/orcdchomp_kdata.cpp:90-94)
+        kdata = []
+        for sid in body["xml"]:
+            kdata.insert(0, sid)
+        k_spheres = []
+        for sid in kdata:                        # :2178-2211  for (sel=d->sphereelems; sel; sel=sel->next) ... push_back
+            k_spheres.append(sid)
+        for sid in body.get("group", []):       # :2216-2259  links in index order, geometries in index order ... push_back
+            k_spheres.append(sid)
+        if not k_spheres:
+            raise RuntimeError("no spheres! kinbody does not have a <orcdchomp> tag defined?")      # :2262-2263
+        for sid in k_spheres:                    # :2265-2291
+            if sid in body["active"]:
+                run_list.insert(0, sid)          # "active; insert at head of r->spheres"
+            else:
+                inactive.insert(0, sid)          # "inactive; insert into s_inactive_head"
+    return run_list + inactive                   # :2299

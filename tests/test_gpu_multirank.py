@@ -62,3 +62,34 @@ def test_bench_starts_its_own_two_ranks_and_gathers(tmp_path):
         with open(os.path.join(keep, "r04_rehearsal_2ranks_gloo.json"), "w") as f:
             json.dump({"command": "python bench.py --gpus 2 --backend gloo --batch 512 --steps 2 --warmup 1 --no-cpu-baseline",
                        "line": line, "gathered_equals_single_process_batch": True}, f, indent=1)
+
+
+def test_in_process_shards_on_distinct_devices():
+    """orc_module_new_multi over DISTINCT ordinals (one shard, one stream and one host thread per physical GPU): skipped
+    on a box with one card, so that the first 8-GPU box the suite meets exercises the per-device replicas and the
+    hipSetDevice-per-thread paths that ordinal 0 repeated cannot.  Bars: the sharded batch equals the single-device batch bit for
+    bit (trajectories, costs, status), for the 16-lane family, the pair-list family (a held body) and an hmc run."""
+    import torch
+    n_dev = torch.cuda.device_count()
+    if n_dev < 2:
+        pytest.skip("needs at least two GPUs (this box has %d)" % n_dev)
+    import numpy as np
+    import common
+    import or_cdchomp_amd
+    devs = list(range(min(n_dev, 8)))
+    n_runs = 64 * len(devs) + 5                       # an uneven cut
+    cases = [("wam", dict(common.CONFIG2_KW), {}), ("held4", dict(common.CONFIG2_KW), {}),
+             ("hmc", dict(common.CONFIG2_KW, use_momentum=1, use_hmc=1, hmc_resample_lambda=0.05), dict(seeds=np.arange(n_runs, dtype=np.uint32)))]
+    for name, kw, extra in cases:
+        out = []
+        for d in (0, devs):
+            mod = or_cdchomp_amd.Module(d)
+            model = common.setup_product_wam_held4(mod)[0] if name == "held4" else common.setup_product_wam(mod)
+            bid = mod.batch_create(model.name, common.wam_goals(n_runs, seed=91), **kw, **extra)
+            costs, status = mod.batch_iterate(bid, 40)
+            out.append((mod.batch_gettraj(bid), costs, status))
+            mod.batch_destroy(bid)
+            mod.close()
+        assert np.array_equal(out[0][2], out[1][2]), name
+        assert np.array_equal(out[0][0], out[1][0]), name
+        assert np.array_equal(out[0][1], out[1][1]), name

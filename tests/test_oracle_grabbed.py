@@ -112,3 +112,45 @@ def test_recheck_sees_the_held_spheres(oracle, wam):
                 found += 1
                 break
     assert found >= 1
+
+
+def test_spheres_geometry_group_order(oracle, wam):
+    """OpenRAVE >= 0.9: a body's spheres are its <orcdchomp> kdata spheres AND the GT_Sphere geometries of the "spheres" group of its
+    links (mod.cpp:2214-2259), appended after them and then pushed onto the head of the run's list: the kdata spheres end in XML
+    order (reversed twice), the group's spheres reversed.  The binding (INTEGRATION.md "Spheres from the spheres geometry group")
+    hands a body's spheres over as ONE array -- the group's last (link, geometry) first, then the kdata spheres in XML order --
+    and that array is the run's order: the literal restatement of the reference's list handling says the same, and the C
+    oracle's list (which takes such an array as "XML order") agrees with it."""
+    m = wam["model"]
+    # ids: the robot's 16 kdata spheres 0..15 in XML order, four group spheres 100..103 on links in index order
+    inactive_links = {m.link_names.index("wam0")}
+    link_of = {i: m.link_names.index(s[0]) for i, s in enumerate(m.spheres)}
+    group = [100, 101, 102, 103]
+    group_link = {100: m.link_names.index("wam0"), 101: m.link_names.index("wam2"), 102: m.link_names.index("wam2"), 103: m.link_names.index("handbase")}
+    link_of.update(group_link)
+    active = {i for i, l in link_of.items() if l not in inactive_links}
+    robot = dict(xml=list(range(16)), group=group, active=active)
+    held = dict(xml=[200, 201], group=[210, 211, 212], active={200, 201, 210, 211, 212})
+    ref = oracle.reference_sphere_list([robot, held])
+    # the binding's rule, body by body: reversed(group) + xml; the last grabbed body first, the robot last; inactive ones behind
+    def binding(body):
+        return list(reversed(body["group"])) + list(body["xml"])
+    want_active = [i for i in binding(held) if i in held["active"]] + [i for i in binding(robot) if i in robot["active"]]
+    want_inactive = [i for i in binding(held) if i not in held["active"]] + [i for i in binding(robot) if i not in robot["active"]]
+    assert ref == want_active + want_inactive, (ref, want_active, want_inactive)
+    assert ref[:5] == [212, 211, 210, 200, 201] and ref[5:8] == [103, 102, 101] and ref[-2:] == [100, 0]
+    # a body without a group: plain XML order (what the oracle and the product were tested with all along)
+    assert oracle.reference_sphere_list([dict(xml=[0, 1, 2], active={0, 1, 2})]) == [0, 1, 2]
+    with pytest.raises(RuntimeError, match="no spheres"):
+        oracle.reference_sphere_list([dict(xml=[], group=[], active=set())])
+    # the C oracle with the robot's array in binding order: its list is that array's active part, then the inactive part
+    import copy
+    model = copy.deepcopy(m)
+    grp = [("wam0", [0.0, 0.0, 0.1], 0.05), ("wam2", [0.0, 0.0, 0.05], 0.04), ("wam2", [0.0, 0.05, 0.0], 0.03), ("handbase", [0.0, 0.0, 0.02], 0.02)]
+    model.spheres = list(reversed(grp)) + list(m.spheres)                 # what collect_spheres of INTEGRATION.md hands over
+    run = oracle.OraRun(oracle.OraRobot(model), wam["base"], wam["q"], list(range(7)), np.zeros(7), [wam["prob"]["sdf"]], [wam["prob"]["pose"]],
+                        oracle.default_params(**KW))
+    order = list(run.sphere_order())                                      # indices into model.spheres
+    ids = [103, 102, 101, 100] + list(range(16))                          # the ids of that array's entries
+    assert [ids[k] for k in order] == [i for i in ref if i < 200], ([ids[k] for k in order], ref)
+    run.destroy()
