@@ -657,8 +657,11 @@ void BatchShard::build_device(const Robot & robot)
    // self-collision pair list (cost_pairs.h).  The spheres keep their sorted order; inactive ones ride on the free lanes.
    bool pairs = false;
    PairTable ptab;
+   const int n_tsrs_in = (int) params.tsrs.size();
    const int asked_block = mod_->workgroup_threads ? mod_->workgroup_threads : params.workgroup_threads;
-   if (sizeof(real) == 8 && M.GS == 32 && !M.tree && M.jt_scan == 1 && !params.free_start && (asked_block == 0 || asked_block == 256 || asked_block == 512)
+   // (ORC_PAIRS16=1: the robots of the 16-lane family too, an experiment: profiles/r05_ab_experiments.txt)
+   if (sizeof(real) == 8 && (M.GS == 32 || (M.GS == 16 && getenv("ORC_PAIRS16") && !M.floating && nj <= 16 && n_tsrs_in == 0)) && !M.tree && M.jt_scan == 1 && !params.free_start
+       && (asked_block == 0 || asked_block == 256 || (asked_block == 512 && M.GS == 32))
        && !getenv("ORC_NO_PAIRS") && !getenv("ORC_NO_KIND") && !getenv("ORC_BLOCK_THREADS"))
    {
       const int ns = getenv("ORC_NO_STATIC_LANES") ? 0 : std::min((int) inact.size(), M.GS - Sa);
@@ -672,7 +675,7 @@ void BatchShard::build_device(const Robot & robot)
    for (int s=0; s<Sa+n_static; s++) slot_of[s] = s;
    int lanes = Sa;
    bool is_placed = false;
-   if (M.GS == 16 && Sa >= 4 && !getenv("ORC_NO_PLACEMENT"))
+   if (M.GS == 16 && Sa >= 4 && !pairs && !getenv("ORC_NO_PLACEMENT"))
    {
       std::vector<int> xml_of(Sa + n_static);
       for (int s=0; s<Sa; s++) xml_of[s] = act[s].xml;
@@ -803,7 +806,7 @@ void BatchShard::build_device(const Robot & robot)
    if (M.GS != 16 && !M.floating && M.jt_scan == (M.tree ? 2 : 1) && !getenv("ORC_NO_KIND") && !pairs)
       tree_ |= 16;                              // many-sphere path: the J^T form is known
    if (pairs) tree_ |= 512 | (M.floating ? 64 : 0);      // the 32-lane family with the dense pair list
-   pair_entries_ = pairs ? ptab.rounds * 32 : 0;
+   pair_entries_ = pairs ? ptab.rounds * M.GS : 0;
 
    hipStream_t st = stream_;
    // TSR hard constraints, folded onto the device's joint order (csrc/tsr.h)

@@ -1091,7 +1091,7 @@ __device__ __forceinline__ Env<real> make_env(const BT & b, unsigned char * smem
    E.saff_s = (unsigned long long *)(smem_raw + L.saff_bytes);
    E.sallow_s = (unsigned long long *)(smem_raw + L.sallow_bytes);
    E.pent_s = (real *)(smem_raw + L.ptab_bytes);
-   E.pgat_s = (int *)(E.pent_s + b.ms.pr_rounds * 32 * 2);
+   E.pgat_s = (int *)(E.pent_s + b.ms.pr_rounds * b.ms.GS * 2);      // (GS = 16 or 32 lanes per round and waypoint)
    ModelView<real> & mod = E.mod;
    mod.nj = nj; mod.n = n; mod.floating = b.ms.floating; mod.tree = b.ms.tree; mod.Sa = Sa; mod.S = S; mod.GS = b.ms.GS; mod.jt_scan = b.ms.jt_scan;
    mod.Sa_real = b.ms.Sa_real; mod.placed = b.ms.placed; mod.live_mask = b.ms.live_mask; mod.slot_of = E.slot_s;
@@ -1176,10 +1176,11 @@ __device__ __attribute__((noinline)) void phase_setup(const void * kp)
 #endif
    for (int e=tid; e<n; e+=BLOCK) { E.jl_s[e] = b.jl_lo[e]; E.jl_s[n+e] = b.jl_hi[e]; }
    if (!GS16)
-      for (int e=tid; e<b.ms.pr_rounds*32; e+=BLOCK)
+      for (int e=tid; e<b.ms.pr_rounds*b.ms.GS; e+=BLOCK)
       {
-         E.pent_s[2*e] = gmod.pr_rsum[e]; *(int *)(E.pent_s + 2*e + 1) = gmod.pr_ab[e];
-         E.pgat_s[2*e] = gmod.pr_gat[2*e]; E.pgat_s[2*e+1] = gmod.pr_gat[2*e+1];
+         const int src = (e / b.ms.GS) * 32 + (e % b.ms.GS);      // (the model's tables have 32 entries per round)
+         E.pent_s[2*e] = gmod.pr_rsum[src]; *(int *)(E.pent_s + 2*e + 1) = gmod.pr_ab[src];
+         E.pgat_s[2*e] = gmod.pr_gat[2*src]; E.pgat_s[2*e+1] = gmod.pr_gat[2*src+1];
       }
    if (b.pcr_in_lds)
       for (int e=tid; e<b.pcr_rows*m; e+=BLOCK) E.pcr_s[e] = b.pcr[e];
@@ -1188,7 +1189,7 @@ __device__ __attribute__((noinline)) void phase_setup(const void * kp)
    if (tid < 8) E.phc_s[tid] = 0;
    __syncthreads();
 
-   if (!GS16 && tid < 64)
+   if (!GS16 && b.ms.pr_rounds == 0 && tid < 64)
    {
       // the spheres a sphere can collide with: active, on another link (src/orcdchomp_mod.cpp:1255-1256)
       unsigned long long allow = 0ull;
@@ -1346,7 +1347,7 @@ __device__ __forceinline__ double phase_cost_body(const void * kp, int ts_in, in
       // 17 .. 32 active spheres on a chain: the dense pair list (KIND 16; 16 | 2 | 8: one field with the world's axes, a fixed
       // base, no inactive sphere left for the loop over them)
       if constexpr ((KIND & 2) != 0) E.mod.floating = 0;
-      cost_tile_pairs<real, BLOCK, KArg<real>, (KIND & 2) != 0, (KIND & 8) != 0>(b, E.mod, ts, te, do_iteration, E.T_s, E.Gc, E.pos_s, E.ax_s, E.srad_s, E.sinact_s,
+      cost_tile_pairs<real, (KIND & 32) ? 16 : 32, BLOCK, KArg<real>, (KIND & 2) != 0, (KIND & 8) != 0>(b, E.mod, ts, te, do_iteration, E.T_s, E.Gc, E.pos_s, E.ax_s, E.srad_s, E.sinact_s,
                                          E.slink_s, E.pent_s, E.pgat_s, inv_eps, inv_eps_self, cost_lane);
    }
    else
@@ -2085,6 +2086,10 @@ static hipError_t launch_iterate_t(const DevBatch<real> & b, size_t lds, hipStre
 #endif
    if constexpr (sizeof(real) == 8)
    {
+#if ORC_FAST_BUILD == 8      // -DORC_FAST_BUILD=8: config 2 with the pair list on 16-lane groups (ORC_PAIRS16=1) beside the row rotations, both budgets
+      if ((variant & 512) && (variant & 2) && (variant & 32) && (variant & 128) && !(variant & 64))
+         return (variant & 256) ? launch_iterate_tt<real, false, false, 256, 58, 4>(b, lds, stream) : launch_iterate_tt<real, false, false, 256, 58>(b, lds, stream);
+#endif
 #if ORC_FAST_BUILD == 7      // -DORC_FAST_BUILD=7: the TSR-constrained WAM (KIND 11) at four 256-thread and eight 128-thread workgroups per CU
       if ((variant & (16 | 2 | 1 | 64)) == (16 | 2) && (variant & 160) == 160)
       {
@@ -2131,6 +2136,15 @@ static hipError_t launch_iterate_t(const DevBatch<real> & b, size_t lds, hipStre
       if constexpr (sizeof(real) == 8)
       {
          const bool lean = (variant & 32) && (variant & 128) && !(variant & 64);      // one aligned field, no inactive sphere left, fixed base
+         if (variant & 2)      // 16 lanes per waypoint (ORC_PAIRS16=1: the experiment of profiles/r05_ab_experiments.txt; the lean kind only)
+         {
+#ifdef ORC_PAIRS16_KERNELS      // (measured -24 % against the row rotations on BASELINE configs[1]: the kernels are not in the product build)
+            if (!lean || (variant & (4 | 8))) return hipErrorInvalidValue;
+            return (variant & 256) ? launch_iterate_tt<real, false, false, 256, 58, 4>(b, lds, stream) : launch_iterate_tt<real, false, false, 256, 58>(b, lds, stream);
+#else
+            return hipErrorInvalidValue;
+#endif
+         }
          if (variant & 4) return hipErrorInvalidValue;      // (no 192-thread shape: batch.cpp keeps such a module on the many-sphere family)
          if (variant & 8) return lean ? launch_iterate_tt<real, false, false, 512, 26>(b, lds, stream) : launch_iterate_tt<real, false, false, 512, 16>(b, lds, stream);
          if (variant & 256) return lean ? launch_iterate_tt<real, false, false, 256, 26, 4>(b, lds, stream) : launch_iterate_tt<real, false, false, 256, 16, 4>(b, lds, stream);

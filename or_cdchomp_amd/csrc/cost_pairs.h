@@ -55,12 +55,13 @@ __device__ __forceinline__ PairEnt<float> pair_entry(const __attribute__((addres
 
 // ONEF: there is one field and its axes are the world's, known at compile time.  NOINACT: no inactive sphere is left for
 // the loop over them (none, or all on free lanes of the group).
-template <typename real, int BLOCK, typename BT, bool ONEF = false, bool NOINACT = false>
+// GSL: lanes per waypoint, 32 (two waypoints per wavefront) or 16 (four: the 16-lane family's robots with the pair list instead of
+// the row rotations, an experiment: ORC_PAIRS16=1, profiles/r05_ab_experiments.txt).
+template <typename real, int GSL, int BLOCK, typename BT, bool ONEF = false, bool NOINACT = false>
 __device__ __forceinline__ void cost_tile_pairs(const BT & b, const ModelView<real> & mod, int ts, int te, bool do_iteration,
    const real * T_s, real * G_s, const real * pos_s, const real * ax_s, const real * srad_s, const real * sinact_s, const int * slink_s,
    const real * pent_gen, const int * pgat_gen, real inv_eps, real inv_eps_self, double & cost_lane)
 {
-   constexpr int GSL = 32;
    typedef const __attribute__((address_space(3))) real * lds_real_p;
    typedef const __attribute__((address_space(3))) int * lds_int_p;
    const int tid = threadIdx.x;
@@ -89,7 +90,7 @@ __device__ __forceinline__ void cost_tile_pairs(const BT & b, const ModelView<re
       // the last round of a tile goes first: it is what the tile's barrier waits for
       if (base_item + BLOCK >= items) __builtin_amdgcn_s_setprio(ORC_PRIO_COST_LAST); else __builtin_amdgcn_s_setprio(ORC_PRIO_COST);
       const int item = base_item + tid;
-      const int wl = item >> 5, s = item & (GSL - 1);
+      const int wl = item / GSL, s = item & (GSL - 1);
       const bool wp_ok = (item < items);
       const bool lane_ok = wp_ok && (((active_mask >> s) & 1ull) != 0);      // an active sphere of a waypoint of the tile
       const int ss = (s < Sa) ? s : 0;             // lanes past the spheres read sphere 0 (valid memory), results masked
@@ -371,9 +372,12 @@ __device__ __forceinline__ void cost_tile_pairs(const BT & b, const ModelView<re
                v += dpp_move<0x102>(v);       // row_shl:2
                v += dpp_move<0x104>(v);       // row_shl:4
                v += dpp_move<0x108>(v);       // row_shl:8
-               const real t16 = read_lane(v, 16), t48 = read_lane(v, 48);
-               v += lower ? ((ln < 32) ? t16 : t48) : (real)0;
-               w6[k] = v;                     // sum over the spheres s .. 31 of this waypoint
+               if constexpr (GSL == 32)
+               {
+                  const real t16 = read_lane(v, 16), t48 = read_lane(v, 48);
+                  v += lower ? ((ln < 32) ? t16 : t48) : (real)0;
+               }
+               w6[k] = v;                     // sum over the spheres s .. GSL-1 of this waypoint
             }
          }
          {
