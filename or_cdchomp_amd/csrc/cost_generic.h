@@ -19,6 +19,14 @@
 //       a fixed summation order.
 #pragma once
 
+#ifndef ORC_SDF_SIGNS
+#define ORC_SDF_SIGNS 1      // 1: which side a one-sided difference looks at is kept as a factor +-1 in a vector register instead of a lane mask in a scalar pair (twelve masks live across the self-collision term spill through v_writelane / v_readlane)
+#endif
+#ifndef ORC_SDF_BATCH
+#define ORC_SDF_BATCH 1      // fields whose cell reads are in flight together (round 3: 4; round 5: 1 -- the first field's reads run under the self-collision term, the others one
+                             // after the other: the registers and lane masks four fields held across that term cost more than the round trips they hid: BASELINE
+                             // configs[4] 257 k -> 234 k vector instructions per run-iteration, 1.78 -> 1.91 M it/s, profiles/r05_ab_experiments.txt)
+#endif
 #ifndef ORC_SDF_DEFER
 #define ORC_SDF_DEFER 1      // the fields' cell reads are used after the self-collision term (0: right after they are issued)
 #endif
@@ -97,9 +105,11 @@ __device__ __forceinline__ void cost_tile_generic(const BT & b, const ModelView<
       // round trip, before the next field's addresses are formed).
       typedef const __attribute__((address_space(4))) DevSdfCell<real> CellDesc;
       CellDesc * fc = (CellDesc *) b.sdfc;
-      real v0[4], vn[4][3], fr[4][3];      // (of the batch of up to four fields in flight)
-      bool prev[4][3], inbq[4];
-      bool use[4] = { false, false, false, false };              // wave-uniform: some sphere of the wavefront is inside the field
+      constexpr int NB = ORC_SDF_BATCH;      // fields in flight together
+      real v0[NB], vn[NB][3], fr[NB][3];      // (of the batch of up to four fields in flight)
+      bool prev[NB][3], inbq[NB];
+      real sg[NB][3];                        // (ORC_SDF_SIGNS: -1 towards the previous cell, +1 towards the next)
+      bool use[NB] = {};              // wave-uniform: some sphere of the wavefront is inside the field
       auto sdf_issue = [&](int i0)
       {
          // The descriptors come by scalar loads in three bursts (the array is padded to whole batches of four, so every
@@ -107,9 +117,9 @@ __device__ __forceinline__ void cost_tile_generic(const BT & b, const ModelView<
          // of the wavefront is inside of being known -- strides and cell pointers of all four; the gradients' matrices
          // in sdf_finish.  A burst per field and stage, as the loop was first written, left the wavefront waiting for
          // eight scalar-cache round trips in a row in front of every waypoint (5.8 k of its 15.6 k cycles).
-         real gx[4][3];
+         real gx[NB][3];
 #pragma unroll
-         for (int q=0; q<4; q++)
+         for (int q=0; q<NB; q++)
          {
             CellDesc & F = fc[i0 + q];
             bool inb = live && (i0 + q < b.n_sdfs);
@@ -125,7 +135,7 @@ __device__ __forceinline__ void cost_tile_generic(const BT & b, const ModelView<
             use[q] = (__builtin_amdgcn_ballot_w64(inb) != 0ull);
          }
 #pragma unroll
-         for (int q=0; q<4; q++)
+         for (int q=0; q<NB; q++)
          {
             CellDesc & F = fc[i0 + q];
             const real m1[3] = { F.fsize_m1[0], F.fsize_m1[1], F.fsize_m1[2] };
@@ -143,6 +153,9 @@ __device__ __forceinline__ void cost_tile_generic(const BT & b, const ModelView<
                fr[q][k] = (g - fl) - (real)0.5;                     // offset from the cell centre, in cells
                // one-sided difference towards the nearer neighbour, inwards at the faces (grid.c:372-389)
                prev[q][k] = (fl == (real)0) ? false : ((fl == m1[k]) ? true : (fr[q][k] < (real)0));
+#if ORC_SDF_SIGNS
+               sg[q][k] = prev[q][k] ? (real)(-1) : (real)1;
+#endif
 #if ORC_LEAN
                off += __mul24((int) fl, sb3[k]);                     // (a full-rate SIGNED 24-bit multiply: cell index and byte stride are below 2^23, checked at create: batch.cpp build_device)
 #else
@@ -165,13 +178,13 @@ __device__ __forceinline__ void cost_tile_generic(const BT & b, const ModelView<
       };
       auto sdf_finish = [&](int i0)
       {
-         real Wq[4][9];                                              // (one burst of scalar loads, see sdf_issue)
+         real Wq[NB][9];                                              // (one burst of scalar loads, see sdf_issue)
 #pragma unroll
-         for (int q=0; q<4; q++)
+         for (int q=0; q<NB; q++)
 #pragma unroll
             for (int k=0; k<9; k++) Wq[q][k] = fc[i0 + q].W[k];
 #pragma unroll
-         for (int q=0; q<4; q++)
+         for (int q=0; q<NB; q++)
          {
             if (i0 + q >= b.n_sdfs || !use[q]) continue;
             bool poisoned = (v0[q] == inf);
@@ -181,7 +194,11 @@ __device__ __forceinline__ void cost_tile_generic(const BT & b, const ModelView<
             {
                poisoned = poisoned || (vn[q][k] == inf);
                const real dd = vn[q][k] - v0[q];
+#if ORC_SDF_SIGNS
+               df[k] = sg[q][k] * dd;                                // after - before (exact: the factor is +-1)
+#else
                df[k] = prev[q][k] ? -dd : dd;                        // after - before
+#endif
                val += df[k] * fr[q][k];
             }
             val = poisoned ? inf : val;
@@ -384,7 +401,7 @@ __device__ __forceinline__ void cost_tile_generic(const BT & b, const ModelView<
 #if ORC_SDF_DEFER
       sdf_finish(0);
 #endif
-      for (int i0=4; i0<b.n_sdfs; i0+=4) { sdf_issue(i0); sdf_finish(i0); }      // (more than four fields: the rest one batch at a time)
+      for (int i0=ORC_SDF_BATCH; i0<b.n_sdfs; i0+=ORC_SDF_BATCH) { sdf_issue(i0); sdf_finish(i0); }      // (more fields than a batch holds: the rest one batch at a time)
 #endif
       {
          const bool on = live && has;
