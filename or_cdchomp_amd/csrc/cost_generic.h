@@ -27,6 +27,9 @@
                              // after the other: the registers and lane masks four fields held across that term cost more than the round trips they hid: BASELINE
                              // configs[4] 257 k -> 234 k vector instructions per run-iteration, 1.78 -> 1.91 M it/s, profiles/r05_ab_experiments.txt)
 #endif
+#ifndef ORC_SDF_BURST
+#define ORC_SDF_BURST 1      // a field's transform and sizes by one burst of scalar loads in front of the in-bounds test
+#endif
 #ifndef ORC_SDF_DEFER
 #define ORC_SDF_DEFER 1      // the fields' cell reads are used after the self-collision term (0: right after they are issued)
 #endif
@@ -122,6 +125,26 @@ __device__ __forceinline__ void cost_tile_generic(const BT & b, const ModelView<
          for (int q=0; q<NB; q++)
          {
             CellDesc & F = fc[i0 + q];
+#if ORC_SDF_BURST
+            // the field's transform and sizes in ONE burst of scalar loads, before anything is tested (written as a chain of
+            // `&&`, the in-bounds test became a ladder of branches with a scalar load and a wait for it on every rung)
+            real Mq[9], tq[3], fsq[3];
+#pragma unroll
+            for (int k=0; k<9; k++) Mq[k] = F.M[k];
+#pragma unroll
+            for (int k=0; k<3; k++) { tq[k] = F.t[k]; fsq[k] = F.fsize[k]; }
+#pragma unroll
+            for (int k=0; k<9; k++) __asm__ volatile("" : "+s"(Mq[k]));
+#pragma unroll
+            for (int k=0; k<3; k++) { __asm__ volatile("" : "+s"(tq[k])); __asm__ volatile("" : "+s"(fsq[k])); }
+            bool inb = live & (i0 + q < b.n_sdfs);
+#pragma unroll
+            for (int k=0; k<3; k++)
+            {
+               gx[q][k] = Mq[k*3+0]*p[0] + Mq[k*3+1]*p[1] + Mq[k*3+2]*p[2] + tq[k];
+               inb = inb & !(gx[q][k] < (real)0) & !(gx[q][k] > fsq[k]);      // the reference's x < 0 || x > 1 (grid.c:196-199)
+            }
+#else
             bool inb = live && (i0 + q < b.n_sdfs);
 #pragma unroll
             for (int k=0; k<3; k++)
@@ -129,6 +152,7 @@ __device__ __forceinline__ void cost_tile_generic(const BT & b, const ModelView<
                gx[q][k] = F.M[k*3+0]*p[0] + F.M[k*3+1]*p[1] + F.M[k*3+2]*p[2] + F.t[k];
                inb = inb && !(gx[q][k] < (real)0) && !(gx[q][k] > F.fsize[k]);      // the reference's x < 0 || x > 1 (grid.c:196-199)
             }
+#endif
             // a field none of the wavefront's spheres is inside of contributes nothing (the reference
             // skips an out-of-bounds lookup, src/orcdchomp_mod.cpp:1176-1183): no cells, no reads
             inbq[q] = inb;
@@ -138,9 +162,16 @@ __device__ __forceinline__ void cost_tile_generic(const BT & b, const ModelView<
          for (int q=0; q<NB; q++)
          {
             CellDesc & F = fc[i0 + q];
-            const real m1[3] = { F.fsize_m1[0], F.fsize_m1[1], F.fsize_m1[2] };
-            const int sb3[3] = { F.stride_b[0], F.stride_b[1], (int) sizeof(real) };
+            real m1[3] = { F.fsize_m1[0], F.fsize_m1[1], F.fsize_m1[2] };
+            int sb3[3] = { F.stride_b[0], F.stride_b[1], (int) sizeof(real) };
             const char * base = (const char *) F.data;
+#if ORC_SDF_BURST > 1
+            // (issued with the first burst's wait still ahead, whether the field is used or not: no scalar-cache round trip behind the test)
+#pragma unroll
+            for (int k=0; k<3; k++) __asm__ volatile("" : "+s"(m1[k]));
+            __asm__ volatile("" : "+s"(sb3[0])); __asm__ volatile("" : "+s"(sb3[1]));
+            __asm__ volatile("" : "+s"(base));
+#endif
             if (!use[q]) continue;
             if (dbg) dbg[5]++;
             int off = 0;
@@ -183,6 +214,12 @@ __device__ __forceinline__ void cost_tile_generic(const BT & b, const ModelView<
          for (int q=0; q<NB; q++)
 #pragma unroll
             for (int k=0; k<9; k++) Wq[q][k] = fc[i0 + q].W[k];
+#if ORC_SDF_BURST > 2
+#pragma unroll
+         for (int q=0; q<NB; q++)
+#pragma unroll
+            for (int k=0; k<9; k++) __asm__ volatile("" : "+s"(Wq[q][k]));
+#endif
 #pragma unroll
          for (int q=0; q<NB; q++)
          {
