@@ -14,6 +14,9 @@
 #define ORC_GS16_CELL 2      // 1: the one-field variants look the field up in cell units with the descriptor in scalar registers; 2: the general 16-lane pass as well (two fields: +3 %)
 #endif
 
+#ifndef ORC_GS16_BURST
+#define ORC_GS16_BURST 1     // round 5: the lean lookup reads its descriptor's scalars in one burst in front of the in-bounds tests
+#endif
 #ifndef ORC_LEAN
 #define ORC_LEAN 1           // round 4: the pass with fewer issue slots (0: the round-3 forms, for A/B builds)
 #endif
@@ -175,18 +178,44 @@ __device__ __forceinline__ bool sdf_lookup_cell_aligned_lean(const CD & F, const
 {
    double fr[3], sgn[3], fl[3];
    bool inb = true;
+#if ORC_GS16_BURST
+   // the descriptor's scalars in one burst in front of the tests (a chain of `&&` makes a ladder of branches with a scalar load and a wait on
+   // every rung: cost_generic.h ORC_SDF_BURST)
+   double Md[3], td[3], fsd[3], fmd[3];
+#pragma unroll
+   for (int k=0; k<3; k++) { Md[k] = F.M[4*k]; td[k] = F.t[k]; fsd[k] = F.fsize[k]; fmd[k] = F.fsize_m1[k]; }
+#pragma unroll
+   for (int k=0; k<3; k++) { __asm__ volatile("" : "+s"(Md[k])); __asm__ volatile("" : "+s"(td[k])); __asm__ volatile("" : "+s"(fsd[k])); __asm__ volatile("" : "+s"(fmd[k])); }
+#if ORC_GS16_BURST > 1
+   // ... the gradient's scale factors too (read where they are used, each was a scalar-cache round trip behind the cell reads)
+   double Wd[3];
+#pragma unroll
+   for (int k=0; k<3; k++) { Wd[k] = F.W[4*k]; __asm__ volatile("" : "+s"(Wd[k])); }
+#endif
+#endif
 #pragma unroll
    for (int k=0; k<3; k++)
    {
+#if ORC_GS16_BURST
+      const double gx = Md[k] * p[k] + td[k];
+      inb = inb & !(gx < 0.0) & !(gx > fsd[k]);
+      double f0 = M<double>::floor_(gx);
+      f0 = M<double>::max_(M<double>::min_(f0, fmd[k]), 0.0);
+#else
       const double gx = F.M[4*k] * p[k] + F.t[k];
       inb = inb && !(gx < 0.0) && !(gx > F.fsize[k]);
       double f0 = M<double>::floor_(gx);
       f0 = M<double>::max_(M<double>::min_(f0, F.fsize_m1[k]), 0.0);
+#endif
       fl[k] = f0;
       fr[k] = (gx - f0) - 0.5;
       // -1: the cell before (previous) is the other end of the difference; +1: the cell after
       const int hi_mid = (fr[k] < 0.0) ? (int) 0xBFF00000 : 0x3FF00000;
+#if ORC_GS16_BURST
+      const int hi_end = (f0 == fmd[k]) ? (int) 0xBFF00000 : hi_mid;
+#else
       const int hi_end = (f0 == F.fsize_m1[k]) ? (int) 0xBFF00000 : hi_mid;
+#endif
       sgn[k] = __hiloint2double((f0 == 0.0) ? 0x3FF00000 : hi_end, 0);
    }
    const double offr = fma(fl[0], F.stride_r[0], fma(fl[1], F.stride_r[1], fl[2] * F.stride_r[2]));
@@ -204,7 +233,11 @@ __device__ __forceinline__ bool sdf_lookup_cell_aligned_lean(const CD & F, const
    {
       poisoned = poisoned || (vn[k] == inf);
       const double df = sgn[k] * (vn[k] - v0);  // after - before
+#if ORC_GS16_BURST > 1
+      gw[k] = Wd[k] * df;
+#else
       gw[k] = F.W[4*k] * df;
+#endif
       v += df * fr[k];
    }
    value = poisoned ? inf : v;
