@@ -69,13 +69,30 @@ if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
     write = c["WRITE_SIZE"]["mean_per_launch"] * 1024
     summary["hbm_bytes_per_launch"] = fetch + write
     entry.update(hbm_bytes_per_launch=fetch + write, fetch_bytes_corrected=fetch, write_bytes=write)
-    # what the bytes are: the results of a launch (trajectories, momentum, costs, trace) are a few MB; everything a launch WRITES
-    # beyond them is register state going to scratch around the phase calls (callee-saved registers, spills), and most of what it
-    # reads is the same bytes coming back
-    results = {2: 8.0 * 1024 * (100 * 7 + 98 * 7 + 3 * 100 + 8), "held4": 8.0 * 1024 * (100 * 7 + 98 * 7 + 3 * 100 + 8)}.get(config)
-    entry["traffic_note"] = ("of the %.2f GB per launch %.2f GB are writes against ~%s of results: scratch traffic of the phase calls' callee-saved "
-                             "registers and spills (and its way back), not the run's state, which stays in LDS; the field sits in L2"
-                             % ((fetch + write) / 1e9, write / 1e9, ("%.0f MB" % (results / 1e6)) if results else "a few MB to tens of MB"))
+    # what the bytes are.  The results of a launch (trajectories, momentum, costs, trace) are a few MB.  The plan of the traced run
+    # (ORC_DEBUG_PLAN line in the log) says where the trajectory T and the cost pass's gradient rows G live: in global memory they
+    # make round trips every iteration (FK reads T, the update phase stages it in and writes it back; the cost pass writes G, the
+    # update phase reads it) -- through L2, of which the counters see what misses and what is written back.  What a launch writes
+    # beyond results and those rows is register state going to scratch around the phase calls (callee-saved registers, spills).
+    plan = None
+    if os.path.exists(log):
+        for line in open(log, errors="replace"):
+            if line.startswith("orc plan:"):
+                plan = line.strip()
+    dims = {2: (100, 7, 8), "held4": (100, 7, 8), "tsr1": (100, 7, 8), "tsr3": (100, 7, 8), 4: (200, 14, 8), 5: (200, 30, 4)}.get(config)
+    state = None
+    if plan and dims:
+        np_, n_, w_ = dims
+        t_glob = " t_in_lds 0" in plan; g_glob = " g_in_lds 0" in plan
+        per_it = (3 * np_ * n_ * w_ if t_glob else 0) + (2 * (np_ - 2) * n_ * w_ if g_glob else 0)
+        state = per_it * batch * n_iter
+    entry["traffic_note"] = ("%.2f GB per launch (%.2f GB of them writes) against a few MB of results.  Plan of the traced run: %s.  "
+                             "By the layout's arithmetic %s; the rest of the writes is register state going to scratch around the phase calls "
+                             "(callee-saved registers, spills) and%s its way back: not algorithmic traffic"
+                             % ((fetch + write) / 1e9, write / 1e9, plan or "not in the log",
+                                ("%.2f GB per launch are the trajectory's and gradient rows' round trips through global memory (3 x T + 2 x G per iteration where the plan keeps them out of LDS)"
+                                 % (state / 1e9)) if state else "the run's state stays in LDS for the launch",
+                                " (for the TSR lines) the constraint step's per-run workspace in global memory, and" if str(config).startswith("tsr") else ""))
     summary["traffic_note"] = entry["traffic_note"]
 if "SQ_INSTS_VALU" in c:
     # the final cost-only pass of a launch is charged to its n_iter iterations
