@@ -66,6 +66,9 @@ __device__ __forceinline__ void sincos_joint(float x, float * sn, float * cs)
    *cs = ((q + 1) & 2) ? -ca : ca;
 }
 
+#ifndef ORC_FK_LAZY64
+#define ORC_FK_LAZY64 1      // fp64: the sphere part of a joint's record is fetched after the frame (0: the whole record, 59 words, in one burst: one scalar-cache round trip per joint instead of two)
+#endif
 #ifndef ORC_FK_AHEAD
 #define ORC_FK_AHEAD 1
 #endif
@@ -255,7 +258,7 @@ __device__ __forceinline__ void fk_waypoint_triad(const ModelView<real> & mod, c
          J = nxt;
          nxt = fk_record<real, true>(mod.fkj + joint_of((idx + 1 < n_steps) ? idx + 1 : idx));      // the next joint's record, a step ahead
       }
-      else J = fk_record<real, false>(mod.fkj + j);
+      else J = fk_record<real, ORC_FK_LAZY64 == 0>(mod.fkj + j);
       if (!own)
       {
          const bool revolute = ((J.ctl >> 24) & 1) != 0;
@@ -273,7 +276,7 @@ __device__ __forceinline__ void fk_waypoint_triad(const ModelView<real> & mod, c
          else if (load_slot == 2) cur = sv2;
          else if (load_slot == 3) cur = sv3;
       }
-      fk_joint_row<real, !AHEAD>(mod, J, mod.fkj + j, cur, qp, sn, cs, valid && own, ax_wp + j*6 + kk, pos_k);
+      fk_joint_row<real, !AHEAD && (ORC_FK_LAZY64 != 0)>(mod, J, mod.fkj + j, cur, qp, sn, cs, valid && own, ax_wp + j*6 + kk, pos_k);
       if (TREE)
       {
          const int save_slot = ((J.ctl >> 20) & 15) - 2;

@@ -77,6 +77,57 @@ std::vector<unsigned char> Robot::self_pairs_excluded() const
    return excl;
 }
 
+// The re-check's self-collision leg for a robot that holds bodies.  OpenRAVE's CheckSelfCollision tests the robot's links
+// against each other (minus adjacent links: self_pairs_excluded, from the ROBOT's own spheres) and every grabbed body against the
+// links it was NOT touching when it was grabbed (the grabbing link is always left out).  For the sphere model: a pair of the
+// robot's own spheres follows the link rule; two spheres of one held body are one rigid body; a held body's sphere against
+// anything else is left out when both ride on the same link, or when the body overlapped that link's own spheres (or that other
+// body) in the configuration the run was created in -- the stand-in for "at the moment of the grab".
+std::vector<unsigned char> Robot::run_self_pairs_excluded(int n_own) const
+{
+   const int ns = (int) spheres.size();
+   std::vector<unsigned char> excl((size_t) ns * ns, 0);
+   Robot own = *this;
+   own.spheres.resize(n_own);
+   const std::vector<unsigned char> link_excl = own.self_pairs_excluded();
+   std::vector<Xform> frames;
+   fk(transform, dof_values, frames);
+   std::vector<double> pw((size_t) ns * 3);
+   for (int a=0; a<ns; a++)
+   {
+      double r[3];
+      mat3_vec(frames[spheres[a].link].R, spheres[a].pos, r);
+      for (int k=0; k<3; k++) pw[(size_t) a*3+k] = r[k] + frames[spheres[a].link].t[k];
+   }
+   auto overlap = [&](int a, int b) {
+      double d2 = 0.0;
+      for (int k=0; k<3; k++) { const double d = pw[(size_t) a*3+k] - pw[(size_t) b*3+k]; d2 += d*d; }
+      return std::sqrt(d2) - (spheres[a].radius + spheres[b].radius) < 0.0;
+   };
+   // a held body's sphere and another sphere belong to the groups (body, any link) and (0, link) / (other body, any link)
+   auto same_group = [&](int a, int b) { return spheres[a].body == spheres[b].body && (spheres[a].body != 0 || spheres[a].link == spheres[b].link); };
+   for (int a=0; a<ns; a++)
+      for (int b=a+1; b<ns; b++)
+      {
+         bool ex;
+         if (spheres[a].body == 0 && spheres[b].body == 0) ex = link_excl[(size_t) spheres[a].link * n_links + spheres[b].link] != 0;
+         else if (spheres[a].body == spheres[b].body) ex = true;
+         else if (spheres[a].link == spheres[b].link) ex = true;
+         else
+         {
+            ex = false;
+            for (int c=0; c<ns && !ex; c++)
+            {
+               if (!same_group(c, a)) continue;
+               for (int d=0; d<ns && !ex; d++) if (same_group(d, b) && overlap(c, d)) ex = true;
+            }
+         }
+         excl[(size_t) a*ns + b] = excl[(size_t) b*ns + a] = ex ? 1 : 0;
+      }
+   for (int a=0; a<ns; a++) excl[(size_t) a*ns + a] = 1;
+   return excl;
+}
+
 void Robot::fk(const Pose & base, const std::vector<double> & q, std::vector<Xform> & frames) const
 {
    frames.resize(n_links);
@@ -374,8 +425,10 @@ Robot Module::robot_for_run(const std::string & rname)
    Robot eff = robot(rname);
    // a body without spheres, the robot itself included (src/orcdchomp_mod.cpp:2262-2263)
    if (eff.spheres.empty()) throw std::runtime_error("no spheres! kinbody does not have a <orcdchomp> tag defined?");
+   int body_index = 0;
    for (const Robot::Grab & g : eff.grabbed)
    {
+      body_index++;
       const KinBody & k = kinbody(g.body);
       if (k.spheres.empty()) throw std::runtime_error("no spheres! kinbody does not have a <orcdchomp> tag defined?");
       for (const Robot::Sphere & ks : k.spheres)
@@ -383,7 +436,7 @@ Robot Module::robot_for_run(const std::string & rname)
          // T_w_rlink^-1 o T_w_klink o pos (mod.cpp:2200-2208); the held body is rigid with its link, so the product of
          // the first two is what the grab recorded
          Robot::Sphere sp;
-         sp.link = g.link; sp.radius = ks.radius;
+         sp.link = g.link; sp.radius = ks.radius; sp.body = body_index;
          mat3_vec(g.rel.R, ks.pos, sp.pos);
          for (int q=0; q<3; q++) sp.pos[q] += g.rel.t[q];
          eff.spheres.push_back(sp);
@@ -423,6 +476,7 @@ int Module::create_batch(const std::string & rname, const BatchParams & p, int n
    }
    std::unique_ptr<Batch> b(new Batch(this, devices_override ? *devices_override : devices, r, p, n_runs, starts, goals, basegoals, seeds));
    b->run_spheres = r.spheres;
+   b->run_self_excl = r.run_self_pairs_excluded((int) robot(rname).spheres.size());
    const int id = next_batch_id_++;
    batches_[id] = std::move(b);
    return id;
@@ -1242,7 +1296,7 @@ void Module::batch_collision_verdict(int id, int * collides, double * time, int 
    if ((int) rob.spheres.size() > 128) throw std::runtime_error("too many spheres for the batched collision verdict!");
    if (self_check && rob.self_check)
    {
-      const std::vector<unsigned char> excl = rob.self_pairs_excluded();
+      const std::vector<unsigned char> & excl = b.run_self_excl;      // sphere by sphere, taken at create (held bodies: Robot::run_self_pairs_excluded)
       const int ns = (int) rob.spheres.size();
       std::vector<int> end_of(ns, 0);
       std::vector<Xform> frames;
@@ -1260,7 +1314,7 @@ void Module::batch_collision_verdict(int id, int * collides, double * time, int 
       for (int a=0; a<ns; a++)
          for (int c=a+1; c<ns; c++)
          {
-            if (excl[(size_t) rob.spheres[a].link * rob.n_links + rob.spheres[c].link]) continue;
+            if (excl[(size_t) a * ns + c]) continue;
             pairs.push_back(end_of[a]); pairs.push_back(end_of[c]); pairs.push_back(a); pairs.push_back(c);
             rsum.push_back(rob.spheres[a].radius + rob.spheres[c].radius);
          }
@@ -1338,7 +1392,8 @@ std::string Module::cmd_gettraj(const std::vector<std::string> & argv, bool batc
       const double step_time = total_dist > 0.0 ? duration * 0.04 / total_dist : duration + 1.0;
       std::vector<Xform> frames;
       std::vector<double> q = rob.dof_values;
-      const std::vector<unsigned char> self_excl = rob.self_pairs_excluded();
+      const std::vector<unsigned char> & self_excl = b.run_self_excl;
+      const size_t n_run_spheres = rob.spheres.size();
       bool collides = false;
       std::ostringstream details;
       int seg = 0; double tseg0 = 0.0;
@@ -1387,7 +1442,7 @@ std::string Module::cmd_gettraj(const std::vector<std::string> & argv, bool batc
             for (size_t c=a+1; c<rob.spheres.size(); c++)
             {
                const Robot::Sphere & sa = rob.spheres[a], & sc = rob.spheres[c];
-               if (self_excl[(size_t) sa.link * rob.n_links + sc.link]) continue;
+               if (self_excl[a * n_run_spheres + c]) continue;
                double pa[3], pc[3], d2 = 0.0;
                mat3_vec(frames[sa.link].R, sa.pos, pa);
                mat3_vec(frames[sc.link].R, sc.pos, pc);

@@ -31,7 +31,7 @@ struct Robot                      // what the path reads from an OpenRAVE::Robot
    int n_dof = 0;
    std::vector<double> limit_lower, limit_upper;
    std::vector<double> limit_vel;   // GetDOFVelocityLimits, used by the retimer of gettraj (default 1)
-   struct Sphere { int link; double pos[3]; double radius; };   // struct sphere, src/orcdchomp_kdata.h:33-39
+   struct Sphere { int link; double pos[3]; double radius; int body = 0; };   // struct sphere, src/orcdchomp_kdata.h:33-39; body: 0 the robot's own, 1 + k a sphere of the k-th grabbed body (robot_for_run)
    std::vector<Sphere> spheres;   // XML order
    // what the TSR constraints address (`con_tsr 'all link NAME'`, `'all manipee NAME'`, src/orcdchomp_mod.cpp:1957-1976)
    std::vector<std::string> link_names;        // GetLink(name); empty: links are addressed as "link<i>"
@@ -53,6 +53,9 @@ struct Robot                      // what the path reads from an OpenRAVE::Robot
    // description declares adjacent, and links whose spheres already overlap with all dofs at zero (KinBody computes
    // its non-adjacent links from the initial configuration the same way)
    std::vector<unsigned char> self_pairs_excluded() const;
+   // ... sphere by sphere for a run's list (the robot's spheres, then those of the bodies it holds, `spheres` as robot_for_run
+   // leaves them, the robot in the configuration of `create`): [n][n], 1 = the pair is never tested
+   std::vector<unsigned char> run_self_pairs_excluded(int n_own) const;
    // world frames of all links for the given state
    void fk(const Pose & base, const std::vector<double> & q, std::vector<Xform> & frames) const;
 };
@@ -254,6 +257,7 @@ public:
    std::vector<int> device_sphere_order;
    std::vector<int> slot_xml;
    std::vector<Robot::Sphere> run_spheres;   // the spheres create collected (robot + held bodies): what the XML indices count through
+   std::vector<unsigned char> run_self_excl; // [n][n] pairs of them the re-check's self-collision leg never tests (Robot::run_self_pairs_excluded, taken at create)
    std::vector<std::unique_ptr<BatchShard>> shards;
    std::vector<int> offs;            // first run of every shard, then n_runs
    bool has_dat() const { return !dat_.empty(); }

@@ -12,6 +12,8 @@
 #endif
 #include "oracle.h"
 
+static void self_pairs(const ora_robot * rob, int ns, const int * link, const double * pos, const double * radius, unsigned char * excl);
+
 /* ------------------------------------------------------------- robot FK */
 
 static void mat3_mul(const double * A, const double * B, double * C)
@@ -118,6 +120,8 @@ struct ora_run              /* src/orcdchomp_mod.cpp:887-966 */
    /* the spheres create collected, robot first, then the grabbed bodies in GetGrabbed() order, each in XML order
     * (xml_index counts through this list); a grabbed body's spheres sit on the grabbing link */
    int * eff_link; double * eff_pos; double * eff_radius;
+   unsigned char * self_excl;   /* [n_eff][n_eff] pairs of them the re-check's self-collision leg never tests, taken at create (run_self_pairs) */
+   int n_eff;
    double * sphere_poss_inactive;
    double * sphere_poss_all;
    double * sphere_poss;
@@ -422,7 +426,7 @@ static void run_free(ora_run * r)
 {
    if (!r) return;
    free(r->traj); free(r->dofvals); free(r->adofindices); free(r->spheres);
-   free(r->eff_link); free(r->eff_pos); free(r->eff_radius);
+   free(r->eff_link); free(r->eff_pos); free(r->eff_radius); free(r->self_excl);
    free(r->sphere_poss_inactive); free(r->sphere_poss_all); free(r->sphere_vels);
    free(r->sphere_accs); free(r->sphere_jacs); free(r->J2); free(r->rsdfs);
    free(r->fkR); free(r->fkt); free(r->fkaxis); free(r->fkanchor);
@@ -677,6 +681,56 @@ ora_run * ora_run_create(const ora_robot * rob, const double base_pose[7], const
          free(R); free(t);
       }
 
+      /* which pairs of them a self-collision check would look at: the stand-in for OpenRAVE's CheckSelfCollision with grabbed
+       * bodies (third party; src/orcdchomp_mod.cpp:2998-2999 calls it).  The robot's own spheres follow the link rule
+       * (self_pairs over the ROBOT's spheres: adjacent links, links that touch with all dofs at zero); two spheres of one held
+       * body are one rigid body; a held body's sphere against anything else is left out when both ride on the same link or when
+       * the body overlapped that link's own spheres (or that other body) in the configuration of create -- OpenRAVE records the
+       * links a body touches at the moment of the grab and ignores them. */
+      {
+         const int nl = rob->n_links;
+         unsigned char * lex = (unsigned char *) malloc((size_t) nl * nl);
+         double * R = (double *) malloc((size_t) nl * 9 * sizeof(double)), * t = (double *) malloc((size_t) nl * 3 * sizeof(double));
+         double * pw = (double *) malloc((size_t) n_eff * 3 * sizeof(double));
+         int a, b2, c, d;
+         self_pairs(rob, rob->n_spheres, rob->sphere_link, rob->sphere_pos, rob->sphere_radius, lex);
+         ora_robot_fk(rob, base_pose, dofvals, R, t, 0, 0);
+         for (a=0; a<n_eff; a++)
+         {
+            mat3_vec(R + 9*r->eff_link[a], r->eff_pos + 3*a, pw + 3*a);
+            for (k=0; k<3; k++) pw[3*a+k] += t[3*r->eff_link[a] + k];
+         }
+         r->n_eff = n_eff;
+         r->self_excl = (unsigned char *) calloc((size_t) n_eff * n_eff, 1);
+#define ORA_SAME_GROUP(x, y) (eff_body[x] == eff_body[y] && (eff_body[x] != 0 || r->eff_link[x] == r->eff_link[y]))
+         for (a=0; a<n_eff; a++)
+         {
+            r->self_excl[a*n_eff + a] = 1;
+            for (b2=a+1; b2<n_eff; b2++)
+            {
+               int ex = 0;
+               if (eff_body[a] == 0 && eff_body[b2] == 0) ex = lex[r->eff_link[a]*nl + r->eff_link[b2]] != 0;
+               else if (eff_body[a] == eff_body[b2]) ex = 1;
+               else if (r->eff_link[a] == r->eff_link[b2]) ex = 1;
+               else
+                  for (c=0; c<n_eff && !ex; c++)
+                  {
+                     if (!ORA_SAME_GROUP(c, a)) continue;
+                     for (d=0; d<n_eff && !ex; d++)
+                     {
+                        double d2 = 0.0;
+                        if (!ORA_SAME_GROUP(d, b2)) continue;
+                        for (k=0; k<3; k++) { const double dd = pw[3*c+k] - pw[3*d+k]; d2 += dd*dd; }
+                        if (sqrt(d2) - (r->eff_radius[c] + r->eff_radius[d]) < 0.0) ex = 1;
+                     }
+                  }
+               r->self_excl[a*n_eff + b2] = r->self_excl[b2*n_eff + a] = (unsigned char) ex;
+            }
+         }
+#undef ORA_SAME_GROUP
+         free(lex); free(R); free(t); free(pw);
+      }
+
       /* active / inactive (2265-2291): is the sphere's robot link moved by an active dof */
       is_active = (int *) malloc((size_t) n_eff * sizeof(int));
       n_act = 0;
@@ -894,7 +948,6 @@ void ora_run_set_traj(ora_run * r, const double * traj) { memcpy(r->traj, traj, 
  * Returns the number of samples walked; *collides 0/1 and the contact's time / XML sphere / field /
  * depth (radius - value). */
 void ora_robot_self_pairs(const ora_robot * rob, unsigned char * excl);
-static void self_pairs(const ora_robot * rob, int ns, const int * link, const double * pos, const double * radius, unsigned char * excl);
 
 int ora_run_collision_recheck(ora_run * r, const double * vmax /* [n_adof] */, int * collides, double * time_out,
    int * sphere_out, int * field_out, double * depth_out)
@@ -966,13 +1019,12 @@ int ora_run_collision_recheck(ora_run * r, const double * vmax /* [n_adof] */, i
       if (!*collides)
       {
          int a, b2;
-         if (!excl) { excl = (unsigned char *) malloc((size_t) r->robot->n_links * r->robot->n_links); self_pairs(r->robot, r->n_spheres, r->eff_link, r->eff_pos, r->eff_radius, excl); }
          for (a=0; a<r->n_spheres && !*collides; a++)
             for (b2=a+1; b2<r->n_spheres; b2++)
             {
                const int la = r->eff_link[a], lb = r->eff_link[b2];
                double pa[3], pb[3], d2 = 0.0, rs, dist;
-               if (la == lb || excl[la * r->robot->n_links + lb]) continue;
+               if (r->self_excl[a * r->n_eff + b2]) continue;      /* (taken at create: run_self_pairs above) */
                mat3_vec(r->fkR + 9*la, r->eff_pos + 3*a, pa);
                mat3_vec(r->fkR + 9*lb, r->eff_pos + 3*b2, pb);
                for (k=0; k<3; k++) { const double d = (pa[k] + r->fkt[3*la+k]) - (pb[k] + r->fkt[3*lb+k]); d2 += d*d; }
@@ -1178,4 +1230,9 @@ int ora_batch_run(const ora_robot * rob, const double base_pose[7], const double
       ora_run_destroy(r);
    }
    return threads;
+}
+
+void ora_run_self_excluded(const ora_run * r, unsigned char * excl)
+{
+   memcpy(excl, r->self_excl, (size_t) r->n_eff * r->n_eff);
 }

@@ -270,6 +270,10 @@ void ora_robot_self_pairs(const ora_robot * rob, unsigned char * excl);
 int ora_run_eval_obstacle(ora_run * r, double * G, double * costs, double * sphere_poss_all);
 /* active-first sphere order: fills idx[n_spheres] with XML indices */
 void ora_run_sphere_order(const ora_run * r, int * idx);
+/* [n][n] (n = the run's spheres, XML order through the robot and the held bodies): 1 = the re-check's self-collision leg never
+ * tests the pair (taken at create: links that are adjacent or touch at the zero pose for the robot's own spheres; a held body
+ * against its holder link and against what it touched in the configuration of create) */
+void ora_run_self_excluded(const ora_run * r, unsigned char * excl);
 
 /* batch driver for the CPU baseline: runs create+iterate for n_runs goals
  * (OpenMP over runs when built with -fopenmp).  traj_out [n_runs][n_points][n],

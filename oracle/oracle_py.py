@@ -134,6 +134,7 @@ def lib():
         L.ora_kin_pose_from_dR.argtypes = [c_double_p, c_double_p, c_double_p]
         L.ora_kin_pose_to_xyzypr.argtypes = [c_double_p, c_double_p]
         L.ora_run_sphere_order.argtypes = [C.c_void_p, c_int_p]
+        L.ora_run_self_excluded.argtypes = [C.c_void_p, C.POINTER(C.c_ubyte)]
         L.ora_batch_run.argtypes = [C.POINTER(Robot), c_double_p, c_double_p, C.c_int, c_int_p, C.c_int,
                                     c_double_p, c_double_p, C.c_int, C.POINTER(C.POINTER(Grid)), c_double_p,
                                     C.POINTER(RunParams), C.POINTER(C.c_uint), C.c_int,
@@ -361,6 +362,12 @@ class OraRun:
         idx = np.zeros(self.S, dtype=np.int32)
         lib().ora_run_sphere_order(self.h, ip(idx))
         return idx
+
+    def self_excluded(self):
+        """[S][S]: pairs of the run's spheres the re-check's self-collision leg never tests"""
+        out = np.zeros((self.S, self.S), dtype=np.uint8)
+        lib().ora_run_self_excluded(self.h, out.ctypes.data_as(C.POINTER(C.c_ubyte)))
+        return out
 
     def destroy(self):
         if self.h:

@@ -393,3 +393,50 @@ def test_computedistancefield_sees_a_held_body_where_its_link_is():
     held.release(model.name, "cup")
     assert same_pose(held.body_transform("cup"), moved)
     for m in (held, put, stale): m.close()
+
+
+def test_recheck_leaves_a_held_body_out_only_against_what_it_touched(scene, oracle):
+    """the self-collision leg of the re-check with a held body (mod.cpp:2998-2999, OpenRAVE's CheckSelfCollision: a grabbed body is
+    tested against the links it did not touch when it was grabbed): the exclusions are taken sphere by sphere at create -- the
+    robot's own link pairs from the robot's own spheres, the body against its holder link and against what it overlaps in that
+    configuration.  Device verdict and oracle agree run by run; a body that reaches the forearm at create is never reported
+    against the forearm, and the robot's own pairs are reported as without it."""
+    s = scene
+    mod = bindings.bind(s["mod"])
+    model = s["model"]
+    vmax = np.ones(model.n_dof)
+    fore = model.link_names.index("wam4")
+    R, t = model.link_frames(s["base"], s["dofvals"])
+    fore_sphere = next(i for i, sp in enumerate(model.spheres) if model.link_names.index(sp[0]) == fore)
+    p_fore = R[fore] @ np.asarray(model.spheres[fore_sphere][1]) + t[fore]
+    pose = list(t[s["hand"]]) + [0, 0, 0, 1]
+    pos = [[0.0, 0.0, 0.1], list(p_fore - t[s["hand"]]), [0.0, 0.12, 0.1]]
+    rad = [0.04, 0.05, 0.04]
+    mod.add_kinbody_boxes("reach", [([0, 0, 0, 0, 0, 0, 1], [0.02, 0.02, 0.02])], transform=pose)
+    mod.set_kinbody_spheres("reach", pos, rad)
+    mod.grab(model.name, "reach", s["hand"])
+    n_runs = 24
+    goals = common.wam_goals(n_runs, seed=53)
+    kw = dict(n_points=40, lambda_=100.0, obs_factor=500.0)
+    bid = mod.batch_create(model.name, goals, **kw)
+    mod.batch_iterate(bid, 20)
+    got = mod.batch_collision_verdict(bid)
+    traj = mod.batch_gettraj(bid)
+    mod.batch_destroy(bid)
+    rob = oracle.OraRobot(model, grabbed=[(s["hand"], pose, pos, rad)])
+    n_self = 0
+    for k in range(n_runs):
+        orun = oracle.OraRun(rob, s["base"], s["dofvals"], s["adofs"], goals[k], [s["prob"]["sdf"]], [s["prob"]["pose"]], oracle.default_params(**kw))
+        ex = orun.self_excluded()
+        orun.set_traj(traj[k])
+        want = orun.collision_recheck(vmax[:7])
+        orun.destroy()
+        assert want["collides"] == got["collides"][k], (k, want, got["sphere"][k], got["field"][k])
+        if want["collides"]:
+            assert want["sphere"] == got["sphere"][k] and want["field"] == got["field"][k], (k, want, got["sphere"][k], got["field"][k])
+            if want["field"] <= -2:
+                n_self += 1
+                assert not ex[want["sphere"], -2 - want["field"]]               # never a pair the rule leaves out
+    link = np.array([model.link_names.index(sp[0]) for sp in model.spheres])
+    assert ex[16:, :16][:, link == fore].all() and ex[16:, :16][:, link == s["hand"]].all()
+    print("re-check with a body that reaches the forearm: %d of %d runs collide, %d of them self collisions" % (got["collides"].sum(), n_runs, n_self))

@@ -154,3 +154,39 @@ def test_spheres_geometry_group_order(oracle, wam):
     ids = [103, 102, 101, 100] + list(range(16))                          # the ids of that array's entries
     assert [ids[k] for k in order] == [i for i in ref if i < 200], ([ids[k] for k in order], ref)
     run.destroy()
+
+
+def test_a_held_body_does_not_change_the_robots_own_link_pairs(oracle, wam):
+    """the self-collision leg of the re-check (mod.cpp:2998-2999): which link pairs of the ROBOT are tested comes from the robot's own
+    spheres; a held body is left out against its holder link and against the links it touches in the configuration of create,
+    and only it -- a fat body that reaches the forearm does not switch off the hand-forearm pairs of the robot's own spheres"""
+    m = wam["model"]
+    hand, fore = m.link_names.index("handbase"), m.link_names.index("wam4")
+    bare = _run(oracle, wam, [])
+    ex0 = bare.self_excluded()
+    n_own = bare.S
+    bare.destroy()
+    # a body in the hand whose second sphere is put onto the forearm's spheres (it touches wam4 at create)
+    R, t, _, _ = oracle.OraRobot(m).fk(wam["base"], wam["q"])
+    fore_sphere = next(i for i, s in enumerate(m.spheres) if m.link_names.index(s[0]) == fore)
+    p_fore = R[fore] @ np.asarray(m.spheres[fore_sphere][1]) + t[fore]
+    pose = list(t[hand]) + [0, 0, 0, 1]
+    held = (hand, pose, [[0, 0, 0.1], list(p_fore - t[hand])], [0.04, 0.05])
+    run = _run(oracle, wam, [held])
+    ex = run.self_excluded()
+    run.destroy()
+    assert ex.shape == (n_own + 2, n_own + 2)
+    assert np.array_equal(ex[:n_own, :n_own], ex0)                              # the robot's own pairs are what they were
+    assert ex[n_own, n_own + 1] == 1                                             # one rigid body
+    link = np.array([m.link_names.index(s[0]) for s in m.spheres])
+    for a in (n_own, n_own + 1):
+        assert ex[a, :n_own][link == hand].all()                                 # never against the link that holds it
+        assert ex[a, :n_own][link == fore].all()                                 # nor against the link it touched at create (either sphere: the BODY touched it)
+    far = [i for i in range(n_own) if link[i] not in (hand, fore) and not ex[n_own + 1, i]]
+    assert len(far) > 0                                                          # but against the links it did not touch
+    # the same body held clear of everything: tested against every link but its holder
+    clear = (hand, list(t[hand] + R[hand] @ np.array([0.0, 0.0, 0.45])) + [0, 0, 0, 1], [[0, 0, 0]], [0.03])
+    run = _run(oracle, wam, [clear])
+    ex = run.self_excluded()
+    run.destroy()
+    assert np.array_equal(ex[n_own, :n_own] == 1, link == hand)
