@@ -985,6 +985,9 @@ __device__ __forceinline__ real smooth_grad(const BT & b, const real * T_s, int 
 
 // 1: the many-sphere cost pass of an iteration is part of the kernel function itself (see the kernel's tile loop);
 // 2: the 16-lane pass as well (no gain measured: it saves 2 callee-saved registers per call); 0: every pass is a call
+#ifndef ORC_UPDATE_BATCH
+#define ORC_UPDATE_BATCH 4     // entries of a thread whose gradient / momentum rows the update phase reads ahead where they live in global memory and a thread has more than four (0: never)
+#endif
 #ifndef ORC_INLINE_COST
 #define ORC_INLINE_COST 1
 #endif
@@ -1283,7 +1286,7 @@ __device__ __forceinline__ void phase_fk_body(const void * kp, int ts_in, int te
       const bool valid = (lane16 < 15) && (w < nfk);
       const int wr = valid ? w : 0;
       fk_waypoint_triad<real, TREE>(E.mod, E.T_s + (ts + wr)*n, n_anc, j_begin, j_end, seg == 0, (lane16 < 15) ? lane16 - 3*triad : 0, valid,
-                                    E.pos_s + wr*E.pstr, E.ax_s + wr*E.astr);
+                                    E.pos_s + wr*E.pstr, E.ax_s + wr*E.astr, !b.t_in_lds);
    }
    __syncthreads();
    phase_mark<real>(b, E, 0);
@@ -1408,6 +1411,33 @@ __device__ __attribute__((noinline)) int phase_update(const void * kp, int it_in
    __builtin_amdgcn_s_setprio(ORC_PRIO_UPDATE);
    if (tid < 2) colmask_s[tid] = 0u;       // read last after the previous step's barrier, set again after the next one
    // G = G/m + A T + B   (chomp.c:492, 515-522)
+#if ORC_UPDATE_BATCH
+   // (four entries of a thread per trip, their gradient rows read first: where the plan keeps the rows in global memory a plain
+   // loop made one round trip through L2 per entry, eleven in a row for a 200-waypoint run of 14 dofs: BASELINE configs[3] +2 %;
+   // for the three entries per thread of a 7 x 100 run it costs 0.7 %: those take the plain loop)
+   const bool batched = ORC_UPDATE_BATCH && mn > 4*BLOCK;      // (workgroup-uniform)
+   if (batched && !b.g_in_lds)
+   for (int e0=tid; e0<mn; e0+=ORC_UPDATE_BATCH*BLOCK)
+   {
+      real gq[ORC_UPDATE_BATCH];
+#pragma unroll
+      for (int q=0; q<ORC_UPDATE_BATCH; q++) { const int e = e0 + q*BLOCK; gq[q] = (e < mn) ? Gc[e] : (real)0; }
+#pragma unroll
+      for (int q=0; q<ORC_UPDATE_BATCH; q++)
+      {
+         const int e = e0 + q*BLOCK;
+         if (e >= mn) break;
+         const int i = div_n(e, rn_f), c = e - i*n;
+         real g = gq[q];
+         g *= b.inv_m;
+         g += smooth_grad<real>(b, T_s, i, c);
+         G_s[e] = g;
+      }
+   }
+   else
+#else
+   const bool batched = false;
+#endif
    for (int e=tid; e<mn; e+=BLOCK)
    {
       const int i = div_n(e, rn_f), c = e - i*n;
@@ -1468,6 +1498,29 @@ __device__ __attribute__((noinline)) int phase_update(const void * kp, int it_in
    else
    {
       const real sc = (leapfrog_first ? (real)0.5 : (real)1) / b.lambda;
+#if ORC_UPDATE_BATCH
+      // (the momentum rows likewise: read four entries ahead where they live in global memory)
+      if (batched && !b.ag_in_lds)
+      for (int e0=tid; e0<mn; e0+=ORC_UPDATE_BATCH*BLOCK)
+      {
+         real aq[ORC_UPDATE_BATCH];
+#pragma unroll
+         for (int q=0; q<ORC_UPDATE_BATCH; q++) { const int e = e0 + q*BLOCK; aq[q] = (e < mn) ? AG_s[e] : (real)0; }
+#pragma unroll
+         for (int q=0; q<ORC_UPDATE_BATCH; q++)
+         {
+            const int e = e0 + q*BLOCK;
+            if (e >= mn) break;
+            const real ag = aq[q] + sc * X[e];
+            AG_s[e] = ag;
+            const real t = T_s[n + e] + step * ag;
+            T_s[n + e] = t;
+            const int c = e - div_n(e, rn_f)*n;
+            viol |= (t < jl_s[c] || t > jl_s[n+c]) ? (1ull << c) : 0ull;
+         }
+      }
+      else
+#endif
       for (int e=tid; e<mn; e+=BLOCK)
       {
          const real ag = AG_s[e] + sc * X[e];

@@ -69,6 +69,9 @@ __device__ __forceinline__ void sincos_joint(float x, float * sn, float * cs)
 #ifndef ORC_FK_LAZY64
 #define ORC_FK_LAZY64 1      // fp64: the sphere part of a joint's record is fetched after the frame (0: the whole record, 59 words, in one burst: one scalar-cache round trip per joint instead of two)
 #endif
+#ifndef ORC_FK_QPRE
+#define ORC_FK_QPRE 3        // trips of the sin/cos loop whose joint values a lane reads ahead when the trajectory lives in global memory (3 cover 9 joints)
+#endif
 #ifndef ORC_FK_AHEAD
 #define ORC_FK_AHEAD 1
 #endif
@@ -180,7 +183,7 @@ __device__ __forceinline__ DevFkJoint<real> fk_record(const __attribute__((addre
 // TREE = the joint tree branches (saved frames).
 template <typename real, bool TREE>
 __device__ __forceinline__ void fk_waypoint_triad(const ModelView<real> & mod, const real * row, int n_anc, int j_begin, int j_end, bool first,
-   int k, bool valid, real * pos_wp, real * ax_wp)
+   int k, bool valid, real * pos_wp, real * ax_wp, bool row_is_global = false)
 {
    const int kk = k;
    real * pos_k = pos_wp + kk;
@@ -212,12 +215,44 @@ __device__ __forceinline__ void fk_waypoint_triad(const ModelView<real> & mod, c
    cur = base;
    if (TREE) { sv0 = base; sv1 = base; sv2 = base; sv3 = base; }
    // the triad's sin/cos of the joints it stores: lane k evaluates joints j_begin + k, + k + 3, ...
+#if ORC_FK_QPRE
+   // (the lane's joint values of the first trips are read before any is used: with the trajectory in global memory every trip
+   // of the loop below began with a round trip through L2)
+   int pk_pre[ORC_FK_QPRE]; real q_pre[ORC_FK_QPRE];
+#pragma unroll
+   for (int tq=0; tq<ORC_FK_QPRE; tq++) { pk_pre[tq] = 0; q_pre[tq] = 0; }
+   if (row_is_global)      // (wave-uniform)
+   {
+#pragma unroll
+   for (int tq=0; tq<ORC_FK_QPRE; tq++)
+   {
+      const int j = j_begin + 3*tq + kk;
+      const int jm = (j < j_end) ? j : j_end - 1;
+      const int jc = (jm < 0) ? 0 : ((jm < mod.nj) ? jm : mod.nj - 1);      // (a walk without joints of its own reads a valid entry it does not use)
+      pk_pre[tq] = mod.jctl[2*jc];
+   }
+#pragma unroll
+   for (int tq=0; tq<ORC_FK_QPRE; tq++) q_pre[tq] = row[(pk_pre[tq] >> 24) & 127];
+   }
+#endif
    for (int j0=j_begin; j0<j_end; j0+=3)
    {
       const int j = j0 + kk;
       const int jm = (j < j_end) ? j : j_end - 1;
+#if ORC_FK_QPRE
+      const int tq_ = (j0 - j_begin) / 3;
+      int pkm; real qm;
+      if (row_is_global && tq_ < ORC_FK_QPRE)
+      {
+         pkm = pk_pre[0]; qm = q_pre[0];
+#pragma unroll
+         for (int tq=1; tq<ORC_FK_QPRE; tq++) { pkm = (tq_ == tq) ? pk_pre[tq] : pkm; qm = (tq_ == tq) ? q_pre[tq] : qm; }
+      }
+      else { pkm = mod.jctl[2*jm]; qm = row[(pkm >> 24) & 127]; }
+#else
       const int pkm = mod.jctl[2*jm];
       real qm = row[(pkm >> 24) & 127];
+#endif
       real snm, csm;
 #ifdef ORC_ABLATE_FKSIN
       snm = qm; csm = (real)1 - qm;

@@ -159,3 +159,34 @@ def test_the_held_body_changes_the_answer_and_release_restores_it(held):
     assert np.array_equal(bare, again)
     ok = h["status"][:64] == 0
     assert max(common.rel_l2(bare[k], h["traj"][k]) for k in np.flatnonzero(ok)) > 1e-4
+
+
+def test_two_fields_take_the_general_kind(held, oracle):
+    """with a second field in the scene (the mug's own) the family's general kind runs (any number of fields, best-of-N lookup,
+    src/orcdchomp_mod.cpp:1171-1196) instead of the one-aligned-field kind: 12 runs against the oracle with both fields"""
+    h = held
+    mod = or_cdchomp_amd.Module(0)
+    model, hand, pose = common.setup_product_wam_held4(mod)
+    mod.SendCommand("computedistancefield kinbody mug aabb_padding 0.15")
+    goals = h["goals"][:12]
+    kw = dict(n_points=60, lambda_=100.0, obs_factor=500.0)
+    bid = mod.batch_create(model.name, goals, **kw)
+    costs, status = mod.batch_iterate(bid, 50)
+    traj = mod.batch_gettraj(bid)
+    mod.batch_destroy(bid)
+    fields, poses = [], []
+    for name in ("table", "mug"):
+        data, lengths, fpose = mod.get_sdf(name)
+        fields.append(oracle.OraGrid(data, list(lengths))); poses.append(list(fpose))     # (the product's own fields: built bit-identically to the oracle's, tests/test_gpu_sdf_fuzz.py)
+    mod.close()
+    _, base, dofvals, adofs = common.wam_state()
+    rob = oracle.OraRobot(model, grabbed=[(hand, pose, common.HELD4_POS, common.HELD4_RAD)])
+    ora = lambda g: oracle.batch_run(rob, base, dofvals, adofs, g, fields, poses, oracle.default_params(**kw), 50)
+    res = ora(goals)
+    amp, stable = common.amplification(ora, goals, res)
+    otraj, ocosts, ost = res[0], res[1], res[2]
+    well = (ost == 0) & (status == 0) & (amp < 1e-9) & stable
+    err = np.array([common.rel_l2(traj[k], otraj[k]) for k in range(len(goals))])
+    assert well.sum() >= 8, (amp, ost, status)
+    assert err[well].max() <= 1e-6, err
+    assert np.allclose(costs[well], ocosts[well], rtol=1e-6, atol=0)
