@@ -536,6 +536,10 @@ __device__ __forceinline__ int limit_rounds_wave(PT T_s, PG G_s, PJ jl_s, int m,
 #ifndef ORC_LIM_SPARSE
 #define ORC_LIM_SPARSE 0       // violated entries up to which a round takes the entry-by-entry form; 0 (default): one or two by the round-2 closed form, more by wave scans.  Measured at 12 on BASELINE configs[3]: +1 % (profiles/r05_ab_experiments.txt), different last bits: not taken
 #endif
+#ifndef ORC_LIM_MASKS
+#define ORC_LIM_MASKS 1        // the register form that looks at lane masks first (limit_regs.h); 0: every slot evaluated in every round (round 2-4)
+#endif
+#include "limit_regs.h"
 // The joint-limit rounds with the violated columns held in REGISTERS.  A round only changes the
 // columns that have a violated entry (Gjlimit, and with it A^-1 Gjlimit, is zero in every other
 // column), so no column can join the set found after the step, and the rounds need nothing but
@@ -547,6 +551,9 @@ __device__ __forceinline__ int limit_rounds_wave(PT T_s, PG G_s, PJ jl_s, int m,
 template <typename real, int NC, int RPL, typename PT, typename PJ>
 __device__ __forceinline__ int limit_rounds_regs(PT T_s, PJ jl_s, int m, int n, real kinv, unsigned long long cols, long long * dbg)
 {
+#if ORC_LIM_MASKS
+   if (!ORC_LIM_SPARSE) return limit_rounds_regs_masks<real, NC, RPL>(T_s, jl_s, m, n, kinv, cols, dbg);
+#endif
    const int lane = threadIdx.x & 63;
    int col[NC]; real lo[NC], hi[NC];
    {
@@ -1425,8 +1432,13 @@ __device__ __attribute__((noinline)) int phase_update(const void * kp, int it_in
 #pragma unroll
       for (int q=0; q<ORC_UPDATE_BATCH; q++)
       {
-         const int e = e0 + q*BLOCK;
+         int e = e0 + q*BLOCK;
          if (e >= mn) break;
+         // (the entry's index is opaque to the compiler from here on: it had split `q*BLOCK` off the index arithmetic into the
+         // instructions' immediate offsets, T_s[c] = *(T_s + (e0 - i n) + q*BLOCK) -- a base BELOW the trajectory for the first
+         // rows; these are FLAT accesses, whose aperture the hardware takes from the base alone: with the trajectory at the
+         // start of LDS the base lay outside the LDS aperture and the access faulted (a 12-dof tree with derivative 2))
+         __asm__ volatile("" : "+v"(e));
          const int i = div_n(e, rn_f), c = e - i*n;
          real g = gq[q];
          g *= b.inv_m;
@@ -1509,8 +1521,9 @@ __device__ __attribute__((noinline)) int phase_update(const void * kp, int it_in
 #pragma unroll
          for (int q=0; q<ORC_UPDATE_BATCH; q++)
          {
-            const int e = e0 + q*BLOCK;
+            int e = e0 + q*BLOCK;
             if (e >= mn) break;
+            __asm__ volatile("" : "+v"(e));      // (as above: no q*BLOCK in the immediate offset of a FLAT access)
             const real ag = aq[q] + sc * X[e];
             AG_s[e] = ag;
             const real t = T_s[n + e] + step * ag;
