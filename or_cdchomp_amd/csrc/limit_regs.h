@@ -18,6 +18,12 @@
 // BASELINE configs[3] makes 1.5 closed-form and 1.3 scan rounds per iteration on up to seven columns x four rows.
 // cols: the columns (ascending); returns the number of rounds made (1000: the caller sets the status).
 #pragma once
+#ifndef ORC_LIM_WAVE_SHIFT
+#define ORC_LIM_WAVE_SHIFT 1     // a scan round takes the neighbour lanes' sums by DPP wave shifts (0: __shfl_up / __shfl_down, two LDS permutes each)
+#endif
+#ifndef ORC_LIM_KEEP_WINNER
+#define ORC_LIM_KEEP_WINNER 1    // a scan round keeps the solved winner's column for the update (0: solves it again)
+#endif
 
 template <typename real, int NC, int RPL, typename PT, typename PJ>
 __device__ __forceinline__ int limit_rounds_regs_masks(PT T_s, PJ jl_s, int m, int n, real kinv, unsigned long long cols, long long * dbg)
@@ -144,6 +150,21 @@ __device__ __forceinline__ int limit_rounds_regs_masks(PT T_s, PJ jl_s, int m, i
          continue;
       }
       if (dbg) *dbg += (1LL << 20);
+#ifdef ORC_LIM_DIAG
+      // diagnostics: how many of the scan rounds have at most two violated entries in every column (counted as "general-loop rounds")
+      {
+         int worst = 0;
+#pragma unroll
+         for (int ci=0; ci<NC; ci++)
+         {
+            int cc = 0;
+#pragma unroll
+            for (int r=0; r<RPL; r++) cc += __popcll(mk[ci][r]);
+            worst = cc > worst ? cc : worst;
+         }
+         if (dbg && worst <= ORC_LIM_DIAG) *dbg += (1LL << 40);
+      }
+#endif
       // More than two: Gjlimit of the slots that hold one, the lane's largest (ties to its first row-major index)
       real g[NC][RPL];
       real best = 0, best_g = 0; int best_e = 0x7fffffff;
@@ -177,8 +198,14 @@ __device__ __forceinline__ int limit_rounds_regs_masks(PT T_s, PJ jl_s, int m, i
 #pragma unroll
          for (int r=0; r<RPL; r++) { sp += gc_[r] * wp[r]; sq += gc_[r] * wq[r]; }
          const real ip = wave_prefix_incl(sp), is = wave_suffix_incl(sq);
+#if ORC_LIM_WAVE_SHIFT
+         // the neighbours' inclusive sums by DPP wave shifts (zero shifted in at the ends) instead of two LDS permutes each
+         real run_p = dpp_move<0x138>(ip);    // wave_shr:1: lane i takes lane i-1
+         real run_q = dpp_move<0x130>(is);    // wave_shl:1: lane i takes lane i+1
+#else
          real run_p = __shfl_up(ip, 1, 64);   if (lane == 0) run_p = 0;
          real run_q = __shfl_down(is, 1, 64); if (lane == 63) run_q = 0;
+#endif
          real q[RPL];
 #pragma unroll
          for (int r=RPL-1; r>=0; r--) { q[r] = run_q; run_q += gc_[r] * wq[r]; }
@@ -190,11 +217,13 @@ __device__ __forceinline__ int limit_rounds_regs_masks(PT T_s, PJ jl_s, int m, i
          }
       };
       real ga_mine = 0;
+      real xw[RPL];
+#pragma unroll
+      for (int r=0; r<RPL; r++) xw[r] = 0;
 #pragma unroll
       for (int ci=0; ci<NC; ci++)
       {
          if (col[ci] != gc) continue;                  // wave-uniform
-         real xw[RPL];
          scan_column(g[ci], xw);
 #pragma unroll
          for (int r=0; r<RPL; r++) ga_mine = (lane*RPL + r == gi) ? xw[r] : ga_mine;
@@ -209,6 +238,24 @@ __device__ __forceinline__ int limit_rounds_regs_masks(PT T_s, PJ jl_s, int m, i
 #pragma unroll
          for (int r=0; r<RPL; r++) anyc |= mk[ci][r];
          if (anyc == 0ull) continue;
+#if ORC_LIM_KEEP_WINNER
+         if (col[ci] == gc)                            // (the winner's column is solved already)
+         {
+#ifdef ORC_LIM_DIAG2
+            {  // diagnostics: the column solved again must give the same bits ("general-loop rounds" counts the rounds where it does not)
+               real xd[RPL];
+               scan_column(g[ci], xd);
+               bool same = true;
+#pragma unroll
+               for (int r=0; r<RPL; r++) same = same && (xd[r] == xw[r] || (xd[r] != xd[r] && xw[r] != xw[r]));
+               if (dbg && __ballot(!same) != 0ull) *dbg += (1LL << 40);
+            }
+#endif
+#pragma unroll
+            for (int r=0; r<RPL; r++) T[ci][r] += sc * xw[r];
+            continue;
+         }
+#endif
          real xc[RPL];
          scan_column(g[ci], xc);
 #pragma unroll
