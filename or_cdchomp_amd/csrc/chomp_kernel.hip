@@ -883,7 +883,11 @@ __device__ __forceinline__ unsigned long long uni64(unsigned long long v)
 __device__ __forceinline__ double unir(double v) { return __longlong_as_double((long long) uni64((unsigned long long) __double_as_longlong(v))); }
 __device__ __forceinline__ float unir(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 
-template <typename real, typename PT>
+#ifndef ORC_LIM_SPLIT
+#define ORC_LIM_SPLIT 1        // the rounds of one or two columns are a function of their own (its register appetite, and with it the callee-saved registers a call saves and restores, is a third of the large cases')
+#endif
+// PART: 0 every case; 1 one or two columns only; 2 three columns and more
+template <typename real, int PART, typename PT>
 __device__ __forceinline__ LimResult limit_rounds_body(PT T_s, real * G_gen, const real * jl_gen, int m_in, int n_in, real kinv_in,
    unsigned long long viol_cols_in)
 {
@@ -897,10 +901,16 @@ __device__ __forceinline__ LimResult limit_rounds_body(PT T_s, real * G_gen, con
    LimResult res; res.rounds = 0; res.kinds = 0;
    long long * dg = &res.kinds;
    const int nc = __popcll(viol_cols);
+   if (PART == 1)
+   {
+      if (nc == 1) res.rounds = limit_rounds_regs_rpl<real, 1>(T_s, jl_s, m, n, kinv, viol_cols, dg);
+      else res.rounds = limit_rounds_regs_rpl<real, 2>(T_s, jl_s, m, n, kinv, viol_cols, dg);
+      return res;
+   }
    switch (nc)
    {
-   case 1: res.rounds = limit_rounds_regs_rpl<real, 1>(T_s, jl_s, m, n, kinv, viol_cols, dg); break;
-   case 2: res.rounds = limit_rounds_regs_rpl<real, 2>(T_s, jl_s, m, n, kinv, viol_cols, dg); break;
+   case 1: if (PART == 0) res.rounds = limit_rounds_regs_rpl<real, 1>(T_s, jl_s, m, n, kinv, viol_cols, dg); break;      // (PART 2 is never called with one or two)
+   case 2: if (PART == 0) res.rounds = limit_rounds_regs_rpl<real, 2>(T_s, jl_s, m, n, kinv, viol_cols, dg); break;
    case 3: res.rounds = limit_rounds_regs_rpl<real, 3>(T_s, jl_s, m, n, kinv, viol_cols, dg); break;
    default:
       // four to eight columns (a trajectory that is leaving its limits for good, the 1000-round
@@ -940,13 +950,27 @@ __device__ __attribute__((noinline)) LimResult limit_rounds_call(real * T_gen, r
    unsigned long long viol_cols)
 {
    typedef __attribute__((address_space(3))) real * lds_ptr;
-   return limit_rounds_body<real>((lds_ptr) T_gen, G_gen, jl_gen, m, n, kinv, viol_cols);
+   return limit_rounds_body<real, ORC_LIM_SPLIT ? 2 : 0>((lds_ptr) T_gen, G_gen, jl_gen, m, n, kinv, viol_cols);
 }
 template <typename real, int SHAPE>
 __device__ __attribute__((noinline)) LimResult limit_rounds_call_global(real * T_gen, real * G_gen, const real * jl_gen, int m, int n, real kinv,
    unsigned long long viol_cols)
 {
-   return limit_rounds_body<real>(T_gen, G_gen, jl_gen, m, n, kinv, viol_cols);
+   return limit_rounds_body<real, ORC_LIM_SPLIT ? 2 : 0>(T_gen, G_gen, jl_gen, m, n, kinv, viol_cols);
+}
+// ... and the same for one or two columns (nearly every call of a 7-dof arm)
+template <typename real, int SHAPE>
+__device__ __attribute__((noinline)) LimResult limit_rounds_call_small(real * T_gen, real * G_gen, const real * jl_gen, int m, int n, real kinv,
+   unsigned long long viol_cols)
+{
+   typedef __attribute__((address_space(3))) real * lds_ptr;
+   return limit_rounds_body<real, 1>((lds_ptr) T_gen, G_gen, jl_gen, m, n, kinv, viol_cols);
+}
+template <typename real, int SHAPE>
+__device__ __attribute__((noinline)) LimResult limit_rounds_call_global_small(real * T_gen, real * G_gen, const real * jl_gen, int m, int n, real kinv,
+   unsigned long long viol_cols)
+{
+   return limit_rounds_body<real, 1>(T_gen, G_gen, jl_gen, m, n, kinv, viol_cols);
 }
 
 template <typename real, int BLOCK, typename BT>
@@ -1569,8 +1593,11 @@ __device__ __attribute__((noinline)) int phase_update(const void * kp, int it_in
          if (tid < 64)
          {
             const real kinv = (real)(-1) / ((real)(m + 1) * b.a_off);      // 1/((m+1) ca), ca = -a_off
-            const LimResult lr = (b.t_in_lds || staged) ? limit_rounds_call<real, (BLOCK == 512) ? 1 : (WGS ? 2 : 0)>(T_s, G_s, jl_s, m, n, kinv, viol_cols)
-                                                      : limit_rounds_call_global<real, (BLOCK == 512) ? 1 : (WGS ? 2 : 0)>(T_s, G_s, jl_s, m, n, kinv, viol_cols);
+            constexpr int SH = (BLOCK == 512) ? 1 : (WGS ? 2 : 0);
+            const bool few = ORC_LIM_SPLIT && __popcll(viol_cols) <= 2;      // (workgroup-uniform)
+            const LimResult lr = (b.t_in_lds || staged)
+               ? (few ? limit_rounds_call_small<real, SH>(T_s, G_s, jl_s, m, n, kinv, viol_cols) : limit_rounds_call<real, SH>(T_s, G_s, jl_s, m, n, kinv, viol_cols))
+               : (few ? limit_rounds_call_global_small<real, SH>(T_s, G_s, jl_s, m, n, kinv, viol_cols) : limit_rounds_call_global<real, SH>(T_s, G_s, jl_s, m, n, kinv, viol_cols));
             if (b.phase_cycles && tid == 0) E.phc_s[7] += lr.kinds;
             if (tid == 0) redi[0] = lr.rounds;
          }
