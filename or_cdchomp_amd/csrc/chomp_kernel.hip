@@ -1417,7 +1417,11 @@ __device__ __attribute__((noinline)) double phase_cost(const void * kp, int ts_i
 
 // ---- update phase (cd_chomp_iterate, src/libcd/chomp.c:490-655): G/m + A T + B, A^-1 G, the step,
 // the joint-limit rounds.  Returns the number of limit rounds made (1000: "ran too many joint limit fixes").
-template <typename real, bool TREE, bool GS16, int BLOCK, int WGS = 0>
+#ifndef ORC_UPDATE_LEAN
+#define ORC_UPDATE_LEAN 1      // runs of the common kind (tridiagonal Toeplitz metric by the scan solve, no TSR constraint, at most 64 dofs, no debug read-back) take a copy of the update phase compiled without the other paths: fewer live scalars, fewer registers saved and restored per call
+#endif
+// LEAN 1 / 2: the caller has checked solve_mode == 2, n <= 64, no lim_generic, no Gdbg, and no TSR constraint (1) or some (2) (the kernel's loop)
+template <typename real, bool TREE, bool GS16, int BLOCK, int WGS = 0, int LEAN = 0>
 __device__ __attribute__((noinline)) int phase_update(const void * kp, int it_in, int leapfrog_first_in)
 {
    KArg<real> & b = *uniform_kernarg<real>(kp);
@@ -1483,16 +1487,16 @@ __device__ __attribute__((noinline)) int phase_update(const void * kp, int it_in
       G_s[e] = g;
    }
    __syncthreads();
-   if (b.Gdbg)
+   if (!LEAN && b.Gdbg)
       for (int e=tid; e<mn; e+=BLOCK) b.Gdbg[(size_t) run*mn + e] = G_s[e];
    // X = A^-1 G   (chomp.c:525-548)
-   real * X = metric_solve<real, BLOCK>(b, pcr_tab, G_s, W_s);
+   real * X = LEAN ? toeplitz_scan_solve<real, BLOCK>(b, G_s) : metric_solve<real, BLOCK>(b, pcr_tab, G_s, W_s);
    // T -= AG/lambda   (chomp.c:604-605)
    const real step = (real)(-1) / b.lambda;
    // the step also notes which columns left their limits (what the first scan of the
    // joint-limit loop would find, chomp.c:615-639): bit c of colmask_s
    unsigned long long viol = 0ull;
-   if (b.n_tsrs > 0)
+   if (LEAN == 2 || (LEAN == 0 && b.n_tsrs > 0))
    {
       // hard constraints (chomp.c:550-600): the unconstrained update AG is completed first, the
       // constraint step moves the trajectory itself, then T -= AG/lambda as always
@@ -1520,7 +1524,7 @@ __device__ __attribute__((noinline)) int phase_update(const void * kp, int it_in
    else if (!b.use_momentum)
    {
       // AG = X is not carried between iterations: keep only the last one (read-back state)
-      const bool keep = (it == b.n_iter - 1) || (b.Gdbg != nullptr);
+      const bool keep = (it == b.n_iter - 1) || (!LEAN && b.Gdbg != nullptr);
       for (int e=tid; e<mn; e+=BLOCK)
       {
          const real x = X[e];
@@ -1584,7 +1588,7 @@ __device__ __attribute__((noinline)) int phase_update(const void * kp, int it_in
 #else
    const unsigned long long viol_cols = ((unsigned long long) colmask_s[1] << 32) | colmask_s[0];      // workgroup-uniform
 #endif
-   if (b.solve_mode == 2 && n <= 64 && !b.lim_generic)
+   if (LEAN || (b.solve_mode == 2 && n <= 64 && !b.lim_generic))
    {
       lim_done = true;
       if (viol_cols != 0ull)
@@ -1606,7 +1610,7 @@ __device__ __attribute__((noinline)) int phase_update(const void * kp, int it_in
          __syncthreads();             // redi is reused by the reductions below
       }
    }
-   if (!lim_done)
+   if (!LEAN && !lim_done)
    for (; num_limadjs<1000; num_limadjs++)
    {
       real best = 0; int best_e = 0x7fffffff;
@@ -1949,7 +1953,10 @@ void chomp_iterate_kernel(const DevBatch<real> b)
 
       if (do_iteration)
       {
-         const int num_limadjs = uni(phase_update<real, TREE, GS16, BLOCK, WGS>(kp, it, leapfrog_first));
+         const bool lean = ORC_UPDATE_LEAN && b.solve_mode == 2 && b.n <= 64 && !b.lim_generic && b.Gdbg == nullptr;      // (workgroup-uniform)
+         const int num_limadjs = !lean ? uni(phase_update<real, TREE, GS16, BLOCK, WGS, 0>(kp, it, leapfrog_first))
+                               : (b.n_tsrs == 0 ? uni(phase_update<real, TREE, GS16, BLOCK, WGS, 1>(kp, it, leapfrog_first))
+                                                : uni(phase_update<real, TREE, GS16, BLOCK, WGS, 2>(kp, it, leapfrog_first)));
          if (b.use_momentum) leapfrog_first = 0;
          if (!(num_limadjs < 1000)) status = -1;
       }

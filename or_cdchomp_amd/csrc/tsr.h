@@ -993,6 +993,129 @@ __device__ void tsr_substitute(const BT & b_, const Env<real> & E, const real * 
 }
 
 // The constraint step.  AG holds the unconstrained update (chomp.c:525-548), T_s the trajectory before it.
+// The constraint step in the reference's dense form (chomp.c:567-599): J A^-1 J^T, LU with partial pivoting (what dgesv does; a singular
+// system leaves h alone and raises the run's flag), back through A^-1 to the trajectory.  What runs for a metric that is not tridiagonal,
+// for blocks the structured solve has no shape for, and after a zero pivot there.  A function of its own: inside phase_tsr its state
+// cost the structured path its scalar registers.
+template <typename real, bool GS16, int BLOCK, int WGS = 0>
+__device__ __attribute__((noinline)) void tsr_dense_step(const void * kp)
+{
+   KArg<real> & b = *uniform_kernarg<real>(kp);
+   const Env<real> E = make_env<real, GS16>(b, orc_smem);
+   const int tid = threadIdx.x, run = blockIdx.x;
+   const int n = b.n, m = b.m, K = b.cons_k, NB = b.tsr_blocks;
+   real * ws = b.tsr_ws + (size_t) run * b.tsr_ws_stride;
+   real * hws = ws;
+   real * h0 = hws + K;
+   real * Jws = h0 + K;
+   real * dws = Jws + (size_t) K * n;
+   real * Mws = dws + (size_t) NB * n;
+   // ---- J Ainv J^T (chomp.c:567-575) ----
+   for (long e=tid; e<(long) K*K; e+=BLOCK)
+   {
+      const int r = (int)(e / K), cidx = (int)(e - (long) r * K);
+      int i1, a1, i2, a2;
+      tsr_row<real>(b, r, i1, a1); tsr_row<real>(b, cidx, i2, a2);
+      real s = 0;
+      for (int q=0; q<n; q++) s += Jws[(size_t) r * n + q] * Jws[(size_t) cidx * n + q];
+      Mws[e] = b.Ainv[(size_t) i1 * m + i2] * s;
+   }
+   __syncthreads();
+   // ---- LU with partial pivoting, forward elimination of h on the way (chomp.c:579-581) ----
+   bool singular = false;
+   for (int k=0; k<K; k++)
+   {
+      real best = (real)(-1); int best_r = 0x7fffffff;
+      for (int r=k+tid; r<K; r+=BLOCK)
+      {
+         const real v = M<real>::fabs_(Mws[(size_t) r * K + k]);
+         if (v > best) { best = v; best_r = r; }
+      }
+      // workgroup arg-max, the first row on ties
+      for (int off=32; off>0; off>>=1)
+      {
+         const real ob = __shfl_xor(best, off, 64); const int orow = __shfl_xor(best_r, off, 64);
+         if (ob > best || (ob == best && orow < best_r)) { best = ob; best_r = orow; }
+      }
+      __syncthreads();
+      if ((tid & 63) == 0) { E.red[tid >> 6] = (double) best; E.redi[tid >> 6] = best_r; }
+      __syncthreads();
+      double gb = E.red[0]; int p = E.redi[0];
+      for (int w=1; w<BLOCK/64; w++)
+         if (E.red[w] > gb || (E.red[w] == gb && E.redi[w] < p)) { gb = E.red[w]; p = E.redi[w]; }
+      if (!(gb > 0.0)) { singular = true; continue; }      // dgetrf notes the zero pivot and goes on (workgroup-uniform)
+      if (p != k)
+      {
+         for (int j=tid; j<K; j+=BLOCK)
+         {
+            const real t0 = Mws[(size_t) k * K + j];
+            Mws[(size_t) k * K + j] = Mws[(size_t) p * K + j];
+            Mws[(size_t) p * K + j] = t0;
+         }
+         if (tid == 0) { const real t0 = hws[k]; hws[k] = hws[p]; hws[p] = t0; }
+      }
+      __syncthreads();
+      const real piv = Mws[(size_t) k * K + k];
+      for (int r=k+1+tid; r<K; r+=BLOCK) Mws[(size_t) r * K + k] = Mws[(size_t) r * K + k] / piv;
+      __syncthreads();
+      const int rem = K - k - 1;
+      for (long e=tid; e<(long) rem*rem; e+=BLOCK)
+      {
+         const int r = k + 1 + (int)(e / rem), j = k + 1 + (int)(e - (long)(e / rem) * rem);
+         Mws[(size_t) r * K + j] -= Mws[(size_t) r * K + k] * Mws[(size_t) k * K + j];
+      }
+      const real hk = hws[k];
+      for (int r=k+1+tid; r<K; r+=BLOCK) hws[r] -= Mws[(size_t) r * K + k] * hk;
+      __syncthreads();
+   }
+   if (singular)
+   {
+      // "constraint inversion error!" (chomp.c:582-590): dgesv leaves the right-hand side as it was
+      for (int r=tid; r<K; r+=BLOCK) hws[r] = h0[r];
+      if (tid == 0 && b.tsr_err) b.tsr_err[run] = 1;
+      __syncthreads();
+   }
+   else
+   {
+      for (int k=K-1; k>=0; k--)
+      {
+         const real xk = hws[k] / Mws[(size_t) k * K + k];
+         __syncthreads();
+         if (tid == 0) hws[k] = xk;
+         for (int r=tid; r<k; r+=BLOCK) hws[r] -= Mws[(size_t) r * K + k] * xk;
+         __syncthreads();
+      }
+   }
+   // ---- back through Ainv to the trajectory (chomp.c:592-599) ----
+   for (int e=tid; e<NB*n; e+=BLOCK)
+   {
+      const int o = e / n, q = e - o*n;
+      int c, i, row0;
+      tsr_block<real>(b, o, c, i, row0);
+      real s = 0;
+      for (int a=0; a<b.tsrs[c].k; a++) s += Jws[(size_t)(row0 + a) * n + q] * hws[row0 + a];
+      dws[e] = s;
+   }
+   __syncthreads();
+   real * Tw = E.T_s;
+   for (int e=tid; e<m*n; e+=BLOCK)
+   {
+      const int r = e / n, q = e - r*n;
+      real t = Tw[n + e];
+      for (int c=b.n_tsrs-1; c>=0; c--)
+      {
+         const int npts = b.tsrs[c].npts, o0 = b.tsrs[c].blk_base;
+         for (int local=0; local<npts; local++)
+         {
+            const int i = (npts == 1) ? b.tsrs[c].point : m - 1 - local;
+            t += (real)(-1) * b.Ainv[(size_t) r * m + i] * dws[(o0 + local)*n + q];
+         }
+      }
+      Tw[n + e] = t;
+   }
+   __syncthreads();
+}
+
 template <typename real, bool GS16, int BLOCK, int WGS = 0>
 __device__ __attribute__((noinline)) void phase_tsr(const void * kp)
 {
@@ -1120,108 +1243,5 @@ __device__ __attribute__((noinline)) void phase_tsr(const void * kp)
       // a singular block: the dense path below treats the case the way the reference does
    }
 #endif
-   // ---- J Ainv J^T (chomp.c:567-575) ----
-   for (long e=tid; e<(long) K*K; e+=BLOCK)
-   {
-      const int r = (int)(e / K), cidx = (int)(e - (long) r * K);
-      int i1, a1, i2, a2;
-      tsr_row<real>(b, r, i1, a1); tsr_row<real>(b, cidx, i2, a2);
-      real s = 0;
-      for (int q=0; q<n; q++) s += Jws[(size_t) r * n + q] * Jws[(size_t) cidx * n + q];
-      Mws[e] = b.Ainv[(size_t) i1 * m + i2] * s;
-   }
-   __syncthreads();
-   // ---- LU with partial pivoting, forward elimination of h on the way (chomp.c:579-581) ----
-   bool singular = false;
-   for (int k=0; k<K; k++)
-   {
-      real best = (real)(-1); int best_r = 0x7fffffff;
-      for (int r=k+tid; r<K; r+=BLOCK)
-      {
-         const real v = M<real>::fabs_(Mws[(size_t) r * K + k]);
-         if (v > best) { best = v; best_r = r; }
-      }
-      // workgroup arg-max, the first row on ties
-      for (int off=32; off>0; off>>=1)
-      {
-         const real ob = __shfl_xor(best, off, 64); const int orow = __shfl_xor(best_r, off, 64);
-         if (ob > best || (ob == best && orow < best_r)) { best = ob; best_r = orow; }
-      }
-      __syncthreads();
-      if ((tid & 63) == 0) { E.red[tid >> 6] = (double) best; E.redi[tid >> 6] = best_r; }
-      __syncthreads();
-      double gb = E.red[0]; int p = E.redi[0];
-      for (int w=1; w<BLOCK/64; w++)
-         if (E.red[w] > gb || (E.red[w] == gb && E.redi[w] < p)) { gb = E.red[w]; p = E.redi[w]; }
-      if (!(gb > 0.0)) { singular = true; continue; }      // dgetrf notes the zero pivot and goes on (workgroup-uniform)
-      if (p != k)
-      {
-         for (int j=tid; j<K; j+=BLOCK)
-         {
-            const real t0 = Mws[(size_t) k * K + j];
-            Mws[(size_t) k * K + j] = Mws[(size_t) p * K + j];
-            Mws[(size_t) p * K + j] = t0;
-         }
-         if (tid == 0) { const real t0 = hws[k]; hws[k] = hws[p]; hws[p] = t0; }
-      }
-      __syncthreads();
-      const real piv = Mws[(size_t) k * K + k];
-      for (int r=k+1+tid; r<K; r+=BLOCK) Mws[(size_t) r * K + k] = Mws[(size_t) r * K + k] / piv;
-      __syncthreads();
-      const int rem = K - k - 1;
-      for (long e=tid; e<(long) rem*rem; e+=BLOCK)
-      {
-         const int r = k + 1 + (int)(e / rem), j = k + 1 + (int)(e - (long)(e / rem) * rem);
-         Mws[(size_t) r * K + j] -= Mws[(size_t) r * K + k] * Mws[(size_t) k * K + j];
-      }
-      const real hk = hws[k];
-      for (int r=k+1+tid; r<K; r+=BLOCK) hws[r] -= Mws[(size_t) r * K + k] * hk;
-      __syncthreads();
-   }
-   if (singular)
-   {
-      // "constraint inversion error!" (chomp.c:582-590): dgesv leaves the right-hand side as it was
-      for (int r=tid; r<K; r+=BLOCK) hws[r] = h0[r];
-      if (tid == 0 && b.tsr_err) b.tsr_err[run] = 1;
-      __syncthreads();
-   }
-   else
-   {
-      for (int k=K-1; k>=0; k--)
-      {
-         const real xk = hws[k] / Mws[(size_t) k * K + k];
-         __syncthreads();
-         if (tid == 0) hws[k] = xk;
-         for (int r=tid; r<k; r+=BLOCK) hws[r] -= Mws[(size_t) r * K + k] * xk;
-         __syncthreads();
-      }
-   }
-   // ---- back through Ainv to the trajectory (chomp.c:592-599) ----
-   for (int e=tid; e<NB*n; e+=BLOCK)
-   {
-      const int o = e / n, q = e - o*n;
-      int c, i, row0;
-      tsr_block<real>(b, o, c, i, row0);
-      real s = 0;
-      for (int a=0; a<b.tsrs[c].k; a++) s += Jws[(size_t)(row0 + a) * n + q] * hws[row0 + a];
-      dws[e] = s;
-   }
-   __syncthreads();
-   real * Tw = E.T_s;
-   for (int e=tid; e<m*n; e+=BLOCK)
-   {
-      const int r = e / n, q = e - r*n;
-      real t = Tw[n + e];
-      for (int c=b.n_tsrs-1; c>=0; c--)
-      {
-         const int npts = b.tsrs[c].npts, o0 = b.tsrs[c].blk_base;
-         for (int local=0; local<npts; local++)
-         {
-            const int i = (npts == 1) ? b.tsrs[c].point : m - 1 - local;
-            t += (real)(-1) * b.Ainv[(size_t) r * m + i] * dws[(o0 + local)*n + q];
-         }
-      }
-      Tw[n + e] = t;
-   }
-   __syncthreads();
+   tsr_dense_step<real, GS16, BLOCK, WGS>(kp);
 }
