@@ -1289,6 +1289,9 @@ __device__ __forceinline__ void copy_batched(real * dst, const real * src, int c
 }
 
 // ---- FK phase of one tile: lane = (waypoint, world axis) (sphere_cost_pre, src/orcdchomp_mod.cpp:988-1093) ----
+#ifndef ORC_FK_SKIP_IDLE
+#define ORC_FK_SKIP_IDLE 1    // wavefronts without a waypoint in a tile skip the FK phase's call (they join its barrier)
+#endif
 #ifndef ORC_INLINE_FK
 #define ORC_INLINE_FK 0      // 1: the FK phase of the fp64 16-lane kernels inside the kernel function (no callee-saved registers to preserve, 37 scalar registers through v_writelane and back per call otherwise) -- but the loop invariants it hoists across the other phases' calls are spilled to scratch and reloaded inside the joint loop: measured slower, kept for A/B
 #endif
@@ -1932,6 +1935,11 @@ void chomp_iterate_kernel(const DevBatch<real> b)
          if (b.stagger_mode == 9 && tk > 0) { if (tk == 1) for (int k=0; k<b.stagger_sleeps; k++) __builtin_amdgcn_s_sleep(10); continue; }
 #ifndef ORC_ABLATE_FK
          if constexpr (ORC_INLINE_FK && GS16 && sizeof(real) == 8) phase_fk_body<real, TREE, GS16, BLOCK, WGS>(kp, ts, te);
+#if ORC_FK_SKIP_IDLE
+         // a wavefront without a waypoint in the tile (20 per wavefront: the second of a 128-thread workgroup in each of its tiles of 14)
+         // only joins the phase's barrier: it saves the call's ~120 scalar registers moved through the vector pipe
+         else if (!b.ms.fk_split && uni(tid >> 6) * 20 >= te - ts + 2) __syncthreads();
+#endif
          else phase_fk<real, TREE, GS16, BLOCK, WGS>(kp, ts, te);      // (skipping the call for the wavefronts without a waypoint in the tile -- their share of the callee-saved registers -- measured nothing: profiles/r04_ab_experiments.txt)
 #ifdef ORC_ABLATE_FKTWICE      // timing experiments: the FK phase twice (what a 2x slower FK would cost)
          phase_fk<real, TREE, GS16, BLOCK, WGS>(kp, ts, te);
