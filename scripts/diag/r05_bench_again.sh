@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; mkdir -p gpurun_out/r05
-for k in 1 2; do timeout -k 10 600 python bench.py > gpurun_out/r05/bench_default_again$k.json 2>/dev/null; echo "bench rc $?"; python - <<PY
+for k in 3; do timeout -k 10 600 python bench.py > gpurun_out/r05/bench_default_again$k.json 2>/dev/null; echo "bench rc $?"; python - <<PY
 import json
 for l in open("gpurun_out/r05/bench_default_again$k.json"):
     if l.startswith("{"):
