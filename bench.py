@@ -70,6 +70,80 @@ def host_cores():
     return min(cores, len(os.sched_getaffinity(0)))
 
 
+COMPACT_LIMIT = 4096            # the driver's record parses the LAST stdout line; it must stay small (round-5 review: a 27 KB line did not parse)
+
+
+def _r(v, digits=5):
+    """numbers at a few significant digits: the compact line is for a parser, the full record keeps every bit"""
+    if v is None or isinstance(v, (bool, int, str)):
+        return v
+    try:
+        return float("%.*g" % (digits, float(v)))
+    except (TypeError, ValueError):
+        return None
+
+
+def compact_line(out, full_path=None):
+    """The one JSON object the driver parses: the contract's keys, `roofline` and `cpu_baseline` as numbers, the parity
+    figures and `summary`.  Everything else of `out` (other_configs, batch_sweep, tsr*, held4, stages, the prose notes)
+    lives in the full record (`--full-out`)."""
+    rf = out.get("roofline") or {}
+    vi = rf.get("valu_issue") or {}
+    cpu = out.get("cpu_baseline")
+    cfg = out.get("config") or {}
+    line = {
+        "metric": out.get("metric"), "value": _r(out.get("value"), 7), "unit": out.get("unit"), "n_gpus": out.get("n_gpus"),
+        "steps": out.get("steps"), "warmup": out.get("warmup"), "ms_per_step": _r(out.get("ms_per_step"), 6),
+        "higher_is_better": True, "scaling": out.get("scaling"), "vs_baseline": None, "dtype": out.get("dtype"),
+        "data": out.get("data"),
+        "config": {"workload": str(cfg.get("workload"))[:200], "runs_per_gpu": cfg.get("runs_per_gpu"), "n_iter": cfg.get("n_iter"),
+                   "n_points": cfg.get("n_points"), "dof": cfg.get("dof"), "parallelism": cfg.get("parallelism")},
+        "value_serial": _r(out.get("value_serial"), 7),
+        "iterations_made": out.get("iterations_made"), "iterations_nominal": out.get("iterations_nominal"),
+        "runs_outside_joint_limits": out.get("runs_outside_joint_limits"),
+        "roofline": {"bound": "hbm", "achieved": _r(rf.get("achieved")), "peak": rf.get("peak"), "unit": rf.get("unit"),
+                     "frac": _r(rf.get("frac")), "traffic": _r(rf.get("traffic")),
+                     "hbm_measured_frac": _r(rf.get("hbm_measured_frac")), "kernel": str(rf.get("kernel"))[:80],
+                     "avg_kernel_ms": _r(rf.get("avg_kernel_ms")), "launches": rf.get("launches"),
+                     "concurrent_launches": rf.get("concurrent_launches"),
+                     "algorithmic_bytes_per_launch": rf.get("algorithmic_bytes_per_launch"),
+                     "counters_say": rf.get("bound"), "valu_issue": {"frac": _r(vi.get("frac"))} if vi else None,
+                     "fp64_vector_frac": _r((rf.get("fp64_vector") or {}).get("frac"))},
+        "cpu_baseline": None if not cpu else {"value": _r(cpu.get("value")), "unit": cpu.get("unit"), "cores": cpu.get("cores"),
+                                              "value_1_core": _r(cpu.get("value_1_core")), "host_cores": cpu.get("host_cores"),
+                                              "kind": cpu.get("kind"), "sample": str(cpu.get("sample"))[:160]},
+        "parity_rel_l2_max_vs_oracle": _r(out.get("parity_rel_l2_max_vs_oracle"), 3), "parity_bound": out.get("parity_bound"),
+        "parity_runs_checked": out.get("parity_runs_checked"),
+        "parity_ill_conditioned_runs": len(out.get("parity_ill_conditioned_runs") or []),
+    }
+    if out.get("per_rank"):
+        line["per_rank_value"] = [_r(p["value"]) for p in out["per_rank"]]
+    if out.get("gather"):
+        line["gather_s"] = _r(out["gather"].get("total_s"))
+    if out.get("backend"):
+        line["backend"] = out["backend"]
+    if full_path:
+        line["full_record"] = os.path.basename(full_path)
+    if out.get("summary"):
+        line["summary"] = out["summary"]
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) > COMPACT_LIMIT:                 # never grow past the limit again: drop the optional parts, widest first
+        for k in ("summary", "per_rank_value", "cpu_baseline.sample", "config.workload"):
+            if "." in k:
+                a, b = k.split(".")
+                if line.get(a):
+                    line[a][b] = str(line[a][b])[:60]
+            elif k == "summary" and isinstance(line.get(k), dict):
+                line[k].pop("sweep", None)
+            else:
+                line.pop(k, None)
+            text = json.dumps(line, separators=(",", ":"))
+            if len(text) <= COMPACT_LIMIT:
+                break
+    assert len(text) <= COMPACT_LIMIT, len(text)
+    return text
+
+
 class Workload:
     """one BASELINE configuration: how to set the scene up, create a batch, and run the oracle on it"""
 
@@ -252,7 +326,7 @@ def launch_ranks(args, argv):
     sys.exit(subprocess.call(cmd, env=env))
 
 
-def run_workload(config, args, rank, world, device, dist, steps, warmup, serial_steps, batch=0, want_gather=True):
+def run_workload(config, args, rank, world, device, dist, steps, warmup, serial_steps, batch=0, want_gather=True, want_cpu=True):
     """one bench line: K steps of one BASELINE configuration on this rank's GPU; returns (line or None, exit code)"""
     import torch
     import or_cdchomp_amd
@@ -386,7 +460,7 @@ def run_workload(config, args, rank, world, device, dist, steps, warmup, serial_
             if j not in well and ost[j] == 0 and st0[idx[j]] == 0 and errs[j] > max(parity_bound, wl.common.CHAOS_FACTOR * self_amp[j]):
                 rc = 3
 
-        if not args.no_cpu_baseline and world == 1:         # the CPU baseline is reported at N=1 only
+        if want_cpu and not args.no_cpu_baseline and world == 1:         # the CPU baseline is reported at N=1 only
             cores = host_cores()
             # ~0.1 s (config 2) to ~2.5 s (config 5) per run of 100 iterations on one core; 10-20 s of wall time
             per_core = {2: 48, 3: 48, 4: 12, 5: 6, "tsr1": 24, "tsr3": 4, "held4": 32}[config]
@@ -656,7 +730,11 @@ def main():
     ap.add_argument("--other-steps", type=int, default=16, help="steps of each `other_configs` line (even: the steps alternate between two streams; "
                                                                "the first and the last step of a stream overlap with nothing: 16 steps are within 2 %% of 40)")
     ap.add_argument("--no-sweep", action="store_true", help="default run only: do not append `batch_sweep`, `tsr1`, `tsr3` and `stages`")
-    ap.add_argument("--sweep-batches", default="1,64,4096,16384,65536", help="batch sizes of `batch_sweep`")
+    ap.add_argument("--sweep-batches", default="1,64,4096,8192,16384,65536", help="batch sizes of `batch_sweep` (8192 = one block of config 3: "
+                                                                                  "the N = 1 point of the multi-GPU curve, like for like)")
+    ap.add_argument("--full-out", default=os.path.join(ROOT, "bench_full.json"),
+                    help="rank 0 writes the FULL record here (every line, sweep, stages, notes); stdout's last line is the compact one")
+    ap.add_argument("--print-full", action="store_true", help="also print the full record as an EARLIER stdout line")
     ap.add_argument("--dump-gather", default="", help="N > 1: rank 0 saves the gathered step-0 trajectories here (.npy)")
     args = ap.parse_args()
     if args.gpus < 1:
@@ -707,6 +785,11 @@ def main():
                 out[c] = line
                 rc = rc or rc_c
             out["stages"] = stage_breakdown(device)
+            # one 8192-run block of config 3 on this GPU, issued like the N > 1 line issues it: the N = 1 point of the
+            # scaling curve, like for like (the N = 1 headline is config 2's 1024 runs, a different per-GPU workload)
+            line, rc_c = run_workload(3, args, rank, world, device, dist, 6, 1, 3, want_gather=False, want_cpu=False)
+            out["c3_block"] = line
+            rc = rc or rc_c
     if rank == 0 and world == 1 and out is not None:
         # every headline number once more, compact, as the LAST key of the line (a record that keeps only the tail of the line keeps this)
         from or_cdchomp_amd import _capi
@@ -714,7 +797,7 @@ def main():
         summ = {"unit": "M it/s", "build": _capi.csrc_hash()}
         key = {2: "c2", 3: "c3", 4: "c4", 5: "c5"}.get(config, str(config))
         lines = [(key, out)] + [({4: "c4", 5: "c5"}[4 + i], l) for i, l in enumerate(out.get("other_configs") or [])]
-        lines += [(c, out[c]) for c in ("tsr1", "tsr3", "held4") if out.get(c)]
+        lines += [(c, out[c]) for c in ("tsr1", "tsr3", "held4", "c3_block") if out.get(c)]
         for k, l in lines:
             summ[k] = r3(l["value"] / 1e6)
             summ[k + "_serial"] = r3(None if l.get("value_serial") is None else l["value_serial"] / 1e6)
@@ -726,7 +809,22 @@ def main():
             summ["sweep"] = {str(e["batch"]): r3(e["value"] / 1e6) for e in out["batch_sweep"]["sweep"]}
         out["summary"] = summ
     if rank == 0:
-        print(json.dumps(out))
+        full_path = args.full_out or None
+        if full_path:
+            try:
+                with open(full_path, "w") as f:
+                    json.dump(out, f)
+                mirror = os.path.join(ROOT, "gpurun_out")           # (a gpurun box brings this directory back)
+                if os.path.isdir(mirror):
+                    with open(os.path.join(mirror, os.path.basename(full_path)), "w") as f:
+                        json.dump(out, f)
+            except OSError as e:
+                print("bench.py: could not write %s: %s" % (full_path, e), file=sys.stderr)
+                full_path = None
+        if args.print_full:
+            print(json.dumps(out))
+        print(compact_line(out, full_path))
+        sys.stdout.flush()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
