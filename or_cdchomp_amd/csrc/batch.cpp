@@ -1044,7 +1044,9 @@ void BatchShard::build_device(const Robot & robot)
    const bool can128 = sizeof(real) == 8 && (tree_ & 16) && (tree_ & 2) && !(tree_ & (1 | 64));
    if (want_wgs == 0 && ((n_tsrs_ > 0 && !(tree_ & 64)) || (tree_ & 512) || (overlapping && !(tree_ & 64)))) want_wgs = 4;
    if (want_wgs == 3) want_wgs = 0;
-   if (force_block == 0 && overlapping && n_tsrs_ > 0 && can128 && !params.free_start && !getenv("ORC_BLOCK_THREADS")) force_block = 128;
+   // (the planner's own 128 is a preference, tried in a pass of its own: a long constrained trajectory that has no 128-thread plan --
+   // 40 KB of LDS at four per CU -- is planned like any other run afterwards; a caller's orc_set_workgroup_threads stays binding)
+   const bool planner128 = force_block == 0 && overlapping && n_tsrs_ > 0 && can128 && !params.free_start && !getenv("ORC_BLOCK_THREADS");
    const int max_wgs_default = max_wgs, force_block_asked = force_block;
    bool budget4 = false;
    const int lanes_per_wp = (GS_ == 16) ? 16 : GS_;
@@ -1052,10 +1054,10 @@ void BatchShard::build_device(const Robot & robot)
    // (a run the four-per-CU budget has no room for -- a long trajectory -- is planned with the default budget instead; a run
    // that has no plan under the experiments' switches -- a forced tile of 33 waypoints at four workgroups per CU, the gradient
    // rows forced out of LDS for a trajectory of three points -- is planned without them: the switches are preferences)
-   for (int pass=0; pass<3 && !tile_m_; pass++)
+   for (int pass=(planner128 ? -1 : 0); pass<3 && !tile_m_; pass++)
    {
    const bool relax = (pass == 2);
-   max_wgs = relax ? max_wgs_budget : max_wgs_default; force_block = force_block_asked;
+   max_wgs = relax ? max_wgs_budget : max_wgs_default; force_block = (pass == -1) ? 128 : force_block_asked;
    if (relax) { force_t = 0; force_pcr = -1; force_ag = -1; }
    budget4 = (pass == 0) && (want_wgs == 4) && sizeof(real) == 8 && (((tree_ & 16) && (tree_ & 2) && (!(tree_ & 64) || (tree_ & 160) == 160)) || (tree_ & 512)) && (force_block == 0 || force_block == 256)
                         && !getenv("ORC_BLOCK_THREADS") && !getenv("ORC_WGS") && !getenv("ORC_TILE_M");      // (the experiments' switches come first)

@@ -66,12 +66,12 @@ def main():
     O.build(ref=False)
     # config 3: the first GPU's block (8192 runs) of the 65 536-run batch
     goals = common.config3_goals(rank=0, world=8)
-    idx = sample_indices(len(goals), 16)
+    idx = sample_indices(len(goals), 64)
     pack("fullsize_config3.npz", idx, run_wam(goals[idx], common.CONFIG2_KW))
 
     # config 4: floating base + arm, momentum + hmc, batch 4096, seed = run index
     goals, basegoals, seeds, kw = common.config4_problem(4096)
-    idx = sample_indices(4096, 8)
+    idx = sample_indices(4096, 32)
     pack("fullsize_config4.npz", idx, run_wam(goals[idx], kw, basegoals=basegoals[idx], seeds=seeds[idx]))
 
     # config 5: 30-dof tree, four fields at 1 cm cells, batch 4096 (the oracle computes in fp64)
@@ -82,7 +82,7 @@ def main():
     dofvals = np.zeros(model.n_dof)
     adofs = list(range(model.n_dof))
     goals = common.config5_goals(4096)
-    idx = sample_indices(4096, 8)
+    idx = sample_indices(4096, 32)
     p = O.default_params(**common.CONFIG5_KW)
     res = [O.batch_run(rob, base, dofvals, adofs, g, grids, poses, p, N_ITER) for g in (goals[idx], goals[idx] * ULP, goals[idx] * ULP_DOWN)]
     extra = {}

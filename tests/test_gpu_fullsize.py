@@ -216,7 +216,7 @@ def test_config5_tree30_four_fields_fp32_4096(oracle):
         _check_sample("config 5 (30-dof tree, 4 fields at 1 cm, 4096 runs, fp%d)" % precision, gold, traj, costs, status, tol)
         assert (status == 0).all() and (iters == N_ITER).all()
         results[precision] = dict(traj=traj, costs=costs, status=status, iters=iters)
-    # fp32 against fp64 of the product itself over the WHOLE batch (the golden sample is 8 runs)
+    # fp32 against fp64 of the product itself over the WHOLE batch (the golden sample is 32 runs)
     e = np.array([common.rel_l2(results[32]["traj"][k], results[64]["traj"][k]) for k in range(4096)])
     assert np.median(e) <= 1e-5 and (e <= 1e-3).mean() >= 0.99, (np.median(e), (e <= 1e-3).mean())
     # the runs above 1e-3 are ill conditioned in the algorithm itself: the fp64 path with the goals moved

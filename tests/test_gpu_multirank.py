@@ -6,7 +6,7 @@ block of the 65 536-run batch of seed 20250102 (cut to --batch 512 runs per rank
 the step-0 trajectories on the host (gloo; no data-path collective) and prints the one JSON line.  The
 gathered trajectories must equal, bit for bit, a single-process batch of the same 1024 goals: a run's
 bits do not depend on which rank or which block it is in.  The log of the rehearsal is kept under
-profiles/ (r04_rehearsal_2ranks_gloo.json) when the test runs on the builder's GPU box.
+profiles/ (r06_rehearsal_2ranks_gloo.json) when the test runs on the builder's GPU box.
 """
 import json
 import os
@@ -32,16 +32,22 @@ def _run_bench(extra, tmp_path, timeout=900):
 
 def test_bench_starts_its_own_two_ranks_and_gathers(tmp_path):
     dump = str(tmp_path / "gathered.npy")
+    full_path = str(tmp_path / "full.json")
     r = _run_bench(["--gpus", "2", "--backend", "gloo", "--batch", "512", "--steps", "2", "--warmup", "1",
-                    "--no-cpu-baseline", "--dump-gather", dump], tmp_path)
+                    "--no-cpu-baseline", "--dump-gather", dump, "--full-out", full_path], tmp_path)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 prints the ONE line
+    assert len(lines[0]) <= 4096                                  # ... the compact one (the driver's record parses it)
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak"
-    assert line["gather"]["runs"] == 1024 and line["runs_total"] == 2 * 2 * 512
-    assert len(line["per_rank"]) == 2 and all(p["value"] > 0 for p in line["per_rank"])
+    assert len(line["per_rank_value"]) == 2 and all(v > 0 for v in line["per_rank_value"])
+    assert line["roofline"]["frac"] > 0 and line["cpu_baseline"] is None      # (the CPU baseline is an N = 1 figure)
     assert line["parity_rel_l2_max_vs_oracle"] is not None and line["parity_rel_l2_max_vs_oracle"] <= 1e-6
+    full = json.load(open(full_path))                             # the full record beside it
+    assert abs(full["value"] - line["value"]) <= 1e-6 * full["value"]
+    assert full["gather"]["runs"] == 1024 and full["runs_total"] == 2 * 2 * 512
+    assert len(full["per_rank"]) == 2 and all(p["value"] > 0 for p in full["per_rank"])
     got = np.load(dump)
     assert got.shape == (1024, 100, 7)
 
@@ -59,7 +65,7 @@ def test_bench_starts_its_own_two_ranks_and_gathers(tmp_path):
 
     keep = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(keep):
-        with open(os.path.join(keep, "r04_rehearsal_2ranks_gloo.json"), "w") as f:
+        with open(os.path.join(keep, "r06_rehearsal_2ranks_gloo.json"), "w") as f:
             json.dump({"command": "python bench.py --gpus 2 --backend gloo --batch 512 --steps 2 --warmup 1 --no-cpu-baseline",
                        "line": line, "gathered_equals_single_process_batch": True}, f, indent=1)
 

@@ -503,3 +503,43 @@ def test_the_same_con_tsr_twice(oracle):
         assert common.rel_l2(traj[k], run.traj()) <= 1e-6, common.rel_l2(traj[k], run.traj())
         assert np.allclose(costs[k], oc, rtol=1e-6, atol=0)
         run.destroy()
+
+
+@pytest.mark.parametrize("n_points", [400, 640])
+def test_con_tsr_long_trajectory_on_an_overlapping_module(oracle, n_points):
+    """round-5 advisor: on a module whose launches overlap (orc_set_num_streams >= 2) the planner prefers 128-thread
+    workgroups for constrained runs; a long trajectory has no such plan (40 KB of LDS at four per CU) and must be planned
+    like any other run instead of failing with "run does not fit the LDS of one CU!".  Same trajectories as streams = 0."""
+    O = oracle
+    base = _unit_base()
+    tool = [0, 0, 0, 0, 0, 0, 1]
+    n_runs, n_iter = 6, 4
+    goals = np.ascontiguousarray(_near_goals(n_runs, 77, spread=0.3))
+    out = {}
+    for streams in (0, 2):
+        mod = or_cdchomp_amd.Module(0)
+        model, dofvals, adofs = _setup(mod, base)
+        Re, te, le = _start_frame(O, model, base, dofvals, "wam7", tool)
+        Bw = [[-1, 1], [-1, 1], [0, 0], [0, 0], [-3, 3], [-3, 3]]
+        tsr = robots.Tsr(T0w_R=Re, T0w_d=te, Bw=Bw)
+        mod.set_num_streams(streams)
+        bid = int(mod.SendCommand("createbatch robot %s n_runs %d adofgoals 0x%x n_points %d lambda 100 obs_factor 200 con_tsr 'all link wam7' '%s'"
+                                  % (model.name, n_runs, goals.ctypes.data, n_points, tsr.serialize())))
+        costs, status = mod.batch_iterate(bid, n_iter)
+        out[streams] = (mod.batch_gettraj(bid), costs, status)
+        mod.batch_destroy(bid)
+        mod.close()
+    assert (out[0][2] == 0).all() and (out[2][2] == 0).all()
+    for k in range(n_runs):
+        assert common.rel_l2(out[2][0][k], out[0][0][k]) <= 1e-9
+    assert np.allclose(out[2][1], out[0][1], rtol=1e-9, atol=0)
+    # and one run against the oracle
+    prob = common.tabletop_problem(O)
+    run = O.OraRun(O.OraRobot(model), base, dofvals, adofs, goals[1], [prob["sdf"]], [prob["pose"]],
+                   O.default_params(n_points=n_points, lambda_=100.0, obs_factor=200.0))
+    assert run.add_contsr(le, tool, O.pose_from_dR(te, Re), [0, 0, 0, 0, 0, 0, 1], Bw) == 2
+    st, oc = run.iterate(n_iter)
+    assert st == 0
+    assert common.rel_l2(out[2][0][1], run.traj()) <= 1e-6
+    assert np.allclose(out[2][1][1], oc, rtol=1e-6, atol=0)
+    run.destroy()
