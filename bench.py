@@ -198,6 +198,18 @@ class Workload:
             self.kernel = "chomp_iterate_kernel<double, chain, 16-lane rows> with the constraint phase (csrc/tsr.h)"
             self.label = ("WAM 7-DOF, n_points=100, batch=%d goals within 0.4 rad of the start, con_tsr 'all link wam7' with %d constrained "
                           "row(s) per moving point, n_iter=%d per step, lambda=100 obs_factor=200" % (self.n_runs, self.rows, N_ITER))
+        elif config in ("d2", "d3"):
+            # config 2's runs with `derivative 2` / `3` (src/libcd/chomp.c:239-340: a penta- / hepta-diagonal smoothness metric; the
+            # reference multiplies by its dense inverse): the band inverse through its rank-D generators, D prefix and D suffix wave
+            # scans per column (DESIGN.md section 3 "metric")
+            self.n_runs = batch or 1024
+            self.goals = None
+            self.kw = dict(common.CONFIG2_KW, derivative=int(config[1]))
+            self.m, self.n, self.Sa, self.n_sdf, self.w, self.momentum = 98, 7, 15, 1, 8, False
+            self.dtype = "f64"
+            self.kernel = "chomp_iterate_kernel<double, chain, 16-lane rows>, band metric by wave scans"
+            self.label = ("WAM 7-DOF, n_points=100, batch=%d random adofgoal, derivative %s, n_iter=%d per step, lambda=100 obs_factor=500"
+                          % (self.n_runs, config[1], N_ITER))
         elif config == "held4":
             # config 2's WAM HOLDING a four-sphere box (RobotBase::Grab; src/orcdchomp_mod.cpp:2168-2300: the held body's spheres
             # join the run's list): 15 + 4 = 19 active spheres, the 32-lane kernel family with the dense pair list (csrc/cost_pairs.h)
@@ -210,7 +222,7 @@ class Workload:
             self.label = ("WAM 7-DOF holding a four-sphere box in its hand (19 active spheres), n_points=100, batch=%d random adofgoal, "
                           "n_iter=%d per step, lambda=100 obs_factor=500, tabletop SDF 40x31x12" % (self.n_runs, N_ITER))
         else:
-            raise SystemExit("--config must be 2, 3, 4, 5, tsr1, tsr3 or held4")
+            raise SystemExit("--config must be 2, 3, 4, 5, tsr1, tsr3, held4, d2 or d3")
         self.bytes_iter = algorithmic_bytes_per_iter(self.m, self.n, self.Sa, self.n_sdf, self.w, self.momentum)
         if config in ("tsr1", "tsr3"):
             # + the constraint step: h and J written and read (2 K (n + 1) w), the rows of C' and r' of the block
@@ -248,7 +260,7 @@ class Workload:
         return self.tsr
 
     def step_goals(self, step, rank):
-        if self.config in (2, "held4"):
+        if self.config in (2, "held4", "d2", "d3"):
             return self.common.wam_goals(self.n_runs, seed=20250101 + 1000 * rank + step)
         if self.config in ("tsr1", "tsr3"):
             rng = np.random.default_rng(20250105 + 1000 * rank + step)
@@ -304,8 +316,11 @@ class Workload:
         kw = {}
         if self.config == 4:
             kw = dict(basegoals=self.basegoals[idx], seeds=self.seeds[idx])
+        okw = dict(self.kw)
+        if "derivative" in okw:
+            okw["D"] = okw.pop("derivative")              # (the oracle's name for it)
         return O.batch_run(rob, base, dofvals, adofs, goals[idx] * scale, self.o_fields[0], self.o_fields[1],
-                           O.default_params(**self.kw), N_ITER, max_threads=threads, **kw)
+                           O.default_params(**okw), N_ITER, max_threads=threads, **kw)
 
 
 def free_port():
@@ -463,7 +478,7 @@ def run_workload(config, args, rank, world, device, dist, steps, warmup, serial_
         if want_cpu and not args.no_cpu_baseline and world == 1:         # the CPU baseline is reported at N=1 only
             cores = host_cores()
             # ~0.1 s (config 2) to ~2.5 s (config 5) per run of 100 iterations on one core; 10-20 s of wall time
-            per_core = {2: 48, 3: 48, 4: 12, 5: 6, "tsr1": 24, "tsr3": 4, "held4": 32}[config]
+            per_core = {2: 48, 3: 48, 4: 12, 5: 6, "tsr1": 24, "tsr3": 4, "held4": 32, "d2": 48, "d3": 48}[config]
             sample = args.cpu_runs or int(min(n_runs, max(8, per_core * cores)))
             sidx = np.arange(min(sample, n_runs))
             c0 = time.perf_counter()
@@ -538,6 +553,7 @@ def run_workload(config, args, rank, world, device, dist, steps, warmup, serial_
         out = {
             "metric": "CHOMP iters/sec, 7-DOF x 100-waypoint" if config in (2, 3) else (
                 "CHOMP iters/sec, 7-DOF x 100-waypoint, the robot holds a four-sphere body" if config == "held4" else
+                "CHOMP iters/sec, 7-DOF x 100-waypoint, derivative %s" % config[1] if config in ("d2", "d3") else
                 "CHOMP iters/sec, 7-DOF x 100-waypoint, TSR-constrained (%s)" % config if isinstance(config, str)
                 else "CHOMP iters/sec (BASELINE configs[%d])" % (config - 1)),
             "value": value,
@@ -708,7 +724,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="", help="BASELINE configuration: 2 (default at --gpus 1), 3 (default at --gpus > 1), 4 or 5; "
+    ap.add_argument("--config", default="", help="BASELINE configuration: 2 (default at --gpus 1), 3 (default at --gpus > 1), 4 or 5; d2 / d3: config 2 with derivative 2 / 3; "
                                                  "tsr1 / tsr3: config 2's runs held on a TSR by one / three hard-constraint rows "
                                                  "on every moving point (con_tsr, SURVEY.md 8f rank 4); held4: config 2's WAM holding a four-sphere box")
     ap.add_argument("--batch", type=int, default=0, help="runs per GPU (default: the configuration's own size)")
@@ -780,8 +796,9 @@ def main():
         # the rest of the metric under the same clock: the batch sweep, the TSR-constrained line, the reference's stage names
         if not args.no_sweep:
             out["batch_sweep"] = batch_sweep(device, [int(b) for b in args.sweep_batches.split(",")])
-            for c in ("tsr1", "tsr3", "held4"):
-                line, rc_c = run_workload(c, args, rank, world, device, dist, args.other_steps, 2, min(args.other_steps, 3))
+            for c in ("tsr1", "tsr3", "held4", "d2", "d3"):
+                line, rc_c = run_workload(c, args, rank, world, device, dist, args.other_steps, 2, min(args.other_steps, 3),
+                                          want_cpu=(c not in ("d2", "d3")))
                 out[c] = line
                 rc = rc or rc_c
             out["stages"] = stage_breakdown(device)
@@ -797,7 +814,7 @@ def main():
         summ = {"unit": "M it/s", "build": _capi.csrc_hash()}
         key = {2: "c2", 3: "c3", 4: "c4", 5: "c5"}.get(config, str(config))
         lines = [(key, out)] + [({4: "c4", 5: "c5"}[4 + i], l) for i, l in enumerate(out.get("other_configs") or [])]
-        lines += [(c, out[c]) for c in ("tsr1", "tsr3", "held4", "c3_block") if out.get(c)]
+        lines += [(c, out[c]) for c in ("tsr1", "tsr3", "held4", "d2", "d3", "c3_block") if out.get(c)]
         for k, l in lines:
             summ[k] = r3(l["value"] / 1e6)
             summ[k + "_serial"] = r3(None if l.get("value_serial") is None else l["value_serial"] / 1e6)

@@ -251,7 +251,10 @@ int orc_batch_gettraj(orc_module * mod, int batch_id, double * traj_out, size_t 
  * (a pair of spheres: -2 - the XML index of the other sphere), penetration depth in metres. */
 int orc_batch_collision_verdict(orc_module * mod, int batch_id, int * collides_out, double * time_out,
                                 int * sphere_out, int * field_out, double * depth_out);
-/* optimizer state read-back for tests: which = "G", "AG", "T" ([n_runs][m][n]) */
+/* optimizer state read-back for tests: which = "G", "AG", "T" ([n_runs][m][n]); "phase" ([n_runs][8] cycle counters with
+ * ORC_PHASE_TIMERS=1); "plan" (8 numbers: kernel variant bits -- 512 = the dense pair-list family, 1 = a tree --, threads per
+ * workgroup, LDS bytes per workgroup, tile, solve mode (2 closed-form scans, 3 band-inverse generators, 1 dense), workgroups
+ * per CU, tiles, lanes per waypoint) */
 int orc_batch_get_state(orc_module * mod, int batch_id, const char * which, double * out, size_t cap_doubles);
 int orc_batch_dims(orc_module * mod, int batch_id, int * n_runs, int * n_points, int * n);
 /* overwrite the trajectories of a batch (warm start; what `create starttraj` does for one run,
@@ -289,13 +292,18 @@ int orc_host_voxelize_trimesh(const int sizes[3], const double lengths[3], const
 int orc_host_shparse(const char * in, char * out, size_t out_cap);
 /* smoothness metric of cd_chomp_init (src/libcd/chomp.c:239-340, 393-403) in the form the
  * kernels use: dense A [m][m], endpoint couplings beta_s/beta_g [m], kappa[3] = kss ksg kgg
- * (trC), and A^-1 applied to rhs [m][ncols] by the same cyclic-reduction tables (D=1) or dense
- * inverse (D>=2) the device uses; any output may be NULL */
+ * (trC), and A^-1 applied to rhs [m][ncols] by what the device uses: the cyclic-reduction tables (D=1), the
+ * generators of the band inverse (2 <= D <= 4: rank-D semiseparable form, D prefix and D suffix scans
+ * per column; replaces the dense dgetrf/dgetri inverse of src/libcd/chomp.c:393-403) or the dense
+ * inverse (D > 4); any output may be NULL */
 int orc_host_metric(int m, int derivative, double dt, double * A_out, double * beta_s_out, double * beta_g_out,
    double kappa_out[3], const double * rhs, int ncols, double * solve_out);
 /* the same with the start point a variable (`start_tsr`: inits[0] == NULL, src/orcdchomp_mod.cpp:2572) */
 int orc_host_metric_free_start(int m, int derivative, double dt, double * A_out, double * beta_s_out, double * beta_g_out,
    double kappa_out[3], const double * rhs, int ncols, double * solve_out);
+/* rank of the semiseparable form of A^-1 the device applies for this metric (0: none -- derivative 1 has its closed
+ * form, derivative > 4 the dense inverse); -1 on bad arguments */
+int orc_host_metric_semisep_rank(int m, int derivative, double dt, int free_start);
 /* GSL's default generator restated (src/orcdchomp_mod.cpp:2303-2304,2763,2767): n gaussians with
  * the given sigma from seed, then one uniform; out_gauss[n], out_uniform[1] */
 int orc_host_gsl_stream(unsigned long seed, double sigma, int n, double * out_gauss, double * out_uniform);

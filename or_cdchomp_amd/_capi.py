@@ -92,6 +92,7 @@ SYMBOLS = [
                                   c_double_p, C.c_int, c_double_p]),
     ("orc_host_metric_free_start", C.c_int, [C.c_int, C.c_int, C.c_double, c_double_p, c_double_p, c_double_p, c_double_p,
                                   c_double_p, C.c_int, c_double_p]),
+    ("orc_host_metric_semisep_rank", C.c_int, [C.c_int, C.c_int, C.c_double, C.c_int]),
     ("orc_host_gsl_stream", C.c_int, [C.c_ulong, C.c_double, C.c_int, c_double_p, c_double_p]),
 ]
 

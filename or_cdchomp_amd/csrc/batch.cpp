@@ -660,7 +660,11 @@ void BatchShard::build_device(const Robot & robot)
    const int n_tsrs_in = (int) params.tsrs.size();
    const int asked_block = mod_->workgroup_threads ? mod_->workgroup_threads : params.workgroup_threads;
    // (ORC_PAIRS16=1: the robots of the 16-lane family too, an experiment: profiles/r05_ab_experiments.txt)
-   if (sizeof(real) == 8 && (M.GS == 32 || (M.GS == 16 && getenv("ORC_PAIRS16") && !M.floating && nj <= 16 && n_tsrs_in == 0)) && !M.tree && M.jt_scan == 1 && !params.free_start
+   // Round 6: trees whose joints move contiguous ranges of the sorted spheres (jt_scan 2: a WAM with its finger dofs active) and
+   // fp32 runs take the family too (256-thread workgroups; the latency shape stays an fp64 chain's)
+   const bool pair_chain64 = sizeof(real) == 8 && !M.tree && M.jt_scan == 1;
+   const bool pair_other = M.GS == 32 && ((M.tree && M.jt_scan == 2) || (!M.tree && M.jt_scan == 1)) && !getenv("ORC_PAIRS_CHAIN64_ONLY");
+   if ((pair_chain64 || pair_other) && (M.GS == 32 || (sizeof(real) == 8 && M.GS == 16 && getenv("ORC_PAIRS16") && !M.floating && nj <= 16 && n_tsrs_in == 0)) && !params.free_start
        && (asked_block == 0 || asked_block == 256 || (asked_block == 512 && M.GS == 32))
        && !getenv("ORC_NO_PAIRS") && !getenv("ORC_NO_KIND") && !getenv("ORC_BLOCK_THREADS"))
    {
@@ -806,6 +810,10 @@ void BatchShard::build_device(const Robot & robot)
    if (M.GS != 16 && !M.floating && M.jt_scan == (M.tree ? 2 : 1) && !getenv("ORC_NO_KIND") && !pairs)
       tree_ |= 16;                              // many-sphere path: the J^T form is known
    if (pairs) tree_ |= 512 | (M.floating ? 64 : 0);      // the 32-lane family with the dense pair list
+   // (the family is a function of the robot and the run, not of the shape asked for: the latency shape -- 512 threads, what the
+   // single-run `create` asks for -- exists for the fp64 chain only; a tree or an fp32 run keeps the family at 256 threads, so
+   // that a run alone has the bits it has inside a batch)
+   pairs_latency_shape_ = pairs && pair_chain64;
    pair_entries_ = pairs ? ptab.rounds * M.GS : 0;
 
    hipStream_t st = stream_;
@@ -978,6 +986,9 @@ void BatchShard::build_device(const Robot & robot)
    // A^-1: closed-form Toeplitz inverse through two wave scans per column when the metric is
    // ca tridiag(-1,2,-1) (derivative 1), else cyclic reduction (tridiagonal) or the dense inverse
    solve_mode_ = (params.derivative == 1) ? 0 : 1;
+   // derivative 2..4: the band inverse through its rank-D generators, D prefix and D suffix wave scans per column (the dense
+   // inverse stays for a metric whose generators the host's check rejects, and as ORC_NO_SEMISEP=1 for A/B runs)
+   if (metric_.ss_rank > 0 && !getenv("ORC_NO_SEMISEP")) solve_mode_ = 3;
    if (params.derivative == 1 && m <= 64*ORC_SCAN_RPL && metric_.Aband.size() == (size_t) 3*m
        && (m < 2 || metric_.Aband[(size_t) 1*m] == -2.0 * metric_.Aband[(size_t) 2*m]) && !getenv("ORC_NO_SCAN_SOLVE"))
       solve_mode_ = 2;
@@ -1000,7 +1011,35 @@ void BatchShard::build_device(const Robot & robot)
          pcr_rows_ = 2*metric_.pcr_levels + 1; pcr_sym_ = 0;
       }
    }
-   if (metric_.Ainv.empty() && n_tsrs_ > 0)
+   if (solve_mode_ == 3)
+   {
+      // The metric's tables of a higher derivative, one array of doubles (also for fp32 runs: the scans and the band rows are
+      // taken in double) that travels like the cyclic-reduction tables of derivative 1 -- staged in LDS when the plan has room,
+      // read through L2 otherwise: U [D][m], V [D][m] (generators of the band inverse), then the D rows at either end of the band
+      // with their couplings to the end points, [2D][2D+3] = A[i][i-D..i+D], beta_s[i], beta_g[i] (the rows between are one
+      // Toeplitz row, kernarg scalars: DevBatch::band_c)
+      const int D = metric_.ss_rank;
+      std::vector<double> tab(metric_.ssU);
+      tab.insert(tab.end(), metric_.ssV.begin(), metric_.ssV.end());
+      for (int e=0; e<2*D; e++)
+      {
+         const int i = (e < D) ? e : m - 2*D + e;
+         for (int k=-D; k<=D; k++) tab.push_back((i+k >= 0 && i+k < m) ? metric_.Aband[(size_t)(k+D)*m + i] : 0.0);
+         tab.push_back(metric_.beta_s[i]); tab.push_back(metric_.beta_g[i]);
+      }
+      const size_t per = sizeof(double) / sizeof(real);                     // reals per table entry
+      pcr_rows_ = (int)((tab.size() * per + (size_t) m - 1) / (size_t) m);
+      tab.resize(((size_t) pcr_rows_ * m + per - 1) / per, 0.0);
+      // (as bytes: for an fp32 run every entry takes two reals of the table area)
+      const size_t bytes = (size_t) pcr_rows_ * m * sizeof(real);
+      real * d = dev_alloc<real>((size_t) pcr_rows_ * m);
+      hip_check(hipMemsetAsync(d, 0, bytes, st), "metric tables");
+      hip_check(hipMemcpyAsync(d, tab.data(), std::min(bytes, tab.size() * sizeof(double)), hipMemcpyHostToDevice, st), "metric tables");
+      hip_check(hipStreamSynchronize(st), "metric tables sync");
+      d_pcr_ = d;
+      pcr_sym_ = 0;
+   }
+   if (metric_.Ainv.empty() && (n_tsrs_ > 0 || solve_mode_ == 1))
    {
       // the constraint step multiplies by entries of the dense inverse (src/libcd/chomp.c:567-575,592-599)
       metric_.Ainv = metric_.Adense;
@@ -1031,6 +1070,7 @@ void BatchShard::build_device(const Robot & robot)
    // can ask for the 192-thread shape for the whole module: orc_set_workgroup_threads (measured, one
    // launch of 1024 WAM runs: 9.3 M it/s against 8.4 M; from 4096 runs on the order is reversed).
    force_block = mod_->workgroup_threads ? mod_->workgroup_threads : params.workgroup_threads;
+   if ((tree_ & 512) && force_block == 512 && !pairs_latency_shape_) force_block = 0;
    // orc_set_workgroups_per_cu(4): the fp64 16-lane kernels of a fixed-base chain also exist at 128 VGPRs, four 256-thread
    // workgroups per CU (three tiles instead of two for the WAM): +3 % when launches overlap, -3 % one launch at a time
    int want_wgs = mod_->workgroups_per_cu ? mod_->workgroups_per_cu : params.workgroups_per_cu;
@@ -1105,7 +1145,7 @@ void BatchShard::build_device(const Robot & robot)
             // T in global memory: the update phase and the cost sums work on a copy staged in the dead tile buffers (round 4)
             // unless the run has constraints (their phase reads the trajectory where FK does) or ORC_T_STAGED=0
             const bool want_staged = !t_lds && n_tsrs_ == 0 && !(getenv("ORC_T_STAGED") && atoi(getenv("ORC_T_STAGED")) == 0);
-            int flags = (solve_mode_ == 2 ? ORC_LDS_SMALL_WORK : 0) | (g_lds ? 0 : ORC_LDS_G_GLOBAL) | (t_lds ? 0 : ORC_LDS_T_GLOBAL)
+            int flags = ((solve_mode_ == 2 || solve_mode_ == 3) ? ORC_LDS_SMALL_WORK : 0) | (g_lds ? 0 : ORC_LDS_G_GLOBAL) | (t_lds ? 0 : ORC_LDS_T_GLOBAL)
                       | (want_staged ? ORC_LDS_T_STAGED : 0);
             if (with_pcr && !pcr_rows) continue;
             if (force_pcr >= 0 && with_pcr != force_pcr && pcr_rows) continue;
@@ -1420,12 +1460,34 @@ void BatchShard::launch(int n_iter, bool final_eval, bool carry)
    b.solve_mode = solve_mode_;
    b.pcr_levels = metric_.pcr_levels;
    b.pcr = (const real *) d_pcr_; b.Ainv = (const real *) d_Ainv_;
+   b.ss_rank = (solve_mode_ == 3) ? metric_.ss_rank : 0;
    b.jl_lo = (const real *) d_jl_lo_; b.jl_hi = (const real *) d_jl_hi_;
    b.hmc_iters = d_hmc_iters_; b.noise = (const real *) d_noise_; b.max_resamples = max_resamples_;
    b.n_iter = n_iter; b.final_eval = final_eval ? 1 : 0; b.carry_status = carry ? 1 : 0;
    b.phase_cycles = d_phase_;
    b.pcr_in_lds = pcr_in_lds_; b.pcr_sym = pcr_sym_; b.pcr_rows = pcr_rows_; b.ag_in_lds = ag_in_lds_;
    b.stagger_mode = stagger_mode_; b.stagger_sleeps = stagger_sleeps_; b.lim_generic = lim_generic_;
+   b.band_toeplitz = 0;
+   for (int k=0; k<=ORC_SS_MAX_RANK; k++) { b.band_c[k] = (real)0; b.band_c64[k] = 0.0; }
+   {
+      // a higher derivative: is the band one Toeplitz row away from the D rows at either end, with no coupling to the end points?
+      const int D = metric_.D;
+      if (solve_mode_ == 3 && D >= 2 && D <= ORC_SS_MAX_RANK && m >= 2*D + 1 && !getenv("ORC_NO_BAND_TOEPLITZ"))
+      {
+         bool ok = true;
+         for (int i=D; i<m-D && ok; i++)
+         {
+            for (int k=-D; k<=D; k++)
+               if (metric_.Aband[(size_t)(k+D)*m + i] != metric_.Aband[(size_t)(std::abs(k)+D)*m + D]) ok = false;
+            if (metric_.beta_s[i] != 0.0 || metric_.beta_g[i] != 0.0) ok = false;
+         }
+         if (ok)
+         {
+            b.band_toeplitz = 1;
+            for (int k=0; k<=D; k++) { b.band_c64[k] = metric_.Aband[(size_t)(k+D)*m + D]; b.band_c[k] = (real) b.band_c64[k]; }
+         }
+      }
+   }
    if (params.derivative == 1 && m >= 2)
    {
       b.a_diag = (real) metric_.Adense[(size_t) 1*m + 1];
@@ -1534,6 +1596,12 @@ void BatchShard::gettraj(double * out)
 {
    DeviceGuard guard(device);
    download(d_traj_, (size_t) n_runs * n_points * n, params.precision, out, stream_);
+}
+
+void BatchShard::get_plan(double out[8]) const
+{
+   out[0] = tree_; out[1] = block_; out[2] = (double) lds_bytes_; out[3] = tile_m_; out[4] = solve_mode_;
+   out[5] = (double)((160*1024) / ((lds_bytes_ + 1279) / 1280 * 1280)); out[6] = n_tiles_; out[7] = GS_;
 }
 
 void BatchShard::get_state(const std::string & which, double * out)
@@ -1669,6 +1737,8 @@ void Batch::gettraj(double * out)
 {
    for_shards([&](size_t k) { shards[k]->gettraj(out + (size_t) offs[k] * n_points * n); }, true);
 }
+
+void Batch::get_plan(double out[8]) { shards[0]->get_plan(out); }
 
 void Batch::get_state(const std::string & which, double * out)
 {

@@ -284,11 +284,15 @@ int orc_env_add_kinbody_trimesh(orc_module * mod, const char * name, int n_tri, 
    return guarded(mod, [&] {
       if (n_tri < 1) throw std::runtime_error("a mesh needs at least one triangle!");
       need(vertices, "vertices");
-      for (int i=0; i<9*n_tri; i++) if (!std::isfinite(vertices[i])) throw std::runtime_error("mesh vertices must be finite numbers!");
+      if (n_tri > (1 << 26)) throw std::runtime_error("too many triangles in one mesh (at most 2^26)!");
+      for (size_t i=0; i<9*(size_t) n_tri; i++) if (!std::isfinite(vertices[i])) throw std::runtime_error("mesh vertices must be finite numbers!");
       const std::string nm = str(name, "name");
       if (mod->impl->has_body(nm))
       {
-         // a kinbody of boxes gets its mesh geometry added (a body may have both kinds); a robot of that name is an error
+         // a kinbody of boxes gets its mesh geometry added (a body may have both kinds); a robot of that name is an error.
+         // A body whose distance field exists already keeps the field of its OLD geometry (computedistancefield refuses a second
+         // one: "We already have an sdf for this kinbody!"), so new geometry for it is an error here, not a stale field later
+         if (mod->impl->find_sdf(nm)) throw std::runtime_error("that kinbody has a distance field already: removefield first!");
          orc::KinBody & k = mod->impl->kinbody(nm);
          k.tris.insert(k.tris.end(), vertices, vertices + 9*(size_t) n_tri);
          return;
@@ -319,6 +323,7 @@ int orc_kinbody_set_spheres(orc_module * mod, const char * name, int n_spheres, 
          for (int q=0; q<3; q++) sp.pos[q] = sphere_pos[3*i+q];
          k.spheres.push_back(sp);
       }
+      mod->impl->refresh_grab_contacts(k.name);      // (a held body's contacts were taken with its old spheres)
    });
 }
 
@@ -489,6 +494,12 @@ int orc_batch_get_state(orc_module * mod, int id, const char * which, double * o
          for (size_t i=0; i<tmp.size(); i++) out[i] = (double) tmp[i];
          return;
       }
+      if (std::string(which) == "plan")
+      {
+         if (cap < 8) throw std::runtime_error("buffer too small!");
+         b.get_plan(out);
+         return;
+      }
       if (cap < (size_t) b.n_runs * b.m * b.n) throw std::runtime_error("buffer too small!");
       b.get_state(which, out);
    });
@@ -587,6 +598,9 @@ int orc_host_voxelize_trimesh(const int sizes[3], const double lengths[3], const
 {
    try
    {
+      if (!sizes || !lengths || !pose_world_gsdf || !occupancy_out || (n_tri > 0 && !world_vertices) || n_tri > (1 << 26)) return 1;
+      for (int i=0; i<3; i++) if (sizes[i] < 1 || !(lengths[i] > 0.0)) return 1;
+      if (!(cube_extent > 0.0)) return 1;
       orc::Grid g;
       for (int i=0; i<3; i++) { g.sizes[i] = sizes[i]; g.lengths[i] = lengths[i]; }
       const std::vector<double> tris(world_vertices, world_vertices + 9*(size_t)(n_tri > 0 ? n_tri : 0));
@@ -643,6 +657,8 @@ static int host_metric_impl(bool free_start, int m, int derivative, double dt, d
             const double * invb = &M.pcr[(size_t)(2*M.pcr_levels)*m];
             for (int i=0; i<m; i++) for (int c=0; c<n; c++) solve_out[(size_t) i*n+c] = cur[(size_t) i*n+c] * invb[i];
          }
+         else if (M.ss_rank > 0)
+            orc::semisep_apply(M, rhs, n, solve_out);      // the device's scans over the band inverse's generators, serially
          else
             for (int i=0; i<m; i++) for (int c=0; c<n; c++)
             {
@@ -665,6 +681,18 @@ int orc_host_metric_free_start(int m, int derivative, double dt, double * A_out,
    double kappa_out[3], const double * rhs, int ncols, double * solve_out)
 {
    return host_metric_impl(true, m, derivative, dt, A_out, beta_s_out, beta_g_out, kappa_out, rhs, ncols, solve_out);
+}
+
+int orc_host_metric_semisep_rank(int m, int derivative, double dt, int free_start)
+{
+   try
+   {
+      if (m < 1 || derivative < 1) return -1;
+      orc::Metric M;
+      orc::build_metric(m, derivative, dt, M, free_start != 0);
+      return M.ss_rank;
+   }
+   catch (...) { return -1; }
 }
 
 int orc_host_gsl_stream(unsigned long seed, double sigma, int n, double * out_gauss, double * out_uniform)

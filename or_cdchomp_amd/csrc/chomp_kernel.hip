@@ -25,6 +25,8 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <atomic>
+#include <type_traits>
+#include <utility>
 #include "dev_types.h"
 
 // the device arithmetic may fuse a*b+c (the host files are built with -ffp-contract=off so that
@@ -444,6 +446,144 @@ __device__ __forceinline__ void toeplitz_scan_column(PT buf, int m, int n, int c
    }
 }
 
+// x = A^-1 g for the band metric of a higher derivative (A = K_D^T K_D / N_D, half-bandwidth D = RANK: penta-diagonal for
+// `derivative 2`, hepta-diagonal for 3; src/libcd/chomp.c:239-340), one column of buf [m][n] in place, by the calling wavefront.
+// The inverse of a band matrix is semiseparable: Ainv[i][j] = sum_k U[k][i] V[k][j] for i <= j (generators from the host,
+// host_math.cpp build_semisep; the mirror image below the diagonal), so
+//    x_i = sum_k U[k][i] S_k(i) + V[k][i] P_k(i),   S_k(i) = sum_{j >= i} V[k][j] g_j,   P_k(i) = sum_{j < i} U[k][j] g_j:
+// RANK prefix and RANK suffix sums per column where the Toeplitz metric of derivative 1 has one of each
+// (toeplitz_scan_column).  A lane owns `rpl` consecutive rows; the sums across lanes are wave scans, in double for either
+// precision of the run.  REGS: the lane's rows and table entries stay in registers (rpl <= 4); else they are read again in the
+// second pass (any rpl).  The reference multiplies by the dense inverse (chomp.c:525-548, dgetrf + dgetri at 393-403).
+template <typename real, int RANK, bool REGS, typename PT>
+__device__ __forceinline__ void semisep_scan_column(PT buf, int m, int n, int c, int rpl, const double * U, const double * V)
+{
+   const int lane = threadIdx.x & 63;
+   const int row0 = lane*rpl;
+   double su[RANK], sv[RANK];
+#pragma unroll
+   for (int k=0; k<RANK; k++) { su[k] = 0.0; sv[k] = 0.0; }
+   if (REGS)
+   {
+      // (reads are unconditional, from a clamped row: a predicated read is a branch around it plus its 64-bit address arithmetic,
+      // and a lone wavefront issues a vector instruction every ~9 cycles; rows past the end take part with g = 0)
+      double g[4], u[RANK][4], v[RANK][4];
+#pragma unroll
+      for (int r=0; r<4; r++)
+      {
+         if (r >= rpl) { g[r] = 0.0; for (int k=0; k<RANK; k++) { u[k][r] = 0.0; v[k][r] = 0.0; } continue; }      // (wave-uniform)
+         const int row = row0 + r, rc = (row < m) ? row : m - 1;
+         const double gv = (double) buf[rc*n + c];
+         g[r] = (row < m) ? gv : 0.0;
+#pragma unroll
+         for (int k=0; k<RANK; k++)
+         {
+            u[k][r] = U[k*m + rc]; v[k][r] = V[k*m + rc];
+            su[k] += u[k][r] * g[r]; sv[k] += v[k][r] * g[r];
+         }
+      }
+      double P[RANK], S[RANK];
+#pragma unroll
+      for (int k=0; k<RANK; k++)
+      {
+         const double ip = wave_prefix_incl(su[k]);
+         P[k] = __shfl_up(ip, 1, 64); if (lane == 0) P[k] = 0.0;      // rows before this lane's
+         S[k] = wave_suffix_incl(sv[k]);                              // rows from this lane's first on
+      }
+#pragma unroll
+      for (int r=0; r<4; r++)
+      {
+         if (r >= rpl) continue;
+         const int row = row0 + r;
+         double x = 0.0;
+#pragma unroll
+         for (int k=0; k<RANK; k++) x += u[k][r] * S[k] + v[k][r] * P[k];
+         if (row < m) buf[row*n + c] = (real) x;
+#pragma unroll
+         for (int k=0; k<RANK; k++) { P[k] += u[k][r] * g[r]; S[k] -= v[k][r] * g[r]; }
+      }
+      return;
+   }
+   for (int r=0; r<rpl; r++)
+   {
+      const int row = row0 + r;
+      if (row >= m) break;
+      const double g = (double) buf[row*n + c];
+#pragma unroll
+      for (int k=0; k<RANK; k++) { su[k] += U[k*m + row] * g; sv[k] += V[k*m + row] * g; }
+   }
+   double P[RANK], S[RANK];
+#pragma unroll
+   for (int k=0; k<RANK; k++)
+   {
+      const double ip = wave_prefix_incl(su[k]);
+      P[k] = __shfl_up(ip, 1, 64); if (lane == 0) P[k] = 0.0;
+      S[k] = wave_suffix_incl(sv[k]);
+   }
+   for (int r=0; r<rpl; r++)
+   {
+      const int row = row0 + r;
+      if (row >= m) break;
+      const double g = (double) buf[row*n + c];
+      double x = 0.0;
+#pragma unroll
+      for (int k=0; k<RANK; k++)
+      {
+         const double uk = U[k*m + row], vk = V[k*m + row];
+         x += uk * S[k] + vk * P[k];
+         P[k] += uk * g; S[k] -= vk * g;
+      }
+      buf[row*n + c] = (real) x;
+   }
+}
+template <typename real, typename PT>
+__device__ __forceinline__ void semisep_scan_column_any(PT buf, int m, int n, int c, int rank, const double * U, const double * V)
+{
+   const int rpl = (m + 63) >> 6;
+   if (rpl <= 4)
+      switch (rank)
+      {
+      case 2: semisep_scan_column<real, 2, true>(buf, m, n, c, rpl, U, V); break;
+      case 3: semisep_scan_column<real, 3, true>(buf, m, n, c, rpl, U, V); break;
+      default: semisep_scan_column<real, 4, true>(buf, m, n, c, rpl, U, V); break;
+      }
+   else
+      switch (rank)
+      {
+      case 2: semisep_scan_column<real, 2, false>(buf, m, n, c, rpl, U, V); break;
+      case 3: semisep_scan_column<real, 3, false>(buf, m, n, c, rpl, U, V); break;
+      default: semisep_scan_column<real, 4, false>(buf, m, n, c, rpl, U, V); break;
+      }
+}
+// all n columns of buf [m][n] in place, a wavefront per column at a time: ONE barrier, like the scan solve of derivative 1.
+// A column that is zero throughout (the joint-limit rounds solve for a Gjlimit with a few non-zero columns) is left alone.
+template <typename real, int BLOCK, typename BT>
+__device__ __forceinline__ real * semisep_scan_solve(const BT & b, const real * tab, real * buf)
+{
+   const int m = b.m, n = b.n, rank = b.ss_rank;
+   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+   const int rpl = (m + 63) >> 6;
+   const double * U = (const double *) tab, * V = U + rank*m;      // (the metric's tables: DevBatch::ss_rank)
+   for (int c=wave; c<n; c+=BLOCK/64)
+   {
+      bool any = false;
+      for (int r=0; r<rpl; r++) { const int row = lane*rpl + r; any = any || ((row < m) && buf[row*n + c] != (real)0); }
+      if (__ballot(any) == 0ull) continue;
+      semisep_scan_column_any<real>(buf, m, n, c, rank, U, V);
+   }
+   __syncthreads();
+   return buf;
+}
+
+// (arguments of a called function arrive in vector registers: these tell the compiler they are wave-uniform)
+__device__ __forceinline__ unsigned long long uni64(unsigned long long v)
+{
+   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned) v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+   return ((unsigned long long) hi << 32) | lo;
+}
+__device__ __forceinline__ double unir(double v) { return __longlong_as_double((long long) uni64((unsigned long long) __double_as_longlong(v))); }
+__device__ __forceinline__ float unir(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+
 // Joint-limit projection rounds (src/libcd/chomp.c:608-655) for the tridiagonal Toeplitz metric,
 // executed by ONE wavefront (the caller's; the others wait at the barrier that follows): a round has
 // no barrier in it.  Lane = `rpl` consecutive waypoints, loop over the columns.  A round is:
@@ -451,8 +591,9 @@ __device__ __forceinline__ void toeplitz_scan_column(PT buf, int m, int n, int c
 // to the first row-major index) -> GA = A^-1 Gjlimit by the scan solve, only for the columns that
 // have a violation -> T += 1.01 Gjlimit[l]/GA[l] * GA on those columns.
 // Returns the number of rounds made (1000: the caller sets the status).
-template <typename real, typename PT, typename PG, typename PJ>
-__device__ __forceinline__ int limit_rounds_wave(PT T_s, PG G_s, PJ jl_s, int m, int n, real kinv, long long * dbg_total)
+// SOLVE: solve_col(c) replaces column c of G_s by A^-1 of it (the calling wavefront's work)
+template <typename real, typename PT, typename PG, typename PJ, typename SOLVE>
+__device__ __forceinline__ int limit_rounds_wave_with(PT T_s, PG G_s, PJ jl_s, int m, int n, SOLVE solve_col, long long * dbg_total)
 {
    const int lane = threadIdx.x & 63;
    const int rpl = (m + 63) >> 6;
@@ -516,7 +657,7 @@ __device__ __forceinline__ int limit_rounds_wave(PT T_s, PG G_s, PJ jl_s, int m,
       const real gl = G_s[ge];                        // Gjlimit[largest]
       if (dbg_total) *dbg_total += __popcll(cols);
       for (int c=0; c<n; c++)
-         if ((cols >> c) & 1ull) toeplitz_scan_column<real>(G_s, m, n, c, rpl, kinv);
+         if ((cols >> c) & 1ull) solve_col(c);
       const real sc = ((real)1.01 * gl) * rcp_fast(G_s[gi*n + gc]);
       for (int c=0; c<n; c++)
          if ((cols >> c) & 1ull)
@@ -530,6 +671,23 @@ __device__ __forceinline__ int limit_rounds_wave(PT T_s, PG G_s, PJ jl_s, int m,
          }
    }
    return rounds;
+}
+template <typename real, typename PT, typename PG, typename PJ>
+__device__ __forceinline__ int limit_rounds_wave(PT T_s, PG G_s, PJ jl_s, int m, int n, real kinv, long long * dbg_total)
+{
+   const int rpl = (m + 63) >> 6;
+   return limit_rounds_wave_with<real>(T_s, G_s, jl_s, m, n, [&](int c) { toeplitz_scan_column<real>(G_s, m, n, c, rpl, kinv); }, dbg_total);
+}
+// ... and for the band metric of a higher derivative (solve_mode 3): the same rounds with the band inverse applied through its
+// generators, one wavefront, no barrier inside (m <= 64 ORC_SCAN_RPL: the lane's rows in registers).  A function of its own,
+// like limit_rounds_call: rare, branchy code that should not take part in the update phase's register allocation.
+template <typename real, int SHAPE>
+__device__ __attribute__((noinline)) int limit_rounds_semisep_call(real * T_gen, real * G_gen, const real * jl_gen, int m_in, int n_in, int rank_in,
+   const double * U_in, const double * V_in)
+{
+   const int m = __builtin_amdgcn_readfirstlane(m_in), n = __builtin_amdgcn_readfirstlane(n_in), rank = __builtin_amdgcn_readfirstlane(rank_in);
+   const double * U = (const double *) uni64((unsigned long long) U_in), * V = (const double *) uni64((unsigned long long) V_in);
+   return limit_rounds_wave_with<real>(T_gen, G_gen, jl_gen, m, n, [&](int c) { semisep_scan_column_any<real>(G_gen, m, n, c, rank, U, V); }, nullptr);
 }
 
 
@@ -875,13 +1033,6 @@ __device__ __forceinline__ int limit_rounds_regs_rpl(PT T_s, PJ jl_s, int m, int
 // (measured: +6 % kernel time when the variants for 4..8 columns were added inline).  One copy per
 // precision serves every kernel variant.  T_s / G_s / jl_s are LDS addresses.
 struct LimResult { int rounds; long long kinds; };      // kinds: closed-form | register scans << 20 | general loop << 40
-__device__ __forceinline__ unsigned long long uni64(unsigned long long v)
-{
-   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned) v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-   return ((unsigned long long) hi << 32) | lo;
-}
-__device__ __forceinline__ double unir(double v) { return __longlong_as_double((long long) uni64((unsigned long long) __double_as_longlong(v))); }
-__device__ __forceinline__ float unir(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 
 #ifndef ORC_LIM_SPLIT
 #define ORC_LIM_SPLIT 1        // the rounds of one or two columns are a function of their own (its register appetite, and with it the callee-saved registers a call saves and restores, is a third of the large cases')
@@ -977,41 +1128,138 @@ template <typename real, int BLOCK, typename BT>
 __device__ __forceinline__ real * metric_solve(const BT & b, const real * tab, real * src, real * tmp)
 {
    if (b.solve_mode == 2) return toeplitz_scan_solve<real, BLOCK>(b, src);
+   if (b.solve_mode == 3) return semisep_scan_solve<real, BLOCK>(b, tab, src);
    return b.solve_mode == 0 ? pcr_solve<real, BLOCK>(b, tab, src, tmp) : dense_solve<real, BLOCK>(b, src, tmp);
+}
+
+// Row i, column c of A T + B for a higher derivative (|D| >= 2, or derivative 1 without a start boundary), in the
+// accumulation type `acc` (double for fp32 runs: the band's entries are ~1/dt^4, 1e7 for 200 waypoints, and the row's sum is of
+// order one to a hundred -- summed in fp32 the rounding alone is of that order; `tab` is then the band in double).
+// bt_out: the row's term of B alone (beta_s[i] q_start + beta_g[i] q_goal).
+// Away from the D rows at either end the band is Toeplitz and B is zero (DevBatch::band_toeplitz, checked on the host): the
+// 2D+1 coefficients are scalars of the kernarg block.  The end rows read their coefficients from the table -- all loads issued
+// before the first use (a loop over a run-time D made one L2 round trip per coefficient: 4 k cycles per entry, a third of the
+// update phase of a `derivative 2` run).
+template <typename real, typename acc, typename BT>
+__device__ __forceinline__ acc band_row(const BT & b, const real * tab, const real * T_s, int i, int c, acc & bt_out)
+{
+   constexpr int R = ORC_SS_MAX_RANK;
+   const int m = b.m, n = b.n;
+   const int D = (b.D < 0) ? -b.D : b.D;      // (-1: tridiagonal without a start boundary, DevBatch::D)
+   const bool dbl = (sizeof(acc) == 8 && sizeof(real) == 4);
+   // (the Toeplitz row's coefficients first, all of them and before any branch: scalar loads of the kernarg block that are then
+   // certain to execute, so the compiler can move them out of the callers' loops)
+   acc cf[R+1];
+#pragma unroll
+   for (int k=0; k<=R; k++) cf[k] = dbl ? (acc) b.band_c64[k] : (acc) b.band_c[k];
+   const int toep = b.band_toeplitz;      // (set only with solve_mode 3: the end rows are in the metric's table)
+   if (D >= 2 && D <= R && toep && sizeof(acc) == 8)
+   {
+      // Every lane evaluates the Toeplitz row (at a clamped row index, so that all reads are unconditional); the wavefronts that
+      // hold one of the D rows at either end then evaluate that row from the metric's table as well -- 2D+1 coefficients and the two
+      // couplings, contiguous, read unconditionally (a lane that has no end row reads row 0; coefficients of columns outside the
+      // matrix are stored as zeros and meet a clamped trajectory row) -- and the lanes pick.  As predicated reads the end rows
+      // cost ~300 vector instructions of address arithmetic and branches for the two wavefronts that hold them: 4 k cycles per pass.
+      const bool is_end = !(i >= D && i < m - D);
+      const int ic = (i < D) ? D : ((i >= m - D) ? m - D - 1 : i);
+      const real * rowT = T_s + (ic+1)*n + c;
+      acc sum = (acc)0;
+      switch (D)      // (wave-uniform; the sums run from k = -D upwards, the order of the reference's dense row)
+      {
+      case 2:
+#pragma unroll
+         for (int k=-2; k<=2; k++) sum += cf[k < 0 ? -k : k] * (acc) rowT[k*n];
+         break;
+      case 3:
+#pragma unroll
+         for (int k=-3; k<=3; k++) sum += cf[k < 0 ? -k : k] * (acc) rowT[k*n];
+         break;
+      default:
+#pragma unroll
+         for (int k=-4; k<=4; k++) sum += cf[k < 0 ? -k : k] * (acc) rowT[k*n];
+         break;
+      }
+      acc bt = (acc)0;
+#if defined(ORC_ABLATE_BANDEND)      // (timing experiments: the end rows take the Toeplitz row -- wrong results)
+      if (false)
+#else
+      if (__builtin_amdgcn_ballot_w64(is_end) != 0ull)
+#endif
+      {
+         const int er = is_end ? ((i < D) ? i : i - (m - 2*D)) : 0;
+         const double * row = (const double *) tab + 2*D*m + er * (2*D + 3);
+         const acc bte = (acc) row[2*D+1] * (acc) T_s[c] + (acc) row[2*D+2] * (acc) T_s[(b.n_points-1)*n + c];
+         acc se = bte;
+         auto end_row = [&](auto dd) {
+            constexpr int DD = decltype(dd)::value;
+#pragma unroll
+            for (int k=-DD; k<=DD; k++)
+            {
+               const int r = i + k, rc = (r < 0) ? 0 : ((r >= m) ? m - 1 : r);
+               se += (acc) row[k+DD] * (acc) T_s[(rc+1)*n + c];
+            }
+         };
+         switch (D)
+         {
+         case 2: end_row(std::integral_constant<int, 2>{}); break;
+         case 3: end_row(std::integral_constant<int, 3>{}); break;
+         default: end_row(std::integral_constant<int, 4>{}); break;
+         }
+         sum = is_end ? se : sum;
+         bt = is_end ? bte : bt;
+      }
+      bt_out = bt;
+      return sum;
+   }
+   const acc * tabA = dbl ? (const acc *) b.metric64 : (const acc *) b.Aband;
+   const acc * tbs = dbl ? tabA + (size_t)(2*D + 1) * m : (const acc *) b.beta_s;
+   const acc * tbg = dbl ? tbs + m : (const acc *) b.beta_g;
+   const acc bt = tbs[i] * (acc) T_s[c] + tbg[i] * (acc) T_s[(b.n_points-1)*n + c];
+   bt_out = bt;
+   acc sum = bt;
+   if (D <= R)
+   {
+      acc a[2*R+1], t[2*R+1];
+#pragma unroll
+      for (int q=0; q<2*R+1; q++)
+      {
+         const int k = q - R, r = i + k;
+         const bool ok = (k >= -D) && (k <= D) && (r >= 0) && (r < m);
+         a[q] = ok ? tabA[(size_t)(k+D) * m + i] : (acc)0;
+         t[q] = ok ? (acc) T_s[(r+1)*n + c] : (acc)0;
+      }
+#pragma unroll
+      for (int q=0; q<2*R+1; q++)
+      {
+         const int k = q - R, r = i + k;
+         if ((k >= -D) && (k <= D) && (r >= 0) && (r < m)) sum += a[q] * t[q];
+      }
+      return sum;
+   }
+   for (int k=-D; k<=D; k++)
+   {
+      const int r = i + k;
+      if (r < 0 || r >= m) continue;
+      sum += tabA[(size_t)(k+D) * m + i] * (acc) T_s[(r+1)*n + c];
+   }
+   return sum;
 }
 
 // (A T + B)[i][c] from the band of A and the endpoint couplings of B.
 // T_s holds all n_points rows (row 0 = start, row n_points-1 = goal).
 template <typename real, typename BT>
-__device__ __forceinline__ real smooth_grad(const BT & b, const real * T_s, int i, int c)
+__device__ __forceinline__ real smooth_grad(const BT & b, const real * tab, const real * T_s, int i, int c)
 {
-   const int m = b.m, n = b.n;
-   int D = b.D;
-   if (D == 1)       // tridiagonal Toeplitz: the end rows couple to the fixed endpoints with a_off
+   const int n = b.n;
+   if (b.D == 1)       // tridiagonal Toeplitz: the end rows couple to the fixed endpoints with a_off
       return b.a_diag * T_s[(i+1)*n + c] + b.a_off * (T_s[i*n + c] + T_s[(i+2)*n + c]);
-   D = (D < 0) ? -D : D;      // (-1: tridiagonal without a start boundary, DevBatch::D)
    if (sizeof(real) == 4 && b.metric64)
    {
-      // fp32 and a higher derivative: the band's entries are ~1/dt^4 (1e7 for 200 waypoints) and the row's sum is of order
-      // one to a hundred: summed in fp32 the rounding alone is of that order.  Taken in double from the band in double.
-      const double * A64 = b.metric64, * bs64 = A64 + (size_t)(2*D + 1) * m, * bg64 = bs64 + m;
-      double s = bs64[i] * (double) T_s[c] + bg64[i] * (double) T_s[(b.n_points-1)*n + c];
-      for (int k=-D; k<=D; k++)
-      {
-         const int r = i + k;
-         if (r < 0 || r >= m) continue;
-         s += A64[(size_t)(k+D) * m + i] * (double) T_s[(r+1)*n + c];
-      }
-      return (real) s;
+      double bt;
+      return (real) band_row<real, double>(b, tab, T_s, i, c, bt);
    }
-   real s = b.beta_s[i] * T_s[c] + b.beta_g[i] * T_s[(b.n_points-1)*n + c];
-   for (int k=-D; k<=D; k++)
-   {
-      const int r = i + k;
-      if (r < 0 || r >= m) continue;
-      s += b.Aband[(size_t)(k+D) * m + i] * T_s[(r+1)*n + c];
-   }
-   return s;
+   real bt;
+   return band_row<real, real>(b, tab, T_s, i, c, bt);
 }
 
 // 1: the many-sphere cost pass of an iteration is part of the kernel function itself (see the kernel's tile loop);
@@ -1473,7 +1721,7 @@ __device__ __attribute__((noinline)) int phase_update(const void * kp, int it_in
          const int i = div_n(e, rn_f), c = e - i*n;
          real g = gq[q];
          g *= b.inv_m;
-         g += smooth_grad<real>(b, T_s, i, c);
+         g += smooth_grad<real>(b, pcr_tab, T_s, i, c);
          G_s[e] = g;
       }
    }
@@ -1486,7 +1734,7 @@ __device__ __attribute__((noinline)) int phase_update(const void * kp, int it_in
       const int i = div_n(e, rn_f), c = e - i*n;
       real g = Gc[e];
       g *= b.inv_m;
-      g += smooth_grad<real>(b, T_s, i, c);
+      g += smooth_grad<real>(b, pcr_tab, T_s, i, c);
       G_s[e] = g;
    }
    __syncthreads();
@@ -1613,7 +1861,26 @@ __device__ __attribute__((noinline)) int phase_update(const void * kp, int it_in
          __syncthreads();             // redi is reused by the reductions below
       }
    }
-   if (!LEAN && !lim_done)
+   if (!LEAN && !lim_done && b.solve_mode == 3 && m <= 64*ORC_SCAN_RPL && n <= 64 && !b.lim_generic)
+   {
+      // a higher derivative: the rounds by one wavefront, the band inverse through its generators (no barrier inside a round)
+      lim_done = true;
+      if (viol_cols != 0ull)
+      {
+         if (tid < 64)
+         {
+            constexpr int SH = (BLOCK == 512) ? 1 : (WGS ? 2 : 0);
+            const double * U = (const double *) pcr_tab;
+            const int r = limit_rounds_semisep_call<real, SH>(T_s, G_s, jl_s, m, n, b.ss_rank, U, U + b.ss_rank*m);
+            if (tid == 0) redi[0] = r;
+         }
+         __syncthreads();
+         num_limadjs = redi[0];
+         __syncthreads();
+      }
+   }
+   // (no column left its limits in the step: the first scan of the loop would find nothing)
+   if (!LEAN && !lim_done && (viol_cols != 0ull || b.lim_generic))
    for (; num_limadjs<1000; num_limadjs++)
    {
       real best = 0; int best_e = 0x7fffffff;
@@ -1771,20 +2038,19 @@ __device__ __attribute__((noinline)) PassCosts phase_costs(const void * kp, int 
          {
             // fp32 and a higher derivative: the band's entries are ~1/dt^4 and the sum is of order one, so this one sum is
             // taken in double from the band in double (the trajectory is what it is: its rounding costs ~1e-5 of the sum)
-            const int D = b.D;
-            const double * A64 = b.metric64, * bs64 = A64 + (size_t)(2*D + 1) * m, * bg64 = bs64 + m;
-            const double bt = bs64[i] * (double) T_s[c] + bg64[i] * (double) T_s[(np-1)*n + c];
-            double s = bt;
-            for (int k=-D; k<=D; k++)
-            {
-               const int r = i + k;
-               if (r < 0 || r >= m) continue;
-               s += A64[(size_t)(k+D) * m + i] * (double) T_s[(r+1)*n + c];
-            }
-            acc += (double) T_s[n + e] * (0.5 * (s + bt));
+            double bt;
+            const double sd = band_row<real, double>(b, E.pcr_tab, T_s, i, c, bt);
+            acc += (double) T_s[n + e] * (0.5 * (sd + bt));
             continue;
          }
-         const real sg = smooth_grad<real>(b, T_s, i, c);     // (A T + B)
+         if (b.D != 1)
+         {
+            real bt;
+            const real sg = band_row<real, real>(b, E.pcr_tab, T_s, i, c, bt);
+            acc += (double) T_s[n + e] * (0.5 * ((double) sg + (double) bt));
+            continue;
+         }
+         const real sg = smooth_grad<real>(b, E.pcr_tab, T_s, i, c);     // (A T + B)
          const real bt = (b.D == 1) ? b.a_off * ((i == 0 ? T_s[c] : (real)0) + (i == m-1 ? T_s[(np-1)*n + c] : (real)0))
                                     : b.beta_s[i] * T_s[c] + b.beta_g[i] * T_s[(np-1)*n + c];
          acc += (double) T_s[n + e] * (0.5 * ((double) sg + (double) bt));
@@ -2239,26 +2505,38 @@ static hipError_t launch_iterate_t(const DevBatch<real> & b, size_t lds, hipStre
             }
       return hipErrorInvalidValue;
    }
-   if (variant & 512)      // 17 .. 32 active spheres on a chain, fp64: the dense pair list (cost_pairs.h; phase_cost KIND 16)
+   if (variant & 512)      // 17 .. 32 active spheres: the dense pair list (cost_pairs.h; phase_cost KIND 16)
    {
+      const bool lean = (variant & 32) && (variant & 128) && !(variant & 64);      // one aligned field, no inactive sphere left, fixed base
       if constexpr (sizeof(real) == 8)
       {
-         const bool lean = (variant & 32) && (variant & 128) && !(variant & 64);      // one aligned field, no inactive sphere left, fixed base
          if (variant & 2)      // 16 lanes per waypoint (ORC_PAIRS16=1: the experiment of profiles/r05_ab_experiments.txt; the lean kind only)
          {
 #ifdef ORC_PAIRS16_KERNELS      // (measured -24 % against the row rotations on BASELINE configs[1]: the kernels are not in the product build)
-            if (!lean || (variant & (4 | 8))) return hipErrorInvalidValue;
+            if (!lean || (variant & (4 | 8 | 1))) return hipErrorInvalidValue;
             return (variant & 256) ? launch_iterate_tt<real, false, false, 256, 58, 4>(b, lds, stream) : launch_iterate_tt<real, false, false, 256, 58>(b, lds, stream);
 #else
             return hipErrorInvalidValue;
 #endif
          }
          if (variant & 4) return hipErrorInvalidValue;      // (no 192-thread shape: batch.cpp keeps such a module on the many-sphere family)
+         if (variant & 1)      // a tree (round 6: the WAM with its finger dofs active that holds something); no latency shape
+         {
+            if (variant & 8) return hipErrorInvalidValue;
+            if (variant & 256) return lean ? launch_iterate_tt<real, true, false, 256, 26, 4>(b, lds, stream) : launch_iterate_tt<real, true, false, 256, 16, 4>(b, lds, stream);
+            return lean ? launch_iterate_tt<real, true, false, 256, 26>(b, lds, stream) : launch_iterate_tt<real, true, false, 256, 16>(b, lds, stream);
+         }
          if (variant & 8) return lean ? launch_iterate_tt<real, false, false, 512, 26>(b, lds, stream) : launch_iterate_tt<real, false, false, 512, 16>(b, lds, stream);
          if (variant & 256) return lean ? launch_iterate_tt<real, false, false, 256, 26, 4>(b, lds, stream) : launch_iterate_tt<real, false, false, 256, 16, 4>(b, lds, stream);
          return lean ? launch_iterate_tt<real, false, false, 256, 26>(b, lds, stream) : launch_iterate_tt<real, false, false, 256, 16>(b, lds, stream);
       }
-      return hipErrorInvalidValue;
+      else
+      {
+         // fp32 (round 6): 256-thread workgroups at the fp32 many-sphere budget (four per CU), chains and trees
+         if (variant & (2 | 4 | 8)) return hipErrorInvalidValue;
+         if (variant & 1) return lean ? launch_iterate_tt<real, true, false, 256, 26>(b, lds, stream) : launch_iterate_tt<real, true, false, 256, 16>(b, lds, stream);
+         return lean ? launch_iterate_tt<real, false, false, 256, 26>(b, lds, stream) : launch_iterate_tt<real, false, false, 256, 16>(b, lds, stream);
+      }
    }
    if ((variant & 16) && !(variant & 2))      // the many-sphere path with its J^T form known (phase_cost KIND 1)
    {

@@ -1,5 +1,6 @@
-// cost_pairs.h -- cost phase of the CHOMP iteration for chains with 17 .. 32 active spheres (the robot that holds
-// something): 32 lanes per waypoint, two waypoints per wavefront, the self-collision term by a DENSE PAIR LIST.
+// cost_pairs.h -- cost phase of the CHOMP iteration for robots with 17 .. 32 active spheres (the robot that holds
+// something; chains and, since round 6, trees, fp64 and fp32): 32 lanes per waypoint, two waypoints per wavefront, the
+// self-collision term by a DENSE PAIR LIST.
 //
 // Included by chomp_kernel.hip.  Reference: sphere_cost, src/orcdchomp_mod.cpp:1134-1327 (per-sphere obstacle term
 // 1171-1246, self collision 1251-1317); velocities/accelerations src/orcdchomp_mod.cpp:1099-1127; the spheres of a
@@ -391,6 +392,20 @@ __device__ __forceinline__ void cost_tile_pairs(const BT & b, const ModelView<re
             const int src = gbase4 + ((ab & (GSL - 1)) << 2);
 #pragma unroll
             for (int k=0; k<6; k++) W[k] = bperm(src, w6[k]);
+            if (mod.jt_scan == 2)
+            {
+               // a robot whose joint tree branches (a WAM with its finger dofs active that holds something): the spheres a joint
+               // moves are a contiguous RANGE [begin, end) of the group's lanes, not a suffix: the suffix sum from `end` comes off
+               // (cost_gs16.h does the same for its trees)
+               const int ae = (jw >> 8) & 255;
+               const int src_e = gbase4 + ((ae & (GSL - 1)) << 2);
+#pragma unroll
+               for (int k=0; k<6; k++)
+               {
+                  const real lo = bperm(src_e, w6[k]);
+                  W[k] -= (ae < GSL) ? lo : (real)0;
+               }
+            }
             const real * ax = ax_s + l*astr + (jok ? j : 0)*6;
             const real c0 = W[0] - (ax[4]*W[5] - ax[5]*W[4]);
             const real c1 = W[1] - (ax[5]*W[3] - ax[3]*W[5]);

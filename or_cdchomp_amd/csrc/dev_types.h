@@ -18,6 +18,7 @@
 #ifndef ORC_WGS_PER_CU_FP32_MANY
 #define ORC_WGS_PER_CU_FP32_MANY 4   // ... of the fp32 kernels for more than 16 active spheres (128 VGPRs)
 #endif
+#define ORC_SS_MAX_RANK   4       // derivatives whose band inverse is applied through its generators (host_math.h has the same)
 #define ORC_SCAN_RPL      4       // rows per lane of the scan solve: m <= 64*ORC_SCAN_RPL
 #define ORC_VERDICT_NONE  0x7fffffffffffffffull      // key of a run without a contact (collision_verdict_kernel)
 #define ORC_LDS_HEADER    256     // bytes in front of the LDS carve-up: reduction scratch [16] doubles, [8] ints, column masks, timer mark, phase counters [8]
@@ -226,7 +227,7 @@ struct DevBatch
                            // terms (~1/dt^4) cancel to a number of order one; null otherwise
    double kss, ksg, kgg;   // trC = 0.5*(kss|s|^2 + 2 ksg s.g + kgg|g|^2)
    // A^-1 application
-   int solve_mode;         // 0 cyclic reduction (tridiagonal), 1 dense A^-1, 2 closed-form Toeplitz inverse by wave scans
+   int solve_mode;         // 0 cyclic reduction (tridiagonal), 1 dense A^-1, 2 closed-form Toeplitz inverse by wave scans, 3 band inverse of a higher derivative by wave scans over its generators
    int pcr_levels;
    const real * pcr;       // [levels][2][m] multipliers, then [m] inverse diagonal
    const real * Ainv;      // dense [m][m] when solve_mode == 1
@@ -266,6 +267,16 @@ struct DevBatch
    real * tsr_ws;             // [n_runs][tsr_ws_stride] workspace: h, h0, J, J^T x, the cons_k x cons_k system
    size_t tsr_ws_stride;
    int * tsr_err;             // [n_runs] 1 after a singular system ("constraint inversion error!")
+   // solve_mode 3 (derivative 2..4): the band inverse through its generators, Ainv[i][j] = sum_k U[k][i] V[k][j] for i <= j
+   // (host_math.cpp build_semisep).  The tables travel where the cyclic-reduction tables of derivative 1 do (`pcr`, in LDS when
+   // the plan has room), as doubles for either precision: U [ss_rank][m], V [ss_rank][m], then the band's D rows at either end,
+   // [2D][2D+3] = A[i][i-D..i+D], beta_s[i], beta_g[i]
+   // |D| >= 2: rows D .. m-D-1 of A are one Toeplitz row (band_c[|k|] = A[i][i+k], the same in every such row, and B is zero
+   // there): the kernels take the 2D+1 coefficients from here instead of a table (host-checked: band_toeplitz)
+   int band_toeplitz;
+   real band_c[ORC_SS_MAX_RANK + 1];
+   double band_c64[ORC_SS_MAX_RANK + 1];
+   int ss_rank;
 };
 
 // Collision verdict of the trajectories of a batch (the step after the path: gettraj's re-check,

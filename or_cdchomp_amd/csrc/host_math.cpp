@@ -391,7 +391,142 @@ void invert_dense(std::vector<double> & Mx, int n)
    for (int i=0; i<n; i++) for (int j=0; j<n; j++) Mx[(size_t) i*n+j] = aug[(size_t) i*2*n+n+j];
 }
 
+// Generators of the semiseparable inverse of the band matrix A (symmetric positive definite, half-bandwidth D >= 2):
+// the part of column j of A^-1 at or above the diagonal solves the homogeneous recurrence of A's rows 0..j-1, whose
+// solutions (started at the top boundary) form a D-dimensional space.  With L [m][D] a basis of it (L[0..D-1] = I, the
+// rest by the recurrence) Ainv[i][j] = sum_k L[i][k] Ainv[k][j] for i <= j.  The basis is then orthonormalised
+// (L = Q R: U = Q, V = Ainv[:, 0..D-1] R^T) so that no term of the sum is much larger than the sum: the solutions are
+// discrete polynomials of degree < 2D, and the unit basis at rows 0..D-1 has them cancel by a factor ~m.
+// Everything in quad precision from the band (LDL^T for the first D columns of the inverse); the result is checked against
+// every entry of the inverse (its columns by the same LDL^T) before it is used.
+bool build_semisep(Metric & out)
+{
+   typedef __float128 ld;      // (quad precision by the compiler's soft-float routines: the recurrence below loses ~m^(2D-1) to growth)
+   auto fabsl = [](ld v) -> ld { return v < 0 ? -v : v; };
+   auto sqrtl = [](ld v) -> ld { ld y = (ld) std::sqrt((double) v); for (int it=0; it<4; it++) y = (y + v/y) / 2; return y; };
+   const int m = out.m, D = out.D;
+   out.ss_rank = 0; out.ssU.clear(); out.ssV.clear();
+   if (D < 2 || D > ORC_SS_MAX_RANK || m < 2*D + 2) return false;
+   auto A = [&](int i, int j) -> ld { const int k = j - i; return (k < -D || k > D) ? (ld)0 : (ld) out.Aband[(size_t)(k+D)*m + i]; };
+   // band LDL^T: Lb[i][q] = L[i][i-q] for q = 1..D
+   std::vector<ld> Lb((size_t) m*(D+1), 0), d(m, 0);
+   for (int i=0; i<m; i++)
+   {
+      for (int j=std::max(0, i-D); j<i; j++)
+      {
+         ld s = A(i, j);
+         for (int k=std::max(0, i-D); k<j; k++) if (j-k <= D) s -= Lb[(size_t) i*(D+1) + (i-k)] * d[k] * Lb[(size_t) j*(D+1) + (j-k)];
+         Lb[(size_t) i*(D+1) + (i-j)] = s / d[j];
+      }
+      ld s = A(i, i);
+      for (int k=std::max(0, i-D); k<i; k++) s -= Lb[(size_t) i*(D+1) + (i-k)] * Lb[(size_t) i*(D+1) + (i-k)] * d[k];
+      if (!(s > 0)) return false;
+      d[i] = s;
+   }
+   auto solve = [&](std::vector<ld> & x)      // in place: x <- A^-1 x
+   {
+      for (int i=0; i<m; i++) for (int k=std::max(0, i-D); k<i; k++) x[i] -= Lb[(size_t) i*(D+1) + (i-k)] * x[k];
+      for (int i=0; i<m; i++) x[i] /= d[i];
+      for (int i=m-1; i>=0; i--) for (int k=i+1; k<=std::min(m-1, i+D); k++) x[i] -= Lb[(size_t) k*(D+1) + (k-i)] * x[k];
+   };
+   // first D columns of the inverse
+   std::vector<ld> V0((size_t) m*D);
+   for (int k=0; k<D; k++)
+   {
+      std::vector<ld> x(m, 0); x[k] = 1; solve(x);
+      for (int j=0; j<m; j++) V0[(size_t) j*D + k] = x[j];
+   }
+   // the solutions of the rows' recurrence that start at the top boundary
+   std::vector<ld> L((size_t) m*D, 0);
+   for (int k=0; k<D; k++) L[(size_t) k*D + k] = 1;
+   for (int r=0; r+D<m; r++)
+   {
+      const ld lead = A(r, r+D);
+      if (lead == 0) return false;
+      for (int k=0; k<D; k++)
+      {
+         ld s = 0;
+         for (int q=-D; q<D; q++) if (r+q >= 0) s += A(r, r+q) * L[(size_t)(r+q)*D + k];
+         L[(size_t)(r+D)*D + k] = -s / lead;
+      }
+   }
+   // L = Q R (modified Gram-Schmidt), U = Q, V = V0 R^T
+   std::vector<ld> Q(L), R((size_t) D*D, 0);
+   for (int k=0; k<D; k++)
+   {
+      for (int p=0; p<k; p++)
+      {
+         ld dot = 0;
+         for (int i=0; i<m; i++) dot += Q[(size_t) i*D + p] * Q[(size_t) i*D + k];
+         R[(size_t) p*D + k] = dot;
+         for (int i=0; i<m; i++) Q[(size_t) i*D + k] -= dot * Q[(size_t) i*D + p];
+      }
+      ld nn = 0;
+      for (int i=0; i<m; i++) nn += Q[(size_t) i*D + k] * Q[(size_t) i*D + k];
+      nn = sqrtl(nn);
+      if (!(nn > 0)) return false;
+      R[(size_t) k*D + k] = nn;
+      for (int i=0; i<m; i++) Q[(size_t) i*D + k] /= nn;
+   }
+   out.ssU.assign((size_t) D*m, 0.0); out.ssV.assign((size_t) D*m, 0.0);
+   for (int k=0; k<D; k++)
+      for (int j=0; j<m; j++)
+      {
+         ld v = 0;
+         for (int p=k; p<D; p++) v += V0[(size_t) j*D + p] * R[(size_t) k*D + p];
+         out.ssU[(size_t) k*m + j] = (double) Q[(size_t) j*D + k];
+         out.ssV[(size_t) k*m + j] = (double) v;
+      }
+   // the check: every entry of the inverse, from the generators as the device holds them (doubles), against the columns of
+   // the inverse by the LDL^T above.  The bar is what a solve in double precision can promise for this matrix at all --
+   // a small fraction of cond_1(A) eps (the dense inverse of the reference, dgetrf + dgetri, src/libcd/chomp.c:393-403, is no
+   // closer to the exact one) -- and never looser than 1e-6; a metric that misses it keeps the dense inverse.
+   ld worst = 0, scale = 0, norm_inv = 0, norm_a = 0;
+   for (int j=0; j<m; j++)
+   {
+      std::vector<ld> x(m, 0); x[j] = 1; solve(x);
+      ld col = 0, cola = 0;
+      for (int i=0; i<m; i++)
+      {
+         const int lo = std::min(i, j), hi = std::max(i, j);
+         ld s = 0;
+         for (int k=0; k<D; k++) s += (ld) out.ssU[(size_t) k*m + lo] * (ld) out.ssV[(size_t) k*m + hi];
+         worst = std::max(worst, fabsl(s - x[i])); scale = std::max(scale, fabsl(x[i]));
+         col += fabsl(x[i]); cola += fabsl(A(i, j));
+      }
+      norm_inv = std::max(norm_inv, col); norm_a = std::max(norm_a, cola);
+   }
+   const ld bar = std::min((ld) 1e-6, std::max((ld) 1e-12, (ld) 0.05 * norm_a * norm_inv * (ld) 2.220446049250313e-16));
+   if (!(worst <= bar * scale)) { out.ssU.clear(); out.ssV.clear(); return false; }
+   out.ss_rank = D;
+   return true;
+}
+
 } // namespace
+
+// x_i = sum_k U[k][i] S_k(i) + V[k][i] P_k(i),  S_k(i) = sum_{j >= i} V[k][j] g_j,  P_k(i) = sum_{j < i} U[k][j] g_j
+void semisep_apply(const Metric & M, const double * rhs, int n, double * out)
+{
+   const int m = M.m, D = M.ss_rank;
+   std::vector<double> S((size_t) D*(m+1));
+   for (int c=0; c<n; c++)
+   {
+      for (int k=0; k<D; k++)
+      {
+         double s = 0.0;
+         S[(size_t) k*(m+1) + m] = 0.0;
+         for (int j=m-1; j>=0; j--) { s += M.ssV[(size_t) k*m + j] * rhs[(size_t) j*n + c]; S[(size_t) k*(m+1) + j] = s; }
+      }
+      std::vector<double> P(D, 0.0);
+      for (int i=0; i<m; i++)
+      {
+         double x = 0.0;
+         for (int k=0; k<D; k++) x += M.ssU[(size_t) k*m + i] * S[(size_t) k*(m+1) + i] + M.ssV[(size_t) k*m + i] * P[k];
+         out[(size_t) i*n + c] = x;
+         for (int k=0; k<D; k++) P[k] += M.ssU[(size_t) k*m + i] * rhs[(size_t) i*n + c];
+      }
+   }
+}
 
 void build_metric(int m, int D, double dt, Metric & out, bool free_start)
 {
@@ -462,6 +597,7 @@ void build_metric(int m, int D, double dt, Metric & out, bool free_start)
       if (i+k >= 0 && i+k < m) out.Aband[(size_t)(k+D)*m + i] = A[(size_t) i*m + i+k];
 
    out.pcr.clear(); out.Ainv.clear(); out.pcr_levels = 0; out.pcr_sym = 0;
+   out.ss_rank = 0; out.ssU.clear(); out.ssV.clear();
    if (D == 1)
    {
       // parallel cyclic reduction, coefficient part: the multipliers only depend on A
@@ -506,8 +642,12 @@ void build_metric(int m, int D, double dt, Metric & out, bool free_start)
    }
    else
    {
-      out.Ainv = A;
-      invert_dense(out.Ainv, m);
+      // (the dense inverse only where the generators are not used: batch.cpp builds it on demand for the constraint step)
+      if (!build_semisep(out))
+      {
+         out.Ainv = A;
+         invert_dense(out.Ainv, m);
+      }
    }
 }
 

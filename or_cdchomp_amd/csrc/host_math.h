@@ -92,7 +92,18 @@ struct Metric
    std::vector<double> pcr;     // [levels][2][m] + [m]
    std::vector<double> Ainv;    // dense [m][m], only when D >= 2
    std::vector<double> Adense;  // dense A (kept for tests / dense fallback)
+   // D >= 2: the inverse of the band matrix A (half-bandwidth D) is semiseparable of rank D,
+   //    Ainv[i][j] = sum_k ssU[k][i] ssV[k][j]  for i <= j   (and its mirror image below the diagonal),
+   // which is what the device applies by D prefix and D suffix wave scans per column (build_semisep);
+   // ss_rank == 0: no generators (D == 1 has its closed form; a metric the check below rejects keeps the dense inverse)
+   int ss_rank;
+   std::vector<double> ssU, ssV; // [D][m] each
 };
+#ifndef ORC_SS_MAX_RANK
+#define ORC_SS_MAX_RANK 4
+#endif
+// x = A^-1 rhs ([m][n], row-major) through the generators, in the device's order of operations (serially)
+void semisep_apply(const Metric & M, const double * rhs, int n, double * out);
 void build_metric(int m, int D, double dt, Metric & out, bool free_start = false);   // free_start: no start boundary (`start_tsr`)
 
 // ------------------------------------------------------------------ rng ---

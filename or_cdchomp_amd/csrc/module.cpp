@@ -82,7 +82,8 @@ std::vector<unsigned char> Robot::self_pairs_excluded() const
 // links it was NOT touching when it was grabbed (the grabbing link is always left out).  For the sphere model: a pair of the
 // robot's own spheres follows the link rule; two spheres of one held body are one rigid body; a held body's sphere against
 // anything else is left out when both ride on the same link, or when the body overlapped that link's own spheres (or that other
-// body) in the configuration the run was created in -- the stand-in for "at the moment of the grab".
+// body) at the moment of the grab (Grab::touch_link / touch_body, recorded by Module::grab -- not in the configuration the run
+// is created in: a body that has come to touch a link since the grab is reported against it).
 std::vector<unsigned char> Robot::run_self_pairs_excluded(int n_own) const
 {
    const int ns = (int) spheres.size();
@@ -90,38 +91,26 @@ std::vector<unsigned char> Robot::run_self_pairs_excluded(int n_own) const
    Robot own = *this;
    own.spheres.resize(n_own);
    const std::vector<unsigned char> link_excl = own.self_pairs_excluded();
-   std::vector<Xform> frames;
-   fk(transform, dof_values, frames);
-   std::vector<double> pw((size_t) ns * 3);
-   for (int a=0; a<ns; a++)
-   {
-      double r[3];
-      mat3_vec(frames[spheres[a].link].R, spheres[a].pos, r);
-      for (int k=0; k<3; k++) pw[(size_t) a*3+k] = r[k] + frames[spheres[a].link].t[k];
-   }
-   auto overlap = [&](int a, int b) {
-      double d2 = 0.0;
-      for (int k=0; k<3; k++) { const double d = pw[(size_t) a*3+k] - pw[(size_t) b*3+k]; d2 += d*d; }
-      return std::sqrt(d2) - (spheres[a].radius + spheres[b].radius) < 0.0;
+   auto body_touches_link = [&](int body, int link) {
+      const Grab & g = grabbed[body - 1];
+      return link == g.link || (link < (int) g.touch_link.size() && g.touch_link[link] != 0);
    };
-   // a held body's sphere and another sphere belong to the groups (body, any link) and (0, link) / (other body, any link)
-   auto same_group = [&](int a, int b) { return spheres[a].body == spheres[b].body && (spheres[a].body != 0 || spheres[a].link == spheres[b].link); };
+   auto bodies_touch = [&](int ba, int bb) {
+      const Grab & ga = grabbed[ba - 1], & gb = grabbed[bb - 1];
+      for (const std::string & nm : ga.touch_body) if (nm == gb.body) return true;
+      for (const std::string & nm : gb.touch_body) if (nm == ga.body) return true;
+      return false;
+   };
    for (int a=0; a<ns; a++)
       for (int b=a+1; b<ns; b++)
       {
+         const int ba = spheres[a].body, bb = spheres[b].body;
          bool ex;
-         if (spheres[a].body == 0 && spheres[b].body == 0) ex = link_excl[(size_t) spheres[a].link * n_links + spheres[b].link] != 0;
-         else if (spheres[a].body == spheres[b].body) ex = true;
-         else if (spheres[a].link == spheres[b].link) ex = true;
-         else
-         {
-            ex = false;
-            for (int c=0; c<ns && !ex; c++)
-            {
-               if (!same_group(c, a)) continue;
-               for (int d=0; d<ns && !ex; d++) if (same_group(d, b) && overlap(c, d)) ex = true;
-            }
-         }
+         if (ba == 0 && bb == 0) ex = link_excl[(size_t) spheres[a].link * n_links + spheres[b].link] != 0;
+         else if (ba == bb) ex = true;
+         else if (ba == 0) ex = body_touches_link(bb, spheres[a].link);
+         else if (bb == 0) ex = body_touches_link(ba, spheres[b].link);
+         else ex = bodies_touch(ba, bb);
          excl[(size_t) a*ns + b] = excl[(size_t) b*ns + a] = ex ? 1 : 0;
       }
    for (int a=0; a<ns; a++) excl[(size_t) a*ns + a] = 1;
@@ -381,7 +370,54 @@ void Module::grab(const std::string & rname, const std::string & body, int link)
    Robot::Grab g;
    g.body = body; g.link = link;
    g.rel = xform_mul(xform_inverse(frames[link]), xform_from_pose(k.transform));
+   note_grab_contacts(r, g);
    r.grabbed.push_back(g);
+}
+
+// What a body overlaps at the moment it is grabbed (or re-anchored): the robot's links, by the robot's own <orcdchomp> spheres
+// against the body's, and the bodies the robot holds already.  RobotBase::Grab records the links in collision with the body and
+// CheckSelfCollision ignores them afterwards (third party; src/orcdchomp_mod.cpp:2998-2999 calls it).
+void Module::note_grab_contacts(Robot & r, Robot::Grab & g)
+{
+   g.touch_link.assign(r.n_links, 0);
+   g.touch_body.clear();
+   const KinBody & k = kinbody(g.body);
+   std::vector<Xform> frames;
+   r.fk(r.transform, r.dof_values, frames);
+   auto world = [&](const Xform & x, const double pos[3], double out[3]) {
+      mat3_vec(x.R, pos, out);
+      for (int q=0; q<3; q++) out[q] += x.t[q];
+   };
+   const Xform xb = xform_mul(frames[g.link], g.rel);
+   std::vector<double> pb(k.spheres.size() * 3);
+   for (size_t a=0; a<k.spheres.size(); a++) world(xb, k.spheres[a].pos, &pb[a*3]);
+   auto overlap = [](const double * p, double rp, const double * q, double rq) {
+      double d2 = 0.0;
+      for (int c=0; c<3; c++) { const double d = p[c] - q[c]; d2 += d*d; }
+      return std::sqrt(d2) - (rp + rq) < 0.0;
+   };
+   for (const Robot::Sphere & sp : r.spheres)
+   {
+      double pw[3];
+      world(frames[sp.link], sp.pos, pw);
+      for (size_t a=0; a<k.spheres.size(); a++)
+         if (overlap(pw, sp.radius, &pb[a*3], k.spheres[a].radius)) { g.touch_link[sp.link] = 1; break; }
+   }
+   for (const Robot::Grab & other : r.grabbed)
+   {
+      if (other.body == g.body) continue;
+      const KinBody & ko = kinbody(other.body);
+      const Xform xo = xform_mul(frames[other.link], other.rel);
+      bool hit = false;
+      for (size_t a=0; a<ko.spheres.size() && !hit; a++)
+      {
+         double po[3];
+         world(xo, ko.spheres[a].pos, po);
+         for (size_t c=0; c<k.spheres.size() && !hit; c++)
+            if (overlap(po, ko.spheres[a].radius, &pb[c*3], k.spheres[c].radius)) hit = true;
+      }
+      if (hit) g.touch_body.push_back(other.body);
+   }
 }
 
 // SetTransform of a kinbody.  A body the robot holds is moved where the caller says and rides with its link from THERE
@@ -398,7 +434,15 @@ void Module::set_kinbody_transform(const std::string & body, const Pose & pose)
             std::vector<Xform> frames;
             kv.second.fk(kv.second.transform, kv.second.dof_values, frames);
             g.rel = xform_mul(xform_inverse(frames[g.link]), xform_from_pose(pose));
+            note_grab_contacts(kv.second, g);      // (a new anchoring is a new grab: what it touches is taken from here)
          }
+}
+
+void Module::refresh_grab_contacts(const std::string & body)
+{
+   for (auto & kv : robots_)
+      for (Robot::Grab & g : kv.second.grabbed)
+         if (g.body == body) note_grab_contacts(kv.second, g);
 }
 
 void Module::release(const std::string & rname, const std::string & body)

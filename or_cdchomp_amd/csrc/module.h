@@ -42,7 +42,10 @@ struct Robot                      // what the path reads from an OpenRAVE::Robot
    bool self_check = true;                     // the sphere-pair stand-in for CheckSelfCollision in gettraj's re-check (orc_robot_set_self_check)
    // kinbodies the robot holds, in the order they were grabbed (RobotBase::Grab / GetGrabbed, src/orcdchomp_mod.cpp:2168-2171):
    // the body is rigid with `link` from the moment of the grab, `rel` = T_w_link^-1 o T_w_body at that moment
-   struct Grab { std::string body; int link; Xform rel; };
+   // touch_link / touch_body: what the body's spheres overlapped AT THE MOMENT OF THE GRAB (Module::grab; taken anew when
+   // set_kinbody_transform re-anchors it): links of the robot, by its own spheres, and bodies the robot held already.
+   // OpenRAVE's CheckSelfCollision leaves a grabbed body out against exactly those (and against the grabbing link).
+   struct Grab { std::string body; int link; Xform rel; std::vector<unsigned char> touch_link; std::vector<std::string> touch_body; };
    std::vector<Grab> grabbed;
    // state
    Pose transform;
@@ -148,6 +151,7 @@ public:
    void sync_begin(double * costs_out, int * status_out, int * iters_out);   // enqueue the copies
    void sync_end();                                                          // wait for them
    void gettraj(double * out);
+   void get_plan(double out[8]) const;      // kernel variant bits, threads per workgroup, LDS bytes, tile, solve mode, workgroups per CU, tiles, lanes per waypoint
    void get_state(const std::string & which, double * out);
    void get_trace(double * out);
    void set_noise(const double * noise, int n_blocks);
@@ -210,6 +214,7 @@ private:
    int block_ = 256;                  // threads per workgroup of the iterate kernel (256 or 192)
    int pcr_in_lds_ = 0;
    int tree_ = 0;
+   bool pairs_latency_shape_ = false;      // the pair-list family's 512-thread kernels exist for this robot and precision (fp64 chains)
    int pair_entries_ = 0;             // entries of the staged self-collision pair list (rounds x 32; 0: the kernel family does not use one)
    int pcr_rows_ = 0, pcr_sym_ = 0, solve_mode_ = 0, ag_in_lds_ = 1, g_in_lds_ = 1, t_in_lds_ = 1, lds_flags_ = 0, GS_ = 0;
    size_t lds_bytes_ = 0;
@@ -237,6 +242,7 @@ public:
    void iterate_async(int n_iter, int iter_begin = 0, bool final_eval = true, bool carry = false);
    void sync(double * costs_out, int * status_out, int * iters_out = nullptr);
    void gettraj(double * out);
+   void get_plan(double out[8]);            // the plan of the first shard (all shards of a batch plan alike)
    void get_state(const std::string & which, double * out);
    void get_trace(double * out);
    void set_noise(const double * noise, int n_blocks);
@@ -286,6 +292,8 @@ public:
    // RobotBase::Grab(body, link) / Release(body) / ReleaseAllGrabbed()
    void grab(const std::string & robot, const std::string & body, int link);
    void release(const std::string & robot, const std::string & body);
+   void note_grab_contacts(Robot & r, Robot::Grab & g);      // fills touch_link / touch_body from the robot's state now
+   void refresh_grab_contacts(const std::string & body);     // ... again, for a body that is held (its spheres were redefined)
    void set_kinbody_transform(const std::string & body, const Pose & pose);      // (a held body is re-anchored to its link)
    void release_all(const std::string & robot);
    // the robot as create collects its spheres (src/orcdchomp_mod.cpp:2148-2300): its own in XML order, then those of

@@ -506,15 +506,19 @@ __device__ void tsr_block_thomas(const BT & b, const Env<real> & E, const real *
    }
 }
 
-// The same elimination with the augmented block [S | F | r] of a point held in REGISTERS, from BOTH ENDS of the
-// trajectory at once (round 3).  In LDS every pivot step was a chain of round trips (pivot, scaled row, the rank-one
-// update, two wave barriers) by one wavefront that issues an instruction every ~9 cycles when it is alone on its
-// SIMD: ~15 k cycles per point, 1.5 M of the 1.6 M cycles of a constrained WAM iteration.
-// * Registers: a block's rows are padded to WP = 16, 32 or 64 columns; lane = (row % (64 / WP), column), register t
-//   of a lane = row t (64 / WP) + row % (64 / WP): a pivot step reads the pivot through v_readlane, the pivot row and
-//   the lane's own multiplier through one ds_bpermute each (no memory behind them) and updates its registers.  The
-//   previous point's [C' | r'] passes from its registers to the next block's the same way; only the rows of C' the
-//   back pass needs go to memory.
+// The same elimination with the block of a point held in REGISTERS, from BOTH ENDS of the trajectory at once (round 3).
+// In LDS every pivot step was a chain of round trips (pivot, scaled row, the rank-one update, two wave barriers) by one
+// wavefront that issues an instruction every ~9 cycles when it is alone on its SIMD: ~15 k cycles per point, 1.5 M of the
+// 1.6 M cycles of a constrained WAM iteration.
+// * Registers: a block's rows are padded to WP = 16 or 32 columns; lane = (row % (64 / WP), column), register t of a lane =
+//   row t (64 / WP) + row % (64 / WP).  Round 6: the block is [S | r] -- S in columns 0 .. N-1, the right-hand side in the
+//   LAST column WP-1 -- and Gauss-Jordan replaces S by its inverse in place (gauss_jordan_regs<.., INPLACE>): C'_i = S_i^-1 F_i
+//   with F_i = f_i [I; 0] is f_i times the delta-delta corner of the inverse, so the columns of F need not ride along (until
+//   round 5 the block was [S | F | r]: 18 columns for a WAM point with three constrained rows, rows of 32 lanes, five registers
+//   and two ds_bpermute per register and step; now 11 columns, rows of 16 lanes, three registers, DPP and v_permlane only).
+//   What the next point takes of this one -- the corner of the inverse and r' -- sits in the SAME lanes and registers of the
+//   next block: nothing moves between lanes when a block is put together.  Only the rows of C' and r' the back pass needs go
+//   to memory.
 // * Both ends (the twisted factorization of a block tridiagonal system): wavefront 0 eliminates the points
 //   0 .. mid-1 upwards (z_i = r'_i - C'_i z_{i+1}), wavefront 1 the points m-1 .. mid downwards
 //   (z_i = r"_i - C"_i z_{i-1}); the two meet in (I - C'_{mid-1} C"_mid) delta_{mid-1} = r'_{mid-1} - C'_{mid-1} r"_mid,
@@ -528,10 +532,6 @@ __device__ __forceinline__ double lane_fetch(double v, int addr4)
 }
 __device__ __forceinline__ float lane_fetch(float v, int addr4) { return __int_as_float(__builtin_amdgcn_ds_bpermute(addr4, __float_as_int(v))); }
 
-// Gauss-Jordan without pivoting on a block held in registers (lane = (row % (64 / WP), column c), register t = row
-// t (64 / WP) + rsub), pivots 0 .. N-1.  All lane fetches of a step (the pivot row at this lane's column, the lane's
-// multipliers of every register) are issued before any is used: one round trip of the cross-lane unit per step, the
-// reciprocal of the pivot is formed meanwhile.  Returns false at a zero or non-finite pivot.
 // A function that is called (not inlined) receives its arguments in vector registers: loop bounds, base addresses and the
 // kernarg block then count as "divergent", loops over them are run by lane masks and their address arithmetic by the vector
 // pipe.  These put a wave-uniform value back into scalar registers.
@@ -543,76 +543,124 @@ __device__ __forceinline__ T * uniform_ptr(T * p)
    return (T *)(((unsigned long long) hi << 32) | lo);
 }
 
+#ifndef ORC_TSR_PRAW
+#define ORC_TSR_PRAW 1      // the pivot row to every row-slot: 0 v_permlane16/32_swap, 1 ds_bpermute (kept: the step is bound by vector issue, profiles/r06_ab_experiments.txt)
+#endif
+#ifndef ORC_TSR_UNIT
+#define ORC_TSR_UNIT 1      // the unit column of the in-place inverse: 0 selects, 1 a multiply by 0 / 1 (kept)
+#endif
 template <int K> struct PivotIndex { static constexpr int value = K; };
 template <int... Ks, typename F>
 __device__ __forceinline__ void for_each_pivot(std::integer_sequence<int, Ks...>, F && f) { (f(PivotIndex<Ks>{}), ...); }
 
-template <typename real, int WP, int NREG>
+// Row-slot J of the wavefront (one of its four 16-lane rows when WP == 16, one of its two 32-lane halves when WP == 32) to every
+// row-slot, lane by lane: v_permlane16_swap / v_permlane32_swap on (x, x) -- the swap of the odd rows of one operand with the even
+// rows of the other leaves (x0 x0 x2 x2) and (x1 x1 x3 x3), the swap of the halves (lo lo) and (hi hi); J is a compile-time constant,
+// so the choice between the two results costs nothing.  No LDS crossbar behind it (ds_bpermute: ~100 cycles in a dependent chain);
+// scripts/ubench/permlane_bcast.hip checks the lane pictures on the card.
+template <int WP, int J>
+__device__ __forceinline__ unsigned slot_bcast_u32(unsigned x)
+{
+   if constexpr (WP == 16)
+   {
+      const auto a = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+      const unsigned y = (J & 1) ? a[1] : a[0];
+      const auto h = __builtin_amdgcn_permlane32_swap(y, y, false, false);
+      return (J & 2) ? h[1] : h[0];
+   }
+   else
+   {
+      const auto h = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+      return J ? h[1] : h[0];
+   }
+}
+template <int WP, int J>
+__device__ __forceinline__ double slot_bcast(double v)
+{
+   const unsigned lo = slot_bcast_u32<WP, J>((unsigned) __double2loint(v)), hi = slot_bcast_u32<WP, J>((unsigned) __double2hiint(v));
+   return __hiloint2double((int) hi, (int) lo);
+}
+template <int WP, int J>
+__device__ __forceinline__ float slot_bcast(float v) { return __uint_as_float(slot_bcast_u32<WP, J>(__float_as_uint(v))); }
+// lane K of every row-slot to the whole slot: DPP row_newbcast inside the 16-lane rows; a 32-lane half takes the row that holds
+// lane K through one v_permlane16_swap
+template <int WP, int K>
+__device__ __forceinline__ unsigned lane_bcast_u32(unsigned x)
+{
+   const unsigned d = (unsigned) __builtin_amdgcn_update_dpp(0, (int) x, 0x150 + (K & 15), 0xF, 0xF, true);
+   if constexpr (WP == 16) return d;
+   else
+   {
+      const auto a = __builtin_amdgcn_permlane16_swap(d, d, false, false);
+      return (K & 16) ? a[1] : a[0];
+   }
+}
+template <int WP, int K>
+__device__ __forceinline__ double lane_bcast(double v)
+{
+   const unsigned lo = lane_bcast_u32<WP, K>((unsigned) __double2loint(v)), hi = lane_bcast_u32<WP, K>((unsigned) __double2hiint(v));
+   return __hiloint2double((int) hi, (int) lo);
+}
+template <int WP, int K>
+__device__ __forceinline__ float lane_bcast(float v) { return __uint_as_float(lane_bcast_u32<WP, K>(__float_as_uint(v))); }
+
+// Gauss-Jordan without pivoting on a block held in registers (lane = (row-slot rsub = row % (64 / WP), column c), register t = row
+// t (64 / WP) + rsub), pivots 0 .. N-1, WP = 16 or 32.  Every step is written out: the pivot's register and the row-slot that holds it
+// are known at compile time, so a step selects nothing, and everything a step takes from other lanes comes without the LDS crossbar
+// (round 6; ds_bpermute until then): the pivot by v_readlane, the pivot row at this lane's column by slot_bcast, the lane's
+// multipliers W[r][k] by lane_bcast.  Steps k >= N are skipped (wave-uniform).
+// INPLACE: the block is S (N x N) with right-hand sides in further columns, and S is replaced by its INVERSE -- column k plays the
+// unit column e_k of the augmented form [S | I] in step k, the step it would become one in; a block then needs N + 1 columns
+// where [S | F | r] with F = f I needed 2 N' + 1 (the WAM's three constrained rows per point: 11 columns instead of 18, rows of 16
+// lanes instead of 32).  Returns false at a zero or non-finite pivot: its reciprocal's Newton step is 0 x inf, the NaN is in every
+// entry one step later, and nothing reads it -- the caller takes the dense path.
+template <typename real, int WP, int NREG, bool INPLACE = false>
 __device__ __forceinline__ bool gauss_jordan_regs(real (& w)[NREG], int N, int c, int rsub)
 {
+   static_assert(WP == 16 || WP == 32, "rows of 16 or 32 lanes");
    constexpr int RPR = 64 / WP;
-   const int kfetch4 = rsub * WP * 4;
-   // (a zero or non-finite pivot is looked for once per block, in its result: a test in every step sat in the steps' dependent
-   // chain; past such a pivot the block fills with NaN, which nothing reads -- the caller takes the dense path)
-   bool ok = true;
-   if constexpr (WP <= 32)
-   {
-      // Every step written out: the pivot's register and the rows that hold it are known at compile time, so no step selects its
-      // pivot row among the registers or compares row numbers, and with 16-lane rows the lane's multipliers W[r][k] are a DPP
-      // broadcast inside its row (row_newbcast: no trip through the cross-lane unit).  Steps k >= N are skipped (wave-uniform).
-      for_each_pivot(std::make_integer_sequence<int, NREG * RPR>{}, [&](auto kc) {
-         constexpr int k = decltype(kc)::value, tk = k / RPR, j = k % RPR;
-         if (k < N)
-         {
-            const real p = read_lane(w[tk], j * WP + k);
-            const real praw = lane_fetch(w[tk], (j * WP + c) * 4);      // the pivot row at this lane's column
-            real f[NREG];
-#pragma unroll
-            for (int t=0; t<NREG; t++)
-            {
-               if constexpr (WP == 16) f[t] = dpp_move<0x150 + (k & 15)>(w[t]);      // W[r][k]: lane k of the lane's own row
-               else f[t] = lane_fetch(w[t], kfetch4 + k * 4);
-            }
-            const real prow = praw * rcp_fast(p);
-#pragma unroll
-            for (int t=0; t<NREG; t++)
-            {
-               const real upd = w[t] - f[t] * prow;
-               w[t] = (t == tk) ? ((rsub == j) ? prow : upd) : upd;
-            }
-         }
-      });
-      // a zero or non-finite pivot: its reciprocal's Newton step is 0 x inf, and the NaN is in every entry one step later
-      bool finite = true;
-#pragma unroll
-      for (int t=0; t<NREG; t++) finite = finite && (M<real>::fabs_(w[t]) < M<real>::inf());
-      return __builtin_amdgcn_ballot_w64(!finite) == 0ull;
-   }
-   for (int k=0; k<N; k++)
-   {
-      const int tk = k / RPR, kbase = (k % RPR) * WP;           // (wavefront-uniform)
-      real wk = w[0];
-#pragma unroll
-      for (int t=1; t<NREG; t++) wk = (tk == t) ? w[t] : wk;
-      const real p = read_lane(wk, kbase + k);
-      const real ap = M<real>::fabs_(p);
-      ok = ok && (ap > (real)0 && ap < M<real>::inf());
-      const real praw = lane_fetch(wk, (kbase + c) * 4);         // the pivot row at this lane's column
-      real f[NREG];
-#pragma unroll
-      for (int t=0; t<NREG; t++) f[t] = lane_fetch(w[t], kfetch4 + k * 4);      // W[r][k]
-      const real prow = praw * rcp_fast(p);
-#pragma unroll
-      for (int t=0; t<NREG; t++)
+   for_each_pivot(std::make_integer_sequence<int, NREG * RPR>{}, [&](auto kc) {
+      constexpr int k = decltype(kc)::value, tk = k / RPR, j = k % RPR;
+      if (k < N)
       {
-         const int r = t*RPR + rsub;
-         w[t] = (r == k) ? prow : w[t] - f[t] * prow;
+         const real p = read_lane(w[tk], j * WP + k);
+#if ORC_TSR_PRAW == 1
+         real praw = lane_fetch(w[tk], (j * WP + c) * 4);       // the pivot row at this lane's column: ds_bpermute (A/B: profiles/r06_ab_experiments.txt)
+#else
+         real praw = slot_bcast<WP, j>(w[tk]);                 // the pivot row at this lane's column
+#endif
+         real f[NREG];
+#pragma unroll
+         for (int t=0; t<NREG; t++) f[t] = lane_bcast<WP, k>(w[t]);      // W[r][k] of the lane's own rows
+         const bool unit = INPLACE && (c == k);
+         if (INPLACE) praw = unit ? (real)1 : praw;
+         const real prow = praw * rcp_fast(p);
+#if ORC_TSR_UNIT == 1
+         const real keep = unit ? (real)0 : (real)1;           // (one multiply per register instead of two 32-bit selects)
+#endif
+#pragma unroll
+         for (int t=0; t<NREG; t++)
+         {
+#if ORC_TSR_UNIT == 1
+            const real from = INPLACE ? w[t] * keep : w[t];
+#else
+            const real from = (INPLACE && unit) ? (real)0 : w[t];
+#endif
+            const real upd = from - f[t] * prow;
+            w[t] = (t == tk) ? ((rsub == j) ? prow : upd) : upd;
+         }
       }
-   }
-   return ok;
+   });
+   bool finite = true;
+#pragma unroll
+   for (int t=0; t<NREG; t++) finite = finite && (M<real>::fabs_(w[t]) < M<real>::inf());
+   return __builtin_amdgcn_ballot_w64(!finite) == 0ull;
 }
 
-template <typename real, int WP, int NREG, int DIR, typename BT>
+// AUG: the every-point loop keeps the AUGMENTED block [S | F | r] of rounds 3-5 (F = f I on the delta rows in columns N .. N+n-1, r in
+// column N+n, plain Gauss-Jordan): for a block that fits rows of 16 lanes either way -- one constrained row on every point of a 7-dof
+// arm: 8 rows, 16 columns, two registers -- the in-place form saves nothing and pays for its unit column (tsr1 7.2 against 7.5 M it/s).
+template <typename real, int WP, int NREG, int DIR, bool AUG = false, typename BT = void>
 __device__ void tsr_eliminate_regs(const BT & b_, const Env<real> & E, const real * hws_, const real * Jws_, real * Cst_, int * flag_,
    int i_begin_, int i_end_, int * rows2_)
 {
@@ -622,6 +670,7 @@ __device__ void tsr_eliminate_regs(const BT & b_, const Env<real> & E, const rea
    int * flag = uniform_ptr(flag_), * rows2 = uniform_ptr(rows2_);
    const int i_begin = __builtin_amdgcn_readfirstlane(i_begin_), i_end = __builtin_amdgcn_readfirstlane(i_end_);
    constexpr int RPR = 64 / WP;               // rows per register slice
+   constexpr int CR = WP - 1;                 // the right-hand side's column
    const int lane = threadIdx.x & 63;
    const int c = lane & (WP - 1), rsub = lane / WP;
    const int n = b.n, m = b.m, n1 = n + 1;
@@ -643,8 +692,10 @@ __device__ void tsr_eliminate_regs(const BT & b_, const Env<real> & E, const rea
       __builtin_amdgcn_wave_barrier();
       return ki;
    };
+   // block [S | r] of a point with ki constrained rows, N = n + ki: rows 0..n-1 = (metric, -J^T | coupling to the point before),
+   // rows n..N-1 = (J, 0 | h); this lane's entries that come from memory
    auto fetch = [&](const int * rows, int ki) {
-      const int N = n + ki, Wd = N + n1;
+      const int N = n + ki;
 #pragma unroll
       for (int t=0; t<NREG; t++)
       {
@@ -655,7 +706,7 @@ __device__ void tsr_eliminate_regs(const BT & b_, const Env<real> & E, const rea
          {
             const int rr = rows[r - n];
             if (c < n) v = Jws[(size_t) rr * n + c];
-            else if (c == Wd - 1) v = hws[rr];
+            else if (c == CR) v = hws[rr];
          }
          jn[t] = v;
       }
@@ -668,13 +719,35 @@ __device__ void tsr_eliminate_regs(const BT & b_, const Env<real> & E, const rea
    int k_all = 0;
    for (int cn=0; cn<b.n_tsrs; cn++) { if (b.tsrs[cn].npts != m) every_point = false; k_all += b.tsrs[cn].k; }
    const bool toeplitz = (b.D == 1);
-   int jrow0[NREG], jstride[NREG], jcol[NREG];      // this lane's entry of register t: J[row][jcol] (jcol >= 0), h[row] (-1), none (-2)
-   real jsign[NREG];
+   // what a lane's entry of register t is, decided once: an entry of the delta-delta corner (metric diagonal, and the previous
+   // point's inverse in the same place), the right-hand side of a delta row (the previous point's r' in the same place), or
+   // neither; where its [C' | r'] entry goes for the back pass
+   bool is_corner[NREG], is_rhs[NREG], st_ok[NREG];
+   int st_off[NREG];
+   real c_diag[NREG];
 #pragma unroll
-   for (int t=0; t<NREG; t++) { jrow0[t] = 0; jstride[t] = 0; jcol[t] = -2; jsign[t] = 1; }
+   for (int t=0; t<NREG; t++)
+   {
+      const int r = t*RPR + rsub;
+      is_corner[t] = (r < n) && (c < n);
+      is_rhs[t] = (r < n) && (c == CR);
+      c_diag[t] = (is_corner[t] && r == c) ? (real)1 : (real)0;
+      st_ok[t] = is_corner[t] || is_rhs[t];
+      st_off[t] = st_ok[t] ? r*n1 + (is_rhs[t] ? n : c) : 0;
+   }
+   typedef const __attribute__((address_space(1))) real * GlobalIn;
+   typedef __attribute__((address_space(1))) real * GlobalOut;
+   if constexpr (AUG)
    if (every_point)
    {
-      const int N = n + k_all, Wd = N + n1;
+      const int N = __builtin_amdgcn_readfirstlane(n + k_all), Wd = N + n1;      // (uniform: the steps k >= N are skipped by scalar branches)
+      // entry = c_diag a_ii + c_fwd a_i,i+1 + c_prev (-a_i,i-1 x the previous point's entry) + c_j (J or h from memory), the
+      // coefficients 0, 1 or -1 and at most two terms not zero: exact, and three multiply-adds instead of a dozen selects
+      real a_cdiag[NREG], a_cfwd[NREG], a_cprev[NREG], a_cj[NREG];
+      bool a_stok[NREG];
+      int a_stoff[NREG];
+      GlobalIn jsrc[NREG]; int jstep[NREG];
+      real jraw[NREG];
 #pragma unroll
       for (int t=0; t<NREG; t++)
       {
@@ -682,59 +755,30 @@ __device__ void tsr_eliminate_regs(const BT & b_, const Env<real> & E, const rea
          int slot = -1, col = -2; real sg = 1;
          if (r < n) { if (c >= n && c < N) { slot = c - n; col = r; sg = -1; } }
          else if (r < N) { slot = r - n; col = (c < n) ? c : ((c == Wd - 1) ? -1 : -2); }
-         jrow0[t] = 0; jstride[t] = 0; jcol[t] = (slot >= 0) ? col : -2; jsign[t] = sg;
+         int jrow0 = 0, jstride = 0;
+         const int jcol = (slot >= 0) ? col : -2;
          int acc = 0;
          for (int cn=0; cn<b.n_tsrs; cn++)
          {
             const int kc = b.tsrs[cn].k;
-            if (slot >= acc && slot < acc + kc) { jrow0[t] = b.tsrs[cn].row_base + (slot - acc); jstride[t] = kc; }
+            if (slot >= acc && slot < acc + kc) { jrow0 = b.tsrs[cn].row_base + (slot - acc); jstride = kc; }
             acc += kc;
          }
-      }
-   }
-   // (the reads are unconditional -- a lane without an entry reads h[row_base] -- and nothing is computed from them here: the
-   // wait for them then sits where the next block is put together, a whole elimination later, instead of behind each load)
-   real jraw[NREG];
-   // (pointers into GLOBAL memory, said so: a read through a generic pointer is a FLAT instruction, which counts on the LDS
-   // counter as well -- the wait for a step's cross-lane fetches then also waited for the next point's J and h)
-   typedef const __attribute__((address_space(1))) real * GlobalIn;
-   typedef __attribute__((address_space(1))) real * GlobalOut;
-   GlobalIn jsrc[NREG]; int jstep[NREG];
-#pragma unroll
-   for (int t=0; t<NREG; t++)
-   {
-      jsrc[t] = (GlobalIn)((jcol[t] >= 0) ? Jws + (size_t) jrow0[t] * n + jcol[t] : hws + jrow0[t]);
-      jstep[t] = (jcol[t] >= 0) ? jstride[t] * n : jstride[t];
-      jraw[t] = 0;
-   }
-   auto fetch_direct = [&](int i) {
-#pragma unroll
-      for (int t=0; t<NREG; t++) jraw[t] = jsrc[t][(m - 1 - i) * jstep[t]];
-   };
-   if (every_point)
-   {
-      // The loop of the common case: every block has the same shape, so what a lane's entries ARE (metric diagonal, coupling
-      // to the next point, a row of C' or r' of the previous point, an entry of J or h) is decided once, and a block is
-      // put together by selects on lane masks -- written with the conditions inside the loop it was 440 of the 600
-      // instructions of a point, most of them branches around two or three instructions.
-      const int N = __builtin_amdgcn_readfirstlane(n + k_all), Wd = N + n1;      // (uniform: the steps k >= N are skipped by scalar branches)
-      // entry = c_diag a_ii + c_fwd a_i,i+1 + c_prev (-a_i,i-1 x the previous point's entry) + c_j (J or h from memory), the
-      // coefficients 0, 1 or -1 and at most two terms not zero: exact, and three multiply-adds instead of a dozen selects
-      real c_diag[NREG], c_fwd[NREG], c_prev[NREG], c_j[NREG];
-      bool st_ok[NREG];
-      int st_off[NREG];
-#pragma unroll
-      for (int t=0; t<NREG; t++)
-      {
-         const int r = t*RPR + rsub;
          const bool is_sd = (r < n) && (c < n);
-         c_diag[t] = (is_sd && r == c) ? (real)1 : (real)0;
-         c_fwd[t] = ((r < n) && (c >= N) && (c < N + n) && (c - N == r)) ? (real)1 : (real)0;
-         c_prev[t] = (is_sd || ((r < n) && (c == Wd - 1))) ? (real)1 : (real)0;
-         c_j[t] = (jcol[t] == -2) ? (real)0 : ((jcol[t] >= 0) ? jsign[t] : (real)1);
-         st_ok[t] = (r < n) && (c >= N) && (c <= N + n);
-         st_off[t] = st_ok[t] ? r*n1 + (c - N) : 0;
+         a_cdiag[t] = (is_sd && r == c) ? (real)1 : (real)0;
+         a_cfwd[t] = ((r < n) && (c >= N) && (c < N + n) && (c - N == r)) ? (real)1 : (real)0;
+         a_cprev[t] = (is_sd || ((r < n) && (c == Wd - 1))) ? (real)1 : (real)0;
+         a_cj[t] = (jcol == -2) ? (real)0 : ((jcol >= 0) ? sg : (real)1);
+         a_stok[t] = (r < n) && (c >= N) && (c <= N + n);
+         a_stoff[t] = a_stok[t] ? r*n1 + (c - N) : 0;
+         jsrc[t] = (GlobalIn)((jcol >= 0) ? Jws + (size_t) jrow0 * n + jcol : hws + jrow0);
+         jstep[t] = (jcol >= 0) ? jstride * n : jstride;
+         jraw[t] = 0;
       }
+      auto fetch_direct = [&](int i) {
+#pragma unroll
+         for (int t=0; t<NREG; t++) jraw[t] = jsrc[t][(m - 1 - i) * jstep[t]];
+      };
       const int psrc4 = (rsub * WP + ((c < n) ? N + c : N + n)) * 4;
       const real a_diag = b.a_diag, a_off = b.a_off;      // (read here: the stores of the loop could alias them)
       fetch_direct(i_begin);
@@ -748,46 +792,105 @@ __device__ void tsr_eliminate_regs(const BT & b_, const Env<real> & E, const rea
          for (int t=0; t<NREG; t++)
          {
             const real pv = lane_fetch(w[t], psrc4);          // C[r][c] (c < n) or r[r] of the previous point (zero in front of the first)
-            real v = c_j[t] * jraw[t];
-            v = fma(c_diag[t], di, v);
-            v = fma(c_fwd[t], fwd, v);
-            w[t] = fma(c_prev[t] * pv, -back, v);
+            real v = a_cj[t] * jraw[t];
+            v = fma(a_cdiag[t], di, v);
+            v = fma(a_cfwd[t], fwd, v);
+            w[t] = fma(a_cprev[t] * pv, -back, v);
          }
          if (i + DIR != i_end) fetch_direct(i + DIR);
-         if (!gauss_jordan_regs<real, WP, NREG>(w, N, c, rsub)) { if (lane == 0) flag[0] = 1; return; }
+         if (!gauss_jordan_regs<real, WP, NREG, false>(w, N, c, rsub)) { if (lane == 0) flag[0] = 1; return; }
          GlobalOut Ci = (GlobalOut)(Cst + (size_t) i*n*n1);
 #pragma unroll
-         for (int t=0; t<NREG; t++) if (st_ok[t]) Ci[st_off[t]] = w[t];
+         for (int t=0; t<NREG; t++) if (a_stok[t]) Ci[a_stoff[t]] = w[t];
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       return;
    }
-   int Nprev = n;
-   int ki = k_all;
-   ki = point_rows(i_begin, rows2); fetch(rows2, ki);
+   if (every_point)
+   {
+      // (pointers into GLOBAL memory, said so: a read through a generic pointer is a FLAT instruction, which counts on the LDS
+      // counter as well)
+      const int N = __builtin_amdgcn_readfirstlane(n + k_all);      // (uniform: the steps k >= N are skipped by scalar branches)
+      int jrow0[NREG], jstride[NREG], jcol[NREG];      // this lane's entry of register t: J[row][jcol] (jcol >= 0), h[row] (-1), none (-2)
+      real c_j[NREG];
+      GlobalIn jsrc[NREG]; int jstep[NREG];
+      real jraw[NREG];
+#pragma unroll
+      for (int t=0; t<NREG; t++)
+      {
+         const int r = t*RPR + rsub;
+         int slot = -1, col = -2; real sg = 1;
+         if (r < n) { if (c >= n && c < N) { slot = c - n; col = r; sg = -1; } }
+         else if (r < N) { slot = r - n; col = (c < n) ? c : ((c == CR) ? -1 : -2); }
+         jrow0[t] = 0; jstride[t] = 0; jcol[t] = (slot >= 0) ? col : -2;
+         int acc = 0;
+         for (int cn=0; cn<b.n_tsrs; cn++)
+         {
+            const int kc = b.tsrs[cn].k;
+            if (slot >= acc && slot < acc + kc) { jrow0[t] = b.tsrs[cn].row_base + (slot - acc); jstride[t] = kc; }
+            acc += kc;
+         }
+         c_j[t] = (jcol[t] == -2) ? (real)0 : ((jcol[t] >= 0) ? sg : (real)1);
+         // (the reads are unconditional -- a lane without an entry reads h[row_base] -- and nothing is computed from them where
+         // they are issued: the wait for them sits where the next block is put together, a whole elimination later)
+         jsrc[t] = (GlobalIn)((jcol[t] >= 0) ? Jws + (size_t) jrow0[t] * n + jcol[t] : hws + jrow0[t]);
+         jstep[t] = (jcol[t] >= 0) ? jstride[t] * n : jstride[t];
+         jraw[t] = 0;
+      }
+      auto fetch_direct = [&](int i) {
+#pragma unroll
+         for (int t=0; t<NREG; t++) jraw[t] = jsrc[t][(m - 1 - i) * jstep[t]];
+      };
+      const real a_diag = b.a_diag, a_off = b.a_off;      // (read here: the stores of the loop could alias them)
+      fetch_direct(i_begin);
+      real fwd_prev = 0;
+      for (int i=i_begin; i!=i_end; i+=DIR)
+      {
+         real lo, di, up;
+         if (toeplitz) { di = a_diag; lo = (i > 0) ? a_off : (real)0; up = (i < m-1) ? a_off : (real)0; }
+         else { lo = (i > 0) ? b.Aband[i] : (real)0; di = b.Aband[(size_t) m + i]; up = (i < m-1) ? b.Aband[(size_t) 2*m + i] : (real)0; }
+         const real back = (i == i_begin) ? (real)0 : ((DIR > 0) ? lo : up), fwd = (DIR > 0) ? up : lo;
+         // S = a_ii I - a_i,i-1 C'_{i-1} with C'_{i-1} = f_{i-1} x (the corner of the previous inverse), r = -a_i,i-1 r'_{i-1}:
+         // both from this lane's own register of the previous block
+         const real kc = back * fwd_prev;
+#pragma unroll
+         for (int t=0; t<NREG; t++)
+         {
+            const real pm = is_corner[t] ? kc : (is_rhs[t] ? back : (real)0);
+            real v = c_j[t] * jraw[t];
+            v = fma(c_diag[t], di, v);
+            w[t] = fma(-pm, w[t], v);
+         }
+         if (i + DIR != i_end) fetch_direct(i + DIR);
+         if (!gauss_jordan_regs<real, WP, NREG, true>(w, N, c, rsub)) { if (lane == 0) flag[0] = 1; return; }
+         GlobalOut Ci = (GlobalOut)(Cst + (size_t) i*n*n1);
+#pragma unroll
+         for (int t=0; t<NREG; t++) if (st_ok[t]) Ci[st_off[t]] = is_rhs[t] ? w[t] : fwd * w[t];
+         fwd_prev = fwd;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      return;
+   }
+   int ki = point_rows(i_begin, rows2);
+   fetch(rows2, ki);
    int par = 0;
+   real fwd_prev = 0;
    for (int i=i_begin; i!=i_end; i+=DIR)
    {
-      const int N = n + ki, Wd = N + n1;
+      const int N = n + ki;
       real lo, di, up;
       if (toeplitz) { di = b.a_diag; lo = (i > 0) ? b.a_off : (real)0; up = (i < m-1) ? b.a_off : (real)0; }
       else { lo = (i > 0) ? b.Aband[i] : (real)0; di = b.Aband[(size_t) m + i]; up = (i < m-1) ? b.Aband[(size_t) 2*m + i] : (real)0; }
       // the coupling to the point eliminated before this one, and to the one that follows
       const real back = (i == i_begin) ? (real)0 : ((DIR > 0) ? lo : up), fwd = (DIR > 0) ? up : lo;
-      // the block of this point; what it takes of the previous point's [C | r] comes out of that block's registers
-      const int psrc4 = (rsub * WP + ((c < n) ? Nprev + c : Nprev + n)) * 4;
+      const real kc = back * fwd_prev;
+      // the block of this point; what it takes of the previous point's inverse and r' is in the same registers
 #pragma unroll
       for (int t=0; t<NREG; t++)
       {
-         const int r = t*RPR + rsub;
-         const real pv = lane_fetch(w[t], psrc4);          // C[r][c] (c < n) or r[r] of the previous point: for the rows r < n
          real v = jn[t];
-         if (r < n)
-         {
-            if (c < n) v = ((r == c) ? di : (real)0) - back * pv;
-            else if (c >= N && c < N + n) v = (c - N == r) ? fwd : (real)0;
-            else if (c == Wd - 1) v = -back * pv;
-         }
+         if (is_corner[t]) v = c_diag[t] * di - kc * w[t];
+         else if (is_rhs[t]) v = -back * w[t];
          w[t] = v;
       }
       // the next point's rows, and its entries of J and h on their way while this block is eliminated
@@ -798,16 +901,13 @@ __device__ void tsr_eliminate_regs(const BT & b_, const Env<real> & E, const rea
          ki_next = point_rows(i + DIR, rows2 + 16 * par);
          fetch(rows2 + 16 * par, ki_next);
       }
-      // Gauss-Jordan in the order delta, x (quasi-definite: no pivoting)
-      if (!gauss_jordan_regs<real, WP, NREG>(w, N, c, rsub)) { if (lane == 0) flag[0] = 1; return; }
-      // the delta rows of [C | r] for the back pass
+      // Gauss-Jordan in the order delta, x (quasi-definite: no pivoting), the inverse in place
+      if (!gauss_jordan_regs<real, WP, NREG, true>(w, N, c, rsub)) { if (lane == 0) flag[0] = 1; return; }
+      // the delta rows of [C' | r'] for the back pass
 #pragma unroll
       for (int t=0; t<NREG; t++)
-      {
-         const int r = t*RPR + rsub;
-         if (r < n && c >= N && c <= N + n) Cst[(size_t) i*n*n1 + r*n1 + (c - N)] = w[t];
-      }
-      Nprev = N; ki = ki_next;
+         if (st_ok[t]) Cst[(size_t) i*n*n1 + st_off[t]] = is_rhs[t] ? w[t] : fwd * w[t];
+      fwd_prev = fwd; ki = ki_next;
    }
    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 }
@@ -1163,11 +1263,13 @@ __device__ __attribute__((noinline)) void phase_tsr(const void * kp)
       real * Cst = Mws + (size_t) K * K;        // [m][n][n+1]
       if (tid == 0) E.redi[0] = 0;
       __syncthreads();
-      const int Nm = b.tsr_nmax, Wm = Nm + n + 1, wave = tid >> 6;
+      const int Nm = b.tsr_nmax, wave = tid >> 6;
       int shape = 0;                             // the register form's padded width, 0: the LDS form (one wavefront)
 #ifndef ORC_TSR_LDS
-      if (BLOCK >= 128 && m >= 4 && n <= 62)
-         shape = (Wm <= 16 && Nm <= 8) ? 16 : ((Wm <= 32 && Nm <= 16) ? 32 : ((Wm <= 64 && Nm <= 20) ? 64 : 0));
+      // a block [S | r] of N = n + (constrained rows of the point) rows needs N + 1 columns: rows of 16 lanes up to N = 15
+      // (a 7-dof arm with up to eight constrained rows on a point), rows of 32 lanes up to N = 24
+      if (BLOCK >= 128 && m >= 4 && n <= 23)
+         shape = (Nm <= 15) ? 16 : ((Nm <= 24) ? 32 : 0);
       if (Nm - n > 16) shape = 0;      // (the row lists of a point hold 16 entries: more constrained rows on one point take the dense path)
 #endif
       if (!shape)
@@ -1186,19 +1288,23 @@ __device__ __attribute__((noinline)) void phase_tsr(const void * kp)
          real * meet = (real *)((int *) E.ax_s + 64);      // [2][n]: delta_{mid-1}, delta_mid
          if (wave == 0)
          {
-            if (shape == 16) tsr_eliminate_regs<real, 16, 2, +1>(b, E, hws, Jws, Cst, E.redi, 0, mid, rows);
-            else if (shape == 32 && Nm <= 10) tsr_eliminate_regs<real, 32, 5, +1>(b, E, hws, Jws, Cst, E.redi, 0, mid, rows);      // (two rows per register: a WAM point with up to three constrained rows)
-            else if (shape == 32 && Nm <= 12) tsr_eliminate_regs<real, 32, 6, +1>(b, E, hws, Jws, Cst, E.redi, 0, mid, rows);
-            else if (shape == 32) tsr_eliminate_regs<real, 32, 8, +1>(b, E, hws, Jws, Cst, E.redi, 0, mid, rows);
-            else tsr_eliminate_regs<real, 64, 20, +1>(b, E, hws, Jws, Cst, E.redi, 0, mid, rows);
+            if (shape == 16 && Nm <= 8 && Nm + n + 1 <= 16) tsr_eliminate_regs<real, 16, 2, +1, true>(b, E, hws, Jws, Cst, E.redi, 0, mid, rows);      // (the augmented block fits as well: see AUG)
+            else if (shape == 16 && Nm <= 8) tsr_eliminate_regs<real, 16, 2, +1>(b, E, hws, Jws, Cst, E.redi, 0, mid, rows);            // (four rows per register)
+            else if (shape == 16 && Nm <= 12) tsr_eliminate_regs<real, 16, 3, +1>(b, E, hws, Jws, Cst, E.redi, 0, mid, rows);     // (a WAM point with up to five constrained rows)
+            else if (shape == 16) tsr_eliminate_regs<real, 16, 4, +1>(b, E, hws, Jws, Cst, E.redi, 0, mid, rows);
+            else if (Nm <= 16) tsr_eliminate_regs<real, 32, 8, +1>(b, E, hws, Jws, Cst, E.redi, 0, mid, rows);                    // (two rows per register)
+            else if (Nm <= 20) tsr_eliminate_regs<real, 32, 10, +1>(b, E, hws, Jws, Cst, E.redi, 0, mid, rows);
+            else tsr_eliminate_regs<real, 32, 12, +1>(b, E, hws, Jws, Cst, E.redi, 0, mid, rows);
          }
          else if (wave == 1)
          {
-            if (shape == 16) tsr_eliminate_regs<real, 16, 2, -1>(b, E, hws, Jws, Cst, E.redi, m - 1, mid - 1, rows);
-            else if (shape == 32 && Nm <= 10) tsr_eliminate_regs<real, 32, 5, -1>(b, E, hws, Jws, Cst, E.redi, m - 1, mid - 1, rows);
-            else if (shape == 32 && Nm <= 12) tsr_eliminate_regs<real, 32, 6, -1>(b, E, hws, Jws, Cst, E.redi, m - 1, mid - 1, rows);
-            else if (shape == 32) tsr_eliminate_regs<real, 32, 8, -1>(b, E, hws, Jws, Cst, E.redi, m - 1, mid - 1, rows);
-            else tsr_eliminate_regs<real, 64, 20, -1>(b, E, hws, Jws, Cst, E.redi, m - 1, mid - 1, rows);
+            if (shape == 16 && Nm <= 8 && Nm + n + 1 <= 16) tsr_eliminate_regs<real, 16, 2, -1, true>(b, E, hws, Jws, Cst, E.redi, m - 1, mid - 1, rows);
+            else if (shape == 16 && Nm <= 8) tsr_eliminate_regs<real, 16, 2, -1>(b, E, hws, Jws, Cst, E.redi, m - 1, mid - 1, rows);
+            else if (shape == 16 && Nm <= 12) tsr_eliminate_regs<real, 16, 3, -1>(b, E, hws, Jws, Cst, E.redi, m - 1, mid - 1, rows);
+            else if (shape == 16) tsr_eliminate_regs<real, 16, 4, -1>(b, E, hws, Jws, Cst, E.redi, m - 1, mid - 1, rows);
+            else if (Nm <= 16) tsr_eliminate_regs<real, 32, 8, -1>(b, E, hws, Jws, Cst, E.redi, m - 1, mid - 1, rows);
+            else if (Nm <= 20) tsr_eliminate_regs<real, 32, 10, -1>(b, E, hws, Jws, Cst, E.redi, m - 1, mid - 1, rows);
+            else tsr_eliminate_regs<real, 32, 12, -1>(b, E, hws, Jws, Cst, E.redi, m - 1, mid - 1, rows);
          }
          __threadfence_block();
          __syncthreads();

@@ -286,6 +286,13 @@ class Module:
         self._check(self._lib.orc_batch_collision_verdict(self._h, bid, _ip(col), _dp(tim), _ip(sph), _ip(fld), _dp(dep)))
         return dict(collides=col, time=tim, sphere=sph, field=fld, depth=dep)
 
+    def batch_plan(self, bid):
+        """what the planner chose for this batch (orc_batch_get_state "plan")"""
+        out = np.zeros(8)
+        self._check(self._lib.orc_batch_get_state(self._h, bid, b"plan", _dp(out), out.size))
+        keys = ("variant", "threads", "lds_bytes", "tile_m", "solve_mode", "workgroups_per_cu", "tiles", "lanes_per_waypoint")
+        return {k: int(v) for k, v in zip(keys, out)}
+
     def batch_state(self, bid, which):
         n_runs, n_points, n = self.batch_dims(bid)
         out = np.zeros((n_runs, n_points - 2, n))

@@ -684,51 +684,61 @@ ora_run * ora_run_create(const ora_robot * rob, const double base_pose[7], const
       /* which pairs of them a self-collision check would look at: the stand-in for OpenRAVE's CheckSelfCollision with grabbed
        * bodies (third party; src/orcdchomp_mod.cpp:2998-2999 calls it).  The robot's own spheres follow the link rule
        * (self_pairs over the ROBOT's spheres: adjacent links, links that touch with all dofs at zero); two spheres of one held
-       * body are one rigid body; a held body's sphere against anything else is left out when both ride on the same link or when
-       * the body overlapped that link's own spheres (or that other body) in the configuration of create -- OpenRAVE records the
-       * links a body touches at the moment of the grab and ignores them. */
+       * body are one rigid body; a held body is never tested against the link that holds it, nor against the links (by their own
+       * spheres) and the other held bodies it overlapped AT THE MOMENT OF ITS GRAB -- OpenRAVE records what a body touches when
+       * it is grabbed and ignores exactly that; what it comes to touch later counts.  For two held bodies the moment is the later
+       * grab's (GetGrabbed() order is the order of the grabs). */
       {
          const int nl = rob->n_links;
          unsigned char * lex = (unsigned char *) malloc((size_t) nl * nl);
          double * R = (double *) malloc((size_t) nl * 9 * sizeof(double)), * t = (double *) malloc((size_t) nl * 3 * sizeof(double));
          double * pw = (double *) malloc((size_t) n_eff * 3 * sizeof(double));
-         int a, b2, c, d;
+         /* touch[g][x]: body 1 + g overlapped, at its grab, link x (x < nl) or body x - nl (x >= nl, an earlier body) */
+         unsigned char * touch = (unsigned char *) calloc((size_t)(rob->n_grabbed + 1) * (nl + rob->n_grabbed + 1), 1);
+         const int tw = nl + rob->n_grabbed + 1;
+         int a, b2;
          self_pairs(rob, rob->n_spheres, rob->sphere_link, rob->sphere_pos, rob->sphere_radius, lex);
-         ora_robot_fk(rob, base_pose, dofvals, R, t, 0, 0);
-         for (a=0; a<n_eff; a++)
+         for (gi=0; gi<rob->n_grabbed; gi++)
          {
-            mat3_vec(R + 9*r->eff_link[a], r->eff_pos + 3*a, pw + 3*a);
-            for (k=0; k<3; k++) pw[3*a+k] += t[3*r->eff_link[a] + k];
+            const ora_grabbed * g = &rob->grabbed[gi];
+            /* everything where it was when body 1 + gi was grabbed: a held body's spheres ride on their link */
+            ora_robot_fk(rob, g->has_grab_state ? g->grab_base_pose : base_pose, g->has_grab_state ? g->grab_dofvals : dofvals, R, t, 0, 0);
+            for (a=0; a<n_eff; a++)
+            {
+               mat3_vec(R + 9*r->eff_link[a], r->eff_pos + 3*a, pw + 3*a);
+               for (k=0; k<3; k++) pw[3*a+k] += t[3*r->eff_link[a] + k];
+            }
+            for (a=0; a<n_eff; a++)
+            {
+               if (eff_body[a] != 1 + gi) continue;
+               for (b2=0; b2<n_eff; b2++)
+               {
+                  double d2 = 0.0;
+                  if (eff_body[b2] > gi) continue;                /* itself, and bodies grabbed after it */
+                  for (k=0; k<3; k++) { const double dd = pw[3*a+k] - pw[3*b2+k]; d2 += dd*dd; }
+                  if (sqrt(d2) - (r->eff_radius[a] + r->eff_radius[b2]) < 0.0)
+                     touch[gi*tw + (eff_body[b2] == 0 ? r->eff_link[b2] : nl + eff_body[b2])] = 1;
+               }
+            }
          }
          r->n_eff = n_eff;
          r->self_excl = (unsigned char *) calloc((size_t) n_eff * n_eff, 1);
-#define ORA_SAME_GROUP(x, y) (eff_body[x] == eff_body[y] && (eff_body[x] != 0 || r->eff_link[x] == r->eff_link[y]))
          for (a=0; a<n_eff; a++)
          {
             r->self_excl[a*n_eff + a] = 1;
             for (b2=a+1; b2<n_eff; b2++)
             {
-               int ex = 0;
-               if (eff_body[a] == 0 && eff_body[b2] == 0) ex = lex[r->eff_link[a]*nl + r->eff_link[b2]] != 0;
-               else if (eff_body[a] == eff_body[b2]) ex = 1;
-               else if (r->eff_link[a] == r->eff_link[b2]) ex = 1;
-               else
-                  for (c=0; c<n_eff && !ex; c++)
-                  {
-                     if (!ORA_SAME_GROUP(c, a)) continue;
-                     for (d=0; d<n_eff && !ex; d++)
-                     {
-                        double d2 = 0.0;
-                        if (!ORA_SAME_GROUP(d, b2)) continue;
-                        for (k=0; k<3; k++) { const double dd = pw[3*c+k] - pw[3*d+k]; d2 += dd*dd; }
-                        if (sqrt(d2) - (r->eff_radius[c] + r->eff_radius[d]) < 0.0) ex = 1;
-                     }
-                  }
+               const int ba = eff_body[a], bb = eff_body[b2];
+               int ex;
+               if (ba == 0 && bb == 0) ex = lex[r->eff_link[a]*nl + r->eff_link[b2]] != 0;
+               else if (ba == bb) ex = 1;
+               else if (ba == 0) ex = (r->eff_link[a] == r->eff_link[b2]) || touch[(bb-1)*tw + r->eff_link[a]];
+               else if (bb == 0) ex = (r->eff_link[a] == r->eff_link[b2]) || touch[(ba-1)*tw + r->eff_link[b2]];
+               else ex = (ba > bb) ? touch[(ba-1)*tw + nl + bb] : touch[(bb-1)*tw + nl + ba];
                r->self_excl[a*n_eff + b2] = r->self_excl[b2*n_eff + a] = (unsigned char) ex;
             }
          }
-#undef ORA_SAME_GROUP
-         free(lex); free(R); free(t); free(pw);
+         free(lex); free(R); free(t); free(pw); free(touch);
       }
 
       /* active / inactive (2265-2291): is the sphere's robot link moved by an active dof */

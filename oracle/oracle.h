@@ -184,6 +184,11 @@ typedef struct ora_grabbed
    int n_spheres;
    const double * sphere_pos;     /* [n_spheres][3] in the kinbody link's frame */
    const double * sphere_radius;  /* [n_spheres] */
+   /* the robot's state at the moment of RobotBase::Grab (the body is rigid with its link from then on): what the body touched
+    * THEN is what CheckSelfCollision leaves it out against.  has_grab_state 0: the body was grabbed in the state of create. */
+   int has_grab_state;
+   double grab_base_pose[7];
+   const double * grab_dofvals;   /* [n_dof] */
 } ora_grabbed;
 
 /* FK: world transforms of all links.  R[n_links][9] row-major, t[n_links][3].

@@ -31,7 +31,8 @@ class Grid(C.Structure):
 
 class Grabbed(C.Structure):
     _fields_ = [("robot_link", C.c_int), ("pose_world_klink", C.c_double * 7), ("n_spheres", C.c_int),
-                ("sphere_pos", c_double_p), ("sphere_radius", c_double_p)]
+                ("sphere_pos", c_double_p), ("sphere_radius", c_double_p),
+                ("has_grab_state", C.c_int), ("grab_base_pose", C.c_double * 7), ("grab_dofvals", c_double_p)]
 
 
 class Robot(C.Structure):
@@ -214,16 +215,26 @@ class OraGrid:
 class OraRobot:
     def __init__(self, model, grabbed=()):
         """grabbed: the kinbodies the robot holds, in GetGrabbed() order (reference src/orcdchomp_mod.cpp:2168-2171):
-        tuples (robot link index, pose_world_klink[7], sphere_pos[k][3], sphere_radius[k])"""
+        tuples (robot link index, pose_world_klink[7], sphere_pos[k][3], sphere_radius[k]) and, optionally, two more entries
+        (base_pose[7], dofvals[n_dof]): the robot's state at the moment of the grab (default: the state of create)"""
         a = model.arrays()
         self._keep = a
         self._grab_keep = []
         self._grabbed = (Grabbed * max(len(grabbed), 1))()
-        for gi, (link, pose, pos, rad) in enumerate(grabbed):
+        for gi, entry in enumerate(grabbed):
+            link, pose, pos, rad = entry[:4]
             pos = f64(pos).reshape(-1, 3); rad = f64(rad).reshape(-1)
             assert len(pos) == len(rad)
             self._grab_keep.append((pos, rad))
             g = self._grabbed[gi]
+            g.has_grab_state = 1 if len(entry) > 4 else 0
+            if len(entry) > 4:
+                gd = f64(entry[5]).reshape(-1)
+                assert len(gd) == a["n_dof"]
+                self._grab_keep.append(gd)
+                for i in range(7):
+                    g.grab_base_pose[i] = float(entry[4][i])
+                g.grab_dofvals = dp(gd)
             g.robot_link = int(link)
             for i in range(7):
                 g.pose_world_klink[i] = float(pose[i])

@@ -25,7 +25,7 @@ if line is None:
 else:
     r = line["roofline"]
     print("%-10s config %s rc %s: value %.3f M  serial %.3f M  kernel %.2f ms (serial %.2f ms)  parity %.2e" % (
-        v, c, rc, line["value"] / 1e6, (line["value_serial"] or 0) / 1e6, r["avg_kernel_ms"], r["serial_avg_kernel_ms"] or 0,
+        v, c, rc, line["value"] / 1e6, (line["value_serial"] or 0) / 1e6, r["avg_kernel_ms"], r.get("serial_avg_kernel_ms") or 0,
         line["parity_rel_l2_max_vs_oracle"] or -1))
 PY
   done

@@ -9,6 +9,7 @@ model = common.setup_product_wam(mod)
 n_runs = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 goals = common.wam_goals(n_runs)
 kw = dict(n_points=100, lambda_=100.0, obs_factor=500.0)
+if len(sys.argv) > 2: kw["derivative"] = int(sys.argv[2])      # python scripts/phase_profile.py 1024 2
 bid = mod.batch_create(model.name, goals, **kw)
 mod.batch_iterate(bid, 5)
 mod.kernel_time(reset=True)

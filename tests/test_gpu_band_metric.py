@@ -1,0 +1,138 @@
+"""`derivative 2` and `derivative 3` (src/libcd/chomp.c:239-340: K_d = diff K_{d-1} makes the smoothness metric penta- / hepta-diagonal;
+`create ... derivative D`, src/orcdchomp_mod.cpp:1888-2079) on the GPU against the oracle.  The reference multiplies by the dense
+inverse of dgetrf + dgetri (chomp.c:393-403, 525-548, 643-649); the HIP path applies the band inverse through its rank-D generators
+by D prefix and D suffix wave scans per column (csrc/chomp_kernel.hip semisep_scan_column, csrc/host_math.cpp build_semisep), in
+the metric solve and in the joint-limit rounds.  Both are within cond(A) eps of the exact solve and of each other."""
+import numpy as np
+import pytest
+
+import common
+import or_cdchomp_amd
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import oracle_py as O
+    O.build(ref=False)
+    return O
+
+
+def _product(goals, n_iter, precision=64, **kw):
+    mod = or_cdchomp_amd.Module(0)
+    model = common.setup_product_wam(mod)
+    extra = dict(precision=32) if precision == 32 else {}
+    bid = mod.batch_create(model.name, goals, **kw, **extra)
+    costs, status = mod.batch_iterate(bid, n_iter)
+    traj = mod.batch_gettraj(bid)
+    mod.batch_destroy(bid)
+    mod.close()
+    return model, traj, costs, status
+
+
+def _oracle(O, model, goals, n_iter, **kw):
+    prob = common.tabletop_problem(O)
+    _, base, dofvals, adofs = common.wam_state()
+    okw = dict(kw); okw["D"] = okw.pop("derivative")
+    okw.pop("precision", None)
+    run = lambda g: O.batch_run(O.OraRobot(model), base, dofvals, adofs, g, [prob["sdf"]], [prob["pose"]], O.default_params(**okw), n_iter)
+    res = run(goals)
+    amp, stable = common.amplification(run, goals, res)
+    return res, amp, stable
+
+
+@pytest.mark.parametrize("D,n_points,lam,n_iter", [(2, 100, 100.0, 40), (3, 100, 100.0, 40), (2, 200, 200.0, 25), (3, 60, 50.0, 30),
+                                                  (4, 50, 100.0, 20), (2, 300, 300.0, 12)])
+def test_band_metric_matches_oracle(oracle, D, n_points, lam, n_iter):
+    """config 2's runs with a higher derivative; 300 waypoints: five rows per lane, the scans' second form"""
+    n_runs = 12
+    goals = common.wam_goals(n_runs, seed=20250101)
+    kw = dict(n_points=n_points, lambda_=lam, obs_factor=500.0, derivative=D)
+    model, traj, costs, status = _product(goals, n_iter, **kw)
+    (otraj, ocosts, ostatus, _), amp, stable = _oracle(oracle, model, goals, n_iter, **kw)
+    well = [k for k in range(n_runs) if amp[k] < 1e-9 and stable[k] and ostatus[k] == 0]
+    assert len(well) >= n_runs // 2, (amp, ostatus)
+    worst = 0.0
+    for k in range(n_runs):
+        if k in well:
+            assert status[k] == 0
+            err = common.rel_l2(traj[k], otraj[k])
+            worst = max(worst, err)
+            assert err <= 1e-6, (k, err)
+            assert np.allclose(costs[k], ocosts[k], rtol=1e-6, atol=0), (k, costs[k], ocosts[k])
+        elif status[k] == 0 and ostatus[k] == 0:
+            assert common.rel_l2(traj[k], otraj[k]) <= max(1e-6, common.CHAOS_FACTOR * amp[k]), k
+    print("derivative %d, %d waypoints: worst rel L2 %.3e over %d well-conditioned runs" % (D, n_points, worst, len(well)))
+
+
+@pytest.mark.parametrize("D", [2, 3])
+def test_band_metric_joint_limit_rounds(oracle, D):
+    """goals at the joint limits: the projection rounds (chomp.c:608-655) run with the band inverse; every run the oracle itself
+    reproduces under one-ulp changes of its goal must come out the same, status included"""
+    model0, _, _, _ = common.wam_state()
+    lo, hi = np.array(model0.limit_lower)[:7], np.array(model0.limit_upper)[:7]
+    rng = np.random.default_rng(5 + D)
+    n_runs = 16
+    goals = np.where(rng.uniform(size=(n_runs, 7)) < 0.5, lo + 0.01, hi - 0.01) * 1.0
+    goals[:, 3:] = common.wam_goals(n_runs, seed=9)[:, 3:]
+    kw = dict(n_points=100, lambda_=20.0, obs_factor=500.0, derivative=D)
+    n_iter = 30
+    model, traj, costs, status = _product(goals, n_iter, **kw)
+    (otraj, ocosts, ostatus, _), amp, stable = _oracle(oracle, model, goals, n_iter, **kw)
+    well = [k for k in range(n_runs) if amp[k] < 1e-9 and stable[k]]
+    assert len(well) >= n_runs // 2
+    for k in well:
+        assert status[k] == ostatus[k], k
+        if ostatus[k] == 0:
+            assert common.rel_l2(traj[k], otraj[k]) <= 1e-6, k
+    assert (traj[status == 0][:, :, :7] >= lo - 1e-9).all() and (traj[status == 0][:, :, :7] <= hi + 1e-9).all()
+
+
+def test_band_metric_joint_limit_rounds_are_made(monkeypatch):
+    """the same workload with the kernel's phase counters on: the projection rounds really run with the band inverse"""
+    import ctypes as C
+    monkeypatch.setenv("ORC_PHASE_TIMERS", "1")
+    model0, _, _, _ = common.wam_state()
+    lo, hi = np.array(model0.limit_lower)[:7], np.array(model0.limit_upper)[:7]
+    rng = np.random.default_rng(7)
+    n_runs = 16
+    goals = np.where(rng.uniform(size=(n_runs, 7)) < 0.5, lo + 0.01, hi - 0.01) * 1.0
+    goals[:, 3:] = common.wam_goals(n_runs, seed=9)[:, 3:]
+    mod = or_cdchomp_amd.Module(0)
+    model = common.setup_product_wam(mod)
+    bid = mod.batch_create(model.name, goals, n_points=100, lambda_=20.0, obs_factor=500.0, derivative=2)
+    mod.batch_iterate(bid, 30)
+    ph = np.zeros((n_runs, 8))
+    mod._check(mod._lib.orc_batch_get_state(mod._h, bid, b"phase", ph.ctypes.data_as(C.POINTER(C.c_double)), ph.size))
+    mod.batch_destroy(bid)
+    mod.close()
+    assert ph[:, 6].sum() >= n_runs, ph[:, 6]                   # rounds made, over the batch
+
+
+def test_band_metric_generators_against_dense_inverse(monkeypatch):
+    """ORC_NO_SEMISEP=1 keeps the dense inverse (the form of the reference and of rounds 1-5): same trajectories to rounding"""
+    goals = common.wam_goals(8, seed=4)
+    kw = dict(n_points=100, lambda_=100.0, obs_factor=500.0, derivative=2, use_momentum=1)
+    _, t_gen, c_gen, s_gen = _product(goals, 30, **kw)
+    monkeypatch.setenv("ORC_NO_SEMISEP", "1")
+    _, t_dense, c_dense, s_dense = _product(goals, 30, **kw)
+    assert np.array_equal(s_gen, s_dense)
+    ok = s_gen == 0
+    assert ok.sum() >= 4
+    errs = [common.rel_l2(t_gen[k], t_dense[k]) for k in np.flatnonzero(ok)]
+    assert np.median(errs) <= 1e-9, errs
+
+
+def test_band_metric_fp32(oracle):
+    """precision 32 with derivative 2: the scans run in double over double generators; 1e-3 as for BASELINE configs[4]"""
+    n_runs = 8
+    goals = common.wam_goals(n_runs, seed=12)
+    kw = dict(n_points=100, lambda_=200.0, obs_factor=200.0, derivative=2)
+    model, traj, costs, status = _product(goals, 25, precision=32, **kw)
+    (otraj, ocosts, ostatus, _), amp, stable = _oracle(oracle, model, goals, 25, **kw)
+    well = [k for k in range(n_runs) if amp[k] < 1e-9 and stable[k] and ostatus[k] == 0]
+    assert len(well) >= 4
+    for k in well:
+        assert status[k] == 0
+        assert common.rel_l2(traj[k], otraj[k]) <= 1e-3, k

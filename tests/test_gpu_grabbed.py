@@ -442,3 +442,57 @@ def test_recheck_leaves_a_held_body_out_only_against_what_it_touched(scene, orac
     link = np.array([model.link_names.index(sp[0]) for sp in model.spheres])
     assert ex[16:, :16][:, link == fore].all() and ex[16:, :16][:, link == s["hand"]].all()
     print("re-check with a body that reaches the forearm: %d of %d runs collide, %d of them self collisions" % (got["collides"].sum(), n_runs, n_self))
+
+
+def test_recheck_takes_a_held_bodys_contacts_at_the_grab(oracle):
+    """round-5 advisor: the links a held body is never tested against are the ones it touched AT THE GRAB (RobotBase::Grab records
+    them; src/orcdchomp_mod.cpp:2998-2999 -> CheckSelfCollision), not the ones it overlaps when the run is created.  A body grabbed
+    with the wrist straight and carried, by bending the wrist, into the forearm: every run starts in that self collision and the
+    re-check says so (first contact at time 0, a held sphere against a forearm sphere), device verdict == oracle.  The same body
+    grabbed in the bent state is left out against the forearm, as before."""
+    model, base, dofvals, adofs = common.wam_state()
+    hand, fore = model.link_names.index("handbase"), model.link_names.index("wam4")
+    q_grab = dofvals.copy(); q_grab[5] = 0.0
+    q_create = dofvals.copy(); q_create[5] = -1.5         # (bent this way no finger dips into the table's field at the start)
+    pos = [[0.0, 0.0, 0.10], [-0.15, 0.0, 0.03]]; rad = [0.04, 0.07]
+    prob = common.tabletop_problem(oracle)
+    n_runs = 8
+    goals = common.wam_goals(n_runs, seed=61)
+    kw = dict(n_points=30, lambda_=100.0, obs_factor=500.0)
+    vmax = np.ones(model.n_dof)
+    n_own = len(model.spheres)
+    link_of = np.array([model.link_names.index(sp[0]) for sp in model.spheres])
+    Rc, tc = model.link_frames(base, q_create)
+    pose_create = list(oracle.pose_from_dR(tc[hand], Rc[hand]))
+    first_self = {}
+    for when, q_at_grab in (("straight", q_grab), ("bent", q_create)):
+        mod = or_cdchomp_amd.Module(0)
+        m2 = common.setup_product_wam(mod)
+        mod.set_dof_values(m2.name, q_at_grab)
+        Rg, tg = model.link_frames(base, q_at_grab)
+        mod.add_kinbody_boxes("tool", [([0, 0, 0, 0, 0, 0, 1], [0.02, 0.02, 0.02])], transform=list(oracle.pose_from_dR(tg[hand], Rg[hand])))
+        mod.set_kinbody_spheres("tool", pos, rad)
+        mod.grab(m2.name, "tool", hand)
+        mod.set_dof_values(m2.name, q_create)                     # the arm moves on, the body with it
+        bid = mod.batch_create(m2.name, goals, **kw)
+        got = mod.batch_collision_verdict(bid)                   # the seed trajectories: straight lines from q_create
+        traj = mod.batch_gettraj(bid)
+        mod.batch_destroy(bid)
+        mod.close()
+        rob = oracle.OraRobot(model, grabbed=[(hand, pose_create, pos, rad, base, q_at_grab)])
+        for k in range(n_runs):
+            orun = oracle.OraRun(rob, base, q_create, adofs, goals[k], [prob["sdf"]], [prob["pose"]], oracle.default_params(**kw))
+            orun.set_traj(traj[k])
+            want = orun.collision_recheck(vmax[:7])
+            orun.destroy()
+            assert want["collides"] == got["collides"][k], (when, k, want, got["sphere"][k], got["field"][k])
+            if want["collides"]:
+                assert want["sphere"] == got["sphere"][k] and want["field"] == got["field"][k], (when, k, want, got["sphere"][k], got["field"][k])
+                assert np.isclose(want["time"], got["time"][k], rtol=1e-12, atol=1e-15)
+        # contacts between a held sphere and a forearm sphere at time 0
+        held_vs_fore = [(got["sphere"][k] >= n_own and got["field"][k] <= -2 and link_of[-2 - got["field"][k]] == fore) or
+                        (got["field"][k] <= -2 and -2 - got["field"][k] >= n_own and got["sphere"][k] < n_own and link_of[got["sphere"][k]] == fore)
+                        for k in range(n_runs)]
+        first_self[when] = np.array(held_vs_fore) & (got["time"] == 0.0) & (got["collides"] != 0)
+    assert first_self["straight"].all(), first_self
+    assert not first_self["bent"].any(), first_self

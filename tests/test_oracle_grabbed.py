@@ -190,3 +190,80 @@ def test_a_held_body_does_not_change_the_robots_own_link_pairs(oracle, wam):
     ex = run.self_excluded()
     run.destroy()
     assert np.array_equal(ex[n_own, :n_own] == 1, link == hand)
+
+
+def test_grab_contacts_are_taken_at_the_grab_not_at_create(oracle, wam):
+    """OpenRAVE records what a body touches at the moment of RobotBase::Grab and CheckSelfCollision leaves exactly that out
+    (src/orcdchomp_mod.cpp:2998-2999 calls it).  A body grabbed with the wrist straight touches the wrist link only; when the
+    run is created with the wrist bent so far that the body meets the forearm, the forearm pair counts.  The same body grabbed
+    in that bent state is left out against the forearm (round-5 advisor: the exclusions used to be taken at create)."""
+    m = wam["model"]
+    hand, fore, wrist = m.link_names.index("handbase"), m.link_names.index("wam4"), m.link_names.index("wam6")
+    q_grab = wam["q"].copy(); q_grab[5] = 0.0
+    q_create = wam["q"].copy(); q_create[5] = 1.5
+    pos = [[0.0, 0.0, 0.10], [0.15, 0.0, 0.03]]; rad = [0.04, 0.07]
+    # the body's own frame is the hand's (it rides with it): its world pose at create
+    R, t = m.link_frames(wam["base"], q_create)
+    pose_create = list(oracle.pose_from_dR(t[hand], R[hand]))
+    link_of = np.array([m.link_names.index(s[0]) for s in m.spheres])
+
+    def world(q):
+        Rq, tq = m.link_frames(wam["base"], q)
+        own = [(link_of[i], Rq[link_of[i]] @ np.asarray(s[1]) + tq[link_of[i]], s[2]) for i, s in enumerate(m.spheres)]
+        held = [(Rq[hand] @ np.asarray(p) + tq[hand], r) for p, r in zip(pos, rad)]
+        return own, held
+
+    def touched(q):
+        own, held = world(q)
+        return {int(l) for l, c, r in own for p, rr in held if np.linalg.norm(p - c) - (r + rr) < 0.0}
+    assert fore not in touched(q_grab) and fore in touched(q_create) and wrist in touched(q_grab)      # the scene is what the test says
+
+    def excl(grabbed):
+        rob = oracle.OraRobot(m, grabbed=grabbed)
+        run = oracle.OraRun(rob, wam["base"], q_create, list(range(7)), np.zeros(7), [wam["prob"]["sdf"]], [wam["prob"]["pose"]],
+                            oracle.default_params(**KW))
+        ex = run.self_excluded().copy()
+        run.destroy()
+        return ex
+    at_grab = excl([(hand, pose_create, pos, rad, wam["base"], q_grab)])
+    at_create = excl([(hand, pose_create, pos, rad)])
+    n = len(m.spheres)
+    for ex, fore_out in ((at_grab, False), (at_create, True)):
+        assert ex.shape == (n + 2, n + 2) and (ex == ex.T).all()
+        assert ex[n:, :n][:, link_of == hand].all() if (link_of == hand).any() else True      # the grabbing link, always
+        assert ex[n:, :n][:, link_of == wrist].all()                                           # touched at either moment
+        assert ex[n:, :n][:, link_of == fore].all() == fore_out
+        assert ex[n, n + 1] and ex[n + 1, n]                                                   # one rigid body
+    assert not at_grab[n:, :n][:, link_of == fore].any()
+    # an independent reading of the rule: a held sphere against a robot sphere is left out iff the BODY touched that sphere's link then
+    for q, ex in ((q_grab, at_grab), (q_create, at_create)):
+        tl = touched(q) | {hand}
+        want = np.array([[link_of[i] in tl for i in range(n)]] * 2)
+        assert np.array_equal(ex[n:, :n].astype(bool), want)
+
+
+def test_two_held_bodies_touch_at_the_later_grab(oracle, wam):
+    """two bodies on two links: whether they are left out against each other is decided where they were when the SECOND was grabbed"""
+    m = wam["model"]
+    hand, fore = m.link_names.index("handbase"), m.link_names.index("wam4")
+    q_apart = wam["q"].copy(); q_apart[5] = 0.0
+    q_touch = wam["q"].copy(); q_touch[5] = 1.5
+    R, t = m.link_frames(wam["base"], q_touch)
+    pose_hand = list(oracle.pose_from_dR(t[hand], R[hand])); pose_fore = list(oracle.pose_from_dR(t[fore], R[fore]))
+    A = [[0.15, 0.0, 0.03]], [0.07]
+    # body B sits on the forearm where A ends up when the wrist is bent
+    pB = np.linalg.inv(R[fore]) @ (R[hand] @ np.asarray(A[0][0]) + t[hand] - t[fore])
+    B = [list(pB)], [0.05]
+    n = len(m.spheres)
+
+    def excl(state_second):
+        second = (fore, pose_fore, B[0], B[1]) + ((wam["base"], state_second) if state_second is not None else ())
+        rob = oracle.OraRobot(m, grabbed=[(hand, pose_hand, A[0], A[1], wam["base"], q_apart), second])
+        run = oracle.OraRun(rob, wam["base"], q_touch, list(range(7)), np.zeros(7), [wam["prob"]["sdf"]], [wam["prob"]["pose"]],
+                            oracle.default_params(**KW))
+        ex = run.self_excluded().copy()
+        run.destroy()
+        return ex
+    assert not excl(q_apart)[n, n + 1]           # apart when B was grabbed: the pair counts, although they touch at create
+    assert excl(q_touch)[n, n + 1]               # touching when B was grabbed: left out
+    assert excl(None)[n, n + 1]                  # (no state given: grabbed in the state of create)
