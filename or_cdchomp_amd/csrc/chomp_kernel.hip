@@ -446,6 +446,15 @@ __device__ __forceinline__ void toeplitz_scan_column(PT buf, int m, int n, int c
    }
 }
 
+// (arguments of a called function arrive in vector registers: these tell the compiler they are wave-uniform)
+__device__ __forceinline__ unsigned long long uni64(unsigned long long v)
+{
+   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned) v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+   return ((unsigned long long) hi << 32) | lo;
+}
+__device__ __forceinline__ double unir(double v) { return __longlong_as_double((long long) uni64((unsigned long long) __double_as_longlong(v))); }
+__device__ __forceinline__ float unir(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+
 // x = A^-1 g for the band metric of a higher derivative (A = K_D^T K_D / N_D, half-bandwidth D = RANK: penta-diagonal for
 // `derivative 2`, hepta-diagonal for 3; src/libcd/chomp.c:239-340), one column of buf [m][n] in place, by the calling wavefront.
 // The inverse of a band matrix is semiseparable: Ainv[i][j] = sum_k U[k][i] V[k][j] for i <= j (generators from the host,
@@ -557,10 +566,13 @@ __device__ __forceinline__ void semisep_scan_column_any(PT buf, int m, int n, in
 }
 // all n columns of buf [m][n] in place, a wavefront per column at a time: ONE barrier, like the scan solve of derivative 1.
 // A column that is zero throughout (the joint-limit rounds solve for a Gjlimit with a few non-zero columns) is left alone.
-template <typename real, int BLOCK, typename BT>
-__device__ __forceinline__ real * semisep_scan_solve(const BT & b, const real * tab, real * buf)
+template <typename real, int BLOCK>
+__device__ __attribute__((noinline)) real * semisep_solve_call(real * buf_in, const real * tab_in, int m_in, int n_in, int rank_in)
 {
-   const int m = b.m, n = b.n, rank = b.ss_rank;
+   // (a function of its own: six instantiations of the column solve, of no interest to a `derivative 1` run's instruction cache)
+   const int m = __builtin_amdgcn_readfirstlane(m_in), n = __builtin_amdgcn_readfirstlane(n_in), rank = __builtin_amdgcn_readfirstlane(rank_in);
+   real * buf = (real *) uni64((unsigned long long) buf_in);
+   const real * tab = (const real *) uni64((unsigned long long) tab_in);
    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
    const int rpl = (m + 63) >> 6;
    const double * U = (const double *) tab, * V = U + rank*m;      // (the metric's tables: DevBatch::ss_rank)
@@ -575,14 +587,6 @@ __device__ __forceinline__ real * semisep_scan_solve(const BT & b, const real * 
    return buf;
 }
 
-// (arguments of a called function arrive in vector registers: these tell the compiler they are wave-uniform)
-__device__ __forceinline__ unsigned long long uni64(unsigned long long v)
-{
-   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned) v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-   return ((unsigned long long) hi << 32) | lo;
-}
-__device__ __forceinline__ double unir(double v) { return __longlong_as_double((long long) uni64((unsigned long long) __double_as_longlong(v))); }
-__device__ __forceinline__ float unir(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 
 // Joint-limit projection rounds (src/libcd/chomp.c:608-655) for the tridiagonal Toeplitz metric,
 // executed by ONE wavefront (the caller's; the others wait at the barrier that follows): a round has
@@ -1128,7 +1132,7 @@ template <typename real, int BLOCK, typename BT>
 __device__ __forceinline__ real * metric_solve(const BT & b, const real * tab, real * src, real * tmp)
 {
    if (b.solve_mode == 2) return toeplitz_scan_solve<real, BLOCK>(b, src);
-   if (b.solve_mode == 3) return semisep_scan_solve<real, BLOCK>(b, tab, src);
+   if (b.solve_mode == 3) return semisep_solve_call<real, BLOCK>(src, tab, b.m, b.n, b.ss_rank);
    return b.solve_mode == 0 ? pcr_solve<real, BLOCK>(b, tab, src, tmp) : dense_solve<real, BLOCK>(b, src, tmp);
 }
 
@@ -1245,21 +1249,68 @@ __device__ __forceinline__ acc band_row(const BT & b, const real * tab, const re
    return sum;
 }
 
-// (A T + B)[i][c] from the band of A and the endpoint couplings of B.
+// (A T + B)[i][c] of the tridiagonal Toeplitz metric of derivative 1: the end rows couple to the fixed endpoints with a_off.
 // T_s holds all n_points rows (row 0 = start, row n_points-1 = goal).
 template <typename real, typename BT>
-__device__ __forceinline__ real smooth_grad(const BT & b, const real * tab, const real * T_s, int i, int c)
+__device__ __forceinline__ real smooth_grad(const BT & b, const real * T_s, int i, int c)
 {
    const int n = b.n;
-   if (b.D == 1)       // tridiagonal Toeplitz: the end rows couple to the fixed endpoints with a_off
-      return b.a_diag * T_s[(i+1)*n + c] + b.a_off * (T_s[i*n + c] + T_s[(i+2)*n + c]);
-   if (sizeof(real) == 4 && b.metric64)
+   return b.a_diag * T_s[(i+1)*n + c] + b.a_off * (T_s[i*n + c] + T_s[(i+2)*n + c]);
+}
+// The two passes over the trajectory that need A T + B, for a metric that is not that one (a higher derivative; derivative 1
+// without a start boundary): G = G/m + A T + B of the update phase and 0.5 tr(T^T A T) + tr(B^T T) of the cost pass, as FUNCTIONS of
+// their own -- inlined, band_row tripled the lean update phase of every `derivative 1` kernel (2.1 k -> 5.4 k instructions) and cost
+// BASELINE configs[1] 1 % through the instruction cache alone (profiles/r06_ab_experiments.txt).
+template <typename real, int BLOCK>
+__device__ __attribute__((noinline)) void band_gradient_pass(const void * kp, const real * tab_in, const real * T_in, const real * Gc_in, real * G_in)
+{
+   // (the kernarg block's address, wave-uniform again; through uni64: readfirstlane returns an int, and OR-ing the low half in as
+   // one sign-extends it -- a launch whose kernarg address has bit 31 set then reads from a wild pointer: the first version did)
+   const __attribute__((address_space(4))) DevBatch<real> & b = *(const __attribute__((address_space(4))) DevBatch<real> *) uni64((unsigned long long) kp);
+   const real * tab = (const real *) uni64((unsigned long long) tab_in), * T_s = (const real *) uni64((unsigned long long) T_in);
+   const real * Gc = (const real *) uni64((unsigned long long) Gc_in);
+   real * G_s = (real *) uni64((unsigned long long) G_in);
+   const int n = b.n, mn = b.m*n;
+   const float rn_f = 1.0f / (float) n;
+   for (int e=threadIdx.x; e<mn; e+=BLOCK)
    {
-      double bt;
-      return (real) band_row<real, double>(b, tab, T_s, i, c, bt);
+      const int i = div_n(e, rn_f), c = e - i*n;
+      real g = Gc[e];
+      g *= b.inv_m;
+      if (sizeof(real) == 4 && b.metric64) { double bt; g += (real) band_row<real, double>(b, tab, T_s, i, c, bt); }
+      else { real bt; g += band_row<real, real>(b, tab, T_s, i, c, bt); }
+      G_s[e] = g;
    }
-   real bt;
-   return band_row<real, real>(b, tab, T_s, i, c, bt);
+}
+template <typename real, int BLOCK>
+__device__ __attribute__((noinline)) double band_cost_pass(const void * kp, const real * tab_in, const real * T_in)
+{
+   // (the kernarg block's address, wave-uniform again; through uni64: readfirstlane returns an int, and OR-ing the low half in as
+   // one sign-extends it -- a launch whose kernarg address has bit 31 set then reads from a wild pointer: the first version did)
+   const __attribute__((address_space(4))) DevBatch<real> & b = *(const __attribute__((address_space(4))) DevBatch<real> *) uni64((unsigned long long) kp);
+   const real * tab = (const real *) uni64((unsigned long long) tab_in), * T_s = (const real *) uni64((unsigned long long) T_in);
+   const int n = b.n, mn = b.m*n;
+   const float rn_f = 1.0f / (float) n;
+   double acc = 0.0;
+   for (int e=threadIdx.x; e<mn; e+=BLOCK)
+   {
+      const int i = div_n(e, rn_f), c = e - i*n;
+      if (sizeof(real) == 4 && b.metric64)
+      {
+         // fp32 and a higher derivative: the band's entries are ~1/dt^4 and the sum is of order one, so this one sum is
+         // taken in double from the band in double (the trajectory is what it is: its rounding costs ~1e-5 of the sum)
+         double bt;
+         const double sd = band_row<real, double>(b, tab, T_s, i, c, bt);
+         acc += (double) T_s[n + e] * (0.5 * (sd + bt));
+      }
+      else
+      {
+         real bt;
+         const real sg = band_row<real, real>(b, tab, T_s, i, c, bt);
+         acc += (double) T_s[n + e] * (0.5 * ((double) sg + (double) bt));
+      }
+   }
+   return acc;
 }
 
 // 1: the many-sphere cost pass of an iteration is part of the kernel function itself (see the kernel's tile loop);
@@ -1697,12 +1748,15 @@ __device__ __attribute__((noinline)) int phase_update(const void * kp, int it_in
    __builtin_amdgcn_s_setprio(ORC_PRIO_UPDATE);
    if (tid < 2) colmask_s[tid] = 0u;       // read last after the previous step's barrier, set again after the next one
    // G = G/m + A T + B   (chomp.c:492, 515-522)
+   const bool band = !LEAN && b.D != 1;      // (a metric that is not the tridiagonal Toeplitz one: its pass is a function of its own)
+   if (band) band_gradient_pass<real, BLOCK>(kp, pcr_tab, T_s, Gc, G_s);
 #if ORC_UPDATE_BATCH
    // (four entries of a thread per trip, their gradient rows read first: where the plan keeps the rows in global memory a plain
    // loop made one round trip through L2 per entry, eleven in a row for a 200-waypoint run of 14 dofs: BASELINE configs[3] +2 %;
    // for the three entries per thread of a 7 x 100 run it costs 0.7 %: those take the plain loop)
    const bool batched = ORC_UPDATE_BATCH && mn > 4*BLOCK;      // (workgroup-uniform)
-   if (batched && !b.g_in_lds)
+   if (band) {}
+   else if (batched && !b.g_in_lds)
    for (int e0=tid; e0<mn; e0+=ORC_UPDATE_BATCH*BLOCK)
    {
       real gq[ORC_UPDATE_BATCH];
@@ -1721,20 +1775,21 @@ __device__ __attribute__((noinline)) int phase_update(const void * kp, int it_in
          const int i = div_n(e, rn_f), c = e - i*n;
          real g = gq[q];
          g *= b.inv_m;
-         g += smooth_grad<real>(b, pcr_tab, T_s, i, c);
+         g += smooth_grad<real>(b, T_s, i, c);
          G_s[e] = g;
       }
    }
    else
 #else
    const bool batched = false;
+   if (!band)
 #endif
    for (int e=tid; e<mn; e+=BLOCK)
    {
       const int i = div_n(e, rn_f), c = e - i*n;
       real g = Gc[e];
       g *= b.inv_m;
-      g += smooth_grad<real>(b, pcr_tab, T_s, i, c);
+      g += smooth_grad<real>(b, T_s, i, c);
       G_s[e] = g;
    }
    __syncthreads();
@@ -2031,28 +2086,13 @@ __device__ __attribute__((noinline)) PassCosts phase_costs(const void * kp, int 
    __builtin_amdgcn_s_setprio(ORC_PRIO_UPDATE);
    {
       double acc = 0.0;
+      if (b.D != 1) acc = band_cost_pass<real, BLOCK>(kp, E.pcr_tab, T_s);
+      else
       for (int e=tid; e<mn; e+=BLOCK)
       {
          const int i = div_n(e, rn_f), c = e - i*n;
-         if (sizeof(real) == 4 && b.metric64)
-         {
-            // fp32 and a higher derivative: the band's entries are ~1/dt^4 and the sum is of order one, so this one sum is
-            // taken in double from the band in double (the trajectory is what it is: its rounding costs ~1e-5 of the sum)
-            double bt;
-            const double sd = band_row<real, double>(b, E.pcr_tab, T_s, i, c, bt);
-            acc += (double) T_s[n + e] * (0.5 * (sd + bt));
-            continue;
-         }
-         if (b.D != 1)
-         {
-            real bt;
-            const real sg = band_row<real, real>(b, E.pcr_tab, T_s, i, c, bt);
-            acc += (double) T_s[n + e] * (0.5 * ((double) sg + (double) bt));
-            continue;
-         }
-         const real sg = smooth_grad<real>(b, E.pcr_tab, T_s, i, c);     // (A T + B)
-         const real bt = (b.D == 1) ? b.a_off * ((i == 0 ? T_s[c] : (real)0) + (i == m-1 ? T_s[(np-1)*n + c] : (real)0))
-                                    : b.beta_s[i] * T_s[c] + b.beta_g[i] * T_s[(np-1)*n + c];
+         const real sg = smooth_grad<real>(b, T_s, i, c);     // (A T + B)
+         const real bt = b.a_off * ((i == 0 ? T_s[c] : (real)0) + (i == m-1 ? T_s[(np-1)*n + c] : (real)0));
          acc += (double) T_s[n + e] * (0.5 * ((double) sg + (double) bt));
       }
       double ss = 0.0, sg2 = 0.0, gg = 0.0;

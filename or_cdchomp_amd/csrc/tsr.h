@@ -543,6 +543,9 @@ __device__ __forceinline__ T * uniform_ptr(T * p)
    return (T *)(((unsigned long long) hi << 32) | lo);
 }
 
+#ifndef ORC_TSR_BIG_SHAPES
+#define ORC_TSR_BIG_SHAPES 1   // rows of 32 lanes with 10 and 12 registers (17 .. 24 rows per block); 0: such blocks take the LDS form
+#endif
 #ifndef ORC_TSR_PRAW
 #define ORC_TSR_PRAW 1      // the pivot row to every row-slot: 0 v_permlane16/32_swap, 1 ds_bpermute (kept: the step is bound by vector issue, profiles/r06_ab_experiments.txt)
 #endif
@@ -1269,7 +1272,7 @@ __device__ __attribute__((noinline)) void phase_tsr(const void * kp)
       // a block [S | r] of N = n + (constrained rows of the point) rows needs N + 1 columns: rows of 16 lanes up to N = 15
       // (a 7-dof arm with up to eight constrained rows on a point), rows of 32 lanes up to N = 24
       if (BLOCK >= 128 && m >= 4 && n <= 23)
-         shape = (Nm <= 15) ? 16 : ((Nm <= 24) ? 32 : 0);
+         shape = (Nm <= 15) ? 16 : ((Nm <= (ORC_TSR_BIG_SHAPES ? 24 : 16)) ? 32 : 0);
       if (Nm - n > 16) shape = 0;      // (the row lists of a point hold 16 entries: more constrained rows on one point take the dense path)
 #endif
       if (!shape)
@@ -1293,8 +1296,10 @@ __device__ __attribute__((noinline)) void phase_tsr(const void * kp)
             else if (shape == 16 && Nm <= 12) tsr_eliminate_regs<real, 16, 3, +1>(b, E, hws, Jws, Cst, E.redi, 0, mid, rows);     // (a WAM point with up to five constrained rows)
             else if (shape == 16) tsr_eliminate_regs<real, 16, 4, +1>(b, E, hws, Jws, Cst, E.redi, 0, mid, rows);
             else if (Nm <= 16) tsr_eliminate_regs<real, 32, 8, +1>(b, E, hws, Jws, Cst, E.redi, 0, mid, rows);                    // (two rows per register)
+#if ORC_TSR_BIG_SHAPES
             else if (Nm <= 20) tsr_eliminate_regs<real, 32, 10, +1>(b, E, hws, Jws, Cst, E.redi, 0, mid, rows);
             else tsr_eliminate_regs<real, 32, 12, +1>(b, E, hws, Jws, Cst, E.redi, 0, mid, rows);
+#endif
          }
          else if (wave == 1)
          {
@@ -1303,8 +1308,10 @@ __device__ __attribute__((noinline)) void phase_tsr(const void * kp)
             else if (shape == 16 && Nm <= 12) tsr_eliminate_regs<real, 16, 3, -1>(b, E, hws, Jws, Cst, E.redi, m - 1, mid - 1, rows);
             else if (shape == 16) tsr_eliminate_regs<real, 16, 4, -1>(b, E, hws, Jws, Cst, E.redi, m - 1, mid - 1, rows);
             else if (Nm <= 16) tsr_eliminate_regs<real, 32, 8, -1>(b, E, hws, Jws, Cst, E.redi, m - 1, mid - 1, rows);
+#if ORC_TSR_BIG_SHAPES
             else if (Nm <= 20) tsr_eliminate_regs<real, 32, 10, -1>(b, E, hws, Jws, Cst, E.redi, m - 1, mid - 1, rows);
             else tsr_eliminate_regs<real, 32, 12, -1>(b, E, hws, Jws, Cst, E.redi, m - 1, mid - 1, rows);
+#endif
          }
          __threadfence_block();
          __syncthreads();

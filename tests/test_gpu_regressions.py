@@ -39,3 +39,26 @@ def test_second_order_metric_long_trajectory_rows_in_global_memory(oracle, momen
     err = max(common.rel_l2(traj[k], otraj[k]) for k in np.flatnonzero(ok))
     assert err <= 1e-6, err
     assert np.allclose(costs[ok], ocosts[ok], rtol=1e-6, atol=0)
+
+
+def test_band_passes_with_any_kernarg_address():
+    """round 6: the band passes of `derivative >= 2` runs are called functions that rebuild the (wave-uniform) address of the kernarg
+    block from two readfirstlane halves; the first version OR-ed the low half in as an int, which sign-extends: a launch whose kernarg
+    block sat at an address with bit 31 set read its batch descriptor from a wild pointer and faulted (half of all launches: the
+    address comes from a ring).  Sixteen launches of the same small batch: all finish, all give the same bits."""
+    import or_cdchomp_amd
+    mod = or_cdchomp_amd.Module(0)
+    model = common.setup_product_wam(mod)
+    goals = common.wam_goals(3, seed=8)
+    ref = None
+    for k in range(16):
+        bid = mod.batch_create(model.name, goals, n_points=60, lambda_=100.0, obs_factor=200.0, derivative=2 + (k % 2))
+        costs, status = mod.batch_iterate(bid, 2)
+        traj = mod.batch_gettraj(bid)
+        mod.batch_destroy(bid)
+        assert (status == 0).all()
+        if k < 2:
+            ref = (ref or {}); ref[k % 2] = (traj, costs)
+        else:
+            assert np.array_equal(traj, ref[k % 2][0]) and np.array_equal(costs, ref[k % 2][1])
+    mod.close()
