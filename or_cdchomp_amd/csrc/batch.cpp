@@ -859,7 +859,8 @@ void BatchShard::build_device(const Robot & robot)
       cons_k_ = base; tsr_blocks_ = blocks;
       const int NB = blocks;
       tsr_ws_stride_ = (size_t) 2*cons_k_ + (size_t) cons_k_ * n + (size_t) NB * n + (size_t) cons_k_ * cons_k_
-                     + (size_t) m * n * (n + 1);      // the last term: delta rows of the structured solve (tsr.h)
+                     + (size_t) m * n * (n + 1)       // delta rows of the structured solve (tsr.h)
+                     + (size_t) NB * nj_ * 6;         // the joints' world axes and anchors of every (constraint, point) block (tsr_eval_point)
       // most constrained rows on one point
       tsr_kmax_ = 0;
       for (int i=0; i<m; i++)

@@ -205,31 +205,44 @@ __device__ __forceinline__ void t_apply_joint(const JT & J, real q, TFrame<real>
 //    B = (xyzypr-Jacobian . pose-Jacobian-inverse)(pose) . spatial transform(table_world)        (mod.cpp:1466-1480)
 // with the sums in the order the full 6 x 7 . 7 x 6 . 6 x 6 products take them (their other terms are exact zeros).
 // KMAX: the most rows a lane holds (3 or 6: six rows of B next to the walk's frames do not fit the register budget).
+// aws: [nj][6][astride] workspace in global memory, this lane's column `slot`: the world axis and anchor of every joint of the chain,
+// written by the walk and read back when the rows of B are known (round 6).  Until then the chain was walked TWICE -- the rows
+// of B need the end effector's pose, the Jacobian columns the joints' axes -- with the first walk's base frame and the second walk's
+// temporaries alive next to B: 596 bytes of scratch per lane, 194 stores and 476 loads per call at the 128-register budget, a third
+// of the constrained lines' HBM traffic (profiles/r06_tsr1_summary.json before / after).
 template <typename real, int KMAX>
-__device__ __forceinline__ void tsr_eval_point_k(const DevModel<real> & gm, const DevTsr<real> & ts, const real * point, int n, real * hrow, real * Jrows)
+__device__ __forceinline__ void tsr_eval_point_k(const DevModel<real> & gm, const DevTsr<real> & ts, const real * point, int n, real * hrow, real * Jrows,
+   real * aws, int astride, int slot)
 {
    typedef const __attribute__((address_space(4))) DevJoint<real> JointC;
    JointC * joints = (JointC *) gm.joints;
    const int nj = __builtin_amdgcn_readfirstlane(gm.nj);
-   TFrame<real> base, cur;
+   TFrame<real> cur;
    if (gm.floating)
    {
       const real q[4] = { point[3], point[4], point[5], point[6] };
-      t_quat_to_R(q, base.R);
-      base.t[0] = point[0]; base.t[1] = point[1]; base.t[2] = point[2];
+      t_quat_to_R(q, cur.R);
+      cur.t[0] = point[0]; cur.t[1] = point[1]; cur.t[2] = point[2];
    }
    else
    {
 #pragma unroll
-      for (int e=0; e<9; e++) base.R[e] = gm.base_R[e];
+      for (int e=0; e<9; e++) cur.R[e] = gm.base_R[e];
 #pragma unroll
-      for (int e=0; e<3; e++) base.t[e] = gm.base_t[e];
+      for (int e=0; e<3; e++) cur.t[e] = gm.base_t[e];
    }
-   // the end-effector link's frame: walk its chain, then the fixed transform to the link
-   cur = base;
+   // the end-effector link's frame: walk its chain (every joint's world axis and anchor go to the workspace), then the fixed
+   // transform to the link
+   typedef __attribute__((address_space(1))) real * GlobalW;
+   GlobalW awg = (GlobalW) aws + slot;
    real aw[3], an[3];
    for (int j=0; j<nj; j++)
-      if ((ts.chain_mask >> j) & 1u) t_apply_joint<real>(joints[j], point[joints[j].col], cur, aw, an);
+      if ((ts.chain_mask >> j) & 1u)
+      {
+         t_apply_joint<real>(joints[j], point[joints[j].col], cur, aw, an);
+#pragma unroll
+         for (int q=0; q<3; q++) { awg[(size_t)(j*6 + q) * astride] = aw[q]; awg[(size_t)(j*6 + 3 + q) * astride] = an[q]; }
+      }
    real Rl[9], tl[3];
 #pragma unroll
    for (int r=0; r<3; r++)
@@ -338,13 +351,13 @@ __device__ __forceinline__ void tsr_eval_point_k(const DevModel<real> & gm, cons
             Jrows[ki*n + c] = s;
          }
    }
-   cur = base;
    for (int j=0; j<nj; j++)
       if ((ts.chain_mask >> j) & 1u)
       {
          JointC & J = joints[j];
          const int col = J.col;
-         t_apply_joint<real>(J, point[col], cur, aw, an);
+#pragma unroll
+         for (int q=0; q<3; q++) { aw[q] = awg[(size_t)(j*6 + q) * astride]; an[q] = awg[(size_t)(j*6 + 3 + q) * astride]; }
          real col6[6];
          if (J.type == 1)
          {
@@ -366,10 +379,11 @@ __device__ __forceinline__ void tsr_eval_point_k(const DevModel<real> & gm, cons
       }
 }
 template <typename real>
-__device__ void tsr_eval_point(const DevModel<real> & gm, const DevTsr<real> & ts, const real * point, int n, real * hrow, real * Jrows)
+__device__ void tsr_eval_point(const DevModel<real> & gm, const DevTsr<real> & ts, const real * point, int n, real * hrow, real * Jrows,
+   real * aws, int astride, int slot)
 {
-   if (ts.k <= 3) tsr_eval_point_k<real, 3>(gm, ts, point, n, hrow, Jrows);
-   else tsr_eval_point_k<real, 6>(gm, ts, point, n, hrow, Jrows);
+   if (ts.k <= 3) tsr_eval_point_k<real, 3>(gm, ts, point, n, hrow, Jrows, aws, astride, slot);
+   else tsr_eval_point_k<real, 6>(gm, ts, point, n, hrow, Jrows, aws, astride, slot);
 }
 
 // (constraint, point) of block o in the reference's list order (the list grows at its head,
@@ -1233,6 +1247,7 @@ __device__ __attribute__((noinline)) void phase_tsr(const void * kp)
    real * Jws = h0 + K;                      // [K][n]
    real * dws = Jws + (size_t) K * n;        // [NB][n] J^T x per block
    real * Mws = dws + (size_t) NB * n;       // [K][K]
+   real * aws = Mws + (size_t) K * K + (size_t) m * n * (n + 1);      // [nj][6][NB]: the joints' world axes and anchors of every block (behind the structured solve's rows)
    const real * AG = b.use_momentum ? E.AG_s : E.AG_g;
    const real * T_s = E.T_s;
    const real inv_lambda = (real)(-1) / b.lambda;
@@ -1249,7 +1264,7 @@ __device__ __attribute__((noinline)) void phase_tsr(const void * kp)
       int c, i, row0;
       tsr_block<real>(b, o, c, i, row0);
       const DevTsr<real> & ts = b.tsrs[c];
-      tsr_eval_point<real>(gm, ts, T_s + (i+1)*n, n, hws + row0, Jws + (size_t) row0 * n);
+      tsr_eval_point<real>(gm, ts, T_s + (i+1)*n, n, hws + row0, Jws + (size_t) row0 * n, aws, NB, o);
       for (int a=0; a<ts.k; a++)
       {
          real s = 0;
