@@ -18,7 +18,7 @@ for a in "$@"; do
     bench)   mode=""; timeout -k 10 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err; rc=$?
              tail -c 1200 $OUT/bench_default.json; echo; cp -f bench_full.json $OUT/bench_full.json 2>/dev/null; [ $rc = 0 ] || exit $rc;;
     toggles) mode=""; timeout -k 10 1100 bash scripts/test_toggles.sh > $OUT/test_toggles.txt 2>&1; rc=$?; grep -c passed $OUT/test_toggles.txt; grep -c failed $OUT/test_toggles.txt; [ $rc = 0 ] || exit $rc;;
-    wide)    mode=""; ORC_RANDOM_ROBOTS=${WIDE:-2000} timeout -k 10 1100 python -m pytest tests/test_gpu_random_robots.py -q -x > $OUT/random_robots_wide.txt 2>&1; rc=$?
+    wide)    mode=""; ORC_RANDOM_ROBOTS=${WIDE:-2000} timeout -k 10 1100 python -m pytest tests/test_gpu_random_robots.py -q > $OUT/random_robots_wide.txt 2>&1; rc=$?
              tail -n 1 $OUT/random_robots_wide.txt; [ $rc = 0 ] || exit $rc;;
     profiles|phase) mode=$a;;
     *) if [ "$mode" = profiles ]; then

@@ -246,3 +246,10 @@ def setup_product_wam_held4(mod):
     mod.set_kinbody_spheres("held4", HELD4_POS, HELD4_RAD)
     mod.grab(model.name, "held4", hand)
     return model, hand, pose
+
+
+def plan_switches_active():
+    """an ORC_* experiment switch is set (scripts/test_toggles.sh runs the suite under each of them): the tests' assertions about WHICH
+    kernel family or solve mode a batch was planned with do not apply then -- the answers must still be right"""
+    import os
+    return any(k.startswith("ORC_") and k not in ("ORC_RANDOM_ROBOTS", "ORC_LIB", "ORC_PHASE_TIMERS", "ORC_DEBUG_PLAN") for k in os.environ)

@@ -212,7 +212,7 @@ def test_wam_with_finger_dofs_holding_the_box(oracle):
     goals = _finger_goals(N_RUNS, 20250101)
     bid = mod.batch_create(model.name, goals, **KW)
     plan = mod.batch_plan(bid)
-    assert plan["variant"] & 512 and plan["variant"] & 1 and plan["lanes_per_waypoint"] == 32, plan
+    assert common.plan_switches_active() or (plan["variant"] & 512 and plan["variant"] & 1 and plan["lanes_per_waypoint"] == 32), plan
     costs, status = mod.batch_iterate(bid, 100)
     traj = mod.batch_gettraj(bid)
     mod.batch_destroy(bid)
@@ -263,7 +263,7 @@ def test_held_box_fp32(oracle, fingers):
     kw = dict(n_points=100, lambda_=100.0, obs_factor=200.0)
     bid = mod.batch_create(model.name, goals, precision=32, **kw)
     plan = mod.batch_plan(bid)
-    assert plan["variant"] & 512 and bool(plan["variant"] & 1) == bool(fingers), plan
+    assert common.plan_switches_active() or (plan["variant"] & 512 and bool(plan["variant"] & 1) == bool(fingers)), plan
     costs, status = mod.batch_iterate(bid, 50)
     traj = mod.batch_gettraj(bid)
     mod.batch_destroy(bid)
@@ -293,6 +293,8 @@ def test_held_box_fp32(oracle, fingers):
 def test_tree_and_chain_kinds_against_the_many_sphere_family(monkeypatch):
     """ORC_PAIRS_CHAIN64_ONLY=1 sends the tree back to the many-sphere family (cost_generic.h, the round-5 path): same trajectories
     to rounding -- two independent implementations of the same sums"""
+    if common.plan_switches_active():
+        pytest.skip("an experiment switch is set: the comparison is between the two families the planner would choose without it")
     out = {}
     for only in (0, 1):
         if only:
