@@ -529,7 +529,8 @@ __device__ void tsr_block_thomas(const BT & b, const Env<real> & E, const real *
 //   LAST column WP-1 -- and Gauss-Jordan replaces S by its inverse in place (gauss_jordan_regs<.., INPLACE>): C'_i = S_i^-1 F_i
 //   with F_i = f_i [I; 0] is f_i times the delta-delta corner of the inverse, so the columns of F need not ride along (until
 //   round 5 the block was [S | F | r]: 18 columns for a WAM point with three constrained rows, rows of 32 lanes, five registers
-//   and two ds_bpermute per register and step; now 11 columns, rows of 16 lanes, three registers, DPP and v_permlane only).
+//   and two ds_bpermute per register and step; now 11 columns, rows of 16 lanes, three registers, DPP for the multipliers
+//   and one ds_bpermute pair for the pivot row -- the v_permlane form of that measured slower, ORC_TSR_PRAW below).
 //   What the next point takes of this one -- the corner of the inverse and r' -- sits in the SAME lanes and registers of the
 //   next block: nothing moves between lanes when a block is put together.  Only the rows of C' and r' the back pass needs go
 //   to memory.
@@ -623,9 +624,10 @@ __device__ __forceinline__ float lane_bcast(float v) { return __uint_as_float(la
 
 // Gauss-Jordan without pivoting on a block held in registers (lane = (row-slot rsub = row % (64 / WP), column c), register t = row
 // t (64 / WP) + rsub), pivots 0 .. N-1, WP = 16 or 32.  Every step is written out: the pivot's register and the row-slot that holds it
-// are known at compile time, so a step selects nothing, and everything a step takes from other lanes comes without the LDS crossbar
-// (round 6; ds_bpermute until then): the pivot by v_readlane, the pivot row at this lane's column by slot_bcast, the lane's
-// multipliers W[r][k] by lane_bcast.  Steps k >= N are skipped (wave-uniform).
+// are known at compile time, so a step selects nothing: the pivot by v_readlane, the lane's multipliers W[r][k] by lane_bcast
+// (DPP; round 6 for rows of 32 lanes, which took two ds_bpermute per register until then), the pivot row at this lane's column by
+// one ds_bpermute pair (ORC_TSR_PRAW 1) or by slot_bcast (0: v_permlane swaps, no LDS crossbar in the chain -- and 7 % slower on
+// the bench lines, whose steps are bound by vector issue: profiles/r06_ab_experiments.txt).  Steps k >= N are skipped (wave-uniform).
 // INPLACE: the block is S (N x N) with right-hand sides in further columns, and S is replaced by its INVERSE -- column k plays the
 // unit column e_k of the augmented form [S | I] in step k, the step it would become one in; a block then needs N + 1 columns
 // where [S | F | r] with F = f I needed 2 N' + 1 (the WAM's three constrained rows per point: 11 columns instead of 18, rows of 16
