@@ -990,7 +990,10 @@ void BatchShard::build_device(const Robot & robot)
    // derivative 2..4: the band inverse through its rank-D generators, D prefix and D suffix wave scans per column (the dense
    // inverse stays for a metric whose generators the host's check rejects, and as ORC_NO_SEMISEP=1 for A/B runs)
    if (metric_.ss_rank > 0 && !getenv("ORC_NO_SEMISEP")) solve_mode_ = 3;
-   if (params.derivative == 1 && m <= 64*ORC_SCAN_RPL && metric_.Aband.size() == (size_t) 3*m
+   // (any length since round 6: beyond 256 moving waypoints the scans read a lane's rows twice instead of holding them in registers;
+   // ORC_SCAN_MAX_M=256 brings the cyclic reduction back for such runs, for A/B)
+   const int scan_max_m = getenv("ORC_SCAN_MAX_M") ? atoi(getenv("ORC_SCAN_MAX_M")) : (1 << 30);
+   if (params.derivative == 1 && m <= scan_max_m && metric_.Aband.size() == (size_t) 3*m
        && (m < 2 || metric_.Aband[(size_t) 1*m] == -2.0 * metric_.Aband[(size_t) 2*m]) && !getenv("ORC_NO_SCAN_SOLVE"))
       solve_mode_ = 2;
    pcr_rows_ = 0;

@@ -364,6 +364,37 @@ __device__ __forceinline__ real wave_suffix_incl(real v)
    return v + add;
 }
 
+// The closed-form scan solve below for trajectories of more than 64 ORC_SCAN_RPL moving waypoints (round 6): the lane's rows read
+// twice instead of held in registers -- a pass for the lane's two partial sums, the wave scans, a pass that forms x row by row
+// (the rows-after sum by taking the lane's own rows off the suffix scan's inclusive value) -- still ONE barrier per solve, where
+// cyclic reduction pays one per level: 300 waypoints ran at 0.6 of the waypoint-iterations/s of 258 (profiles/r06_long_trajectories.txt).
+template <typename real, typename PT>
+__device__ __forceinline__ void toeplitz_scan_column_long(PT buf, int m, int n, int c, int rpl, real kinv)
+{
+   const int lane = threadIdx.x & 63;
+   const int row0 = lane*rpl;
+   real sp = 0, sq = 0;
+   for (int r=0; r<rpl; r++)
+   {
+      const int row = row0 + r;
+      if (row >= m) break;
+      const real g = buf[row*n + c];
+      sp += g * (real)(row + 1); sq += g * (real)(m - row);
+   }
+   const real ip = wave_prefix_incl(sp);
+   real run_p = __shfl_up(ip, 1, 64); if (lane == 0) run_p = 0;      // rows before this lane's
+   real run_q = wave_suffix_incl(sq);                                // rows from this lane's first on
+   for (int r=0; r<rpl; r++)
+   {
+      const int row = row0 + r;
+      if (row >= m) break;
+      const real g = buf[row*n + c];
+      const real wp = (real)(row + 1), wq = (real)(m - row);
+      run_p += g * wp;                                               // rows up to row r
+      run_q -= g * wq;                                               // rows after row r
+      buf[row*n + c] = kinv * (wq * run_p + wp * run_q);
+   }
+}
 // x = A^-1 g in place for the tridiagonal Toeplitz metric A = ca tridiag(-1, 2, -1) (derivative 1),
 // all n columns of buf [m][n].  The inverse is known in closed form,
 //    Ainv[i][v] = (min(i,v)+1) (m - max(i,v)) / ((m+1) ca),
@@ -379,6 +410,12 @@ __device__ __forceinline__ real * toeplitz_scan_solve(const BT & b, real * buf)
    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
    const int rpl = (m + 63) >> 6;
    const real kinv = (real)(-1) / ((real)(m + 1) * b.a_off);      // 1/((m+1) ca), ca = -a_off
+   if (rpl > ORC_SCAN_RPL)      // (more than 256 moving waypoints: the rows are read twice instead of held in registers, below)
+   {
+      for (int c=wave; c<n; c+=BLOCK/64) toeplitz_scan_column_long<real>(buf, m, n, c, rpl, kinv);
+      __syncthreads();
+      return buf;
+   }
    for (int c=wave; c<n; c+=BLOCK/64)
    {
       real g[ORC_SCAN_RPL], wp[ORC_SCAN_RPL], wq[ORC_SCAN_RPL];
@@ -588,6 +625,14 @@ __device__ __attribute__((noinline)) real * semisep_solve_call(real * buf_in, co
 }
 
 
+template <typename real, typename PT>
+__device__ __forceinline__ void toeplitz_scan_column_any(PT buf, int m, int n, int c, real kinv)
+{
+   const int rpl = (m + 63) >> 6;
+   if (rpl <= ORC_SCAN_RPL) toeplitz_scan_column<real>(buf, m, n, c, rpl, kinv);
+   else toeplitz_scan_column_long<real>(buf, m, n, c, rpl, kinv);
+}
+
 // Joint-limit projection rounds (src/libcd/chomp.c:608-655) for the tridiagonal Toeplitz metric,
 // executed by ONE wavefront (the caller's; the others wait at the barrier that follows): a round has
 // no barrier in it.  Lane = `rpl` consecutive waypoints, loop over the columns.  A round is:
@@ -666,11 +711,10 @@ __device__ __forceinline__ int limit_rounds_wave_with(PT T_s, PG G_s, PJ jl_s, i
       for (int c=0; c<n; c++)
          if ((cols >> c) & 1ull)
          {
-#pragma unroll
-            for (int r=0; r<ORC_SCAN_RPL; r++)
+            for (int r=0; r<rpl; r++)      // (any number of rows per lane: trajectories of more than 256 moving waypoints come here)
             {
                const int row = lane*rpl + r;
-               if ((r < rpl) && (row < m)) T_s[n + row*n + c] += sc * G_s[row*n + c];
+               if (row < m) T_s[n + row*n + c] += sc * G_s[row*n + c];
             }
          }
    }
@@ -680,7 +724,8 @@ template <typename real, typename PT, typename PG, typename PJ>
 __device__ __forceinline__ int limit_rounds_wave(PT T_s, PG G_s, PJ jl_s, int m, int n, real kinv, long long * dbg_total)
 {
    const int rpl = (m + 63) >> 6;
-   return limit_rounds_wave_with<real>(T_s, G_s, jl_s, m, n, [&](int c) { toeplitz_scan_column<real>(G_s, m, n, c, rpl, kinv); }, dbg_total);
+   (void) rpl;
+   return limit_rounds_wave_with<real>(T_s, G_s, jl_s, m, n, [&](int c) { toeplitz_scan_column_any<real>(G_s, m, n, c, kinv); }, dbg_total);
 }
 // ... and for the band metric of a higher derivative (solve_mode 3): the same rounds with the band inverse applied through its
 // generators, one wavefront, no barrier inside (m <= 64 ORC_SCAN_RPL: the lane's rows in registers).  A function of its own,
@@ -1056,6 +1101,14 @@ __device__ __forceinline__ LimResult limit_rounds_body(PT T_s, real * G_gen, con
    LimResult res; res.rounds = 0; res.kinds = 0;
    long long * dg = &res.kinds;
    const int nc = __popcll(viol_cols);
+   if (m > 64*ORC_SCAN_RPL)
+   {
+      // more than 256 moving waypoints: the register forms hold at most four rows per lane; the rounds through G in LDS (still one
+      // wavefront, no barrier inside a round; until round 6 such runs took the workgroup loop with a cyclic-reduction solve per round)
+      res.rounds = limit_rounds_wave<real>(T_s, G_s, jl_s, m, n, kinv, nullptr);
+      res.kinds += (long long) res.rounds << 40;
+      return res;
+   }
    if (PART == 1)
    {
       if (nc == 1) res.rounds = limit_rounds_regs_rpl<real, 1>(T_s, jl_s, m, n, kinv, viol_cols, dg);
@@ -1916,7 +1969,7 @@ __device__ __attribute__((noinline)) int phase_update(const void * kp, int it_in
          __syncthreads();             // redi is reused by the reductions below
       }
    }
-   if (!LEAN && !lim_done && b.solve_mode == 3 && m <= 64*ORC_SCAN_RPL && n <= 64 && !b.lim_generic)
+   if (!LEAN && !lim_done && b.solve_mode == 3 && n <= 64 && !b.lim_generic)
    {
       // a higher derivative: the rounds by one wavefront, the band inverse through its generators (no barrier inside a round)
       lim_done = true;

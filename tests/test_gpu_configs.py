@@ -385,3 +385,45 @@ def test_ten_link_chain_two_waypoints_per_wavefront(oracle):
         run.destroy()
     assert errs and max(errs) <= 1e-6, errs
     print("10-link chain (20 spheres, 32 lanes per waypoint) worst rel L2 %.3e" % max(errs))
+
+
+@pytest.mark.parametrize("n_points,momentum", [(300, 0), (520, 0), (300, 1)])
+def test_long_trajectory_scan_solve(oracle, n_points, momentum, monkeypatch):
+    """more than 256 moving waypoints (round 6): the closed-form scans with a lane's rows read twice instead of held in registers, in the
+    metric solve and in the joint-limit rounds (goals at the limits: rounds are made), against the oracle; and against the cyclic
+    reduction such runs took until then (ORC_SCAN_MAX_M=256) to rounding"""
+    model0, base, dofvals, adofs = common.wam_state()
+    lo, hi = np.array(model0.limit_lower)[:7], np.array(model0.limit_upper)[:7]
+    rng = np.random.default_rng(n_points)
+    n_runs = 6
+    goals = common.wam_goals(n_runs, seed=3)
+    goals[:3, :2] = np.where(rng.uniform(size=(3, 2)) < 0.5, lo[:2] + 0.005, hi[:2] - 0.005)
+    kw = dict(n_points=n_points, lambda_=40.0 * n_points / 100.0, obs_factor=500.0, use_momentum=momentum)
+    n_iter = 12
+    out = {}
+    switched = common.plan_switches_active()
+    for name, env in (("scan", None), ("pcr", "256")):
+        if env:
+            monkeypatch.setenv("ORC_SCAN_MAX_M", env)
+        mod = _mk_module()
+        model = common.setup_product_wam(mod)
+        bid = mod.batch_create(model.name, goals, **kw)
+        plan = mod.batch_plan(bid)
+        assert switched or plan["solve_mode"] == (0 if env else 2), plan
+        costs, status = mod.batch_iterate(bid, n_iter)
+        out[name] = (mod.batch_gettraj(bid), costs, status)
+        mod.batch_destroy(bid)
+        mod.close()
+    monkeypatch.delenv("ORC_SCAN_MAX_M", raising=False)
+    prob = common.tabletop_problem(oracle)
+    ora = lambda g: oracle.batch_run(oracle.OraRobot(model), base, dofvals, adofs, g, [prob["sdf"]], [prob["pose"]], oracle.default_params(**kw), n_iter)
+    res = ora(goals)
+    amp, stable = common.amplification(ora, goals, res)
+    traj, costs, status = out["scan"]
+    well = (res[2] == 0) & (status == 0) & (amp < 1e-9) & stable
+    assert well.sum() >= 4, (amp, res[2], status)
+    for k in np.flatnonzero(well):
+        assert common.rel_l2(traj[k], res[0][k]) <= 1e-6, k
+        assert np.allclose(costs[k], res[1][k], rtol=1e-6, atol=0), k
+    assert np.array_equal(out["scan"][2], out["pcr"][2])
+    assert max(common.rel_l2(out["scan"][0][k], out["pcr"][0][k]) for k in np.flatnonzero(well)) <= 1e-9
