@@ -66,8 +66,8 @@ def test_band_metric_matches_oracle(oracle, D, n_points, lam, n_iter):
     print("derivative %d, %d waypoints: worst rel L2 %.3e over %d well-conditioned runs" % (D, n_points, worst, len(well)))
 
 
-@pytest.mark.parametrize("D", [2, 3])
-def test_band_metric_joint_limit_rounds(oracle, D):
+@pytest.mark.parametrize("D,n_points", [(2, 100), (3, 100), (2, 300)])
+def test_band_metric_joint_limit_rounds(oracle, D, n_points):
     """goals at the joint limits: the projection rounds (chomp.c:608-655) run with the band inverse; every run the oracle itself
     reproduces under one-ulp changes of its goal must come out the same, status included"""
     model0, _, _, _ = common.wam_state()
@@ -76,8 +76,8 @@ def test_band_metric_joint_limit_rounds(oracle, D):
     n_runs = 16
     goals = np.where(rng.uniform(size=(n_runs, 7)) < 0.5, lo + 0.01, hi - 0.01) * 1.0
     goals[:, 3:] = common.wam_goals(n_runs, seed=9)[:, 3:]
-    kw = dict(n_points=100, lambda_=20.0, obs_factor=500.0, derivative=D)
-    n_iter = 30
+    kw = dict(n_points=n_points, lambda_=20.0 * n_points / 100.0, obs_factor=500.0, derivative=D)      # (300 waypoints: five rows per lane, the rounds' long form)
+    n_iter = 30 if n_points == 100 else 12
     model, traj, costs, status = _product(goals, n_iter, **kw)
     (otraj, ocosts, ostatus, _), amp, stable = _oracle(oracle, model, goals, n_iter, **kw)
     well = [k for k in range(n_runs) if amp[k] < 1e-9 and stable[k]]
