@@ -543,3 +543,62 @@ def test_con_tsr_long_trajectory_on_an_overlapping_module(oracle, n_points):
     assert common.rel_l2(out[2][0][1], run.traj()) <= 1e-6
     assert np.allclose(out[2][1][1], oc, rtol=1e-6, atol=0)
     run.destroy()
+
+
+def _chain(n_dof):
+    """a serial chain of n_dof revolute joints, alternating z / y / x axes with a bend in between, 0.12 m links, one sphere per link
+    (at most 16 active spheres: the 16-lane cost pass)"""
+    r = robots.RobotModel("chain%d" % n_dof)
+    r.add_link("base")
+    prev = "base"
+    axes = ((0, 0, 1), (0, 1, 0), (1, 0, 0))
+    for i in range(n_dof):
+        nm = "l%d" % i
+        r.add_link(nm, prev, (0.02 if i % 2 else 0.0, 0.0, 0.12), quat=robots.quat_from_axis_angle((1, 0.3 * i, 0.2), 0.25 * ((i % 3) - 1)),
+                   joint=robots.JOINT_REVOLUTE, axis=axes[i % 3], limits=(-2.5, 2.5))
+        if i < 16:
+            r.add_sphere(nm, (0, 0, 0.06), 0.04)
+        prev = nm
+    return r
+
+
+@pytest.mark.parametrize("n_dof,k", [(5, 3), (9, 3), (12, 3), (13, 3), (14, 3), (17, 3), (20, 3), (21, 3), (22, 3)])
+def test_con_tsr_every_register_shape_of_the_elimination(oracle, n_dof, k):
+    """the block of a point has N = n + k rows: rows of 16 lanes with 2 (N <= 8, the augmented form when 2 n + k + 1 <= 16), 3 (<= 12) and
+    4 (<= 15) registers, rows of 32 lanes with 8 (<= 16), 10 (<= 20) and 12 (<= 24) registers, the LDS form beyond: a chain of n
+    revolute joints with k constrained rows on its last link walks them all (csrc/tsr.h phase_tsr; src/libcd/chomp.c:553-600)"""
+    O = oracle
+    model = _chain(n_dof)
+    base = [0.2, -0.1, 0.9, 0, 0, 0, 1]
+    rng = np.random.default_rng(100 + n_dof)
+    dofvals = 0.4 * rng.uniform(-1, 1, size=n_dof)
+    adofs = list(range(n_dof))
+    mod = or_cdchomp_amd.Module(0)
+    mod.add_robot(model, transform=base, dof_values=dofvals, active_dofs=adofs)
+    from or_cdchomp_amd import scenes
+    scenes.add_tabletop(mod)
+    mod.SendCommand("computedistancefield kinbody table")
+    rob = O.OraRobot(model)
+    R, t, _, _ = rob.fk(base, dofvals)
+    li = model.link_names.index("l%d" % (n_dof - 1))
+    Bw = [[-1, 1], [0, 0], [0, 0], [0, 0], [-3, 3], [-3, 3]] if k == 3 else [[-1, 1], [-1, 1], [0, 0], [-3, 3], [-3, 3], [-3, 3]]
+    tsr = robots.Tsr(T0w_R=R[li], T0w_d=t[li], Bw=Bw)
+    n_runs, n_points, n_iter = 3, 24, 8
+    goals = np.ascontiguousarray(dofvals[None, :] + 0.25 * rng.uniform(-1, 1, size=(n_runs, n_dof)))
+    bid = int(mod.SendCommand("createbatch robot %s n_runs %d adofgoals 0x%x n_points %d lambda 200 obs_factor 100 con_tsr 'all link l%d' '%s'"
+                              % (model.name, n_runs, goals.ctypes.data, n_points, n_dof - 1, tsr.serialize())))
+    costs, status = mod.batch_iterate(bid, n_iter)
+    traj = mod.batch_gettraj(bid)
+    mod.batch_destroy(bid)
+    mod.close()
+    prob = common.tabletop_problem(O)
+    worst = 0.0
+    for r in range(n_runs):
+        run = O.OraRun(rob, base, dofvals, adofs, goals[r], [prob["sdf"]], [prob["pose"]], O.default_params(n_points=n_points, lambda_=200.0, obs_factor=100.0))
+        assert run.add_contsr(li, [0, 0, 0, 0, 0, 0, 1], O.pose_from_dR(t[li], R[li]), [0, 0, 0, 0, 0, 0, 1], Bw) == k
+        st, oc = run.iterate(n_iter)
+        assert st == 0 and status[r] == 0, (n_dof, r, st, status[r])
+        worst = max(worst, common.rel_l2(traj[r], run.traj()))
+        assert np.allclose(costs[r], oc, rtol=1e-6, atol=1e-12), (n_dof, r, costs[r], oc)
+        run.destroy()
+    assert worst <= 1e-6, (n_dof, worst)
