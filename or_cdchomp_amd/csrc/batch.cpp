@@ -1090,7 +1090,11 @@ void BatchShard::build_device(const Robot & robot)
    if (want_wgs == 3) want_wgs = 0;
    // (the planner's own 128 is a preference, tried in a pass of its own: a long constrained trajectory that has no 128-thread plan --
    // 40 KB of LDS at four per CU -- is planned like any other run afterwards; a caller's orc_set_workgroup_threads stays binding)
-   const bool planner128 = force_block == 0 && overlapping && n_tsrs_ > 0 && can128 && !params.free_start && !getenv("ORC_BLOCK_THREADS");
+   // ... and so is the 128-thread shape for SHORT trajectories (round 6): a run of at most 32 moving waypoints has two rounds of work for
+   // two wavefronts where four wavefronts idle through most of its phases (8 waypoints 52.8 -> 77 M it/s, 16: +8 %, 34: +11 %; from 50
+   // on the 256-thread shapes are ahead again: scripts/diag/short_traj_shapes.py, profiles/r06_regime_sweep.txt)
+   const bool short128 = m <= 32 && !getenv("ORC_NO_SHORT128");
+   const bool planner128 = force_block == 0 && ((overlapping && n_tsrs_ > 0) || short128) && can128 && !params.free_start && !getenv("ORC_BLOCK_THREADS");
    const int max_wgs_default = max_wgs, force_block_asked = force_block;
    bool budget4 = false;
    const int lanes_per_wp = (GS_ == 16) ? 16 : GS_;
